@@ -1,0 +1,371 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference).
+
+Runs only in the build container (the reference never travels).  Fixtures are data:
+inputs (procedural-weight seeds, film params, every random draw the reference made,
+recorded in call order) and the reference's outputs, per stage and end to end.
+
+    python tools/make_golden.py            # writes tests/golden/
+"""
+import functools
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_import  # noqa: E402
+from fenerf_amd import procedural as proc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CURR = dict(fov=12, ray_start=0.88, ray_end=1.12, h_stddev=0.3, v_stddev=0.155,
+            h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, sample_dist="gaussian")
+
+
+class DrawRecorder:
+    """Records every torch.rand / torch.randn / torch.randperm call (shape, values) in order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._orig = (torch.rand, torch.randn, torch.randperm)
+
+        def wrap(fn, kind):
+            def inner(*a, **k):
+                t = fn(*a, **k)
+                self.draws.append((kind, t.detach().cpu().numpy().copy()))
+                return t
+            return inner
+
+        torch.rand, torch.randn, torch.randperm = wrap(torch.rand, "rand"), wrap(torch.randn, "randn"), wrap(torch.randperm, "randperm")
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn, torch.randperm = self._orig
+
+
+class CallRecorder:
+    """Wraps callables in a module namespace and records (args, result) per call."""
+
+    def __init__(self, module, names):
+        self.module, self.names = module, names
+        self.calls = {n: [] for n in names}
+
+    def __enter__(self):
+        self._orig = {n: getattr(self.module, n) for n in self.names}
+        for n in self.names:
+            def mk(n, fn):
+                def inner(*a, **k):
+                    r = fn(*a, **k)
+                    self.calls[n].append((a, k, r))
+                    return r
+                return inner
+            setattr(self.module, n, mk(n, self._orig[n]))
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self._orig.items():
+            setattr(self.module, n, fn)
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy() if torch.is_tensor(t) else t
+
+
+def load_sd(module, sd):
+    tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    if "spatial_embeddings" in tsd:
+        module.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    missing, unexpected = module.load_state_dict(tsd, strict=True)
+    assert not missing and not unexpected
+
+
+def build_ref_generator(refs, spec, seed, sigma_gain):
+    siren_mod, gens, vr, cur = refs
+    H = spec["hidden_dim"]
+    if spec["kind"] == "texture":
+        cls = functools.partial(siren_mod.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=H)
+    elif spec["kind"] == "baseline":
+        cls = functools.partial(siren_mod.SIRENBASELINESEMANTICDISENTANGLE, hidden_dim=H)
+    else:
+        cls = functools.partial(siren_mod.SPATIALSIRENBASELINE, hidden_dim=H)
+    if spec["kind"] == "spatial":
+        g = gens.ImplicitGenerator3d(cls, spec["z_dim"], spec["output_dim"])
+    else:
+        g = gens.DoubleImplicitGenerator3d(cls, spec["z_dim"], spec["z_dim"], spec["output_dim"])
+    sd = proc.make_state_dict(spec, seed=seed, sigma_gain=sigma_gain)
+    load_sd(g.siren, sd)
+    g.eval()
+    g.device = torch.device("cpu")
+    g.siren.device = g.device
+    return g, sd
+
+
+def rand_dict_from_draws(draws, hierarchical):
+    """appendix A.6 order -> oracle `rand` dict (theta/phi are pre-clamp angles built by host code)."""
+    kinds = [k for k, _ in draws]
+    vals = [v for _, v in draws]
+    assert kinds[:3] == ["rand", "randn", "randn"], kinds
+    rd = dict(u_jitter=vals[0], r_theta=vals[1], r_phi=vals[2], noise_coarse=vals[3])
+    if hierarchical:
+        assert kinds[3:6] == ["randn", "rand", "randn"], kinds
+        rd.update(u_fine=vals[4], noise_fine=vals[5])
+    return rd
+
+
+def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, film_scale=1.0, stages=True, staged=False):
+    """forward_with_frequencies / staged_forward_with_frequencies with explicit film params."""
+    siren_mod, gens, vr, cur = refs
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale)
+    tf = {k: torch.from_numpy(v) for k, v in film.items()}
+    torch.manual_seed(1234 + seed)
+    rec_names = ["fancy_integration", "sample_pdf", "transform_sampled_points", "get_initial_rays_trig"]
+    siren_calls = []
+    orig_fw = g.siren.forward_with_frequencies_phase_shifts
+
+    def siren_rec(*a, **k):
+        r = orig_fw(*a, **k)
+        siren_calls.append((a, k, r))
+        return r
+    g.siren.forward_with_frequencies_phase_shifts = siren_rec
+    common = dict(img_size=S, num_steps=N, hierarchical_sample=hier, fov=CURR["fov"], ray_start=CURR["ray_start"],
+                  ray_end=CURR["ray_end"], h_stddev=CURR["h_stddev"], v_stddev=CURR["v_stddev"],
+                  h_mean=CURR["h_mean"], v_mean=CURR["v_mean"], sample_dist=CURR["sample_dist"])
+    common.update(kwargs)
+    with torch.no_grad(), DrawRecorder() as dr, CallRecorder(gens, rec_names) as cr:
+        if staged:
+            if spec["kind"] == "spatial":
+                res = g.staged_forward_with_frequencies(tf["freq_geo"], tf["phase_geo"], max_batch_size=1000, **common)
+            else:
+                res = g.staged_forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"],
+                                                        max_batch_size=1000, **common)
+        else:
+            if spec["kind"] == "spatial":
+                res = g.forward_with_frequencies(tf["freq_geo"], tf["phase_geo"], **common)
+            else:
+                res = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
+    out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_S=S, meta_N=N, meta_hier=int(hier),
+               meta_film_scale=film_scale, meta_staged=int(staged), meta_weights_checksum=proc.checksum(sd))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    for k, v in kwargs.items():
+        out["kw_" + k] = v
+    rd = rand_dict_from_draws(dr.draws, hier)
+    for k, v in rd.items():
+        out["rand_" + k] = v
+    out["pixels"] = np_(res[0])
+    if staged:
+        out["depth"] = np_(res[1])
+        if len(res) > 2:
+            out["third"] = np_(res[2])
+    else:
+        out["poses"] = np_(res[1])
+    if stages:
+        tsp = cr.calls["transform_sampled_points"][0][2]
+        for nm, t in zip(["points", "z_coarse", "dirs", "origins", "pitch", "yaw"], tsp):
+            out["st_" + nm] = np_(t)
+        rays = cr.calls["get_initial_rays_trig"][0][2]
+        out["st_points_cam"], out["st_z_cam"], out["st_dirs_cam"] = (np_(t) for t in rays)
+        fi = cr.calls["fancy_integration"]
+        if hier:
+            out["st_coarse_weights"] = np_(fi[0][2][2])
+            sp = cr.calls["sample_pdf"][0]
+            out["st_pdf_bins"], out["st_pdf_weights"], out["st_z_fine"] = np_(sp[0][0]), np_(sp[0][1]), np_(sp[2])
+        last = fi[-1]
+        out["st_all_out"], out["st_all_z"] = np_(last[0][0]), np_(last[0][1])
+        out["st_final_rgb"], out["st_final_depth"], out["st_final_third"] = (np_(t) for t in last[2])
+        if not staged:
+            out["st_siren_coarse"] = np_(siren_calls[0][2])
+            if hier:
+                out["st_siren_fine"] = np_(siren_calls[1][2])
+                out["st_fine_points"] = np_(siren_calls[1][0][0])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: pixels {out['pixels'].shape}  -> {os.path.getsize(path) / 1024:.0f} KiB")
+    return g, sd, out
+
+
+def run_integration_variants(refs, base, name):
+    """fancy_integration over every flag combination on one fixed (all_out, all_z) block + noise."""
+    siren_mod, gens, vr, cur = refs
+    rs, z = torch.from_numpy(base["st_all_out"]), torch.from_numpy(base["st_all_z"])
+    # sharpen sigma so weights_sum straddles the 0.9 fill threshold on a good share of rays
+    rs = rs.clone()
+    fac = torch.tensor([40.0, 1.0, 0.05, -1.0, 4.0]).repeat(rs.shape[1] // 5 + 1)[:rs.shape[1]]
+    rs[..., -1] = rs[..., -1] * fac[None, :, None]
+    out = dict(rgb_sigma=np_(rs), z_vals=np_(z))
+    variants = []
+    for clamp in ("relu", "softplus"):
+        for flags in (dict(), dict(last_back=True), dict(white_back=True), dict(black_back=True),
+                      dict(last_back=True, white_back=True)):
+            variants.append(dict(clamp_mode=clamp, noise_std=0.0, **flags))
+    variants.append(dict(clamp_mode="relu", noise_std=0.5))
+    variants.append(dict(clamp_mode="softplus", noise_std=1.0, last_back=True))
+    # 'debug' / 'weight_debug' assign a 22-vector into the 21-channel rgb_final and raise RuntimeError for
+    # output_dim=22 models (volumetric_rendering.py:54,66) -> not representable as a vector; see test of the raise.
+    for fm in ("weight", "seg_padding_background", "eval_seg_padding_background"):
+        variants.append(dict(clamp_mode="relu", noise_std=0.0, fill_mode=fm))
+    for fc in ("white", "grey", "light_grey", "black", "none"):
+        variants.append(dict(clamp_mode="relu", noise_std=0.0, fill_mode="seg_padding_background", fill_color=fc))
+        variants.append(dict(clamp_mode="relu", noise_std=0.0, fill_mode="eval_seg_padding_background", fill_color=fc,
+                             white_back=True))
+    out["n_variants"] = len(variants)
+    for i, v in enumerate(variants):
+        torch.manual_seed(77 + i)
+        with DrawRecorder() as dr:
+            r = vr.fancy_integration(rs.clone(), z.clone(), device="cpu", **v)
+        out[f"v{i}_noise"] = dr.draws[0][1]
+        out[f"v{i}_kw"] = repr(v)
+        out[f"v{i}_rgb"], out[f"v{i}_depth"], out[f"v{i}_third"] = (np_(t).copy() for t in r)
+    # 3-channel model path for eval_white_back
+    rs4 = torch.cat([rs[..., -4:-1], rs[..., -1:]], -1).contiguous()
+    r = vr.fancy_integration(rs4.clone(), z.clone(), device="cpu", clamp_mode="relu", noise_std=0.0, fill_mode="eval_white_back")
+    out["ewb_rgb_sigma"] = np_(rs4)
+    out["ewb_rgb"], out["ewb_depth"], out["ewb_third"] = (np_(t).copy() for t in r)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(variants)} variants -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_sample_pdf_cases(refs, name):
+    siren_mod, gens, vr, cur = refs
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for i, (R, K, Ni) in enumerate([(40, 4, 6), (33, 22, 24), (8, 46, 48), (5, 1, 7)]):
+        bins = torch.sort(torch.rand(R, K + 1, generator=g) * 0.24 + 0.88, dim=-1)[0]
+        w = torch.rand(R, K, generator=g) ** 4
+        if i == 1:
+            w[::3] = 0.0            # all-zero rows -> uniform pdf after eps
+            w[1::3, 5:] = 0.0       # zero-weight bins -> denom<eps branch
+        w = w + 1e-5
+        torch.manual_seed(100 + i)
+        with DrawRecorder() as dr:
+            s = vr.sample_pdf(bins, w, Ni, det=False)
+        u = dr.draws[0][1]
+        sd = vr.sample_pdf(bins, w, Ni, det=True)
+        out[f"c{i}_bins"], out[f"c{i}_weights"], out[f"c{i}_u"] = np_(bins), np_(w), u
+        out[f"c{i}_samples"], out[f"c{i}_samples_det"] = np_(s), np_(sd)
+        cases.append(i)
+    # edge: u exactly on cdf knots (0 and interior) -> searchsorted-left semantics
+    bins = torch.linspace(0.9, 1.1, 5).repeat(3, 1)
+    w = torch.tensor([[1.0, 1.0, 1.0, 1.0], [0.0, 1.0, 0.0, 1.0], [1.0, 0.0, 0.0, 0.0]]) + 1e-5
+    orig = torch.rand
+    u_edge = torch.tensor([[0.0, 0.25, 0.5, 0.75, 0.999999], [0.0, 1e-6, 0.5, 0.5000001, 0.9], [0.0, 0.3, 0.9, 0.5, 0.1]])
+    torch.rand = lambda *a, **k: u_edge.clone()
+    try:
+        s = vr.sample_pdf(bins, w, 5, det=False)
+    finally:
+        torch.rand = orig
+    out["edge_bins"], out["edge_weights"], out["edge_u"], out["edge_samples"] = np_(bins), np_(w), np_(u_edge), np_(s)
+    out["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(cases)} cases + edge")
+
+
+def run_camera_cases(refs, name):
+    siren_mod, gens, vr, cur = refs
+    out = {}
+    modes = ["uniform", "normal", "gaussian", "spherical_uniform", "fixed"]
+    for i, m in enumerate(modes):
+        torch.manual_seed(9 + i)
+        with DrawRecorder() as dr:
+            o, phi, theta = vr.sample_camera_positions(device="cpu", n=6, r=1, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                       horizontal_mean=np.pi * 0.5, vertical_mean=np.pi * 0.5, mode=m)
+        out[f"m{i}_mode"] = m
+        out[f"m{i}_draws"] = np.stack([d for _, d in dr.draws]) if dr.draws else np.zeros((0, 6, 1), np.float32)
+        out[f"m{i}_origin"], out[f"m{i}_phi"], out[f"m{i}_theta"] = np_(o), np_(phi), np_(theta)
+        fwd = vr.normalize_vecs(-o)
+        out[f"m{i}_cam2world"] = np_(vr.create_cam2world_matrix(fwd, o, device="cpu"))
+    # extreme pitch (clamp) case
+    o, phi, theta = vr.sample_camera_positions(device="cpu", n=2, horizontal_stddev=0, vertical_stddev=0,
+                                               horizontal_mean=0.3, vertical_mean=-0.2, mode="fixed")
+    out["clamp_origin"], out["clamp_phi"], out["clamp_theta"] = np_(o), np_(phi), np_(theta)
+    # rays at several resolutions
+    for j, (S, N) in enumerate([(4, 3), (8, 6), (5, 1)]):
+        p, z, d = vr.get_initial_rays_trig(2, N, "cpu", 12, (S, S), 0.88, 1.12)
+        out[f"r{j}_S"], out[f"r{j}_N"] = S, N
+        out[f"r{j}_points"], out[f"r{j}_z"], out[f"r{j}_dirs"] = np_(p), np_(z), np_(d)
+    out["n_modes"] = len(modes)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: camera + rays")
+
+
+def run_mapping_and_full(refs, name):
+    """z -> mapping nets -> forward / staged_forward (psi truncation with recorded avg draws)."""
+    siren_mod, gens, vr, cur = refs
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=8, z_dim=16)
+    g, sd = build_ref_generator(refs, spec, seed=3, sigma_gain=300.0)
+    B, S, N = 2, 6, 6
+    zg = torch.from_numpy(proc.normal("z_geo", (B, 16), 1.0, 3))
+    za = torch.from_numpy(proc.normal("z_app", (B, 16), 1.0, 3))
+    out = dict(z_geo=np_(zg), z_app=np_(za), meta_weights_checksum=proc.checksum(sd))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    with torch.no_grad():
+        fg, pg = g.siren.geo_mapping_network(zg)
+        fa, pa = g.siren.app_mapping_network(za)
+    out.update(map_freq_geo=np_(fg), map_phase_geo=np_(pg), map_freq_app=np_(fa), map_phase_app=np_(pa))
+    kw = dict(img_size=S, num_steps=N, hierarchical_sample=True, clamp_mode="relu", nerf_noise=0.0, **CURR)
+    torch.manual_seed(42)
+    with torch.no_grad(), DrawRecorder() as dr:
+        px, poses = g.forward(zg, za, **kw)
+    rd = rand_dict_from_draws(dr.draws, True)
+    for k, v in rd.items():
+        out["fwd_rand_" + k] = v
+    out["fwd_pixels"], out["fwd_poses"] = np_(px), np_(poses)
+    # staged_forward: first two draws are the 10000-z avg-frequency pass (generators.py:530-543)
+    torch.manual_seed(43)
+    with torch.no_grad(), DrawRecorder() as dr:
+        px, depth = g.staged_forward(zg, za, psi=0.7, max_batch_size=97, fill_mode="seg_padding_background",
+                                     fill_color="white", **kw)
+    assert dr.draws[0][1].shape == (10000, 16) and dr.draws[1][1].shape == (10000, 16)
+    out["stg_avg_freq_geo"], out["stg_avg_phase_geo"] = np_(g.avg_frequencies_geo), np_(g.avg_phase_shifts_geo)
+    out["stg_avg_freq_app"], out["stg_avg_phase_app"] = np_(g.avg_frequencies_app), np_(g.avg_phase_shifts_app)
+    rd = rand_dict_from_draws(dr.draws[2:], True)
+    for k, v in rd.items():
+        out["stg_rand_" + k] = v
+    out["stg_pixels"], out["stg_depth"] = np_(px), np_(depth)
+    out["stg_psi"] = 0.7
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: mapping + forward + staged_forward")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    refs = ref_import.import_reference()
+    relu = dict(clamp_mode="relu", nerf_noise=0.0)
+
+    tiny = proc.model_spec("texture", hidden_dim=32, grid_size=8, z_dim=16)
+    _, _, base = run_film_case(refs, "tiny_texture_fwd", tiny, seed=1, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
+    run_film_case(refs, "tiny_texture_fwd_nohier", tiny, seed=2, sigma_gain=300.0, B=2, S=8, N=6, hier=False,
+                  kwargs=dict(clamp_mode="softplus", nerf_noise=0.5, last_back=True))
+    run_film_case(refs, "tiny_texture_staged", tiny, seed=1, sigma_gain=300.0, B=2, S=8, N=6, hier=True, staged=True,
+                  kwargs=dict(clamp_mode="relu", nerf_noise=0.0, fill_mode="seg_padding_background", fill_color="black"))
+    run_film_case(refs, "tiny_texture_staged_lock", tiny, seed=4, sigma_gain=300.0, B=1, S=8, N=6, hier=True, staged=True,
+                  kwargs=dict(clamp_mode="relu", nerf_noise=0.3, fill_mode="eval_seg_padding_background",
+                              fill_color="grey", lock_view_dependence=True))
+    run_integration_variants(refs, base, "integration_variants")
+    run_sample_pdf_cases(refs, "sample_pdf_cases")
+    run_camera_cases(refs, "camera_rays")
+    run_mapping_and_full(refs, "tiny_texture_z_full")
+
+    baseline = proc.model_spec("baseline", hidden_dim=32, z_dim=16)
+    run_film_case(refs, "tiny_baseline_fwd", baseline, seed=5, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
+
+    # H=256 / 96^3 grid: output-level vectors only (weights are procedural; checksum pinned)
+    full = proc.model_spec("texture", hidden_dim=256, grid_size=96)
+    run_film_case(refs, "h256_texture_16x16_n12", full, seed=0, sigma_gain=1.0, B=1, S=16, N=12, hier=True, kwargs=relu)
+    run_film_case(refs, "h256_texture_16x16_n24_trained", full, seed=0, sigma_gain=2000.0, B=1, S=16, N=24, hier=True, kwargs=relu)
+    fullb = proc.model_spec("baseline", hidden_dim=256)
+    run_film_case(refs, "h256_baseline_8x8_n12", fullb, seed=6, sigma_gain=2000.0, B=2, S=8, N=12, hier=True, kwargs=relu)
+
+
+if __name__ == "__main__":
+    main()
