@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""Benchmark of the forward-render hot path (BASELINE.json metric: rays/s per GPU).
+
+A step = one fenerf_render_forward pass (coarse SIREN -> composite -> resample -> fine SIREN -> merge ->
+composite) over one batch of synthetic rays already resident in HBM.  Workload = BASELINE.json configs[1]:
+TextureEmbeddingPiGAN256SEMANTICDISENTANGLE_DIM_96 (H=256 FiLM-SIREN + 32x96^3 grid, 22 channels), 128x128 rays,
+24+24 hierarchical samples, batch 1 per GPU, procedural (random-init-range) weights, synthetic latents.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, weak scaling)
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (siren_kernel, MFMA-bound): algorithmic
+FLOPs per launch (1,603,584 FLOP/point x points) / its hipEvent-timed average duration, against the
+fp32-matrix peak.  `cpu_baseline` times the numpy oracle (a port of the reference CPU path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 1_603_584          # SURVEY.md §8(d) / BASELINE.md §4 (dense layers, 2 FLOP per MAC)
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+
+
+def cpu_baseline(spec, sd, film, seed):
+    """Oracle (numpy port of the reference CPU path) on a bounded sample of the same workload: 96x96 rays,
+    24+24 samples, same model -- sized for ~10-30 s of CPU work."""
+    from fenerf_amd import procedural as proc
+    from oracle import fenerf_oracle as O
+    S, N, B = 96, 24, 1
+    R = S * S
+    rng = np.random.default_rng(seed)
+    rand = dict(u_jitter=rng.random((B, R, N, 1), dtype=np.float32), theta=np.full((B, 1), np.pi / 2 + 0.1, np.float32),
+                phi=np.full((B, 1), np.pi / 2 - 0.05, np.float32), noise_coarse=None, u_fine=rng.random((B * R, N), dtype=np.float32),
+                noise_fine=None)
+    t0 = time.perf_counter()
+    O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rand, hierarchical_sample=True, clamp_mode="relu")
+    dt = time.perf_counter() - t0
+    return dict(value=R / dt, unit="rays/s", cores=os.cpu_count(), kind="port",
+                sample=f"numpy oracle render_forward, {S}x{S} rays, {N}+{N} samples, H=256+96^3 grid, 1 run of {dt:.1f}s "
+                       f"(BLAS GEMMs use all {os.cpu_count()} host cores, elementwise ops 1)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--img-size", type=int, default=128)
+    ap.add_argument("--num-steps", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used only for the timing barrier / max-reduce
+
+    from fenerf_amd import _lib, native, procedural as proc
+    from fenerf_amd.generators import volumetric_rendering as VR
+
+    spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
+    sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, dev)
+    B, S, N = args.batch, args.img_size, args.num_steps
+    R = S * S
+    # every rank renders its own images (shard by image, no data-path collective): different latents / poses per rank
+    film = proc.film_params(spec, B, seed=1000 + rank)
+    tf = tuple(torch.as_tensor(film[k], device=dev) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    torch.manual_seed(1234 + rank)
+    o, d, z, _, _ = VR.sample_rays(B, N, dev, 12, (S, S), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((B * R, N), device=dev)
+    opts = _lib.composite_opts("relu", 0.0, fill_mode="seg_padding_background", fill_color="black")
+
+    def step():
+        return nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_total = world * B * R * args.steps
+    value = rays_total / dt
+
+    out = None
+    if rank == 0:
+        # dominant kernel alone (coarse-pass shape == fine-pass shape): hipEvents on the launch stream
+        pts = B * R * N
+        k_ms = nat.time_siren_rays(o, d, z, *tf, iters=max(5, args.steps // 2))
+        achieved = pts * FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "rays/s/GPU forward render (128x128, 24+24 samples, H=256 FiLM-SIREN + 32x96^3 grid)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: CelebA_double_semantic_texture_embedding_256_dim_96 generator, {S}x{S}, "
+                                   f"{N}+{N} hierarchical samples, batch {B}/GPU, forward-only render, procedural weights",
+                       "img_size": S, "num_steps": N, "batch_per_gpu": B, "sharding": "by image, no collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel": "siren_kernel<256,true>", "kernel_ms": k_ms, "points_per_launch": pts,
+                         "flop_per_point_algorithmic": FLOP_PER_POINT, "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32)"},
+            "rays_per_s_per_gpu": value / world,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            film1 = proc.film_params(spec, 1, seed=1000)
+            out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

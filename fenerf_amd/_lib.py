@@ -1,0 +1,169 @@
+"""ctypes binding of libfenerf_hip.so (the C-ABI of include/fenerf.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, we raise.
+The library itself is torch-free; device pointers come from torch tensors' data_ptr() and the
+stream from torch.cuda.current_stream().cuda_stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfenerf_hip.so")
+
+ABI_VERSION = 1
+MAX_GEO, MAX_COLOR, MAX_LABEL = 8, 4, 3
+
+OK, E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CLAMP_MODE = 0, -1, -2, -3, -4, -5
+CLAMP = {"relu": 1, "softplus": 2}
+FILL = {None: 0, "weight": 1, "seg_padding_background": 2, "eval_seg_padding_background": 3, "eval_white_back": 4}
+FILL_COLORS = {"white": 1.0, "black": 0.0, "grey": 0.5, "light_grey": 0.81}
+
+_fp = C.POINTER(C.c_float)
+
+
+class FenerfModelDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("hidden_dim", C.c_int32), ("n_geo", C.c_int32), ("n_color", C.c_int32),
+        ("n_label_layers", C.c_int32), ("output_dim", C.c_int32), ("grid_ch", C.c_int32),
+        ("grid_d", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32), ("box_scale", C.c_float),
+        ("geo_w", _fp * MAX_GEO), ("geo_b", _fp * MAX_GEO),
+        ("color_w", _fp * MAX_COLOR), ("color_b", _fp * MAX_COLOR),
+        ("label_w", _fp * MAX_LABEL), ("label_b", _fp * MAX_LABEL),
+        ("sigma_w", _fp), ("sigma_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp), ("grid", _fp),
+    ]
+
+
+class FenerfCompositeOpts(C.Structure):
+    _fields_ = [("clamp_mode", C.c_int32), ("noise_std", C.c_float), ("last_back", C.c_int32),
+                ("white_back", C.c_int32), ("black_back", C.c_int32), ("fill_mode", C.c_int32),
+                ("fill_value", C.c_float), ("fill_enabled", C.c_int32)]
+
+
+class FenerfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fenerf error {code}: {msg}")
+        self.code = code
+
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_SIGS = {
+    "fenerf_last_error": (C.c_char_p, []),
+    "fenerf_abi_version": (_i, []),
+    "fenerf_pack_weights_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_fp), C.POINTER(_sz), C.POINTER(_fp), C.POINTER(_sz)]),
+    "fenerf_free_host": (None, [_vp]),
+    "fenerf_model_create": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_vp)]),
+    "fenerf_model_update": (_i, [_vp, C.POINTER(FenerfModelDesc), _vp]),
+    "fenerf_model_destroy": (None, [_vp]),
+    "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
+    "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
+    "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
+    "fenerf_siren_time_rays": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_float), _vp]),
+    "fenerf_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_resample": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_sample_pdf": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_merge_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or make -C fenerf_amd/csrc).  fenerf_amd has no CPU / PyTorch fallback for the render path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export what include/fenerf.h declares
+            fn.restype, fn.argtypes = res, args
+        if l.fenerf_abi_version() != ABI_VERSION:
+            raise RuntimeError("libfenerf_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise FenerfError(rc, lib().fenerf_last_error().decode())
+
+
+def _as_f32(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    return a, a.ctypes.data_as(_fp)
+
+
+def make_desc(sd, spec):
+    """Builds a FenerfModelDesc from a reference-named state dict of numpy arrays.
+    Returns (desc, keepalive) -- keepalive holds the host arrays the desc points into."""
+    keep = []
+
+    def P(name):
+        a, p = _as_f32(sd[name])
+        keep.append(a)
+        return p
+
+    d = FenerfModelDesc()
+    d.abi_version = ABI_VERSION
+    d.hidden_dim, d.n_geo, d.n_color = spec["hidden_dim"], spec["n_geo"], spec["n_color"]
+    d.n_label_layers, d.output_dim, d.grid_ch = spec["n_label_layers"], spec["output_dim"], spec["grid_ch"]
+    d.box_scale = 2 / 0.24
+    for i in range(spec["n_geo"]):
+        d.geo_w[i], d.geo_b[i] = P(f"network.{i}.layer.weight"), P(f"network.{i}.layer.bias")
+    if spec["kind"] == "spatial":
+        d.color_w[0], d.color_b[0] = P("color_layer_sine.layer.weight"), P("color_layer_sine.layer.bias")
+    else:
+        for i in range(spec["n_color"]):
+            d.color_w[i], d.color_b[i] = P(f"color_layer_sine.{i}.layer.weight"), P(f"color_layer_sine.{i}.layer.bias")
+    for i in range(spec["n_label_layers"]):
+        d.label_w[i], d.label_b[i] = P(f"label_layer_linear.{i}.weight"), P(f"label_layer_linear.{i}.bias")
+    d.sigma_w, d.sigma_b = P("final_layer.weight"), P("final_layer.bias")
+    d.rgb_w, d.rgb_b = P("color_layer_linear.0.weight"), P("color_layer_linear.0.bias")
+    if spec["grid_ch"]:
+        g = sd["spatial_embeddings"]
+        d.grid_d, d.grid_h, d.grid_w = int(g.shape[2]), int(g.shape[3]), int(g.shape[4])
+        d.grid = P("spatial_embeddings")
+    return d, keep
+
+
+def pack_weights_host(sd, spec):
+    """(blob, consts) numpy copies of the packed streaming layout (CPU only; layout tests)."""
+    d, keep = make_desc(sd, spec)
+    blob, consts = _fp(), _fp()
+    nb, nc = _sz(), _sz()
+    check(lib().fenerf_pack_weights_host(C.byref(d), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc)))
+    try:
+        b = np.ctypeslib.as_array(blob, shape=(nb.value,)).copy()
+        c = np.ctypeslib.as_array(consts, shape=(nc.value,)).copy()
+    finally:
+        lib().fenerf_free_host(blob)
+        lib().fenerf_free_host(consts)
+    return b, c
+
+
+def composite_opts(clamp_mode, noise_std=0.0, last_back=False, white_back=False, black_back=False, fill_mode=None,
+                   fill_color="black"):
+    """kwargs of fancy_integration -> FenerfCompositeOpts.  Mirrors the reference's error behaviour:
+    an unknown clamp_mode is a TypeError (volumetric_rendering.py:34 raises a str), 'debug'/'weight_debug'
+    raise RuntimeError for 21-channel outputs (:54, :66)."""
+    if clamp_mode not in CLAMP:
+        raise TypeError("exceptions must derive from BaseException")  # what `raise "Need to choose clamp mode"` does
+    if fill_mode in ("debug", "weight_debug"):
+        raise RuntimeError("shape mismatch: value tensor of shape [22] cannot be broadcast to indexing result "
+                           "(reference fill_mode=%r is only shape-valid for 22 colour channels)" % fill_mode)
+    if fill_mode not in FILL:
+        fill_mode = None  # unknown strings fall through every elif in the reference -> plain return
+    o = FenerfCompositeOpts()
+    o.clamp_mode = CLAMP[clamp_mode]
+    o.noise_std = float(noise_std)
+    o.last_back, o.white_back, o.black_back = int(bool(last_back)), int(bool(white_back)), int(bool(black_back))
+    o.fill_mode = FILL[fill_mode]
+    o.fill_enabled = int(fill_color in FILL_COLORS)
+    o.fill_value = FILL_COLORS.get(fill_color, 0.0)
+    return o

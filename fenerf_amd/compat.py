@@ -1,0 +1,15 @@
+"""Import-path aliases so code (and pickles) written against the reference resolve to this package:
+`import curriculums`, `from generators import generators`, `from siren import siren`
+(pickled checkpoints embed `generators.generators.DoubleImplicitGenerator3d` / `siren.siren.*`)."""
+import sys
+
+
+def install_aliases():
+    from . import curriculums, generators, siren
+    sys.modules.setdefault("curriculums", curriculums)
+    sys.modules.setdefault("generators", generators)
+    sys.modules.setdefault("generators.generators", generators.generators)
+    sys.modules.setdefault("generators.volumetric_rendering", generators.volumetric_rendering)
+    sys.modules.setdefault("generators.math_utils_torch", generators.math_utils_torch)
+    sys.modules.setdefault("siren", siren)
+    sys.modules.setdefault("siren.siren", siren.siren)

@@ -1,0 +1,367 @@
+// C-ABI entry points (include/fenerf.h): argument validation, model handle, stage orchestration.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fenerf_internal.h"
+
+namespace fenerf {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+  return fail(FENERF_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);   \
+  } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int check_opts(const FenerfCompositeOpts* o) {
+  if (!o) return fail(FENERF_E_INVALID, "opts is NULL");
+  if (o->clamp_mode != FENERF_CLAMP_RELU && o->clamp_mode != FENERF_CLAMP_SOFTPLUS)
+    return fail(FENERF_E_CLAMP_MODE, "Need to choose clamp mode");  // volumetric_rendering.py:34
+  if (o->fill_mode < FENERF_FILL_NONE || o->fill_mode > FENERF_FILL_EVAL_WHITE_BACK)
+    return fail(FENERF_E_INVALID, "unknown fill_mode");
+  return FENERF_OK;
+}
+
+static int out_channels(int C, const FenerfCompositeOpts* o) {
+  const bool pad = o->fill_mode == FENERF_FILL_SEG_PADDING_BACKGROUND || o->fill_mode == FENERF_FILL_EVAL_SEG_PADDING_BACKGROUND;
+  return pad ? C : C - 1;
+}
+
+static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t stream, bool allocate) {
+  std::vector<float> blob, consts;
+  std::string err;
+  int rc = pack_weights(d, blob, consts, err);
+  if (rc) return fail(rc, err);
+  if (allocate) {
+    HIP_TRY(hipMalloc((void**)&m->d_stream, blob.size() * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&m->d_consts, consts.size() * sizeof(float)));
+  }
+  HIP_TRY(hipMemcpyAsync(m->d_stream, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(m->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  if (d->grid_ch && d->grid) {
+    const size_t n = (size_t)d->grid_ch * d->grid_d * d->grid_h * d->grid_w;
+    if (allocate) HIP_TRY(hipMalloc((void**)&m->d_grid, n * sizeof(float)));
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, n * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(tmp, d->grid, n * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+      rc = launch_grid_relayout(tmp, m->d_grid, d->grid_ch, d->grid_d, d->grid_h, d->grid_w, stream);
+      if (rc == FENERF_OK) e = hipStreamSynchronize(stream);
+    }
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "grid upload");
+  } else if (d->grid_ch && allocate) {
+    return fail(FENERF_E_INVALID, "grid_ch > 0 but grid pointer is NULL");
+  }
+  HIP_TRY(hipStreamSynchronize(stream));  // blob/consts are stack-owned host vectors
+  return FENERF_OK;
+}
+}  // namespace fenerf
+
+using namespace fenerf;
+
+extern "C" const char* fenerf_last_error(void) { return g_err.c_str(); }
+extern "C" int fenerf_abi_version(void) { return FENERF_ABI_VERSION; }
+
+extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) {
+  if (!out) return fail(FENERF_E_INVALID, "out is NULL");
+  *out = nullptr;
+  std::string err;
+  int rc = validate_desc(d, err);
+  if (rc) return fail(rc, err);
+  FenerfModel* m = new (std::nothrow) FenerfModel();
+  if (!m) return fail(FENERF_E_NOMEM, "out of host memory");
+  memset(m, 0, sizeof(*m));
+  m->H = d->hidden_dim; m->n_geo = d->n_geo; m->n_color = d->n_color; m->C = d->output_dim;
+  m->n_lab = d->output_dim - 4; m->L = d->n_geo + d->n_color;
+  m->grid_ch = d->grid_ch; m->gd = d->grid_d; m->gh = d->grid_h; m->gw = d->grid_w;
+  m->box_scale = d->box_scale;
+  m->sh = stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) { delete m; return hip_fail(e, "hipGetDeviceProperties"); }
+  m->num_cus = prop.multiProcessorCount;
+  rc = upload_model(m, d, nullptr, true);
+  if (rc) { fenerf_model_destroy(m); return rc; }
+  *out = m;
+  return FENERF_OK;
+}
+
+extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  std::string err;
+  int rc = validate_desc(d, err);
+  if (rc) return fail(rc, err);
+  if (d->hidden_dim != m->H || d->n_geo != m->n_geo || d->n_color != m->n_color || d->output_dim != m->C ||
+      d->grid_ch != m->grid_ch || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
+    return fail(FENERF_E_INVALID, "fenerf_model_update: architecture differs from the created model");
+  m->box_scale = d->box_scale;
+  return upload_model(m, d, (hipStream_t)stream, false);
+}
+
+extern "C" void fenerf_model_destroy(FenerfModel* m) {
+  if (!m) return;
+  if (m->d_stream) (void)hipFree(m->d_stream);
+  if (m->d_consts) (void)hipFree(m->d_consts);
+  if (m->d_grid) (void)hipFree(m->d_grid);
+  delete m;
+}
+
+extern "C" size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B) {
+  if (!m || B <= 0) return 0;
+  return align_up((size_t)2 * B * m->L * m->H * sizeof(float), 256);
+}
+
+static int film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+                     void* film_ws, const float** fp, const float** pp, void* stream) {
+  if (!fg || !pg) return fail(FENERF_E_INVALID, "freq_geo / phase_geo is NULL");
+  if (!fa || !pa) return fail(FENERF_E_INVALID, "freq_app / phase_app is NULL");
+  if (!film_ws) return fail(FENERF_E_INVALID, "film workspace is NULL");
+  float* f = (float*)film_ws;
+  float* p = f + (size_t)B * m->L * m->H;
+  *fp = f; *pp = p;
+  return launch_film_prep(m, B, fg, pg, fa, pa, f, p, stream);
+}
+
+static void fill_common(const FenerfModel* m, SirenParams& sp, const float* fp, const float* pp) {
+  memset(&sp, 0, sizeof(sp));
+  sp.stream = m->d_stream;
+  sp.consts = m->d_consts;
+  sp.fp = fp; sp.pp = pp;
+  sp.grid = m->d_grid; sp.gd = m->gd; sp.gh = m->gh; sp.gw = m->gw;
+  sp.box_scale = m->box_scale;
+  sp.ring_offset_floats = (long long)m->sh.l0_entries * 256;
+}
+
+extern "C" int fenerf_siren_forward(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                    const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                    const float* phase_app, float* out, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P == 0) return FENERF_OK;
+  if (!points || !out) return fail(FENERF_E_INVALID, "points / out is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.points = points; sp.pdirs = ray_dirs;
+  sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
+  sp.out = out;
+  return launch_siren(m, sp, stream);
+}
+
+extern "C" int fenerf_siren_forward_rays(const FenerfModel* m, int B, int R, int N, const float* origins,
+                                         const float* dirs, const float* z, int lock_view, const float* freq_geo,
+                                         const float* phase_geo, const float* freq_app, const float* phase_app,
+                                         float* out, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (B <= 0 || R < 0 || N <= 0) return fail(FENERF_E_INVALID, "B, N must be > 0 and R >= 0");
+  if (R == 0) return FENERF_OK;
+  if (!origins || !dirs || !z || !out) return fail(FENERF_E_INVALID, "origins / dirs / z / out is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.origins = origins; sp.dirs = dirs; sp.z = z; sp.n_per_ray = N; sp.lock_view = lock_view;
+  sp.P = (long long)B * R * N; sp.pts_per_image = (long long)R * N;
+  sp.out = out;
+  return launch_siren(m, sp, stream);
+}
+
+extern "C" int fenerf_siren_time_rays(const FenerfModel* m, int B, int R, int N, const float* origins, const float* dirs,
+                                      const float* z, const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                      const float* phase_app, float* out, void* film_ws, int iters, float* avg_ms,
+                                      void* stream) {
+  if (!m || !avg_ms || iters < 1) return fail(FENERF_E_INVALID, "model / avg_ms is NULL or iters < 1");
+  if (B <= 0 || R <= 0 || N <= 0 || !origins || !dirs || !z || !out) return fail(FENERF_E_INVALID, "bad shape or NULL pointer");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.origins = origins; sp.dirs = dirs; sp.z = z; sp.n_per_ray = N;
+  sp.P = (long long)B * R * N; sp.pts_per_image = (long long)R * N;
+  sp.out = out;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  rc = launch_siren(m, sp, stream);  // warm-up (also sets the LDS attribute)
+  if (rc == FENERF_OK) {
+    hipError_t e = hipEventRecord(e0, (hipStream_t)stream);
+    for (int i = 0; i < iters && rc == FENERF_OK; ++i) rc = launch_siren(m, sp, stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess && rc == FENERF_OK) rc = hip_fail(e, "event timing");
+    *avg_ms = ms / (float)iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+extern "C" int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma, const float* z, const float* noise,
+                                const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, float* out_weights,
+                                float* out_wsum, void* stream) {
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  if (BR < 0 || M < 1 || M > 128 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= M <= 128, C >= 2");
+  if (BR == 0) return FENERF_OK;
+  if (!rgb_sigma || !z) return fail(FENERF_E_INVALID, "rgb_sigma / z is NULL");
+  if (opts->fill_mode == FENERF_FILL_EVAL_WHITE_BACK && C != 4) return fail(FENERF_E_INVALID, "eval_white_back needs a 3-channel model");
+  CompositeParams p;
+  memset(&p, 0, sizeof(p));
+  p.BR = BR; p.M = M; p.C = C; p.N = M;
+  p.rows_a = rgb_sigma; p.z_a = z; p.noise = noise; p.o = *opts;
+  p.out_rgb = out_rgb; p.out_depth = out_depth; p.out_weights = out_weights; p.out_wsum = out_wsum;
+  p.out_ch = out_channels(C, opts);
+  p.sigma_only = out_rgb ? 0 : 1;
+  return launch_composite(p, false, stream);
+}
+
+extern "C" int fenerf_resample(int64_t BR, int N, const float* z_coarse, const float* coarse_weights, const float* u,
+                               float* z_fine, void* stream) {
+  if (BR < 0 || N < 3 || N > 128) return fail(FENERF_E_INVALID, "need BR >= 0 and 3 <= N <= 128");
+  if (BR == 0) return FENERF_OK;
+  if (!z_coarse || !coarse_weights || !u || !z_fine) return fail(FENERF_E_INVALID, "NULL pointer");
+  return launch_resample(BR, N, z_coarse, coarse_weights, u, z_fine, stream);
+}
+
+extern "C" int fenerf_sample_pdf(int64_t BR, int K, int n_importance, const float* bins, const float* weights,
+                                 const float* u, float* samples, void* stream) {
+  if (BR < 0 || K < 1 || K > 127 || n_importance < 1 || n_importance > 128)
+    return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= K <= 127, 1 <= n_importance <= 128");
+  if (BR == 0) return FENERF_OK;
+  if (!bins || !weights || !u || !samples) return fail(FENERF_E_INVALID, "NULL pointer");
+  return launch_sample_pdf(BR, K, n_importance, bins, weights, u, samples, stream);
+}
+
+extern "C" int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const float* coarse,
+                                      const float* z_fine, const float* z_coarse, const float* noise,
+                                      const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth,
+                                      float* out_weights, float* out_wsum, float* out_z_sorted, void* stream) {
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  if (BR < 0 || N < 1 || 2 * N > 128 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= N <= 64, C >= 2");
+  if (BR == 0) return FENERF_OK;
+  if (!fine || !coarse || !z_fine || !z_coarse) return fail(FENERF_E_INVALID, "NULL pointer");
+  if (opts->fill_mode == FENERF_FILL_EVAL_WHITE_BACK && C != 4) return fail(FENERF_E_INVALID, "eval_white_back needs a 3-channel model");
+  CompositeParams p;
+  memset(&p, 0, sizeof(p));
+  p.BR = BR; p.M = 2 * N; p.C = C; p.N = N;
+  p.rows_a = fine; p.rows_b = coarse; p.z_a = z_fine; p.z_b = z_coarse; p.noise = noise; p.o = *opts;
+  p.out_rgb = out_rgb; p.out_depth = out_depth; p.out_weights = out_weights; p.out_wsum = out_wsum; p.out_z = out_z_sorted;
+  p.out_ch = out_channels(C, opts);
+  p.sigma_only = out_rgb ? 0 : 1;
+  return launch_composite(p, true, stream);
+}
+
+// workspace layout of fenerf_render_forward
+namespace {
+struct RenderWs {
+  size_t film, coarse, fine, wts, zf, total;
+};
+RenderWs render_ws(const FenerfModel* m, int B, int R, int N, int hier) {
+  RenderWs w;
+  const size_t pts = (size_t)B * R * N;
+  size_t off = 0;
+  w.film = off; off += fenerf_film_workspace_bytes(m, B);
+  w.coarse = off; off += align_up(pts * m->C * sizeof(float), 256);
+  w.fine = off; off += hier ? align_up(pts * m->C * sizeof(float), 256) : 0;
+  w.wts = off; off += hier ? align_up(pts * sizeof(float), 256) : 0;
+  w.zf = off; off += hier ? align_up(pts * sizeof(float), 256) : 0;
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t fenerf_render_workspace_bytes(const FenerfModel* m, int B, int R, int N, int hierarchical) {
+  if (!m || B <= 0 || R <= 0 || N <= 0) return 0;
+  return render_ws(m, B, R, N, hierarchical).total;
+}
+
+extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, int hierarchical, int lock_view,
+                                     const float* origins, const float* dirs, const float* z_coarse, const float* u,
+                                     const float* noise_coarse, const float* noise_final, const float* freq_geo,
+                                     const float* phase_geo, const float* freq_app, const float* phase_app,
+                                     const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth,
+                                     float* out_weights, float* out_wsum, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  if (B <= 0 || R <= 0 || N <= 0) return fail(FENERF_E_INVALID, "B, R, N must be > 0");
+  const int M = hierarchical ? 2 * N : N;
+  if (M > 128) return fail(FENERF_E_INVALID, "at most 128 samples per ray (64+64 hierarchical)");
+  if (hierarchical && N < 3) return fail(FENERF_E_INVALID, "hierarchical sampling needs num_steps >= 3");
+  if (!origins || !dirs || !z_coarse || !out_rgb) return fail(FENERF_E_INVALID, "origins / dirs / z_coarse / out_rgb is NULL");
+  if (hierarchical && !u) return fail(FENERF_E_INVALID, "hierarchical sampling needs u");
+  if (opts->fill_mode == FENERF_FILL_EVAL_WHITE_BACK && m->C != 4) return fail(FENERF_E_INVALID, "eval_white_back needs a 3-channel model");
+  const RenderWs ws = render_ws(m, B, R, N, hierarchical);
+  if (!workspace || workspace_bytes < ws.total) return fail(FENERF_E_INVALID, "workspace too small (see fenerf_render_workspace_bytes)");
+  char* base = (char*)workspace;
+  const float *fp, *pp;
+  rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, base + ws.film, &fp, &pp, stream);
+  if (rc) return rc;
+  float* coarse = (float*)(base + ws.coarse);
+  const long long BR = (long long)B * R;
+
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.origins = origins; sp.dirs = dirs; sp.n_per_ray = N; sp.lock_view = lock_view;
+  sp.P = BR * N; sp.pts_per_image = (long long)R * N;
+  sp.z = z_coarse; sp.out = coarse;
+  rc = launch_siren(m, sp, stream);                       // coarse pass   (generators.py:479)
+  if (rc) return rc;
+
+  CompositeParams cp;
+  if (!hierarchical) {
+    memset(&cp, 0, sizeof(cp));
+    cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;
+    cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_final; cp.o = *opts;
+    cp.out_rgb = out_rgb; cp.out_depth = out_depth; cp.out_weights = out_weights; cp.out_wsum = out_wsum;
+    cp.out_ch = out_channels(m->C, opts);
+    return launch_composite(cp, false, stream);           // (generators.py:519)
+  }
+  float* fine = (float*)(base + ws.fine);
+  float* wts = (float*)(base + ws.wts);
+  float* zf = (float*)(base + ws.zf);
+  memset(&cp, 0, sizeof(cp));                             // coarse weights only (generators.py:487)
+  cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;
+  cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_coarse;
+  cp.o.clamp_mode = opts->clamp_mode; cp.o.noise_std = opts->noise_std;
+  cp.out_weights = wts; cp.sigma_only = 1; cp.out_ch = m->C - 1;
+  rc = launch_composite(cp, false, stream);
+  if (rc) return rc;
+  rc = launch_resample(BR, N, z_coarse, wts, u, zf, stream);   // (generators.py:489-499)
+  if (rc) return rc;
+  sp.z = zf; sp.out = fine;
+  rc = launch_siren(m, sp, stream);                       // fine pass     (generators.py:505)
+  if (rc) return rc;
+  memset(&cp, 0, sizeof(cp));                             // merge + final composite (generators.py:508-519)
+  cp.BR = BR; cp.M = 2 * N; cp.C = m->C; cp.N = N;
+  cp.rows_a = fine; cp.rows_b = coarse; cp.z_a = zf; cp.z_b = z_coarse; cp.noise = noise_final; cp.o = *opts;
+  cp.out_rgb = out_rgb; cp.out_depth = out_depth; cp.out_weights = out_weights; cp.out_wsum = out_wsum;
+  cp.out_ch = out_channels(m->C, opts);
+  return launch_composite(cp, true, stream);
+}

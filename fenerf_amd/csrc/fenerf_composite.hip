@@ -1,0 +1,274 @@
+// Ray-tail kernels for gfx950: alpha compositing (fancy_integration), inverse-CDF resampling (sample_pdf)
+// and the sorted merge of coarse+fine samples -- one 64-lane wavefront per ray, lane = sample.
+//
+// reference: generators/volumetric_rendering.py:18-106 (fancy_integration), :259-300 (sample_pdf),
+//            generators/generators.py:486-519 (resample orchestration, cat/sort/gather merge).
+// The reference runs these as ~15-25 tiny ATen launches over [B,R,M,*] tensors and materialises the
+// sorted [B,R,2N,22] tensor; here the exclusive transmittance product is a wavefront shuffle scan, the
+// merge is a rank computation in LDS (stable, like torch.sort on CPU) and the sorted tensor never exists.
+#include <hip/hip_runtime.h>
+
+#include "fenerf_internal.h"
+
+namespace fenerf {
+
+#define MAX_M 128  // samples per ray handled by one wave (2 per lane)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inclusive scans across the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o, 64);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) {  // F.softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite (+ optional merge of fine/coarse): one wave per ray
+// ------------------------------------------------------------------------------------------------
+template <bool MERGE>
+__global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
+  __shared__ float s_z[4][MAX_M];      // z by source index (merge) / sorted z
+  __shared__ float s_zs[4][MAX_M + 1]; // sorted z
+  __shared__ int s_ord[4][MAX_M];      // sorted position -> source index
+  __shared__ float s_w[4][MAX_M];      // weights by sorted position
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int M = P.M, C = P.C, N = P.N;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
+    float zk[2], sg[2];
+    int src[2];
+    // ---- sorted order
+    if (MERGE) {
+      // source index i < N: fine sample i, else coarse sample i-N   (cat([fine, coarse]), generators.py:508-509)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) s_z[wv][i] = i < N ? P.z_a[ray * N + i] : P.z_b[ray * N + (i - N)];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) {
+          const float zi = s_z[wv][i];
+          int rank = 0;
+          for (int j = 0; j < M; ++j) {
+            const float zj = s_z[wv][j];
+            rank += (zj < zi || (zj == zi && j < i)) ? 1 : 0;   // stable ascending (torch.sort, generators.py:510)
+          }
+          s_ord[wv][rank] = i;
+          s_zs[wv][rank] = zi;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) { s_ord[wv][i] = i; s_zs[wv][i] = P.z_a[ray * M + i]; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- per-sample alpha (volumetric_rendering.py:23-34)
+    float alpha[2], tt[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k = lane + 64 * s;
+      alpha[s] = 0.f; tt[s] = 1.f; zk[s] = 0.f; src[s] = 0; sg[s] = 0.f;
+      if (k < M) {
+        src[s] = s_ord[wv][k];
+        zk[s] = s_zs[wv][k];
+        const float* row = MERGE ? (src[s] < N ? P.rows_a + (ray * N + src[s]) * (long long)C
+                                               : P.rows_b + (ray * N + (src[s] - N)) * (long long)C)
+                                 : P.rows_a + (ray * M + k) * (long long)C;
+        sg[s] = row[C - 1];
+        const float delta = (k == M - 1) ? 1e10f : (s_zs[wv][k + 1] - zk[s]);
+        float x = sg[s];
+        if (P.noise) x = __fadd_rn(x, __fmul_rn(P.noise[ray * M + k], P.o.noise_std));
+        const float act = P.o.clamp_mode == FENERF_CLAMP_SOFTPLUS ? softplus_f(x) : fmaxf(x, 0.f);
+        alpha[s] = 1.f - expf(-delta * act);
+        tt[s] = 1.f - alpha[s] + 1e-10f;
+      }
+    }
+    // ---- exclusive transmittance: T_k = prod_{j<k} (1 - alpha_j + 1e-10)   (cumprod, :36-37)
+    const float inc0 = wave_scan_mul(tt[0], lane);
+    const float tot0 = __shfl(inc0, 63, 64);
+    float ex0 = __shfl_up(inc0, 1, 64);
+    if (lane == 0) ex0 = 1.f;
+    float w[2];
+    w[0] = alpha[0] * ex0;
+    w[1] = 0.f;
+    if (M > 64) {
+      const float inc1 = wave_scan_mul(tt[1], lane);
+      float ex1 = __shfl_up(inc1, 1, 64);
+      if (lane == 0) ex1 = 1.f;
+      w[1] = alpha[1] * (tot0 * ex1);
+    }
+    const float wsum = wave_sum(w[0] + w[1]);
+    if (P.o.last_back) {   // weights[:, :, -1] += (1 - weights_sum)   (:40-41)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (lane + 64 * s == M - 1) w[s] += 1.f - wsum;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k = lane + 64 * s;
+      if (k < M) {
+        s_w[wv][k] = w[s];
+        if (P.out_weights) P.out_weights[ray * M + k] = w[s];
+        if (P.out_z) P.out_z[ray * M + k] = zk[s];
+      }
+    }
+    if (P.out_wsum && lane == 0) P.out_wsum[ray] = wsum;
+    const float depth = wave_sum(w[0] * zk[0] + w[1] * zk[1]);   // (:44)
+    if (P.out_depth && lane == 0) P.out_depth[ray] = depth;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- colour / label accumulation: lane = (channel c = lane & 31 [+32 in a 2nd pass], sample parity)  (:43)
+    if (!P.sigma_only && P.out_rgb) {
+      const int nch = C - 1;
+      const bool pad = P.o.fill_mode == FENERF_FILL_SEG_PADDING_BACKGROUND || P.o.fill_mode == FENERF_FILL_EVAL_SEG_PADDING_BACKGROUND;
+      const bool low = wsum < 0.9f;
+      const bool fill = low && ((pad && P.o.fill_enabled) || P.o.fill_mode == FENERF_FILL_EVAL_WHITE_BACK);
+      float* orow = P.out_rgb + ray * (long long)P.out_ch;
+      for (int c0 = 0; c0 < nch; c0 += 32) {
+        const int c = c0 + (lane & 31), par = lane >> 5;
+        float acc = 0.f;
+        if (c < nch) {
+          for (int k = par; k < M; k += 2) {
+            const int sidx = s_ord[wv][k];
+            const float* row = MERGE ? (sidx < N ? P.rows_a + (ray * N + sidx) * (long long)C
+                                                 : P.rows_b + (ray * N + (sidx - N)) * (long long)C)
+                                     : P.rows_a + (ray * M + k) * (long long)C;
+            acc += s_w[wv][k] * row[c];
+          }
+        }
+        acc += __shfl_xor(acc, 32, 64);
+        if (P.o.white_back) acc = acc + 1.f - wsum;          // (:46-47)
+        if (P.o.black_back) acc = acc + (1.f - wsum) * -1.f; // (:49-50)
+        if (par == 0 && c < nch) {
+          if (pad) orow[c + 1] = fill ? P.o.fill_value : acc;                       // (:71-83 / :85-97)
+          else if (P.o.fill_mode == FENERF_FILL_EVAL_WHITE_BACK) orow[c] = fill ? 1.f : acc;  // (:99-102)
+          else orow[c] = acc;
+        }
+      }
+      if (pad && lane == 0) orow[0] = fill ? 1.f : 0.f;   // background channel prepended, 1 on filled rays
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// importance resampling: generators.py:486-499 + sample_pdf (volumetric_rendering.py:259-300)
+// ------------------------------------------------------------------------------------------------
+// RAW = false: zc [BR,N], wc [BR,N] (coarse z / weights), K = N-2, draws N samples      (generators.py:486-499)
+// RAW = true : zc = bins [BR,K+1], wc = weights [BR,K] as the caller passes them to sample_pdf, draws NS samples
+template <bool RAW>
+__global__ __launch_bounds__(256) void resample_kernel(long long BR, int K, int NS, const float* __restrict__ zc,
+                                                       const float* __restrict__ wc, const float* __restrict__ u,
+                                                       float* __restrict__ zf) {
+  __shared__ float s_cdf[4][MAX_M];
+  __shared__ float s_bin[4][MAX_M];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int N = K + 2;          // RAW=false: coarse samples per ray; pdf bins = weights[:, 1:-1]; cdf has K+1 knots
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long ray = (long long)blockIdx.x * 4 + wv; ray < BR; ray += nwaves) {
+    float ww[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;   // pdf bin j uses coarse weight j+1
+      ww[s] = 0.f;
+      if (RAW) {
+        if (j < K) ww[s] = __fadd_rn(wc[ray * K + j], 1e-5f);                          // + eps (:273)
+        if (j < K + 1) s_bin[wv][j] = zc[ray * (K + 1) + j];
+      } else {
+        if (j < K) ww[s] = __fadd_rn(__fadd_rn(wc[ray * N + j + 1], 1e-5f), 1e-5f);    // +1e-5 (generators.py:489) + eps (:273)
+        if (j < K + 1) s_bin[wv][j] = 0.5f * (zc[ray * N + j] + zc[ray * N + j + 1]);  // z_vals_mid (generators.py:494)
+      }
+    }
+    const float tot = wave_sum(ww[0] + ww[1]);
+    const float pdf0 = ww[0] / tot, pdf1 = ww[1] / tot;                               // (:274)
+    const float inc0 = wave_scan_add(pdf0, lane);
+    const float tot0 = __shfl(inc0, 63, 64);
+    if (lane == 0) s_cdf[wv][0] = 0.f;                                                 // (:276)
+    if (lane < K) s_cdf[wv][lane + 1] = inc0;
+    if (K > 64) {
+      const float inc1 = wave_scan_add(pdf1, lane);
+      if (lane + 64 < K) s_cdf[wv][lane + 65] = tot0 + inc1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = lane + 64 * s;
+      if (i < NS) {
+        const float ui = u[ray * NS + i];
+        int inds = 0;                                   // torch.searchsorted(cdf, u) (left): #knots < u  (:286)
+        for (int j = 0; j <= K; ++j) inds += s_cdf[wv][j] < ui ? 1 : 0;
+        const int below = inds - 1 > 0 ? inds - 1 : 0;  // (:287-288)
+        const int above = inds < K ? inds : K;
+        const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
+        const float b0 = s_bin[wv][below], b1 = s_bin[wv][above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;                 // (:295-296)
+        zf[ray * NS + i] = b0 + (ui - c0) / denom * (b1 - b0);   // (:299)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static int hip_fail2(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+int launch_composite(const CompositeParams& p, bool merge, void* stream) {
+  if (p.BR <= 0) return FENERF_OK;
+  long long blocks = (p.BR + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (merge) hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail2(e, "composite launch");
+}
+
+int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream) {
+  if (BR <= 0) return FENERF_OK;
+  long long blocks = (BR + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(resample_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail2(e, "resample launch");
+}
+
+int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const float* w, const float* u, float* out, void* stream) {
+  if (BR <= 0) return FENERF_OK;
+  long long blocks = (BR + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(resample_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail2(e, "sample_pdf launch");
+}
+
+}  // namespace fenerf

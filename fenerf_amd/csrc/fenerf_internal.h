@@ -1,0 +1,78 @@
+// Internal declarations shared by the host API, the packer and the kernel launchers.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/fenerf.h"
+#include "fenerf_layout.h"
+
+namespace fenerf {
+
+void set_error(const std::string& msg);
+int validate_desc(const FenerfModelDesc* d, std::string& err);
+int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
+
+}  // namespace fenerf
+
+// Opaque model handle: device-resident packed weights + shape info.
+struct FenerfModel {
+  int H, n_geo, n_color, n_lab, C, L;
+  int grid_ch, gd, gh, gw;
+  float box_scale;
+  fenerf::StreamShape sh;
+  float* d_stream;  // [l0 entries | ring stream] * 256 floats
+  float* d_consts;  // head bias | rgb bias | film biases
+  float* d_grid;    // channels-last [D][H][W][32] or nullptr
+  int num_cus;
+};
+
+namespace fenerf {
+
+// Kernel parameter blocks (plain structs passed by value).
+struct SirenParams {
+  const float* stream;     // packed weights
+  const float* consts;     // head bias [32] | rgb bias [4] | ...
+  const float* fp;         // [B][L][H]  f' = (15 f + 30) / 2pi
+  const float* pp;         // [B][L][H]  p' = (f b + p) / 2pi
+  const float* grid;       // channels-last grid or nullptr
+  int gd, gh, gw;
+  float box_scale;
+  // inputs: explicit points (points != nullptr) or rays
+  const float* points;     // [P][3]
+  const float* pdirs;      // [P][3] or nullptr (lock)
+  const float* origins;    // [B*R][3]
+  const float* dirs;       // [B*R][3]
+  const float* z;          // [B*R][N]
+  int n_per_ray;
+  int lock_view;
+  long long P;             // total points = B * pts_per_image
+  long long pts_per_image;
+  float* out;              // [P][C]
+  long long ring_offset_floats;  // offset of the ring stream inside `stream`
+};
+
+struct CompositeParams {
+  long long BR;
+  int M, C, N;             // M samples composited; merge: M = 2N
+  const float* rows_a;     // non-merge: rgb_sigma [BR][M][C]; merge: fine [BR][N][C]
+  const float* rows_b;     // merge: coarse [BR][N][C]
+  const float* z_a;        // non-merge: z [BR][M]; merge: z_fine [BR][N]
+  const float* z_b;        // merge: z_coarse [BR][N]
+  const float* noise;      // [BR][M] or nullptr
+  FenerfCompositeOpts o;
+  float* out_rgb; float* out_depth; float* out_weights; float* out_wsum; float* out_z;
+  int out_ch;              // channels written per ray (C-1 or C)
+  int sigma_only;          // coarse pass: only weights wanted, skip colour accumulation
+};
+
+int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+                     float* fp, float* pp, void* stream);
+int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);
+int launch_composite(const CompositeParams& p, bool merge, void* stream);
+int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);
+int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const float* w, const float* u, float* out, void* stream);
+int launch_grid_relayout(const float* src_ncdhw, float* dst_cl, int C, int D, int Hh, int W, void* stream);
+
+}  // namespace fenerf

@@ -1,0 +1,58 @@
+// Streaming weight layout shared by the host packer (fenerf_pack.cpp) and the SIREN kernel
+// (fenerf_siren.hip).  See DESIGN.md "SIREN kernel" for the derivation.
+//
+// The per-point network is evaluated TRANSPOSED on v_mfma_f32_32x32x2_f32: D[feature][point] +=
+// W[feature][k] * X^T[k][point].  One wave owns 32 points (MFMA columns) and ALL H features of them.
+// MFMA C/D layout (lane l, acc register r): column = l&31 (the point), row = (r&3) + 8*(r>>2) + 4*(l>>5).
+// So after a layer, lane (point m, half h) holds, for n-block nb and register r, output feature
+//      feat_of(16*nb + r, h) = 32*nb + (r&3) + 8*(r>>2) + 4*h .
+// The next layer contracts over k in exactly that order: k-step s (s = 16*nb + r) multiplies
+// B = {half 0: feature feat_of(s,0), half 1: feature feat_of(s,1)} -- the lane's OWN register --
+// with A = W[n][feat_of(s, l>>5)].  The K permutation is applied to the weights once, on the host,
+// so activations never leave the lane that produced them (no LDS transpose, no cross-lane traffic).
+//
+// An "entry" is one wave-wide float4 load: 64 lanes x 16 B = 1 KiB = the A operands of 4 consecutive
+// k-steps for one 32-row n-block.  Bodies (one n-block of one stage) are padded to a multiple of
+// FENERF_PF entries so the software prefetch ring has compile-time slot indices.
+#pragma once
+
+#define FENERF_PF 8            /* prefetch ring depth, entries */
+#define FENERF_E_KSTEPS 16     /* 32 grid channels = 16 k-steps (half h holds channels 16h..16h+15) */
+
+#ifdef __cplusplus
+namespace fenerf {
+
+constexpr int pad_pf(int n) { return (n + FENERF_PF - 1) / FENERF_PF * FENERF_PF; }
+constexpr int feat_of(int s, int h) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h; }
+
+struct StreamShape {
+  int H, NB, KGX, KGXP;  // features, n-blocks, k-groups of an H-wide input, padded
+  int c0_kg, c0_kgp;     // colour-layer-0 body: x + grid + dir k-groups, padded
+  int l0_entries;        // layer-0 block (plain loads, not in the ring)
+  long long ring_entries; // total entries of the ring stream incl. the PF tail pad
+};
+
+inline StreamShape stream_shape(int H, int n_geo, int n_color, bool grid) {
+  StreamShape s;
+  s.H = H; s.NB = H / 32; s.KGX = H / 8; s.KGXP = pad_pf(s.KGX);
+  s.c0_kg = s.KGX + (grid ? FENERF_E_KSTEPS / 4 : 0) + 1;
+  s.c0_kgp = pad_pf(s.c0_kg);
+  s.l0_entries = s.NB;
+  long long e = 0;
+  e += (long long)(n_geo - 1) * s.NB * s.KGXP;   // G1..G(n_geo-1)
+  e += (long long)s.NB * s.c0_kgp;               // C0
+  e += s.KGXP;                                   // HEAD (labels + sigma)
+  e += (long long)(n_color - 1) * s.NB * s.KGXP; // C1..
+  e += s.KGXP;                                   // RGB
+  e += FENERF_PF;                                // tail pad (prefetch runs past the end)
+  s.ring_entries = e;
+  return s;
+}
+
+// consts layout (floats): [0,32) head bias by head row, [32,36) rgb bias, [36, 36 + L*H) FiLM-layer biases
+constexpr int CONST_HEAD_BIAS = 0;
+constexpr int CONST_RGB_BIAS = 32;
+constexpr int CONST_FILM_BIAS = 36;
+
+}  // namespace fenerf
+#endif

@@ -1,0 +1,185 @@
+// Host-side weight packer: nn.Linear-layout fp32 weights -> the SIREN kernel's streaming layout
+// (fenerf_layout.h).  Pure C++ (no HIP), so layout tests can run without a GPU.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/fenerf.h"
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+
+namespace fenerf {
+
+// One k-step of a body: the source column each lane-half multiplies (-1 = zero).
+struct KStep { int col_h0, col_h1; };
+
+// Emits one body (one 32-row n-block): rows r0..r0+31 of W (row-major [nrows][ncols], rows >= nrows are
+// zero), k-steps as listed, padded to whole entries and to a multiple of PF entries.
+static void emit_body(std::vector<float>& out, const double* W, int nrows, int ncols, int r0,
+                      const std::vector<KStep>& ks, int padded_entries) {
+  const int n_entries = ((int)ks.size() + 3) / 4;
+  for (int e = 0; e < padded_entries; ++e) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = r0 + (lane & 31), h = lane >> 5;
+      for (int j = 0; j < 4; ++j) {
+        float v = 0.f;
+        const int s = e * 4 + j;
+        if (e < n_entries && s < (int)ks.size() && row < nrows) {
+          const int col = h ? ks[s].col_h1 : ks[s].col_h0;
+          if (col >= 0) v = (float)W[(size_t)row * ncols + col];
+        }
+        out.push_back(v);
+      }
+    }
+  }
+}
+
+static std::vector<double> to_f64(const float* p, size_t n) {
+  std::vector<double> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = p[i];
+  return v;
+}
+
+int validate_desc(const FenerfModelDesc* d, std::string& err) {
+  if (!d) { err = "desc is NULL"; return FENERF_E_INVALID; }
+  if (d->abi_version != FENERF_ABI_VERSION) { err = "abi_version mismatch"; return FENERF_E_INVALID; }
+  const int H = d->hidden_dim;
+  if (!(H == 32 || H == 64 || H == 128 || H == 256)) { err = "hidden_dim must be 32, 64, 128 or 256"; return FENERF_E_UNSUPPORTED; }
+  if (d->n_geo < 2 || d->n_geo > FENERF_MAX_GEO) { err = "n_geo out of range"; return FENERF_E_INVALID; }
+  if (d->n_color < 1 || d->n_color > FENERF_MAX_COLOR) { err = "n_color out of range"; return FENERF_E_INVALID; }
+  if (d->n_label_layers < 0 || d->n_label_layers > FENERF_MAX_LABEL_LAYERS) { err = "n_label_layers out of range"; return FENERF_E_INVALID; }
+  const int n_lab = d->output_dim - 4;
+  if (n_lab < 0 || n_lab + 1 > 32) { err = "output_dim must be in [4, 35]"; return FENERF_E_INVALID; }
+  if ((n_lab > 0) != (d->n_label_layers > 0)) { err = "label layers and output_dim disagree"; return FENERF_E_INVALID; }
+  if (!(d->grid_ch == 0 || d->grid_ch == 32)) { err = "grid_ch must be 0 or 32"; return FENERF_E_UNSUPPORTED; }
+  if (d->grid_ch && (d->grid_d < 2 || d->grid_h < 2 || d->grid_w < 2)) { err = "grid dims must be >= 2"; return FENERF_E_INVALID; }
+  for (int i = 0; i < d->n_geo; ++i) if (!d->geo_w[i] || !d->geo_b[i]) { err = "geo weight pointer is NULL"; return FENERF_E_INVALID; }
+  for (int i = 0; i < d->n_color; ++i) if (!d->color_w[i] || !d->color_b[i]) { err = "color weight pointer is NULL"; return FENERF_E_INVALID; }
+  for (int i = 0; i < d->n_label_layers; ++i) if (!d->label_w[i] || !d->label_b[i]) { err = "label weight pointer is NULL"; return FENERF_E_INVALID; }
+  if (!d->sigma_w || !d->sigma_b || !d->rgb_w || !d->rgb_b) { err = "sigma/rgb weight pointer is NULL"; return FENERF_E_INVALID; }
+  return FENERF_OK;
+}
+
+int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err) {
+  int rc = validate_desc(d, err);
+  if (rc) return rc;
+  const int H = d->hidden_dim, n_lab = d->output_dim - 4;
+  const bool grid = d->grid_ch != 0;
+  const StreamShape sh = stream_shape(H, d->n_geo, d->n_color, grid);
+  const int L = d->n_geo + d->n_color;
+  blob.clear();
+  blob.reserve((size_t)(sh.l0_entries + sh.ring_entries) * 256);
+
+  // k-steps over an H-wide activation held in MFMA C/D order, optionally shifted by a column offset
+  auto x_ksteps = [&](int col_off) {
+    std::vector<KStep> ks(H / 2);
+    for (int s = 0; s < H / 2; ++s) ks[s] = {col_off + feat_of(s, 0), col_off + feat_of(s, 1)};
+    return ks;
+  };
+
+  // ---- layer 0 (3 -> H): k-steps (x | y), (z | 0); one entry per n-block, floats 2,3 unused
+  {
+    auto W0 = to_f64(d->geo_w[0], (size_t)H * 3);
+    std::vector<KStep> ks = {{0, 1}, {2, -1}};
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, W0.data(), H, 3, nb * 32, ks, 1);
+  }
+  // ---- G1..G(n_geo-1)
+  for (int l = 1; l < d->n_geo; ++l) {
+    auto W = to_f64(d->geo_w[l], (size_t)H * H);
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, W.data(), H, H, nb * 32, ks, sh.KGXP);
+  }
+  // ---- C0: reference columns are [dir(3) | grid feats(32) | x(H)]  (siren.py:1522 / :1222)
+  {
+    const int cin = 3 + d->grid_ch + H;
+    auto W = to_f64(d->color_w[0], (size_t)H * cin);
+    auto ks = x_ksteps(3 + d->grid_ch);
+    if (grid)
+      for (int j = 0; j < FENERF_E_KSTEPS; ++j) ks.push_back({3 + j, 3 + 16 + j});  // half h holds channels 16h + j
+    ks.push_back({0, 1});   // (dir.x | dir.y)
+    ks.push_back({2, -1});  // (dir.z | 0)
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, W.data(), H, cin, nb * 32, ks, sh.c0_kgp);
+  }
+  // ---- HEAD: rows [0, n_lab) = folded label head, row n_lab = sigma.  The label head is 2-3 Linear layers with
+  //      no activation between them (siren.py:1490-1494), i.e. one affine map; fold it in fp64.
+  std::vector<double> head_b(32, 0.0);
+  {
+    std::vector<double> Wh((size_t)32 * H, 0.0);
+    if (n_lab > 0) {
+      // A (rows x H), c (rows): running affine map, start with layer 0
+      int rows = (d->n_label_layers == 1) ? n_lab : H;
+      std::vector<double> A = to_f64(d->label_w[0], (size_t)rows * H), c = to_f64(d->label_b[0], rows);
+      for (int i = 1; i < d->n_label_layers; ++i) {
+        const int orow = (i == d->n_label_layers - 1) ? n_lab : H;
+        auto Wi = to_f64(d->label_w[i], (size_t)orow * rows);
+        auto bi = to_f64(d->label_b[i], orow);
+        std::vector<double> A2((size_t)orow * H, 0.0), c2(orow, 0.0);
+        for (int o = 0; o < orow; ++o) {
+          double cb = bi[o];
+          for (int k = 0; k < rows; ++k) {
+            const double w = Wi[(size_t)o * rows + k];
+            cb += w * c[k];
+            const double* arow = &A[(size_t)k * H];
+            double* drow = &A2[(size_t)o * H];
+            for (int x = 0; x < H; ++x) drow[x] += w * arow[x];
+          }
+          c2[o] = cb;
+        }
+        A.swap(A2); c.swap(c2); rows = orow;
+      }
+      for (int o = 0; o < n_lab; ++o) {
+        for (int x = 0; x < H; ++x) Wh[(size_t)o * H + x] = A[(size_t)o * H + x];
+        head_b[o] = c[o];
+      }
+    }
+    for (int x = 0; x < H; ++x) Wh[(size_t)n_lab * H + x] = d->sigma_w[x];
+    head_b[n_lab] = d->sigma_b[0];
+    emit_body(blob, Wh.data(), 32, H, 0, x_ksteps(0), sh.KGXP);
+  }
+  // ---- C1..
+  for (int l = 1; l < d->n_color; ++l) {
+    auto W = to_f64(d->color_w[l], (size_t)H * H);
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, W.data(), H, H, nb * 32, ks, sh.KGXP);
+  }
+  // ---- RGB (3 rows)
+  {
+    auto W = to_f64(d->rgb_w, (size_t)3 * H);
+    emit_body(blob, W.data(), 3, H, 0, x_ksteps(0), sh.KGXP);
+  }
+  // ---- tail pad
+  blob.insert(blob.end(), (size_t)FENERF_PF * 256, 0.f);
+  if (blob.size() != (size_t)(sh.l0_entries + sh.ring_entries) * 256) { err = "internal: stream size mismatch"; return FENERF_E_INVALID; }
+
+  consts.assign((size_t)CONST_FILM_BIAS + (size_t)L * H, 0.f);
+  for (int i = 0; i < 32; ++i) consts[CONST_HEAD_BIAS + i] = (float)head_b[i];
+  for (int i = 0; i < 3; ++i) consts[CONST_RGB_BIAS + i] = d->rgb_b[i];
+  for (int l = 0; l < d->n_geo; ++l) memcpy(&consts[CONST_FILM_BIAS + (size_t)l * H], d->geo_b[l], sizeof(float) * H);
+  for (int l = 0; l < d->n_color; ++l) memcpy(&consts[CONST_FILM_BIAS + (size_t)(d->n_geo + l) * H], d->color_b[l], sizeof(float) * H);
+  return FENERF_OK;
+}
+
+}  // namespace fenerf
+
+extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats, float** consts,
+                                        size_t* n_consts) {
+  std::vector<float> b, c;
+  std::string err;
+  int rc = fenerf::pack_weights(desc, b, c, err);
+  if (rc) { fenerf::set_error(err); return rc; }
+  if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
+  *blob = (float*)malloc(b.size() * sizeof(float));
+  *consts = (float*)malloc(c.size() * sizeof(float));
+  if (!*blob || !*consts) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  memcpy(*blob, b.data(), b.size() * sizeof(float));
+  memcpy(*consts, c.data(), c.size() * sizeof(float));
+  *n_floats = b.size();
+  *n_consts = c.size();
+  return FENERF_OK;
+}
+
+extern "C" void fenerf_free_host(void* p) { free(p); }

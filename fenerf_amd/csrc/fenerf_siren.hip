@@ -1,0 +1,410 @@
+// FiLM-SIREN radiance field, fused per 32-point tile, for gfx950 (MI355X).
+//
+// Replaces <siren>.forward_with_frequencies_phase_shifts (reference siren/siren.py:1509-1530, :1210-1229,
+// :227-244) = UniformBoxWarp + trilinear 3-D feature-grid gather + 8 FiLM layers + sigma / label heads +
+// 1-3 FiLM colour layers + sigmoid rgb head: ~60 separate ATen launches per call in the reference, with
+// every activation round-tripping HBM.  Here one wave carries 32 points through the WHOLE network:
+//
+//   * transposed GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 == fmaf chain): D[feat][pt] += W[feat][k] X^T[k][pt];
+//     MFMA columns are the wave's 32 points, so a layer's output registers ARE the next layer's B operand
+//     (K order pre-permuted on the host, fenerf_layout.h) -- activations never move between lanes;
+//   * weights are the only HBM/L2 stream: one contiguous fp32 stream in consumption order, read with 1 KiB
+//     wave-wide float4 loads through an 8-deep register prefetch ring that runs across n-block, layer and
+//     stage boundaries; all 256 CUs read the same 2.9 MB, so it lives in L2;
+//   * FiLM epilogue fused on the accumulators: t = f'*acc + p' (revolutions, bias folded into p'),
+//     exact range reduction t - rint(2t)/2, degree-9 odd polynomial for sin(2 pi r);
+//   * the layer output is parked in the wave's private LDS slab (32 KB at H=256, lane-major float4, conflict
+//     free) while the old activations are still needed as B operands, then read back into the same registers;
+//   * grid features: channels-last re-laid grid, lane-half h gathers channels 16h..16h+15 of its point's 8
+//     corners (4 x 16 B each) at tile start, hidden behind layer 0..7 MFMAs, consumed by colour layer 0;
+//   * 1 wave / SIMD (4 waves per CU, each its own tile stream), persistent over tiles, XCD-contiguous tile
+//     ranges so neighbouring rays share an L2 for grid reads.
+#include <hip/hip_runtime.h>
+
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+
+namespace fenerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// sin(2*pi*t) for t in revolutions (|t| < 2^22).  k = rint(2t); r = t - k/2 is exact and |r| <= 1/4;
+// sin(2 pi t) = (-1)^k sin(2 pi r).  Polynomial: least-squares fit on Chebyshev nodes, max abs err 2.1e-7
+// evaluated in fp32 (3.4e-9 in exact arithmetic).
+__device__ __forceinline__ float sin2pi(float t) {
+  const float k = __builtin_rintf(t + t);
+  const float r = __builtin_fmaf(k, -0.5f, t);
+  const float u = r * r;
+  float p = __builtin_fmaf(u, 39.53581619262695f, -76.5496597290039f);
+  p = __builtin_fmaf(p, u, 81.60099792480469f);
+  p = __builtin_fmaf(p, u, -41.34165573120117f);
+  p = __builtin_fmaf(p, u, 6.283185005187988f);
+  const float s = p * r;
+  const unsigned sign = ((unsigned)(int)k) << 31;
+  return __uint_as_float(__float_as_uint(s) ^ sign);
+}
+
+struct Ring {
+  float4 w[FENERF_PF];
+  const float4* ptr;  // per-lane cursor: next entry to fetch
+};
+
+// Consume the next ring entry (compile-time slot) and refill the slot with the entry PF ahead.
+#define RING_NEXT(ring, slot, dst)      \
+  do {                                  \
+    (dst) = (ring).w[(slot)];           \
+    (ring).w[(slot)] = *(ring).ptr;     \
+    (ring).ptr += 64;                   \
+  } while (0)
+
+// acc += W_body[:, k-steps of an H-wide activation] * b  (NKG real entries, NKGP consumed)
+template <int NIN, int NKG, int NKGP>
+__device__ __forceinline__ void mfma_x(f32x16& acc, const float (&b)[NIN], Ring& ring) {
+  static_assert(NKG * 4 == NIN, "k-groups must cover the activation");
+  static_assert(NKGP % FENERF_PF == 0, "bodies are padded to the ring depth");
+#pragma unroll
+  for (int kg = 0; kg < NKGP; ++kg) {
+    float4 w;
+    RING_NEXT(ring, kg % FENERF_PF, w);
+    if (kg < NKG) {
+      acc = MFMA(w.x, b[4 * kg + 0], acc);
+      acc = MFMA(w.y, b[4 * kg + 1], acc);
+      acc = MFMA(w.z, b[4 * kg + 2], acc);
+      acc = MFMA(w.w, b[4 * kg + 3], acc);
+    }
+    // pin the (refill, 4 x MFMA) order: without it the scheduler sinks the refill loads next to their use
+    // (to shorten live ranges) and the prefetch distance collapses from PF entries to ~1.
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// FiLM parameters of one n-block for this lane-half: features 32nb + 8j + 4h + {0..3}, j = 0..3.
+// Loaded BEFORE the n-block's MFMAs so the L2 latency hides behind them.
+struct FilmNB { float4 f[4], p[4]; };
+__device__ __forceinline__ FilmNB film_load(const float* fpl, const float* ppl, int nb) {
+  FilmNB fm;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fm.f[j] = *reinterpret_cast<const float4*>(fpl + 32 * nb + 8 * j);
+    fm.p[j] = *reinterpret_cast<const float4*>(ppl + 32 * nb + 8 * j);
+  }
+  return fm;
+}
+
+// FiLM epilogue of one n-block: out = sin(2 pi (f' acc + p')) -> this lane's LDS slab, groups nb*4 .. nb*4+3
+__device__ __forceinline__ void film_store(const f32x16& acc, const FilmNB& fm, int nb, float4* slab /* + lane */) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 f = fm.f[j], p = fm.p[j];
+    float4 o;
+    o.x = sin2pi(__builtin_fmaf(f.x, acc[4 * j + 0], p.x));
+    o.y = sin2pi(__builtin_fmaf(f.y, acc[4 * j + 1], p.y));
+    o.z = sin2pi(__builtin_fmaf(f.z, acc[4 * j + 2], p.z));
+    o.w = sin2pi(__builtin_fmaf(f.w, acc[4 * j + 3], p.w));
+    slab[(nb * 4 + j) * 64] = o;
+  }
+}
+
+template <int NIN>
+__device__ __forceinline__ void load_act(float (&in)[NIN], const float4* slab) {
+#pragma unroll
+  for (int g = 0; g < NIN / 4; ++g) {
+    const float4 v = slab[g * 64];
+    in[4 * g + 0] = v.x; in[4 * g + 1] = v.y; in[4 * g + 2] = v.z; in[4 * g + 3] = v.w;
+  }
+}
+
+// A square FiLM layer H -> H.
+template <int H>
+__device__ __forceinline__ void square_layer(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl,
+                                             float4* slab) {
+  constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
+#pragma unroll 1
+  for (int nb = 0; nb < NB; ++nb) {
+    const FilmNB fm = film_load(fpl, ppl, nb);
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+    film_store(acc, fm, nb, slab);
+  }
+  load_act<H / 2>(in, slab);
+}
+
+template <int H, bool GRID>
+__global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
+  constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
+  constexpr int C0_KG = KGX + (GRID ? FENERF_E_KSTEPS / 4 : 0) + 1, C0_KGP = pad_pf(C0_KG);
+  constexpr int SLAB_F4 = (H / 8) * 64;        // activation slab per wave, float4 units
+  extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int stage_f4 = (32 * C + 3) / 4;
+  float4* slab = smem + wave * (SLAB_F4 + stage_f4) + lane;
+  float* stage = reinterpret_cast<float*>(smem + wave * (SLAB_F4 + stage_f4) + SLAB_F4);
+
+  const int L = n_geo + n_color;
+  const float4* l0w = reinterpret_cast<const float4*>(P.stream) + lane;
+  const float4* ring_base = reinterpret_cast<const float4*>(P.stream + P.ring_offset_floats) + lane;
+
+  // XCD-contiguous tile ranges: block b runs on XCD b % 8 (observed, speed only)
+  const long long ntiles = (P.P + 31) / 32;
+  const int nblk = gridDim.x;
+  const int nx = nblk < 8 ? nblk : 8;
+  const int x = blockIdx.x % nx, bi = blockIdx.x / nx;
+  const int blocks_in_x = nblk / nx + (x < nblk % nx ? 1 : 0);
+  const long long t_begin = ntiles * x / nx, t_end = ntiles * (x + 1) / nx;
+  const int wstride = blocks_in_x * 4;
+
+  for (long long tile = t_begin + bi * 4 + wave; tile < t_end; tile += wstride) {
+    // ---------------- this lane's point ----------------
+    long long pt = tile * 32 + m;
+    const bool valid = pt < P.P;
+    if (!valid) pt = P.P - 1;
+    const long long img = pt / P.pts_per_image;
+    float px, py, pz, dx, dy, dz;
+    if (P.points) {
+      px = P.points[pt * 3 + 0]; py = P.points[pt * 3 + 1]; pz = P.points[pt * 3 + 2];
+      if (P.pdirs) { dx = P.pdirs[pt * 3 + 0]; dy = P.pdirs[pt * 3 + 1]; dz = P.pdirs[pt * 3 + 2]; }
+      else { dx = 0.f; dy = 0.f; dz = -1.f; }
+    } else {
+      const long long ray = pt / P.n_per_ray;
+      const float zz = P.z[pt];
+      const float ox = P.origins[ray * 3 + 0], oy = P.origins[ray * 3 + 1], oz = P.origins[ray * 3 + 2];
+      dx = P.dirs[ray * 3 + 0]; dy = P.dirs[ray * 3 + 1]; dz = P.dirs[ray * 3 + 2];
+      // generators.py:504: origins + dirs * z as separate mul and add (torch does not contract to fma)
+      px = __fadd_rn(ox, __fmul_rn(dx, zz)); py = __fadd_rn(oy, __fmul_rn(dy, zz)); pz = __fadd_rn(oz, __fmul_rn(dz, zz));
+      if (P.lock_view) { dx = 0.f; dy = 0.f; dz = -1.f; }
+    }
+    // UniformBoxWarp, siren.py:181-187
+    const float qx = px * P.box_scale, qy = py * P.box_scale, qz = pz * P.box_scale;
+
+    // ---------------- prime the weight ring ----------------
+    Ring ring;
+    ring.ptr = ring_base;
+#pragma unroll
+    for (int i = 0; i < FENERF_PF; ++i) { ring.w[i] = *ring.ptr; ring.ptr += 64; }
+
+    // ---------------- grid features (sample_from_3dgrid, siren.py:314-330; grid_sample trilinear,
+    //                  zeros padding, align_corners=True).  Lane-half h blends channels 16h..16h+15. ----------
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    if (GRID) {
+      const float ix = ((qx + 1.f) / 2.f) * (float)(P.gw - 1);
+      const float iy = ((qy + 1.f) / 2.f) * (float)(P.gh - 1);
+      const float iz = ((qz + 1.f) / 2.f) * (float)(P.gd - 1);
+      const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int cz = c >> 2, cy = (c >> 1) & 1, cx = c & 1;
+        const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
+        const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
+        const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
+        const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
+        const float wgt = wx * wy * wz;
+        const bool ok = xi >= 0.f && xi <= (float)(P.gw - 1) && yi >= 0.f && yi <= (float)(P.gh - 1) && zi >= 0.f &&
+                        zi <= (float)(P.gd - 1);
+        if (ok) {
+          const long long vox = ((long long)(int)zi * P.gh + (int)yi) * P.gw + (int)xi;
+          const float4* g = reinterpret_cast<const float4*>(P.grid + vox * 32 + 16 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = g[q];
+            e[4 * q + 0] += v.x * wgt; e[4 * q + 1] += v.y * wgt; e[4 * q + 2] += v.z * wgt; e[4 * q + 3] += v.w * wgt;
+          }
+        }
+      }
+    }
+
+    const float* fpl = P.fp + (size_t)img * L * H + 4 * h;   // FiLM params of this lane's image, + half offset
+    const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
+
+    // ---------------- layer 0: 3 -> H.  k-steps (x|y), (z|0) ----------------
+    {
+      const float b0 = h ? qy : qx, b1 = h ? 0.f : qz;
+#pragma unroll 1
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 w = l0w[nb * 64];
+        const FilmNB fm = film_load(fpl, ppl, nb);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = MFMA(w.x, b0, acc);
+        acc = MFMA(w.y, b1, acc);
+        film_store(acc, fm, nb, slab);
+      }
+    }
+    float in[H / 2];
+    load_act<H / 2>(in, slab);
+
+    // ---------------- geometry trunk G1 .. G(n_geo-1) ----------------
+#pragma unroll 1
+    for (int l = 1; l < n_geo; ++l) square_layer<H>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, slab);
+
+    // ---------------- colour layer 0: [x | grid feats | dir] -> H ----------------
+    {
+      const float* f0 = fpl + (size_t)n_geo * H;
+      const float* p0 = ppl + (size_t)n_geo * H;
+      const float bd0 = h ? dy : dx, bd1 = h ? 0.f : dz;
+#pragma unroll 1
+      for (int nb = 0; nb < NB; ++nb) {
+        const FilmNB fm = film_load(f0, p0, nb);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < C0_KGP; ++kg) {
+          float4 w;
+          RING_NEXT(ring, kg % FENERF_PF, w);
+          if (kg < KGX) {
+            acc = MFMA(w.x, in[4 * kg + 0], acc);
+            acc = MFMA(w.y, in[4 * kg + 1], acc);
+            acc = MFMA(w.z, in[4 * kg + 2], acc);
+            acc = MFMA(w.w, in[4 * kg + 3], acc);
+          } else if (GRID && kg < KGX + FENERF_E_KSTEPS / 4) {
+            const int q = kg - KGX;
+            acc = MFMA(w.x, e[4 * q + 0], acc);
+            acc = MFMA(w.y, e[4 * q + 1], acc);
+            acc = MFMA(w.z, e[4 * q + 2], acc);
+            acc = MFMA(w.w, e[4 * q + 3], acc);
+          } else if (kg == C0_KG - 1) {
+            acc = MFMA(w.x, bd0, acc);
+            acc = MFMA(w.y, bd1, acc);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        film_store(acc, fm, nb, slab);
+      }
+    }
+    // ---------------- head: rows [0,n_lab) folded label head, row n_lab sigma (consumes x of the trunk) -------
+    {
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row <= n_lab) {
+          const int ch = row < n_lab ? row : C - 1;
+          stage[m * C + ch] = acc[r] + P.consts[CONST_HEAD_BIAS + row];
+        }
+      }
+    }
+    load_act<H / 2>(in, slab);
+
+    // ---------------- colour layers 1.. ----------------
+#pragma unroll 1
+    for (int c = 1; c < n_color; ++c)
+      square_layer<H>(in, ring, fpl + (size_t)(n_geo + c) * H, ppl + (size_t)(n_geo + c) * H, slab);
+
+    // ---------------- rgb head + sigmoid ----------------
+    {
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+      if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float v = acc[r] + P.consts[CONST_RGB_BIAS + r];
+          stage[m * C + (C - 4) + r] = 1.f / (1.f + __expf(-v));
+        }
+      }
+    }
+    // ---------------- coalesced write-out of the tile's [32][C] block ----------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const long long base = tile * 32 * C;
+      const long long limit = P.P * C;
+      for (int i = lane; i < 32 * C; i += 64)
+        if (base + i < limit) P.out[base + i] = stage[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FiLM pre-pass: f' = (15 f + 30) / 2pi, p' = ((15 f + 30) b + p) / 2pi  (double, rounded once).
+// The '*15 + 30' itself is done in fp32 with separate mul and add exactly like siren.py:1510-1511.
+// ------------------------------------------------------------------------------------------------
+__global__ void film_prep_kernel(int B, int H, int n_geo, int n_color, const float* fg, const float* pg, const float* fa,
+                                 const float* pa, const float* bias /* [L][H] */, float* fp, float* pp) {
+  const int L = n_geo + n_color;
+  const long long total = (long long)B * L * H;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % H);
+    const int l = (int)((i / H) % L);
+    const long long b = i / ((long long)H * L);
+    float fr, ph;
+    if (l < n_geo) { fr = fg[(b * n_geo + l) * H + n]; ph = pg[(b * n_geo + l) * H + n]; }
+    else { fr = fa[(b * n_color + (l - n_geo)) * H + n]; ph = pa[(b * n_color + (l - n_geo)) * H + n]; }
+    const float f = __fadd_rn(__fmul_rn(fr, 15.f), 30.f);
+    const double inv2pi = 0.15915494309189533576888;
+    fp[i] = (float)((double)f * inv2pi);
+    pp[i] = (float)(((double)f * (double)bias[l * H + n] + (double)ph) * inv2pi);
+  }
+}
+
+// NCDHW -> channels-last [D][H][W][C] (C = 32): one 128-B line per voxel.
+__global__ void grid_relayout_kernel(const float* src, float* dst, int C, long long vox) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < vox * C; i += (long long)gridDim.x * blockDim.x) {
+    const long long v = i / C;
+    const int c = (int)(i % C);
+    dst[i] = src[(long long)c * vox + v];
+  }
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+                     float* fp, float* pp, void* stream) {
+  const long long total = (long long)B * m->L * m->H;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(film_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, m->H, m->n_geo, m->n_color, fg,
+                     pg, fa, pa, m->d_consts + CONST_FILM_BIAS, fp, pp);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail(e, "film_prep launch");
+}
+
+int launch_grid_relayout(const float* src, float* dst, int C, int D, int Hh, int W, void* stream) {
+  const long long vox = (long long)D * Hh * W;
+  hipLaunchKernelGGL(grid_relayout_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, src, dst, C, vox);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail(e, "grid_relayout launch");
+}
+
+template <int H, bool GRID>
+static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stream) {
+  const int stage_f4 = (32 * m->C + 3) / 4;
+  const size_t lds = (size_t)4 * ((H / 8) * 64 + stage_f4) * sizeof(float4);
+  static size_t configured = 0;  // per instantiation
+  auto kfn = siren_kernel<H, GRID>;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+    configured = lds;
+  }
+  const long long ntiles = (p.P + 31) / 32;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail(e, "siren launch");
+}
+
+int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
+  if (p.P <= 0) return FENERF_OK;
+  const bool g = m->grid_ch != 0;
+  switch (m->H) {
+    case 32: return g ? launch_siren_t<32, true>(m, p, stream) : launch_siren_t<32, false>(m, p, stream);
+    case 64: return g ? launch_siren_t<64, true>(m, p, stream) : launch_siren_t<64, false>(m, p, stream);
+    case 128: return g ? launch_siren_t<128, true>(m, p, stream) : launch_siren_t<128, false>(m, p, stream);
+    case 256: return g ? launch_siren_t<256, true>(m, p, stream) : launch_siren_t<256, false>(m, p, stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+}  // namespace fenerf

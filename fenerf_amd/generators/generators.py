@@ -1,0 +1,276 @@
+"""Implicit generators for 3-D volumes -- drop-in for the reference's generators/generators.py API
+(ImplicitGenerator3d :13-431, DoubleImplicitGenerator3d :434-910): same constructor, attributes, method
+signatures, kwargs bag (the curriculum dict is splatted into every call), return shapes and RNG draw order.
+
+What differs is everything underneath: per call the host draws the random tensors with torch (reference
+order), builds rays (origins / dirs / jittered z), runs the tiny mapping networks in
+PyTorch, and hands the rest -- coarse SIREN, compositing, importance resampling, fine SIREN, sorted merge,
+final compositing (generators.py:479-519) -- to ONE C-ABI call, fenerf_render_forward, i.e. hand-written HIP
+kernels for gfx950.  There is no PyTorch fallback for that part.
+
+Forward only in this round: methods must run under torch.no_grad() (the reference's D-steps, FID dumps and
+all inference scripts do); the G-step / inversion backward is the next row.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
+
+
+def _needs_no_grad(what):
+    if torch.is_grad_enabled():
+        raise NotImplementedError(
+            f"fenerf_amd: {what} is forward-only in this round (backward of the fused HIP pipeline is SURVEY §8f.1); "
+            "call it under torch.no_grad()")
+
+
+class _Generator3dBase(nn.Module):
+    """Shared host-side orchestration of one render (a15-a17 of SURVEY §8)."""
+
+    draws = _DEFAULT_DRAWS   # random source; tests replace it with RecordedDraws
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def _render(self, film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                hierarchical_sample, sample_dist, lock_view_dependence, kwargs, use_fill, third):
+        """film = (freq_geo, phase_geo, freq_app, phase_app) raw mapping outputs.
+        third: None | 'weights' | 'auto' (what fancy_integration would have returned third for this fill_mode).
+        Returns (pixels [B,R,C'], depth [B,R], third tensor or None, pitch, yaw)."""
+        B = film[0].shape[0]
+        dev = self.device
+        R, N = img_size * img_size, num_steps
+        d = self.draws
+        # draw order: jitter rand [B,R,N,1] -> theta randn [B,1] -> phi randn [B,1]   (volumetric_rendering.py:135,193-194)
+        origins, dirs, z_vals, pitch, yaw = sample_rays(B, N, dev, fov, (img_size, img_size), ray_start, ray_end, h_stddev,
+                                                        v_stddev, h_mean, v_mean, sample_dist, draws=d)
+        noise_std = kwargs["nerf_noise"]
+        clamp_mode = kwargs["clamp_mode"]
+        opts = _lib.composite_opts(clamp_mode, noise_std, kwargs.get("last_back", False), kwargs.get("white_back", False),
+                                   kwargs.get("black_back", False), kwargs.get("fill_mode", None) if use_fill else None,
+                                   kwargs.get("fill_color", "black"))
+        u = noise_c = None
+        if hierarchical_sample:
+            # -> coarse noise randn [B,R,N,1] (always drawn, volumetric_rendering.py:27) -> u rand [B*R,N] (:283)
+            noise_c = d.randn((B, R, N, 1), dev)
+            u = d.rand((B * R, N), dev)
+        M = 2 * N if hierarchical_sample else N
+        noise_f = d.randn((B, R, M, 1), dev)   # final composite's noise
+        use_noise = noise_std != 0
+        fill_mode = kwargs.get("fill_mode", None) if use_fill else None
+        want_w = third == "weights" or (third == "auto" and fill_mode not in ("weight", "eval_seg_padding_background", "eval_white_back"))
+        want_ws = third == "auto" and not want_w
+        nat = self.siren.native(dev)
+        rgb, depth, weights, wsum = nat.render(
+            origins, dirs, z_vals, u, noise_c.reshape(B, R, N) if (use_noise and noise_c is not None) else None,
+            noise_f.reshape(B, R, M) if use_noise else None, film[0], film[1], film[2], film[3], opts,
+            hierarchical=bool(hierarchical_sample), lock_view=bool(lock_view_dependence), want_weights=want_w, want_wsum=want_ws)
+        t = None
+        if want_w:
+            t = weights.unsqueeze(-1)
+        elif want_ws:
+            t = wsum.unsqueeze(-1).expand_as(rgb)
+        return rgb, depth, t, pitch, yaw
+
+    def _finish(self, pixels, batch_size, img_size):
+        if self.softmax_label:
+            seg, rgb = pixels[..., :-3], pixels[..., -3:]
+            seg = torch.nn.Softmax(dim=-1)(seg)
+            pixels = torch.cat([seg, rgb], dim=-1)
+        pixels = pixels.reshape((batch_size, img_size, img_size, -1))
+        return pixels.permute(0, 3, 1, 2).contiguous()
+
+
+class DoubleImplicitGenerator3d(_Generator3dBase):
+    """Two-latent generator (z_geo, z_app) -> 18 semantic logits + rgb (generators.py:434-910)."""
+
+    def __init__(self, siren, z_geo_dim, z_app_dim, output_dim, softmax_label=False, **kwargs):
+        super().__init__()
+        self.z_geo_dim = z_geo_dim
+        self.z_app_dim = z_app_dim
+        self.output_dim = output_dim
+        self.siren = siren(output_dim=self.output_dim, z_geo_dim=self.z_geo_dim, z_app_dim=self.z_app_dim, input_dim=3, device=None)
+        self.epoch = 0
+        self.step = 0
+        self.channel_dim = self.output_dim - 1
+        self.softmax_label = softmax_label
+
+    def set_device(self, device):
+        self.device = device
+        self.siren.device = device
+        self.generate_avg_frequencies()
+
+    def generate_avg_frequencies(self):
+        """Mean FiLM parameters over 10 000 random latents (generators.py:530-543); draws randn twice."""
+        z_geo = self.draws.randn((10000, self.z_geo_dim), self.siren.device)
+        z_app = self.draws.randn((10000, self.z_app_dim), self.siren.device)
+        with torch.no_grad():
+            frequencies_geo, phase_shifts_geo = self.siren.geo_mapping_network(z_geo)
+            frequencies_app, phase_shifts_app = self.siren.app_mapping_network(z_app)
+        self.avg_frequencies_geo = frequencies_geo.mean(0, keepdim=True)
+        self.avg_phase_shifts_geo = phase_shifts_geo.mean(0, keepdim=True)
+        self.avg_frequencies_app = frequencies_app.mean(0, keepdim=True)
+        self.avg_phase_shifts_app = phase_shifts_app.mean(0, keepdim=True)
+        return self.avg_frequencies_geo, self.avg_phase_shifts_geo, self.avg_frequencies_app, self.avg_phase_shifts_app
+
+    def forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
+        """-> (pixels [B, output_dim-1, S, S] in [-1,1], cat(pitch, yaw) [B,2])   (generators.py:452-527)."""
+        _needs_no_grad("DoubleImplicitGenerator3d.forward")
+        batch_size = z_app.shape[0]
+        grad_points = kwargs.get("grad_points", img_size * img_size)
+        if grad_points != img_size * img_size:
+            raise NotImplementedError("part_forward (grad on a random ray subset, generators.py:858-910) needs the backward pass")
+        fg, pg = self.siren.geo_mapping_network(z_geo)
+        fa, pa = self.siren.app_mapping_network(z_app)
+        # forward() ignores fill_mode (generators.py:519) -> C-1 channels
+        pixels, depth, _, pitch, yaw = self._render((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
+                                                    v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
+                                                    lock_view_dependence, kwargs, use_fill=False, third=None)
+        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        return pixels, torch.cat([pitch, yaw], -1)
+
+    def staged_forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                       psi=1, lock_view_dependence=False, max_batch_size=50000, depth_map=False, near_clip=0, far_clip=2,
+                       sample_dist=None, hierarchical_sample=False, **kwargs):
+        """Inference render with the truncation trick -> (pixels.cpu(), depth_map.cpu())   (generators.py:546-646).
+        max_batch_size is accepted and ignored: the fused kernel never materialises per-point activations."""
+        batch_size = z_app.shape[0]
+        self.generate_avg_frequencies()
+        with torch.no_grad():
+            raw_fg, raw_pg = self.siren.geo_mapping_network(z_geo)
+            raw_fa, raw_pa = self.siren.app_mapping_network(z_app)
+            fg = self.avg_frequencies_geo + psi * (raw_fg - self.avg_frequencies_geo)
+            pg = self.avg_phase_shifts_geo + psi * (raw_pg - self.avg_phase_shifts_geo)
+            fa = self.avg_frequencies_app + psi * (raw_fa - self.avg_frequencies_app)
+            pa = self.avg_phase_shifts_app + psi * (raw_pa - self.avg_phase_shifts_app)
+            pixels, depth, _, pitch, yaw = self._render((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
+                                                        v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
+                                                        lock_view_dependence, kwargs, use_fill=True, third=None)
+            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            pixels = self._finish(pixels, batch_size, img_size).cpu() * 2 - 1
+        return pixels, depth_map
+
+    def staged_forward_with_frequencies(self, truncated_frequencies_geo, truncated_frequencies_app, truncated_phase_shifts_geo,
+                                        truncated_phase_shifts_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev,
+                                        v_stddev, h_mean, v_mean, psi=0.7, lock_view_dependence=False, max_batch_size=50000,
+                                        depth_map=False, near_clip=0, far_clip=2, sample_dist=None, hierarchical_sample=False,
+                                        **kwargs):
+        """-> (pixels.cpu(), depth.cpu(), third.cpu()*2-1) (generators.py:649-732); `third` is weights_sum for the
+        eval_*/weight fill modes and the per-sample weights [B,M,S,S] otherwise (reference quirk)."""
+        batch_size = truncated_frequencies_app.shape[0]
+        with torch.no_grad():
+            pixels, depth, third, pitch, yaw = self._render(
+                (truncated_frequencies_geo, truncated_phase_shifts_geo, truncated_frequencies_app, truncated_phase_shifts_app),
+                img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
+                sample_dist, lock_view_dependence, kwargs, use_fill=True, third="auto")
+            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            weights_sum = third.reshape((batch_size, img_size, img_size, -1))
+            weights_sum = weights_sum.permute(0, 3, 1, 2).contiguous().cpu() * 2 - 1
+            pixels = self._finish(pixels, batch_size, img_size).cpu() * 2 - 1
+        return pixels, depth_map, weights_sum
+
+    def forward_with_frequencies(self, frequencies_geo, frequencies_app, phase_shifts_geo, phase_shifts_app, img_size, fov,
+                                 ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
+                                 sample_dist=None, lock_view_dependence=False, **kwargs):
+        """-> (pixels [B, output_dim-1, S, S], poses)   (generators.py:735-797)."""
+        _needs_no_grad("DoubleImplicitGenerator3d.forward_with_frequencies")
+        batch_size = frequencies_app.shape[0]
+        pixels, depth, _, pitch, yaw = self._render((frequencies_geo, phase_shifts_geo, frequencies_app, phase_shifts_app),
+                                                    img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
+                                                    v_mean, hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
+                                                    use_fill=False, third=None)
+        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        return pixels, torch.cat([pitch, yaw], -1)
+
+
+class ImplicitGenerator3d(_Generator3dBase):
+    """Single-latent pi-GAN generator (generators.py:13-431), used with SPATIALSIRENBASELINE (curriculum `CelebA`)."""
+
+    def __init__(self, siren, z_dim, output_dim, neural_renderer_img=None, neural_renderer_seg=None, softmax_label=False, **kwargs):
+        super().__init__()
+        if neural_renderer_img is not None or neural_renderer_seg is not None:
+            raise NotImplementedError("2-D neural renderers are outside the rendering-core scope (SURVEY §2)")
+        self.z_dim = z_dim
+        self.output_dim = output_dim
+        self.siren = siren(output_dim=self.output_dim, z_dim=self.z_dim, input_dim=3, device=None)
+        self.epoch = 0
+        self.step = 0
+        self.channel_dim = self.output_dim - 1
+        self.softmax_label = softmax_label
+        self.neural_renderer_img = None
+        self.neural_renderer_seg = None
+
+    def set_device(self, device):
+        self.device = device
+        self.siren.device = device
+        self.generate_avg_frequencies()
+
+    def generate_avg_frequencies(self):
+        """(generators.py:121-130)"""
+        z = self.draws.randn((10000, self.z_dim), self.siren.device)
+        with torch.no_grad():
+            frequencies, phase_shifts = self.siren.mapping_network(z)
+        self.avg_frequencies = frequencies.mean(0, keepdim=True)
+        self.avg_phase_shifts = phase_shifts.mean(0, keepdim=True)
+        return self.avg_frequencies, self.avg_phase_shifts
+
+    def _film(self, frequencies, phase_shifts):
+        return self.siren.split_film(frequencies, phase_shifts)
+
+    def forward(self, z, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
+                sample_dist=None, lock_view_dependence=False, **kwargs):
+        """-> (pixels [B,3,S,S], poses)   (generators.py:32-119)."""
+        _needs_no_grad("ImplicitGenerator3d.forward")
+        batch_size = z.shape[0]
+        frequencies, phase_shifts = self.siren.mapping_network(z)
+        pixels, depth, _, pitch, yaw = self._render(self._film(frequencies, phase_shifts), img_size, fov, ray_start, ray_end,
+                                                    num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
+                                                    sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
+        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        return pixels, torch.cat([pitch, yaw], -1)
+
+    def staged_forward(self, z, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, psi=1,
+                       lock_view_dependence=False, max_batch_size=50000, depth_map=False, near_clip=0, far_clip=2,
+                       sample_dist=None, hierarchical_sample=False, **kwargs):
+        """-> (pixels.cpu(), depth_map.cpu(), weights_sum.cpu()*2-1): the single-latent class returns 3 values
+        (generators.py:132-248)."""
+        batch_size = z.shape[0]
+        self.generate_avg_frequencies()
+        with torch.no_grad():
+            raw_frequencies, raw_phase_shifts = self.siren.mapping_network(z)
+            f = self.avg_frequencies + psi * (raw_frequencies - self.avg_frequencies)
+            p = self.avg_phase_shifts + psi * (raw_phase_shifts - self.avg_phase_shifts)
+            pixels, depth, third, pitch, yaw = self._render(self._film(f, p), img_size, fov, ray_start, ray_end, num_steps,
+                                                            h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
+                                                            lock_view_dependence, kwargs, use_fill=True, third="auto")
+            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            weights_sum = third.reshape((batch_size, img_size, img_size, -1)).permute(0, 3, 1, 2).contiguous().cpu() * 2 - 1
+            pixels = self._finish(pixels, batch_size, img_size) * 2 - 1   # stays on the device (generators.py:231)
+        return pixels, depth_map, weights_sum
+
+    def staged_forward_with_frequencies(self, truncated_frequencies, truncated_phase_shifts, img_size, fov, ray_start, ray_end,
+                                        num_steps, h_stddev, v_stddev, h_mean, v_mean, psi=0.7, lock_view_dependence=False,
+                                        max_batch_size=50000, depth_map=False, near_clip=0, far_clip=2, sample_dist=None,
+                                        hierarchical_sample=False, **kwargs):
+        """-> (pixels (device), depth_map.cpu()): two values for the single-latent class (generators.py:251-335)."""
+        batch_size = truncated_frequencies.shape[0]
+        with torch.no_grad():
+            pixels, depth, _, pitch, yaw = self._render(self._film(truncated_frequencies, truncated_phase_shifts), img_size,
+                                                        fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                                                        hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
+                                                        use_fill=True, third=None)
+            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        return pixels, depth_map
+
+    def forward_with_frequencies(self, frequencies, phase_shifts, img_size, fov, ray_start, ray_end, num_steps, h_stddev,
+                                 v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist=None, lock_view_dependence=False,
+                                 **kwargs):
+        """(generators.py:353-431)"""
+        _needs_no_grad("ImplicitGenerator3d.forward_with_frequencies")
+        batch_size = frequencies.shape[0]
+        pixels, depth, _, pitch, yaw = self._render(self._film(frequencies, phase_shifts), img_size, fov, ray_start, ray_end,
+                                                    num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
+                                                    sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
+        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        return pixels, torch.cat([pitch, yaw], -1)

@@ -1,0 +1,206 @@
+"""Torch-side plumbing over the C-ABI: device pointers, streams, workspaces.  No math lives here."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expected a contiguous fp32 device tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class NativeModel:
+    """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
+
+    def __init__(self, sd, spec, device):
+        self.spec = dict(spec)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % device)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            d, keep = _lib.make_desc(sd, spec)
+            _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
+        self.C = spec["output_dim"]
+        self._ws = {}
+
+    def update(self, sd):
+        with torch.cuda.device(self.device):
+            d, keep = _lib.make_desc(sd, self.spec)
+            _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fenerf_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def _workspace(self, key, nbytes):
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = buf
+        return buf
+
+    def _film(self, B, fg, pg, fa, pa):
+        H, ng, nc = self.spec["hidden_dim"], self.spec["n_geo"], self.spec["n_color"]
+        dev = self.device
+        fg, pg, fa, pa = (_f32(t, dev) for t in (fg, pg, fa, pa))
+        for t, n in ((fg, ng), (pg, ng), (fa, nc), (pa, nc)):
+            if tuple(t.shape) != (B, n * H):
+                raise ValueError(f"film parameter of shape {tuple(t.shape)}, expected {(B, n * H)}")
+        return fg, pg, fa, pa
+
+    def siren_forward(self, points, ray_dirs, fg, pg, fa, pa):
+        """[B,P,3] points (+ per-point dirs or None) -> [B,P,C]   (siren.py:1509-1530)"""
+        B, P = points.shape[0], points.shape[1]
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        points = _f32(points, self.device)
+        ray_dirs = _f32(ray_dirs, self.device) if ray_dirs is not None else None
+        out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_forward(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg),
+                                                       _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
+        return out
+
+    def siren_forward_rays(self, origins, dirs, z, fg, pg, fa, pa, lock_view=False):
+        """origins/dirs [B,R,3], z [B,R,N] -> [B,R,N,C]"""
+        B, R, N = z.shape
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        origins, dirs, z = _f32(origins, self.device), _f32(dirs, self.device), _f32(z, self.device)
+        out = torch.empty((B, R, N, self.C), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_forward_rays(self._h, B, R, N, _ptr(origins), _ptr(dirs), _ptr(z), int(lock_view),
+                                                            _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out),
+                                                            C.c_void_p(ws.data_ptr()), _stream()))
+        return out
+
+    def time_siren_rays(self, origins, dirs, z, fg, pg, fa, pa, iters=10):
+        """Average duration (ms) of the SIREN kernel alone on these rays, hipEvent-timed on the current stream."""
+        B, R, N = z.shape
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        origins, dirs, z = _f32(origins, self.device), _f32(dirs, self.device), _f32(z, self.device)
+        out = torch.empty((B, R, N, self.C), dtype=torch.float32, device=self.device)
+        ms = C.c_float(0)
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_time_rays(self._h, B, R, N, _ptr(origins), _ptr(dirs), _ptr(z), _ptr(fg), _ptr(pg),
+                                                         _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), int(iters),
+                                                         C.byref(ms), _stream()))
+        return float(ms.value)
+
+    def render(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, hierarchical=True,
+               lock_view=False, want_weights=False, want_wsum=False):
+        """The fused coarse->resample->fine->merge->composite pipeline (generators.py:479-519).
+        Returns (rgb [B,R,C'], depth [B,R], weights [B,R,M] or None, wsum [B,R] or None)."""
+        B, R, N = z_coarse.shape
+        dev = self.device
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        origins, dirs, z_coarse = _f32(origins, dev), _f32(dirs, dev), _f32(z_coarse, dev)
+        u = _f32(u, dev) if u is not None else None
+        noise_coarse = _f32(noise_coarse, dev) if noise_coarse is not None else None
+        noise_final = _f32(noise_final, dev) if noise_final is not None else None
+        M = 2 * N if hierarchical else N
+        pad = opts.fill_mode in (_lib.FILL["seg_padding_background"], _lib.FILL["eval_seg_padding_background"])
+        Cout = self.C if pad else self.C - 1
+        rgb = torch.empty((B, R, Cout), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, R), dtype=torch.float32, device=dev)
+        weights = torch.empty((B, R, M), dtype=torch.float32, device=dev) if want_weights else None
+        wsum = torch.empty((B, R), dtype=torch.float32, device=dev) if want_wsum else None
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            nbytes = l.fenerf_render_workspace_bytes(self._h, B, R, N, int(hierarchical))
+            ws = self._workspace("render", nbytes)
+            _lib.check(l.fenerf_render_forward(self._h, B, R, N, int(hierarchical), int(lock_view), _ptr(origins), _ptr(dirs),
+                                               _ptr(z_coarse), _ptr(u), _ptr(noise_coarse), _ptr(noise_final), _ptr(fg),
+                                               _ptr(pg), _ptr(fa), _ptr(pa), C.byref(opts), _ptr(rgb), _ptr(depth),
+                                               _ptr(weights), _ptr(wsum), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
+                                               _stream()))
+        return rgb, depth, weights, wsum
+
+
+# ----------------------------------------------------------------------
+# stand-alone ray-tail ops (no model needed)
+# ----------------------------------------------------------------------
+def composite(rgb_sigma, z, noise, opts, want_weights=True, want_wsum=True):
+    """fancy_integration on [..., M, C] / [..., M] device tensors -> (rgb, depth, weights, wsum)."""
+    lead = rgb_sigma.shape[:-2]
+    M, Cc = rgb_sigma.shape[-2], rgb_sigma.shape[-1]
+    dev = rgb_sigma.device
+    BR = int(np.prod(lead)) if len(lead) else 1
+    rs, zz = _f32(rgb_sigma, dev).reshape(BR, M, Cc), _f32(z, dev).reshape(BR, M)
+    nz = _f32(noise, dev).reshape(BR, M) if noise is not None else None
+    pad = opts.fill_mode in (_lib.FILL["seg_padding_background"], _lib.FILL["eval_seg_padding_background"])
+    Cout = Cc if pad else Cc - 1
+    rgb = torch.empty((BR, Cout), dtype=torch.float32, device=dev)
+    depth = torch.empty((BR,), dtype=torch.float32, device=dev)
+    w = torch.empty((BR, M), dtype=torch.float32, device=dev) if want_weights else None
+    ws = torch.empty((BR,), dtype=torch.float32, device=dev) if want_wsum else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_composite(BR, M, Cc, _ptr(rs), _ptr(zz), _ptr(nz), C.byref(opts), _ptr(rgb), _ptr(depth),
+                                               _ptr(w), _ptr(ws), _stream()))
+    return (rgb.reshape(*lead, Cout), depth.reshape(*lead), w.reshape(*lead, M) if w is not None else None,
+            ws.reshape(*lead) if ws is not None else None)
+
+
+def resample(z_coarse, coarse_weights, u):
+    """[BR,N] x3 -> fine z [BR,N]   (generators.py:489-499 + sample_pdf)"""
+    BR, N = z_coarse.shape
+    dev = z_coarse.device
+    zc, wc, uu = _f32(z_coarse, dev), _f32(coarse_weights, dev), _f32(u, dev)
+    zf = torch.empty((BR, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_resample(BR, N, _ptr(zc), _ptr(wc), _ptr(uu), _ptr(zf), _stream()))
+    return zf
+
+
+def sample_pdf(bins, weights, u):
+    """bins [R,K+1], weights [R,K], u [R,Ns] -> samples [R,Ns]   (sample_pdf, reference shape)"""
+    R, K = weights.shape
+    Ns = u.shape[1]
+    dev = bins.device
+    b, w, uu = _f32(bins, dev), _f32(weights, dev), _f32(u, dev)
+    out = torch.empty((R, Ns), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_sample_pdf(R, K, Ns, _ptr(b), _ptr(w), _ptr(uu), _ptr(out), _stream()))
+    return out
+
+
+def merge_composite(fine, coarse, z_fine, z_coarse, noise, opts, want_weights=True, want_wsum=True, want_z=True):
+    """[BR,N,C] x2, [BR,N] x2 -> (rgb, depth, weights[BR,2N], wsum, z_sorted[BR,2N])   (generators.py:508-519)"""
+    BR, N, Cc = fine.shape
+    dev = fine.device
+    f, c, zf, zc = _f32(fine, dev), _f32(coarse, dev), _f32(z_fine, dev), _f32(z_coarse, dev)
+    nz = _f32(noise, dev).reshape(BR, 2 * N) if noise is not None else None
+    pad = opts.fill_mode in (_lib.FILL["seg_padding_background"], _lib.FILL["eval_seg_padding_background"])
+    Cout = Cc if pad else Cc - 1
+    rgb = torch.empty((BR, Cout), dtype=torch.float32, device=dev)
+    depth = torch.empty((BR,), dtype=torch.float32, device=dev)
+    w = torch.empty((BR, 2 * N), dtype=torch.float32, device=dev) if want_weights else None
+    ws = torch.empty((BR,), dtype=torch.float32, device=dev) if want_wsum else None
+    zs = torch.empty((BR, 2 * N), dtype=torch.float32, device=dev) if want_z else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_merge_composite(BR, N, Cc, _ptr(f), _ptr(c), _ptr(zf), _ptr(zc), _ptr(nz), C.byref(opts),
+                                                     _ptr(rgb), _ptr(depth), _ptr(w), _ptr(ws), _ptr(zs), _stream()))
+    return rgb, depth, w, ws, zs

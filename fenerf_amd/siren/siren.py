@@ -1,0 +1,240 @@
+"""SIREN radiance-field heads -- drop-in for the reference's siren/siren.py classes that are reachable from
+its curriculums.  The nn.Module only OWNS the parameters (same attribute / state_dict names as the reference,
+so pickled reference checkpoints load after fenerf_amd.compat.install_aliases()); evaluation is a single
+fused HIP kernel behind fenerf_siren_forward (include/fenerf.h).  The mapping networks (z -> FiLM
+frequencies / phases; per image, tiny) stay in PyTorch.
+
+reference: FiLMLayer siren.py:113-123, CustomMappingNetwork :82-102, frequency_init :104-110,
+UniformBoxWarp :181-187, SPATIALSIRENBASELINE :189-244, SIRENBASELINESEMANTICDISENTANGLE :1163-1229,
+TextureEmbeddingPiGAN128SEMANTICDISENTANGLE :1451-1530 (+256 :1533, _DIM_96 :1541).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import native
+
+
+def kaiming_leaky_init(m):
+    if m.__class__.__name__.find("Linear") != -1:
+        torch.nn.init.kaiming_normal_(m.weight, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+
+
+def frequency_init(freq):
+    def init(m):
+        with torch.no_grad():
+            if isinstance(m, nn.Linear):
+                num_input = m.weight.size(-1)
+                m.weight.uniform_(-np.sqrt(6 / num_input) / freq, np.sqrt(6 / num_input) / freq)
+    return init
+
+
+def first_layer_film_sine_init(m):
+    with torch.no_grad():
+        if isinstance(m, nn.Linear):
+            num_input = m.weight.size(-1)
+            m.weight.uniform_(-1 / num_input, 1 / num_input)
+
+
+def modified_first_sine_init(m):
+    with torch.no_grad():
+        if isinstance(m, nn.Linear):
+            m.weight.uniform_(-1 / 3, 1 / 3)
+
+
+class CustomMappingNetwork(nn.Module):
+    """z -> (frequencies, phase_shifts); stays PyTorch (siren.py:82-102)."""
+
+    def __init__(self, z_dim, map_hidden_dim, map_output_dim, n_blocks=3):
+        super().__init__()
+        layers = [nn.Linear(z_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True)]
+        for _ in range(n_blocks):
+            layers += [nn.Linear(map_hidden_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True)]
+        layers.append(nn.Linear(map_hidden_dim, map_output_dim))
+        self.network = nn.Sequential(*layers)
+        self.network.apply(kaiming_leaky_init)
+        with torch.no_grad():
+            self.network[-1].weight *= 0.25
+
+    def forward(self, z):
+        out = self.network(z)
+        half = out.shape[-1] // 2
+        return out[..., :half], out[..., half:]
+
+
+class FiLMLayer(nn.Module):
+    """Parameter holder for one FiLM layer (the sin(freq*(Wx+b)+phase) itself runs fused on the GPU)."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.layer = nn.Linear(input_dim, hidden_dim)
+
+
+class UniformBoxWarp(nn.Module):
+    def __init__(self, sidelength):
+        super().__init__()
+        self.scale_factor = 2 / sidelength
+
+    def forward(self, coordinates):
+        return coordinates * self.scale_factor
+
+
+class _NativeSiren(nn.Module):
+    """Shared machinery: exports parameters to the native model, re-packs when they change."""
+
+    KIND = None
+    N_LABEL_LAYERS = 0
+    GRID_CH = 0
+
+    def _spec(self):
+        H = self.hidden_dim
+        n_color = 1 if self.KIND == "spatial" else len(self.color_layer_sine)
+        return dict(kind=self.KIND, hidden_dim=H, n_geo=len(self.network), n_color=n_color, grid_ch=self.GRID_CH,
+                    n_label_layers=self.N_LABEL_LAYERS, output_dim=self.output_dim)
+
+    def _render_params(self):
+        return [p for n, p in self.named_parameters() if "mapping_network" not in n]
+
+    def _state_numpy(self):
+        return {n: p.detach().to("cpu", torch.float32).contiguous().numpy() for n, p in self.named_parameters()
+                if "mapping_network" not in n}
+
+    def native(self, device=None):
+        """The FenerfModel for the current parameter values on `device` (re-packed lazily after updates)."""
+        params = self._render_params()
+        device = torch.device(device if device is not None else params[0].device)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        nat = self.__dict__.get("_native_model")
+        if nat is None or nat.device != device:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device)
+            self.__dict__["_native_model"] = nat
+        elif self.__dict__.get("_native_version") != ver:
+            nat.update(self._state_numpy())
+        self.__dict__["_native_version"] = ver
+        return nat
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_native_model", None)
+        st.pop("_native_version", None)
+        return st
+
+
+class _DoubleLatentSiren(_NativeSiren):
+    def forward(self, input, z_geo, z_app, ray_directions, **kwargs):
+        fg, pg = self.geo_mapping_network(z_geo)
+        fa, pa = self.app_mapping_network(z_app)
+        return self.forward_with_frequencies_phase_shifts(input, fg, fa, pg, pa, ray_directions, **kwargs)
+
+    def forward_with_frequencies_phase_shifts(self, input, frequencies_geo, frequencies_app, phase_shifts_geo,
+                                              phase_shifts_app, ray_directions, **kwargs):
+        """[B,P,3] points, [B,P,3] dirs -> [B,P,output_dim] = [labels | rgb | sigma]   (siren.py:1509-1530)"""
+        if torch.is_grad_enabled() and (input.requires_grad or frequencies_geo.requires_grad or
+                                        any(p.requires_grad for p in self._render_params())):
+            _needs_backward()
+        return self.native(input.device).siren_forward(input, ray_directions, frequencies_geo, phase_shifts_geo,
+                                                       frequencies_app, phase_shifts_app)
+
+
+def _needs_backward():
+    raise NotImplementedError(
+        "fenerf_amd: the fused HIP pipeline is forward-only in this round (SURVEY.md §8f.1: backward is the next "
+        "row); call under torch.no_grad() (both D-steps, FID dumps, rendering)")
+
+
+class SIRENBASELINESEMANTICDISENTANGLE(_DoubleLatentSiren):
+    """README 'w/o latent grid' model (siren.py:1163-1229)."""
+    KIND, N_LABEL_LAYERS, GRID_CH = "baseline", 2, 0
+
+    def __init__(self, input_dim=2, z_geo_dim=100, z_app_dim=100, hidden_dim=256, output_dim=1, device=None):
+        super().__init__()
+        self.device, self.input_dim, self.z_geo_dim, self.z_app_dim = device, input_dim, z_geo_dim, z_app_dim
+        self.hidden_dim, self.output_dim = hidden_dim, output_dim
+        self.network = nn.ModuleList([FiLMLayer(3, hidden_dim)] + [FiLMLayer(hidden_dim, hidden_dim) for _ in range(7)])
+        self.final_layer = nn.Linear(hidden_dim, 1)
+        self.color_layer_sine = nn.ModuleList([FiLMLayer(hidden_dim + 3, hidden_dim), FiLMLayer(hidden_dim, hidden_dim),
+                                               FiLMLayer(hidden_dim, hidden_dim)])
+        self.color_layer_linear = nn.Sequential(nn.Linear(hidden_dim, 3))
+        self.geo_mapping_network = CustomMappingNetwork(z_geo_dim, 256, len(self.network) * hidden_dim * 2)
+        self.app_mapping_network = CustomMappingNetwork(z_app_dim, 256, len(self.color_layer_sine) * hidden_dim * 2)
+        self.label_layer_linear = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, self.output_dim - 4))
+        for mod in (self.network, self.final_layer, self.color_layer_sine, self.color_layer_linear, self.label_layer_linear):
+            mod.apply(frequency_init(25))
+        self.network[0].apply(first_layer_film_sine_init)
+        self.gridwarper = UniformBoxWarp(0.24)
+
+
+class TextureEmbeddingPiGAN128SEMANTICDISENTANGLE(_DoubleLatentSiren):
+    """FENeRF 'w/ latent grid' model: 32-channel 3-D feature grid feeding the colour branch (siren.py:1451-1530)."""
+    KIND, N_LABEL_LAYERS, GRID_CH = "texture", 3, 32
+
+    def __init__(self, input_dim=2, z_geo_dim=100, z_app_dim=100, hidden_dim=128, output_dim=1, device=None):
+        super().__init__()
+        self.device, self.input_dim, self.z_geo_dim, self.z_app_dim = device, input_dim, z_geo_dim, z_app_dim
+        self.hidden_dim, self.output_dim = hidden_dim, output_dim
+        self.network = nn.ModuleList([FiLMLayer(3, hidden_dim)] + [FiLMLayer(hidden_dim, hidden_dim) for _ in range(7)])
+        self.final_layer = nn.Linear(hidden_dim, 1)
+        self.color_layer_sine = nn.ModuleList([FiLMLayer(hidden_dim + 32 + 3, hidden_dim), FiLMLayer(hidden_dim, hidden_dim),
+                                               FiLMLayer(hidden_dim, hidden_dim)])
+        self.color_layer_linear = nn.Sequential(nn.Linear(hidden_dim, 3))
+        self.geo_mapping_network = CustomMappingNetwork(z_geo_dim, 256, len(self.network) * hidden_dim * 2)
+        self.app_mapping_network = CustomMappingNetwork(z_app_dim, 256, len(self.color_layer_sine) * hidden_dim * 2)
+        self.label_layer_linear = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, hidden_dim),
+                                                nn.Linear(hidden_dim, self.output_dim - 4))
+        for mod in (self.network, self.final_layer, self.color_layer_sine, self.color_layer_linear, self.label_layer_linear):
+            mod.apply(frequency_init(25))
+        self.network[0].apply(modified_first_sine_init)
+        self.spatial_embeddings = nn.Parameter(torch.randn(1, 32, 96, 96, 96) * 0.01)
+        self.gridwarper = UniformBoxWarp(0.24)
+
+
+class TextureEmbeddingPiGAN256SEMANTICDISENTANGLE(TextureEmbeddingPiGAN128SEMANTICDISENTANGLE):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs, hidden_dim=256)
+        self.spatial_embeddings = nn.Parameter(torch.randn(1, 32, 64, 64, 64) * 0.1)
+
+
+class TextureEmbeddingPiGAN256SEMANTICDISENTANGLE_DIM_96(TextureEmbeddingPiGAN128SEMANTICDISENTANGLE):
+    """The model of curriculum CelebA_double_semantic_texture_embedding_256_dim_96 (curriculums.py:159): H=256, 96^3 grid."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs, hidden_dim=256)
+        self.spatial_embeddings = nn.Parameter(torch.randn(1, 32, 96, 96, 96) * 0.1)
+
+
+class SPATIALSIRENBASELINE(_NativeSiren):
+    """Single-latent pi-GAN head, rgb+sigma (siren.py:189-244); curriculum `CelebA`."""
+    KIND, N_LABEL_LAYERS, GRID_CH = "spatial", 0, 0
+
+    def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
+        super().__init__()
+        self.device, self.input_dim, self.z_dim = device, input_dim, z_dim
+        self.hidden_dim = hidden_dim
+        self.output_dim = 4  # the reference stores output_dim but always emits [rgb | sigma] (siren.py:244)
+        self.network = nn.ModuleList([FiLMLayer(3, hidden_dim)] + [FiLMLayer(hidden_dim, hidden_dim) for _ in range(7)])
+        self.final_layer = nn.Linear(hidden_dim, 1)
+        self.color_layer_sine = FiLMLayer(hidden_dim + 3, hidden_dim)
+        self.color_layer_linear = nn.Sequential(nn.Linear(hidden_dim, 3))
+        self.mapping_network = CustomMappingNetwork(z_dim, 256, (len(self.network) + 1) * hidden_dim * 2)
+        for mod in (self.network, self.final_layer, self.color_layer_sine, self.color_layer_linear):
+            mod.apply(frequency_init(25))
+        self.network[0].apply(first_layer_film_sine_init)
+        self.gridwarper = UniformBoxWarp(0.24)
+
+    def forward(self, input, z, ray_directions, **kwargs):
+        frequencies, phase_shifts = self.mapping_network(z)
+        return self.forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
+
+    def split_film(self, frequencies, phase_shifts):
+        """[B, 9H] -> geo [B, 8H] + colour [B, H] (the last H, siren.py:241)."""
+        H = self.hidden_dim
+        n = len(self.network) * H
+        return (frequencies[..., :n].contiguous(), phase_shifts[..., :n].contiguous(),
+                frequencies[..., -H:].contiguous(), phase_shifts[..., -H:].contiguous())
+
+    def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
+        if torch.is_grad_enabled() and (input.requires_grad or frequencies.requires_grad or
+                                        any(p.requires_grad for p in self._render_params())):
+            _needs_backward()
+        fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
+        return self.native(input.device).siren_forward(input, ray_directions, fg, pg, fa, pa)

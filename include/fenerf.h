@@ -1,0 +1,179 @@
+/*
+ * fenerf.h -- C-ABI of the MI355X-native volumetric rendering core (libfenerf_hip.so).
+ *
+ * The reference (MrTornado24/FENeRF) has NO FFI on this path: the boundary today is plain Python
+ * method calls on torch tensors.  Each entry point below names the reference code it replaces
+ * (file:line under /root/reference).  Conventions:
+ *   - plain C, int status return: 0 = ok, <0 = FENERF_E_* ; fenerf_last_error() gives a message
+ *     (thread-local).  No exceptions cross the boundary, no torch types in any signature.
+ *   - every pointer marked [dev] is a DEVICE pointer owned by the caller (e.g. a torch allocation),
+ *     contiguous fp32 unless noted; [host] pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it,
+ *     nothing synchronises unless stated.
+ *   - all randomness (stratified jitter, importance-sampling u, sigma noise, camera pose) is drawn by the
+ *     caller and passed in: the library is deterministic.
+ *   - a FenerfModel is immutable after create/update and may be used from several threads/streams.
+ */
+#ifndef FENERF_H_
+#define FENERF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FENERF_ABI_VERSION 1
+
+enum {
+  FENERF_OK = 0,
+  FENERF_E_INVALID = -1,     /* bad argument / unsupported shape */
+  FENERF_E_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
+  FENERF_E_NOMEM = -3,
+  FENERF_E_UNSUPPORTED = -4, /* model variant not built (hidden_dim not in {32,64,128,256}, ...) */
+  FENERF_E_CLAMP_MODE = -5   /* reference raises TypeError("Need to choose clamp mode"), volumetric_rendering.py:34 */
+};
+
+/* clamp_mode of fancy_integration (volumetric_rendering.py:29-34) */
+enum { FENERF_CLAMP_RELU = 1, FENERF_CLAMP_SOFTPLUS = 2 };
+
+/* fill_mode of fancy_integration (volumetric_rendering.py:52-104) */
+enum {
+  FENERF_FILL_NONE = 0,
+  FENERF_FILL_WEIGHT = 1,                      /* 'weight'                       -> third = weights_sum */
+  FENERF_FILL_SEG_PADDING_BACKGROUND = 2,      /* 'seg_padding_background'       -> third = weights     */
+  FENERF_FILL_EVAL_SEG_PADDING_BACKGROUND = 3, /* 'eval_seg_padding_background'  -> third = weights_sum */
+  FENERF_FILL_EVAL_WHITE_BACK = 4              /* 'eval_white_back' (3-channel models)                 */
+};
+
+/* Radiance-field description: the per-point network of siren/siren.py.  All weight pointers are
+ * [host], fp32, in torch nn.Linear layout weight[out][in], bias[out].
+ *   TextureEmbeddingPiGAN{128,256}SEMANTICDISENTANGLE(_DIM_96)  siren.py:1451-1546 : grid_ch=32, n_color=3, n_label_layers=3
+ *   SIRENBASELINESEMANTICDISENTANGLE                             siren.py:1163-1229 : grid_ch=0,  n_color=3, n_label_layers=2
+ *   SPATIALSIRENBASELINE                                         siren.py:189-244   : grid_ch=0,  n_color=1, n_label_layers=0, output_dim=4
+ */
+#define FENERF_MAX_GEO 8
+#define FENERF_MAX_COLOR 4
+#define FENERF_MAX_LABEL_LAYERS 3
+
+typedef struct FenerfModelDesc {
+  int32_t abi_version;      /* FENERF_ABI_VERSION */
+  int32_t hidden_dim;       /* H in {32,64,128,256} */
+  int32_t n_geo;            /* FiLM layers of the density trunk (8) */
+  int32_t n_color;          /* FiLM layers of the colour branch (3, or 1) */
+  int32_t n_label_layers;   /* plain Linear layers of the semantic head (3, 2 or 0); NO activation between them */
+  int32_t output_dim;       /* 22 = 18 labels + rgb + sigma ; 4 = rgb + sigma */
+  int32_t grid_ch;          /* 32 or 0 */
+  int32_t grid_d, grid_h, grid_w; /* spatial_embeddings is [1, grid_ch, D, H, W] (NCDHW, as torch stores it) */
+  float box_scale;          /* UniformBoxWarp scale 2/0.24 (siren.py:181-187) */
+  const float* geo_w[FENERF_MAX_GEO];   const float* geo_b[FENERF_MAX_GEO];     /* network[i].layer       */
+  const float* color_w[FENERF_MAX_COLOR]; const float* color_b[FENERF_MAX_COLOR]; /* color_layer_sine[i].layer ; [0] has in = 3 + grid_ch + H, columns [dir | grid feats | x] */
+  const float* label_w[FENERF_MAX_LABEL_LAYERS]; const float* label_b[FENERF_MAX_LABEL_LAYERS]; /* label_layer_linear[i] */
+  const float* sigma_w; const float* sigma_b;   /* final_layer         [1][H]  */
+  const float* rgb_w;   const float* rgb_b;     /* color_layer_linear[0] [3][H]  */
+  const float* grid;        /* [host] spatial_embeddings or NULL */
+} FenerfModelDesc;
+
+typedef struct FenerfModel FenerfModel;
+
+/* per-call compositing options = the kwargs fancy_integration reads (volumetric_rendering.py:18) */
+typedef struct FenerfCompositeOpts {
+  int32_t clamp_mode;   /* FENERF_CLAMP_* ; 0 -> FENERF_E_CLAMP_MODE */
+  float noise_std;      /* multiplies the caller-drawn N(0,1) noise (`nerf_noise`) */
+  int32_t last_back, white_back, black_back;
+  int32_t fill_mode;    /* FENERF_FILL_* */
+  float fill_value;     /* colour written to filled pixels: black 0, white 1, grey 0.5, light_grey 0.81 */
+  int32_t fill_enabled; /* 0 when fill_color is none of the four names (reference then pads channel 0 but does not fill) */
+} FenerfCompositeOpts;
+
+const char* fenerf_last_error(void);
+int fenerf_abi_version(void);
+
+/* Packs (host side, no GPU needed) the weights of `desc` into the kernel's streaming layout; used by
+ * fenerf_model_create and exposed for layout tests.  *blob is malloc'd, free with fenerf_free_host. */
+int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats,
+                             float** consts, size_t* n_consts);
+void fenerf_free_host(void* p);
+
+/* replaces: constructing the siren nn.Module + .to(device)  (generators/generators.py:440) */
+int fenerf_model_create(const FenerfModelDesc* desc, FenerfModel** out);
+/* replaces: optimizer.step() mutating the nn.Module in place -- re-packs weights (and the grid if non-NULL) */
+int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* desc, void* stream);
+void fenerf_model_destroy(FenerfModel* m);
+
+/* Bytes of [dev] scratch the FiLM pre-pass needs for a batch of B images. */
+size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B);
+
+/* replaces: <siren>.forward_with_frequencies_phase_shifts  (siren.py:1509-1530 / :1210-1229 / :227-244),
+ *           incl. UniformBoxWarp (:181-187), sample_from_3dgrid (:314-330) and FiLMLayer (:113-123).
+ * points [B,P,3], ray_dirs [B,P,3] (NULL = lock_view_dependence, i.e. (0,0,-1): generators.py:474-476),
+ * freq/phase = RAW mapping-network outputs (the '*15+30' is applied inside): freq_geo/phase_geo [B, n_geo*H],
+ * freq_app/phase_app [B, n_color*H].  out [B,P,output_dim] = [labels | rgb | sigma]. */
+int fenerf_siren_forward(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                         const float* freq_geo, const float* phase_geo, const float* freq_app,
+                         const float* phase_app, float* out, void* film_ws, void* stream);
+
+/* Same network evaluated on points generated in-kernel from rays: point (b,r,k) = origins[b,r] + dirs[b,r]*z[b,r,k]
+ * (generators.py:504 for the fine pass; the coarse pass of the reference transforms camera-space points
+ * instead, volumetric_rendering.py:160 -- equal up to fp32 rounding).  lock_view: use (0,0,-1) as view dir. */
+int fenerf_siren_forward_rays(const FenerfModel* m, int B, int R, int N, const float* origins, const float* dirs,
+                              const float* z, int lock_view, const float* freq_geo, const float* phase_geo,
+                              const float* freq_app, const float* phase_app, float* out, void* film_ws,
+                              void* stream);
+
+/* Measurement hook (bench.py roofline leg; replaces nothing): runs the FiLM pre-pass once, then `iters` back-to-back
+ * launches of ONLY the SIREN kernel of fenerf_siren_forward_rays, bracketed by hipEvents recorded on `stream`;
+ * synchronises and returns the average kernel duration in milliseconds. */
+int fenerf_siren_time_rays(const FenerfModel* m, int B, int R, int N, const float* origins, const float* dirs,
+                           const float* z, const float* freq_geo, const float* phase_geo, const float* freq_app,
+                           const float* phase_app, float* out, void* film_ws, int iters, float* avg_ms, void* stream);
+
+/* replaces: fancy_integration (volumetric_rendering.py:18-106).
+ * rgb_sigma [BR, M, C], z [BR, M], noise [BR, M] N(0,1) draws or NULL.
+ * out_rgb [BR, C-1] (or [BR, C] for the two seg-padding fill modes), out_depth [BR],
+ * out_weights [BR, M] or NULL, out_wsum [BR] or NULL. */
+int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma, const float* z, const float* noise,
+                     const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, float* out_weights,
+                     float* out_wsum, void* stream);
+
+/* replaces: the importance-resampling block generators.py:486-499 + sample_pdf (volumetric_rendering.py:259-300):
+ * weights+1e-5, z_mid, sample_pdf(z_mid, w[:,1:-1], N, det=False) with the caller's u ~ U[0,1) [BR, N].
+ * z_coarse [BR,N], coarse_weights [BR,N] (fancy_integration's 3rd output) -> z_fine [BR,N] (unsorted). */
+int fenerf_resample(int64_t BR, int N, const float* z_coarse, const float* coarse_weights, const float* u,
+                    float* z_fine, void* stream);
+
+/* replaces: sample_pdf itself (volumetric_rendering.py:259-300) in its reference shape: bins [BR,K+1], weights [BR,K]
+ * (the function adds eps=1e-5), u [BR,n_importance] -> samples [BR,n_importance]. */
+int fenerf_sample_pdf(int64_t BR, int K, int n_importance, const float* bins, const float* weights, const float* u,
+                      float* samples, void* stream);
+
+/* replaces: cat([fine, coarse]) -> torch.sort(z) -> gather -> fancy_integration (generators.py:508-519):
+ * merges without materialising the sorted [BR,2N,C] tensor.  fine/coarse [BR,N,C], z_* [BR,N], noise [BR,2N] or NULL
+ * (indexed by SORTED position, like the reference's noise tensor).  out_weights [BR,2N] in sorted order or NULL;
+ * out_z_sorted [BR,2N] or NULL. */
+int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const float* coarse, const float* z_fine,
+                           const float* z_coarse, const float* noise, const FenerfCompositeOpts* opts,
+                           float* out_rgb, float* out_depth, float* out_weights, float* out_wsum,
+                           float* out_z_sorted, void* stream);
+
+/* Bytes of [dev] scratch fenerf_render_forward needs. */
+size_t fenerf_render_workspace_bytes(const FenerfModel* m, int B, int R, int N, int hierarchical);
+
+/* replaces: the body of DoubleImplicitGenerator3d.forward / staged_forward / *_with_frequencies after the rays
+ * exist (generators.py:479-519, :583-637, :666-724, :753-791) = coarse SIREN -> composite -> resample ->
+ * fine SIREN -> merge -> composite, for B images of R rays with N coarse (+N fine) samples.
+ * origins/dirs [B,R,3] world space, z_coarse [B,R,N] (already jittered), u [B*R,N], noise_coarse [B,R,N] / noise_final
+ * [B,R,2N or N] (NULL when nerf_noise == 0).  Outputs as fenerf_merge_composite.  `opts` applies to the FINAL
+ * composite; the coarse one uses clamp_mode + noise_std only, like the reference. */
+int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, int hierarchical, int lock_view,
+                          const float* origins, const float* dirs, const float* z_coarse, const float* u,
+                          const float* noise_coarse, const float* noise_final, const float* freq_geo,
+                          const float* phase_geo, const float* freq_app, const float* phase_app,
+                          const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, float* out_weights,
+                          float* out_wsum, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FENERF_H_ */

@@ -1,0 +1,393 @@
+"""GPU parity tests (-m gpu): every call goes through the C-ABI (libfenerf_hip.so) on cuda:0 and is checked
+against (a) golden vectors captured from the reference and (b) the numpy oracle on the same seeded inputs.
+
+Tolerances (north_star: <= 1e-3 max-abs RGB vs the reference CPU path, exact argmax semantics):
+  SIREN outputs (teacher-forced points)   rgb <= 1e-4, labels <= 1e-4 abs + 1e-4 rel, sigma <= 2e-4 * sigma_gain scale
+  composite / resample / merge            <= 1e-5 (pure fp32 re-association)
+  end to end                              <= 1e-3 on every pixel whose |weights_sum - 0.9| is not within rounding of the
+                                          fill threshold; the count of excluded pixels is asserted small and reported.
+"""
+import ast
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import kwargs_from_golden, load_golden, spec_from_golden
+from fenerf_amd import _lib, native, procedural as proc
+from fenerf_amd.generators import generators as G
+from fenerf_amd.generators import volumetric_rendering as VR
+from fenerf_amd.siren import siren as S
+from oracle import fenerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+@functools.lru_cache(maxsize=None)
+def _native_for(name):
+    g = load_golden(name)
+    spec = spec_from_golden(g)
+    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]), with_mapping=False)
+    return native.NativeModel(sd, spec, DEV), spec, sd
+
+
+def _film(g, spec):
+    f = proc.film_params(spec, int(g["meta_B"]), seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]))
+    return f, tuple(T(f[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+
+
+def _report(tag, got, ref):
+    d = np.abs(got - ref)
+    print(f"[parity] {tag}: max|err| rgb {d[..., -4:-1].max():.3e}  sigma {d[..., -1].max():.3e}  "
+          f"labels {d[..., :-4].max() if got.shape[-1] > 4 else 0:.3e}  (|sigma| max {np.abs(ref[..., -1]).max():.3g})")
+
+
+# ---------------------------------------------------------------------------------------------------
+# loaded native code is the product path
+# ---------------------------------------------------------------------------------------------------
+def test_native_library_is_loaded():
+    l = _lib.lib()
+    assert l.fenerf_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libfenerf_hip.so" in maps
+
+
+# ---------------------------------------------------------------------------------------------------
+# a8-a12: SIREN kernel vs reference outputs (teacher-forced points)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n12",
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
+def test_siren_forward_vs_reference(name):
+    g = load_golden(name)
+    nat, spec, sd = _native_for(name)
+    film, tf = _film(g, spec)
+    B, R, N = g["st_z_coarse"].shape[:3]
+    pts = g["st_points"].reshape(B, R * N, 3)
+    dirs = np.broadcast_to(g["st_dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
+    out = N_(nat.siren_forward(T(pts), T(dirs), *tf))
+    ref = g["st_siren_coarse"]
+    _report(name + " coarse vs reference", out, ref)
+    gain = max(1.0, float(g["meta_sigma_gain"]))
+    np.testing.assert_allclose(out[..., -4:-1], ref[..., -4:-1], atol=1e-4)
+    np.testing.assert_allclose(out[..., :-4], ref[..., :-4], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(out[..., -1], ref[..., -1], atol=2e-4 * gain / 10 + 1e-4, rtol=2e-4)
+    # fine points (explicit) too, and the fp64 oracle as a tighter arbiter on rgb
+    fo = N_(nat.siren_forward(T(g["st_fine_points"]), T(dirs), *tf))
+    _report(name + " fine vs reference", fo, g["st_siren_fine"])
+    np.testing.assert_allclose(fo[..., -4:-1], g["st_siren_fine"][..., -4:-1], atol=1e-4)
+    o64 = O.siren_forward(sd, spec, pts[:, :512], dirs[:, :512], film["freq_geo"], film["phase_geo"], film["freq_app"],
+                          film["phase_app"], dtype=np.float64)
+    _report(name + " vs fp64 oracle", out[:, :512], o64)
+    np.testing.assert_allclose(out[:, :512, -4:-1], o64[..., -4:-1], atol=5e-5)
+
+
+def test_siren_rays_mode_lock_view_and_ragged_tiles():
+    """points generated in-kernel from (o, d, z); lock_view_dependence; P not a multiple of the 32-point tile;
+    tiles straddling image boundaries; tile-independence (bit-exact sub-batch)."""
+    g = load_golden("tiny_texture_fwd")
+    nat, spec, sd = _native_for("tiny_texture_fwd")
+    film, tf = _film(g, spec)
+    B, R, N = g["st_z_coarse"].shape[:3]
+    o, d, z = T(g["st_origins"]), T(g["st_dirs"]), T(g["st_z_coarse"][..., 0])
+    out = N_(nat.siren_forward_rays(o, d, z, *tf))
+    _report("rays mode vs reference", out.reshape(B, R * N, -1), g["st_siren_coarse"])
+    np.testing.assert_allclose(out.reshape(B, R * N, -1)[..., -4:-1], g["st_siren_coarse"][..., -4:-1], atol=2e-4)
+    # ragged: 5 rays x 6 samples = 30 points per image (tile of 32 straddles the two images)
+    o5, d5, z5 = o[:, :5].contiguous(), d[:, :5].contiguous(), z[:, :5].contiguous()
+    sub = N_(nat.siren_forward_rays(o5, d5, z5, *tf))
+    assert np.array_equal(sub, out[:, :5]), "per-point results must not depend on tiling"
+    # explicit points == rays with identical inputs
+    pts = (o[:, :, None, :] + d[:, :, None, :] * z[..., None]).reshape(B, R * N, 3)
+    dd = d[:, :, None, :].expand(B, R, N, 3).reshape(B, R * N, 3).contiguous()
+    ep = N_(nat.siren_forward(pts.contiguous(), dd, *tf))
+    np.testing.assert_allclose(ep, out.reshape(B, R * N, -1), atol=2e-5)
+    # lock_view_dependence: dirs := (0,0,-1)   (generators.py:474-476)
+    lk = N_(nat.siren_forward_rays(o, d, z, *tf, lock_view=True))
+    lock_dirs = np.zeros((B, R * N, 3), np.float32)
+    lock_dirs[..., -1] = -1
+    ref = O.siren_forward(sd, spec, N_(pts), lock_dirs, film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    np.testing.assert_allclose(lk.reshape(B, R * N, -1)[..., -4:-1], ref[..., -4:-1], atol=2e-4)
+    lk2 = N_(nat.siren_forward(pts.contiguous(), None, *tf))
+    np.testing.assert_allclose(lk2, lk.reshape(B, R * N, -1), atol=2e-5)
+    # sigma and labels do not depend on the view direction or the grid
+    np.testing.assert_array_equal(lk[..., -1], out[..., -1])
+    # empty input
+    e = nat.siren_forward(torch.empty((2, 0, 3), device=DEV), torch.empty((2, 0, 3), device=DEV), *tf)
+    assert e.shape == (2, 0, 22)
+
+
+def test_siren_single_latent_spatial_model():
+    spec = proc.model_spec("spatial", hidden_dim=64, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=21, sigma_gain=100.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-0.12, 0.12, (2, 77, 3)).astype(np.float32)
+    dirs = rng.normal(size=(2, 77, 3)).astype(np.float32)
+    f = proc.normal("f9", (2, 9 * 64), 0.4, 21)
+    p = proc.normal("p9", (2, 9 * 64), 0.4, 21)
+    out = N_(nat.siren_forward(T(pts), T(dirs), T(f[:, :512]), T(p[:, :512]), T(f[:, -64:]), T(p[:, -64:])))
+    ref = O.siren_forward(sd, spec, pts, dirs, f, p)
+    np.testing.assert_allclose(out[..., :3], ref[..., :3], atol=1e-4)
+    np.testing.assert_allclose(out[..., 3], ref[..., 3], atol=2e-3, rtol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a13: fancy_integration -- every flag combination the reference's own golden block covers
+# ---------------------------------------------------------------------------------------------------
+def test_composite_variants_vs_reference():
+    g = load_golden("integration_variants")
+    rs, z = T(g["rgb_sigma"]), T(g["z_vals"])
+    worst = 0.0
+    for i in range(int(g["n_variants"])):
+        kw = ast.literal_eval(str(g[f"v{i}_kw"]))
+        draws = VR.RecordedDraws([g[f"v{i}_noise"]])
+        rgb, depth, third = VR.fancy_integration(rs, z, DEV, draws=draws, **kw)
+        for a, b in ((rgb, g[f"v{i}_rgb"]), (depth, g[f"v{i}_depth"]), (third, g[f"v{i}_third"])):
+            err = np.abs(N_(a) - b).max()
+            worst = max(worst, err)
+            assert N_(a).shape == b.shape and err < 1e-5, (kw, err)
+    print(f"[parity] composite: {int(g['n_variants'])} variants, worst max|err| {worst:.3e}")
+    rgb, depth, third = VR.fancy_integration(T(g["ewb_rgb_sigma"]), z, DEV, noise_std=0.0, clamp_mode="relu", fill_mode="eval_white_back")
+    np.testing.assert_allclose(N_(rgb), g["ewb_rgb"], atol=1e-5)
+    np.testing.assert_allclose(N_(third), g["ewb_third"], atol=1e-5)
+    with pytest.raises(TypeError):
+        VR.fancy_integration(rs, z, DEV, clamp_mode=None)
+    with pytest.raises(RuntimeError):
+        VR.fancy_integration(rs, z, DEV, clamp_mode="relu", fill_mode="debug")
+    # C-ABI level error code for a missing clamp mode
+    o = _lib.composite_opts("relu")
+    o.clamp_mode = 0
+    with pytest.raises(_lib.FenerfError) as ei:
+        native.composite(rs, z.squeeze(-1), None, o)
+    assert ei.value.code == _lib.E_CLAMP_MODE
+
+
+def test_composite_max_samples_and_empty():
+    """M = 128 (two samples per lane, the documented maximum), M = 1, zero rays."""
+    rng = np.random.default_rng(5)
+    for M in (128, 65, 64, 1):
+        rs = rng.normal(size=(3, 7, M, 22)).astype(np.float32)
+        rs[..., -1] *= 30
+        z = np.sort(rng.uniform(0.88, 1.12, (3, 7, M, 1)).astype(np.float32), axis=2)
+        opts = _lib.composite_opts("relu", last_back=(M % 2 == 0))
+        rgb, depth, w, ws = native.composite(T(rs), T(z[..., 0]), None, opts)
+        r_rgb, r_depth, r_w = O.fancy_integration(rs, z, clamp_mode="relu", last_back=(M % 2 == 0))
+        np.testing.assert_allclose(N_(rgb), r_rgb, atol=2e-5)
+        np.testing.assert_allclose(N_(depth), r_depth[..., 0], atol=2e-5)
+        np.testing.assert_allclose(N_(w), r_w[..., 0], atol=1e-5)
+    e = native.composite(torch.empty((0, 4, 22), device=DEV), torch.empty((0, 4), device=DEV), None, _lib.composite_opts("relu"))
+    assert e[0].shape == (0, 21)
+    with pytest.raises(_lib.FenerfError):
+        native.composite(torch.zeros((1, 129, 22), device=DEV), torch.zeros((1, 129), device=DEV), None, _lib.composite_opts("relu"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# a14 / a15: sample_pdf, resample, merge
+# ---------------------------------------------------------------------------------------------------
+def test_sample_pdf_and_resample_vs_reference():
+    g = load_golden("sample_pdf_cases")
+    for i in range(int(g["n_cases"])):
+        draws = VR.RecordedDraws([g[f"c{i}_u"]])
+        s = VR.sample_pdf(T(g[f"c{i}_bins"]), T(g[f"c{i}_weights"]), g[f"c{i}_u"].shape[1], det=False, draws=draws)
+        np.testing.assert_allclose(N_(s), g[f"c{i}_samples"], atol=3e-6)
+    draws = VR.RecordedDraws([g["edge_u"]])
+    s = VR.sample_pdf(T(g["edge_bins"]), T(g["edge_weights"]), 5, draws=draws)
+    np.testing.assert_allclose(N_(s), g["edge_samples"], atol=3e-6)
+    for name in ("tiny_texture_fwd", "h256_texture_16x16_n24_trained"):
+        g = load_golden(name)
+        B, R, N = g["st_z_coarse"].shape[:3]
+        zf = native.resample(T(g["st_z_coarse"].reshape(B * R, N)), T(g["st_coarse_weights"].reshape(B * R, N)), T(g["rand_u_fine"]))
+        err = np.abs(N_(zf) - g["st_z_fine"]).max()
+        print(f"[parity] resample {name}: max|err| {err:.3e}")
+        assert err < 3e-6
+    with pytest.raises(_lib.FenerfError):
+        native.resample(torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV))
+
+
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n24_trained"])
+def test_merge_composite_vs_reference(name):
+    g = load_golden(name)
+    B, R, N = g["st_z_coarse"].shape[:3]
+    C = g["st_siren_coarse"].shape[-1]
+    fine, coarse = g["st_siren_fine"].reshape(B * R, N, C), g["st_siren_coarse"].reshape(B * R, N, C)
+    opts = _lib.composite_opts("relu")
+    rgb, depth, w, ws, zs = native.merge_composite(T(fine), T(coarse), T(g["st_z_fine"]), T(g["st_z_coarse"].reshape(B * R, N)), None, opts)
+    np.testing.assert_array_equal(N_(zs), g["st_all_z"].reshape(B * R, 2 * N))         # sort is exact
+    np.testing.assert_allclose(N_(rgb), g["st_final_rgb"].reshape(B * R, -1), atol=1e-5)
+    np.testing.assert_allclose(N_(depth), g["st_final_depth"].reshape(B * R), atol=1e-5)
+    np.testing.assert_allclose(N_(w), g["st_final_third"].reshape(B * R, 2 * N), atol=1e-5)
+    np.testing.assert_allclose(N_(ws), N_(w).sum(-1), atol=1e-5)
+    assert (np.diff(N_(zs), axis=-1) >= 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# a15-a17: the generator API end to end, teacher-forced with the reference's recorded random draws
+# ---------------------------------------------------------------------------------------------------
+def _make_generator(g, spec):
+    H = spec["hidden_dim"]
+    cls = {"texture": S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, "baseline": S.SIRENBASELINESEMANTICDISENTANGLE}[spec["kind"]]
+    gen = G.DoubleImplicitGenerator3d(functools.partial(cls, hidden_dim=H), spec.get("z_dim", 256), spec.get("z_dim", 256), 22)
+    sd = proc.make_state_dict(dict(spec, z_dim=spec.get("z_dim", 256), map_hidden=256), seed=int(g["meta_seed"]) if "meta_seed" in g else 3,
+                              sigma_gain=float(g["meta_sigma_gain"]) if "meta_sigma_gain" in g else 300.0)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    if "spatial_embeddings" in tsd:
+        gen.siren.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    gen.siren.load_state_dict(tsd, strict=True)
+    gen = gen.to(DEV).eval()
+    gen.device = torch.device(DEV)
+    gen.siren.device = gen.device
+    return gen
+
+
+def _e2e_check(tag, px, ref_px, tol=1e-3, max_bad_frac=0.03):
+    err = np.abs(px - ref_px).max(axis=1)
+    bad = err > tol
+    print(f"[parity] {tag}: max|err| over agreeing pixels {err[~bad].max():.3e}; {int(bad.sum())}/{bad.size} pixels differ by "
+          f"more than {tol} (fill-threshold / resampling flips), worst {err.max():.3e}")
+    assert bad.mean() <= max_bad_frac
+    top2 = np.sort(ref_px[:, :-3], axis=1)
+    decided = (top2[:, -1] - top2[:, -2]) > 10 * tol
+    am, am_ref = px[:, :-3].argmax(1), ref_px[:, :-3].argmax(1)
+    assert (am == am_ref)[~bad & decided].all(), "exact argmax semantics"
+    return bad
+
+
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "h256_texture_16x16_n12",
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
+def test_forward_with_frequencies_vs_reference(name):
+    g = load_golden(name)
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, dict(spec, z_dim=16 if spec["hidden_dim"] == 32 else 256))
+    film, tf = _film(g, spec)
+    hier = bool(g["meta_hier"])
+    seq = [g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"]]
+    if hier:
+        seq += [g["rand_u_fine"], g["rand_noise_fine"]]
+    gen.draws = VR.RecordedDraws(seq)
+    kw = kwargs_from_golden(g)
+    with torch.no_grad():
+        px, poses = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], img_size=int(g["meta_S"]), fov=12, ray_start=0.88,
+                                                 ray_end=1.12, num_steps=int(g["meta_N"]), h_stddev=0.3, v_stddev=0.155,
+                                                 h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, hierarchical_sample=hier,
+                                                 sample_dist="gaussian", **kw)
+    assert not gen.draws.arrays, "all recorded draws consumed, in order"
+    assert px.shape == g["pixels"].shape and px.is_cuda
+    np.testing.assert_allclose(N_(poses), g["poses"], atol=1e-6)
+    _e2e_check(name, N_(px), g["pixels"])
+
+
+@pytest.mark.parametrize("name", ["tiny_texture_staged", "tiny_texture_staged_lock"])
+def test_staged_forward_with_frequencies_vs_reference(name):
+    g = load_golden(name)
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, dict(spec, z_dim=16))
+    film, tf = _film(g, spec)
+    gen.draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"], g["rand_u_fine"],
+                                  g["rand_noise_fine"]])
+    kw = kwargs_from_golden(g)
+    px, depth, third = gen.staged_forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], img_size=int(g["meta_S"]), fov=12,
+                                                           ray_start=0.88, ray_end=1.12, num_steps=int(g["meta_N"]), h_stddev=0.3,
+                                                           v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5,
+                                                           hierarchical_sample=True, sample_dist="gaussian", max_batch_size=1000, **kw)
+    assert not px.is_cuda and px.shape == g["pixels"].shape and third.shape == g["third"].shape
+    bad = _e2e_check(name, N_(px), g["pixels"], max_bad_frac=0.06)
+    np.testing.assert_allclose(N_(depth)[~bad], g["depth"][~bad], atol=1e-4)
+    terr = np.abs(N_(third) - g["third"]).max(axis=1)
+    assert (terr[~bad] < 2e-3).all()
+
+
+def test_forward_and_staged_forward_from_latents():
+    """z -> mapping nets (PyTorch) -> render; staged_forward's truncation with the reference's avg frequencies."""
+    g = load_golden("tiny_texture_z_full")
+    spec = spec_from_golden(g)
+    gen = _make_generator(dict(meta_seed=3, meta_sigma_gain=300.0), spec)
+    zg, za = T(g["z_geo"]), T(g["z_app"])
+    with torch.no_grad():
+        fg, pg = gen.siren.geo_mapping_network(zg)
+    np.testing.assert_allclose(N_(fg), g["map_freq_geo"], atol=5e-5)
+    kw = dict(img_size=6, num_steps=6, hierarchical_sample=True, clamp_mode="relu", nerf_noise=0.0, fov=12, ray_start=0.88,
+              ray_end=1.12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, sample_dist="gaussian")
+    rd = {k[len("fwd_rand_"):]: v for k, v in g.items() if k.startswith("fwd_rand_")}
+    gen.draws = VR.RecordedDraws([rd["u_jitter"], rd["r_theta"], rd["r_phi"], rd["noise_coarse"], rd["u_fine"], rd["noise_fine"]])
+    with torch.no_grad():
+        px, poses = gen(zg, za, **kw)
+    np.testing.assert_allclose(N_(poses), g["fwd_poses"], atol=1e-6)
+    _e2e_check("forward(z)", N_(px), g["fwd_pixels"], max_bad_frac=0.06)
+    # staged_forward: first two draws are the 10000-z avg pass; replace its result by the reference's recorded means
+    rd = {k[len("stg_rand_"):]: v for k, v in g.items() if k.startswith("stg_rand_")}
+    gen.draws = VR.RecordedDraws([np.zeros((10000, 16), np.float32)] * 2 +
+                                 [rd["u_jitter"], rd["r_theta"], rd["r_phi"], rd["noise_coarse"], rd["u_fine"], rd["noise_fine"]])
+    orig = gen.generate_avg_frequencies
+
+    def patched():
+        orig()
+        gen.avg_frequencies_geo, gen.avg_phase_shifts_geo = T(g["stg_avg_freq_geo"]), T(g["stg_avg_phase_geo"])
+        gen.avg_frequencies_app, gen.avg_phase_shifts_app = T(g["stg_avg_freq_app"]), T(g["stg_avg_phase_app"])
+    gen.generate_avg_frequencies = patched
+    px, depth = gen.staged_forward(zg, za, psi=float(g["stg_psi"]), max_batch_size=97, fill_mode="seg_padding_background",
+                                   fill_color="white", **kw)
+    assert px.shape == g["stg_pixels"].shape and not px.is_cuda
+    bad = _e2e_check("staged_forward(z, psi=0.7)", N_(px), g["stg_pixels"], max_bad_frac=0.06)
+    np.testing.assert_allclose(N_(depth)[~bad], g["stg_depth"][~bad], atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties + oracle spot check on a ray subset
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_128_24p24_properties_and_oracle_subset():
+    spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
+    sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV)
+    B, S_, N = 1, 128, 24
+    R = S_ * S_
+    film = proc.film_params(spec, B, seed=0)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    torch.manual_seed(0)
+    o, d, z, pitch, yaw = VR.sample_rays(B, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((B * R, N), device=DEV)
+    opts = _lib.composite_opts("relu", fill_mode="seg_padding_background", fill_color="white")
+    rgb, depth, w, _ = nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True, want_weights=True)
+    rgb2, depth2, w2, _ = nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True, want_weights=True)
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and torch.equal(w, w2), "deterministic"
+    rgb, depth, w = N_(rgb), N_(depth), N_(w)
+    assert np.isfinite(rgb).all() and np.isfinite(depth).all()
+    ws = w.sum(-1)
+    assert (w >= 0).all() and (ws <= 1 + 1e-4).all()
+    filled = rgb[..., 0] == 1
+    assert ((ws < 0.9) == filled).all(), "background channel set exactly on rays below the 0.9 threshold"
+    assert (rgb[filled][:, 1:] == 1).all()
+    assert ((depth >= -1e-6) & (depth <= 1.12 * (1 + 1e-4) + 0.02)).all()
+    assert ((rgb[~filled][:, -3:] >= 0) & (rgb[~filled][:, -3:] <= 1 + 1e-4)).all()
+    # sub-batch independence at full size: rows [5000, 5200) alone == the same rows of the full render (bit-exact)
+    sl = slice(5000, 5200)
+    r3, d3, w3, _ = nat.render(o[:, sl].contiguous(), d[:, sl].contiguous(), z[:, sl].contiguous(), u[sl].contiguous(), None, None, *tf,
+                               opts, hierarchical=True, want_weights=True)
+    assert np.array_equal(N_(r3), rgb[:, sl]) and np.array_equal(N_(w3), w[:, sl])
+    # oracle on a random subset of rays (same inputs), stage-wise teacher forcing avoided: plain end-to-end
+    idx = np.sort(np.random.default_rng(1).choice(R, 192, replace=False))
+    oo, dd, zz, uu = N_(o)[:, idx], N_(d)[:, idx], N_(z)[:, idx], N_(u)[idx]
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    pts = (oo[:, :, None, :] + dd[:, :, None, :] * zz[..., None]).reshape(B, -1, 3)
+    dexp = np.broadcast_to(dd[:, :, None, :], (B, len(idx), N, 3)).reshape(B, -1, 3)
+    coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(B, len(idx), N, -1)
+    _, _, cw = O.fancy_integration(coarse, zz[..., None], clamp_mode="relu")
+    zf = O.fine_z_from_coarse(cw, zz[..., None], uu)
+    fpts = (oo[:, :, None, :] + dd[:, :, None, :] * zf).reshape(B, -1, 3)
+    fine = O.siren_forward(sd, spec, fpts, dexp, *args).reshape(B, len(idx), N, -1)
+    ao, az = O.merge_sorted(fine, coarse, zf, zz[..., None])
+    r_rgb, r_depth, r_w = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color="white")
+    err = np.abs(rgb[:, idx] - r_rgb).max(-1)
+    bad = err > 1e-3
+    print(f"[parity] 128x128 24+24 H=256 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
+    assert bad.mean() <= 0.03
+    np.testing.assert_allclose(depth[:, idx][~bad], r_depth[..., 0][~bad], atol=1e-4)

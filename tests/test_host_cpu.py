@@ -1,0 +1,138 @@
+"""CPU tests of the host-side logic (no GPU, no HIP compute): curriculum data, ray/camera sampling in torch vs the
+golden vectors captured from the reference, draw order, error behaviour of the API surface."""
+import functools
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from fenerf_amd import curriculums, _lib
+from fenerf_amd.generators import generators as G
+from fenerf_amd.generators import volumetric_rendering as VR
+from fenerf_amd.siren import siren as S
+
+
+def test_curriculums_match_reference_values():
+    ref = json.load(open(os.path.join(GOLDEN, "curriculums.json")))
+    for name, d in ref.items():
+        mine = getattr(curriculums, name)
+        got = {(f"int:{k}" if isinstance(k, int) else k): (list(v) if isinstance(v, tuple) else v) for k, v in mine.items()}
+        assert got == d, name
+    md = curriculums.extract_metadata(curriculums.CelebA_double_semantic_texture_embedding_256_dim_96, 60000)
+    assert md["img_size"] == 128 and md["num_steps"] == 24 and md["model"].endswith("DIM_96")
+    assert curriculums.next_upsample_step(curriculums.CelebA_double_semantic_texture_embedding_256_dim_96, 0) == 20000
+    assert curriculums.last_upsample_step(curriculums.CelebA_double_semantic_texture_embedding_256_dim_96, 30000) == 20000
+
+
+def test_rays_camera_host_functions():
+    g = load_golden("camera_rays")
+    for j in range(3):
+        S_, N = int(g[f"r{j}_S"]), int(g[f"r{j}_N"])
+        p, z, d = VR.get_initial_rays_trig(2, N, "cpu", 12, (S_, S_), 0.88, 1.12)
+        np.testing.assert_allclose(p.numpy(), g[f"r{j}_points"], atol=1e-7)
+        np.testing.assert_allclose(z.numpy(), g[f"r{j}_z"], atol=1e-7)
+        np.testing.assert_allclose(d.numpy(), g[f"r{j}_dirs"], atol=1e-7)
+    for i in range(int(g["n_modes"])):
+        mode = str(g[f"m{i}_mode"])
+        draws = VR.RecordedDraws(list(g[f"m{i}_draws"]))
+        o, phi, theta = VR.sample_camera_positions("cpu", n=6, r=1, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                   horizontal_mean=np.pi * 0.5, vertical_mean=np.pi * 0.5, mode=mode, draws=draws)
+        assert not draws.arrays
+        np.testing.assert_allclose(o.numpy(), g[f"m{i}_origin"], atol=1e-7)
+        np.testing.assert_allclose(phi.numpy(), g[f"m{i}_phi"], atol=1e-7)
+        c2w = VR.create_cam2world_matrix(VR.normalize_vecs(-o), o, device="cpu")
+        np.testing.assert_allclose(c2w.numpy(), g[f"m{i}_cam2world"], atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier"])
+def test_sample_rays_matches_reference_transform(name):
+    """The lean ray setup the fused renderer uses == reference get_initial_rays_trig + transform_sampled_points."""
+    g = load_golden(name)
+    B, S_, N = int(g["meta_B"]), int(g["meta_S"]), int(g["meta_N"])
+    draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"]])
+    o, d, z, pitch, yaw = VR.sample_rays(B, N, "cpu", 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi * 0.5, np.pi * 0.5, "gaussian", draws=draws)
+    np.testing.assert_allclose(o.numpy(), g["st_origins"], atol=2e-7)
+    np.testing.assert_allclose(d.numpy(), g["st_dirs"], atol=2e-7)
+    np.testing.assert_allclose(z.numpy(), g["st_z_coarse"][..., 0], atol=2e-7)
+    np.testing.assert_allclose(torch.cat([pitch, yaw], -1).numpy(), g["poses"], atol=1e-7)
+    # points = o + d*z reproduces the reference's transformed points up to fp32 rounding
+    pts = o[:, :, None, :] + d[:, :, None, :] * z[..., None]
+    np.testing.assert_allclose(pts.numpy(), g["st_points"], atol=5e-7)
+    # and the full reference-shaped API too
+    draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"]])
+    pc, zc, dc = VR.get_initial_rays_trig(B, N, "cpu", 12, (S_, S_), 0.88, 1.12)
+    tp, tz, td, to, pi_, ya = VR.transform_sampled_points(pc, zc, dc, "cpu", h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5,
+                                                         v_mean=np.pi * 0.5, mode="gaussian", draws=draws)
+    np.testing.assert_allclose(tp.numpy(), g["st_points"], atol=3e-7)
+    np.testing.assert_allclose(tz.numpy(), g["st_z_coarse"], atol=1e-7)
+
+
+def test_generator_surface_and_loud_failures():
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 16, 16, 22)
+    assert gen.channel_dim == 21 and gen.step == 0 and gen.epoch == 0 and hasattr(gen.siren, "geo_mapping_network")
+    names = set(dict(gen.siren.named_parameters()))
+    for k in ("network.0.layer.weight", "final_layer.bias", "color_layer_sine.2.layer.weight", "color_layer_linear.0.weight",
+              "label_layer_linear.2.bias", "geo_mapping_network.network.8.weight", "spatial_embeddings"):
+        assert k in names, k
+    assert tuple(gen.siren.color_layer_sine[0].layer.weight.shape) == (32, 32 + 32 + 3)
+    md = curriculums.extract_metadata(curriculums.CelebA_double_semantic_texture_embedding_256_dim_96, 0)
+    with torch.no_grad(), pytest.raises(KeyError):       # callers add nerf_noise (train...py:277); reference KeyErrors too
+        gen.device = torch.device("cpu")
+        gen(torch.randn(1, 16), torch.randn(1, 16), **md)
+    md["nerf_noise"] = 0.0
+    gen.device = torch.device("cpu")
+    gen.siren.device = gen.device
+    z = torch.randn(1, 16)
+    with pytest.raises(NotImplementedError):       # grad mode: backward is the next row, fail loudly
+        gen(z, z, **md)
+    with torch.no_grad(), pytest.raises(RuntimeError):   # CPU device: there is no CPU render path
+        gen(z, z, **md)
+    with torch.no_grad(), pytest.raises(TypeError):      # reference: raise "Need to choose clamp mode" -> TypeError
+        gen(z, z, **dict(md, clamp_mode=None))
+    sg = G.ImplicitGenerator3d(functools.partial(S.SPATIALSIRENBASELINE, hidden_dim=32), 16, 4)
+    f, p = sg.siren.mapping_network(torch.randn(2, 16))
+    assert f.shape == (2, 9 * 32)
+    fg, pg, fa, pa = sg.siren.split_film(f, p)
+    assert fg.shape == (2, 8 * 32) and fa.shape == (2, 32) and torch.equal(fa, f[:, -32:])
+
+
+def test_draw_order_matches_reference():
+    """A.6: forward draws rand[B,R,N,1], randn[B,1] x2, randn[B,R,N,1], rand[B*R,N], randn[B,R,2N,1]."""
+    log = []
+
+    class Spy:
+        def rand(self, shape, device):
+            log.append(("rand", tuple(shape)))
+            return torch.rand(shape)
+
+        def randn(self, shape, device):
+            log.append(("randn", tuple(shape)))
+            return torch.randn(shape)
+
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.SIRENBASELINESEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.draws = Spy()
+    gen.device = torch.device("cpu")
+    gen.siren.device = gen.device
+    md = dict(img_size=4, fov=12, ray_start=0.88, ray_end=1.12, num_steps=5, h_stddev=0.3, v_stddev=0.155, h_mean=1.57, v_mean=1.57,
+              hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.0)
+    z = torch.randn(3, 8)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        gen(z, z, **md)   # stops at the GPU call, after every draw has been made
+    assert log == [("rand", (3, 16, 5, 1)), ("randn", (3, 1)), ("randn", (3, 1)), ("randn", (3, 16, 5, 1)), ("rand", (48, 5)),
+                   ("randn", (3, 16, 10, 1))]
+    log.clear()
+    with pytest.raises(RuntimeError):
+        gen.staged_forward(z, z, **md)
+    assert log[:2] == [("randn", (10000, 8)), ("randn", (10000, 8))] and log[2] == ("rand", (3, 16, 5, 1))
+
+
+def test_composite_opts_mapping():
+    o = _lib.composite_opts("softplus", 0.5, last_back=True, fill_mode="seg_padding_background", fill_color="light_grey")
+    assert (o.clamp_mode, o.last_back, o.fill_mode, o.fill_enabled) == (2, 1, 2, 1) and abs(o.fill_value - 0.81) < 1e-7
+    o = _lib.composite_opts("relu", fill_mode="eval_seg_padding_background", fill_color="none")
+    assert o.fill_enabled == 0 and o.fill_mode == 3
+    o = _lib.composite_opts("relu", fill_mode="something_else")
+    assert o.fill_mode == 0

@@ -1,0 +1,203 @@
+"""CPU check of the host weight packer (fenerf_pack.cpp) + the K-permutation scheme of the SIREN kernel.
+
+A numpy emulation of one wave of fenerf_siren.hip -- same stream walk, same MFMA 32x32x2 operand / result
+lane maps (cdna_hip_programming.md §3), same ring consumption order -- is run on the blob the C packer
+produced and compared with the oracle.  This pins packer + dataflow without a GPU; the MFMA lane maps
+themselves are re-checked on hardware by tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from fenerf_amd import _lib, procedural as proc
+from oracle import fenerf_oracle as O
+
+PF = 8
+LANE = np.arange(64)
+M_, H_ = LANE & 31, LANE >> 5
+
+
+def mfma(a, b, acc):
+    """v_mfma_f32_32x32x2_f32: a[l] = A[i=l&31][k=l>>5], b[l] = B[k=l>>5][j=l&31], acc[l][r] = D[row(r,l>>5)][l&31]."""
+    A = np.zeros((32, 2)); B = np.zeros((2, 32))
+    A[M_, H_] = a
+    B[H_, M_] = b
+    D = A @ B
+    for r in range(16):
+        acc[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * H_, M_]
+
+
+def sin2pi(t):
+    return np.sin(2 * np.pi * t)
+
+
+def emulate_tile(blob, consts, spec, pts, dirs, film, grid_cl):
+    H, NB, KGX = spec["hidden_dim"], spec["hidden_dim"] // 32, spec["hidden_dim"] // 8
+    pad = lambda n: (n + PF - 1) // PF * PF
+    KGXP = pad(KGX)
+    has_grid = spec["grid_ch"] > 0
+    C0_KG = KGX + (4 if has_grid else 0) + 1
+    C0_KGP = pad(C0_KG)
+    n_geo, n_color, C = spec["n_geo"], spec["n_color"], spec["output_dim"]
+    n_lab = C - 4
+    L = n_geo + n_color
+    entries = blob.reshape(-1, 64, 4).astype(np.float64)
+    cur = [NB]  # ring cursor (entry index); layer-0 block occupies entries [0, NB)
+
+    def next_entry():
+        e = entries[cur[0]]
+        cur[0] += 1
+        return e
+
+    # FiLM pre-pass (film_prep_kernel), single image
+    fg = film["freq_geo"][0].astype(np.float32) * np.float32(15) + np.float32(30)
+    fa = film["freq_app"][0].astype(np.float32) * np.float32(15) + np.float32(30)
+    f_all = np.concatenate([fg, fa]).astype(np.float64).reshape(L, H)
+    p_all = np.concatenate([film["phase_geo"][0], film["phase_app"][0]]).astype(np.float64).reshape(L, H)
+    bias = consts[36:36 + L * H].astype(np.float64).reshape(L, H)
+    fp, pp = f_all / (2 * np.pi), (f_all * bias + p_all) / (2 * np.pi)
+
+    p = pts[M_].astype(np.float64)
+    d = dirs[M_].astype(np.float64)
+    q = p * (2 / 0.24)
+
+    slab = np.zeros((H // 8, 64, 4))
+
+    def film_store(acc, layer, nb):
+        for j in range(4):
+            feat = 32 * nb + 8 * j + 4 * H_[:, None] + np.arange(4)[None, :]
+            slab[nb * 4 + j] = sin2pi(fp[layer][feat] * acc[:, 4 * j:4 * j + 4] + pp[layer][feat])
+
+    def load_act():
+        return slab.transpose(1, 0, 2).reshape(64, H // 2).copy()   # in[l][4g+i] = slab[g][l][i]
+
+    def mfma_x(acc, act, n_real, n_pad):
+        for kg in range(n_pad):
+            w = next_entry()
+            if kg < n_real:
+                for i in range(4):
+                    mfma(w[:, i], act[:, 4 * kg + i], acc)
+
+    # grid features: half h blends channels 16h..16h+15
+    e = np.zeros((64, 16))
+    if has_grid:
+        Dg, Hg, Wg = grid_cl.shape[:3]
+        ix, iy, iz = (q[:, 0] + 1) / 2 * (Wg - 1), (q[:, 1] + 1) / 2 * (Hg - 1), (q[:, 2] + 1) / 2 * (Dg - 1)
+        x0, y0, z0 = np.floor(ix), np.floor(iy), np.floor(iz)
+        for c in range(8):
+            cz, cy, cx = c >> 2, (c >> 1) & 1, c & 1
+            xi, yi, zi = x0 + cx, y0 + cy, z0 + cz
+            wgt = (ix - x0 if cx else x0 + 1 - ix) * (iy - y0 if cy else y0 + 1 - iy) * (iz - z0 if cz else z0 + 1 - iz)
+            ok = (xi >= 0) & (xi <= Wg - 1) & (yi >= 0) & (yi <= Hg - 1) & (zi >= 0) & (zi <= Dg - 1)
+            for l in range(64):
+                if ok[l]:
+                    e[l] += grid_cl[int(zi[l]), int(yi[l]), int(xi[l]), 16 * H_[l]:16 * H_[l] + 16] * wgt[l]
+
+    # layer 0
+    b0 = np.where(H_ == 1, q[:, 1], q[:, 0])
+    b1 = np.where(H_ == 1, 0.0, q[:, 2])
+    for nb in range(NB):
+        w = entries[nb]
+        acc = np.zeros((64, 16))
+        mfma(w[:, 0], b0, acc)
+        mfma(w[:, 1], b1, acc)
+        film_store(acc, 0, nb)
+    act = load_act()
+    for l in range(1, n_geo):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            mfma_x(acc, act, KGX, KGXP)
+            film_store(acc, l, nb)
+        act = load_act()
+    # colour layer 0
+    bd0 = np.where(H_ == 1, d[:, 1], d[:, 0])
+    bd1 = np.where(H_ == 1, 0.0, d[:, 2])
+    for nb in range(NB):
+        acc = np.zeros((64, 16))
+        for kg in range(C0_KGP):
+            w = next_entry()
+            if kg < KGX:
+                for i in range(4):
+                    mfma(w[:, i], act[:, 4 * kg + i], acc)
+            elif has_grid and kg < KGX + 4:
+                qq = kg - KGX
+                for i in range(4):
+                    mfma(w[:, i], e[:, 4 * qq + i], acc)
+            elif kg == C0_KG - 1:
+                mfma(w[:, 0], bd0, acc)
+                mfma(w[:, 1], bd1, acc)
+        film_store(acc, n_geo, nb)
+    out = np.zeros((32, C))
+    acc = np.zeros((64, 16))
+    mfma_x(acc, act, KGX, KGXP)
+    for r in range(16):
+        row = (r & 3) + 8 * (r >> 2) + 4 * H_
+        for l in range(64):
+            if row[l] <= n_lab:
+                ch = row[l] if row[l] < n_lab else C - 1
+                out[M_[l], ch] = acc[l, r] + consts[row[l]]
+    act = load_act()
+    for c in range(1, n_color):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            mfma_x(acc, act, KGX, KGXP)
+            film_store(acc, n_geo + c, nb)
+        act = load_act()
+    acc = np.zeros((64, 16))
+    mfma_x(acc, act, KGX, KGXP)
+    for r in range(3):
+        for l in range(32):
+            out[l, C - 4 + r] = 1 / (1 + np.exp(-(acc[l, r] + consts[32 + r])))
+    assert cur[0] + PF == entries.shape[0], "stream must be consumed exactly (+ the PF tail pad)"
+    return out
+
+
+@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("texture", 64, 4), ("baseline", 32, 0), ("spatial", 32, 0),
+                                         ("texture", 256, 6)])
+def test_packer_and_kpermutation(kind, H, grid):
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=11, sigma_gain=3.0, with_mapping=False)
+    blob, consts = _lib.pack_weights_host(sd, spec)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-0.13, 0.13, (32, 3)).astype(np.float32)   # a few points fall outside the grid box
+    dirs = rng.normal(size=(32, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, 1, seed=11)
+    if kind == "spatial":   # single latent: the colour layer uses the 9th slice of the same mapping output
+        film["freq_app"] = proc.normal("film.freq_app", (1, H), 0.4, 11)
+        film["phase_app"] = proc.normal("film.phase_app", (1, H), 0.4, 11)
+    grid_cl = np.ascontiguousarray(sd["spatial_embeddings"][0].transpose(1, 2, 3, 0)).astype(np.float64) if grid else None
+    got = emulate_tile(blob, consts, spec, pts, dirs, film, grid_cl)
+    if kind == "spatial":
+        fg = np.concatenate([film["freq_geo"], film["freq_app"]], -1)
+        pg = np.concatenate([film["phase_geo"], film["phase_app"]], -1)
+        ref = O.siren_forward(sd, spec, pts[None], dirs[None], fg, pg, dtype=np.float64)[0]
+    else:
+        ref = O.siren_forward(sd, spec, pts[None], dirs[None], film["freq_geo"], film["phase_geo"], film["freq_app"],
+                              film["phase_app"], dtype=np.float64)[0]
+    np.testing.assert_allclose(got, ref, atol=2e-6, rtol=1e-6)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/fenerf.h <-> libfenerf_hip.so: every declared entry point is exported (no compute calls)."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(_lib.__file__), "..", "include", "fenerf.h")).read()
+    declared = set(re.findall(r"\b(fenerf_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    l = _lib.lib()
+    for name in declared:
+        assert hasattr(l, name)
+    assert l.fenerf_abi_version() == _lib.ABI_VERSION
+
+
+def test_desc_validation_errors():
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=4, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=1, with_mapping=False)
+    bad = dict(spec, hidden_dim=48)
+    with pytest.raises(_lib.FenerfError) as ei:
+        _lib.pack_weights_host(sd, bad)
+    assert ei.value.code == _lib.E_UNSUPPORTED
+    with pytest.raises(TypeError):
+        _lib.composite_opts(None)
+    with pytest.raises(RuntimeError):
+        _lib.composite_opts("relu", fill_mode="debug")
