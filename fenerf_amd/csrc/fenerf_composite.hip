@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
         float x = sg[s];
         if (P.noise) x = __fadd_rn(x, __fmul_rn(P.noise[ray * M + k], P.o.noise_std));
         const float act = P.o.clamp_mode == FENERF_CLAMP_SOFTPLUS ? softplus_f(x) : fmaxf(x, 0.f);
-        alpha[s] = 1.f - expf(-delta * act);
+        // M == 1: the reference builds delta_inf from deltas[:, :, :1] of an EMPTY deltas tensor (:23-25), so every
+        // per-sample tensor is empty and rgb / depth / weights_sum come out 0 -- reproduce that.
+        alpha[s] = M > 1 ? 1.f - expf(-delta * act) : 0.f;
         tt[s] = 1.f - alpha[s] + 1e-10f;
       }
     }

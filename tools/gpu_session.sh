@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.log
 nproc >> gpurun_out/device.log
 if [[ $what == all || $what == tests ]]; then
-  timeout 900 python -m pytest tests -m gpu -q -s -x 2>&1 | tail -150 > gpurun_out/tests.log
+  timeout 900 python -m pytest tests -m gpu -q -s 2>&1 | tail -250 > gpurun_out/tests.log
   echo "pytest exit: $?" >> gpurun_out/tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
   echo "smoke exit: $?" >> gpurun_out/smoke.log
@@ -19,7 +19,7 @@ if [[ $what == all || $what == bench ]]; then
 fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
   echo "prof exit: $?" >> gpurun_out/prof.log
   find gpurun_out/prof -name "*stats*" | head >> gpurun_out/prof.log
   # keep only the small summaries (traces can be large)
