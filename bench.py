@@ -65,10 +65,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    from fenerf_amd import dist as fdist
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used only for the timing barrier / max-reduce
+        fdist.init_from_env(backend="nccl", device=dev)   # RCCL over xGMI; used only for the timing barrier / max-reduce
 
     from fenerf_amd import _lib, native, procedural as proc
     from fenerf_amd.generators import volumetric_rendering as VR
@@ -103,10 +103,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = fdist.max_over_ranks(dt, device=dev)
     rays_total = world * B * R * args.steps
     value = rays_total / dt
 

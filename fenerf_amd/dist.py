@@ -1,0 +1,65 @@
+"""Multi-GPU sharding of the render path: one process per GPU, shard by image, NO data-path collective
+(rays/images are independent; the model -- 2.75 MB of weights + 113 MB grid -- is replicated).
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm, "gloo" in CPU tests) is used only to agree on timing
+and, optionally, to gather finished images on one rank.
+
+reference analogue: the rank-strided image loop of fid_evaluation.py:136-150 and DistributedSampler sharding
+(datasets.py:96-113); the reference itself initialises gloo (train_double_latent_semantic.py:63).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None, device=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run).  Returns (rank, local_rank, world)."""
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def rank_strided(total, rank, world):
+    """Image ids rank, rank+world, ... (< total) -- the reference's FID-dump split (fid_evaluation.py:136-150)."""
+    return list(range(rank, total, world))
+
+
+def contiguous_shard(total, rank, world):
+    """[begin, end) of a balanced contiguous split (first `total % world` ranks get one extra)."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value, device="cpu"):
+    """Wall-clock agreement for benchmarks: MAX of a python float over all ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_images(local, dst=0):
+    """Collects per-rank image batches [b_i, C, S, S] (b_i may differ) on rank `dst`, in rank order.  Returns the
+    concatenated tensor on dst, None elsewhere.  Off the hot path (inference convenience)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[:local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([o[:c] for o, c in zip(out, counts)], 0)

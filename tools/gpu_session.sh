@@ -26,3 +26,4 @@ if [[ $what == all || $what == prof ]]; then
   find gpurun_out/prof -type f ! -name "*stats*" -size +2M -delete
 fi
 tail -5 gpurun_out/tests.log gpurun_out/smoke.log gpurun_out/bench.log 2>/dev/null
+exit 0
