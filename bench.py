@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--num-steps", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="arithmetic of the dense layers: exact fp32 MFMA, or error-compensated fp16 MFMA (fp32-class accuracy)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,7 +77,7 @@ def main():
 
     spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
     sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
-    nat = native.NativeModel(sd, spec, dev)
+    nat = native.NativeModel(sd, spec, dev, args.precision)
     B, S, N = args.batch, args.img_size, args.num_steps
     R = S * S
     # every rank renders its own images (shard by image, no data-path collective): different latents / poses per rank

@@ -32,6 +32,7 @@ class FenerfModelDesc(C.Structure):
         ("color_w", _fp * MAX_COLOR), ("color_b", _fp * MAX_COLOR),
         ("label_w", _fp * MAX_LABEL), ("label_b", _fp * MAX_LABEL),
         ("sigma_w", _fp), ("sigma_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp), ("grid", _fp),
+        ("precision", C.c_int32),
     ]
 
 
@@ -99,7 +100,10 @@ def _as_f32(a):
     return a, a.ctypes.data_as(_fp)
 
 
-def make_desc(sd, spec):
+PRECISION = {"f32": 0, "f16x3": 1}
+
+
+def make_desc(sd, spec, precision="f32"):
     """Builds a FenerfModelDesc from a reference-named state dict of numpy arrays.
     Returns (desc, keepalive) -- keepalive holds the host arrays the desc points into."""
     keep = []
@@ -114,6 +118,7 @@ def make_desc(sd, spec):
     d.hidden_dim, d.n_geo, d.n_color = spec["hidden_dim"], spec["n_geo"], spec["n_color"]
     d.n_label_layers, d.output_dim, d.grid_ch = spec["n_label_layers"], spec["output_dim"], spec["grid_ch"]
     d.box_scale = 2 / 0.24
+    d.precision = PRECISION[precision]
     for i in range(spec["n_geo"]):
         d.geo_w[i], d.geo_b[i] = P(f"network.{i}.layer.weight"), P(f"network.{i}.layer.bias")
     if spec["kind"] == "spatial":
@@ -132,9 +137,9 @@ def make_desc(sd, spec):
     return d, keep
 
 
-def pack_weights_host(sd, spec):
+def pack_weights_host(sd, spec, precision="f32"):
     """(blob, consts) numpy copies of the packed streaming layout (CPU only; layout tests)."""
-    d, keep = make_desc(sd, spec)
+    d, keep = make_desc(sd, spec, precision)
     blob, consts = _fp(), _fp()
     nb, nc = _sz(), _sz()
     check(lib().fenerf_pack_weights_host(C.byref(d), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc)))

@@ -44,7 +44,7 @@ static int out_channels(int C, const FenerfCompositeOpts* o) {
 static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t stream, bool allocate) {
   std::vector<float> blob, consts;
   std::string err;
-  int rc = pack_weights(d, blob, consts, err);
+  int rc = d->precision == FENERF_PREC_F16X3 ? pack_weights_f16(d, blob, consts, err) : pack_weights(d, blob, consts, err);
   if (rc) return fail(rc, err);
   if (allocate) {
     HIP_TRY(hipMalloc((void**)&m->d_stream, blob.size() * sizeof(float)));
@@ -91,6 +91,8 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   m->n_lab = d->output_dim - 4; m->L = d->n_geo + d->n_color;
   m->grid_ch = d->grid_ch; m->gd = d->grid_d; m->gh = d->grid_h; m->gw = d->grid_w;
   m->box_scale = d->box_scale;
+  m->precision = d->precision;
+  if (d->precision != FENERF_PREC_F32 && d->precision != FENERF_PREC_F16X3) { delete m; return fail(FENERF_E_INVALID, "unknown precision"); }
   m->sh = stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   int dev = 0;
   hipDeviceProp_t prop;
@@ -110,7 +112,7 @@ extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, voi
   int rc = validate_desc(d, err);
   if (rc) return fail(rc, err);
   if (d->hidden_dim != m->H || d->n_geo != m->n_geo || d->n_color != m->n_color || d->output_dim != m->C ||
-      d->grid_ch != m->grid_ch || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
+      d->grid_ch != m->grid_ch || d->precision != m->precision || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
     return fail(FENERF_E_INVALID, "fenerf_model_update: architecture differs from the created model");
   m->box_scale = d->box_scale;
   return upload_model(m, d, (hipStream_t)stream, false);

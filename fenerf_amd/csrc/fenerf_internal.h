@@ -13,6 +13,7 @@ namespace fenerf {
 void set_error(const std::string& msg);
 int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
+int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 
 }  // namespace fenerf
 
@@ -26,6 +27,7 @@ struct FenerfModel {
   float* d_consts;  // head bias | rgb bias | film biases
   float* d_grid;    // channels-last [D][H][W][32] or nullptr
   int num_cus;
+  int precision;    // FENERF_PREC_*
 };
 
 namespace fenerf {
@@ -69,7 +71,8 @@ struct CompositeParams {
 
 int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
                      float* fp, float* pp, void* stream);
-int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);
+int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
+int launch_siren16(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 kernel (fenerf_siren_f16.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);
 int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const float* w, const float* u, float* out, void* stream);

@@ -49,10 +49,48 @@ inline StreamShape stream_shape(int H, int n_geo, int n_color, bool grid) {
   return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// f16x3 mode (error-compensated fp16 MFMA): v_mfma_f32_32x32x16_f16, k-step = 16 features.
+// Each fp32 product w*x is evaluated as wh*xh + wh*xl + wl*xh with (h, l) = fp16 hi/lo splits of
+// (w * 2^e_layer) and (x * 16); the result is exact to ~2^-22 relative (fp32 class), accumulated in fp32.
+// An f16 entry = 64 lanes x 8 halves = the A operand of ONE k-step of one 32-row block; per k-step the
+// stream holds [hi entry, lo entry].  Lane (m, h) holds, for k-step s16 and slot t (0..7), the feature
+//      feat16_of(s16, h, t) = feat_of(16*(s16>>1) + 8*(s16&1) + t, h)
+// i.e. accumulator registers r = 8*(s16&1)+t of n-block s16>>1 (same C/D layout as the fp32 MFMA).
+constexpr int feat16_of(int s16, int h, int t) { return feat_of(16 * (s16 >> 1) + 8 * (s16 & 1) + t, h); }
+constexpr float F16_ACT_SCALE = 16.f;   // activations are carried as x*16 so the lo halves stay normal fp16
+
+struct StreamShape16 {
+  int H, NB, KS16, body_e, body_ep;  // k-steps of an H-wide input; entries per square body, padded
+  int c0_ks, c0_e, c0_ep;            // colour-layer-0 body
+  int l0_entries;
+  long long ring_entries;
+};
+
+inline StreamShape16 stream_shape16(int H, int n_geo, int n_color, bool grid) {
+  StreamShape16 s;
+  s.H = H; s.NB = H / 32; s.KS16 = H / 16;
+  s.body_e = 2 * s.KS16; s.body_ep = pad_pf(s.body_e);
+  s.c0_ks = s.KS16 + (grid ? 2 : 0) + 1;
+  s.c0_e = 2 * s.c0_ks; s.c0_ep = pad_pf(s.c0_e);
+  s.l0_entries = s.NB;
+  long long e = 0;
+  e += (long long)(n_geo - 1) * s.NB * s.body_ep;
+  e += (long long)s.NB * s.c0_ep;
+  e += s.body_ep;
+  e += (long long)(n_color - 1) * s.NB * s.body_ep;
+  e += s.body_ep;
+  e += FENERF_PF;
+  s.ring_entries = e;
+  return s;
+}
+
 // consts layout (floats): [0,32) head bias by head row, [32,36) rgb bias, [36, 36 + L*H) FiLM-layer biases
 constexpr int CONST_HEAD_BIAS = 0;
 constexpr int CONST_RGB_BIAS = 32;
 constexpr int CONST_FILM_BIAS = 36;
+// f16x3 mode appends after the FiLM biases: [L] per-FiLM-layer result scale 1/(2^e * 16) (1 for layer 0),
+// then head_inv_scale, rgb_inv_scale.
 
 }  // namespace fenerf
 #endif

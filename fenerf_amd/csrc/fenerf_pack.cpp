@@ -163,13 +163,171 @@ int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector
   return FENERF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// f16x3 packing (fenerf_layout.h "f16x3 mode")
+// ------------------------------------------------------------------------------------------------
+struct KStep16 { int col[2][8]; };   // source column per lane-half and slot, -1 = zero
+
+static inline uint16_t f16_bits(_Float16 v) { uint16_t b; memcpy(&b, &v, 2); return b; }
+
+// row_scale[row] (power of two) is applied before the hi/lo split; rows >= nrows are zero.
+static void emit_body16(std::vector<uint16_t>& out, const double* W, int nrows, int ncols, int r0,
+                        const std::vector<KStep16>& ks, int padded_entries, const std::vector<double>& row_scale) {
+  const int real = 2 * (int)ks.size();
+  for (int e = 0; e < padded_entries; ++e) {
+    const int s = e >> 1, lo = e & 1;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = r0 + (lane & 31), h = lane >> 5;
+      for (int t = 0; t < 8; ++t) {
+        uint16_t bits = 0;
+        if (e < real && row < nrows) {
+          const int col = ks[s].col[h][t];
+          if (col >= 0) {
+            const float w = (float)(W[(size_t)row * ncols + col] * row_scale[row]);   // exact: power-of-two scale
+            const _Float16 hi = (_Float16)w;
+            bits = lo ? f16_bits((_Float16)(w - (float)hi)) : f16_bits(hi);
+          }
+        }
+        out.push_back(bits);
+      }
+    }
+  }
+}
+
+// power of two s with max|row| * s in [0.5, 1)  (1 for an all-zero row)
+static std::vector<double> row_scales(const double* W, int nrows, int ncols) {
+  std::vector<double> sc(nrows, 1.0);
+  for (int r = 0; r < nrows; ++r) {
+    double m = 0;
+    for (int c = 0; c < ncols; ++c) m = std::fmax(m, std::fabs((double)(float)W[(size_t)r * ncols + c]));
+    if (m > 0) { int ex; std::frexp(m, &ex); sc[r] = std::ldexp(1.0, -ex); }
+  }
+  return sc;
+}
+
+int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err) {
+  int rc = validate_desc(d, err);
+  if (rc) return rc;
+  const int H = d->hidden_dim, n_lab = d->output_dim - 4;
+  const bool grid = d->grid_ch != 0;
+  const StreamShape16 sh = stream_shape16(H, d->n_geo, d->n_color, grid);
+  const int L = d->n_geo + d->n_color;
+  std::vector<float> l0;          // fp32 layer-0 block, identical to the f32 mode
+  {
+    auto W0 = to_f64(d->geo_w[0], (size_t)H * 3);
+    std::vector<KStep> ks = {{0, 1}, {2, -1}};
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(l0, W0.data(), H, 3, nb * 32, ks, 1);
+  }
+  std::vector<uint16_t> ring;
+  ring.reserve((size_t)sh.ring_entries * 512);
+  std::vector<float> inv_scale((size_t)L * H, 1.f), head_inv(32, 1.f), rgb_inv(4, 1.f);
+
+  auto x_ksteps = [&](int col_off) {
+    std::vector<KStep16> ks(H / 16);
+    for (int s = 0; s < H / 16; ++s)
+      for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 8; ++t) ks[s].col[h][t] = col_off + feat16_of(s, h, t);
+    return ks;
+  };
+  const double act = (double)F16_ACT_SCALE;
+  for (int l = 1; l < d->n_geo; ++l) {
+    auto W = to_f64(d->geo_w[l], (size_t)H * H);
+    auto sc = row_scales(W.data(), H, H);
+    for (int n = 0; n < H; ++n) inv_scale[(size_t)l * H + n] = (float)(1.0 / (sc[n] * act));
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, H, nb * 32, ks, sh.body_ep, sc);
+  }
+  {  // C0: [x | grid feats | dir]; lane-half h holds grid channels 16h..16h+15: k-step j slot t <-> channel 16h + 8j + t
+    const int cin = 3 + d->grid_ch + H;
+    auto W = to_f64(d->color_w[0], (size_t)H * cin);
+    auto sc = row_scales(W.data(), H, cin);
+    for (int n = 0; n < H; ++n) inv_scale[(size_t)d->n_geo * H + n] = (float)(1.0 / (sc[n] * act));
+    auto ks = x_ksteps(3 + d->grid_ch);
+    if (grid)
+      for (int j = 0; j < 2; ++j) {
+        KStep16 k;
+        for (int h = 0; h < 2; ++h) for (int t = 0; t < 8; ++t) k.col[h][t] = 3 + 16 * h + 8 * j + t;
+        ks.push_back(k);
+      }
+    KStep16 kd;
+    for (int h = 0; h < 2; ++h) for (int t = 0; t < 8; ++t) kd.col[h][t] = (h == 0 && t < 3) ? t : -1;
+    ks.push_back(kd);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, cin, nb * 32, ks, sh.c0_ep, sc);
+  }
+  std::vector<double> head_b(32, 0.0);
+  {  // HEAD: folded label rows + sigma row, per-row scaled (label and sigma magnitudes differ by orders)
+    std::vector<float> tmp_blob, tmp_consts;
+    std::vector<double> Wh((size_t)32 * H, 0.0);
+    if (n_lab > 0) {
+      int rows = (d->n_label_layers == 1) ? n_lab : H;
+      std::vector<double> A = to_f64(d->label_w[0], (size_t)rows * H), c = to_f64(d->label_b[0], rows);
+      for (int i = 1; i < d->n_label_layers; ++i) {
+        const int orow = (i == d->n_label_layers - 1) ? n_lab : H;
+        auto Wi = to_f64(d->label_w[i], (size_t)orow * rows);
+        auto bi = to_f64(d->label_b[i], orow);
+        std::vector<double> A2((size_t)orow * H, 0.0), c2(orow, 0.0);
+        for (int o = 0; o < orow; ++o) {
+          double cb = bi[o];
+          for (int k = 0; k < rows; ++k) {
+            const double w = Wi[(size_t)o * rows + k];
+            cb += w * c[k];
+            for (int x = 0; x < H; ++x) A2[(size_t)o * H + x] += w * A[(size_t)k * H + x];
+          }
+          c2[o] = cb;
+        }
+        A.swap(A2); c.swap(c2); rows = orow;
+      }
+      for (int o = 0; o < n_lab; ++o) {
+        for (int x = 0; x < H; ++x) Wh[(size_t)o * H + x] = A[(size_t)o * H + x];
+        head_b[o] = c[o];
+      }
+    }
+    for (int x = 0; x < H; ++x) Wh[(size_t)n_lab * H + x] = d->sigma_w[x];
+    head_b[n_lab] = d->sigma_b[0];
+    auto sc = row_scales(Wh.data(), 32, H);
+    for (int r = 0; r < 32; ++r) head_inv[r] = (float)(1.0 / (sc[r] * act));
+    emit_body16(ring, Wh.data(), 32, H, 0, x_ksteps(0), sh.body_ep, sc);
+  }
+  for (int l = 1; l < d->n_color; ++l) {
+    auto W = to_f64(d->color_w[l], (size_t)H * H);
+    auto sc = row_scales(W.data(), H, H);
+    for (int n = 0; n < H; ++n) inv_scale[(size_t)(d->n_geo + l) * H + n] = (float)(1.0 / (sc[n] * act));
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, H, nb * 32, ks, sh.body_ep, sc);
+  }
+  {
+    auto W = to_f64(d->rgb_w, (size_t)3 * H);
+    auto sc = row_scales(W.data(), 3, H);
+    for (int r = 0; r < 3; ++r) rgb_inv[r] = (float)(1.0 / (sc[r] * act));
+    emit_body16(ring, W.data(), 3, H, 0, x_ksteps(0), sh.body_ep, sc);
+  }
+  ring.insert(ring.end(), (size_t)FENERF_PF * 512, 0);
+  if (ring.size() != (size_t)sh.ring_entries * 512) { err = "internal: f16 stream size mismatch"; return FENERF_E_INVALID; }
+  blob = l0;
+  const size_t off = blob.size();
+  blob.resize(off + ring.size() / 2);
+  memcpy(&blob[off], ring.data(), ring.size() * 2);
+
+  consts.assign((size_t)CONST_FILM_BIAS + (size_t)2 * L * H + 36, 0.f);
+  for (int i = 0; i < 32; ++i) consts[CONST_HEAD_BIAS + i] = (float)head_b[i];
+  for (int i = 0; i < 3; ++i) consts[CONST_RGB_BIAS + i] = d->rgb_b[i];
+  for (int l = 0; l < d->n_geo; ++l) memcpy(&consts[CONST_FILM_BIAS + (size_t)l * H], d->geo_b[l], sizeof(float) * H);
+  for (int l = 0; l < d->n_color; ++l) memcpy(&consts[CONST_FILM_BIAS + (size_t)(d->n_geo + l) * H], d->color_b[l], sizeof(float) * H);
+  float* sc_out = &consts[CONST_FILM_BIAS + (size_t)L * H];
+  memcpy(sc_out, inv_scale.data(), sizeof(float) * (size_t)L * H);
+  memcpy(sc_out + (size_t)L * H, head_inv.data(), sizeof(float) * 32);
+  memcpy(sc_out + (size_t)L * H + 32, rgb_inv.data(), sizeof(float) * 4);
+  return FENERF_OK;
+}
+
 }  // namespace fenerf
 
 extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats, float** consts,
                                         size_t* n_consts) {
   std::vector<float> b, c;
   std::string err;
-  int rc = fenerf::pack_weights(desc, b, c, err);
+  int rc = (desc && desc->precision == FENERF_PREC_F16X3) ? fenerf::pack_weights_f16(desc, b, c, err)
+                                                          : fenerf::pack_weights(desc, b, c, err);
   if (rc) { fenerf::set_error(err); return rc; }
   if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
   *blob = (float*)malloc(b.size() * sizeof(float));

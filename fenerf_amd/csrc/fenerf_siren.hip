@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 // The '*15 + 30' itself is done in fp32 with separate mul and add exactly like siren.py:1510-1511.
 // ------------------------------------------------------------------------------------------------
 __global__ void film_prep_kernel(int B, int H, int n_geo, int n_color, const float* fg, const float* pg, const float* fa,
-                                 const float* pa, const float* bias /* [L][H] */, float* fp, float* pp) {
+                                 const float* pa, const float* bias /* [L][H] */, const float* inv_scale /* [L][H] or null */,
+                                 float* fp, float* pp) {
   const int L = n_geo + n_color;
   const long long total = (long long)B * L * H;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -338,7 +339,9 @@ __global__ void film_prep_kernel(int B, int H, int n_geo, int n_color, const flo
     else { fr = fa[(b * n_color + (l - n_geo)) * H + n]; ph = pa[(b * n_color + (l - n_geo)) * H + n]; }
     const float f = __fadd_rn(__fmul_rn(fr, 15.f), 30.f);
     const double inv2pi = 0.15915494309189533576888;
-    fp[i] = (float)((double)f * inv2pi);
+    // f16x3 mode: fold the (power-of-two, exact) result scale of the layer's GEMM into the frequency
+    const double sc = inv_scale ? (double)inv_scale[l * H + n] : 1.0;
+    fp[i] = (float)((double)f * inv2pi * sc);
     pp[i] = (float)(((double)f * (double)bias[l * H + n] + (double)ph) * inv2pi);
   }
 }
@@ -362,7 +365,8 @@ int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* 
   const long long total = (long long)B * m->L * m->H;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(film_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, m->H, m->n_geo, m->n_color, fg,
-                     pg, fa, pa, m->d_consts + CONST_FILM_BIAS, fp, pp);
+                     pg, fa, pa, m->d_consts + CONST_FILM_BIAS,
+                     m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr, fp, pp);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail(e, "film_prep launch");
 }
@@ -396,6 +400,7 @@ static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stre
 
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
+  if (m->precision == FENERF_PREC_F16X3) return launch_siren16(m, p, stream);
   const bool g = m->grid_ch != 0;
   switch (m->H) {
     case 32: return g ? launch_siren_t<32, true>(m, p, stream) : launch_siren_t<32, false>(m, p, stream);

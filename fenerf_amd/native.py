@@ -25,21 +25,22 @@ def _f32(t, device):
 class NativeModel:
     """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
 
-    def __init__(self, sd, spec, device):
+    def __init__(self, sd, spec, device, precision="f32"):
         self.spec = dict(spec)
+        self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % device)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, spec)
+            d, keep = _lib.make_desc(sd, spec, precision)
             _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
         self.C = spec["output_dim"]
         self._ws = {}
 
     def update(self, sd):
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, self.spec)
+            d, keep = _lib.make_desc(sd, self.spec, self.precision)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
 
     def close(self):

@@ -85,6 +85,7 @@ class _NativeSiren(nn.Module):
     KIND = None
     N_LABEL_LAYERS = 0
     GRID_CH = 0
+    precision = "f32"   # "f32": exact fp32 MFMA; "f16x3": error-compensated fp16 MFMA (fp32-class accuracy, ~4x faster)
 
     def _spec(self):
         H = self.hidden_dim
@@ -105,8 +106,8 @@ class _NativeSiren(nn.Module):
         device = torch.device(device if device is not None else params[0].device)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_model")
-        if nat is None or nat.device != device:
-            nat = native.NativeModel(self._state_numpy(), self._spec(), device)
+        if nat is None or nat.device != device or nat.precision != self.precision:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision)
             self.__dict__["_native_model"] = nat
         elif self.__dict__.get("_native_version") != ver:
             nat.update(self._state_numpy())

@@ -35,6 +35,9 @@ enum {
   FENERF_E_CLAMP_MODE = -5   /* reference raises TypeError("Need to choose clamp mode"), volumetric_rendering.py:34 */
 };
 
+/* arithmetic of the dense layers inside the SIREN kernel */
+enum { FENERF_PREC_F32 = 0, FENERF_PREC_F16X3 = 1 };
+
 /* clamp_mode of fancy_integration (volumetric_rendering.py:29-34) */
 enum { FENERF_CLAMP_RELU = 1, FENERF_CLAMP_SOFTPLUS = 2 };
 
@@ -73,6 +76,8 @@ typedef struct FenerfModelDesc {
   const float* sigma_w; const float* sigma_b;   /* final_layer         [1][H]  */
   const float* rgb_w;   const float* rgb_b;     /* color_layer_linear[0] [3][H]  */
   const float* grid;        /* [host] spatial_embeddings or NULL */
+  int32_t precision;        /* FENERF_PREC_F32 (exact fp32 MFMA) or FENERF_PREC_F16X3 (error-compensated fp16 MFMA,
+                               3 MFMAs per product, fp32-class accuracy, ~2^-22 relative per product) */
 } FenerfModelDesc;
 
 typedef struct FenerfModel FenerfModel;

@@ -33,12 +33,20 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
+PRECISIONS = ["f32", "f16x3"]   # exact fp32 MFMA / error-compensated fp16 MFMA (3 MFMAs per product)
+
+
 @functools.lru_cache(maxsize=None)
-def _native_for(name):
+def _weights_for(name):
     g = load_golden(name)
     spec = spec_from_golden(g)
-    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]), with_mapping=False)
-    return native.NativeModel(sd, spec, DEV), spec, sd
+    return spec, proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]), with_mapping=False)
+
+
+@functools.lru_cache(maxsize=None)
+def _native_for(name, precision="f32"):
+    spec, sd = _weights_for(name)
+    return native.NativeModel(sd, spec, DEV, precision), spec, sd
 
 
 def _film(g, spec):
@@ -65,11 +73,13 @@ def test_native_library_is_loaded():
 # ---------------------------------------------------------------------------------------------------
 # a8-a12: SIREN kernel vs reference outputs (teacher-forced points)
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n12",
                                   "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
-def test_siren_forward_vs_reference(name):
+def test_siren_forward_vs_reference(name, precision):
     g = load_golden(name)
-    nat, spec, sd = _native_for(name)
+    nat, spec, sd = _native_for(name, precision)
+    name = f"{name}[{precision}]"
     film, tf = _film(g, spec)
     B, R, N = g["st_z_coarse"].shape[:3]
     pts = g["st_points"].reshape(B, R * N, 3)
@@ -91,11 +101,12 @@ def test_siren_forward_vs_reference(name):
     np.testing.assert_allclose(out[:, :512, -4:-1], o64[..., -4:-1], atol=5e-5)
 
 
-def test_siren_rays_mode_lock_view_and_ragged_tiles():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_siren_rays_mode_lock_view_and_ragged_tiles(precision):
     """points generated in-kernel from (o, d, z); lock_view_dependence; P not a multiple of the 32-point tile;
     tiles straddling image boundaries; tile-independence (bit-exact sub-batch)."""
     g = load_golden("tiny_texture_fwd")
-    nat, spec, sd = _native_for("tiny_texture_fwd")
+    nat, spec, sd = _native_for("tiny_texture_fwd", precision)
     film, tf = _film(g, spec)
     B, R, N = g["st_z_coarse"].shape[:3]
     o, d, z = T(g["st_origins"]), T(g["st_dirs"]), T(g["st_z_coarse"][..., 0])
@@ -126,10 +137,11 @@ def test_siren_rays_mode_lock_view_and_ragged_tiles():
     assert e.shape == (2, 0, 22)
 
 
-def test_siren_single_latent_spatial_model():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_siren_single_latent_spatial_model(precision):
     spec = proc.model_spec("spatial", hidden_dim=64, z_dim=8)
     sd = proc.make_state_dict(spec, seed=21, sigma_gain=100.0, with_mapping=False)
-    nat = native.NativeModel(sd, spec, DEV)
+    nat = native.NativeModel(sd, spec, DEV, precision)
     rng = np.random.default_rng(3)
     pts = rng.uniform(-0.12, 0.12, (2, 77, 3)).astype(np.float32)
     dirs = rng.normal(size=(2, 77, 3)).astype(np.float32)
@@ -239,7 +251,7 @@ def test_merge_composite_vs_reference(name):
 # ---------------------------------------------------------------------------------------------------
 # a15-a17: the generator API end to end, teacher-forced with the reference's recorded random draws
 # ---------------------------------------------------------------------------------------------------
-def _make_generator(g, spec):
+def _make_generator(g, spec, precision="f32"):
     H = spec["hidden_dim"]
     cls = {"texture": S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, "baseline": S.SIRENBASELINESEMANTICDISENTANGLE}[spec["kind"]]
     gen = G.DoubleImplicitGenerator3d(functools.partial(cls, hidden_dim=H), spec.get("z_dim", 256), spec.get("z_dim", 256), 22)
@@ -250,6 +262,7 @@ def _make_generator(g, spec):
         gen.siren.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
     gen.siren.load_state_dict(tsd, strict=True)
     gen = gen.to(DEV).eval()
+    gen.siren.precision = precision
     gen.device = torch.device(DEV)
     gen.siren.device = gen.device
     return gen
@@ -268,12 +281,14 @@ def _e2e_check(tag, px, ref_px, tol=1e-3, max_bad_frac=0.03):
     return bad
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "h256_texture_16x16_n12",
                                   "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
-def test_forward_with_frequencies_vs_reference(name):
+def test_forward_with_frequencies_vs_reference(name, precision):
     g = load_golden(name)
     spec = spec_from_golden(g)
-    gen = _make_generator(g, dict(spec, z_dim=16 if spec["hidden_dim"] == 32 else 256))
+    gen = _make_generator(g, dict(spec, z_dim=16 if spec["hidden_dim"] == 32 else 256), precision)
+    name = f"{name}[{precision}]"
     film, tf = _film(g, spec)
     hier = bool(g["meta_hier"])
     seq = [g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"]]
@@ -350,10 +365,16 @@ def test_forward_and_staged_forward_from_latents():
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json sizes: size-independent properties + oracle spot check on a ray subset
 # ---------------------------------------------------------------------------------------------------
-def test_full_size_128_24p24_properties_and_oracle_subset():
+@functools.lru_cache(maxsize=None)
+def _full_weights():
     spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
-    sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
-    nat = native.NativeModel(sd, spec, DEV)
+    return spec, proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_128_24p24_properties_and_oracle_subset(precision):
+    spec, sd = _full_weights()
+    nat = native.NativeModel(sd, spec, DEV, precision)
     B, S_, N = 1, 128, 24
     R = S_ * S_
     film = proc.film_params(spec, B, seed=0)
@@ -394,6 +415,6 @@ def test_full_size_128_24p24_properties_and_oracle_subset():
     r_rgb, r_depth, r_w = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color="white")
     err = np.abs(rgb[:, idx] - r_rgb).max(-1)
     bad = err > 1e-3
-    print(f"[parity] 128x128 24+24 H=256 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
+    print(f"[parity] 128x128 24+24 H=256 [{precision}] vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
     assert bad.mean() <= 0.03
     np.testing.assert_allclose(depth[:, idx][~bad], r_depth[..., 0][~bad], atol=5e-4)
