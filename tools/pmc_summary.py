@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
     per_dispatch = defaultdict(dict)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "siren_kernel" not in row.get("Kernel_Name", ""):
+            if "siren" not in row.get("Kernel_Name", "") or "_kernel" not in row.get("Kernel_Name", ""):
                 continue
             per_dispatch[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
     for d, cs in per_dispatch.items():
