@@ -128,7 +128,8 @@ extern "C" void fenerf_model_destroy(FenerfModel* m) {
 
 extern "C" size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B) {
   if (!m || B <= 0) return 0;
-  return align_up((size_t)2 * B * m->L * m->H * sizeof(float), 256);
+  // + 1 KiB: the shared-stream kernel fetches FiLM parameters with whole-KiB LDS-DMA transfers
+  return align_up((size_t)2 * B * m->L * m->H * sizeof(float) + 1024, 256);
 }
 
 static int film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
