@@ -27,6 +27,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 1_603_584          # SURVEY.md §8(d) / BASELINE.md §4 (dense layers, 2 FLOP per MAC)
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+# HBM bytes per siren launch at this workload from rocprofv3 PMC passes (profiles/r01_pmc_*.txt): FETCH_SIZE 173 MiB-equivalent
+# KiB counter (x1024, uncorrected; dominated by the scattered grid gather) + WRITE_SIZE 34.6 MB.  MFMA-bound kernel: context only.
+TRAFFIC_BYTES_PER_LAUNCH = int(177.07e6 + 34.60e6)
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA (v_mfma_f32_32x32x16_f16)
 
 
 def cpu_baseline(spec, sd, film, seed):
@@ -57,7 +61,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="arithmetic of the dense layers: exact fp32 MFMA, or error-compensated fp16 MFMA (fp32-class accuracy)")
     args = ap.parse_args()
 
@@ -115,18 +119,28 @@ def main():
         pts = B * R * N
         k_ms = nat.time_siren_rays(o, d, z, *tf, iters=max(5, args.steps // 2))
         achieved = pts * FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
+        if args.precision == "f32":
+            peak, dtype = PEAK_FP32_MATRIX_TFLOPS, "f32"
+            kname, mfma = "siren_kernel<256,true>", "v_mfma_f32_32x32x2_f32 (exact fp32)"
+            extra = {}
+        else:
+            # every algorithmic product is evaluated as 3 fp16 MFMAs (wh*xh + wh*xl + wl*xh, fp32 accumulate): the attainable
+            # ceiling of this algorithm on the fp16 pipe is peak/3; `frac` is quoted against the full dense fp16 peak.
+            peak, dtype = PEAK_F16_MATRIX_TFLOPS, "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
+            kname, mfma = "siren16s_kernel<256,true>", "v_mfma_f32_32x32x16_f16, 3 per product"
+            extra = {"frac_of_f16x3_ceiling": achieved / (peak / 3)}
         out = {
             "metric": "rays/s/GPU forward render (128x128, 24+24 samples, H=256 FiLM-SIREN + 32x96^3 grid)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"configs[1]: CelebA_double_semantic_texture_embedding_256_dim_96 generator, {S}x{S}, "
                                    f"{N}+{N} hierarchical samples, batch {B}/GPU, forward-only render, procedural weights",
                        "img_size": S, "num_steps": N, "batch_per_gpu": B, "sharding": "by image, no collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                         "kernel": "siren_kernel<256,true>", "kernel_ms": k_ms, "points_per_launch": pts,
-                         "flop_per_point_algorithmic": FLOP_PER_POINT, "mfma": "v_mfma_f32_32x32x2_f32 (exact fp32)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                         "kernel": kname, "kernel_ms": k_ms, "points_per_launch": pts,
+                         "flop_per_point_algorithmic": FLOP_PER_POINT, "mfma": mfma, **extra},
             "rays_per_s_per_gpu": value / world,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfenerf_hip.so")
+LIB_PATH = os.environ.get("FENERF_LIB", os.path.join(_HERE, "libfenerf_hip.so"))   # FENERF_LIB: kernel A/B experiments only
 
 ABI_VERSION = 1
 MAX_GEO, MAX_COLOR, MAX_LABEL = 8, 4, 3

@@ -93,17 +93,28 @@ struct AK { float4 hi, lo; };
 __device__ __forceinline__ AK ws_read_k(const WStream& w, int slot, int j, int lane) {
   const float4* p = reinterpret_cast<const float4*>(w.ring + slot * (CH * 1024)) + lane;
   AK a;
+#ifdef EXP_NOLDSREAD
+  a.hi = make_float4(1e-3f * lane, 2e-3f, 3e-3f, 4e-3f); a.lo = a.hi;
+  asm volatile("" : "+v"(a.hi.x), "+v"(a.lo.y));
+#else
   a.hi = p[(2 * j) * 64];
   a.lo = p[(2 * j + 1) * 64];
+#endif
   return a;
 }
 
 // Top of a pipeline step: issue chunk c+D, make chunk c+1 visible to every wave.  The A operands are then read one
 // k-step ahead of their MFMAs (two KiB in registers, not a whole chunk).
 __device__ __forceinline__ void ws_step(WStream& w) {
+#ifndef EXP_NODMA
   ws_issue(w);
+#endif
+#ifndef EXP_NOWAIT
   WAIT_VMCNT(2 * (DPF - 1));          // this wave's quarter of the next chunk has landed (loads retire in order)
+#endif
+#ifndef EXP_NOBARRIER
   __builtin_amdgcn_s_barrier();       // ... and every other wave's quarter
+#endif
   LDS_FENCE();
 }
 __device__ __forceinline__ void ws_advance(WStream& w) {
@@ -125,42 +136,72 @@ __device__ __forceinline__ void put4(half8& dst, const half4& v, int q /* 0: slo
   else        { dst[4] = v[0]; dst[5] = v[1]; dst[6] = v[2]; dst[7] = v[3]; }
 }
 
-// FiLM epilogue, quarter Q (registers 4Q..4Q+3) of n-block NBP: 16 sin(2 pi (f'' acc + p')) -> (hi, lo) halves of
-// k-step 2*NBP + (Q>>1), slots 4*(Q&1)..+3 of the output activation registers.  f'', p' come from the LDS film buffer.
+// FiLM epilogue of one quarter (accumulator registers 4q..4q+3 of n-block nbp), cut into four pieces that are issued
+// behind the four k-steps of a chunk step: each piece is <= 8 VALU slots, which fit under the 32 cycles the k-step's last
+// MFMA is still executing (a wave issues in order, so VALU placed after a dependent MFMA chain overlaps only its tail).
+//   piece 0: 16 sin(2 pi (f'' acc + p')) for values 0,1      piece 1: values 2,3
+//   piece 2: hi = rn_f16(v), remainder v - hi                  piece 3: lo = rn_f16(remainder); store
+// Outputs are the (hi, lo) halves of k-step 2*nbp + (q>>1), slots 4*(q&1)..+3: the first NBL n-blocks' outputs wait
+// in the wave's LDS slab (unit (2*ks + which) = 64 lanes x 16 B), the rest in the y registers.
+struct EpiQ {
+  float4 f, p;
+  float v[4];
+  float r[4];
+  half4 hi;
+};
+__device__ __forceinline__ void epi_load(EpiQ& e, int nbp, int q, const float* film_f, const float* film_p) {
+  e.f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);   // + 4*h folded into the pointer
+  e.p = *reinterpret_cast<const float4*>(film_p + 32 * nbp + 8 * q);
+}
+__device__ __forceinline__ void epi_p0(EpiQ& e, const f32x16& acc, int q) {
+  e.v[0] = __builtin_amdgcn_sinf(__builtin_fmaf(e.f.x, acc[4 * q + 0], e.p.x)) * F16_ACT_SCALE;
+  e.v[1] = __builtin_amdgcn_sinf(__builtin_fmaf(e.f.y, acc[4 * q + 1], e.p.y)) * F16_ACT_SCALE;
+}
+__device__ __forceinline__ void epi_p1(EpiQ& e, const f32x16& acc, int q) {
+  e.v[2] = __builtin_amdgcn_sinf(__builtin_fmaf(e.f.z, acc[4 * q + 2], e.p.z)) * F16_ACT_SCALE;
+  e.v[3] = __builtin_amdgcn_sinf(__builtin_fmaf(e.f.w, acc[4 * q + 3], e.p.w)) * F16_ACT_SCALE;
+}
+__device__ __forceinline__ void epi_p2(EpiQ& e) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const _Float16 h = (_Float16)e.v[t];
+    e.hi[t] = h;
+    e.r[t] = e.v[t] - (float)h;
+  }
+}
+template <int KS, int NBL>
+__device__ __forceinline__ void epi_p3(EpiQ& e, int nbp, int q, half8 (&yh)[KS], half8 (&yl)[KS], char* slab) {
+  half4 lo;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) lo[t] = (_Float16)e.r[t];
+  const int ks = 2 * nbp + (q >> 1);
+  if (nbp < NBL) {
+    *reinterpret_cast<half4*>(slab + (2 * ks + 0) * 1024 + (q & 1) * 8) = e.hi;
+    *reinterpret_cast<half4*>(slab + (2 * ks + 1) * 1024 + (q & 1) * 8) = lo;
+  } else {
+    put4(yh[ks], e.hi, q & 1);
+    put4(yl[ks], lo, q & 1);
+  }
+}
+// whole quarter at once (layer tails, layer 0, small-H bodies)
+template <int KS, int NBL>
+__device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
+                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab) {
+  EpiQ e;
+  epi_load(e, nbp, q, film_f, film_p);
+  epi_p0(e, acc, q);
+  epi_p1(e, acc, q);
+  epi_p2(e);
+  epi_p3<KS, NBL>(e, nbp, q, yh, yl, slab);
+}
+// layer 0 writes straight into x (nothing is reading it yet)
 template <int KS>
 __device__ __forceinline__ void epi_quarter(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
                                             half8 (&yh)[KS], half8 (&yl)[KS]) {
-  const float4 f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);   // + 4*h folded into the pointer
-  const float4 p = *reinterpret_cast<const float4*>(film_p + 32 * nbp + 8 * q);
-  float v[4];
-  v[0] = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[4 * q + 0], p.x)) * F16_ACT_SCALE;
-  v[1] = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[4 * q + 1], p.y)) * F16_ACT_SCALE;
-  v[2] = __builtin_amdgcn_sinf(__builtin_fmaf(f.z, acc[4 * q + 2], p.z)) * F16_ACT_SCALE;
-  v[3] = __builtin_amdgcn_sinf(__builtin_fmaf(f.w, acc[4 * q + 3], p.w)) * F16_ACT_SCALE;
-  half4 hi, lo;
-  split4(v, hi, lo);
-  put4(yh[2 * nbp + (q >> 1)], hi, q & 1);
-  put4(yl[2 * nbp + (q >> 1)], lo, q & 1);
+  epi_route<KS, 0>(acc, nbp, q, film_f, film_p, yh, yl, nullptr);
 }
 
-// Same, for the n-blocks whose outputs are parked in the wave's LDS slab: unit (2*ks + which) holds 64 lanes x 16 B.
-__device__ __forceinline__ void epi_quarter_lds(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                                char* slab /* + lane*16 */) {
-  const float4 f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);
-  const float4 p = *reinterpret_cast<const float4*>(film_p + 32 * nbp + 8 * q);
-  float v[4];
-  v[0] = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[4 * q + 0], p.x)) * F16_ACT_SCALE;
-  v[1] = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[4 * q + 1], p.y)) * F16_ACT_SCALE;
-  v[2] = __builtin_amdgcn_sinf(__builtin_fmaf(f.z, acc[4 * q + 2], p.z)) * F16_ACT_SCALE;
-  v[3] = __builtin_amdgcn_sinf(__builtin_fmaf(f.w, acc[4 * q + 3], p.w)) * F16_ACT_SCALE;
-  half4 hi, lo;
-  split4(v, hi, lo);
-  const int ks = 2 * nbp + (q >> 1);
-  *reinterpret_cast<half4*>(slab + (2 * ks + 0) * 1024 + (q & 1) * 8) = hi;
-  *reinterpret_cast<half4*>(slab + (2 * ks + 1) * 1024 + (q & 1) * 8) = lo;
-}
-
-// 4 k-steps (one chunk) of hi/lo MFMAs: entries [hi0, lo0, hi1, lo1, hi2, lo2, hi3, lo3]
+// 3 MFMAs of one k-step: wl*xh + wh*xl + wh*xh
 #define KSTEP_MFMA(acc, ak, bh, bl)                  \
   do {                                               \
     (acc) = MFMA16(as_half8((ak).lo), (bh), (acc));  \
@@ -169,17 +210,20 @@ __device__ __forceinline__ void epi_quarter_lds(const f32x16& acc, int nbp, int 
   } while (0)
 
 // One chunk step: barrier (next chunk visible), then 4 k-steps.  bop(k, bh, bl) supplies the B operands of k-step k
-// (false = padding k-step); a_cur holds the A operands of the chunk's first k-step on entry and of the NEXT chunk's
-// first k-step on exit: A operands are read from the LDS ring exactly one k-step (96 MFMA cycles) ahead of use.
-template <class BOP>
-__device__ __forceinline__ void chunk_step(f32x16& acc, AK& a_cur, WStream& ws, int lane, int k0, BOP bop) {
+// (false = padding k-step); piece(j) is the epilogue piece issued behind k-step j.  a_cur holds the A operands of the
+// chunk's first k-step on entry and of the NEXT chunk's first k-step on exit: A operands are read from the LDS ring
+// exactly one k-step (96 MFMA cycles) ahead of use.
+template <class BOP, class PIECE>
+__device__ __forceinline__ void chunk_step(f32x16& acc, AK& a_cur, WStream& ws, int lane, int k0, BOP bop, PIECE piece) {
   ws_step(ws);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const AK a_nxt = (j < 3) ? ws_read_k(ws, ws.sc, j + 1, lane) : ws_read_k(ws, ws.sn, 0, lane);
     half8 bh, bl;
     if (bop(k0 + j, bh, bl)) KSTEP_MFMA(acc, a_cur, bh, bl);
+    piece(j);
     a_cur = a_nxt;
+    __builtin_amdgcn_sched_barrier(0);
   }
   ws_advance(ws);
 }
@@ -188,14 +232,6 @@ template <int KS>
 __device__ __forceinline__ void copy_act(half8 (&dh)[KS], half8 (&dl)[KS], const half8 (&sh)[KS], const half8 (&sl)[KS]) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) { dh[s] = sh[s]; dl[s] = sl[s]; }
-}
-
-// Epilogue quarter q of n-block nbp: outputs of the first NBL n-blocks go to the LDS slab, the rest to y registers.
-template <int KS, int NBL>
-__device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab) {
-  if (nbp < NBL) epi_quarter_lds(acc, nbp, q, film_f, film_p, slab);
-  else epi_quarter<KS>(acc, nbp, q, film_f, film_p, yh, yl);
 }
 
 // Layer end: x <- outputs (first 2*NBL k-steps from the slab, the rest from y).
@@ -233,12 +269,20 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int qc = 0; qc < QB; ++qc) {
-      chunk_step(acc, a_cur, ws, lane, 4 * qc, bop);
-      if (nb > 0) {   // FiLM epilogue of the previous n-block, interleaved with this chunk's MFMAs by the scheduler
-#pragma unroll
-        for (int e = 0; e < EQ; ++e) epi_route<KS, NBL>(acc_prev, nb - 1, qc * EQ + e, film_f, film_p, yh, yl, slab);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      // FiLM epilogue of the previous n-block, one quarter per chunk step (QB == 4), piece-wise behind the k-steps
+      EpiQ eq;
+      const bool fine = nb > 0 && EQ == 1;
+      if (fine) epi_load(eq, nb - 1, qc, film_f, film_p);
+      chunk_step(acc, a_cur, ws, lane, 4 * qc, bop, [&](int j) {
+        if (fine) {
+          if (j == 0) epi_p0(eq, acc_prev, qc);
+          else if (j == 1) epi_p1(eq, acc_prev, qc);
+          else if (j == 2) epi_p2(eq);
+          else epi_p3<KS, NBL>(eq, nb - 1, qc, yh, yl, slab);
+        } else if (nb > 0 && j < EQ) {
+          epi_route<KS, NBL>(acc_prev, nb - 1, qc * EQ + j, film_f, film_p, yh, yl, slab);
+        }
+      });
     }
     acc_prev = acc;
   }
@@ -259,8 +303,7 @@ __device__ __forceinline__ void head_body_s(f32x16& acc, const half8 (&xh)[H / 1
   };
 #pragma unroll
   for (int qc = 0; qc < QB; ++qc) {
-    chunk_step(acc, a_cur, ws, lane, 4 * qc, bop);
-    __builtin_amdgcn_sched_barrier(0);
+    chunk_step(acc, a_cur, ws, lane, 4 * qc, bop, [](int) {});
   }
 }
 
@@ -443,13 +486,21 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
           f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int qc = 0; qc < C0_QB; ++qc) {
-            chunk_step(acc, a_cur, ws, lane, 4 * qc, bop0);
-            if (nb > 0 && qc < 4) epi_route<KS, NBL>(acc_prev, nb - 1, qc, ff, fq, yh, yl, slab);
+            EpiQ eq;
+            const bool fine = nb > 0 && qc < 4;
+            if (fine) epi_load(eq, nb - 1, qc, ff, fq);
+            chunk_step(acc, a_cur, ws, lane, 4 * qc, bop0, [&](int j) {
+              if (fine) {
+                if (j == 0) epi_p0(eq, acc_prev, qc);
+                else if (j == 1) epi_p1(eq, acc_prev, qc);
+                else if (j == 2) epi_p2(eq);
+                else epi_p3<KS, NBL>(eq, nb - 1, qc, yh, yl, slab);
+              }
+            });
             if (nb > 0 && C0_QB < 4 && qc == C0_QB - 1) {
 #pragma unroll
               for (int q = C0_QB; q < 4; ++q) epi_route<KS, NBL>(acc_prev, nb - 1, q, ff, fq, yh, yl, slab);
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
           acc_prev = acc;
         }
