@@ -72,7 +72,6 @@ struct CompositeParams {
 int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
                      float* fp, float* pp, void* stream);
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
-int launch_siren16(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3, per-wave weight stream (fenerf_siren_f16.hip)
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);

@@ -60,11 +60,22 @@ inline StreamShape stream_shape(int H, int n_geo, int n_color, bool grid) {
 constexpr int feat16_of(int s16, int h, int t) { return feat_of(16 * (s16 >> 1) + 8 * (s16 & 1) + t, h); }
 constexpr float F16_ACT_SCALE = 16.f;   // activations are carried as x*16 so the lo halves stay normal fp16
 
+// Workgroup-shared stream geometry (fenerf_siren_f16s.hip): chunks of FENERF_CH entries travel through an LDS ring of
+// FENERF_NSLOT slots, FENERF_DPF chunks ahead of the consumer.  Every STAGE (a layer's n-block bodies) is padded to a
+// whole number of ring revolutions, so every stage starts at ring slot 0 and all slot indices are compile-time constants;
+// the first FENERF_DPF chunks are replicated after the end, so the prefetch pointer never wraps inside a tile.
+#define FENERF_CH 8
+#define FENERF_NSLOT 8
+#define FENERF_DPF 6
+constexpr int pad_stage(int entries) { return (entries + FENERF_CH * FENERF_NSLOT - 1) / (FENERF_CH * FENERF_NSLOT) * (FENERF_CH * FENERF_NSLOT); }
+
 struct StreamShape16 {
-  int H, NB, KS16, body_e, body_ep;  // k-steps of an H-wide input; entries per square body, padded
+  int H, NB, KS16, body_e, body_ep;  // k-steps of an H-wide input; entries per square body, padded to whole chunks
   int c0_ks, c0_e, c0_ep;            // colour-layer-0 body
+  int sq_stage_e, c0_stage_e, head_stage_e;   // entries per stage incl. stage padding
   int l0_entries;
-  long long ring_entries;
+  long long tile_entries;            // entries one tile consumes (= nchunk * FENERF_CH)
+  long long ring_entries;            // tile_entries + replicated head (FENERF_DPF chunks)
 };
 
 inline StreamShape16 stream_shape16(int H, int n_geo, int n_color, bool grid) {
@@ -73,15 +84,18 @@ inline StreamShape16 stream_shape16(int H, int n_geo, int n_color, bool grid) {
   s.body_e = 2 * s.KS16; s.body_ep = pad_pf(s.body_e);
   s.c0_ks = s.KS16 + (grid ? 2 : 0) + 1;
   s.c0_e = 2 * s.c0_ks; s.c0_ep = pad_pf(s.c0_e);
+  s.sq_stage_e = pad_stage(s.NB * s.body_ep);
+  s.c0_stage_e = pad_stage(s.NB * s.c0_ep);
+  s.head_stage_e = pad_stage(s.body_ep);
   s.l0_entries = s.NB;
   long long e = 0;
-  e += (long long)(n_geo - 1) * s.NB * s.body_ep;
-  e += (long long)s.NB * s.c0_ep;
-  e += s.body_ep;
-  e += (long long)(n_color - 1) * s.NB * s.body_ep;
-  e += s.body_ep;
-  e += FENERF_PF;
-  s.ring_entries = e;
+  e += (long long)(n_geo - 1) * s.sq_stage_e;   // G1..
+  e += s.c0_stage_e;                             // C0
+  e += s.head_stage_e;                           // HEAD (labels + sigma)
+  e += (long long)(n_color - 1) * s.sq_stage_e; // C1..
+  e += s.head_stage_e;                           // RGB
+  s.tile_entries = e;
+  s.ring_entries = e + FENERF_DPF * FENERF_CH;
   return s;
 }
 

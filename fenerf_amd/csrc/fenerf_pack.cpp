@@ -230,12 +230,18 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
     return ks;
   };
   const double act = (double)F16_ACT_SCALE;
+  auto pad_stage_to = [&](size_t stage_begin_halves, int stage_entries) {   // zero entries up to the padded stage size
+    const size_t want = stage_begin_halves + (size_t)stage_entries * 512;
+    if (ring.size() < want) ring.insert(ring.end(), want - ring.size(), 0);
+  };
   for (int l = 1; l < d->n_geo; ++l) {
+    const size_t begin = ring.size();
     auto W = to_f64(d->geo_w[l], (size_t)H * H);
     auto sc = row_scales(W.data(), H, H);
     for (int n = 0; n < H; ++n) inv_scale[(size_t)l * H + n] = (float)(1.0 / (sc[n] * act));
     auto ks = x_ksteps(0);
     for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, H, nb * 32, ks, sh.body_ep, sc);
+    pad_stage_to(begin, sh.sq_stage_e);
   }
   {  // C0: [x | grid feats | dir]; lane-half h holds grid channels 16h..16h+15: k-step j slot t <-> channel 16h + 8j + t
     const int cin = 3 + d->grid_ch + H;
@@ -252,7 +258,9 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
     KStep16 kd;
     for (int h = 0; h < 2; ++h) for (int t = 0; t < 8; ++t) kd.col[h][t] = (h == 0 && t < 3) ? t : -1;
     ks.push_back(kd);
+    const size_t begin = ring.size();
     for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, cin, nb * 32, ks, sh.c0_ep, sc);
+    pad_stage_to(begin, sh.c0_stage_e);
   }
   std::vector<double> head_b(32, 0.0);
   {  // HEAD: folded label rows + sigma row, per-row scaled (label and sigma magnitudes differ by orders)
@@ -286,23 +294,30 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
     head_b[n_lab] = d->sigma_b[0];
     auto sc = row_scales(Wh.data(), 32, H);
     for (int r = 0; r < 32; ++r) head_inv[r] = (float)(1.0 / (sc[r] * act));
+    const size_t begin = ring.size();
     emit_body16(ring, Wh.data(), 32, H, 0, x_ksteps(0), sh.body_ep, sc);
+    pad_stage_to(begin, sh.head_stage_e);
   }
   for (int l = 1; l < d->n_color; ++l) {
+    const size_t begin = ring.size();
     auto W = to_f64(d->color_w[l], (size_t)H * H);
     auto sc = row_scales(W.data(), H, H);
     for (int n = 0; n < H; ++n) inv_scale[(size_t)(d->n_geo + l) * H + n] = (float)(1.0 / (sc[n] * act));
     auto ks = x_ksteps(0);
     for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, H, nb * 32, ks, sh.body_ep, sc);
+    pad_stage_to(begin, sh.sq_stage_e);
   }
   {
+    const size_t begin = ring.size();
     auto W = to_f64(d->rgb_w, (size_t)3 * H);
     auto sc = row_scales(W.data(), 3, H);
     for (int r = 0; r < 3; ++r) rgb_inv[r] = (float)(1.0 / (sc[r] * act));
     emit_body16(ring, W.data(), 3, H, 0, x_ksteps(0), sh.body_ep, sc);
+    pad_stage_to(begin, sh.head_stage_e);
   }
-  ring.insert(ring.end(), (size_t)FENERF_PF * 512, 0);
-  if (ring.size() != (size_t)sh.ring_entries * 512) { err = "internal: f16 stream size mismatch"; return FENERF_E_INVALID; }
+  if (ring.size() != (size_t)sh.tile_entries * 512) { err = "internal: f16 stream size mismatch"; return FENERF_E_INVALID; }
+  // replicated head: the prefetch of the next tile's first chunks reads past the end instead of wrapping
+  ring.insert(ring.end(), ring.begin(), ring.begin() + (size_t)FENERF_DPF * FENERF_CH * 512);
   blob = l0;
   const size_t off = blob.size();
   blob.resize(off + ring.size() / 2);

@@ -391,11 +391,7 @@ static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stre
 
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
-  if (m->precision == FENERF_PREC_F16X3) {
-    // default: workgroup-shared weight stream; FENERF_F16_PRIVATE=1 selects the per-wave-stream kernel (A/B comparisons)
-    static const bool priv = [] { const char* e = getenv("FENERF_F16_PRIVATE"); return e && e[0] == '1'; }();
-    return priv ? launch_siren16(m, p, stream) : launch_siren16s(m, p, stream);
-  }
+  if (m->precision == FENERF_PREC_F16X3) return launch_siren16s(m, p, stream);
   const bool g = m->grid_ch != 0;
   switch (m->H) {
     case 32: return g ? launch_siren_t<32, true>(m, p, stream) : launch_siren_t<32, false>(m, p, stream);

@@ -34,10 +34,12 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-constexpr int CH = 8;          // entries (KiB) per chunk
-constexpr int DPF = 6;         // chunks in flight ahead of the chunk being consumed (48 KiB per CU)
-constexpr int NSLOT = DPF + 2; // LDS ring slots
+constexpr int CH = FENERF_CH;        // entries (KiB) per chunk
+constexpr int DPF = FENERF_DPF;      // chunks in flight ahead of the chunk being consumed (48 KiB per CU)
+constexpr int NSLOT = FENERF_NSLOT;  // LDS ring slots; every stage is a whole number of ring revolutions (packer), so every
+                                     // stage starts at slot 0 and slot indices / LDS offsets are compile-time constants
 static_assert(CH == FENERF_PF, "bodies are padded to whole chunks by the packer");
+static_assert(NSLOT >= DPF + 2, "a slot is refilled two barriers after its last reader issued its reads");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -69,32 +71,36 @@ __device__ __forceinline__ void glds_1k(const char* g_lane, unsigned lds_uniform
 
 // Per-wave view of the workgroup-shared weight stream.
 struct WStream {
-  const char* g_lane;   // stream base + this wave's quarter offset within a chunk + lane*16
-  const char* ring;     // LDS ring base (generic pointer, for the ds_reads)
-  unsigned ring_lds;    // LDS byte address of the ring + this wave's quarter offset (for M0)
-  int nchunk;           // chunks per tile (stream is cyclic)
-  int ci;               // next chunk to issue (mod nchunk)
-  int si;               // its ring slot
-  int sc;               // ring slot of the chunk being consumed
-  int sn;               // ring slot of the next chunk
+  unsigned long long g_next;   // global address of the next chunk to issue (uniform; + voff per lane)
+  unsigned voff;               // this lane's byte offset inside a chunk: wave*2048 + lane*16
+  unsigned ring_lds;           // LDS byte address of ring slot 0 + wave*2048 (for M0)
+  const char* ring_lane;       // generic pointer to ring slot 0 + lane*16 (for the ds_reads)
 };
 
-__device__ __forceinline__ void ws_issue(WStream& w) {
-  const char* g = w.g_lane + (size_t)w.ci * (CH * 1024);
-  const unsigned l = w.ring_lds + (unsigned)w.si * (CH * 1024);
-  glds_1k(g, l);
-  glds_1k(g + 1024, l + 1024);
-  w.ci = (w.ci + 1 == w.nchunk) ? 0 : w.ci + 1;
-  w.si = (w.si + 1 == NSLOT) ? 0 : w.si + 1;
+// Issue this wave's quarter (2 KiB) of the next chunk into ring slot `slot` (compile-time after unrolling).
+// Instruction diet: address = SGPR base + VGPR offset (saddr form); the instruction offset applies to BOTH the global
+// and the LDS address (LDS_addr = M0 + inst_offset + lane*16), so one M0 write serves both KiB; no M0 save/restore
+// (nothing else in this kernel uses M0) -- 4 instructions per chunk instead of 14.
+__device__ __forceinline__ void ws_issue(WStream& w, int slot) {
+  const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:1024"
+      :
+      : "v"(w.voff), "s"(w.g_next), "s"(m0)
+      : "memory");
+  w.g_next += CH * 1024;
 }
 
 // A operands of one k-step (entries 2j = hi, 2j+1 = lo) of the chunk in ring slot `slot`
 struct AK { float4 hi, lo; };
-__device__ __forceinline__ AK ws_read_k(const WStream& w, int slot, int j, int lane) {
-  const float4* p = reinterpret_cast<const float4*>(w.ring + slot * (CH * 1024)) + lane;
+__device__ __forceinline__ AK ws_read_k(const WStream& w, int slot, int j) {
+  const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024));
   AK a;
 #ifdef EXP_NOLDSREAD
-  a.hi = make_float4(1e-3f * lane, 2e-3f, 3e-3f, 4e-3f); a.lo = a.hi;
+  a.hi = make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f); a.lo = a.hi;
   asm volatile("" : "+v"(a.hi.x), "+v"(a.lo.y));
 #else
   a.hi = p[(2 * j) * 64];
@@ -103,11 +109,10 @@ __device__ __forceinline__ AK ws_read_k(const WStream& w, int slot, int j, int l
   return a;
 }
 
-// Top of a pipeline step: issue chunk c+D, make chunk c+1 visible to every wave.  The A operands are then read one
-// k-step ahead of their MFMAs (two KiB in registers, not a whole chunk).
-__device__ __forceinline__ void ws_step(WStream& w) {
+// Top of pipeline step i of a stage: issue chunk i+D, make chunk i+1 visible to every wave.
+__device__ __forceinline__ void ws_step(WStream& w, int i) {
 #ifndef EXP_NODMA
-  ws_issue(w);
+  ws_issue(w, (i + DPF) % NSLOT);
 #endif
 #ifndef EXP_NOWAIT
   WAIT_VMCNT(2 * (DPF - 1));          // this wave's quarter of the next chunk has landed (loads retire in order)
@@ -116,10 +121,6 @@ __device__ __forceinline__ void ws_step(WStream& w) {
   __builtin_amdgcn_s_barrier();       // ... and every other wave's quarter
 #endif
   LDS_FENCE();
-}
-__device__ __forceinline__ void ws_advance(WStream& w) {
-  w.sc = w.sn;
-  w.sn = (w.sn + 1 == NSLOT) ? 0 : w.sn + 1;
 }
 
 // split 4 fp32 values into packed fp16 (hi, lo)
@@ -209,23 +210,28 @@ __device__ __forceinline__ void epi_quarter(const f32x16& acc, int nbp, int q, c
     (acc) = MFMA16(as_half8((ak).hi), (bh), (acc));  \
   } while (0)
 
-// One chunk step: barrier (next chunk visible), then 4 k-steps.  bop(k, bh, bl) supplies the B operands of k-step k
-// (false = padding k-step); piece(j) is the epilogue piece issued behind k-step j.  a_cur holds the A operands of the
-// chunk's first k-step on entry and of the NEXT chunk's first k-step on exit: A operands are read from the LDS ring
-// exactly one k-step (96 MFMA cycles) ahead of use.
+// Chunk step i of a stage: barrier (chunk i+1 visible), then 4 k-steps.  bop(k, bh, bl) supplies the B operands of
+// k-step k (false = padding k-step); piece(j) is the epilogue piece issued behind k-step j.  a_cur holds the A operands of
+// the chunk's first k-step on entry and of chunk i+1's first k-step on exit: A operands are read from the LDS ring one
+// k-step (96 MFMA cycles) ahead of use.  Ring slot of chunk i = i % NSLOT (stages start at slot 0).
 template <class BOP, class PIECE>
-__device__ __forceinline__ void chunk_step(f32x16& acc, AK& a_cur, WStream& ws, int lane, int k0, BOP bop, PIECE piece) {
-  ws_step(ws);
+__device__ __forceinline__ void chunk_step(f32x16& acc, AK& a_cur, WStream& ws, int i, int k0, BOP bop, PIECE piece) {
+  ws_step(ws, i);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const AK a_nxt = (j < 3) ? ws_read_k(ws, ws.sc, j + 1, lane) : ws_read_k(ws, ws.sn, 0, lane);
+    const AK a_nxt = (j < 3) ? ws_read_k(ws, i % NSLOT, j + 1) : ws_read_k(ws, (i + 1) % NSLOT, 0);
     half8 bh, bl;
     if (bop(k0 + j, bh, bl)) KSTEP_MFMA(acc, a_cur, bh, bl);
     piece(j);
     a_cur = a_nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
-  ws_advance(ws);
+}
+// Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's first k-step.
+__device__ __forceinline__ void chunk_skip(AK& a_cur, WStream& ws, int i) {
+  ws_step(ws, i);
+  a_cur = ws_read_k(ws, (i + 1) % NSLOT, 0);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int KS>
@@ -254,9 +260,10 @@ __device__ __forceinline__ void collect_act(half8 (&xh)[KS], half8 (&xl)[KS], co
 // A square FiLM layer H -> H.  x: input activations (B operands); outputs replace x at the end.
 template <int H>
 __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[H / 16], WStream& ws, AK& a_cur,
-                                               const float* film_f, const float* film_p, char* slab, int lane) {
+                                               const float* film_f, const float* film_p, char* slab) {
   constexpr int NB = H / 32, KS = H / 16, NBL = NB / 2;
   constexpr int QB = (2 * KS + CH - 1) / CH;          // chunks per n-block body (4 at H=256)
+  constexpr int STAGE_CHUNKS = pad_stage(NB * QB * CH) / CH;
   constexpr int EQ = 4 / QB > 0 ? 4 / QB : 1;         // epilogue quarters per chunk
   half8 yh[KS], yl[KS];
   auto bop = [&](int k, half8& bh, half8& bl) -> bool {
@@ -273,7 +280,7 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
       EpiQ eq;
       const bool fine = nb > 0 && EQ == 1;
       if (fine) epi_load(eq, nb - 1, qc, film_f, film_p);
-      chunk_step(acc, a_cur, ws, lane, 4 * qc, bop, [&](int j) {
+      chunk_step(acc, a_cur, ws, nb * QB + qc, 4 * qc, bop, [&](int j) {
         if (fine) {
           if (j == 0) epi_p0(eq, acc_prev, qc);
           else if (j == 1) epi_p1(eq, acc_prev, qc);
@@ -287,6 +294,8 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
     acc_prev = acc;
   }
 #pragma unroll
+  for (int i = NB * QB; i < STAGE_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+#pragma unroll
   for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, film_f, film_p, yh, yl, slab);
   collect_act<KS, NBL>(xh, xl, yh, yl, slab);
 }
@@ -294,17 +303,20 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
 // A head body (labels+sigma, rgb): acc over the whole activation, no FiLM.
 template <int H>
 __device__ __forceinline__ void head_body_s(f32x16& acc, const half8 (&xh)[H / 16], const half8 (&xl)[H / 16], WStream& ws,
-                                            AK& a_cur, int lane) {
+                                            AK& a_cur) {
   constexpr int KS = H / 16;
   constexpr int QB = (2 * KS + CH - 1) / CH;
+  constexpr int STAGE_CHUNKS = pad_stage(QB * CH) / CH;
   auto bop = [&](int k, half8& bh, half8& bl) -> bool {
     if (k < KS) { bh = xh[k]; bl = xl[k]; return true; }
     return false;
   };
 #pragma unroll
   for (int qc = 0; qc < QB; ++qc) {
-    chunk_step(acc, a_cur, ws, lane, 4 * qc, bop, [](int) {});
+    chunk_step(acc, a_cur, ws, qc, 4 * qc, bop, [](int) {});
   }
+#pragma unroll
+  for (int i = QB; i < STAGE_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
 }
 
 template <int H, bool GRID>
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
   constexpr int NB = H / 32, KS = H / 16;
   constexpr int C0_KS = KS + (GRID ? 2 : 0) + 1;
   constexpr int C0_QB = (2 * C0_KS + CH - 1) / CH;     // chunks of a colour-layer-0 body (5 at H=256 with grid)
-  constexpr int SQ_CHUNKS = NB * ((2 * KS + CH - 1) / CH);   // chunks per square layer
+  constexpr int SQ_CHUNKS = pad_stage(NB * ((2 * KS + CH - 1) / CH) * CH) / CH;   // chunks per square layer (>= 8)
   constexpr int NBL = NB / 2;                                 // n-blocks whose outputs wait in the LDS slab
   constexpr int SLAB_BYTES = NBL * 4 * 1024;                  // per wave: 2*NBL k-steps x (hi, lo) x 1 KiB
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -334,19 +346,19 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
   const float4* l0w = reinterpret_cast<const float4*>(P.stream) + lane;
 
   WStream ws;
-  ws.g_lane = reinterpret_cast<const char*>(P.stream + P.ring_offset_floats) + wave * 2048 + lane * 16;
-  ws.ring = ring;
+  const unsigned long long g_stream = reinterpret_cast<unsigned long long>(P.stream + P.ring_offset_floats);
+  ws.g_next = g_stream;
+  ws.voff = wave * 2048 + lane * 16;
   ws.ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 2048);
-  ws.nchunk = nchunk;
-  ws.ci = 0; ws.si = 0; ws.sc = 0; ws.sn = 1;
+  ws.ring_lane = ring + lane * 16;
 
   // ---- prime the shared stream: chunks 0..D-1 in flight, first k-step of chunk 0 in registers
-#pragma unroll 1
-  for (int i = 0; i < DPF; ++i) ws_issue(ws);
+#pragma unroll
+  for (int i = 0; i < DPF; ++i) ws_issue(ws, i);
   WAIT_VMCNT(2 * (DPF - 1));
   __builtin_amdgcn_s_barrier();
   LDS_FENCE();
-  AK a_cur = ws_read_k(ws, 0, 0, lane);
+  AK a_cur = ws_read_k(ws, 0, 0);
 
   // work split: quads of tiles (one tile per wave), XCD-contiguous ranges
   const long long ntiles = (P.P + 31) / 32;
@@ -358,6 +370,8 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
   const long long q_begin = nquads * x / nx, q_end = nquads * (x + 1) / nx;
 
   for (long long quad = q_begin + bi; quad < q_end; quad += blocks_in_x) {
+    // the previous tile ended by issuing the replicated head chunks nchunk..nchunk+D-1 (== this tile's chunks 0..D-1)
+    ws.g_next = g_stream + (unsigned long long)DPF * (CH * 1024);
     const long long tile = quad * 4 + wave;
     // ---------------- this lane's point ----------------
     long long pt = tile * 32 + m;
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
             EpiQ eq;
             const bool fine = nb > 0 && qc < 4;
             if (fine) epi_load(eq, nb - 1, qc, ff, fq);
-            chunk_step(acc, a_cur, ws, lane, 4 * qc, bop0, [&](int j) {
+            chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 4 * qc, bop0, [&](int j) {
               if (fine) {
                 if (j == 0) epi_p0(eq, acc_prev, qc);
                 else if (j == 1) epi_p1(eq, acc_prev, qc);
@@ -505,11 +519,13 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
           acc_prev = acc;
         }
 #pragma unroll
+        for (int i = NB * C0_QB; i < pad_stage(NB * C0_QB * CH) / CH; ++i) chunk_skip(a_cur, ws, i);
+#pragma unroll
         for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, ff, fq, yh, yl, slab);
         // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
         {
           f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          head_body_s<H>(acc, xh, xl, ws, a_cur, lane);
+          head_body_s<H>(acc, xh, xl, ws, a_cur);
           const float* head_inv = P.consts + CONST_FILM_BIAS + (size_t)2 * L * H;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -525,13 +541,13 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
       } else {
         if (l + 1 < L) film_issue(l + 1);
         if (SQ_CHUNKS < DPF) WAIT_VMCNT(0);
-        square_layer_s<H>(xh, xl, ws, a_cur, ff, fq, slab, lane);
+        square_layer_s<H>(xh, xl, ws, a_cur, ff, fq, slab);
       }
     }
     // ---------------- rgb head + sigmoid ----------------
     {
       f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      head_body_s<H>(acc, xh, xl, ws, a_cur, lane);
+      head_body_s<H>(acc, xh, xl, ws, a_cur);
       const float* rgb_inv = P.consts + CONST_FILM_BIAS + (size_t)2 * L * H + 32;
       if (h == 0) {
 #pragma unroll
@@ -577,7 +593,7 @@ static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* s
     configured = lds;
   }
   const StreamShape16 sh = stream_shape16(H, m->n_geo, m->n_color, GRID);
-  const int nchunk = (int)((sh.ring_entries - FENERF_PF) / CH);
+  const int nchunk = (int)(sh.tile_entries / CH);
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > m->num_cus) blocks = m->num_cus;

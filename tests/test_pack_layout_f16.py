@@ -46,6 +46,15 @@ def emulate_tile_f16(blob, consts, spec, pts, dirs, film, grid_cl):
         cur[0] += 1
         return e
 
+    stage_begin = [0]
+
+    def end_stage():   # every stage is padded to a whole number of ring revolutions (8 chunks x 8 entries)
+        used = cur[0] - stage_begin[0]
+        padded = (used + 63) // 64 * 64
+        assert not ring[cur[0]:stage_begin[0] + padded].any()
+        cur[0] = stage_begin[0] + padded
+        stage_begin[0] = cur[0]
+
     fg = film["freq_geo"][0].astype(np.float32) * np.float32(15) + np.float32(30)
     fa = film["freq_app"][0].astype(np.float32) * np.float32(15) + np.float32(30)
     f_all = np.concatenate([fg, fa]).astype(np.float64).reshape(L, H)
@@ -105,6 +114,7 @@ def emulate_tile_f16(blob, consts, spec, pts, dirs, film, grid_cl):
             acc = np.zeros((64, 16))
             mfma_x(acc, xh, xl)
             film_store(acc, l, nb)
+        end_stage()
         xh, xl = slab_h.copy(), slab_l.copy()
     eh = [None, None]; el = [None, None]
     for j in range(2):
@@ -122,9 +132,11 @@ def emulate_tile_f16(blob, consts, spec, pts, dirs, film, grid_cl):
         for _ in range(2 * C0_KS, C0_EP):
             next_entry()
         film_store(acc, n_geo, nb)
+    end_stage()
     out = np.zeros((32, C))
     acc = np.zeros((64, 16))
     mfma_x(acc, xh, xl)
+    end_stage()
     for r in range(16):
         row = (r & 3) + 8 * (r >> 2) + 4 * H_
         for l in range(64):
@@ -137,13 +149,17 @@ def emulate_tile_f16(blob, consts, spec, pts, dirs, film, grid_cl):
             acc = np.zeros((64, 16))
             mfma_x(acc, xh, xl)
             film_store(acc, n_geo + c, nb)
+        end_stage()
         xh, xl = slab_h.copy(), slab_l.copy()
     acc = np.zeros((64, 16))
     mfma_x(acc, xh, xl)
+    end_stage()
     for r in range(3):
         for l in range(32):
             out[l, C - 4 + r] = 1 / (1 + np.exp(-(acc[l, r] * rgb_inv[r] + consts[32 + r])))
-    assert cur[0] + PF == ring.shape[0], "f16 stream must be consumed exactly (+ the PF tail pad)"
+    DPF_CH = 6 * 8   # the first 6 chunks are replicated after the end (prefetch of the next tile never wraps)
+    assert cur[0] + DPF_CH == ring.shape[0], "f16 stream must be consumed exactly (+ the replicated head)"
+    assert np.array_equal(ring[cur[0]:], ring[:DPF_CH])
     return out
 
 
