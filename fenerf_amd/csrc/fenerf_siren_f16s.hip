@@ -109,6 +109,8 @@ __device__ __forceinline__ AK ws_read_k(const WStream& w, int slot, int j) {
   return a;
 }
 
+struct AK2 { AK c, n; };   // A operands of the current and the next k-step
+
 // Top of pipeline step i of a stage: issue chunk i+D, make chunk i+1 visible to every wave.
 __device__ __forceinline__ void ws_step(WStream& w, int i) {
 #ifndef EXP_NODMA
@@ -215,22 +217,25 @@ __device__ __forceinline__ void epi_quarter(const f32x16& acc, int nbp, int q, c
 // the chunk's first k-step on entry and of chunk i+1's first k-step on exit: A operands are read from the LDS ring one
 // k-step (96 MFMA cycles) ahead of use.  Ring slot of chunk i = i % NSLOT (stages start at slot 0).
 template <class BOP, class PIECE>
-__device__ __forceinline__ void chunk_step(f32x16& acc, AK& a_cur, WStream& ws, int i, int k0, BOP bop, PIECE piece) {
+__device__ __forceinline__ void chunk_step(f32x16& acc, AK2& a, WStream& ws, int i, int k0, BOP bop, PIECE piece) {
   ws_step(ws, i);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const AK a_nxt = (j < 3) ? ws_read_k(ws, i % NSLOT, j + 1) : ws_read_k(ws, (i + 1) % NSLOT, 0);
+    // A operands are fetched TWO k-steps (192 MFMA cycles) ahead of use: one k-step did not cover the loaded LDS latency
+    const AK a_nn = (j < 2) ? ws_read_k(ws, i % NSLOT, j + 2) : ws_read_k(ws, (i + 1) % NSLOT, j - 2);
     half8 bh, bl;
-    if (bop(k0 + j, bh, bl)) KSTEP_MFMA(acc, a_cur, bh, bl);
+    if (bop(k0 + j, bh, bl)) KSTEP_MFMA(acc, a.c, bh, bl);
     piece(j);
-    a_cur = a_nxt;
+    a.c = a.n;
+    a.n = a_nn;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's first k-step.
-__device__ __forceinline__ void chunk_skip(AK& a_cur, WStream& ws, int i) {
+// Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's first two k-steps.
+__device__ __forceinline__ void chunk_skip(AK2& a, WStream& ws, int i) {
   ws_step(ws, i);
-  a_cur = ws_read_k(ws, (i + 1) % NSLOT, 0);
+  a.c = ws_read_k(ws, (i + 1) % NSLOT, 0);
+  a.n = ws_read_k(ws, (i + 1) % NSLOT, 1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -259,7 +264,7 @@ __device__ __forceinline__ void collect_act(half8 (&xh)[KS], half8 (&xl)[KS], co
 
 // A square FiLM layer H -> H.  x: input activations (B operands); outputs replace x at the end.
 template <int H>
-__device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[H / 16], WStream& ws, AK& a_cur,
+__device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[H / 16], WStream& ws, AK2& a_cur,
                                                const float* film_f, const float* film_p, char* slab) {
   constexpr int NB = H / 32, KS = H / 16, NBL = NB / 2;
   constexpr int QB = (2 * KS + CH - 1) / CH;          // chunks per n-block body (4 at H=256)
@@ -303,7 +308,7 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
 // A head body (labels+sigma, rgb): acc over the whole activation, no FiLM.
 template <int H>
 __device__ __forceinline__ void head_body_s(f32x16& acc, const half8 (&xh)[H / 16], const half8 (&xl)[H / 16], WStream& ws,
-                                            AK& a_cur) {
+                                            AK2& a_cur) {
   constexpr int KS = H / 16;
   constexpr int QB = (2 * KS + CH - 1) / CH;
   constexpr int STAGE_CHUNKS = pad_stage(QB * CH) / CH;
@@ -358,7 +363,9 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
   WAIT_VMCNT(2 * (DPF - 1));
   __builtin_amdgcn_s_barrier();
   LDS_FENCE();
-  AK a_cur = ws_read_k(ws, 0, 0);
+  AK2 a_cur;
+  a_cur.c = ws_read_k(ws, 0, 0);
+  a_cur.n = ws_read_k(ws, 0, 1);
 
   // work split: quads of tiles (one tile per wave), XCD-contiguous ranges
   const long long ntiles = (P.P + 31) / 32;
