@@ -60,6 +60,7 @@ _SIGS = {
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
+    "fenerf_ray_setup": (_i, [_i, _i, _i, C.c_float, C.c_float, C.c_float] + [_vp] * 9),
     "fenerf_siren_time_rays": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_float), _vp]),
     "fenerf_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp]),
     "fenerf_resample": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -223,6 +223,15 @@ extern "C" int fenerf_siren_time_rays(const FenerfModel* m, int B, int R, int N,
   return rc;
 }
 
+extern "C" int fenerf_ray_setup(int B, int img_size, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
+                                const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch,
+                                float* yaw, void* stream) {
+  if (B < 0 || img_size < 0 || N < 1) return fail(FENERF_E_INVALID, "need B, img_size >= 0 and N >= 1");
+  if (B == 0 || img_size == 0) return FENERF_OK;
+  if (!u_jitter || !theta || !phi || !origins || !dirs || !z || !pitch || !yaw) return fail(FENERF_E_INVALID, "NULL pointer");
+  return launch_ray_setup(B, img_size, N, z_cam, ray_start, ray_end, u_jitter, theta, phi, origins, dirs, z, pitch, yaw, stream);
+}
+
 extern "C" int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma, const float* z, const float* noise,
                                 const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, float* out_weights,
                                 float* out_wsum, void* stream) {

@@ -240,6 +240,81 @@ __global__ __launch_bounds__(256) void resample_kernel(long long BR, int K, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ray setup: get_initial_rays_trig + perturb_points + camera pose -> cam2world -> world-space rays
+// (volumetric_rendering.py:109-168, :220-248) in one launch instead of ~40 tiny ATen ops.
+// One thread per ray; the per-image camera basis is recomputed per thread (a few dozen flops).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float torch_linspace(float start, float end, int steps, int i) {
+  // torch.linspace kernel: step = (end-start)/(steps-1); i < steps/2 ? start + step*i : end - step*(steps-1-i)
+  if (steps == 1) return start;
+  const float step = __fdiv_rn(__fsub_rn(end, start), (float)(steps - 1));
+  return i < steps / 2 ? __fadd_rn(start, __fmul_rn(step, (float)i)) : __fsub_rn(end, __fmul_rn(step, (float)(steps - 1 - i)));
+}
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+  const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+  x = __fdiv_rn(x, n); y = __fdiv_rn(y, n); z = __fdiv_rn(z, n);
+}
+
+__global__ __launch_bounds__(256) void ray_setup_kernel(int B, int S, int N, float z_cam, float ray_start, float ray_end,
+                                                        const float* __restrict__ u_jitter, const float* __restrict__ theta_in,
+                                                        const float* __restrict__ phi_in, float* __restrict__ origins,
+                                                        float* __restrict__ dirs, float* __restrict__ z_out,
+                                                        float* __restrict__ pitch, float* __restrict__ yaw) {
+  const long long R = (long long)S * S;
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * R) return;
+  const int b = (int)(idx / R);
+  const int r = (int)(idx % R);
+  const int row = r / S, col = r % S;
+  // camera-space direction: x = linspace(-1,1,W)[col], y = linspace(1,-1,H)[row], z = -1/tan(fov/2)   (:113-121)
+  float dx = torch_linspace(-1.f, 1.f, S, col), dy = torch_linspace(1.f, -1.f, S, row), dz = z_cam;
+  normalize3(dx, dy, dz);
+  // camera origin on the unit sphere (:220-228)
+  const float theta = theta_in[b];
+  float phi = phi_in[b];
+  phi = fminf(fmaxf(phi, 1e-5f), 3.14159265358979323846f - 1e-5f);
+  const float sp = sinf(phi), cp = cosf(phi), st = sinf(theta), ct = cosf(theta);
+  const float ox = __fmul_rn(sp, ct), oy = cp, oz = __fmul_rn(sp, st);
+  // look-at basis (:230-248): forward = normalize(normalize(-o)), left = normalize(up x f), up' = normalize(f x left)
+  float fx = -ox, fy = -oy, fz = -oz;
+  normalize3(fx, fy, fz);
+  normalize3(fx, fy, fz);
+  float lx = __fsub_rn(__fmul_rn(1.f, fz), __fmul_rn(0.f, fy));   // cross((0,1,0), f)
+  float ly = __fsub_rn(__fmul_rn(0.f, fx), __fmul_rn(0.f, fz));
+  float lz = __fsub_rn(__fmul_rn(0.f, fy), __fmul_rn(1.f, fx));
+  normalize3(lx, ly, lz);
+  float ux = __fsub_rn(__fmul_rn(fy, lz), __fmul_rn(fz, ly));     // cross(f, left)
+  float uy = __fsub_rn(__fmul_rn(fz, lx), __fmul_rn(fx, lz));
+  float uz = __fsub_rn(__fmul_rn(fx, ly), __fmul_rn(fy, lx));
+  normalize3(ux, uy, uz);
+  // R = [-left | up | -f] (columns); world dir = R @ d_cam  (:162)
+  const float wx = __fadd_rn(__fadd_rn(__fmul_rn(-lx, dx), __fmul_rn(ux, dy)), __fmul_rn(-fx, dz));
+  const float wy = __fadd_rn(__fadd_rn(__fmul_rn(-ly, dx), __fmul_rn(uy, dy)), __fmul_rn(-fy, dz));
+  const float wz = __fadd_rn(__fadd_rn(__fmul_rn(-lz, dx), __fmul_rn(uz, dy)), __fmul_rn(-fz, dz));
+  dirs[idx * 3 + 0] = wx; dirs[idx * 3 + 1] = wy; dirs[idx * 3 + 2] = wz;
+  origins[idx * 3 + 0] = ox; origins[idx * 3 + 1] = oy; origins[idx * 3 + 2] = oz;
+  // stratified jitter (:133-139): z_k = linspace(start,end,N)[k] + (u - 0.5) * (z_1 - z_0)
+  const float step = N > 1 ? __fsub_rn(torch_linspace(ray_start, ray_end, N, 1), torch_linspace(ray_start, ray_end, N, 0)) : 0.f;
+  for (int k = 0; k < N; ++k) {
+    const float u = u_jitter[idx * N + k];
+    z_out[idx * N + k] = __fadd_rn(torch_linspace(ray_start, ray_end, N, k), __fmul_rn(__fsub_rn(u, 0.5f), step));
+  }
+  if (r == 0) { pitch[b] = phi; yaw[b] = theta; }
+}
+
+int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
+                     const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch, float* yaw,
+                     void* stream) {
+  const long long total = (long long)B * S * S;
+  if (total <= 0) return FENERF_OK;
+  hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, S, N, z_cam,
+                     ray_start, ray_end, u_jitter, theta, phi, origins, dirs, z, pitch, yaw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("ray_setup launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+  return FENERF_OK;
+}
+
 static int hip_fail2(hipError_t e, const char* what) {
   set_error(std::string(what) + ": " + hipGetErrorString(e));
   return FENERF_E_HIP;

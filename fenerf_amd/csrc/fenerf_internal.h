@@ -76,6 +76,9 @@ int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);
 int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const float* w, const float* u, float* out, void* stream);
+int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
+                     const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch, float* yaw,
+                     void* stream);
 int launch_grid_relayout(const float* src_ncdhw, float* dst_cl, int C, int D, int Hh, int W, void* stream);
 
 }  // namespace fenerf

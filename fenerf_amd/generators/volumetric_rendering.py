@@ -82,6 +82,36 @@ def truncated_normal_(tensor, mean=0, std=1):
     return tensor
 
 
+def sample_camera_angles(device, n, horizontal_stddev, vertical_stddev, horizontal_mean, vertical_mean, mode, draws=_DEFAULT_DRAWS):
+    """The random part of sample_camera_positions (:188-218): (theta, phi) [n,1] BEFORE the phi clamp, same draws/order."""
+    if mode == "uniform":
+        theta = (draws.rand((n, 1), device) - 0.5) * 2 * horizontal_stddev + horizontal_mean
+        phi = (draws.rand((n, 1), device) - 0.5) * 2 * vertical_stddev + vertical_mean
+    elif mode == "normal" or mode == "gaussian":
+        theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
+        phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
+    elif mode == "hybrid":
+        if random.random() < 0.5:
+            theta = (draws.rand((n, 1), device) - 0.5) * 2 * horizontal_stddev * 2 + horizontal_mean
+            phi = (draws.rand((n, 1), device) - 0.5) * 2 * vertical_stddev * 2 + vertical_mean
+        else:
+            theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
+            phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
+    elif mode == "truncated_gaussian":
+        theta = truncated_normal_(torch.zeros((n, 1), device=device)) * horizontal_stddev + horizontal_mean
+        phi = truncated_normal_(torch.zeros((n, 1), device=device)) * vertical_stddev + vertical_mean
+    elif mode == "spherical_uniform":
+        theta = (draws.rand((n, 1), device) - .5) * 2 * horizontal_stddev + horizontal_mean
+        v_stddev, v_mean = vertical_stddev / math.pi, vertical_mean / math.pi
+        v = ((draws.rand((n, 1), device) - .5) * 2 * v_stddev + v_mean)
+        v = torch.clamp(v, 1e-5, 1 - 1e-5)
+        phi = torch.arccos(1 - 2 * v)
+    else:  # just use the mean
+        theta = torch.ones((n, 1), device=device, dtype=torch.float) * horizontal_mean
+        phi = torch.ones((n, 1), device=device, dtype=torch.float) * vertical_mean
+    return theta, phi
+
+
 def sample_camera_positions(device, n=1, r=1, horizontal_stddev=1, vertical_stddev=1, horizontal_mean=math.pi * 0.5,
                             vertical_mean=math.pi * 0.5, mode="normal", draws=_DEFAULT_DRAWS):
     """Camera origins on a sphere; returns (origin [n,3], phi/pitch [n,1], theta/yaw [n,1])  (:179-228)."""
@@ -155,8 +185,15 @@ def sample_rays(n, num_steps, device, fov, resolution, ray_start, ray_end, h_std
                 draws=_DEFAULT_DRAWS):
     """What the fused renderer needs from get_initial_rays_trig + transform_sampled_points, without materialising
     the [n,R,N,3] point tensor: world-space origins/dirs [n,R,3] and jittered z [n,R,N] (same draws, same order:
-    jitter rand -> theta -> phi).  Points are origins + dirs*z inside the kernel."""
+    jitter rand -> theta -> phi).  Points are origins + dirs*z inside the kernel.
+    On a GPU device this is ONE HIP launch (fenerf_ray_setup) after the draws; the PyTorch formulation below is the
+    host-logic statement of the same math (CPU tests pin it to the reference's vectors, GPU tests pin the kernel to it)."""
     W, H = resolution
+    if torch.device(device).type == "cuda" and W == H:
+        u = draws.rand((n, W * H, num_steps, 1), device)
+        theta, phi = sample_camera_angles(device, n, h_stddev, v_stddev, h_mean, v_mean, mode, draws=draws)
+        z_cam = (-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item()   # as the reference's fp32 tensor op rounds it
+        return native.ray_setup(n, W, num_steps, z_cam, ray_start, ray_end, u, theta, phi)
     x, y = torch.meshgrid(torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device), indexing="ij")
     x = x.T.flatten()
     y = y.T.flatten()

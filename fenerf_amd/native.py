@@ -144,6 +144,22 @@ class NativeModel:
 # ----------------------------------------------------------------------
 # stand-alone ray-tail ops (no model needed)
 # ----------------------------------------------------------------------
+def ray_setup(B, img_size, N, z_cam, ray_start, ray_end, u_jitter, theta, phi):
+    """u_jitter [B,R,N(,1)], theta/phi [B(,1)] device tensors -> (origins [B,R,3], dirs [B,R,3], z [B,R,N], pitch [B,1], yaw [B,1])"""
+    dev = u_jitter.device
+    R = img_size * img_size
+    u, th, ph = _f32(u_jitter, dev).reshape(B, R, N), _f32(theta, dev).reshape(B), _f32(phi, dev).reshape(B)
+    origins = torch.empty((B, R, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((B, R, 3), dtype=torch.float32, device=dev)
+    z = torch.empty((B, R, N), dtype=torch.float32, device=dev)
+    pitch = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    yaw = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_ray_setup(B, img_size, N, float(z_cam), float(ray_start), float(ray_end), _ptr(u), _ptr(th),
+                                               _ptr(ph), _ptr(origins), _ptr(dirs), _ptr(z), _ptr(pitch), _ptr(yaw), _stream()))
+    return origins, dirs, z, pitch, yaw
+
+
 def composite(rgb_sigma, z, noise, opts, want_weights=True, want_wsum=True):
     """fancy_integration on [..., M, C] / [..., M] device tensors -> (rgb, depth, weights, wsum)."""
     lead = rgb_sigma.shape[:-2]

@@ -127,6 +127,14 @@ int fenerf_siren_forward_rays(const FenerfModel* m, int B, int R, int N, const f
                               const float* freq_app, const float* phase_app, float* out, void* film_ws,
                               void* stream);
 
+/* replaces: get_initial_rays_trig + perturb_points + the pose / cam2world / bmm part of transform_sampled_points
+ * (volumetric_rendering.py:109-168, :220-248) for square images: u_jitter [B,R,N] ~ U[0,1) and the camera angles theta (yaw),
+ * phi (pitch, before the [1e-5, pi-1e-5] clamp) [B] are the caller's draws; z_cam = -1/tan(fov/2) as the caller computes it.
+ * -> origins [B,R,3], dirs [B,R,3] (world space), z [B,R,N] (jittered), pitch [B] (clamped phi), yaw [B]. */
+int fenerf_ray_setup(int B, int img_size, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
+                     const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch, float* yaw,
+                     void* stream);
+
 /* Measurement hook (bench.py roofline leg; replaces nothing): runs the FiLM pre-pass once, then `iters` back-to-back
  * launches of ONLY the SIREN kernel of fenerf_siren_forward_rays, bracketed by hipEvents recorded on `stream`;
  * synchronises and returns the average kernel duration in milliseconds. */

@@ -418,3 +418,28 @@ def test_full_size_128_24p24_properties_and_oracle_subset(precision):
     print(f"[parity] 128x128 24+24 H=256 [{precision}] vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
     assert bad.mean() <= 0.03
     np.testing.assert_allclose(depth[:, idx][~bad], r_depth[..., 0][~bad], atol=5e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1-a5: HIP ray setup (fenerf_ray_setup) vs the reference's recorded rays
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "h256_texture_16x16_n24_trained"])
+def test_ray_setup_kernel_vs_reference(name):
+    g = load_golden(name)
+    B, S_, N = int(g["meta_B"]), int(g["meta_S"]), int(g["meta_N"])
+    draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"]])
+    o, d, z, pitch, yaw = VR.sample_rays(B, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi * 0.5, np.pi * 0.5, "gaussian", draws=draws)
+    assert not draws.arrays and o.is_cuda
+    np.testing.assert_allclose(N_(o), g["st_origins"], atol=3e-7)
+    np.testing.assert_allclose(N_(d), g["st_dirs"], atol=3e-7)
+    np.testing.assert_allclose(N_(z), g["st_z_coarse"][..., 0], atol=2e-7)
+    np.testing.assert_allclose(N_(torch.cat([pitch, yaw], -1)), g["poses"], atol=2e-7)
+    # the PyTorch statement of the same math (what CPU tests pin) agrees with the kernel
+    draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"]])
+    o2, d2, z2, p2, y2 = VR.sample_rays(B, N, "cpu", 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi * 0.5, np.pi * 0.5, "gaussian", draws=draws)
+    np.testing.assert_allclose(N_(d), d2.numpy(), atol=3e-7)
+    np.testing.assert_allclose(N_(z), z2.numpy(), atol=2e-7)
+    # extreme pitch is clamped like the reference (:220)
+    u = torch.rand((1, 16, 3, 1), device=DEV)
+    o3, d3, z3, p3, y3 = native.ray_setup(1, 4, 3, -9.5, 0.88, 1.12, u, torch.tensor([0.3], device=DEV), torch.tensor([-0.2], device=DEV))
+    assert abs(float(p3) - 1e-5) < 1e-9 and np.isfinite(N_(d3)).all()
