@@ -443,3 +443,44 @@ def test_ray_setup_kernel_vs_reference(name):
     u = torch.rand((1, 16, 3, 1), device=DEV)
     o3, d3, z3, p3, y3 = native.ray_setup(1, 4, 3, -9.5, 0.88, 1.12, u, torch.tensor([0.3], device=DEV), torch.tensor([-0.2], device=DEV))
     assert abs(float(p3) - 1e-5) < 1e-9 and np.isfinite(N_(d3)).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: staged_forward 256x256, 48+48 samples (96 composited samples per ray = 2 per lane), and
+# configs[0]: 64x64, 12 coarse samples, no hierarchical sampling
+# ---------------------------------------------------------------------------------------------------
+def test_config5_256_48p48_and_config1_64_12():
+    spec, sd = _full_weights()
+    nat = native.NativeModel(sd, spec, DEV, "f16x3")
+    film = proc.film_params(spec, 1, seed=0)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    for (S_, N, hier) in ((256, 48, True), (64, 12, False)):
+        R = S_ * S_
+        torch.manual_seed(3)
+        o, d, z, _, _ = VR.sample_rays(1, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+        u = torch.rand((R, N), device=DEV) if hier else None
+        opts = _lib.composite_opts("relu", fill_mode="seg_padding_background", fill_color="black")
+        rgb, depth, w, ws = nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=hier, want_weights=True, want_wsum=True)
+        rgb, depth, w, ws = N_(rgb), N_(depth), N_(w), N_(ws)
+        M = 2 * N if hier else N
+        assert rgb.shape == (1, R, 22) and w.shape == (1, R, M) and np.isfinite(rgb).all()
+        np.testing.assert_allclose(w.sum(-1), ws, atol=2e-5)
+        assert ((ws < 0.9) == (rgb[..., 0] == 1)).all()
+        idx = np.sort(np.random.default_rng(2).choice(R, 96, replace=False))
+        oo, dd, zz = N_(o)[:, idx], N_(d)[:, idx], N_(z)[:, idx]
+        pts = (oo[:, :, None, :] + dd[:, :, None, :] * zz[..., None]).reshape(1, -1, 3)
+        dexp = np.broadcast_to(dd[:, :, None, :], (1, len(idx), N, 3)).reshape(1, -1, 3)
+        coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(1, len(idx), N, -1)
+        if hier:
+            _, _, cw = O.fancy_integration(coarse, zz[..., None], clamp_mode="relu")
+            zf = O.fine_z_from_coarse(cw, zz[..., None], N_(u)[idx])
+            fine = O.siren_forward(sd, spec, (oo[:, :, None, :] + dd[:, :, None, :] * zf).reshape(1, -1, 3), dexp, *args).reshape(1, len(idx), N, -1)
+            ao, az = O.merge_sorted(fine, coarse, zf, zz[..., None])
+        else:
+            ao, az = coarse, zz[..., None]
+        r_rgb, r_depth, _ = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color="black")
+        err = np.abs(rgb[:, idx] - r_rgb).max(-1)
+        bad = err > 1e-3
+        print(f"[parity] {S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
+        assert bad.mean() <= 0.04
