@@ -130,7 +130,7 @@ def main():
             kname, mfma = "siren16s_kernel<256,true>", "v_mfma_f32_32x32x16_f16, 3 per product"
             extra = {"frac_of_f16x3_ceiling": achieved / (peak / 3)}
         out = {
-            "metric": "rays/s/GPU forward render (128x128, 24+24 samples, H=256 FiLM-SIREN + 32x96^3 grid)",
+            "metric": f"rays/s/GPU forward render ({S}x{S}, {N}+{N} samples, H=256 FiLM-SIREN + 32x96^3 grid)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",

@@ -484,3 +484,49 @@ def test_config5_256_48p48_and_config1_64_12():
         bad = err > 1e-3
         print(f"[parity] {S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
         assert bad.mean() <= 0.04
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-latent pi-GAN generator (ImplicitGenerator3d + SPATIALSIRENBASELINE, curriculum `CelebA`) end to end
+# ---------------------------------------------------------------------------------------------------
+def _make_spatial_generator(g, spec, precision):
+    gen = G.ImplicitGenerator3d(functools.partial(S.SPATIALSIRENBASELINE, hidden_dim=spec["hidden_dim"]), spec["z_dim"], 4)
+    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
+    gen.siren.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    gen = gen.to(DEV).eval()
+    gen.siren.precision = precision
+    gen.device = torch.device(DEV)
+    gen.siren.device = gen.device
+    return gen
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_single_latent_generator_vs_reference(precision):
+    g = load_golden("tiny_spatial_fwd")
+    spec = spec_from_golden(g)
+    gen = _make_spatial_generator(g, spec, precision)
+    f = proc.film_params(spec, int(g["meta_B"]), seed=int(g["meta_seed"]))
+    freq = T(np.concatenate([f["freq_geo"], f["freq_app"]], -1))
+    phase = T(np.concatenate([f["phase_geo"], f["phase_app"]], -1))
+    common = dict(img_size=int(g["meta_S"]), fov=12, ray_start=0.88, ray_end=1.12, num_steps=int(g["meta_N"]), h_stddev=0.3,
+                  v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, hierarchical_sample=True, sample_dist="gaussian")
+    seq = [g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"], g["rand_u_fine"], g["rand_noise_fine"]]
+    gen.draws = VR.RecordedDraws(seq)
+    with torch.no_grad():
+        px, poses = gen.forward_with_frequencies(freq, phase, **common, **kwargs_from_golden(g))
+    assert px.shape == g["pixels"].shape == (2, 3, 8, 8)
+    err = np.abs(N_(px) - g["pixels"]).max(axis=1)
+    print(f"[parity] single-latent forward_with_frequencies[{precision}]: max|err| {err.max():.3e}")
+    assert (err > 1e-3).mean() <= 0.05
+    np.testing.assert_allclose(N_(poses), g["poses"], atol=1e-6)
+    # staged variant, eval_white_back fill (3-channel model), returns (pixels on device, depth.cpu()) -- two values
+    g2 = load_golden("tiny_spatial_staged")
+    gen.draws = VR.RecordedDraws([g2["rand_u_jitter"], g2["rand_r_theta"], g2["rand_r_phi"], g2["rand_noise_coarse"], g2["rand_u_fine"],
+                                  g2["rand_noise_fine"]])
+    res = gen.staged_forward_with_frequencies(freq, phase, **common, **kwargs_from_golden(g2))
+    assert len(res) == 2 and res[0].is_cuda and not res[1].is_cuda
+    err = np.abs(N_(res[0]) - g2["pixels"]).max(axis=1)
+    bad = err > 1e-3
+    print(f"[parity] single-latent staged_forward_with_frequencies[{precision}]: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
+    assert bad.mean() <= 0.05
+    np.testing.assert_allclose(N_(res[1])[~bad], g2["depth"][~bad], atol=1e-4)

@@ -22,6 +22,9 @@ def _model(g):
     sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
     assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-6 * max(1.0, abs(float(g["meta_weights_checksum"])))
     film = proc.film_params(spec, int(g["meta_B"]), seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]))
+    if spec["kind"] == "spatial":   # single latent: one [B, 9H] tensor, the colour layer uses its last H (siren.py:241)
+        film = dict(freq_geo=np.concatenate([film["freq_geo"], film["freq_app"]], -1),
+                    phase_geo=np.concatenate([film["phase_geo"], film["phase_app"]], -1))
     return spec, sd, film
 
 
@@ -97,7 +100,7 @@ def test_integration_variants():
         O.fancy_integration(rs, z, clamp_mode=None)
 
 
-@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd"])
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "tiny_spatial_fwd"])
 def test_forward_stagewise(name):
     g = load_golden(name)
     px, depth, third, st = _render(g)
@@ -106,13 +109,16 @@ def test_forward_stagewise(name):
     np.testing.assert_allclose(st["dirs"], g["st_dirs"], atol=3e-7)
     np.testing.assert_allclose(st["origins"], g["st_origins"], atol=3e-7)
     B, R, N = st["z_coarse"].shape[:3]
-    np.testing.assert_allclose(st["coarse"].reshape(B, R * N, -1), g["st_siren_coarse"], atol=3e-4, rtol=1e-4)
+    sig_tol = 1e-5 * float(g["meta_sigma_gain"])   # sigma head is scaled by sigma_gain: fp32 re-association noise scales with it
+    np.testing.assert_allclose(st["coarse"].reshape(B, R * N, -1)[..., :-1], g["st_siren_coarse"][..., :-1], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(st["coarse"].reshape(B, R * N, -1)[..., -1], g["st_siren_coarse"][..., -1], atol=sig_tol, rtol=1e-4)
     # teacher-forced per-stage checks (discontinuities: resampling / sort depend on upstream rounding)
     spec, sd, film = _model(g)
     args = (film["freq_geo"], film["phase_geo"], film.get("freq_app"), film.get("phase_app"))
     dirs = np.broadcast_to(g["st_dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
     out = O.siren_forward(sd, spec, g["st_points"].reshape(B, R * N, 3), dirs, *args)
-    np.testing.assert_allclose(out, g["st_siren_coarse"], atol=3e-4, rtol=1e-4)
+    np.testing.assert_allclose(out[..., :-1], g["st_siren_coarse"][..., :-1], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(out[..., -1], g["st_siren_coarse"][..., -1], atol=sig_tol, rtol=1e-4)
     if bool(g["meta_hier"]):
         coarse_ref = g["st_siren_coarse"].reshape(B, R, N, -1)
         _, _, w = O.fancy_integration(coarse_ref, g["st_z_coarse"], noise=g["rand_noise_coarse"],
@@ -121,7 +127,8 @@ def test_forward_stagewise(name):
         zf = O.fine_z_from_coarse(g["st_coarse_weights"], g["st_z_coarse"], g["rand_u_fine"])
         np.testing.assert_allclose(zf.reshape(B * R, N), g["st_z_fine"], atol=2e-6)
         fo = O.siren_forward(sd, spec, g["st_fine_points"], dirs, *args)
-        np.testing.assert_allclose(fo, g["st_siren_fine"], atol=3e-4, rtol=1e-4)
+        np.testing.assert_allclose(fo[..., :-1], g["st_siren_fine"][..., :-1], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(fo[..., -1], g["st_siren_fine"][..., -1], atol=sig_tol, rtol=1e-4)
         ao, az = O.merge_sorted(g["st_siren_fine"].reshape(B, R, N, -1), coarse_ref, zf, g["st_z_coarse"])
         np.testing.assert_allclose(az, g["st_all_z"], atol=2e-6)
         np.testing.assert_allclose(ao, g["st_all_out"], atol=1e-6)
@@ -130,7 +137,7 @@ def test_forward_stagewise(name):
     np.testing.assert_allclose(st["yaw"], g["poses"][:, 1:], atol=2e-7)
 
 
-@pytest.mark.parametrize("name", ["tiny_texture_staged", "tiny_texture_staged_lock"])
+@pytest.mark.parametrize("name", ["tiny_texture_staged", "tiny_texture_staged_lock", "tiny_spatial_staged"])
 def test_staged_with_frequencies(name):
     g = load_golden(name)
     px, depth, third, st = _render(g)

@@ -123,6 +123,9 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
     g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
     film = proc.film_params(spec, B, seed=seed, scale=film_scale)
     tf = {k: torch.from_numpy(v) for k, v in film.items()}
+    if spec["kind"] == "spatial":   # single latent: one [B, 9H] frequency / phase tensor; the colour layer uses the last H
+        tf["freq_geo"] = torch.cat([tf["freq_geo"], tf["freq_app"]], -1)
+        tf["phase_geo"] = torch.cat([tf["phase_geo"], tf["phase_app"]], -1)
     torch.manual_seed(1234 + seed)
     rec_names = ["fancy_integration", "sample_pdf", "transform_sampled_points", "get_initial_rays_trig"]
     siren_calls = []
@@ -363,6 +366,11 @@ def main():
     full = proc.model_spec("texture", hidden_dim=256, grid_size=96)
     run_film_case(refs, "h256_texture_16x16_n12", full, seed=0, sigma_gain=1.0, B=1, S=16, N=12, hier=True, kwargs=relu)
     run_film_case(refs, "h256_texture_16x16_n24_trained", full, seed=0, sigma_gain=2000.0, B=1, S=16, N=24, hier=True, kwargs=relu)
+    spatial = proc.model_spec("spatial", hidden_dim=32, z_dim=16)
+    run_film_case(refs, "tiny_spatial_fwd", spatial, seed=8, sigma_gain=300.0, B=2, S=8, N=6, hier=True,
+                  kwargs=dict(clamp_mode="relu", nerf_noise=0.0, last_back=True))
+    run_film_case(refs, "tiny_spatial_staged", spatial, seed=8, sigma_gain=300.0, B=2, S=8, N=6, hier=True, staged=True,
+                  kwargs=dict(clamp_mode="relu", nerf_noise=0.0, fill_mode="eval_white_back"))
     fullb = proc.model_spec("baseline", hidden_dim=256)
     run_film_case(refs, "h256_baseline_8x8_n12", fullb, seed=6, sigma_gain=2000.0, B=2, S=8, N=12, hier=True, kwargs=relu)
 
