@@ -1,0 +1,95 @@
+"""Thin callers of the generator API -- the library-level counterparts of the reference's inference scripts
+(SURVEY §8f.2 / f.3).  They add nothing to the hot path: every render goes through generator.staged_forward* /
+siren.forward_with_frequencies_phase_shifts, i.e. the HIP kernels.
+
+reference: mask2color + COLOR_MAP  train_double_latent_semantic.py:35-72
+           multi-view loop         render_multiview_images_double_semantic.py:24-85
+           voxel-grid evaluation   extract_double_semantic_shapes.py:13-90
+"""
+import numpy as np
+import torch
+
+# label id -> RGB (train_double_latent_semantic.py:35-55); configuration data of the dataset's 19 classes
+COLOR_MAP = {
+    0: [0, 0, 0], 1: [204, 0, 0], 2: [76, 153, 0], 3: [204, 204, 0], 4: [51, 51, 255], 5: [204, 0, 204], 6: [0, 255, 255],
+    7: [255, 204, 204], 8: [102, 51, 0], 9: [255, 0, 0], 10: [102, 204, 0], 11: [255, 255, 0], 12: [0, 0, 153],
+    13: [0, 0, 204], 14: [255, 51, 153], 15: [0, 204, 204], 16: [0, 51, 0], 17: [255, 153, 51], 18: [0, 204, 0],
+}
+
+
+def mask2color(masks):
+    """[B,19,H,W] logits -> [B,3,H,W] float colours (0..255) on the CPU, like the reference: argmax over the label
+    channels (first index wins ties) then the LUT (train_double_latent_semantic.py:66-72)."""
+    idx = torch.argmax(masks, dim=1)
+    lut = torch.zeros((max(COLOR_MAP) + 1, 3), dtype=torch.float)
+    for k, v in COLOR_MAP.items():
+        lut[k] = torch.tensor(v, dtype=torch.float)
+    return lut[idx.cpu()].permute(0, 3, 1, 2).contiguous()
+
+
+def multiview_kwargs(curriculum, image_size=256, ray_step_multiplier=2, lock_view_dependence=False):
+    """The kwargs bag render_multiview_images_double_semantic.py:43-54 builds from a curriculum."""
+    c = dict(curriculum)
+    c["num_steps"] = curriculum[0]["num_steps"] * ray_step_multiplier
+    c["img_size"] = image_size
+    c["psi"] = 0.7
+    c["v_stddev"] = 0
+    c["h_stddev"] = 0
+    c["lock_view_dependence"] = lock_view_dependence
+    c["last_back"] = False
+    c["nerf_noise"] = 0
+    return {k: v for k, v in c.items() if type(k) is str}
+
+
+def render_multiview(generator, curriculum, seed, device, face_angles=(-0.5, -0.25, 0.0, 0.25, 0.5), image_size=256,
+                     ray_step_multiplier=2, lock_view_dependence=False, z_dim=256):
+    """Five yaw angles of one identity (render_multiview_images_double_semantic.py:66-85).
+    -> (images [V,3,S,S] in [-1,1], segmaps [V,3,S,S] in [0,1]) on the CPU."""
+    kw = multiview_kwargs(curriculum, image_size, ray_step_multiplier, lock_view_dependence)
+    h_mean = kw["h_mean"]
+    images, segmaps = [], []
+    for a in face_angles:
+        kw["h_mean"] = a + h_mean
+        torch.manual_seed(seed)
+        z_geo = torch.randn((1, z_dim), device=device)
+        z_app = torch.randn((1, z_dim), device=device)
+        with torch.no_grad():
+            img, _ = generator.staged_forward(z_geo, z_app, **kw)
+        images.append(img[:, -3:])
+        segmaps.append(mask2color(img[:, :-3]) / 255.0)
+    return torch.cat(images), torch.cat(segmaps)
+
+
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0):
+    """Voxel-centre coordinates [1, N^3, 3] exactly as the reference builds them (extract_double_semantic_shapes.py:13-35):
+    note the y / x indices are (i / N) % N and (i / N / N) % N in FLOAT arithmetic (not floor-divided) -- kept as is."""
+    voxel_origin = np.array(voxel_origin) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    overall_index = torch.arange(0, N ** 3, 1, dtype=torch.long)
+    samples = torch.zeros(N ** 3, 3)
+    samples[:, 2] = overall_index % N
+    samples[:, 1] = (overall_index.float() / N) % N
+    samples[:, 0] = ((overall_index.float() / N) / N) % N
+    samples[:, 0] = (samples[:, 0] * voxel_size) + voxel_origin[2]
+    samples[:, 1] = (samples[:, 1] * voxel_size) + voxel_origin[1]
+    samples[:, 2] = (samples[:, 2] * voxel_size) + voxel_origin[0]
+    return samples.unsqueeze(0), voxel_origin, voxel_size
+
+
+def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolution=256, voxel_origin=(0, 0, 0), cube_length=2.0,
+                     psi=0.5):
+    """Density volume [N,N,N] (numpy) of one identity for marching cubes (extract_double_semantic_shapes.py:38-62):
+    truncated FiLM parameters, view direction locked to (0,0,-1).  One fused kernel launch evaluates all N^3 points;
+    `max_batch` is accepted for signature compatibility and ignored.  (The reference passes the same z to both mapping
+    networks; pass z_app to differ.)"""
+    z_app = z_geo if z_app is None else z_app
+    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length)
+    samples = samples.to(z_geo.device)
+    avg_fg, avg_pg, avg_fa, avg_pa = generator.generate_avg_frequencies()
+    with torch.no_grad():
+        raw_fg, raw_pg = generator.siren.geo_mapping_network(z_geo)
+        raw_fa, raw_pa = generator.siren.app_mapping_network(z_app)
+        fg, pg = avg_fg + psi * (raw_fg - avg_fg), avg_pg + psi * (raw_pg - avg_pg)
+        fa, pa = avg_fa + psi * (raw_fa - avg_fa), avg_pa + psi * (raw_pa - avg_pa)
+        out = generator.siren.native(samples.device).siren_forward(samples, None, fg, pg, fa, pa)   # None = locked view dir
+    return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()

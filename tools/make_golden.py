@@ -358,6 +358,7 @@ def main():
     run_sample_pdf_cases(refs, "sample_pdf_cases")
     run_camera_cases(refs, "camera_rays")
     run_mapping_and_full(refs, "tiny_texture_z_full")
+    run_caller_helpers()
 
     baseline = proc.model_spec("baseline", hidden_dim=32, z_dim=16)
     run_film_case(refs, "tiny_baseline_fwd", baseline, seed=5, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
@@ -377,3 +378,29 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def run_caller_helpers(name="caller_helpers"):
+    """mask2color (train_double_latent_semantic.py:36-72) and create_samples (extract_double_semantic_shapes.py:13-35):
+    the two function bodies are executed straight from the reference sources (AST-extracted, so the scripts' heavy
+    unrelated imports -- datasets, torch_ema, tensorboard, mrcfile ... -- are never triggered)."""
+    import ast
+    ns = {"torch": torch, "np": np}
+    for fn, wanted in (("train_double_latent_semantic.py", {"COLOR_MAP", "mask2color"}), ("extract_double_semantic_shapes.py", {"create_samples"})):
+        tree = ast.parse(open(os.path.join(ref_import.REFERENCE_ROOT, fn)).read())
+        keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
+                (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in wanted for t in n.targets))]
+        exec(compile(ast.Module(body=keep, type_ignores=[]), fn, "exec"), ns)
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    masks = torch.randn(3, 19, 6, 5, generator=g)
+    masks[0, :, 0, 0] = 0.0          # exact tie -> argmax picks the first index
+    masks[1, 7, 2, 2] = masks[1, 3, 2, 2] = masks[1].max() + 1.0
+    out["masks"] = np_(masks)
+    out["colors"] = np_(ns["mask2color"](masks))
+    out["color_map"] = np.array([ns["COLOR_MAP"][k] for k in range(19)], dtype=np.float32)
+    for N in (4, 5):
+        s, vo, vs = ns["create_samples"](N, [0, 0, 0], 0.3)
+        out[f"samples_{N}"], out[f"voxel_origin_{N}"], out[f"voxel_size_{N}"] = np_(s), np.asarray(vo, np.float64), np.float64(vs)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: mask2color + create_samples")
