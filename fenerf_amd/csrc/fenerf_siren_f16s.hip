@@ -41,9 +41,6 @@ constexpr int NSLOT = FENERF_NSLOT;  // LDS ring slots; every stage is a whole n
 static_assert(CH == FENERF_PF, "bodies are padded to whole chunks by the packer");
 static_assert(NSLOT >= DPF + 2, "a slot is refilled two barriers after its last reader issued its reads");
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
 __device__ __forceinline__ half8 as_half8(const float4& v) { return __builtin_bit_cast(half8, v); }
 
 // LDS-DMA of one KiB: lane i's 16 bytes at g + 16 i  ->  lds + 16 i   (lds wave-uniform, passed in M0).
@@ -239,12 +236,6 @@ __device__ __forceinline__ void chunk_skip(AK2& a, WStream& ws, int i) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int KS>
-__device__ __forceinline__ void copy_act(half8 (&dh)[KS], half8 (&dl)[KS], const half8 (&sh)[KS], const half8 (&sl)[KS]) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) { dh[s] = sh[s]; dl[s] = sl[s]; }
-}
-
 // Layer end: x <- outputs (first 2*NBL k-steps from the slab, the rest from y).
 template <int KS, int NBL>
 __device__ __forceinline__ void collect_act(half8 (&xh)[KS], half8 (&xl)[KS], const half8 (&yh)[KS], const half8 (&yl)[KS],
@@ -325,7 +316,7 @@ __device__ __forceinline__ void head_body_s(f32x16& acc, const half8 (&xh)[H / 1
 }
 
 template <int H, bool GRID>
-__global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C, int nchunk) {
+__global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 16;
   constexpr int C0_KS = KS + (GRID ? 2 : 0) + 1;
   constexpr int C0_QB = (2 * C0_KS + CH - 1) / CH;     // chunks of a colour-layer-0 body (5 at H=256 with grid)
@@ -599,13 +590,11 @@ static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* s
     if (e != hipSuccess) return hip_fail16s(e, "hipFuncSetAttribute(max dynamic LDS)");
     configured = lds;
   }
-  const StreamShape16 sh = stream_shape16(H, m->n_geo, m->n_color, GRID);
-  const int nchunk = (int)(sh.tile_entries / CH);
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > m->num_cus) blocks = m->num_cus;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C, nchunk);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail16s(e, "siren16s launch");
 }

@@ -8,40 +8,35 @@ reference's scripts can splat them unchanged.
 import math
 
 
-def next_upsample_step(curriculum, current_step):
-    current_size = extract_metadata(curriculum, current_step)['img_size']
-    for curriculum_step in sorted([cs for cs in curriculum.keys() if type(cs) == int]):
-        if curriculum_step > current_step and curriculum[curriculum_step].get('img_size', 512) > current_size:
-            return curriculum_step
-    return float('Inf')
-
-
-def last_upsample_step(curriculum, current_step):
-    current_size = extract_metadata(curriculum, current_step)['img_size']
-    for curriculum_step in sorted([cs for cs in curriculum.keys() if type(cs) == int]):
-        if curriculum_step <= current_step and curriculum[curriculum_step]['img_size'] == current_size:
-            return curriculum_step
-    return 0
-
-
-def get_current_step(curriculum, epoch):
-    step = 0
-    for update_epoch in curriculum['update_epochs']:
-        if epoch >= update_epoch:
-            step += 1
-    return step
+def _stages(curriculum):
+    """Stage start steps (the int keys), ascending."""
+    return sorted(k for k in curriculum if isinstance(k, int))
 
 
 def extract_metadata(curriculum, current_step):
-    return_dict = {}
-    for curriculum_step in sorted([cs for cs in curriculum.keys() if type(cs) == int], reverse=True):
-        if curriculum_step <= current_step:
-            for key, value in curriculum[curriculum_step].items():
-                return_dict[key] = value
-            break
-    for key in [k for k in curriculum.keys() if type(k) != int]:
-        return_dict[key] = curriculum[key]
-    return return_dict
+    """Merged kwargs bag for `current_step`: the latest stage that has started, overlaid with the global (str) keys."""
+    started = [k for k in _stages(curriculum) if k <= current_step]
+    md = dict(curriculum[started[-1]]) if started else {}
+    md.update({k: v for k, v in curriculum.items() if not isinstance(k, int)})
+    return md
+
+
+def next_upsample_step(curriculum, current_step):
+    """First later stage whose img_size exceeds the current one (inf if none)."""
+    size_now = extract_metadata(curriculum, current_step)["img_size"]
+    later = [k for k in _stages(curriculum) if k > current_step and curriculum[k].get("img_size", 512) > size_now]
+    return later[0] if later else float("Inf")
+
+
+def last_upsample_step(curriculum, current_step):
+    """Start step of the current resolution stage (0 if none)."""
+    size_now = extract_metadata(curriculum, current_step)["img_size"]
+    same = [k for k in _stages(curriculum) if k <= current_step and curriculum[k]["img_size"] == size_now]
+    return same[0] if same else 0
+
+
+def get_current_step(curriculum, epoch):
+    return sum(1 for e in curriculum["update_epochs"] if epoch >= e)
 
 
 _CAMERA = dict(fov=12, ray_start=0.88, ray_end=1.12, fade_steps=10000, h_stddev=0.3, v_stddev=0.155,

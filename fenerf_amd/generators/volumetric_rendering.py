@@ -48,36 +48,40 @@ class RecordedDraws:
 _DEFAULT_DRAWS = TorchDraws()
 
 
-def get_initial_rays_trig(n, num_steps, device, fov, resolution, ray_start, ray_end):
-    """Camera-space sample points, z_vals and ray directions (volumetric_rendering.py:109-131)."""
+def _camera_ray_dirs(resolution, fov, device):
+    """Unit camera-space directions [R,3] of the W x H pixel grid: x in [-1,1] left->right, y in [1,-1] top->bottom,
+    z = -1/tan(fov/2); ray index = row*W + col (volumetric_rendering.py:113-121)."""
     W, H = resolution
-    x, y = torch.meshgrid(torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device), indexing="ij")
-    x = x.T.flatten()
-    y = y.T.flatten()
-    z = -torch.ones_like(x, device=device) / np.tan((2 * math.pi * fov / 360) / 2)
-    rays_d_cam = normalize_vecs(torch.stack([x, y, z], -1))
-    z_vals = torch.linspace(ray_start, ray_end, num_steps, device=device).reshape(1, num_steps, 1).repeat(W * H, 1, 1)
-    points = rays_d_cam.unsqueeze(1).repeat(1, num_steps, 1) * z_vals
-    points = torch.stack(n * [points])
-    z_vals = torch.stack(n * [z_vals])
-    rays_d_cam = torch.stack(n * [rays_d_cam]).to(device)
-    return points, z_vals, rays_d_cam
+    xs = torch.linspace(-1, 1, W, device=device)
+    ys = torch.linspace(1, -1, H, device=device)
+    x = xs.repeat(H)                       # col varies fastest
+    y = ys.repeat_interleave(W)
+    z = -torch.ones_like(x) / np.tan((2 * math.pi * fov / 360) / 2)
+    return normalize_vecs(torch.stack([x, y, z], -1))
+
+
+def get_initial_rays_trig(n, num_steps, device, fov, resolution, ray_start, ray_end):
+    """Camera-space sample points [n,R,N,3], z_vals [n,R,N,1] and ray directions [n,R,3] (volumetric_rendering.py:109-131)."""
+    d_cam = _camera_ray_dirs(resolution, fov, device)
+    depths = torch.linspace(ray_start, ray_end, num_steps, device=device)
+    z_vals = depths.reshape(1, num_steps, 1).repeat(d_cam.shape[0], 1, 1)
+    points = d_cam.unsqueeze(1) * z_vals
+    batch = lambda t: t.unsqueeze(0).repeat(n, *([1] * t.dim()))
+    return batch(points), batch(z_vals), batch(d_cam)
 
 
 def perturb_points(points, z_vals, ray_directions, device, draws=_DEFAULT_DRAWS):
-    distance_between_points = z_vals[:, :, 1:2, :] - z_vals[:, :, 0:1, :]
-    offset = (draws.rand(z_vals.shape, device) - 0.5) * distance_between_points
-    z_vals = z_vals + offset
-    points = points + offset * ray_directions.unsqueeze(2)
-    return points, z_vals
+    """Stratified jitter: every sample moves by (U[0,1) - 0.5) * bin width along its ray (:133-139)."""
+    bin_width = z_vals[:, :, 1:2, :] - z_vals[:, :, 0:1, :]
+    shift = (draws.rand(z_vals.shape, device) - 0.5) * bin_width
+    return points + shift * ray_directions.unsqueeze(2), z_vals + shift
 
 
 def truncated_normal_(tensor, mean=0, std=1):
-    size = tensor.shape
-    tmp = tensor.new_empty(size + (4,)).normal_()
-    valid = (tmp < 2) & (tmp > -2)
-    ind = valid.max(-1, keepdim=True)[1]
-    tensor.data.copy_(tmp.gather(-1, ind).squeeze(-1))
+    """In place: N(mean, std) truncated to +-2 std by taking the first of 4 candidate draws that falls inside (:170-177)."""
+    cand = tensor.new_empty(tuple(tensor.shape) + (4,)).normal_()
+    first_ok = ((cand < 2) & (cand > -2)).max(-1, keepdim=True)[1]
+    tensor.data.copy_(cand.gather(-1, first_ok).squeeze(-1))
     tensor.data.mul_(std).add_(mean)
     return tensor
 
@@ -114,71 +118,49 @@ def sample_camera_angles(device, n, horizontal_stddev, vertical_stddev, horizont
 
 def sample_camera_positions(device, n=1, r=1, horizontal_stddev=1, vertical_stddev=1, horizontal_mean=math.pi * 0.5,
                             vertical_mean=math.pi * 0.5, mode="normal", draws=_DEFAULT_DRAWS):
-    """Camera origins on a sphere; returns (origin [n,3], phi/pitch [n,1], theta/yaw [n,1])  (:179-228)."""
-    if mode == "uniform":
-        theta = (draws.rand((n, 1), device) - 0.5) * 2 * horizontal_stddev + horizontal_mean
-        phi = (draws.rand((n, 1), device) - 0.5) * 2 * vertical_stddev + vertical_mean
-    elif mode == "normal" or mode == "gaussian":
-        theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
-        phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
-    elif mode == "hybrid":
-        if random.random() < 0.5:
-            theta = (draws.rand((n, 1), device) - 0.5) * 2 * horizontal_stddev * 2 + horizontal_mean
-            phi = (draws.rand((n, 1), device) - 0.5) * 2 * vertical_stddev * 2 + vertical_mean
-        else:
-            theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
-            phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
-    elif mode == "truncated_gaussian":
-        theta = truncated_normal_(torch.zeros((n, 1), device=device)) * horizontal_stddev + horizontal_mean
-        phi = truncated_normal_(torch.zeros((n, 1), device=device)) * vertical_stddev + vertical_mean
-    elif mode == "spherical_uniform":
-        theta = (draws.rand((n, 1), device) - .5) * 2 * horizontal_stddev + horizontal_mean
-        v_stddev, v_mean = vertical_stddev / math.pi, vertical_mean / math.pi
-        v = ((draws.rand((n, 1), device) - .5) * 2 * v_stddev + v_mean)
-        v = torch.clamp(v, 1e-5, 1 - 1e-5)
-        phi = torch.arccos(1 - 2 * v)
-    else:  # just use the mean
-        theta = torch.ones((n, 1), device=device, dtype=torch.float) * horizontal_mean
-        phi = torch.ones((n, 1), device=device, dtype=torch.float) * vertical_mean
+    """Camera origins on a sphere of radius r; returns (origin [n,3], phi = pitch [n,1], theta = yaw [n,1])  (:179-228).
+    phi is clamped to [1e-5, pi - 1e-5]; y is up: origin = r (sin phi cos theta, cos phi, sin phi sin theta)."""
+    theta, phi = sample_camera_angles(device, n, horizontal_stddev, vertical_stddev, horizontal_mean, vertical_mean, mode, draws)
     phi = torch.clamp(phi, 1e-5, math.pi - 1e-5)
-    output_points = torch.zeros((n, 3), device=device)
-    output_points[:, 0:1] = r * torch.sin(phi) * torch.cos(theta)
-    output_points[:, 2:3] = r * torch.sin(phi) * torch.sin(theta)
-    output_points[:, 1:2] = r * torch.cos(phi)
-    return output_points, phi, theta
+    origin = torch.cat([r * torch.sin(phi) * torch.cos(theta), r * torch.cos(phi), r * torch.sin(phi) * torch.sin(theta)], -1)
+    return origin, phi, theta
+
+
+def _lookat_rotation(forward_vector):
+    """[n,3,3] rotation whose columns are (-left, up, -forward) for a camera looking along `forward`, world up = +y."""
+    f = normalize_vecs(forward_vector)
+    world_up = torch.zeros_like(f)
+    world_up[:, 1] = 1
+    left = normalize_vecs(torch.cross(world_up, f, dim=-1))
+    up = normalize_vecs(torch.cross(f, left, dim=-1))
+    return torch.stack((-left, up, -f), dim=-1)
 
 
 def create_cam2world_matrix(forward_vector, origin, device=None):
-    """Look-at matrix with +y up (:230-248)."""
-    forward_vector = normalize_vecs(forward_vector)
-    up_vector = torch.tensor([0, 1, 0], dtype=torch.float, device=device).expand_as(forward_vector)
-    left_vector = normalize_vecs(torch.cross(up_vector, forward_vector, dim=-1))
-    up_vector = normalize_vecs(torch.cross(forward_vector, left_vector, dim=-1))
-    rotation_matrix = torch.eye(4, device=device).unsqueeze(0).repeat(forward_vector.shape[0], 1, 1)
-    rotation_matrix[:, :3, :3] = torch.stack((-left_vector, up_vector, -forward_vector), axis=-1)
-    translation_matrix = torch.eye(4, device=device).unsqueeze(0).repeat(forward_vector.shape[0], 1, 1)
-    translation_matrix[:, :3, 3] = origin
-    return translation_matrix @ rotation_matrix
+    """4x4 camera-to-world matrices [n,4,4] = translate(origin) @ rotate(look-at)  (:230-248)."""
+    n = forward_vector.shape[0]
+    m = torch.zeros((n, 4, 4), device=forward_vector.device, dtype=forward_vector.dtype)
+    m[:, :3, :3] = _lookat_rotation(forward_vector)
+    m[:, :3, 3] = origin
+    m[:, 3, 3] = 1
+    return m
 
 
 def transform_sampled_points(points, z_vals, ray_directions, device, h_stddev=1, v_stddev=1, h_mean=math.pi * 0.5,
                              v_mean=math.pi * 0.5, mode="normal", draws=_DEFAULT_DRAWS):
-    """Reference-shaped API: jitter + camera pose + cam->world of points, dirs, origins (:142-168)."""
-    n, num_rays, num_steps, channels = points.shape
+    """Reference-shaped API (:142-168): jitter the samples, draw a camera pose, map points / directions / origins to
+    world space.  Returns (points [n,R,N,3], z_vals, dirs [n,R,3], origins [n,R,3], pitch, yaw).  Draw order: jitter,
+    theta, phi.  (The fused renderer uses sample_rays / fenerf_ray_setup instead and never builds the point tensor.)"""
+    n, num_rays, num_steps, _ = points.shape
     points, z_vals = perturb_points(points, z_vals, ray_directions, device, draws)
-    camera_origin, pitch, yaw = sample_camera_positions(n=points.shape[0], r=1, horizontal_stddev=h_stddev,
-                                                        vertical_stddev=v_stddev, horizontal_mean=h_mean,
-                                                        vertical_mean=v_mean, device=device, mode=mode, draws=draws)
-    forward_vector = normalize_vecs(-camera_origin)
-    cam2world_matrix = create_cam2world_matrix(forward_vector, camera_origin, device=device)
-    points_homogeneous = torch.ones((points.shape[0], points.shape[1], points.shape[2], points.shape[3] + 1), device=device)
-    points_homogeneous[:, :, :, :3] = points
-    transformed_points = torch.bmm(cam2world_matrix, points_homogeneous.reshape(n, -1, 4).permute(0, 2, 1)).permute(0, 2, 1).reshape(n, num_rays, num_steps, 4)
-    transformed_ray_directions = torch.bmm(cam2world_matrix[..., :3, :3], ray_directions.reshape(n, -1, 3).permute(0, 2, 1)).permute(0, 2, 1).reshape(n, num_rays, 3)
-    homogeneous_origins = torch.zeros((n, 4, num_rays), device=device)
-    homogeneous_origins[:, 3, :] = 1
-    transformed_ray_origins = torch.bmm(cam2world_matrix, homogeneous_origins).permute(0, 2, 1).reshape(n, num_rays, 4)[..., :3]
-    return transformed_points[..., :3], z_vals, transformed_ray_directions, transformed_ray_origins, pitch, yaw
+    cam_origin, pitch, yaw = sample_camera_positions(n=n, r=1, horizontal_stddev=h_stddev, vertical_stddev=v_stddev,
+                                                     horizontal_mean=h_mean, vertical_mean=v_mean, device=device, mode=mode,
+                                                     draws=draws)
+    rot = _lookat_rotation(normalize_vecs(-cam_origin))                       # [n,3,3]
+    world_points = torch.matmul(points.reshape(n, -1, 3), rot.transpose(1, 2)) + cam_origin.unsqueeze(1)
+    world_dirs = torch.matmul(ray_directions.reshape(n, -1, 3), rot.transpose(1, 2))
+    world_origins = cam_origin.unsqueeze(1).expand(n, num_rays, 3).contiguous()
+    return world_points.reshape(n, num_rays, num_steps, 3), z_vals, world_dirs.reshape(n, num_rays, 3), world_origins, pitch, yaw
 
 
 def sample_rays(n, num_steps, device, fov, resolution, ray_start, ray_end, h_stddev, v_stddev, h_mean, v_mean, mode,
@@ -194,11 +176,7 @@ def sample_rays(n, num_steps, device, fov, resolution, ray_start, ray_end, h_std
         theta, phi = sample_camera_angles(device, n, h_stddev, v_stddev, h_mean, v_mean, mode, draws=draws)
         z_cam = (-torch.ones(1) / np.tan((2 * math.pi * fov / 360) / 2)).item()   # as the reference's fp32 tensor op rounds it
         return native.ray_setup(n, W, num_steps, z_cam, ray_start, ray_end, u, theta, phi)
-    x, y = torch.meshgrid(torch.linspace(-1, 1, W, device=device), torch.linspace(1, -1, H, device=device), indexing="ij")
-    x = x.T.flatten()
-    y = y.T.flatten()
-    zc = -torch.ones_like(x) / np.tan((2 * math.pi * fov / 360) / 2)
-    rays_d_cam = normalize_vecs(torch.stack([x, y, zc], -1))                                  # [R,3]
+    rays_d_cam = _camera_ray_dirs(resolution, fov, device)                                   # [R,3]
     z_lin = torch.linspace(ray_start, ray_end, num_steps, device=device)                      # [N]
     step = (z_lin[1] - z_lin[0]) if num_steps > 1 else torch.zeros((), device=device)
     u = draws.rand((n, W * H, num_steps, 1), device)
@@ -206,9 +184,9 @@ def sample_rays(n, num_steps, device, fov, resolution, ray_start, ray_end, h_std
     camera_origin, pitch, yaw = sample_camera_positions(n=n, r=1, horizontal_stddev=h_stddev, vertical_stddev=v_stddev,
                                                         horizontal_mean=h_mean, vertical_mean=v_mean, device=device,
                                                         mode=mode, draws=draws)
-    cam2world = create_cam2world_matrix(normalize_vecs(-camera_origin), camera_origin, device=device)
-    dirs = torch.matmul(rays_d_cam.unsqueeze(0), cam2world[:, :3, :3].transpose(1, 2))       # [n,R,3]
-    origins = cam2world[:, :3, 3].unsqueeze(1).expand(n, W * H, 3).contiguous()
+    rot = _lookat_rotation(normalize_vecs(-camera_origin))
+    dirs = torch.matmul(rays_d_cam.unsqueeze(0), rot.transpose(1, 2))                        # [n,R,3]
+    origins = camera_origin.unsqueeze(1).expand(n, W * H, 3).contiguous()
     return origins, dirs.contiguous(), z_vals.contiguous(), pitch, yaw
 
 
