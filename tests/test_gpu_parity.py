@@ -565,3 +565,38 @@ def test_callers_multiview_and_voxel_grid():
     lock[..., -1] = -1
     ref = O.siren_forward(sd, spec, samples.numpy(), lock, film[0], film[1], film[2], film[3])
     np.testing.assert_allclose(vol.reshape(-1), ref[0, :, -1], atol=3e-3, rtol=2e-4)
+
+
+def test_reference_checkpoint_renders_like_the_reference():
+    """A pickled reference generator (whole nn.Module, the reference's checkpoint format) loaded through the import aliases
+    renders, on the HIP path, what the reference rendered from it."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from fenerf_amd import compat; compat.install_aliases()\n"
+        "from fenerf_amd.generators import volumetric_rendering as VR\n"
+        "g = dict(np.load(%r))\n"
+        "gen = torch.load(%r, weights_only=False).to('cuda:0').eval()\n"
+        "gen.device = torch.device('cuda:0'); gen.siren.device = gen.device\n"
+        "T = lambda a: torch.as_tensor(a, device='cuda:0')\n"
+        "rd = {k[len('stg_rand_'):]: v for k, v in g.items() if k.startswith('stg_rand_')}\n"
+        "gen.draws = VR.RecordedDraws([np.zeros((10000, 16), np.float32)] * 2 + [rd['u_jitter'], rd['r_theta'], rd['r_phi'], rd['noise_coarse'], rd['u_fine'], rd['noise_fine']])\n"
+        "orig = gen.generate_avg_frequencies\n"
+        "def patched():\n"
+        "    orig()\n"
+        "    gen.avg_frequencies_geo, gen.avg_phase_shifts_geo = T(g['stg_avg_freq_geo']), T(g['stg_avg_phase_geo'])\n"
+        "    gen.avg_frequencies_app, gen.avg_phase_shifts_app = T(g['stg_avg_freq_app']), T(g['stg_avg_phase_app'])\n"
+        "gen.generate_avg_frequencies = patched\n"
+        "kw = dict(img_size=6, num_steps=6, hierarchical_sample=True, clamp_mode='relu', nerf_noise=0.0, fov=12, ray_start=0.88, ray_end=1.12,\n"
+        "          h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, sample_dist='gaussian')\n"
+        "px, depth = gen.staged_forward(T(g['z_geo']), T(g['z_app']), psi=float(g['stg_psi']), fill_mode='seg_padding_background', fill_color='white', **kw)\n"
+        "err = np.abs(px.numpy() - g['stg_pixels']).max(axis=1)\n"
+        "assert (err > 1e-3).mean() <= 0.06, err.max()\n"
+        "print('ok', float(err[err <= 1e-3].max()))\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "tiny_texture_z_full.npz"),
+                                                                 os.path.join(GOLDEN, "ref_generator_tiny.pth"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    print("[parity] pickled reference generator -> HIP staged_forward:", r.stdout.strip())

@@ -150,3 +150,24 @@ def test_mask2color_and_voxel_samples_match_reference():
     kw = callers.multiview_kwargs(curriculums.CelebA_double_semantic_texture_embedding_256_dim_96, image_size=64)
     assert kw["num_steps"] == 48 and kw["img_size"] == 64 and kw["psi"] == 0.7 and kw["h_stddev"] == 0 and kw["nerf_noise"] == 0
     assert all(isinstance(k, str) for k in kw) and kw["fill_mode"] == "seg_padding_background"
+
+
+def test_reference_checkpoint_unpickles_into_this_package():
+    """generator.pth of the reference is a pickled nn.Module (train_double_latent_semantic.py:526) whose class paths are
+    generators.generators.* / siren.siren.*; with the import aliases it loads as this package's drop-in classes."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from fenerf_amd import compat; compat.install_aliases()\n"
+        "g = torch.load(%r, weights_only=False)\n"
+        "assert type(g).__module__ == 'fenerf_amd.generators.generators' and type(g.siren).__module__ == 'fenerf_amd.siren.siren'\n"
+        "assert g.siren.hidden_dim == 32 and g.output_dim == 22 and g.step == 0 and g.siren.gridwarper.scale_factor == 2 / 0.24\n"
+        "import numpy as np; from fenerf_amd import procedural as proc\n"
+        "spec = proc.model_spec('texture', hidden_dim=32, grid_size=8, z_dim=16)\n"
+        "sd = proc.make_state_dict(spec, seed=3, sigma_gain=300.0)\n"
+        "mine = g.siren.state_dict()\n"
+        "assert set(mine) == set(sd) and all(np.array_equal(mine[k].numpy(), sd[k]) for k in sd)\n"
+        "print('ok')\n") % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.join(GOLDEN, "ref_generator_tiny.pth"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

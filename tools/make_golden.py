@@ -335,6 +335,12 @@ def run_mapping_and_full(refs, name):
         out["stg_rand_" + k] = v
     out["stg_pixels"], out["stg_depth"] = np_(px), np_(depth)
     out["stg_psi"] = 0.7
+    # the reference's checkpoint format: the whole pickled nn.Module (train_double_latent_semantic.py:526); pins that
+    # fenerf_amd.compat.install_aliases() lets such a file unpickle into this package's classes
+    for attr in ("avg_frequencies_geo", "avg_phase_shifts_geo", "avg_frequencies_app", "avg_phase_shifts_app"):
+        if hasattr(g, attr):
+            delattr(g, attr)
+    torch.save(g, os.path.join(OUT, "ref_generator_tiny.pth"))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: mapping + forward + staged_forward")
 
