@@ -66,6 +66,7 @@ _SIGS = {
     "fenerf_resample": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_sample_pdf": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_merge_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
 }

@@ -288,6 +288,24 @@ extern "C" int fenerf_merge_composite(int64_t BR, int N, int C, const float* fin
   return launch_composite(p, true, stream);
 }
 
+extern "C" int fenerf_composite_backward(int64_t BR, int N, int C, int merge, const float* rows_a, const float* rows_b,
+                                         const float* z_a, const float* z_b, const float* noise, const FenerfCompositeOpts* opts,
+                                         const float* g_rgb, float* d_rows_a, float* d_rows_b, void* stream) {
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  const int M = merge ? 2 * N : N;
+  if (BR < 0 || N < 1 || M > 128 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= samples <= 128, C >= 2");
+  if (opts->fill_mode != FENERF_FILL_NONE) return fail(FENERF_E_UNSUPPORTED, "fill modes are not differentiated (generator.forward does not use them)");
+  if (BR == 0) return FENERF_OK;
+  if (!rows_a || !z_a || !g_rgb || !d_rows_a || (merge && (!rows_b || !z_b || !d_rows_b))) return fail(FENERF_E_INVALID, "NULL pointer");
+  CompositeParams p;
+  memset(&p, 0, sizeof(p));
+  p.BR = BR; p.M = M; p.C = C; p.N = N;
+  p.rows_a = rows_a; p.rows_b = rows_b; p.z_a = z_a; p.z_b = z_b; p.noise = noise; p.o = *opts;
+  p.g_rgb = g_rgb; p.d_rows_a = d_rows_a; p.d_rows_b = d_rows_b;
+  return launch_composite_backward(p, merge != 0, stream);
+}
+
 // workspace layout of fenerf_render_forward
 namespace {
 struct RenderWs {

@@ -182,6 +182,160 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// composite backward: d(loss)/d(rgb_final) -> d(loss)/d(rows) for the final fancy_integration of a render
+// (what torch autograd derives for volumetric_rendering.py:23-50).  Same wave-per-ray layout; the suffix sum
+// S_k = sum_{j>k} dw_j w_j is a reverse wavefront scan.  fill modes are not differentiated (generator.forward, the only
+// differentiated caller, does not use them: generators.py:519); depth is not differentiated.
+//   w_k = a_k T_k, T_k = prod_{j<k} u_j, u_j = 1 - a_j + 1e-10, a_k = 1 - exp(-delta_k act(sigma_k + noise))
+//   dL/da_k = T_k dL/dw_k - S_k / u_k ;  dL/dsigma_k = dL/da_k * delta_k (1 - a_k) act'(.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_suffix_incl(float v, int lane) {   // inclusive suffix sum across lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(v, o, 64);
+    if (lane + o < 64) v += t;
+  }
+  return v;
+}
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams P) {
+  __shared__ float s_z[4][MAX_M];
+  __shared__ float s_zs[4][MAX_M + 1];
+  __shared__ int s_ord[4][MAX_M];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int M = P.M, C = P.C, N = P.N, nch = C - 1;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
+    // ---- sorted order (identical to the forward kernel)
+    if (MERGE) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) s_z[wv][i] = i < N ? P.z_a[ray * N + i] : P.z_b[ray * N + (i - N)];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) {
+          const float zi = s_z[wv][i];
+          int rank = 0;
+          for (int j = 0; j < M; ++j) {
+            const float zj = s_z[wv][j];
+            rank += (zj < zi || (zj == zi && j < i)) ? 1 : 0;
+          }
+          s_ord[wv][rank] = i;
+          s_zs[wv][rank] = zi;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) { s_ord[wv][i] = i; s_zs[wv][i] = P.z_a[ray * M + i]; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- forward quantities per sample + dL/dw'_k = sum_c g_c row_k[c]
+    float alpha[2], tt[2], dact[2], delta[2], gw[2];
+    const float* row[2];
+    float* drow[2];
+    const float* g = P.g_rgb + ray * (long long)nch;
+    float gsum = 0.f;
+    for (int c = lane; c < nch; c += 64) gsum += g[c];
+    gsum = wave_sum(gsum);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k = lane + 64 * s;
+      alpha[s] = 0.f; tt[s] = 1.f; dact[s] = 0.f; delta[s] = 0.f; gw[s] = 0.f; row[s] = nullptr; drow[s] = nullptr;
+      if (k < M) {
+        const int src = s_ord[wv][k];
+        if (MERGE) {
+          const long long off = src < N ? (ray * N + src) * (long long)C : (ray * N + (src - N)) * (long long)C;
+          row[s] = (src < N ? P.rows_a : P.rows_b) + off;
+          drow[s] = (src < N ? P.d_rows_a : P.d_rows_b) + off;
+        } else {
+          row[s] = P.rows_a + (ray * M + k) * (long long)C;
+          drow[s] = P.d_rows_a + (ray * M + k) * (long long)C;
+        }
+        delta[s] = (k == M - 1) ? 1e10f : (s_zs[wv][k + 1] - s_zs[wv][k]);
+        float x = row[s][C - 1];
+        if (P.noise) x = __fadd_rn(x, __fmul_rn(P.noise[ray * M + k], P.o.noise_std));
+        float act;
+        if (P.o.clamp_mode == FENERF_CLAMP_SOFTPLUS) { act = softplus_f(x); dact[s] = x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+        else { act = fmaxf(x, 0.f); dact[s] = x > 0.f ? 1.f : 0.f; }
+        alpha[s] = M > 1 ? 1.f - expf(-delta[s] * act) : 0.f;
+        tt[s] = 1.f - alpha[s] + 1e-10f;
+        float acc = 0.f;
+        for (int c = 0; c < nch; ++c) acc += g[c] * row[s][c];
+        gw[s] = acc;
+      }
+    }
+    // exclusive transmittance, weights (as forward)
+    const float inc0 = wave_scan_mul(tt[0], lane);
+    const float tot0 = __shfl(inc0, 63, 64);
+    float T[2];
+    T[0] = __shfl_up(inc0, 1, 64);
+    if (lane == 0) T[0] = 1.f;
+    T[1] = 1.f;
+    if (M > 64) {
+      const float inc1 = wave_scan_mul(tt[1], lane);
+      float ex1 = __shfl_up(inc1, 1, 64);
+      if (lane == 0) ex1 = 1.f;
+      T[1] = tot0 * ex1;
+    }
+    float w[2] = {alpha[0] * T[0], (M > 64) ? alpha[1] * T[1] : 0.f};
+    const float wsum = wave_sum(w[0] + w[1]);
+    // rgb += (1 - wsum) for white_back, -= for black_back: d/dw_j = -+ sum_c g_c
+    if (P.o.white_back) { gw[0] -= gsum; gw[1] -= gsum; }
+    if (P.o.black_back) { gw[0] += gsum; gw[1] += gsum; }
+    float wp[2] = {w[0], w[1]};   // weights actually used in the colour sum (after last_back)
+    if (P.o.last_back) {
+      // w'_last = w_last + 1 - sum_j w_j  ->  dL/dw_j = dL/dw'_j - dL/dw'_last
+      const int ls = (M - 1) >> 6, ll = (M - 1) & 63;
+      const float g_last = __shfl(ls ? gw[1] : gw[0], ll, 64);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (lane + 64 * s == M - 1) wp[s] += 1.f - wsum;
+        gw[s] -= g_last;
+      }
+    }
+    // S_k = sum_{j>k} gw_j w_j
+    float q[2] = {gw[0] * w[0], gw[1] * w[1]};
+    if (lane + 64 >= M) q[1] = 0.f;
+    if (lane >= M) q[0] = 0.f;
+    const float suf1 = wave_suffix_incl(q[1], lane);
+    const float tot1 = __shfl(suf1, 0, 64);
+    const float suf0 = wave_suffix_incl(q[0], lane) + tot1;
+    const float S[2] = {suf0 - q[0], suf1 - q[1]};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k = lane + 64 * s;
+      if (k < M) {
+        const float dalpha = T[s] * gw[s] - S[s] / tt[s];
+        const float dsigma = (M > 1) ? dalpha * delta[s] * (1.f - alpha[s]) * dact[s] : 0.f;
+        for (int c = 0; c < nch; ++c) drow[s][c] = wp[s] * g[c];
+        drow[s][C - 1] = dsigma;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int launch_composite_backward(const CompositeParams& p, bool merge, void* stream) {
+  if (p.BR <= 0) return FENERF_OK;
+  long long blocks = (p.BR + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (merge) hipLaunchKernelGGL(composite_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(composite_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("composite_backward launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+  return FENERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // importance resampling: generators.py:486-499 + sample_pdf (volumetric_rendering.py:259-300)
 // ------------------------------------------------------------------------------------------------
 // RAW = false: zc [BR,N], wc [BR,N] (coarse z / weights), K = N-2, draws N samples      (generators.py:486-499)

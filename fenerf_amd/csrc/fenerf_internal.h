@@ -67,6 +67,10 @@ struct CompositeParams {
   float* out_rgb; float* out_depth; float* out_weights; float* out_wsum; float* out_z;
   int out_ch;              // channels written per ray (C-1 or C)
   int sigma_only;          // coarse pass: only weights wanted, skip colour accumulation
+  // backward (fenerf_composite_backward): gradient of the loss wrt out_rgb [BR][C-1] in, wrt the rows out
+  const float* g_rgb;
+  float* d_rows_a;         // non-merge: [BR][M][C]; merge: d fine [BR][N][C]
+  float* d_rows_b;         // merge: d coarse [BR][N][C]
 };
 
 int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
@@ -74,6 +78,7 @@ int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* 
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
+int launch_composite_backward(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);
 int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const float* w, const float* u, float* out, void* stream);
 int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,

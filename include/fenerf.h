@@ -170,6 +170,15 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
                            float* out_rgb, float* out_depth, float* out_weights, float* out_wsum,
                            float* out_z_sorted, void* stream);
 
+/* replaces: what torch autograd derives for the final fancy_integration of a differentiable render
+ * (generators.py:519 / :790; G-step and inversion): gradient wrt rgb_final g_rgb [BR, C-1] -> gradients wrt the SIREN
+ * outputs.  merge = 0: rows_a [BR,N,C], z_a [BR,N] -> d_rows_a [BR,N,C].  merge = 1: fine rows_a / coarse rows_b with
+ * z_a / z_b as in fenerf_merge_composite -> d_rows_a (fine), d_rows_b (coarse), each in its own (unsorted) order.
+ * noise is indexed by sorted position like the forward.  fill_mode must be FENERF_FILL_NONE; depth is not differentiated. */
+int fenerf_composite_backward(int64_t BR, int N, int C, int merge, const float* rows_a, const float* rows_b,
+                              const float* z_a, const float* z_b, const float* noise, const FenerfCompositeOpts* opts,
+                              const float* g_rgb, float* d_rows_a, float* d_rows_b, void* stream);
+
 /* Bytes of [dev] scratch fenerf_render_forward needs. */
 size_t fenerf_render_workspace_bytes(const FenerfModel* m, int B, int R, int N, int hierarchical);
 

@@ -600,3 +600,57 @@ def test_reference_checkpoint_renders_like_the_reference():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     print("[parity] pickled reference generator -> HIP staged_forward:", r.stdout.strip())
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward: composite gradient vs torch autograd of the fp64 restatement
+# ---------------------------------------------------------------------------------------------------
+def _grad_case(BR, N, C, seed, merge):
+    rng = np.random.default_rng(seed)
+    M = 2 * N if merge else N
+    rows = rng.normal(size=(BR, M, C)).astype(np.float32)
+    rows[..., -1] = rng.normal(size=(BR, M)).astype(np.float32) * 6 * (1 + (np.arange(BR) % 5))[:, None]
+    z = np.sort(rng.uniform(0.88, 1.12, (BR, M)).astype(np.float32), -1)
+    if merge:
+        z = rng.permuted(z, axis=-1)     # fine / coarse halves are each unsorted relative to the union
+        z[:, :N] = np.sort(z[:, :N], -1); z[:, N:] = np.sort(z[:, N:], -1)
+    noise = rng.normal(size=(BR, M)).astype(np.float32)
+    g = rng.normal(size=(BR, C - 1)).astype(np.float32)
+    return rows, z, noise, g
+
+
+@pytest.mark.parametrize("clamp,last_back,white,black,noise_std", [("relu", False, False, False, 0.0), ("softplus", False, False, False, 0.5),
+                                                                    ("relu", True, False, False, 0.3), ("relu", False, True, False, 0.0),
+                                                                    ("softplus", True, False, True, 0.2)])
+@pytest.mark.parametrize("N", [1, 7, 24, 64, 100])
+def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise_std):
+    from oracle import fenerf_oracle_grad as OG
+    rows, z, noise, g = _grad_case(37, N, 22, 5 + N, False)
+    opts = _lib.composite_opts(clamp, last_back=last_back, white_back=white, black_back=black, noise_std=noise_std)
+    got = N_(native.composite_backward(T(g), T(rows), T(z), opts, noise=T(noise)))
+    r = torch.tensor(rows, dtype=torch.float64, requires_grad=True)
+    rgb, _, _ = OG.composite(r, torch.tensor(z, dtype=torch.float64), torch.tensor(noise, dtype=torch.float64), noise_std=noise_std,
+                             clamp_mode=clamp, last_back=last_back, white_back=white, black_back=black)
+    (rgb * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    ref = r.grad.numpy()
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    print(f"[parity] composite backward N={N} {clamp} lb={last_back}: max|err| {err:.2e} (|grad| max {scale:.3g})")
+    assert err <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("N", [12, 24, 64])
+def test_merge_composite_backward_vs_autograd(N):
+    from oracle import fenerf_oracle_grad as OG
+    rows, z, noise, g = _grad_case(29, N, 22, 40 + N, True)
+    opts = _lib.composite_opts("relu", noise_std=0.4)
+    df, dc = native.composite_backward(T(g), T(rows[:, :N]), T(z[:, :N]), opts, rows_b=T(rows[:, N:]), z_b=T(z[:, N:]), noise=T(noise))
+    f = torch.tensor(rows[:, :N], dtype=torch.float64, requires_grad=True)
+    c = torch.tensor(rows[:, N:], dtype=torch.float64, requires_grad=True)
+    rgb, _, _ = OG.merge_composite(f, c, torch.tensor(z[:, :N], dtype=torch.float64), torch.tensor(z[:, N:], dtype=torch.float64),
+                                   torch.tensor(noise, dtype=torch.float64), noise_std=0.4, clamp_mode="relu")
+    (rgb * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    scale = max(1.0, f.grad.abs().max().item(), c.grad.abs().max().item())
+    err = max(np.abs(N_(df) - f.grad.numpy()).max(), np.abs(N_(dc) - c.grad.numpy()).max())
+    print(f"[parity] merge composite backward N={N}: max|err| {err:.2e} (|grad| max {scale:.3g})")
+    assert err <= 2e-5 * scale

@@ -197,3 +197,30 @@ def test_mapping_and_truncation():
     bad = np.abs(px - g["stg_pixels"]).max(axis=1) > 2e-3
     assert bad.mean() <= 0.05
     np.testing.assert_allclose(depth[~bad], g["stg_depth"][~bad], atol=1e-4)
+
+
+def test_grad_oracle_matches_numpy_oracle():
+    """The differentiable (torch) restatement used to check the HIP backward kernels computes the same forward as the
+    golden-pinned numpy oracle, so its autograd gradients are gradients of the reference's function."""
+    import torch
+    from oracle import fenerf_oracle_grad as OG
+    rng = np.random.default_rng(0)
+    rows = rng.normal(size=(2, 5, 9, 22)); rows[..., -1] *= 8
+    z = np.sort(rng.uniform(.88, 1.12, (2, 5, 9, 1)), -2)
+    nz = rng.normal(size=(2, 5, 9, 1))
+    for kw in [dict(clamp_mode="relu"), dict(clamp_mode="softplus", last_back=True), dict(clamp_mode="relu", white_back=True),
+               dict(clamp_mode="relu", black_back=True, last_back=True)]:
+        a = O.fancy_integration(rows, z, nz, noise_std=.3, **kw)
+        b = OG.composite(torch.tensor(rows).reshape(10, 9, 22), torch.tensor(z).reshape(10, 9), torch.tensor(nz).reshape(10, 9),
+                         noise_std=.3, **kw)
+        np.testing.assert_allclose(a[0].reshape(10, 21), b[0].numpy(), atol=1e-13)
+        np.testing.assert_allclose(a[1].reshape(10), b[1].numpy(), atol=1e-13)
+        np.testing.assert_allclose(a[2].reshape(10, 9), b[2].numpy(), atol=1e-13)
+    # merge: fine|coarse cat + stable sort + gather
+    f, c = rows[:, :, :4], rows[:, :, 4:8]
+    zf, zc = z[:, :, [0, 2, 4, 6]], z[:, :, [1, 3, 5, 7]]
+    mo, mz = O.merge_sorted(f, c, zf, zc)
+    a = O.fancy_integration(mo, mz, None, clamp_mode="relu")
+    b = OG.merge_composite(torch.tensor(f).reshape(10, 4, 22), torch.tensor(c).reshape(10, 4, 22), torch.tensor(zf).reshape(10, 4),
+                           torch.tensor(zc).reshape(10, 4), None, clamp_mode="relu")
+    np.testing.assert_allclose(a[0].reshape(10, 21), b[0].numpy(), atol=1e-13)
