@@ -32,7 +32,7 @@ class FenerfModelDesc(C.Structure):
         ("color_w", _fp * MAX_COLOR), ("color_b", _fp * MAX_COLOR),
         ("label_w", _fp * MAX_LABEL), ("label_b", _fp * MAX_LABEL),
         ("sigma_w", _fp), ("sigma_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp), ("grid", _fp),
-        ("precision", C.c_int32),
+        ("precision", C.c_int32), ("differentiable", C.c_int32),
     ]
 
 
@@ -66,6 +66,10 @@ _SIGS = {
     "fenerf_resample": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_sample_pdf": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_merge_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_siren_tape_floats": (_sz, [_vp, _i64]),
+    "fenerf_siren_forward_save": (_i, [_vp, _i, _i64] + [_vp] * 11),
+    "fenerf_siren_backward": (_i, [_vp, _i, _i64] + [_vp] * 11),
+    "fenerf_grid_backward": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
@@ -105,7 +109,7 @@ def _as_f32(a):
 PRECISION = {"f32": 0, "f16x3": 1}
 
 
-def make_desc(sd, spec, precision="f32"):
+def make_desc(sd, spec, precision="f32", differentiable=False):
     """Builds a FenerfModelDesc from a reference-named state dict of numpy arrays.
     Returns (desc, keepalive) -- keepalive holds the host arrays the desc points into."""
     keep = []
@@ -121,6 +125,7 @@ def make_desc(sd, spec, precision="f32"):
     d.n_label_layers, d.output_dim, d.grid_ch = spec["n_label_layers"], spec["output_dim"], spec["grid_ch"]
     d.box_scale = 2 / 0.24
     d.precision = PRECISION[precision]
+    d.differentiable = int(bool(differentiable))
     for i in range(spec["n_geo"]):
         d.geo_w[i], d.geo_b[i] = P(f"network.{i}.layer.weight"), P(f"network.{i}.layer.bias")
     if spec["kind"] == "spatial":

@@ -52,6 +52,13 @@ static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t st
   }
   HIP_TRY(hipMemcpyAsync(m->d_stream, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(m->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  std::vector<float> bwd;
+  if (m->differentiable) {
+    rc = pack_weights_bwd(d, bwd, err);
+    if (rc) return fail(rc, err);
+    if (allocate) HIP_TRY(hipMalloc((void**)&m->d_bwd_stream, bwd.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(m->d_bwd_stream, bwd.data(), bwd.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  }
   if (d->grid_ch && d->grid) {
     const size_t n = (size_t)d->grid_ch * d->grid_d * d->grid_h * d->grid_w;
     if (allocate) HIP_TRY(hipMalloc((void**)&m->d_grid, n * sizeof(float)));
@@ -92,7 +99,10 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   m->grid_ch = d->grid_ch; m->gd = d->grid_d; m->gh = d->grid_h; m->gw = d->grid_w;
   m->box_scale = d->box_scale;
   m->precision = d->precision;
+  m->differentiable = d->differentiable != 0;
   if (d->precision != FENERF_PREC_F32 && d->precision != FENERF_PREC_F16X3) { delete m; return fail(FENERF_E_INVALID, "unknown precision"); }
+  if (m->differentiable && d->precision != FENERF_PREC_F32) { delete m; return fail(FENERF_E_UNSUPPORTED, "differentiable models run at FENERF_PREC_F32"); }
+  m->bsh = bwd_stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   m->sh = stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   int dev = 0;
   hipDeviceProp_t prop;
@@ -112,7 +122,7 @@ extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, voi
   int rc = validate_desc(d, err);
   if (rc) return fail(rc, err);
   if (d->hidden_dim != m->H || d->n_geo != m->n_geo || d->n_color != m->n_color || d->output_dim != m->C ||
-      d->grid_ch != m->grid_ch || d->precision != m->precision || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
+      d->grid_ch != m->grid_ch || d->precision != m->precision || (d->differentiable != 0) != (m->differentiable != 0) || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
     return fail(FENERF_E_INVALID, "fenerf_model_update: architecture differs from the created model");
   m->box_scale = d->box_scale;
   return upload_model(m, d, (hipStream_t)stream, false);
@@ -123,6 +133,7 @@ extern "C" void fenerf_model_destroy(FenerfModel* m) {
   if (m->d_stream) (void)hipFree(m->d_stream);
   if (m->d_consts) (void)hipFree(m->d_consts);
   if (m->d_grid) (void)hipFree(m->d_grid);
+  if (m->d_bwd_stream) (void)hipFree(m->d_bwd_stream);
   delete m;
 }
 
@@ -286,6 +297,62 @@ extern "C" int fenerf_merge_composite(int64_t BR, int N, int C, const float* fin
   p.out_ch = out_channels(C, opts);
   p.sigma_only = out_rgb ? 0 : 1;
   return launch_composite(p, true, stream);
+}
+
+extern "C" size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points) {
+  if (!m || total_points <= 0) return 0;
+  return (size_t)m->L * m->H * (size_t)total_points;
+}
+
+extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                         const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                         const float* phase_app, float* out, float* tape, float* tape_e, void* film_ws,
+                                         void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P == 0) return FENERF_OK;
+  if (!points || !out || !tape || (m->grid_ch && !tape_e)) return fail(FENERF_E_INVALID, "points / out / tape is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.points = points; sp.pdirs = ray_dirs;
+  sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
+  sp.out = out; sp.tape = tape; sp.tape_e = tape_e;
+  return launch_siren(m, sp, stream);
+}
+
+extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                     const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                     const float* tape, float* d_t, float* d_e, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P == 0) return FENERF_OK;
+  if (!out || !d_out || !tape || !d_t || (m->grid_ch && !d_e)) return fail(FENERF_E_INVALID, "NULL pointer");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenBwdParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.stream = m->d_bwd_stream;
+  bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
+  bp.fp = fp; bp.pp = pp;
+  bp.P = (long long)B * P; bp.pts_per_image = P;
+  bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
+  return launch_siren_backward(m, bp, stream);
+}
+
+extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e,
+                                    float* d_grid_cl, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "model has no feature grid");
+  if (total_points < 0) return fail(FENERF_E_INVALID, "total_points < 0");
+  if (total_points == 0) return FENERF_OK;
+  if (!points || !d_e || !d_grid_cl) return fail(FENERF_E_INVALID, "NULL pointer");
+  return launch_grid_backward(m, total_points, points, d_e, d_grid_cl, stream);
 }
 
 extern "C" int fenerf_composite_backward(int64_t BR, int N, int C, int merge, const float* rows_a, const float* rows_b,

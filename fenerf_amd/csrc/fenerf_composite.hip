@@ -288,9 +288,6 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
     }
     float w[2] = {alpha[0] * T[0], (M > 64) ? alpha[1] * T[1] : 0.f};
     const float wsum = wave_sum(w[0] + w[1]);
-    // rgb += (1 - wsum) for white_back, -= for black_back: d/dw_j = -+ sum_c g_c
-    if (P.o.white_back) { gw[0] -= gsum; gw[1] -= gsum; }
-    if (P.o.black_back) { gw[0] += gsum; gw[1] += gsum; }
     float wp[2] = {w[0], w[1]};   // weights actually used in the colour sum (after last_back)
     if (P.o.last_back) {
       // w'_last = w_last + 1 - sum_j w_j  ->  dL/dw_j = dL/dw'_j - dL/dw'_last
@@ -302,6 +299,10 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
         gw[s] -= g_last;
       }
     }
+    // rgb += (1 - wsum) for white_back, -= for black_back (wsum taken BEFORE the last_back adjustment,
+    // volumetric_rendering.py:40-48): d/dw_j = -+ sum_c g_c
+    if (P.o.white_back) { gw[0] -= gsum; gw[1] -= gsum; }
+    if (P.o.black_back) { gw[0] += gsum; gw[1] += gsum; }
     // S_k = sum_{j>k} gw_j w_j
     float q[2] = {gw[0] * w[0], gw[1] * w[1]};
     if (lane + 64 >= M) q[1] = 0.f;

@@ -14,6 +14,7 @@ void set_error(const std::string& msg);
 int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
+int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err);
 
 }  // namespace fenerf
 
@@ -28,6 +29,9 @@ struct FenerfModel {
   float* d_grid;    // channels-last [D][H][W][32] or nullptr
   int num_cus;
   int precision;    // FENERF_PREC_*
+  int differentiable;       // desc->differentiable: the backward-chain stream is resident too
+  fenerf::BwdShape bsh;
+  float* d_bwd_stream;      // [rgb-head^T entries | backward ring] * 256 floats, or nullptr
 };
 
 namespace fenerf {
@@ -53,6 +57,23 @@ struct SirenParams {
   long long pts_per_image;
   float* out;              // [P][C]
   long long ring_offset_floats;  // offset of the ring stream inside `stream`
+  // differentiable evaluation (fenerf_siren_forward_save): pre-FiLM accumulators W x (no bias) of every FiLM layer,
+  // feature-major [L][H][P], and the sampled grid features [P][32]
+  float* tape;
+  float* tape_e;
+};
+
+struct SirenBwdParams {
+  const float* stream;     // backward stream
+  long long ring_offset_floats;
+  const float* fp;         // [B][L][H] as the forward
+  const float* pp;
+  long long P, pts_per_image;
+  const float* out;        // [P][C] forward outputs (sigmoid' of the rgb head)
+  const float* d_out;      // [P][C] gradient wrt the outputs
+  const float* tape;       // [L][H][P] from the forward
+  float* d_t;              // [L][H][P] out: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
+  float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
 };
 
 struct CompositeParams {
@@ -76,6 +97,8 @@ struct CompositeParams {
 int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
                      float* fp, float* pp, void* stream);
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
+int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
+int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_composite_backward(const CompositeParams& p, bool merge, void* stream);

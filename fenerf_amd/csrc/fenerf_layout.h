@@ -50,6 +50,35 @@ inline StreamShape stream_shape(int H, int n_geo, int n_color, bool grid) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward chain (fenerf_siren_bwd.hip): dx_{l-1} = W_l^T dz_l runs on the same transposed fp32 MFMA with the same
+// C/D -> B register identity, so its stream is the forward format applied to the TRANSPOSED matrices, in reverse
+// layer order:  [rgb-head^T block: NB plain entries] | ring: C_{L-1}^T .. C_{n_geo+1}^T, the colour-layer-0 stage
+// (NB bodies [W_c0[:, x-part]^T | head^T (16 k-steps: lane-half h multiplies head row 16h + s)], then one body
+// W_c0[:, grid-part]^T -> d(grid features)), G_{n_geo-1}^T .. G_1^T, tail pad.
+#define FENERF_HEAD_KSTEPS 16
+struct BwdShape {
+  int H, NB, KGX, KGXP;
+  int c0_kg, c0_kgp;
+  int ht_entries;
+  long long ring_entries;
+};
+
+inline BwdShape bwd_stream_shape(int H, int n_geo, int n_color, bool grid) {
+  BwdShape s;
+  s.H = H; s.NB = H / 32; s.KGX = H / 8; s.KGXP = pad_pf(s.KGX);
+  s.c0_kg = s.KGX + FENERF_HEAD_KSTEPS / 4;
+  s.c0_kgp = pad_pf(s.c0_kg);
+  s.ht_entries = s.NB;
+  long long e = 0;
+  e += (long long)(n_color - 1) * s.NB * s.KGXP;
+  e += (long long)s.NB * s.c0_kgp + (grid ? s.KGXP : 0);
+  e += (long long)(n_geo - 1) * s.NB * s.KGXP;
+  e += FENERF_PF;
+  s.ring_entries = e;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // f16x3 mode (error-compensated fp16 MFMA): v_mfma_f32_32x32x16_f16, k-step = 16 features.
 // Each fp32 product w*x is evaluated as wh*xh + wh*xl + wl*xh with (h, l) = fp16 hi/lo splits of
 // (w * 2^e_layer) and (x * 16); the result is exact to ~2^-22 relative (fp32 class), accumulated in fp32.

@@ -1,0 +1,90 @@
+// Device helpers shared by the forward (fenerf_siren.hip) and backward (fenerf_siren_bwd.hip) fp32-MFMA SIREN kernels:
+// the v_mfma_f32_32x32x2_f32 wrapper, the 8-deep register prefetch ring over the packed weight stream, FiLM parameter
+// loads and the per-wave LDS activation slab.  Layout conventions: fenerf_layout.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fenerf_layout.h"
+
+namespace fenerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// sin(2*pi*t), t in revolutions: v_sin_f32 (does its own range reduction).  Measured on MI355X
+// (tools/probe/probe.hip): max abs error 1.2e-7 for |t| <= 45 revolutions -- tighter than a degree-9 polynomial
+// evaluated in fp32 (2.1e-7) and one quarter-rate instruction instead of thirteen.
+__device__ __forceinline__ float sin2pi(float t) { return __builtin_amdgcn_sinf(t); }
+
+struct Ring {
+  float4 w[FENERF_PF];
+  const float4* ptr;  // per-lane cursor: next entry to fetch
+};
+
+// Consume the next ring entry (compile-time slot) and refill the slot with the entry PF ahead.
+#define RING_NEXT(ring, slot, dst)      \
+  do {                                  \
+    (dst) = (ring).w[(slot)];           \
+    (ring).w[(slot)] = *(ring).ptr;     \
+    (ring).ptr += 64;                   \
+  } while (0)
+
+// acc += W_body[:, k-steps of an H-wide activation] * b  (NKG real entries, NKGP consumed)
+template <int NIN, int NKG, int NKGP>
+__device__ __forceinline__ void mfma_x(f32x16& acc, const float (&b)[NIN], Ring& ring) {
+  static_assert(NKG * 4 == NIN, "k-groups must cover the activation");
+  static_assert(NKGP % FENERF_PF == 0, "bodies are padded to the ring depth");
+#pragma unroll
+  for (int kg = 0; kg < NKGP; ++kg) {
+    float4 w;
+    RING_NEXT(ring, kg % FENERF_PF, w);
+    if (kg < NKG) {
+      acc = MFMA(w.x, b[4 * kg + 0], acc);
+      acc = MFMA(w.y, b[4 * kg + 1], acc);
+      acc = MFMA(w.z, b[4 * kg + 2], acc);
+      acc = MFMA(w.w, b[4 * kg + 3], acc);
+    }
+    // pin the (refill, 4 x MFMA) order: without it the scheduler sinks the refill loads next to their use
+    // (to shorten live ranges) and the prefetch distance collapses from PF entries to ~1.
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// FiLM parameters of one n-block for this lane-half: features 32nb + 8j + 4h + {0..3}, j = 0..3.
+// Loaded BEFORE the n-block's MFMAs so the L2 latency hides behind them.
+struct FilmNB { float4 f[4], p[4]; };
+__device__ __forceinline__ FilmNB film_load(const float* fpl, const float* ppl, int nb) {
+  FilmNB fm;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fm.f[j] = *reinterpret_cast<const float4*>(fpl + 32 * nb + 8 * j);
+    fm.p[j] = *reinterpret_cast<const float4*>(ppl + 32 * nb + 8 * j);
+  }
+  return fm;
+}
+
+// FiLM epilogue of one n-block: out = sin(2 pi (f' acc + p')) -> this lane's LDS slab, groups nb*4 .. nb*4+3
+__device__ __forceinline__ void film_store(const f32x16& acc, const FilmNB& fm, int nb, float4* slab /* + lane */) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 f = fm.f[j], p = fm.p[j];
+    float4 o;
+    o.x = sin2pi(__builtin_fmaf(f.x, acc[4 * j + 0], p.x));
+    o.y = sin2pi(__builtin_fmaf(f.y, acc[4 * j + 1], p.y));
+    o.z = sin2pi(__builtin_fmaf(f.z, acc[4 * j + 2], p.z));
+    o.w = sin2pi(__builtin_fmaf(f.w, acc[4 * j + 3], p.w));
+    slab[(nb * 4 + j) * 64] = o;
+  }
+}
+
+template <int NIN>
+__device__ __forceinline__ void load_act(float (&in)[NIN], const float4* slab) {
+#pragma unroll
+  for (int g = 0; g < NIN / 4; ++g) {
+    const float4 v = slab[g * 64];
+    in[4 * g + 0] = v.x; in[4 * g + 1] = v.y; in[4 * g + 2] = v.z; in[4 * g + 3] = v.w;
+  }
+}
+
+}  // namespace fenerf

@@ -44,6 +44,42 @@ static std::vector<double> to_f64(const float* p, size_t n) {
   return v;
 }
 
+// HEAD matrix [32][H]: rows [0, n_lab) = the label head folded to one affine map (2-3 Linear layers with no activation
+// between them, siren.py:1490-1494; folded in fp64), row n_lab = sigma.  head_b = the matching biases.
+static void fold_head(const FenerfModelDesc* d, std::vector<double>& Wh, std::vector<double>& head_b) {
+  const int H = d->hidden_dim, n_lab = d->output_dim - 4;
+  Wh.assign((size_t)32 * H, 0.0);
+  head_b.assign(32, 0.0);
+  if (n_lab > 0) {
+    int rows = (d->n_label_layers == 1) ? n_lab : H;
+    std::vector<double> A = to_f64(d->label_w[0], (size_t)rows * H), c = to_f64(d->label_b[0], rows);
+    for (int i = 1; i < d->n_label_layers; ++i) {
+      const int orow = (i == d->n_label_layers - 1) ? n_lab : H;
+      auto Wi = to_f64(d->label_w[i], (size_t)orow * rows);
+      auto bi = to_f64(d->label_b[i], orow);
+      std::vector<double> A2((size_t)orow * H, 0.0), c2(orow, 0.0);
+      for (int o = 0; o < orow; ++o) {
+        double cb = bi[o];
+        for (int k = 0; k < rows; ++k) {
+          const double w = Wi[(size_t)o * rows + k];
+          cb += w * c[k];
+          const double* arow = &A[(size_t)k * H];
+          double* drow = &A2[(size_t)o * H];
+          for (int x = 0; x < H; ++x) drow[x] += w * arow[x];
+        }
+        c2[o] = cb;
+      }
+      A.swap(A2); c.swap(c2); rows = orow;
+    }
+    for (int o = 0; o < n_lab; ++o) {
+      for (int x = 0; x < H; ++x) Wh[(size_t)o * H + x] = A[(size_t)o * H + x];
+      head_b[o] = c[o];
+    }
+  }
+  for (int x = 0; x < H; ++x) Wh[(size_t)n_lab * H + x] = d->sigma_w[x];
+  head_b[n_lab] = d->sigma_b[0];
+}
+
 int validate_desc(const FenerfModelDesc* d, std::string& err) {
   if (!d) { err = "desc is NULL"; return FENERF_E_INVALID; }
   if (d->abi_version != FENERF_ABI_VERSION) { err = "abi_version mismatch"; return FENERF_E_INVALID; }
@@ -67,7 +103,7 @@ int validate_desc(const FenerfModelDesc* d, std::string& err) {
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err) {
   int rc = validate_desc(d, err);
   if (rc) return rc;
-  const int H = d->hidden_dim, n_lab = d->output_dim - 4;
+  const int H = d->hidden_dim;
   const bool grid = d->grid_ch != 0;
   const StreamShape sh = stream_shape(H, d->n_geo, d->n_color, grid);
   const int L = d->n_geo + d->n_color;
@@ -106,38 +142,9 @@ int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector
   }
   // ---- HEAD: rows [0, n_lab) = folded label head, row n_lab = sigma.  The label head is 2-3 Linear layers with
   //      no activation between them (siren.py:1490-1494), i.e. one affine map; fold it in fp64.
-  std::vector<double> head_b(32, 0.0);
+  std::vector<double> head_b, Wh;
+  fold_head(d, Wh, head_b);
   {
-    std::vector<double> Wh((size_t)32 * H, 0.0);
-    if (n_lab > 0) {
-      // A (rows x H), c (rows): running affine map, start with layer 0
-      int rows = (d->n_label_layers == 1) ? n_lab : H;
-      std::vector<double> A = to_f64(d->label_w[0], (size_t)rows * H), c = to_f64(d->label_b[0], rows);
-      for (int i = 1; i < d->n_label_layers; ++i) {
-        const int orow = (i == d->n_label_layers - 1) ? n_lab : H;
-        auto Wi = to_f64(d->label_w[i], (size_t)orow * rows);
-        auto bi = to_f64(d->label_b[i], orow);
-        std::vector<double> A2((size_t)orow * H, 0.0), c2(orow, 0.0);
-        for (int o = 0; o < orow; ++o) {
-          double cb = bi[o];
-          for (int k = 0; k < rows; ++k) {
-            const double w = Wi[(size_t)o * rows + k];
-            cb += w * c[k];
-            const double* arow = &A[(size_t)k * H];
-            double* drow = &A2[(size_t)o * H];
-            for (int x = 0; x < H; ++x) drow[x] += w * arow[x];
-          }
-          c2[o] = cb;
-        }
-        A.swap(A2); c.swap(c2); rows = orow;
-      }
-      for (int o = 0; o < n_lab; ++o) {
-        for (int x = 0; x < H; ++x) Wh[(size_t)o * H + x] = A[(size_t)o * H + x];
-        head_b[o] = c[o];
-      }
-    }
-    for (int x = 0; x < H; ++x) Wh[(size_t)n_lab * H + x] = d->sigma_w[x];
-    head_b[n_lab] = d->sigma_b[0];
     emit_body(blob, Wh.data(), 32, H, 0, x_ksteps(0), sh.KGXP);
   }
   // ---- C1..
@@ -208,7 +215,7 @@ static std::vector<double> row_scales(const double* W, int nrows, int ncols) {
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err) {
   int rc = validate_desc(d, err);
   if (rc) return rc;
-  const int H = d->hidden_dim, n_lab = d->output_dim - 4;
+  const int H = d->hidden_dim;
   const bool grid = d->grid_ch != 0;
   const StreamShape16 sh = stream_shape16(H, d->n_geo, d->n_color, grid);
   const int L = d->n_geo + d->n_color;
@@ -262,36 +269,9 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
     for (int nb = 0; nb < sh.NB; ++nb) emit_body16(ring, W.data(), H, cin, nb * 32, ks, sh.c0_ep, sc);
     pad_stage_to(begin, sh.c0_stage_e);
   }
-  std::vector<double> head_b(32, 0.0);
+  std::vector<double> head_b, Wh;
+  fold_head(d, Wh, head_b);
   {  // HEAD: folded label rows + sigma row, per-row scaled (label and sigma magnitudes differ by orders)
-    std::vector<float> tmp_blob, tmp_consts;
-    std::vector<double> Wh((size_t)32 * H, 0.0);
-    if (n_lab > 0) {
-      int rows = (d->n_label_layers == 1) ? n_lab : H;
-      std::vector<double> A = to_f64(d->label_w[0], (size_t)rows * H), c = to_f64(d->label_b[0], rows);
-      for (int i = 1; i < d->n_label_layers; ++i) {
-        const int orow = (i == d->n_label_layers - 1) ? n_lab : H;
-        auto Wi = to_f64(d->label_w[i], (size_t)orow * rows);
-        auto bi = to_f64(d->label_b[i], orow);
-        std::vector<double> A2((size_t)orow * H, 0.0), c2(orow, 0.0);
-        for (int o = 0; o < orow; ++o) {
-          double cb = bi[o];
-          for (int k = 0; k < rows; ++k) {
-            const double w = Wi[(size_t)o * rows + k];
-            cb += w * c[k];
-            for (int x = 0; x < H; ++x) A2[(size_t)o * H + x] += w * A[(size_t)k * H + x];
-          }
-          c2[o] = cb;
-        }
-        A.swap(A2); c.swap(c2); rows = orow;
-      }
-      for (int o = 0; o < n_lab; ++o) {
-        for (int x = 0; x < H; ++x) Wh[(size_t)o * H + x] = A[(size_t)o * H + x];
-        head_b[o] = c[o];
-      }
-    }
-    for (int x = 0; x < H; ++x) Wh[(size_t)n_lab * H + x] = d->sigma_w[x];
-    head_b[n_lab] = d->sigma_b[0];
     auto sc = row_scales(Wh.data(), 32, H);
     for (int r = 0; r < 32; ++r) head_inv[r] = (float)(1.0 / (sc[r] * act));
     const size_t begin = ring.size();
@@ -332,6 +312,65 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
   memcpy(sc_out, inv_scale.data(), sizeof(float) * (size_t)L * H);
   memcpy(sc_out + (size_t)L * H, head_inv.data(), sizeof(float) * 32);
   memcpy(sc_out + (size_t)L * H + 32, rgb_inv.data(), sizeof(float) * 4);
+  return FENERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-chain stream (fenerf_layout.h "Backward chain"): the forward format applied to transposed matrices
+// ------------------------------------------------------------------------------------------------
+int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err) {
+  int rc = validate_desc(d, err);
+  if (rc) return rc;
+  const int H = d->hidden_dim;
+  const bool grid = d->grid_ch != 0;
+  const BwdShape sh = bwd_stream_shape(H, d->n_geo, d->n_color, grid);
+  blob.clear();
+  blob.reserve((size_t)(sh.ht_entries + sh.ring_entries) * 256);
+  auto x_ksteps = [&](int col_off) {
+    std::vector<KStep> ks(H / 2);
+    for (int s = 0; s < H / 2; ++s) ks[s] = {col_off + feat_of(s, 0), col_off + feat_of(s, 1)};
+    return ks;
+  };
+  auto transposed = [&](const float* W, int rows, int cols, int col0, int ncol) {   // -> [ncol][rows] = W[:, col0:col0+ncol]^T
+    std::vector<double> T((size_t)ncol * rows);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < ncol; ++c) T[(size_t)c * rows + r] = W[(size_t)r * cols + col0 + c];
+    return T;
+  };
+  {  // rgb head^T: [H][3], k-steps (d_r | d_g), (d_b | 0)
+    auto T = transposed(d->rgb_w, 3, H, 0, H);
+    std::vector<KStep> ks = {{0, 1}, {2, -1}};
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, 3, nb * 32, ks, 1);
+  }
+  for (int l = d->n_color - 1; l >= 1; --l) {
+    auto T = transposed(d->color_w[l], H, H, 0, H);
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, H, nb * 32, ks, sh.KGXP);
+  }
+  {  // colour layer 0 (reference columns [dir(3) | grid(32) | x(H)], siren.py:1522) + the heads that read the trunk
+    const int cin = 3 + d->grid_ch + H;
+    std::vector<double> Wh, hb;
+    fold_head(d, Wh, hb);
+    std::vector<double> M((size_t)H * (H + 32), 0.0);   // row j: [W_c0[:, x_j] (H) | head[:, j] (32)]
+    for (int j = 0; j < H; ++j) {
+      for (int i = 0; i < H; ++i) M[(size_t)j * (H + 32) + i] = d->color_w[0][(size_t)i * cin + 3 + d->grid_ch + j];
+      for (int r = 0; r < 32; ++r) M[(size_t)j * (H + 32) + H + r] = Wh[(size_t)r * H + j];
+    }
+    auto ks = x_ksteps(0);
+    for (int s = 0; s < FENERF_HEAD_KSTEPS; ++s) ks.push_back({H + s, H + 16 + s});
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, M.data(), H, H + 32, nb * 32, ks, sh.c0_kgp);
+    if (grid) {
+      auto T = transposed(d->color_w[0], H, cin, 3, 32);   // [32][H]
+      emit_body(blob, T.data(), 32, H, 0, x_ksteps(0), sh.KGXP);
+    }
+  }
+  for (int l = d->n_geo - 1; l >= 1; --l) {
+    auto T = transposed(d->geo_w[l], H, H, 0, H);
+    auto ks = x_ksteps(0);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, H, nb * 32, ks, sh.KGXP);
+  }
+  blob.insert(blob.end(), (size_t)FENERF_PF * 256, 0.f);
+  if (blob.size() != (size_t)(sh.ht_entries + sh.ring_entries) * 256) { err = "internal: backward stream size mismatch"; return FENERF_E_INVALID; }
   return FENERF_OK;
 }
 

@@ -25,104 +25,35 @@
 
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_mfma32.h"
 
 namespace fenerf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// sin(2*pi*t), t in revolutions: v_sin_f32 (does its own range reduction).  Measured on MI355X
-// (tools/probe/probe.hip): max abs error 1.2e-7 for |t| <= 45 revolutions -- tighter than a degree-9 polynomial
-// evaluated in fp32 (2.1e-7) and one quarter-rate instruction instead of thirteen.
-__device__ __forceinline__ float sin2pi(float t) { return __builtin_amdgcn_sinf(t); }
-
-struct Ring {
-  float4 w[FENERF_PF];
-  const float4* ptr;  // per-lane cursor: next entry to fetch
-};
-
-// Consume the next ring entry (compile-time slot) and refill the slot with the entry PF ahead.
-#define RING_NEXT(ring, slot, dst)      \
-  do {                                  \
-    (dst) = (ring).w[(slot)];           \
-    (ring).w[(slot)] = *(ring).ptr;     \
-    (ring).ptr += 64;                   \
-  } while (0)
-
-// acc += W_body[:, k-steps of an H-wide activation] * b  (NKG real entries, NKGP consumed)
-template <int NIN, int NKG, int NKGP>
-__device__ __forceinline__ void mfma_x(f32x16& acc, const float (&b)[NIN], Ring& ring) {
-  static_assert(NKG * 4 == NIN, "k-groups must cover the activation");
-  static_assert(NKGP % FENERF_PF == 0, "bodies are padded to the ring depth");
+// differentiable mode: keep the n-block's pre-FiLM accumulators.  tp = tape + (layer*H + 4h) * P + pt
+__device__ __forceinline__ void tape_store(const f32x16& acc, int nb, float* tp, long long Ptot, bool valid) {
+  if (valid) {
 #pragma unroll
-  for (int kg = 0; kg < NKGP; ++kg) {
-    float4 w;
-    RING_NEXT(ring, kg % FENERF_PF, w);
-    if (kg < NKG) {
-      acc = MFMA(w.x, b[4 * kg + 0], acc);
-      acc = MFMA(w.y, b[4 * kg + 1], acc);
-      acc = MFMA(w.z, b[4 * kg + 2], acc);
-      acc = MFMA(w.w, b[4 * kg + 3], acc);
-    }
-    // pin the (refill, 4 x MFMA) order: without it the scheduler sinks the refill loads next to their use
-    // (to shorten live ranges) and the prefetch distance collapses from PF entries to ~1.
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// FiLM parameters of one n-block for this lane-half: features 32nb + 8j + 4h + {0..3}, j = 0..3.
-// Loaded BEFORE the n-block's MFMAs so the L2 latency hides behind them.
-struct FilmNB { float4 f[4], p[4]; };
-__device__ __forceinline__ FilmNB film_load(const float* fpl, const float* ppl, int nb) {
-  FilmNB fm;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    fm.f[j] = *reinterpret_cast<const float4*>(fpl + 32 * nb + 8 * j);
-    fm.p[j] = *reinterpret_cast<const float4*>(ppl + 32 * nb + 8 * j);
-  }
-  return fm;
-}
-
-// FiLM epilogue of one n-block: out = sin(2 pi (f' acc + p')) -> this lane's LDS slab, groups nb*4 .. nb*4+3
-__device__ __forceinline__ void film_store(const f32x16& acc, const FilmNB& fm, int nb, float4* slab /* + lane */) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 f = fm.f[j], p = fm.p[j];
-    float4 o;
-    o.x = sin2pi(__builtin_fmaf(f.x, acc[4 * j + 0], p.x));
-    o.y = sin2pi(__builtin_fmaf(f.y, acc[4 * j + 1], p.y));
-    o.z = sin2pi(__builtin_fmaf(f.z, acc[4 * j + 2], p.z));
-    o.w = sin2pi(__builtin_fmaf(f.w, acc[4 * j + 3], p.w));
-    slab[(nb * 4 + j) * 64] = o;
-  }
-}
-
-template <int NIN>
-__device__ __forceinline__ void load_act(float (&in)[NIN], const float4* slab) {
-#pragma unroll
-  for (int g = 0; g < NIN / 4; ++g) {
-    const float4 v = slab[g * 64];
-    in[4 * g + 0] = v.x; in[4 * g + 1] = v.y; in[4 * g + 2] = v.z; in[4 * g + 3] = v.w;
+    for (int r = 0; r < 16; ++r) tp[(long long)(32 * nb + (r & 3) + 8 * (r >> 2)) * Ptot] = acc[r];
   }
 }
 
 // A square FiLM layer H -> H.
-template <int H>
+template <int H, bool SAVE>
 __device__ __forceinline__ void square_layer(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl,
-                                             float4* slab) {
+                                             float4* slab, float* tp, long long Ptot, bool valid) {
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
 #pragma unroll 1
   for (int nb = 0; nb < NB; ++nb) {
     const FilmNB fm = film_load(fpl, ppl, nb);
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+    if (SAVE) tape_store(acc, nb, tp, Ptot, valid);
     film_store(acc, fm, nb, slab);
   }
   load_act<H / 2>(in, slab);
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
   constexpr int C0_KG = KGX + (GRID ? FENERF_E_KSTEPS / 4 : 0) + 1, C0_KGP = pad_pf(C0_KG);
@@ -212,6 +143,13 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 
     const float* fpl = P.fp + (size_t)img * L * H + 4 * h;   // FiLM params of this lane's image, + half offset
     const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
+    float* tp = SAVE ? P.tape + (long long)(4 * h) * P.P + pt : nullptr;   // + layer * H * P
+    const long long tl = (long long)H * P.P;
+    if (SAVE && GRID && valid) {
+      float4* ep = reinterpret_cast<float4*>(P.tape_e + pt * 32 + 16 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ep[q] = make_float4(e[4 * q + 0], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+    }
 
     // ---------------- layer 0: 3 -> H.  k-steps (x|y), (z|0) ----------------
     {
@@ -223,6 +161,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = MFMA(w.x, b0, acc);
         acc = MFMA(w.y, b1, acc);
+        if (SAVE) tape_store(acc, nb, tp, P.P, valid);
         film_store(acc, fm, nb, slab);
       }
     }
@@ -231,7 +170,8 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 
     // ---------------- geometry trunk G1 .. G(n_geo-1) ----------------
 #pragma unroll 1
-    for (int l = 1; l < n_geo; ++l) square_layer<H>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, slab);
+    for (int l = 1; l < n_geo; ++l)
+      square_layer<H, SAVE>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, slab, SAVE ? tp + l * tl : nullptr, P.P, valid);
 
     // ---------------- colour layer 0: [x | grid feats | dir] -> H ----------------
     {
@@ -263,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (SAVE) tape_store(acc, nb, tp + n_geo * tl, P.P, valid);
         film_store(acc, fm, nb, slab);
       }
     }
@@ -284,7 +225,8 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
     // ---------------- colour layers 1.. ----------------
 #pragma unroll 1
     for (int c = 1; c < n_color; ++c)
-      square_layer<H>(in, ring, fpl + (size_t)(n_geo + c) * H, ppl + (size_t)(n_geo + c) * H, slab);
+      square_layer<H, SAVE>(in, ring, fpl + (size_t)(n_geo + c) * H, ppl + (size_t)(n_geo + c) * H, slab,
+                            SAVE ? tp + (n_geo + c) * tl : nullptr, P.P, valid);
 
     // ---------------- rgb head + sigmoid ----------------
     {
@@ -369,12 +311,12 @@ int launch_grid_relayout(const float* src, float* dst, int C, int D, int Hh, int
   return e == hipSuccess ? FENERF_OK : hip_fail(e, "grid_relayout launch");
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const int stage_f4 = (32 * m->C + 3) / 4;
   const size_t lds = (size_t)4 * ((H / 8) * 64 + stage_f4) * sizeof(float4);
   static size_t configured = 0;  // per instantiation
-  auto kfn = siren_kernel<H, GRID>;
+  auto kfn = siren_kernel<H, GRID, SAVE>;
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
@@ -389,15 +331,24 @@ static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stre
   return e == hipSuccess ? FENERF_OK : hip_fail(e, "siren launch");
 }
 
+template <int H>
+static int launch_siren_h(const FenerfModel* m, const SirenParams& p, void* stream) {
+  const bool g = m->grid_ch != 0;
+  if (p.tape) return g ? launch_siren_t<H, true, true>(m, p, stream) : launch_siren_t<H, false, true>(m, p, stream);
+  return g ? launch_siren_t<H, true, false>(m, p, stream) : launch_siren_t<H, false, false>(m, p, stream);
+}
+
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
-  if (m->precision == FENERF_PREC_F16X3) return launch_siren16s(m, p, stream);
-  const bool g = m->grid_ch != 0;
+  if (m->precision == FENERF_PREC_F16X3) {
+    if (p.tape) { set_error("the differentiable path runs on the fp32 model (precision FENERF_PREC_F32)"); return FENERF_E_UNSUPPORTED; }
+    return launch_siren16s(m, p, stream);
+  }
   switch (m->H) {
-    case 32: return g ? launch_siren_t<32, true>(m, p, stream) : launch_siren_t<32, false>(m, p, stream);
-    case 64: return g ? launch_siren_t<64, true>(m, p, stream) : launch_siren_t<64, false>(m, p, stream);
-    case 128: return g ? launch_siren_t<128, true>(m, p, stream) : launch_siren_t<128, false>(m, p, stream);
-    case 256: return g ? launch_siren_t<256, true>(m, p, stream) : launch_siren_t<256, false>(m, p, stream);
+    case 32: return launch_siren_h<32>(m, p, stream);
+    case 64: return launch_siren_h<64>(m, p, stream);
+    case 128: return launch_siren_h<128>(m, p, stream);
+    case 256: return launch_siren_h<256>(m, p, stream);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

@@ -1,0 +1,270 @@
+// Backward chain of the FiLM-SIREN radiance field for gfx950 (MI355X) -- the data-path half of what torch autograd
+// derives for <siren>.forward_with_frequencies_phase_shifts (reference siren/siren.py:1509-1530, FiLMLayer :227-244)
+// in the generator step and in inversion (train_double_latent_semantic.py: g_loss.backward(); inverse_render_double_semantic.py).
+//
+// Per layer l (x_l = sin(theta_l), theta_l = f_l (W_l x_{l-1} + b_l) + p_l):
+//     dL/dtheta_l = dL/dx_l * cos(theta_l)          -> written to d_t[l]   (feature-major [H][P])
+//     dL/dz_l     = dL/dtheta_l * f_l               -> the B operand of the next GEMM
+//     dL/dx_{l-1} = W_l^T dL/dz_l                   -> transposed fp32 MFMA, same register identity as the forward
+// One wave carries 32 points through the whole chain; activations are not recomputed: theta_l comes from the forward's
+// saved pre-FiLM accumulators (tape), one coalesced 128-B read per feature row and lane-half.  What is left for the
+// caller are reductions over points with plain library GEMMs on d_t and the tape (weight / bias / FiLM gradients,
+// fenerf_amd/siren/autograd.py) -- they contract over the point axis and do not belong in a per-tile kernel.
+#include <hip/hip_runtime.h>
+
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+#include "fenerf_mfma32.h"
+
+namespace fenerf {
+
+__device__ __forceinline__ float cos2pi(float t) { return __builtin_amdgcn_cosf(t); }   // v_cos_f32, revolutions
+
+struct TapeNB { float a[16]; };
+// pre-FiLM accumulators of n-block nb for this lane.  tl = tape + layer*H*P (wave-uniform: the row address stays in
+// SGPRs), loff = 4h*P + pt (32-bit lane offset) -> global_load with scalar base + vector offset, no 64-bit VALU math.
+__device__ __forceinline__ TapeNB tape_load(const float* tl, unsigned loff, int nb, long long Ptot) {
+  TapeNB t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* row = tl + (long long)(32 * nb + (r & 3) + 8 * (r >> 2)) * Ptot;
+    t.a[r] = row[loff];
+  }
+  return t;
+}
+
+// acc = dL/dx of n-block nb.  Writes dL/dtheta to d_t and parks dL/dz in the LDS slab.
+__device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, float4* slab,
+                                          float* dtl, unsigned loff, long long Ptot, bool valid) {
+  const float TWO_PI = 6.28318530717958647692f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float f[4] = {fm.f[j].x, fm.f[j].y, fm.f[j].z, fm.f[j].w};
+    const float p[4] = {fm.p[j].x, fm.p[j].y, fm.p[j].z, fm.p[j].w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * j + i;
+      const float dt = acc[r] * cos2pi(__builtin_fmaf(f[i], tn.a[r], p[i]));
+      float* row = dtl + (long long)(32 * nb + i + 8 * j) * Ptot;
+      if (valid) row[loff] = dt;
+      o[i] = dt * (f[i] * TWO_PI);
+    }
+    slab[(nb * 4 + j) * 64] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dz_l (in registers) -> dz_{l-1}: one transposed square stage
+template <int H>
+__device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl, float4* slab,
+                                           const float* tl, float* dtl, unsigned loff, long long Ptot, bool valid) {
+  constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
+#pragma unroll 1
+  for (int nb = 0; nb < NB; ++nb) {
+    const FilmNB fm = film_load(fpl, ppl, nb);
+    const TapeNB tn = tape_load(tl, loff, nb, Ptot);
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+    bwd_store(acc, fm, tn, nb, slab, dtl, loff, Ptot, valid);
+  }
+  load_act<H / 2>(in, slab);
+}
+
+template <int H, bool GRID>
+__global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
+  constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
+  constexpr int C0_KG = KGX + FENERF_HEAD_KSTEPS / 4, C0_KGP = pad_pf(C0_KG);
+  constexpr int SLAB_F4 = (H / 8) * 64;
+  extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  float4* slab = smem + wave * SLAB_F4 + lane;
+  const int L = n_geo + n_color;
+  const float4* htw = reinterpret_cast<const float4*>(P.stream) + lane;
+  const float4* ring_base = reinterpret_cast<const float4*>(P.stream + P.ring_offset_floats) + lane;
+
+  const long long ntiles = (P.P + 31) / 32;
+  const long long wstride = (long long)gridDim.x * 4;
+  const long long tl = (long long)H * P.P;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+    long long pt = tile * 32 + m;
+    const bool valid = pt < P.P;
+    if (!valid) pt = P.P - 1;
+    const long long img = pt / P.pts_per_image;
+    const float* fpl = P.fp + (size_t)img * L * H + 4 * h;
+    const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
+    const unsigned loff = (unsigned)((long long)(4 * h) * P.P + pt);   // < 2^32: the API bounds the point count
+
+    Ring ring;
+    ring.ptr = ring_base;
+#pragma unroll
+    for (int i = 0; i < FENERF_PF; ++i) { ring.w[i] = *ring.ptr; ring.ptr += 64; }
+
+    // gradient wrt the head rows this lane-half multiplies: row 16h + s  (rows [0,n_lab) labels, row n_lab sigma)
+    float dh[FENERF_HEAD_KSTEPS];
+#pragma unroll
+    for (int s = 0; s < FENERF_HEAD_KSTEPS; ++s) {
+      const int row = 16 * h + s;
+      const int ch = row < n_lab ? row : (row == n_lab ? C - 1 : -1);
+      dh[s] = ch >= 0 ? P.d_out[pt * C + ch] : 0.f;
+    }
+    // ---------------- rgb head: d(pre-sigmoid) = d_rgb * s (1 - s);  dx_{L-1} = W_rgb^T d(pre) ----------------
+    {
+      float dpre[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s = P.out[pt * C + (C - 4) + c];
+        dpre[c] = P.d_out[pt * C + (C - 4) + c] * (s * (1.f - s));
+      }
+      const float b0 = h ? dpre[1] : dpre[0], b1 = h ? 0.f : dpre[2];
+      const int l = L - 1;
+#pragma unroll 1
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 w = htw[nb * 64];
+        const FilmNB fm = film_load(fpl + (size_t)l * H, ppl + (size_t)l * H, nb);
+        const TapeNB tn = tape_load(P.tape + l * tl, loff, nb, P.P);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = MFMA(w.x, b0, acc);
+        acc = MFMA(w.y, b1, acc);
+        bwd_store(acc, fm, tn, nb, slab, P.d_t + l * tl, loff, P.P, valid);
+      }
+    }
+    float in[H / 2];
+    load_act<H / 2>(in, slab);
+
+    // ---------------- colour layers L-1 .. n_geo+1 ----------------
+#pragma unroll 1
+    for (int l = L - 1; l > n_geo; --l)
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, P.tape + (l - 1) * tl, P.d_t + (l - 1) * tl, loff, P.P, valid);
+
+    // ---------------- colour layer 0 + heads: dx_{n_geo-1} = W_c0[:, x]^T dz_{n_geo} + head^T d_head; d(grid feats) ----
+    {
+      const int l = n_geo - 1;
+#pragma unroll 1
+      for (int nb = 0; nb < NB; ++nb) {
+        const FilmNB fm = film_load(fpl + (size_t)l * H, ppl + (size_t)l * H, nb);
+        const TapeNB tn = tape_load(P.tape + l * tl, loff, nb, P.P);
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < C0_KGP; ++kg) {
+          float4 w;
+          RING_NEXT(ring, kg % FENERF_PF, w);
+          if (kg < KGX) {
+            acc = MFMA(w.x, in[4 * kg + 0], acc);
+            acc = MFMA(w.y, in[4 * kg + 1], acc);
+            acc = MFMA(w.z, in[4 * kg + 2], acc);
+            acc = MFMA(w.w, in[4 * kg + 3], acc);
+          } else if (kg < C0_KG) {
+            const int q = kg - KGX;
+            acc = MFMA(w.x, dh[4 * q + 0], acc);
+            acc = MFMA(w.y, dh[4 * q + 1], acc);
+            acc = MFMA(w.z, dh[4 * q + 2], acc);
+            acc = MFMA(w.w, dh[4 * q + 3], acc);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bwd_store(acc, fm, tn, nb, slab, P.d_t + l * tl, loff, P.P, valid);
+      }
+      if (GRID) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
+        if (valid) {
+          float4* ep = reinterpret_cast<float4*>(P.d_e + pt * 32 + 4 * h);   // channels 8j + 4h + {0..3}
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ep[2 * j] = make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        }
+      }
+    }
+    load_act<H / 2>(in, slab);
+
+    // ---------------- geometry trunk n_geo-1 .. 1 ----------------
+#pragma unroll 1
+    for (int l = n_geo - 1; l >= 1; --l)
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, P.tape + (l - 1) * tl, P.d_t + (l - 1) * tl, loff, P.P, valid);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient wrt the 3-D feature grid: the transpose of the forward's trilinear gather (sample_from_3dgrid,
+// siren.py:314-330; zeros padding, align_corners=True).  One thread per (point, channel): channels are contiguous in
+// the channels-last gradient grid, so each corner is one 128-B line of hardware float atomics.
+// ------------------------------------------------------------------------------------------------
+__global__ void grid_backward_kernel(long long P, const float* points, float box_scale, const float* d_e, float* d_grid_cl,
+                                     int gd, int gh, int gw) {
+  const long long total = P * 32;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pt = i >> 5;
+    const int ch = (int)(i & 31);
+    const float g = d_e[i];
+    const float qx = points[pt * 3 + 0] * box_scale, qy = points[pt * 3 + 1] * box_scale, qz = points[pt * 3 + 2] * box_scale;
+    const float ix = ((qx + 1.f) / 2.f) * (float)(gw - 1);
+    const float iy = ((qy + 1.f) / 2.f) * (float)(gh - 1);
+    const float iz = ((qz + 1.f) / 2.f) * (float)(gd - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cz = c >> 2, cy = (c >> 1) & 1, cx = c & 1;
+      const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
+      const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
+      const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
+      const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
+      const bool ok = xi >= 0.f && xi <= (float)(gw - 1) && yi >= 0.f && yi <= (float)(gh - 1) && zi >= 0.f && zi <= (float)(gd - 1);
+      if (ok) {
+        const long long vox = ((long long)(int)zi * gh + (int)yi) * gw + (int)xi;
+        unsafeAtomicAdd(d_grid_cl + vox * 32 + ch, g * (wx * wy * wz));
+      }
+    }
+  }
+}
+
+static int hip_fail_b(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream) {
+  if (P <= 0) return FENERF_OK;
+  long long blocks = (P * 32 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(grid_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, points, m->box_scale, d_e,
+                     d_grid_cl, m->gd, m->gh, m->gw);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail_b(e, "grid_backward launch");
+}
+
+template <int H, bool GRID>
+static int launch_bwd_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  const size_t lds = (size_t)4 * ((H / 8) * 64) * sizeof(float4);
+  static size_t configured = 0;
+  auto kfn = siren_bwd_kernel<H, GRID>;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_fail_b(e, "hipFuncSetAttribute(max dynamic LDS)");
+    configured = lds;
+  }
+  const long long ntiles = (p.P + 31) / 32;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail_b(e, "siren backward launch");
+}
+
+int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  if (p.P <= 0) return FENERF_OK;
+  const bool g = m->grid_ch != 0;
+  switch (m->H) {
+    case 32: return g ? launch_bwd_t<32, true>(m, p, stream) : launch_bwd_t<32, false>(m, p, stream);
+    case 64: return g ? launch_bwd_t<64, true>(m, p, stream) : launch_bwd_t<64, false>(m, p, stream);
+    case 128: return g ? launch_bwd_t<128, true>(m, p, stream) : launch_bwd_t<128, false>(m, p, stream);
+    case 256: return g ? launch_bwd_t<256, true>(m, p, stream) : launch_bwd_t<256, false>(m, p, stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+}  // namespace fenerf

@@ -8,21 +8,18 @@ PyTorch, and hands the rest -- coarse SIREN, compositing, importance resampling,
 final compositing (generators.py:479-519) -- to ONE C-ABI call, fenerf_render_forward, i.e. hand-written HIP
 kernels for gfx950.  There is no PyTorch fallback for that part.
 
-Forward only in this round: methods must run under torch.no_grad() (the reference's D-steps, FID dumps and
-all inference scripts do); the G-step / inversion backward is the next row.
+Under torch.no_grad() (both D-steps, FID dumps, every inference script) a render is that one fused call.  With grad
+enabled (generator step, inversion) forward / forward_with_frequencies run the differentiable composition of the same
+kernels (_render_grad): fenerf_siren_forward_save + fenerf_siren_backward for the two SIREN passes and
+fenerf_merge_composite + fenerf_composite_backward for the final integration, wired into torch autograd.
 """
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, native
+from ..siren import autograd as _siren_autograd
+from .autograd import CompositeFunction, MergeCompositeFunction
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
-
-
-def _needs_no_grad(what):
-    if torch.is_grad_enabled():
-        raise NotImplementedError(
-            f"fenerf_amd: {what} is forward-only in this round (backward of the fused HIP pipeline is SURVEY §8f.1); "
-            "call it under torch.no_grad()")
 
 
 class _Generator3dBase(nn.Module):
@@ -71,6 +68,56 @@ class _Generator3dBase(nn.Module):
             t = wsum.unsqueeze(-1).expand_as(rgb)
         return rgb, depth, t, pitch, yaw
 
+    def _wants_grad(self, film):
+        return torch.is_grad_enabled() and (any(t.requires_grad for t in film) or
+                                            any(p.requires_grad for p in self.siren._render_params()))
+
+    def _render_grad(self, film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                     hierarchical_sample, sample_dist, lock_view_dependence, kwargs):
+        """The differentiable render of generators.py:468-519: same random draws in the same order as _render, same kernels,
+        but the two SIREN passes and the final integration are autograd nodes with native backward kernels.  The coarse
+        weights and the resampled depths are constants (computed under no_grad in the reference too, :485-503).
+        Returns (pixels [B,R,C-1], depth [B,R], pitch, yaw)."""
+        fg, pg, fa, pa = film
+        B = fg.shape[0]
+        dev = self.device
+        R, N = img_size * img_size, num_steps
+        d = self.draws
+        origins, dirs, z_vals, pitch, yaw = sample_rays(B, N, dev, fov, (img_size, img_size), ray_start, ray_end, h_stddev,
+                                                        v_stddev, h_mean, v_mean, sample_dist, draws=d)
+        noise_std = kwargs["nerf_noise"]
+        opts = _lib.composite_opts(kwargs["clamp_mode"], noise_std, kwargs.get("last_back", False), kwargs.get("white_back", False),
+                                   kwargs.get("black_back", False), None, kwargs.get("fill_color", "black"))
+        u = noise_c = None
+        if hierarchical_sample:
+            noise_c = d.randn((B, R, N, 1), dev)
+            u = d.rand((B * R, N), dev)
+        M = 2 * N if hierarchical_sample else N
+        noise_f = d.randn((B, R, M, 1), dev)
+        use_noise = noise_std != 0
+        C = self.siren.output_dim
+
+        def field(z):      # [B,R,N] depths -> [B,R*N,C] radiance-field samples, an autograd node
+            pts = origins.unsqueeze(2) + dirs.unsqueeze(2) * z.unsqueeze(-1)              # generators.py:504
+            rd = None if lock_view_dependence else dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, R * N, 3)
+            return _siren_autograd.siren_apply(self.siren, pts.reshape(B, R * N, 3), rd, fg, pg, fa, pa)
+
+        z_c = z_vals.reshape(B, R, N)
+        coarse = field(z_c)
+        if not hierarchical_sample:
+            rgb, depth = CompositeFunction.apply(coarse.reshape(B * R, N, C), z_c.reshape(B * R, N),
+                                                 noise_f.reshape(B * R, M) if use_noise else None, opts)
+            return rgb.reshape(B, R, C - 1), depth.reshape(B, R), pitch, yaw
+        with torch.no_grad():
+            copts = _lib.composite_opts(kwargs["clamp_mode"], noise_std)
+            _, _, w_c, _ = native.composite(coarse.detach().reshape(B * R, N, C), z_c.reshape(B * R, N),
+                                            noise_c.reshape(B * R, N) if use_noise else None, copts, want_wsum=False)
+            z_f = native.resample(z_c.reshape(B * R, N), w_c, u)
+        fine = field(z_f.reshape(B, R, N))
+        rgb, depth = MergeCompositeFunction.apply(fine.reshape(B * R, N, C), coarse.reshape(B * R, N, C), z_f, z_c.reshape(B * R, N),
+                                                  noise_f.reshape(B * R, M) if use_noise else None, opts)
+        return rgb.reshape(B, R, C - 1), depth.reshape(B, R), pitch, yaw
+
     def _finish(self, pixels, batch_size, img_size):
         if self.softmax_label:
             seg, rgb = pixels[..., :-3], pixels[..., -3:]
@@ -115,13 +162,18 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
     def forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                 hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
         """-> (pixels [B, output_dim-1, S, S] in [-1,1], cat(pitch, yaw) [B,2])   (generators.py:452-527)."""
-        _needs_no_grad("DoubleImplicitGenerator3d.forward")
         batch_size = z_app.shape[0]
         grad_points = kwargs.get("grad_points", img_size * img_size)
         if grad_points != img_size * img_size:
-            raise NotImplementedError("part_forward (grad on a random ray subset, generators.py:858-910) needs the backward pass")
+            raise NotImplementedError("part_forward (grad on a random ray subset, generators.py:858-910) is not provided: "
+                                      "the fused backward has no activation-memory reason to subsample rays")
         fg, pg = self.siren.geo_mapping_network(z_geo)
         fa, pa = self.siren.app_mapping_network(z_app)
+        if self._wants_grad((fg, pg, fa, pa)):
+            pixels, depth, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
+                                                          v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
+                                                          lock_view_dependence, kwargs)
+            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
         # forward() ignores fill_mode (generators.py:519) -> C-1 channels
         pixels, depth, _, pitch, yaw = self._render((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                     v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
@@ -173,8 +225,13 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
                                  ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                                  sample_dist=None, lock_view_dependence=False, **kwargs):
         """-> (pixels [B, output_dim-1, S, S], poses)   (generators.py:735-797)."""
-        _needs_no_grad("DoubleImplicitGenerator3d.forward_with_frequencies")
         batch_size = frequencies_app.shape[0]
+        film = (frequencies_geo, phase_shifts_geo, frequencies_app, phase_shifts_app)
+        if self._wants_grad(film):
+            pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                                          h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
+                                                          kwargs)
+            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
         pixels, depth, _, pitch, yaw = self._render((frequencies_geo, phase_shifts_geo, frequencies_app, phase_shifts_app),
                                                     img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
                                                     v_mean, hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
@@ -220,10 +277,15 @@ class ImplicitGenerator3d(_Generator3dBase):
     def forward(self, z, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                 sample_dist=None, lock_view_dependence=False, **kwargs):
         """-> (pixels [B,3,S,S], poses)   (generators.py:32-119)."""
-        _needs_no_grad("ImplicitGenerator3d.forward")
         batch_size = z.shape[0]
         frequencies, phase_shifts = self.siren.mapping_network(z)
-        pixels, depth, _, pitch, yaw = self._render(self._film(frequencies, phase_shifts), img_size, fov, ray_start, ray_end,
+        film = self._film(frequencies, phase_shifts)
+        if self._wants_grad(film):
+            pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                                          h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
+                                                          kwargs)
+            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+        pixels, depth, _, pitch, yaw = self._render(film, img_size, fov, ray_start, ray_end,
                                                     num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                                                     sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
         pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
@@ -267,9 +329,14 @@ class ImplicitGenerator3d(_Generator3dBase):
                                  v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist=None, lock_view_dependence=False,
                                  **kwargs):
         """(generators.py:353-431)"""
-        _needs_no_grad("ImplicitGenerator3d.forward_with_frequencies")
         batch_size = frequencies.shape[0]
-        pixels, depth, _, pitch, yaw = self._render(self._film(frequencies, phase_shifts), img_size, fov, ray_start, ray_end,
+        film = self._film(frequencies, phase_shifts)
+        if self._wants_grad(film):
+            pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                                          h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
+                                                          kwargs)
+            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+        pixels, depth, _, pitch, yaw = self._render(film, img_size, fov, ray_start, ray_end,
                                                     num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                                                     sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
         pixels = self._finish(pixels, batch_size, img_size) * 2 - 1

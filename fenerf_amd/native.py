@@ -25,22 +25,24 @@ def _f32(t, device):
 class NativeModel:
     """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
 
-    def __init__(self, sd, spec, device, precision="f32"):
+    def __init__(self, sd, spec, device, precision="f32", differentiable=False):
         self.spec = dict(spec)
         self.precision = precision
+        self.differentiable = bool(differentiable)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % device)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, spec, precision)
+            d, keep = _lib.make_desc(sd, spec, precision, differentiable)
             _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
         self.C = spec["output_dim"]
+        self.box_scale = 2 / 0.24       # UniformBoxWarp(0.24), siren.py:181-187 (what _lib.make_desc sets)
         self._ws = {}
 
     def update(self, sd):
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, self.spec, self.precision)
+            d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
 
     def close(self):
@@ -83,6 +85,46 @@ class NativeModel:
             _lib.check(_lib.lib().fenerf_siren_forward(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg),
                                                        _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
         return out
+
+    def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa):
+        """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators [L,H,B*P]) and the
+        sampled grid features [B*P,32] (None without a grid) that siren_backward consumes."""
+        B, P = points.shape[0], points.shape[1]
+        H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        points = _f32(points, self.device)
+        ray_dirs = _f32(ray_dirs, self.device) if ray_dirs is not None else None
+        out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
+        tape = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
+        tape_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device) if self.spec["grid_ch"] else None
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_forward_save(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa),
+                                                            _ptr(pa), _ptr(out), _ptr(tape), _ptr(tape_e), C.c_void_p(ws.data_ptr()),
+                                                            _stream()))
+        return out, tape, tape_e
+
+    def siren_backward(self, B, P, fg, pg, fa, pa, out, d_out, tape):
+        """-> (d_t [L,H,B*P] = dL/dtheta per FiLM layer, d_e [B*P,32] or None)"""
+        H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        out, d_out = _f32(out, self.device), _f32(d_out, self.device)
+        d_t = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
+        d_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device) if self.spec["grid_ch"] else None
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_backward(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
+                                                        _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
+        return d_t, d_e
+
+    def grid_backward(self, points, d_e, grid_shape):
+        """Scatter d_e [Ptot,32] into the gradient of spatial_embeddings; returns it in the parameter's [1,32,D,H,W] shape."""
+        D, Hh, W = grid_shape
+        points = _f32(points, self.device).reshape(-1, 3)
+        g = torch.zeros((D, Hh, W, 32), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_grid_backward(self._h, points.shape[0], _ptr(points), _ptr(d_e), _ptr(g), _stream()))
+        return g.permute(3, 0, 1, 2).unsqueeze(0)
 
     def siren_forward_rays(self, origins, dirs, z, fg, pg, fa, pa, lock_view=False):
         """origins/dirs [B,R,3], z [B,R,N] -> [B,R,N,C]"""

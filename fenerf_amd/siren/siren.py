@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import native
+from . import autograd as _autograd
 
 
 def kaiming_leaky_init(m):
@@ -116,10 +117,42 @@ class _NativeSiren(nn.Module):
         self.__dict__["_native_version"] = ver
         return nat
 
+    def native_differentiable(self, device=None):
+        """The fp32 FenerfModel with the backward-chain stream resident (generator step / inversion); re-packed lazily."""
+        params = self._render_params()
+        device = torch.device(device if device is not None else params[0].device)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        nat = self.__dict__.get("_native_diff")
+        if nat is None or nat.device != device:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, "f32", differentiable=True)
+            self.__dict__["_native_diff"] = nat
+        elif self.__dict__.get("_native_diff_version") != ver:
+            nat.update(self._state_numpy())
+        self.__dict__["_native_diff_version"] = ver
+        return nat
+
+    def _roles(self, params):
+        """`params` = tensors in _render_params() order -> which layer each one is."""
+        names = [n for n, _ in self.named_parameters() if "mapping_network" not in n]
+        t = dict(zip(names, params))
+        n_geo = len(self.network)
+        if self.KIND == "spatial":
+            color = [(t["color_layer_sine.layer.weight"], t["color_layer_sine.layer.bias"])]
+        else:
+            color = [(t[f"color_layer_sine.{i}.layer.weight"], t[f"color_layer_sine.{i}.layer.bias"]) for i in range(len(self.color_layer_sine))]
+        return dict(geo=[(t[f"network.{i}.layer.weight"], t[f"network.{i}.layer.bias"]) for i in range(n_geo)], color=color,
+                    label=[(t[f"label_layer_linear.{i}.weight"], t[f"label_layer_linear.{i}.bias"]) for i in range(self.N_LABEL_LAYERS)],
+                    sigma=(t["final_layer.weight"], t["final_layer.bias"]),
+                    rgb=(t["color_layer_linear.0.weight"], t["color_layer_linear.0.bias"]), grid=t.get("spatial_embeddings"))
+
+    def _wants_grad(self, *tensors):
+        return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors) or
+                                            any(p.requires_grad for p in self._render_params()))
+
     def __getstate__(self):
         st = self.__dict__.copy()
-        st.pop("_native_model", None)
-        st.pop("_native_version", None)
+        for k in ("_native_model", "_native_version", "_native_diff", "_native_diff_version"):
+            st.pop(k, None)
         return st
 
 
@@ -132,17 +165,11 @@ class _DoubleLatentSiren(_NativeSiren):
     def forward_with_frequencies_phase_shifts(self, input, frequencies_geo, frequencies_app, phase_shifts_geo,
                                               phase_shifts_app, ray_directions, **kwargs):
         """[B,P,3] points, [B,P,3] dirs -> [B,P,output_dim] = [labels | rgb | sigma]   (siren.py:1509-1530)"""
-        if torch.is_grad_enabled() and (input.requires_grad or frequencies_geo.requires_grad or
-                                        any(p.requires_grad for p in self._render_params())):
-            _needs_backward()
+        if self._wants_grad(input, ray_directions, frequencies_geo, frequencies_app, phase_shifts_geo, phase_shifts_app):
+            return _autograd.siren_apply(self, input, ray_directions, frequencies_geo, phase_shifts_geo, frequencies_app,
+                                         phase_shifts_app)
         return self.native(input.device).siren_forward(input, ray_directions, frequencies_geo, phase_shifts_geo,
                                                        frequencies_app, phase_shifts_app)
-
-
-def _needs_backward():
-    raise NotImplementedError(
-        "fenerf_amd: the fused HIP pipeline is forward-only in this round (SURVEY.md §8f.1: backward is the next "
-        "row); call under torch.no_grad() (both D-steps, FID dumps, rendering)")
 
 
 class SIRENBASELINESEMANTICDISENTANGLE(_DoubleLatentSiren):
@@ -236,8 +263,7 @@ class SPATIALSIRENBASELINE(_NativeSiren):
                 frequencies[..., -H:].contiguous(), phase_shifts[..., -H:].contiguous())
 
     def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
-        if torch.is_grad_enabled() and (input.requires_grad or frequencies.requires_grad or
-                                        any(p.requires_grad for p in self._render_params())):
-            _needs_backward()
         fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
+        if self._wants_grad(input, ray_directions, frequencies, phase_shifts):
+            return _autograd.siren_apply(self, input, ray_directions, fg, pg, fa, pa)
         return self.native(input.device).siren_forward(input, ray_directions, fg, pg, fa, pa)

@@ -78,6 +78,8 @@ typedef struct FenerfModelDesc {
   const float* grid;        /* [host] spatial_embeddings or NULL */
   int32_t precision;        /* FENERF_PREC_F32 (exact fp32 MFMA) or FENERF_PREC_F16X3 (error-compensated fp16 MFMA,
                                3 MFMAs per product, fp32-class accuracy, ~2^-22 relative per product) */
+  int32_t differentiable;   /* != 0: also keep the backward-chain weight stream resident (fenerf_siren_backward);
+                               requires FENERF_PREC_F32 */
 } FenerfModelDesc;
 
 typedef struct FenerfModel FenerfModel;
@@ -169,6 +171,30 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
                            const float* z_coarse, const float* noise, const FenerfCompositeOpts* opts,
                            float* out_rgb, float* out_depth, float* out_weights, float* out_wsum,
                            float* out_z_sorted, void* stream);
+
+/* ---- differentiable evaluation (generator step / inversion).  replaces what torch autograd records and replays for
+ * <siren>.forward_with_frequencies_phase_shifts (siren.py:1509-1530) in train_double_latent_semantic.py (g_loss.backward())
+ * and inverse_render_double_semantic.py.  Model must be created with differentiable != 0.
+ *
+ * fenerf_siren_forward_save = fenerf_siren_forward that also keeps, per FiLM layer l, the pre-FiLM accumulators
+ *   tape[l][n][p] = (W_l x_{l-1})[n] (no bias; feature-major, p over all B*P points)  and the sampled grid features
+ *   tape_e[p][32] (NULL without a grid).  tape holds fenerf_siren_tape_floats(m, B*P) floats.
+ * fenerf_siren_backward: d_out [B,P,output_dim] (gradient wrt the outputs) ->
+ *   d_t[l][n][p] = dL/dtheta, theta = f (W x + b) + p   (same shape as tape)
+ *   d_e[p][32]   = gradient wrt the sampled grid features (NULL without a grid)
+ *   From these the parameter gradients are reductions over points (plain GEMMs): with f = 15 freq + 30,
+ *   dL/dphase = sum_p d_t, dL/dfreq = 15 sum_p d_t (tape + b), dL/db = sum_p f d_t, dL/dW = (f d_t) x_{l-1}^T.
+ * fenerf_grid_backward: scatters d_e into a zero-initialised channels-last gradient grid d_grid_cl [D][H][W][32]
+ *   (the transpose of sample_from_3dgrid, siren.py:314-330). */
+size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
+int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                              const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                              float* out, float* tape, float* tape_e, void* film_ws, void* stream);
+int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                          const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                          const float* tape, float* d_t, float* d_e, void* film_ws, void* stream);
+int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e, float* d_grid_cl,
+                         void* stream);
 
 /* replaces: what torch autograd derives for the final fancy_integration of a differentiable render
  * (generators.py:519 / :790; G-step and inversion): gradient wrt rgb_final g_rgb [BR, C-1] -> gradients wrt the SIREN

@@ -41,3 +41,42 @@ def merge_composite(fine, coarse, z_fine, z_coarse, noise=None, **kw):
     zs, idx = torch.sort(z, dim=1, stable=True)
     rows = torch.gather(rows, 1, idx[..., None].expand(-1, -1, rows.shape[-1]))
     return composite(rows, zs, noise, **kw)
+
+
+BOX_SCALE = 2 / 0.24
+
+
+def _film(x, w, b, freq, phase):
+    return torch.sin(freq[:, None, :] * (x @ w.T + b) + phase[:, None, :])
+
+
+def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app, phase_app):
+    """Differentiable restatement of siren.py:1509-1530 / :1210-1229 / :227-244.  sd: reference-named torch tensors
+    (leaves with requires_grad as wanted); raw FiLM parameters split as (geo [B,n_geo*H], app [B,n_color*H]).
+    points / ray_dirs [B,P,3] -> [B,P,output_dim]."""
+    H = spec["hidden_dim"]
+    fg, fa = freq_geo * 15 + 30, freq_app * 15 + 30
+    x = points * BOX_SCALE
+    feats = None
+    if spec["grid_ch"]:
+        B, P = points.shape[:2]
+        g = sd["spatial_embeddings"].expand(B, -1, -1, -1, -1)
+        feats = F.grid_sample(g, x.reshape(B, 1, 1, P, 3), mode="bilinear", padding_mode="zeros", align_corners=True)
+        feats = feats.reshape(B, -1, P).permute(0, 2, 1)
+    for i in range(spec["n_geo"]):
+        x = _film(x, sd[f"network.{i}.layer.weight"], sd[f"network.{i}.layer.bias"], fg[:, i * H:(i + 1) * H],
+                  phase_geo[:, i * H:(i + 1) * H])
+    sigma = x @ sd["final_layer.weight"].T + sd["final_layer.bias"]
+    if spec["kind"] == "spatial":
+        c = _film(torch.cat([ray_dirs, x], -1), sd["color_layer_sine.layer.weight"], sd["color_layer_sine.layer.bias"], fa, phase_app)
+        rgb = torch.sigmoid(c @ sd["color_layer_linear.0.weight"].T + sd["color_layer_linear.0.bias"])
+        return torch.cat([rgb, sigma], -1)
+    labels = x
+    for i in range(spec["n_label_layers"]):
+        labels = labels @ sd[f"label_layer_linear.{i}.weight"].T + sd[f"label_layer_linear.{i}.bias"]
+    c = torch.cat([ray_dirs, feats, x], -1) if feats is not None else torch.cat([ray_dirs, x], -1)
+    for i in range(spec["n_color"]):
+        c = _film(c, sd[f"color_layer_sine.{i}.layer.weight"], sd[f"color_layer_sine.{i}.layer.bias"], fa[:, i * H:(i + 1) * H],
+                  phase_app[:, i * H:(i + 1) * H])
+    rgb = torch.sigmoid(c @ sd["color_layer_linear.0.weight"].T + sd["color_layer_linear.0.bias"])
+    return torch.cat([labels, rgb, sigma], -1)

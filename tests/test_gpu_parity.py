@@ -654,3 +654,136 @@ def test_merge_composite_backward_vs_autograd(N):
     err = max(np.abs(N_(df) - f.grad.numpy()).max(), np.abs(N_(dc) - c.grad.numpy()).max())
     print(f"[parity] merge composite backward N={N}: max|err| {err:.2e} (|grad| max {scale:.3g})")
     assert err <= 2e-5 * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward: fused SIREN chain kernel + point-axis reductions vs torch autograd of the fp64 restatement
+# ---------------------------------------------------------------------------------------------------
+def _siren_module(kind, H, grid, seed=4, sigma_gain=30.0):
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=seed, sigma_gain=sigma_gain, with_mapping=False)
+    if kind == "spatial":
+        mod = S.SPATIALSIRENBASELINE(hidden_dim=H, z_dim=8)
+    else:
+        cls = {"texture": S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, "baseline": S.SIRENBASELINESEMANTICDISENTANGLE}[kind]
+        mod = cls(hidden_dim=H, z_geo_dim=8, z_app_dim=8, output_dim=22)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    if "spatial_embeddings" in tsd:
+        mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    mod.load_state_dict(tsd, strict=False)
+    return mod.to(DEV), spec, sd
+
+
+def _rel_err(got, ref):
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
+
+
+@pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 75), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 33),
+                                             ("texture", 256, 6, 2, 200)])
+def test_siren_backward_vs_autograd(kind, H, grid, B, P):
+    from oracle import fenerf_oracle_grad as OG
+    mod, spec, sd = _siren_module(kind, H, grid)
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)     # some points leave the grid box: zero padding
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, B, seed=4)
+    if kind == "spatial":
+        film["freq_app"] = proc.normal("film.freq_app", (B, H), 0.4, 4)
+        film["phase_app"] = proc.normal("film.phase_app", (B, H), 0.4, 4)
+    Cc = spec["output_dim"]
+    g_out = rng.normal(size=(B, P, Cc)).astype(np.float32)
+    g_out[..., -1] *= 0.02      # sigma is ~sigma_gain x larger than the other outputs; keep the contributions comparable
+
+    film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+    if kind == "spatial":
+        out = mod.forward_with_frequencies_phase_shifts(T(pts), torch.cat([film_t["freq_geo"], film_t["freq_app"]], -1),
+                                                        torch.cat([film_t["phase_geo"], film_t["phase_app"]], -1), T(dirs))
+    else:
+        out = mod.forward_with_frequencies_phase_shifts(T(pts), film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"],
+                                                        film_t["phase_app"], T(dirs))
+    assert out.requires_grad
+    (out * T(g_out)).sum().backward()
+
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
+    film64 = {k: t64(v).requires_grad_(True) for k, v in film.items()}
+    ref = OG.siren_forward(sd64, spec, t64(pts), t64(dirs), film64["freq_geo"], film64["phase_geo"], film64["freq_app"], film64["phase_app"])
+    (ref * t64(g_out)).sum().backward()
+    fwd_err = np.abs(N_(out) - ref.detach().numpy())
+    print(f"[parity] differentiable forward {kind} H={H}: max|err| rgb/labels {fwd_err[..., :-1].max():.2e} sigma {fwd_err[..., -1].max():.2e}")
+    assert fwd_err[..., :-1].max() <= 1e-4 and fwd_err[..., -1].max() <= 2e-4 * 30
+
+    worst = 0.0
+    for k in film:
+        e = _rel_err(N_(film_t[k].grad), film64[k].grad.numpy())
+        worst = max(worst, e)
+        assert e <= 2e-4, (k, e)
+    named = dict(mod.named_parameters())
+    for k, v in sd64.items():
+        assert named[k].grad is not None, k
+        e = _rel_err(N_(named[k].grad), v.grad.numpy())
+        worst = max(worst, e)
+        assert e <= 2e-4, (k, e)
+    print(f"[parity] SIREN backward {kind} H={H} B={B} P={P}: worst relative error over {len(sd64) + len(film)} gradient tensors {worst:.2e}")
+
+
+def test_generator_gradient_end_to_end():
+    """g_loss.backward() through DoubleImplicitGenerator3d.forward (hierarchical 12+12, noise, last_back off): gradients of
+    a pixel loss wrt z-mapped FiLM parameters and every render weight vs torch autograd of the fp64 restatement run on the
+    SAME rays, resampled depths and noise (those are no_grad constants in the reference too)."""
+    from oracle import fenerf_oracle_grad as OG
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0)
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    B, S_, N = 2, 6, 12
+    film = proc.film_params(spec, B, seed=4)
+    film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+    kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
+    torch.manual_seed(11)
+    px, poses = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+    assert px.requires_grad and px.shape == (B, 21, S_, S_)
+    w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    (px * w).sum().backward()
+
+    # replay: same seed -> same draws; recompute the constants (rays, z, resampled z, noise) with the no-grad HIP pieces
+    torch.manual_seed(11)
+    R = S_ * S_
+    origins, dirs, z_vals, _, _ = VR.sample_rays(B, N, gen.device, kw["fov"], (S_, S_), kw["ray_start"], kw["ray_end"], kw["h_stddev"],
+                                                 kw["v_stddev"], kw["h_mean"], kw["v_mean"], kw["sample_dist"], draws=gen.draws)
+    noise_c = gen.draws.randn((B, R, N, 1), gen.device); u = gen.draws.rand((B * R, N), gen.device)
+    noise_f = gen.draws.randn((B, R, 2 * N, 1), gen.device)
+    z_c = z_vals.reshape(B, R, N)
+    nat = mod.native_differentiable(DEV)
+    with torch.no_grad():
+        pts_c = origins.unsqueeze(2) + dirs.unsqueeze(2) * z_c.unsqueeze(-1)
+        rd = dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, R * N, 3)
+        coarse = nat.siren_forward(pts_c.reshape(B, R * N, 3), rd, *(film_t[k] for k in ("freq_geo", "phase_geo", "freq_app", "phase_app")))
+        _, _, w_c, _ = native.composite(coarse.reshape(B * R, N, 22), z_c.reshape(B * R, N), noise_c.reshape(B * R, N),
+                                        _lib.composite_opts("relu", 0.2), want_wsum=False)
+        z_f = native.resample(z_c.reshape(B * R, N), w_c, u).reshape(B, R, N)
+        pts_f = origins.unsqueeze(2) + dirs.unsqueeze(2) * z_f.unsqueeze(-1)
+    t64 = lambda a: torch.as_tensor(N_(a) if torch.is_tensor(a) else np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
+    film64 = {k: t64(v).requires_grad_(True) for k, v in film.items()}
+    args = (film64["freq_geo"], film64["phase_geo"], film64["freq_app"], film64["phase_app"])
+    c64 = OG.siren_forward(sd64, spec, t64(pts_c.reshape(B, R * N, 3)), t64(rd), *args)
+    f64 = OG.siren_forward(sd64, spec, t64(pts_f.reshape(B, R * N, 3)), t64(rd), *args)
+    rgb, _, _ = OG.merge_composite(f64.reshape(B * R, N, 22), c64.reshape(B * R, N, 22), t64(z_f.reshape(B * R, N)), t64(z_c.reshape(B * R, N)),
+                                   t64(noise_f.reshape(B * R, 2 * N)), noise_std=0.2, clamp_mode="relu")
+    ref_px = rgb.reshape(B, S_, S_, 21).permute(0, 3, 1, 2) * 2 - 1
+    (ref_px * t64(w)).sum().backward()
+    fe = np.abs(N_(px) - ref_px.detach().numpy()).max()
+    print(f"[parity] differentiable generator forward: max|err| {fe:.2e}")
+    assert fe <= 1e-3
+    worst = 0.0
+    for k in film:
+        worst = max(worst, _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()))
+    named = dict(mod.named_parameters())
+    for k, v in sd64.items():
+        worst = max(worst, _rel_err(N_(named[k].grad), v.grad.numpy()))
+    print(f"[parity] generator gradient end to end: worst relative error {worst:.2e}")
+    assert worst <= 5e-4

@@ -86,7 +86,7 @@ def test_generator_surface_and_loud_failures():
     gen.device = torch.device("cpu")
     gen.siren.device = gen.device
     z = torch.randn(1, 16)
-    with pytest.raises(NotImplementedError):       # grad mode: backward is the next row, fail loudly
+    with pytest.raises(RuntimeError):              # grad mode takes the differentiable HIP path: no CPU path there either
         gen(z, z, **md)
     with torch.no_grad(), pytest.raises(RuntimeError):   # CPU device: there is no CPU render path
         gen(z, z, **md)

@@ -224,3 +224,26 @@ def test_grad_oracle_matches_numpy_oracle():
     b = OG.merge_composite(torch.tensor(f).reshape(10, 4, 22), torch.tensor(c).reshape(10, 4, 22), torch.tensor(zf).reshape(10, 4),
                            torch.tensor(zc).reshape(10, 4), None, clamp_mode="relu")
     np.testing.assert_allclose(a[0].reshape(10, 21), b[0].numpy(), atol=1e-13)
+
+
+@pytest.mark.parametrize("kind,grid", [("texture", 5), ("baseline", 0), ("spatial", 0)])
+def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
+    import torch
+    from oracle import fenerf_oracle_grad as OG
+    spec = proc.model_spec(kind, hidden_dim=32, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=3, sigma_gain=20.0, with_mapping=False)
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-0.13, 0.13, (2, 40, 3))
+    dirs = rng.normal(size=(2, 40, 3)); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, 2, seed=3)
+    if kind == "spatial":
+        film["freq_app"] = proc.normal("film.freq_app", (2, 32), 0.4, 3)
+        film["phase_app"] = proc.normal("film.phase_app", (2, 32), 0.4, 3)
+        ref = O.siren_forward(sd, spec, pts, dirs, np.concatenate([film["freq_geo"], film["freq_app"]], -1),
+                              np.concatenate([film["phase_geo"], film["phase_app"]], -1), dtype=np.float64)
+    else:
+        ref = O.siren_forward(sd, spec, pts, dirs, film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"], dtype=np.float64)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    got = OG.siren_forward({k: t(v) for k, v in sd.items()}, spec, t(pts), t(dirs), t(film["freq_geo"]), t(film["phase_geo"]),
+                           t(film["freq_app"]), t(film["phase_app"]))
+    np.testing.assert_allclose(got.numpy(), ref, atol=1e-11, rtol=1e-11)
