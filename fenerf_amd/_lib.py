@@ -21,6 +21,7 @@ FILL = {None: 0, "weight": 1, "seg_padding_background": 2, "eval_seg_padding_bac
 FILL_COLORS = {"white": 1.0, "black": 0.0, "grey": 0.5, "light_grey": 0.81}
 
 _fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
 
 
 class FenerfModelDesc(C.Structure):
@@ -36,6 +37,12 @@ class FenerfModelDesc(C.Structure):
     ]
 
 
+class FenerfSirenGrads(C.Structure):
+    _fields_ = [("geo_w", _vp * MAX_GEO), ("geo_b", _vp * MAX_GEO), ("color_w", _vp * MAX_COLOR), ("color_b", _vp * MAX_COLOR),
+                ("head_w", _vp), ("head_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp),
+                ("d_freq_geo", _vp), ("d_phase_geo", _vp), ("d_freq_app", _vp), ("d_phase_app", _vp)]
+
+
 class FenerfCompositeOpts(C.Structure):
     _fields_ = [("clamp_mode", C.c_int32), ("noise_std", C.c_float), ("last_back", C.c_int32),
                 ("white_back", C.c_int32), ("black_back", C.c_int32), ("fill_mode", C.c_int32),
@@ -48,7 +55,7 @@ class FenerfError(RuntimeError):
         self.code = code
 
 
-_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_i, _i64, _sz = C.c_int, C.c_int64, C.c_size_t
 _SIGS = {
     "fenerf_last_error": (C.c_char_p, []),
     "fenerf_abi_version": (_i, []),
@@ -69,6 +76,8 @@ _SIGS = {
     "fenerf_siren_tape_floats": (_sz, [_vp, _i64]),
     "fenerf_siren_forward_save": (_i, [_vp, _i, _i64] + [_vp] * 11),
     "fenerf_siren_backward": (_i, [_vp, _i, _i64] + [_vp] * 11),
+    "fenerf_siren_grad_workspace_bytes": (_sz, [_vp, _i, _i64]),
+    "fenerf_siren_param_grads": (_i, [_vp, _i, _i64] + [_vp] * 11 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_grid_backward": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

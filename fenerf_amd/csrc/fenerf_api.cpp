@@ -311,6 +311,7 @@ extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P,
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
   if (P == 0) return FENERF_OK;
   if (!points || !out || !tape || (m->grid_ch && !tape_e)) return fail(FENERF_E_INVALID, "points / out / tape is NULL");
   const float *fp, *pp;
@@ -330,6 +331,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
   if (P == 0) return FENERF_OK;
   if (!out || !d_out || !tape || !d_t || (m->grid_ch && !d_e)) return fail(FENERF_E_INVALID, "NULL pointer");
   const float *fp, *pp;
@@ -343,6 +345,32 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.P = (long long)B * P; bp.pts_per_image = P;
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
   return launch_siren_backward(m, bp, stream);
+}
+
+extern "C" size_t fenerf_siren_grad_workspace_bytes(const FenerfModel* m, int B, int64_t P) {
+  if (!m || B <= 0 || P <= 0) return 0;
+  return align_up(wgrad_workspace_bytes(m, B, P), 256);
+}
+
+extern "C" int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                        const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                        const float* phase_app, const float* out, const float* d_out, const float* tape,
+                                        const float* tape_e, const float* d_t, const FenerfSirenGrads* g, void* workspace,
+                                        void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (P == 0) return FENERF_OK;
+  if (!points || !out || !d_out || !tape || !d_t || !g || !workspace || (m->grid_ch && !tape_e)) return fail(FENERF_E_INVALID, "NULL pointer");
+  for (int i = 0; i < m->n_geo; ++i) if (!g->geo_w[i] || !g->geo_b[i]) return fail(FENERF_E_INVALID, "grads: geo pointer is NULL");
+  for (int i = 0; i < m->n_color; ++i) if (!g->color_w[i] || !g->color_b[i]) return fail(FENERF_E_INVALID, "grads: color pointer is NULL");
+  if (!g->head_w || !g->head_b || !g->rgb_w || !g->rgb_b || !g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app)
+    return fail(FENERF_E_INVALID, "grads: head / rgb / film pointer is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, tape_e, d_t, *g, workspace, stream);
 }
 
 extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e,

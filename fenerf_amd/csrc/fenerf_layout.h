@@ -78,6 +78,13 @@ inline BwdShape bwd_stream_shape(int H, int n_geo, int n_color, bool grid) {
   return s;
 }
 
+// Tape (differentiable mode): the forward's pre-FiLM accumulators and the backward's dL/dtheta are kept as REGISTER DUMPS
+// of the 32-point tiles, [tile][layer][g = 4 nb + j (H/8)][lane (64)][4 floats]: element i of lane (m, half) in group g is
+// feature 32 nb + 8 j + 4 half + i of point 32 tile + m.  Every wave store / load is one contiguous 1-KiB transfer and a
+// tile's whole tape is one contiguous L*H*128-byte run (vs 128-B pieces scattered over L*H rows for a feature-major
+// matrix: measured 10x slower).  Point counts are padded to whole tiles by the caller (pad gradients are zero).
+constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * (g & 3) + 4 * half + i; }
+
 // ---------------------------------------------------------------------------------------------
 // f16x3 mode (error-compensated fp16 MFMA): v_mfma_f32_32x32x16_f16, k-step = 16 features.
 // Each fp32 product w*x is evaluated as wh*xh + wh*xl + wl*xh with (h, l) = fp16 hi/lo splits of

@@ -29,25 +29,24 @@
 
 namespace fenerf {
 
-// differentiable mode: keep the n-block's pre-FiLM accumulators.  tp = tape + (layer*H + 4h) * P + pt
-__device__ __forceinline__ void tape_store(const f32x16& acc, int nb, float* tp, long long Ptot, bool valid) {
-  if (valid) {
+// differentiable mode: keep the n-block's pre-FiLM accumulators as a register dump (fenerf_layout.h "Tape"):
+// tp = tape4 + ((tile*L + layer) * (H/8)) * 64 + lane; one contiguous 1-KiB wave store per 4 accumulator registers.
+__device__ __forceinline__ void tape_store(const f32x16& acc, int nb, float4* tp) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tp[(long long)(32 * nb + (r & 3) + 8 * (r >> 2)) * Ptot] = acc[r];
-  }
+  for (int j = 0; j < 4; ++j) tp[(nb * 4 + j) * 64] = make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
 }
 
 // A square FiLM layer H -> H.
 template <int H, bool SAVE>
 __device__ __forceinline__ void square_layer(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl,
-                                             float4* slab, float* tp, long long Ptot, bool valid) {
+                                             float4* slab, float4* tp) {
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
 #pragma unroll 1
   for (int nb = 0; nb < NB; ++nb) {
     const FilmNB fm = film_load(fpl, ppl, nb);
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
-    if (SAVE) tape_store(acc, nb, tp, Ptot, valid);
+    if (SAVE) tape_store(acc, nb, tp);
     film_store(acc, fm, nb, slab);
   }
   load_act<H / 2>(in, slab);
@@ -143,8 +142,8 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 
     const float* fpl = P.fp + (size_t)img * L * H + 4 * h;   // FiLM params of this lane's image, + half offset
     const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
-    float* tp = SAVE ? P.tape + (long long)(4 * h) * P.P + pt : nullptr;   // + layer * H * P
-    const long long tl = (long long)H * P.P;
+    float4* tp = SAVE ? reinterpret_cast<float4*>(P.tape) + tile * L * (long long)(H / 8) * 64 + lane : nullptr;   // + layer * tl
+    constexpr int tl = (H / 8) * 64;
     if (SAVE && GRID && valid) {
       float4* ep = reinterpret_cast<float4*>(P.tape_e + pt * 32 + 16 * h);
 #pragma unroll
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = MFMA(w.x, b0, acc);
         acc = MFMA(w.y, b1, acc);
-        if (SAVE) tape_store(acc, nb, tp, P.P, valid);
+        if (SAVE) tape_store(acc, nb, tp);
         film_store(acc, fm, nb, slab);
       }
     }
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
     // ---------------- geometry trunk G1 .. G(n_geo-1) ----------------
 #pragma unroll 1
     for (int l = 1; l < n_geo; ++l)
-      square_layer<H, SAVE>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, slab, SAVE ? tp + l * tl : nullptr, P.P, valid);
+      square_layer<H, SAVE>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, slab, SAVE ? tp + l * tl : nullptr);
 
     // ---------------- colour layer 0: [x | grid feats | dir] -> H ----------------
     {
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (SAVE) tape_store(acc, nb, tp + n_geo * tl, P.P, valid);
+        if (SAVE) tape_store(acc, nb, tp + n_geo * tl);
         film_store(acc, fm, nb, slab);
       }
     }
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 #pragma unroll 1
     for (int c = 1; c < n_color; ++c)
       square_layer<H, SAVE>(in, ring, fpl + (size_t)(n_geo + c) * H, ppl + (size_t)(n_geo + c) * H, slab,
-                            SAVE ? tp + (n_geo + c) * tl : nullptr, P.P, valid);
+                            SAVE ? tp + (n_geo + c) * tl : nullptr);
 
     // ---------------- rgb head + sigmoid ----------------
     {

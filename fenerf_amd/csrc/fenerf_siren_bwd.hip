@@ -21,35 +21,35 @@ namespace fenerf {
 __device__ __forceinline__ float cos2pi(float t) { return __builtin_amdgcn_cosf(t); }   // v_cos_f32, revolutions
 
 struct TapeNB { float a[16]; };
-// pre-FiLM accumulators of n-block nb for this lane.  tl = tape + layer*H*P (wave-uniform: the row address stays in
-// SGPRs), loff = 4h*P + pt (32-bit lane offset) -> global_load with scalar base + vector offset, no 64-bit VALU math.
-__device__ __forceinline__ TapeNB tape_load(const float* tl, unsigned loff, int nb, long long Ptot) {
+// pre-FiLM accumulators of n-block nb for this lane from the forward's register dump (fenerf_layout.h "Tape"):
+// tp = tape4 + ((tile*L + layer) * (H/8)) * 64 + lane
+__device__ __forceinline__ TapeNB tape_load(const float4* tp, int nb) {
   TapeNB t;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float* row = tl + (long long)(32 * nb + (r & 3) + 8 * (r >> 2)) * Ptot;
-    t.a[r] = row[loff];
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = tp[(nb * 4 + j) * 64];
+    t.a[4 * j + 0] = v.x; t.a[4 * j + 1] = v.y; t.a[4 * j + 2] = v.z; t.a[4 * j + 3] = v.w;
   }
   return t;
 }
 
 // acc = dL/dx of n-block nb.  Writes dL/dtheta to d_t and parks dL/dz in the LDS slab.
 __device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, float4* slab,
-                                          float* dtl, unsigned loff, long long Ptot, bool valid) {
+                                          float4* dtp) {
   const float TWO_PI = 6.28318530717958647692f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float f[4] = {fm.f[j].x, fm.f[j].y, fm.f[j].z, fm.f[j].w};
     const float p[4] = {fm.p[j].x, fm.p[j].y, fm.p[j].z, fm.p[j].w};
-    float o[4];
+    float o[4], d[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * j + i;
       const float dt = acc[r] * cos2pi(__builtin_fmaf(f[i], tn.a[r], p[i]));
-      float* row = dtl + (long long)(32 * nb + i + 8 * j) * Ptot;
-      if (valid) row[loff] = dt;
+      d[i] = dt;
       o[i] = dt * (f[i] * TWO_PI);
     }
+    dtp[(nb * 4 + j) * 64] = make_float4(d[0], d[1], d[2], d[3]);
     slab[(nb * 4 + j) * 64] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -57,15 +57,15 @@ __device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, c
 // dz_l (in registers) -> dz_{l-1}: one transposed square stage
 template <int H>
 __device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl, float4* slab,
-                                           const float* tl, float* dtl, unsigned loff, long long Ptot, bool valid) {
+                                           const float4* tp, float4* dtp) {
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
 #pragma unroll 1
   for (int nb = 0; nb < NB; ++nb) {
     const FilmNB fm = film_load(fpl, ppl, nb);
-    const TapeNB tn = tape_load(tl, loff, nb, Ptot);
+    const TapeNB tn = tape_load(tp, nb);
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
-    bwd_store(acc, fm, tn, nb, slab, dtl, loff, Ptot, valid);
+    bwd_store(acc, fm, tn, nb, slab, dtp);
   }
   load_act<H / 2>(in, slab);
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
 
   const long long ntiles = (P.P + 31) / 32;
   const long long wstride = (long long)gridDim.x * 4;
-  const long long tl = (long long)H * P.P;
+  constexpr int tl = (H / 8) * 64;   // float4 units per (tile, layer)
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
     long long pt = tile * 32 + m;
     const bool valid = pt < P.P;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     const long long img = pt / P.pts_per_image;
     const float* fpl = P.fp + (size_t)img * L * H + 4 * h;
     const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
-    const unsigned loff = (unsigned)((long long)(4 * h) * P.P + pt);   // < 2^32: the API bounds the point count
+    const float4* tp = reinterpret_cast<const float4*>(P.tape) + tile * L * (long long)tl + lane;   // + layer * tl
+    float4* dtp = reinterpret_cast<float4*>(P.d_t) + tile * L * (long long)tl + lane;
 
     Ring ring;
     ring.ptr = ring_base;
@@ -124,11 +125,11 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
       for (int nb = 0; nb < NB; ++nb) {
         const float4 w = htw[nb * 64];
         const FilmNB fm = film_load(fpl + (size_t)l * H, ppl + (size_t)l * H, nb);
-        const TapeNB tn = tape_load(P.tape + l * tl, loff, nb, P.P);
+        const TapeNB tn = tape_load(tp + l * tl, nb);
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = MFMA(w.x, b0, acc);
         acc = MFMA(w.y, b1, acc);
-        bwd_store(acc, fm, tn, nb, slab, P.d_t + l * tl, loff, P.P, valid);
+        bwd_store(acc, fm, tn, nb, slab, dtp + l * tl);
       }
     }
     float in[H / 2];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     // ---------------- colour layers L-1 .. n_geo+1 ----------------
 #pragma unroll 1
     for (int l = L - 1; l > n_geo; --l)
-      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, P.tape + (l - 1) * tl, P.d_t + (l - 1) * tl, loff, P.P, valid);
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl, dtp + (l - 1) * tl);
 
     // ---------------- colour layer 0 + heads: dx_{n_geo-1} = W_c0[:, x]^T dz_{n_geo} + head^T d_head; d(grid feats) ----
     {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
 #pragma unroll 1
       for (int nb = 0; nb < NB; ++nb) {
         const FilmNB fm = film_load(fpl + (size_t)l * H, ppl + (size_t)l * H, nb);
-        const TapeNB tn = tape_load(P.tape + l * tl, loff, nb, P.P);
+        const TapeNB tn = tape_load(tp + l * tl, nb);
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int kg = 0; kg < C0_KGP; ++kg) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        bwd_store(acc, fm, tn, nb, slab, P.d_t + l * tl, loff, P.P, valid);
+        bwd_store(acc, fm, tn, nb, slab, dtp + l * tl);
       }
       if (GRID) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     // ---------------- geometry trunk n_geo-1 .. 1 ----------------
 #pragma unroll 1
     for (int l = n_geo - 1; l >= 1; --l)
-      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, P.tape + (l - 1) * tl, P.d_t + (l - 1) * tl, loff, P.P, valid);
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl, dtp + (l - 1) * tl);
     __builtin_amdgcn_wave_barrier();
   }
 }

@@ -1,0 +1,407 @@
+// Parameter gradients of the FiLM-SIREN: the contractions over the point axis that follow the backward chain kernel
+// (fenerf_siren_bwd.hip).  What torch autograd does in the reference with one addmm-backward + several elementwise /
+// reduction kernels per layer (siren.py:113-123 FiLMLayer, :1509-1530) is here one MFMA kernel family that reads the two
+// register-dump tapes (fenerf_layout.h "Tape") directly:
+//
+//     dL/dW_l [H x K_l] = sum_b diag(f_bl) * sum_{p in image b} dtheta_l[:, p] * in_l[:, p]^T
+//     dL/dphase_bl = sum_p dtheta_l         dL/dfreq_bl = 15 sum_p dtheta_l * (W x + b)       dL/db_l = sum_b f_bl dL/dphase_bl
+//
+// with in_l = x_{l-1} = sin(2 pi (f' tape_{l-1} + p')) recomputed on the fly (bitwise the forward's activations), so no
+// activation matrix and no f-scaled copy of dtheta ever exists in HBM.  A library GEMM is the wrong tool: M = N = 256 with
+// K = 10^5..10^6 points gave 4 busy workgroups in rocBLAS (measured 33 TFLOP/s); here the point axis is split over
+// workgroups (one image, one chunk of tiles each), every workgroup keeps a full 256x256 fp32 accumulator in AGPRs
+// (v_mfma_f32_32x32x2_f32, 4 waves x 4x4 tiles) and writes one partial; a small second kernel sums the partials over chunks
+// and images (applying f) straight into nn.Linear-layout gradient buffers -- deterministic, no atomics.
+//
+// Per 32-point tile a workgroup stages the operand rows through LDS ([feature][32 points], row stride 36 floats:
+// conflict-free b128 reads): that is the transpose between the dump layout (lane = point) and the MFMA A/B layout
+// (lane = feature, K = points).  FiLM sums fall out of the same staging: thread t owns row t.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+#include "fenerf_mfma32.h"
+
+namespace fenerf {
+
+constexpr int WG_LD = 36;   // LDS row stride (floats): 16-B aligned rows, conflict-free 128-bit reads across 8 rows
+
+enum WgJob { WG_SQ = 0, WG_L0 = 1, WG_C0X = 2, WG_HEAD = 3, WG_RGB = 4 };
+
+struct WgradParams {
+  const float* tape; const float* d_t; const float* tape_e; const float* points; const float* dirs;
+  const float* out; const float* d_out; const float* fp; const float* pp; const float* bias;
+  float box_scale;
+  int B, L, n_geo, n_lab, C, H;
+  long long P;                 // points per image (multiple of 32)
+  int tiles_per_image, nchunk; // chunks per (job, image)
+  int layer0;                  // WG_SQ: first layer of the launch (blockIdx.z -> layer0 + z); other jobs: the layer
+  float* partial;              // [z][b][chunk][MT*32][KT*32]
+  float* film_partial;         // [L][b][chunk][H][2] or nullptr
+  float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
+};
+
+// Stage one register-dump tile (layer `l` of `src`) into LDS rows [H][WG_LD]; optional FiLM transform to activations.
+template <int H, bool SIN>
+__device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst, int wave, int lane, const float* f_s, const float* p_s) {
+  const int m = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < H / 32; ++q) {
+    const int g = wave * (H / 32) + q;
+    const int row = tape_feature(g, half, 0);
+    float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = e[i];
+      if (SIN) x = sin2pi(__builtin_fmaf(f_s[row + i], x, p_s[row + i]));
+      dst[(row + i) * WG_LD + m] = x;
+    }
+  }
+}
+
+template <int H>
+__device__ __forceinline__ void load_dump(float4 (&v)[H / 32], const float4* src /* (tile, layer) base */, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < H / 32; ++q) v[q] = src[(wave * (H / 32) + q) * 64 + lane];
+}
+
+// JOB: which operands.  MT x KT = output tiles (32x32) of the workgroup; WM x WK = tiles per wave.
+template <int H, int JOB>
+struct WgShape {
+  static constexpr int NB = H / 32;
+  static constexpr int MT = (JOB == WG_HEAD || JOB == WG_RGB) ? 1 : NB;
+  static constexpr int KT = (JOB == WG_SQ || JOB == WG_HEAD || JOB == WG_RGB) ? NB : (JOB == WG_C0X ? 2 : 1);
+  // wave grid: SQ 2x2 (big tiles); A-tall thin jobs 4x1; B-wide thin jobs 1x4
+  static constexpr int WGM = (JOB == WG_SQ) ? 2 : ((MT >= 4) ? 4 : 1);
+  static constexpr int WGK = 4 / WGM;
+  static constexpr int WM = (MT + WGM - 1) / WGM;
+  static constexpr int WK = (KT + WGK - 1) / WGK;
+  static constexpr bool A_DUMP = (JOB == WG_SQ || JOB == WG_L0 || JOB == WG_C0X);
+  static constexpr bool B_DUMP = (JOB == WG_SQ || JOB == WG_HEAD || JOB == WG_RGB);
+  static constexpr bool FILM = (JOB == WG_SQ || JOB == WG_L0);   // FiLM sums of layer l (needs tape_l as well)
+  static constexpr int A_ROWS = MT * 32, B_ROWS = KT * 32;
+};
+
+template <int H, int JOB>
+__global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
+  using S = WgShape<H, JOB>;
+  constexpr int NQ = H / 32;                   // dump groups per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* A_s = lds;                                         // [A_ROWS][WG_LD]
+  float* B_s = A_s + S::A_ROWS * WG_LD;                     // [B_ROWS][WG_LD]
+  float* C_s = B_s + S::B_ROWS * WG_LD;                     // FILM: tape_l rows [H][WG_LD]
+  float* f_s = C_s + (S::FILM ? H * WG_LD : 0);             // f', p' of the B-side layer; bias of layer l
+  float* p_s = f_s + H;
+  float* b_s = p_s + H;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x, img = blockIdx.y;
+  const int l = (JOB == WG_SQ) ? P.layer0 + blockIdx.z : P.layer0;   // layer whose dtheta is the A side (SQ/L0/C0X)
+  const int lb = (JOB == WG_SQ) ? l - 1 : ((JOB == WG_HEAD) ? P.n_geo - 1 : P.L - 1);   // B-side activation layer
+  const int L = P.L, C = P.C;
+
+  if (S::B_DUMP) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
+  if (S::FILM) for (int i = tid; i < H; i += 256) b_s[i] = P.bias[(size_t)l * H + i];
+  if (!S::A_DUMP) for (int i = tid; i < S::A_ROWS * WG_LD; i += 256) A_s[i] = 0.f;     // padded rows stay zero
+  if (!S::B_DUMP) for (int i = tid; i < S::B_ROWS * WG_LD; i += 256) B_s[i] = 0.f;
+  __syncthreads();
+
+  const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
+  const int t0 = chunk * t_per, t1 = min(P.tiles_per_image, t0 + t_per);
+  const long long tile_base = (long long)img * P.tiles_per_image;
+  const long long tl = (long long)(H / 8) * 64;              // float4 per (tile, layer)
+  const float4* tape4 = reinterpret_cast<const float4*>(P.tape);
+  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
+
+  f32x16 acc[S::WM][S::WK];
+#pragma unroll
+  for (int a = 0; a < S::WM; ++a)
+#pragma unroll
+    for (int b = 0; b < S::WK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int wm0 = (wave / S::WGK) * S::WM, wk0 = (wave % S::WGK) * S::WK;
+  float s0 = 0.f, s1 = 0.f;    // FiLM sums (thread = row) / head row sums
+
+  float4 va[NQ], vb[NQ], vc[NQ];
+  auto fetch = [&](int t) {
+    const long long tile = tile_base + t;
+    if (S::A_DUMP) load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
+    if (S::B_DUMP) load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
+    if (S::FILM) load_dump<H>(vc, tape4 + (tile * L + l) * tl, wave, lane);
+  };
+  if (t0 < t1) fetch(t0);
+  for (int t = t0; t < t1; ++t) {
+    const long long pt0 = (tile_base + t) * 32;
+    // ---- stage the tile
+    if (S::A_DUMP) stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
+    if (S::B_DUMP) stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
+    if (S::FILM) stage_dump<H, false>(vc, C_s, wave, lane, nullptr, nullptr);
+    if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
+      if (tid < 96) { const int c = tid >> 5, m = tid & 31; B_s[c * WG_LD + m] = P.points[(pt0 + m) * 3 + c] * P.box_scale; }
+    }
+    if (JOB == WG_C0X) {           // B rows 0..31 = grid features, 32..34 = view direction
+      if (P.tape_e) {
+        const int m = tid >> 3, c4 = (tid & 7) * 4;
+        const float4 e = *reinterpret_cast<const float4*>(P.tape_e + (pt0 + m) * 32 + c4);
+        B_s[(c4 + 0) * WG_LD + m] = e.x; B_s[(c4 + 1) * WG_LD + m] = e.y; B_s[(c4 + 2) * WG_LD + m] = e.z; B_s[(c4 + 3) * WG_LD + m] = e.w;
+      }
+      if (tid < 96) {
+        const int c = tid >> 5, m = tid & 31;
+        B_s[(32 + c) * WG_LD + m] = P.dirs ? P.dirs[(pt0 + m) * 3 + c] : (c == 2 ? -1.f : 0.f);
+      }
+    }
+    if (JOB == WG_HEAD) {          // A row r = gradient wrt head row r: labels [0,n_lab), sigma n_lab
+      for (int i = tid; i < 32 * 32; i += 256) {
+        const int r = i >> 5, m = i & 31;
+        const int ch = r < P.n_lab ? r : (r == P.n_lab ? C - 1 : -1);
+        A_s[r * WG_LD + m] = ch >= 0 ? P.d_out[(pt0 + m) * C + ch] : 0.f;
+      }
+    }
+    if (JOB == WG_RGB) {
+      if (tid < 96) {
+        const int c = tid >> 5, m = tid & 31;
+        const float s = P.out[(pt0 + m) * C + (C - 4) + c];
+        A_s[c * WG_LD + m] = P.d_out[(pt0 + m) * C + (C - 4) + c] * (s * (1.f - s));
+      }
+    }
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);          // next tile's global loads fly behind this tile's MFMAs
+
+    // ---- row sums (thread = row)
+    if (S::FILM) {
+      if (tid < H) {
+        const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
+        const float4* cr = reinterpret_cast<const float4*>(C_s + tid * WG_LD);
+        const float bb = b_s[tid];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 a = ar[q], c = cr[q];
+          s0 += (a.x + a.y) + (a.z + a.w);
+          s1 += (a.x * (c.x + bb) + a.y * (c.y + bb)) + (a.z * (c.z + bb) + a.w * (c.w + bb));
+        }
+      }
+    } else if (JOB == WG_HEAD || JOB == WG_RGB) {
+      if (tid < 32) {
+        const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 a = ar[q]; s0 += (a.x + a.y) + (a.z + a.w); }
+      }
+    }
+    // ---- MFMA: lane (i, kh) contracts points 16 kh + s, s = 0..15
+    {
+      const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+      for (int kt = 0; kt < S::WK; ++kt) {
+        float b[16];
+        const int tc = (wk0 + kt < S::KT) ? wk0 + kt : S::KT - 1;   // waves beyond the tile grid recompute the last tile (not stored)
+        const float4* br = reinterpret_cast<const float4*>(B_s + (tc * 32 + i) * WG_LD + 16 * kh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 v = br[q]; b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int mt = 0; mt < S::WM; ++mt) {
+          float a[16];
+          const int tr = (wm0 + mt < S::MT) ? wm0 + mt : S::MT - 1;
+          const float4* ar = reinterpret_cast<const float4*>(A_s + (tr * 32 + i) * WG_LD + 16 * kh);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float4 v = ar[q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+#pragma unroll
+          for (int s = 0; s < 16; ++s) acc[mt][kt] = MFMA(a[s], b[s], acc[mt][kt]);
+          __builtin_amdgcn_sched_barrier(0);   // keep operand reads next to their MFMAs (register budget: 256 accumulators)
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- partials
+  {
+    const int zi = (JOB == WG_SQ) ? blockIdx.z : 0;
+    float* out = P.partial + (((size_t)zi * P.B + img) * P.nchunk + chunk) * (size_t)(S::A_ROWS * S::B_ROWS);
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < S::WM; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < S::WK; ++kt)
+        if (wm0 + mt < S::MT && wk0 + kt < S::KT)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
+          }
+    if (S::FILM && tid < H) {
+      float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.nchunk + chunk) * H + tid) * 2;
+      fpart[0] = s0; fpart[1] = s1;
+    }
+    if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
+  }
+}
+
+// dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
+__global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
+                                    int rows, int cols, int B, int nchunk, const float* fp, int L, int H, int layer) {
+  const float TWO_PI = 6.28318530717958647692f;
+  const int total = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i % cols;
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float s = 0.f;
+      for (int k = 0; k < nchunk; ++k) s += src[(((size_t)b * nchunk + k) * src_rows + r) * src_ld + src_col0 + c];
+      sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI) : s;
+    }
+    dst[(size_t)r * dst_ld + dst_col0 + c] = sum;
+  }
+}
+
+// FiLM sums: film_partial [L][B][nchunk][H][2] -> d_phase / d_freq [B][n*H] (geo | app split), d_bias[l][H] via pointers
+__global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n_geo, int nchunk, const float* fp, float* d_freq_geo,
+                                   float* d_phase_geo, float* d_freq_app, float* d_phase_app, FenerfSirenGrads g) {
+  const float TWO_PI = 6.28318530717958647692f;
+  const int n_color = L - n_geo;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * H; i += gridDim.x * blockDim.x) {
+    const int l = i / H, n = i % H;
+    float db = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = 0; k < nchunk; ++k) {
+        const float* p = part + ((((size_t)l * B + b) * nchunk + k) * H + n) * 2;
+        s0 += p[0]; s1 += p[1];
+      }
+      db += s0 * (fp[((size_t)b * L + l) * H + n] * TWO_PI);
+      if (l < n_geo) { d_phase_geo[((size_t)b * n_geo + l) * H + n] = s0; d_freq_geo[((size_t)b * n_geo + l) * H + n] = 15.f * s1; }
+      else { d_phase_app[((size_t)b * n_color + (l - n_geo)) * H + n] = s0; d_freq_app[((size_t)b * n_color + (l - n_geo)) * H + n] = 15.f * s1; }
+    }
+    float* dst = l < n_geo ? g.geo_b[l] : g.color_b[l - n_geo];
+    dst[n] = db;
+  }
+}
+
+__global__ void rowsum_reduce_kernel(const float* part, int B, int nchunk, int rows, float* dst) {
+  const int r = threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int k = 0; k < B * nchunk; ++k) s += part[(size_t)k * 32 + r];
+  dst[r] = s;
+}
+
+namespace {
+int hipfail(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+template <int H, int JOB>
+size_t wg_lds_bytes() {
+  using S = WgShape<H, JOB>;
+  return (size_t)((S::A_ROWS + S::B_ROWS + (S::FILM ? H : 0)) * WG_LD + 3 * H) * sizeof(float);
+}
+
+template <int H, int JOB>
+int launch_job(const WgradParams& p, int nz, hipStream_t st) {
+  auto kfn = siren_wgrad_kernel<H, JOB>;
+  const size_t lds = wg_lds_bytes<H, JOB>();
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(wgrad LDS)");
+    configured = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad launch");
+}
+
+void reduce_mat(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rows, int cols,
+                int B, int nchunk, const float* fp, int L, int H, int layer, hipStream_t st) {
+  const int total = rows * cols;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dst, dst_ld, dst_col0, src, src_rows, src_ld,
+                     src_col0, rows, cols, B, nchunk, fp, L, H, layer);
+}
+}  // namespace
+
+int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
+  // ~3 workgroups per CU over the (L-1) * B square jobs; each chunk at least a few tiles
+  long long n = (3LL * m->num_cus + (long long)(m->L - 1) * B - 1) / ((long long)(m->L - 1) * B);
+  if (n < 1) n = 1;
+  if (n > tiles_per_image) n = tiles_per_image;
+  if (n > 64) n = 64;
+  return (int)n;
+}
+
+size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
+  const long long tiles = (P + 31) / 32;
+  const int nc = wgrad_nchunk(m, B, tiles);
+  const size_t H = m->H;
+  size_t f = (size_t)(m->L - 1) * B * nc * H * H;          // square partials (also reused by the thin jobs)
+  f += (size_t)m->L * B * nc * H * 2;                       // FiLM sums
+  f += (size_t)B * nc * 32;                                 // head row sums
+  return f * sizeof(float) + 1024;
+}
+
+template <int H>
+static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, hipStream_t st) {
+  const int L = m->L, ng = m->n_geo, B = p.B, nc = p.nchunk;
+  const int G = m->grid_ch;
+  float* sq = ws;
+  float* film = sq + (size_t)(L - 1) * B * nc * H * H;
+  float* rows = film + (size_t)L * B * nc * H * 2;
+  p.film_partial = film; p.rowsum_partial = rows;
+  int rc;
+  // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch; FiLM sums of layers 1..L-1
+  p.partial = sq; p.layer0 = 1;
+  if ((rc = launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
+  for (int l = 1; l < L; ++l) {
+    const float* src = sq + (size_t)(l - 1) * B * nc * H * H;
+    if (l < ng) reduce_mat(g.geo_w[l], H, 0, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
+    else if (l == ng) reduce_mat(g.color_w[0], 3 + G + H, 3 + G, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
+    else reduce_mat(g.color_w[l - ng], H, 0, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
+  }
+  // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above)
+  p.layer0 = 0;
+  if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
+  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nc, p.fp, L, H, 0, st);
+  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, p.fp, g.d_freq_geo,
+                     g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
+  p.layer0 = ng;
+  if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
+  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nc, p.fp, L, H, ng, st);          // view direction columns
+  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nc, p.fp, L, H, ng, st);    // grid feature columns
+  p.layer0 = ng - 1;
+  if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
+  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nc, nullptr, L, H, 0, st);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nc, 32, g.head_b);
+  p.layer0 = L - 1;
+  if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
+  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nc, nullptr, L, H, 0, st);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nc, 3, g.rgb_b);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
+}
+
+int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
+                       const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
+                       const FenerfSirenGrads& g, void* workspace, void* stream) {
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.tape = tape; p.d_t = d_t; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
+  p.fp = fp; p.pp = pp; p.bias = m->d_consts + CONST_FILM_BIAS;
+  p.box_scale = m->box_scale;
+  p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
+  p.P = P; p.tiles_per_image = (int)(P / 32);
+  p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
+  float* ws = (float*)workspace;
+  switch (m->H) {
+    case 32: return param_grads_t<32>(m, p, g, ws, (hipStream_t)stream);
+    case 64: return param_grads_t<64>(m, p, g, ws, (hipStream_t)stream);
+    case 128: return param_grads_t<128>(m, p, g, ws, (hipStream_t)stream);
+    case 256: return param_grads_t<256>(m, p, g, ws, (hipStream_t)stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+}  // namespace fenerf

@@ -117,6 +117,36 @@ class NativeModel:
                                                         _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
 
+    def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t):
+        """(tape, d_t) -> dict of parameter gradients in nn.Linear layout: geo_w/geo_b/color_w/color_b lists, head_w [32,H]
+        (folded label rows + sigma row), head_b [32], rgb_w [3,H], rgb_b [3], d_freq_geo / d_phase_geo [B,n_geo*H],
+        d_freq_app / d_phase_app [B,n_color*H]."""
+        sp = self.spec
+        H, ng, nc, G = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["grid_ch"]
+        B, P = points.shape[0], points.shape[1]
+        dev = self.device
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        res = dict(geo_w=[new(H, 3)] + [new(H, H) for _ in range(ng - 1)], geo_b=[new(H) for _ in range(ng)],
+                   color_w=[new(H, 3 + G + H)] + [new(H, H) for _ in range(nc - 1)], color_b=[new(H) for _ in range(nc)],
+                   head_w=new(32, H), head_b=new(32), rgb_w=new(3, H), rgb_b=new(3),
+                   d_freq_geo=new(B, ng * H), d_phase_geo=new(B, ng * H), d_freq_app=new(B, nc * H), d_phase_app=new(B, nc * H))
+        g = _lib.FenerfSirenGrads()
+        for i in range(ng):
+            g.geo_w[i], g.geo_b[i] = res["geo_w"][i].data_ptr(), res["geo_b"][i].data_ptr()
+        for i in range(nc):
+            g.color_w[i], g.color_b[i] = res["color_w"][i].data_ptr(), res["color_b"][i].data_ptr()
+        for k in ("head_w", "head_b", "rgb_w", "rgb_b", "d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app"):
+            setattr(g, k, res[k].data_ptr())
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
+            ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
+            _lib.check(l.fenerf_siren_param_grads(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
+                                                  _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), _ptr(tape_e),
+                                                  _ptr(d_t), C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
+        return res
+
     def grid_backward(self, points, d_e, grid_shape):
         """Scatter d_e [Ptot,32] into the gradient of spatial_embeddings; returns it in the parameter's [1,32,D,H,W] shape."""
         D, Hh, W = grid_shape

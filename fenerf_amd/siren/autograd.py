@@ -42,87 +42,49 @@ class SirenFunction(torch.autograd.Function):
         points, dirs, fg, pg, fa, pa, out, tape, tape_e, *params = ctx.saved_tensors
         roles = module._roles(params)
         spec = nat.spec
-        H, ng, nc, C = spec["hidden_dim"], spec["n_geo"], spec["n_color"], spec["output_dim"]
-        L, n_lab = ng + nc, C - 4
+        ng, C = spec["n_geo"], spec["output_dim"]
+        n_lab = C - 4
         B, P = points.shape[0], points.shape[1]
-        Pt = B * P
         d_out = d_out.contiguous().float()
         d_t, d_e = nat.siren_backward(B, P, fg, pg, fa, pa, out, d_out, tape)
-
-        f = torch.cat([fg.reshape(B, ng, H), fa.reshape(B, nc, H)], 1) * 15 + 30        # [B,L,H]
-        ph = torch.cat([pg.reshape(B, ng, H), pa.reshape(B, nc, H)], 1)
-        layers = roles["geo"] + roles["color"]
-        d_f = torch.empty_like(f)
-        d_p = torch.empty_like(f)
+        r = nat.siren_param_grads(points, dirs if ctx.has_dirs else None, fg, pg, fa, pa, out, d_out, tape,
+                                  tape_e if tape_e.numel() else None, d_t)
         grads = {}
-        q = (points.reshape(Pt, 3) * nat.box_scale)
-        if ctx.has_dirs:
-            dflat = dirs.reshape(Pt, 3)
-        else:
-            dflat = points.new_tensor([0.0, 0.0, -1.0]).expand(Pt, 3)
-        d2 = d_out.reshape(Pt, C)
-        x_prev = None                      # X_{l-1} as [H, Pt]
-        for l in range(L):
-            W, b = layers[l]
-            fl = f[:, l].t().unsqueeze(-1)                              # [H,B,1]
-            pl = ph[:, l].t().unsqueeze(-1)
-            T = tape[l].view(H, B, P)
-            D = d_t[l].view(H, B, P)
-            Z = T + b.view(H, 1, 1)
-            d_p[:, l] = D.sum(-1).t()
-            d_f[:, l] = (D * Z).sum(-1).t()
-            DZ = (D * fl).reshape(H, Pt)
-            grads[id(b)] = DZ.sum(-1)
-            if l == 0:
-                dW = DZ @ q
-            elif l == ng:
-                parts = [DZ @ dflat]
-                if tape_e.numel():
-                    parts.append(DZ @ tape_e)
-                parts.append(DZ @ x_prev.t())
-                dW = torch.cat(parts, 1)
-            else:
-                dW = DZ @ x_prev.t()
-            grads[id(W)] = dW
-            x_l = torch.sin(fl * Z + pl).reshape(H, Pt)
-            if l == ng - 1:                 # the heads read the trunk output
-                sw, sb = roles["sigma"]
-                grads[id(sw)] = d2[:, C - 1:].t() @ x_l.t()
-                grads[id(sb)] = d2[:, C - 1].sum().reshape(1)
-                if n_lab > 0:
-                    dA = d2[:, :n_lab].t() @ x_l.t()
-                    dc = d2[:, :n_lab].sum(0)
-                    with torch.enable_grad():
-                        leaves = [(Wi.detach().requires_grad_(True), bi.detach().requires_grad_(True)) for Wi, bi in roles["label"]]
-                        A, c = _fold_label_head(leaves)
-                        flat = [t for pair in leaves for t in pair]
-                        g = torch.autograd.grad([A, c], flat, [dA, dc], allow_unused=True)
-                    for (Wi, bi), gw, gb in zip(roles["label"], g[0::2], g[1::2]):
-                        grads[id(Wi)] = gw if gw is not None else torch.zeros_like(Wi)
-                        grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
-            if l == L - 1:
-                rw, rb = roles["rgb"]
-                s = out.reshape(Pt, C)[:, C - 4:C - 1]
-                dpre = d2[:, C - 4:C - 1] * (s * (1 - s))
-                grads[id(rw)] = dpre.t() @ x_l.t()
-                grads[id(rb)] = dpre.sum(0)
-            x_prev = x_l
+        for (W, b), gw, gb in zip(roles["geo"] + roles["color"], r["geo_w"] + r["color_w"], r["geo_b"] + r["color_b"]):
+            grads[id(W)], grads[id(b)] = gw, gb
+        sw, sb = roles["sigma"]
+        grads[id(sw)], grads[id(sb)] = r["head_w"][n_lab:n_lab + 1], r["head_b"][n_lab:n_lab + 1]
+        if n_lab > 0:      # back through the fold of the activation-free label head (tiny H x H products)
+            with torch.enable_grad():
+                leaves = [(Wi.detach().requires_grad_(True), bi.detach().requires_grad_(True)) for Wi, bi in roles["label"]]
+                A, c = _fold_label_head(leaves)
+                flat = [t for pair in leaves for t in pair]
+                g = torch.autograd.grad([A, c], flat, [r["head_w"][:n_lab], r["head_b"][:n_lab]], allow_unused=True)
+            for (Wi, bi), gw, gb in zip(roles["label"], g[0::2], g[1::2]):
+                grads[id(Wi)] = gw if gw is not None else torch.zeros_like(Wi)
+                grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
+        rw, rb = roles["rgb"]
+        grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
         if roles["grid"] is not None:
             grads[id(roles["grid"])] = nat.grid_backward(points, d_e, roles["grid"].shape[2:]).contiguous()
-
-        d_f = d_f * 15
         need = ctx.needs_input_grad
-        g_fg = d_f[:, :ng].reshape(B, ng * H) if need[3] else None
-        g_pg = d_p[:, :ng].reshape(B, ng * H) if need[4] else None
-        g_fa = d_f[:, ng:].reshape(B, nc * H) if need[5] else None
-        g_pa = d_p[:, ng:].reshape(B, nc * H) if need[6] else None
         g_params = tuple(grads[id(p)].reshape(p.shape) if need[7 + i] else None for i, p in enumerate(params))
-        return (None, None, None, g_fg, g_pg, g_fa, g_pa) + g_params
+        return (None, None, None, r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
+                r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None) + g_params
 
 
 def siren_apply(module, points, dirs, fg, pg, fa, pa):
+    """Differentiable SIREN evaluation.  The native path works on whole 32-point tiles per image: other point counts are
+    padded here (with the last point; the pads get no gradient because their outputs are sliced away)."""
     if points.requires_grad or (dirs is not None and dirs.requires_grad):
         raise NotImplementedError("fenerf_amd: gradients wrt sample positions / view directions are not provided "
                                   "(the reference's training and inversion loops do not use them)")
     params = module._render_params()
-    return SirenFunction.apply(module, points, dirs, fg, pg, fa, pa, *params)
+    P = points.shape[1]
+    pad = (-P) % 32
+    if pad:
+        points = torch.cat([points, points[:, -1:].expand(-1, pad, -1)], 1)
+        if dirs is not None:
+            dirs = torch.cat([dirs, dirs[:, -1:].expand(-1, pad, -1)], 1)
+    out = SirenFunction.apply(module, points.contiguous(), dirs.contiguous() if dirs is not None else None, fg, pg, fa, pa, *params)
+    return out[:, :P] if pad else out

@@ -174,18 +174,29 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
 
 /* ---- differentiable evaluation (generator step / inversion).  replaces what torch autograd records and replays for
  * <siren>.forward_with_frequencies_phase_shifts (siren.py:1509-1530) in train_double_latent_semantic.py (g_loss.backward())
- * and inverse_render_double_semantic.py.  Model must be created with differentiable != 0.
+ * and inverse_render_double_semantic.py.  The model must be created with differentiable != 0; P (points per image) must
+ * be a multiple of 32 (pad with any valid point and give the pads a zero gradient).
  *
- * fenerf_siren_forward_save = fenerf_siren_forward that also keeps, per FiLM layer l, the pre-FiLM accumulators
- *   tape[l][n][p] = (W_l x_{l-1})[n] (no bias; feature-major, p over all B*P points)  and the sampled grid features
- *   tape_e[p][32] (NULL without a grid).  tape holds fenerf_siren_tape_floats(m, B*P) floats.
- * fenerf_siren_backward: d_out [B,P,output_dim] (gradient wrt the outputs) ->
- *   d_t[l][n][p] = dL/dtheta, theta = f (W x + b) + p   (same shape as tape)
- *   d_e[p][32]   = gradient wrt the sampled grid features (NULL without a grid)
- *   From these the parameter gradients are reductions over points (plain GEMMs): with f = 15 freq + 30,
- *   dL/dphase = sum_p d_t, dL/dfreq = 15 sum_p d_t (tape + b), dL/db = sum_p f d_t, dL/dW = (f d_t) x_{l-1}^T.
+ * fenerf_siren_forward_save = fenerf_siren_forward that also keeps the pre-FiLM accumulators (W_l x_{l-1}, no bias) of
+ *   every FiLM layer as a tape of fenerf_siren_tape_floats(m, B*P) floats (opaque: 32-point register dumps,
+ *   fenerf_amd/csrc/fenerf_layout.h "Tape") and the sampled grid features tape_e [B*P][32] (NULL without a grid).
+ * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t (same size and layout as the tape) = dL/dtheta per FiLM layer,
+ *   theta = f (W x + b) + p, and d_e [B*P][32] = gradient wrt the sampled grid features (NULL without a grid).
+ * fenerf_siren_param_grads: (tape, d_t) -> every parameter gradient, written to the buffers of FenerfSirenGrads.
  * fenerf_grid_backward: scatters d_e into a zero-initialised channels-last gradient grid d_grid_cl [D][H][W][32]
  *   (the transpose of sample_from_3dgrid, siren.py:314-330). */
+typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in] row-major) like FenerfModelDesc */
+  float* geo_w[FENERF_MAX_GEO];     float* geo_b[FENERF_MAX_GEO];
+  float* color_w[FENERF_MAX_COLOR]; float* color_b[FENERF_MAX_COLOR];   /* color_w[0]: columns [dir | grid feats | x] */
+  float* head_w;   /* [32][H]: rows [0, n_lab) = gradient wrt the FOLDED label head (the product of label_layer_linear),
+                      row n_lab = final_layer (sigma); the caller back-propagates the fold (tiny H x H products) */
+  float* head_b;   /* [32] */
+  float* rgb_w;    /* [3][H] color_layer_linear[0] */
+  float* rgb_b;    /* [3] */
+  float* d_freq_geo;  float* d_phase_geo;   /* [B][n_geo*H]   gradient wrt the RAW mapping-network outputs */
+  float* d_freq_app;  float* d_phase_app;   /* [B][n_color*H] */
+} FenerfSirenGrads;
+
 size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
 int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                               const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
@@ -193,6 +204,11 @@ int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const floa
 int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
                           const float* freq_app, const float* phase_app, const float* out, const float* d_out,
                           const float* tape, float* d_t, float* d_e, void* film_ws, void* stream);
+size_t fenerf_siren_grad_workspace_bytes(const FenerfModel* m, int B, int64_t P);
+int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                             const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                             const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
+                             const FenerfSirenGrads* grads, void* workspace, void* film_ws, void* stream);
 int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e, float* d_grid_cl,
                          void* stream);
 
