@@ -64,6 +64,8 @@ _SIGS = {
     "fenerf_model_create": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_vp)]),
     "fenerf_model_update": (_i, [_vp, C.POINTER(FenerfModelDesc), _vp]),
     "fenerf_model_destroy": (None, [_vp]),
+    "fenerf_pack_backward_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_fp), C.POINTER(_sz)]),
+    "fenerf_model_load_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
@@ -151,6 +153,17 @@ def make_desc(sd, spec, precision="f32", differentiable=False):
         d.grid_d, d.grid_h, d.grid_w = int(g.shape[2]), int(g.shape[3]), int(g.shape[4])
         d.grid = P("spatial_embeddings")
     return d, keep
+
+
+def pack_backward_host(sd, spec):
+    """numpy copy of the backward-chain stream (CPU only; layout tests and the device-side packing index map)."""
+    d, keep = make_desc(sd, spec, "f32", True)
+    blob, nb = _fp(), _sz()
+    check(lib().fenerf_pack_backward_host(C.byref(d), C.byref(blob), C.byref(nb)))
+    try:
+        return np.ctypeslib.as_array(blob, shape=(nb.value,)).copy()
+    finally:
+        lib().fenerf_free_host(blob)
 
 
 def pack_weights_host(sd, spec, precision="f32"):

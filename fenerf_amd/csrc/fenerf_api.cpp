@@ -128,6 +128,25 @@ extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, voi
   return upload_model(m, d, (hipStream_t)stream, false);
 }
 
+extern "C" int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev,
+                                        size_t n_consts, const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (m->precision != FENERF_PREC_F32) return fail(FENERF_E_UNSUPPORTED, "device-side packing is defined for FENERF_PREC_F32 streams");
+  const size_t want_s = (size_t)(m->sh.l0_entries + m->sh.ring_entries) * 256, want_c = (size_t)CONST_FILM_BIAS + (size_t)m->L * m->H;
+  const size_t want_b = (size_t)(m->bsh.ht_entries + m->bsh.ring_entries) * 256;
+  if (!stream_dev || !consts_dev || n_stream != want_s || n_consts != want_c) return fail(FENERF_E_INVALID, "packed stream / consts size mismatch");
+  if (m->differentiable && (!bwd_dev || n_bwd != want_b)) return fail(FENERF_E_INVALID, "backward stream size mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(m->d_stream, stream_dev, n_stream * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(m->d_consts, consts_dev, n_consts * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (m->differentiable) HIP_TRY(hipMemcpyAsync(m->d_bwd_stream, bwd_dev, n_bwd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (grid_dev) {
+    if (!m->grid_ch) return fail(FENERF_E_INVALID, "model has no feature grid");
+    return launch_grid_relayout(grid_dev, m->d_grid, m->grid_ch, m->gd, m->gh, m->gw, stream);
+  }
+  return FENERF_OK;
+}
+
 extern "C" void fenerf_model_destroy(FenerfModel* m) {
   if (!m) return;
   if (m->d_stream) (void)hipFree(m->d_stream);

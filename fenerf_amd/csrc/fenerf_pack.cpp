@@ -394,4 +394,17 @@ extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blo
   return FENERF_OK;
 }
 
+extern "C" int fenerf_pack_backward_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats) {
+  std::vector<float> b;
+  std::string err;
+  int rc = fenerf::pack_weights_bwd(desc, b, err);
+  if (rc) { fenerf::set_error(err); return rc; }
+  if (!blob || !n_floats) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
+  *blob = (float*)malloc(b.size() * sizeof(float));
+  if (!*blob) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  memcpy(*blob, b.data(), b.size() * sizeof(float));
+  *n_floats = b.size();
+  return FENERF_OK;
+}
+
 extern "C" void fenerf_free_host(void* p) { free(p); }

@@ -45,6 +45,71 @@ class NativeModel:
             d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
 
+    # ---- device-side packing (training): the fp32 streams are permutations of the parameters -------------------------
+    def _canonical(self):
+        """[(reference name, shape)] of the render parameters in the flat order of the index maps; the label head is its fold."""
+        sp = self.spec
+        H, ng, nc, G, n_lab = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["grid_ch"], sp["output_dim"] - 4
+        items = [("network.0.layer.weight", (H, 3)), ("network.0.layer.bias", (H,))]
+        for i in range(1, ng):
+            items += [(f"network.{i}.layer.weight", (H, H)), (f"network.{i}.layer.bias", (H,))]
+        cname = (lambda i: "color_layer_sine.layer") if sp["kind"] == "spatial" else (lambda i: f"color_layer_sine.{i}.layer")
+        items += [(cname(0) + ".weight", (H, 3 + G + H)), (cname(0) + ".bias", (H,))]
+        for i in range(1, nc):
+            items += [(cname(i) + ".weight", (H, H)), (cname(i) + ".bias", (H,))]
+        if n_lab > 0:
+            items += [("label_layer_linear.0.weight", (n_lab, H)), ("label_layer_linear.0.bias", (n_lab,))]
+        items += [("final_layer.weight", (1, H)), ("final_layer.bias", (1,)), ("color_layer_linear.0.weight", (3, H)),
+                  ("color_layer_linear.0.bias", (3,))]
+        return items
+
+    def _index_maps(self):
+        """Packs index-valued weights once on the host: every stream element is then (1 + flat index) of its source
+        parameter element, 0 for padding -- exact in fp32 below 2^24 elements."""
+        if getattr(self, "_maps", None) is None:
+            items = self._canonical()
+            total = sum(int(np.prod(sh)) for _, sh in items)
+            if total + 1 >= 1 << 24:
+                raise RuntimeError("too many render parameters for fp32 index tagging")
+            tag, off = {}, 1
+            for name, sh in items:
+                n = int(np.prod(sh))
+                tag[name] = np.arange(off, off + n, dtype=np.float32).reshape(sh)
+                off += n
+            spec1 = dict(self.spec, n_label_layers=1 if self.spec["output_dim"] > 4 else 0)
+            if self.spec["grid_ch"]:
+                tag["spatial_embeddings"] = np.zeros((1, 32, 2, 2, 2), np.float32)
+            blob, consts = _lib.pack_weights_host(tag, spec1, "f32")
+            bwd = _lib.pack_backward_host(tag, spec1) if self.differentiable else None
+            to_idx = lambda a: torch.from_numpy(a.astype(np.int64)).to(self.device)
+            self._maps = (to_idx(blob), to_idx(consts), to_idx(bwd) if bwd is not None else None)
+        return self._maps
+
+    def load_from_device(self, params):
+        """Re-pack from device-resident parameters {reference name: tensor} without touching the host (fp32 models)."""
+        if self.precision != "f32":
+            raise RuntimeError("device-side packing is defined for the fp32 streams")
+        m_s, m_c, m_b = self._index_maps()
+        sp = self.spec
+        n_lab = sp["output_dim"] - 4
+        p = {k: v.detach().to(self.device, torch.float32) for k, v in params.items()}
+        if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
+            A, c = p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"]
+            for i in range(1, sp["n_label_layers"]):
+                W, b = p[f"label_layer_linear.{i}.weight"], p[f"label_layer_linear.{i}.bias"]
+                c = W @ c + b
+                A = W @ A
+            p = dict(p)
+            p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
+        flat = torch.cat([torch.zeros(1, device=self.device)] + [p[name].reshape(-1) for name, _ in self._canonical()])
+        s_, c_ = flat[m_s], flat[m_c]
+        b_ = flat[m_b] if m_b is not None else None
+        grid = p.get("spatial_embeddings")
+        grid = grid.contiguous() if grid is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_model_load_packed(self._h, _ptr(s_), s_.numel(), _ptr(c_), c_.numel(), _ptr(b_),
+                                                           b_.numel() if b_ is not None else 0, _ptr(grid), _stream()))
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().fenerf_model_destroy(self._h)

@@ -127,7 +127,8 @@ class _NativeSiren(nn.Module):
             nat = native.NativeModel(self._state_numpy(), self._spec(), device, "f32", differentiable=True)
             self.__dict__["_native_diff"] = nat
         elif self.__dict__.get("_native_diff_version") != ver:
-            nat.update(self._state_numpy())
+            # weights live on the GPU during training: re-pack there (a gather), never through the host
+            nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n})
         self.__dict__["_native_diff_version"] = ver
         return nat
 

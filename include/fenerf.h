@@ -109,6 +109,16 @@ int fenerf_model_create(const FenerfModelDesc* desc, FenerfModel** out);
 int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* desc, void* stream);
 void fenerf_model_destroy(FenerfModel* m);
 
+/* Training keeps the weights on the GPU, so re-packing them through the host every optimizer step (fenerf_model_update)
+ * costs more than the step itself.  For FENERF_PREC_F32 models the packed streams are pure permutations (plus zero
+ * padding) of the parameters: the caller builds them on the device (a gather with an index map obtained ONCE by packing
+ * index-valued weights with fenerf_pack_weights_host / fenerf_pack_backward_host) and hands them over here with
+ * device-to-device copies.  stream_dev / consts_dev as fenerf_pack_weights_host returns them, bwd_dev as
+ * fenerf_pack_backward_host (NULL unless the model is differentiable), grid_dev = spatial_embeddings [1,32,D,H,W] or NULL. */
+int fenerf_pack_backward_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats);
+int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev, size_t n_consts,
+                             const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream);
+
 /* Bytes of [dev] scratch the FiLM pre-pass needs for a batch of B images. */
 size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B);
 

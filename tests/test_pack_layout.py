@@ -201,3 +201,28 @@ def test_desc_validation_errors():
         _lib.composite_opts(None)
     with pytest.raises(RuntimeError):
         _lib.composite_opts("relu", fill_mode="debug")
+
+
+def test_device_packing_index_maps_reproduce_the_host_streams():
+    """Training re-packs on the GPU with a gather (NativeModel.load_from_device).  The index maps come from packing
+    index-valued weights; applied to the real parameters they must reproduce the host packer's streams exactly
+    (forward stream, consts and the backward-chain stream)."""
+    import torch
+    from fenerf_amd import native
+    for kind, H, grid in [("texture", 64, 4), ("baseline", 32, 0), ("spatial", 32, 0)]:
+        spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+        sd = proc.make_state_dict(spec, seed=1, sigma_gain=10.0, with_mapping=False)
+        nm = object.__new__(native.NativeModel)            # no GPU here: only the host-side map construction is exercised
+        nm.spec, nm.differentiable, nm.device, nm.precision, nm._maps, nm._h = dict(spec), True, torch.device("cpu"), "f32", None, None
+        ms, mc, mb = nm._index_maps()
+        p = {k: torch.from_numpy(v) for k, v in sd.items()}
+        if spec["n_label_layers"]:
+            A, c = p["label_layer_linear.0.weight"].double(), p["label_layer_linear.0.bias"].double()
+            for i in range(1, spec["n_label_layers"]):
+                W, b = p[f"label_layer_linear.{i}.weight"].double(), p[f"label_layer_linear.{i}.bias"].double()
+                c, A = W @ c + b, W @ A
+            p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A.float(), c.float()
+        flat = torch.cat([torch.zeros(1)] + [p[n].reshape(-1) for n, _ in nm._canonical()])
+        blob, consts = _lib.pack_weights_host(sd, spec, "f32")
+        bwd = _lib.pack_backward_host(sd, spec)
+        assert np.array_equal(flat[ms].numpy(), blob) and np.array_equal(flat[mc].numpy(), consts) and np.array_equal(flat[mb].numpy(), bwd)
