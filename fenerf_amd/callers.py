@@ -5,6 +5,7 @@ siren.forward_with_frequencies_phase_shifts, i.e. the HIP kernels.
 reference: mask2color + COLOR_MAP  train_double_latent_semantic.py:35-72
            multi-view loop         render_multiview_images_double_semantic.py:24-85
            voxel-grid evaluation   extract_double_semantic_shapes.py:13-90
+           inversion loop          inverse_render_double_semantic.py:306-410
 """
 import numpy as np
 import torch
@@ -93,3 +94,59 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
         fa, pa = avg_fa + psi * (raw_fa - avg_fa), avg_pa + psi * (raw_pa - avg_pa)
         out = generator.siren.native(samples.device).siren_forward(samples, None, fg, pg, fa, pa)   # None = locked view dir
     return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()
+
+
+def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_psi=0.0, lambda_seg=1.0, lambda_img=1.0,
+                   lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None):
+    """GAN inversion in FiLM space (inverse_render_double_semantic.py:306-410): optimise additive offsets on the geometry /
+    appearance frequencies and phase shifts with Adam (lr 1e-2, weight_decay 1e-4, StepLR(100, 0.75)) under annealed
+    latent noise so that generator.forward_with_frequencies reproduces gt_image [1,3,S,S] and gt_seg [1,18,S,S] (both in
+    [-1,1]).  Every iteration is a native differentiable render; when the generator's parameters do not require grad
+    only the FiLM gradients are computed.  `percept` (e.g. an LPIPS module) is optional -- none is shipped.
+    Returns a dict with the reference's checkpoint keys (w_*_frequencies, w_*_phase_shifts, w_*_offsets) + `losses`."""
+    device = generator.device
+    siren = generator.siren
+
+    def init(mapping):     # :307-327
+        z = torch.randn((10000, z_dim), device=device)
+        rand_z = torch.randn((1, z_dim), device=device)
+        with torch.no_grad():
+            freq, phase = mapping(z)
+            rand_f, rand_p = mapping(rand_z)
+        w_f, w_p = freq.mean(0, keepdim=True), phase.mean(0, keepdim=True)
+        w_f = w_f + init_psi * (rand_f - w_f)
+        w_p = w_p + init_psi * (rand_p - w_p)
+        return w_f, w_p, torch.zeros_like(w_f).requires_grad_(), torch.zeros_like(w_p).requires_grad_()
+
+    w_gf, w_gp, o_gf, o_gp = init(siren.geo_mapping_network)
+    w_af, w_ap, o_af, o_ap = init(siren.app_mapping_network)
+    if lambda_img == 0:        # :371-376
+        opt_params = [o_gf, o_gp]
+    elif lambda_seg == 0:
+        opt_params = [o_af, o_ap]
+    else:
+        opt_params = [o_gf, o_gp, o_af, o_ap]
+    optimizer = torch.optim.Adam(opt_params, lr=lr, weight_decay=1e-4)
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 100, gamma=0.75)
+    mse = torch.nn.MSELoss(reduction="mean")
+    losses = []
+    for i in range(n_iterations):
+        k = 0.03 * (n_iterations - i) / n_iterations
+        frame, _ = generator.forward_with_frequencies(w_gf + k * torch.randn_like(w_gf) + o_gf, w_af + k * torch.randn_like(w_af) + o_af,
+                                                      w_gp + k * torch.randn_like(w_gp) + o_gp, w_ap + k * torch.randn_like(w_ap) + o_ap,
+                                                      **options)
+        loss = lambda_seg * mse(frame[:, :-3], gt_seg) + lambda_img * mse(frame[:, -3:], gt_image)
+        if lambda_percept and percept is not None:
+            loss = loss + lambda_percept * percept(frame[:, -3:], gt_image).sum()
+        if lambda_norm > 0:
+            loss = loss + lambda_norm * sum((o ** 2).mean() for o in (o_gf, o_gp, o_af, o_ap))
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        scheduler.step()
+        losses.append(float(loss.detach()))
+        if on_step is not None:
+            on_step(i, losses[-1])
+    return dict(w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
+                w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
+                w_app_frequency_offsets=o_af.detach(), w_app_phase_shift_offsets=o_ap.detach(), losses=losses)

@@ -382,14 +382,18 @@ extern "C" int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, 
   if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
   if (P == 0) return FENERF_OK;
   if (!points || !out || !d_out || !tape || !d_t || !g || !workspace || (m->grid_ch && !tape_e)) return fail(FENERF_E_INVALID, "NULL pointer");
-  for (int i = 0; i < m->n_geo; ++i) if (!g->geo_w[i] || !g->geo_b[i]) return fail(FENERF_E_INVALID, "grads: geo pointer is NULL");
-  for (int i = 0; i < m->n_color; ++i) if (!g->color_w[i] || !g->color_b[i]) return fail(FENERF_E_INVALID, "grads: color pointer is NULL");
-  if (!g->head_w || !g->head_b || !g->rgb_w || !g->rgb_b || !g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app)
-    return fail(FENERF_E_INVALID, "grads: head / rgb / film pointer is NULL");
+  if (!g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
+  // all weight / bias pointers NULL = FiLM gradients only (inversion); otherwise every one of them is required
+  int have = 0, want = 0;
+  for (int i = 0; i < m->n_geo; ++i) { want += 2; have += (g->geo_w[i] != nullptr) + (g->geo_b[i] != nullptr); }
+  for (int i = 0; i < m->n_color; ++i) { want += 2; have += (g->color_w[i] != nullptr) + (g->color_b[i] != nullptr); }
+  want += 4; have += (g->head_w != nullptr) + (g->head_b != nullptr) + (g->rgb_w != nullptr) + (g->rgb_b != nullptr);
+  if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
+  const bool film_only = have == 0;
   const float *fp, *pp;
   int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
   if (rc) return rc;
-  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, tape_e, d_t, *g, workspace, stream);
+  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, tape_e, d_t, *g, film_only, workspace, stream);
 }
 
 extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e,

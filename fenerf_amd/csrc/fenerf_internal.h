@@ -101,7 +101,7 @@ int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* s
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, void* workspace, void* stream);
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);

@@ -240,6 +240,53 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   }
 }
 
+// Inversion optimises only the FiLM frequencies / phases (inverse_render_double_semantic.py:324-350): the FiLM sums alone,
+// straight from the two dumps -- per-lane partial sums over the block's tiles, one cross-lane reduction at the end.
+template <int H>
+__global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
+  constexpr int NQ = H / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x, img = blockIdx.y, l = blockIdx.z;
+  const int L = P.L;
+  const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
+  const int t0 = chunk * t_per, t1 = min(P.tiles_per_image, t0 + t_per);
+  const long long tile_base = (long long)img * P.tiles_per_image;
+  const long long tl = (long long)(H / 8) * 64;
+  const float4* tape4 = reinterpret_cast<const float4*>(P.tape);
+  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
+  float s0[NQ][4], s1[NQ][4], bb[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0[q][i] = 0.f; s1[q][i] = 0.f;
+      bb[q][i] = P.bias[(size_t)l * H + tape_feature(wave * NQ + q, lane >> 5, i)];
+    }
+  for (int t = t0; t < t1; ++t) {
+    const long long base = ((tile_base + t) * L + l) * tl;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 d = dt4[base + (wave * NQ + q) * 64 + lane], z = tape4[base + (wave * NQ + q) * 64 + lane];
+      s0[q][0] += d.x; s0[q][1] += d.y; s0[q][2] += d.z; s0[q][3] += d.w;
+      s1[q][0] += d.x * (z.x + bb[q][0]); s1[q][1] += d.y * (z.y + bb[q][1]);
+      s1[q][2] += d.z * (z.z + bb[q][2]); s1[q][3] += d.w * (z.w + bb[q][3]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s0[q][i], b = s1[q][i];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // over the 32 points of a half
+      if ((lane & 31) == 0) {
+        const int n = tape_feature(wave * NQ + q, lane >> 5, i);
+        float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.nchunk + chunk) * H + n) * 2;
+        fpart[0] = a; fpart[1] = b;
+      }
+    }
+}
+
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
 __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
                                     int rows, int cols, int B, int nchunk, const float* fp, int L, int H, int layer) {
@@ -276,7 +323,7 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
       else { d_phase_app[((size_t)b * n_color + (l - n_geo)) * H + n] = s0; d_freq_app[((size_t)b * n_color + (l - n_geo)) * H + n] = 15.f * s1; }
     }
     float* dst = l < n_geo ? g.geo_b[l] : g.color_b[l - n_geo];
-    dst[n] = db;
+    if (dst) dst[n] = db;
   }
 }
 
@@ -343,7 +390,7 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
 }
 
 template <int H>
-static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, hipStream_t st) {
+static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, bool film_only, hipStream_t st) {
   const int L = m->L, ng = m->n_geo, B = p.B, nc = p.nchunk;
   const int G = m->grid_ch;
   float* sq = ws;
@@ -351,6 +398,13 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   float* rows = film + (size_t)L * B * nc * H * 2;
   p.film_partial = film; p.rowsum_partial = rows;
   int rc;
+  if (film_only) {
+    hipLaunchKernelGGL(film_sums_kernel<H>, dim3(nc, B, L), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, p.fp, g.d_freq_geo,
+                       g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FENERF_OK : hipfail(e, "film sums launch");
+  }
   // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch; FiLM sums of layers 1..L-1
   p.partial = sq; p.layer0 = 1;
   if ((rc = launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
@@ -384,7 +438,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
 
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, void* workspace, void* stream) {
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream) {
   WgradParams p;
   memset(&p, 0, sizeof(p));
   p.tape = tape; p.d_t = d_t; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
@@ -395,10 +449,10 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {
-    case 32: return param_grads_t<32>(m, p, g, ws, (hipStream_t)stream);
-    case 64: return param_grads_t<64>(m, p, g, ws, (hipStream_t)stream);
-    case 128: return param_grads_t<128>(m, p, g, ws, (hipStream_t)stream);
-    case 256: return param_grads_t<256>(m, p, g, ws, (hipStream_t)stream);
+    case 32: return param_grads_t<32>(m, p, g, ws, film_only, (hipStream_t)stream);
+    case 64: return param_grads_t<64>(m, p, g, ws, film_only, (hipStream_t)stream);
+    case 128: return param_grads_t<128>(m, p, g, ws, film_only, (hipStream_t)stream);
+    case 256: return param_grads_t<256>(m, p, g, ws, film_only, (hipStream_t)stream);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

@@ -182,7 +182,7 @@ class NativeModel:
                                                         _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
 
-    def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t):
+    def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t, film_only=False):
         """(tape, d_t) -> dict of parameter gradients in nn.Linear layout: geo_w/geo_b/color_w/color_b lists, head_w [32,H]
         (folded label rows + sigma row), head_b [32], rgb_w [3,H], rgb_b [3], d_freq_geo / d_phase_geo [B,n_geo*H],
         d_freq_app / d_phase_app [B,n_color*H]."""
@@ -192,17 +192,19 @@ class NativeModel:
         dev = self.device
         fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        res = dict(geo_w=[new(H, 3)] + [new(H, H) for _ in range(ng - 1)], geo_b=[new(H) for _ in range(ng)],
-                   color_w=[new(H, 3 + G + H)] + [new(H, H) for _ in range(nc - 1)], color_b=[new(H) for _ in range(nc)],
-                   head_w=new(32, H), head_b=new(32), rgb_w=new(3, H), rgb_b=new(3),
-                   d_freq_geo=new(B, ng * H), d_phase_geo=new(B, ng * H), d_freq_app=new(B, nc * H), d_phase_app=new(B, nc * H))
+        res = dict(d_freq_geo=new(B, ng * H), d_phase_geo=new(B, ng * H), d_freq_app=new(B, nc * H), d_phase_app=new(B, nc * H))
         g = _lib.FenerfSirenGrads()
-        for i in range(ng):
-            g.geo_w[i], g.geo_b[i] = res["geo_w"][i].data_ptr(), res["geo_b"][i].data_ptr()
-        for i in range(nc):
-            g.color_w[i], g.color_b[i] = res["color_w"][i].data_ptr(), res["color_b"][i].data_ptr()
-        for k in ("head_w", "head_b", "rgb_w", "rgb_b", "d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app"):
-            setattr(g, k, res[k].data_ptr())
+        if not film_only:
+            res.update(geo_w=[new(H, 3)] + [new(H, H) for _ in range(ng - 1)], geo_b=[new(H) for _ in range(ng)],
+                       color_w=[new(H, 3 + G + H)] + [new(H, H) for _ in range(nc - 1)], color_b=[new(H) for _ in range(nc)],
+                       head_w=new(32, H), head_b=new(32), rgb_w=new(3, H), rgb_b=new(3))
+            for i in range(ng):
+                g.geo_w[i], g.geo_b[i] = res["geo_w"][i].data_ptr(), res["geo_b"][i].data_ptr()
+            for i in range(nc):
+                g.color_w[i], g.color_b[i] = res["color_w"][i].data_ptr(), res["color_b"][i].data_ptr()
+        for k in res:
+            if not isinstance(res[k], list):
+                setattr(g, k, res[k].data_ptr())
         l = _lib.lib()
         with torch.cuda.device(dev):
             fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))

@@ -46,9 +46,15 @@ class SirenFunction(torch.autograd.Function):
         n_lab = C - 4
         B, P = points.shape[0], points.shape[1]
         d_out = d_out.contiguous().float()
+        need = ctx.needs_input_grad
+        film_only = not any(need[7:])        # inversion: only the FiLM parameters are optimised
         d_t, d_e = nat.siren_backward(B, P, fg, pg, fa, pa, out, d_out, tape)
         r = nat.siren_param_grads(points, dirs if ctx.has_dirs else None, fg, pg, fa, pa, out, d_out, tape,
-                                  tape_e if tape_e.numel() else None, d_t)
+                                  tape_e if tape_e.numel() else None, d_t, film_only=film_only)
+        film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
+                      r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
+        if film_only:
+            return (None, None, None) + film_grads + (None,) * len(params)
         grads = {}
         for (W, b), gw, gb in zip(roles["geo"] + roles["color"], r["geo_w"] + r["color_w"], r["geo_b"] + r["color_b"]):
             grads[id(W)], grads[id(b)] = gw, gb
@@ -67,10 +73,8 @@ class SirenFunction(torch.autograd.Function):
         grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
         if roles["grid"] is not None:
             grads[id(roles["grid"])] = nat.grid_backward(points, d_e, roles["grid"].shape[2:]).contiguous()
-        need = ctx.needs_input_grad
         g_params = tuple(grads[id(p)].reshape(p.shape) if need[7 + i] else None for i, p in enumerate(params))
-        return (None, None, None, r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
-                r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None) + g_params
+        return (None, None, None) + film_grads + g_params
 
 
 def siren_apply(module, points, dirs, fg, pg, fa, pa):

@@ -192,7 +192,9 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
  *   fenerf_amd/csrc/fenerf_layout.h "Tape") and the sampled grid features tape_e [B*P][32] (NULL without a grid).
  * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t (same size and layout as the tape) = dL/dtheta per FiLM layer,
  *   theta = f (W x + b) + p, and d_e [B*P][32] = gradient wrt the sampled grid features (NULL without a grid).
- * fenerf_siren_param_grads: (tape, d_t) -> every parameter gradient, written to the buffers of FenerfSirenGrads.
+ * fenerf_siren_param_grads: (tape, d_t) -> every parameter gradient, written to the buffers of FenerfSirenGrads.  With all
+ *   weight / bias pointers NULL only the FiLM gradients (d_freq_*, d_phase_*) are computed -- what inversion optimises
+ *   (inverse_render_double_semantic.py:324-350).
  * fenerf_grid_backward: scatters d_e into a zero-initialised channels-last gradient grid d_grid_cl [D][H][W][32]
  *   (the transpose of sample_from_3dgrid, siren.py:314-330). */
 typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in] row-major) like FenerfModelDesc */
