@@ -36,28 +36,40 @@ struct WgradParams {
   float box_scale;
   int B, L, n_geo, n_lab, C, H;
   long long P;                 // points per image (multiple of 32)
-  int tiles_per_image, nchunk; // chunks per (job, image)
+  int tiles_per_image, nchunk; // chunks per (job, image) of this launch
+  int film_stride;             // chunk slots per (layer, image) in film_partial (>= every launch's nchunk)
   int layer0;                  // WG_SQ: first layer of the launch (blockIdx.z -> layer0 + z); other jobs: the layer
   float* partial;              // [z][b][chunk][MT*32][KT*32]
   float* film_partial;         // [L][b][chunk][H][2] or nullptr
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
 };
 
-// Stage one register-dump tile (layer `l` of `src`) into LDS rows [H][WG_LD]; optional FiLM transform to activations.
+// Stage one register-dump tile into LDS rows [H][WG_LD]; optional FiLM transform to activations.  The f' / p' rows are
+// fetched (128-bit LDS reads) for the whole tile BEFORE the first write: LDS reads cannot be moved across LDS writes by the
+// compiler, and one read-wait-write per element serialised the staging on LDS latency (measured: 35 % of the kernel).
 template <int H, bool SIN>
 __device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst, int wave, int lane, const float* f_s, const float* p_s) {
+  constexpr int NQ = H / 32;
   const int m = lane & 31, half = lane >> 5;
+  float4 f4[NQ], p4[NQ];
+  if (SIN) {
 #pragma unroll
-  for (int q = 0; q < H / 32; ++q) {
-    const int g = wave * (H / 32) + q;
-    const int row = tape_feature(g, half, 0);
-    float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = e[i];
-      if (SIN) x = sin2pi(__builtin_fmaf(f_s[row + i], x, p_s[row + i]));
-      dst[(row + i) * WG_LD + m] = x;
+    for (int q = 0; q < NQ; ++q) {
+      const int row = tape_feature(wave * NQ + q, half, 0);
+      f4[q] = *reinterpret_cast<const float4*>(f_s + row);
+      p4[q] = *reinterpret_cast<const float4*>(p_s + row);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int row = tape_feature(wave * NQ + q, half, 0);
+    float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+    if (SIN) {
+      e[0] = sin2pi(__builtin_fmaf(f4[q].x, e[0], p4[q].x)); e[1] = sin2pi(__builtin_fmaf(f4[q].y, e[1], p4[q].y));
+      e[2] = sin2pi(__builtin_fmaf(f4[q].z, e[2], p4[q].z)); e[3] = sin2pi(__builtin_fmaf(f4[q].w, e[3], p4[q].w));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[(row + i) * WG_LD + m] = e[i];
   }
 }
 
@@ -191,26 +203,38 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
         for (int q = 0; q < 8; ++q) { const float4 a = ar[q]; s0 += (a.x + a.y) + (a.z + a.w); }
       }
     }
-    // ---- MFMA: lane (i, kh) contracts points 16 kh + s, s = 0..15
+    // ---- MFMA: lane (i, kh) contracts points 16 kh + s, s = 0..15.  Operand fragments are read from LDS one
+    //      (mt, kt) group ahead of their 16 MFMAs (1024 cycles), so no LDS latency is exposed.
     {
       const int i = lane & 31, kh = lane >> 5;
+      auto frag = [&](const float* base, int tile_idx, float (&f)[16]) {
+        const float4* r = reinterpret_cast<const float4*>(base + (tile_idx * 32 + i) * WG_LD + 16 * kh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 v = r[q]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+      };
+      auto a_tile = [&](int mt) { return (wm0 + mt < S::MT) ? wm0 + mt : S::MT - 1; };   // waves beyond the tile grid recompute
+      auto b_tile = [&](int kt) { return (wk0 + kt < S::KT) ? wk0 + kt : S::KT - 1; };   // the last tile (not stored)
+      float a_cur[16], b_cur[16], a_nxt[16], b_nxt[16];
+      frag(A_s, a_tile(0), a_cur);
+      frag(B_s, b_tile(0), b_cur);
 #pragma unroll
       for (int kt = 0; kt < S::WK; ++kt) {
-        float b[16];
-        const int tc = (wk0 + kt < S::KT) ? wk0 + kt : S::KT - 1;   // waves beyond the tile grid recompute the last tile (not stored)
-        const float4* br = reinterpret_cast<const float4*>(B_s + (tc * 32 + i) * WG_LD + 16 * kh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const float4 v = br[q]; b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
 #pragma unroll
         for (int mt = 0; mt < S::WM; ++mt) {
-          float a[16];
-          const int tr = (wm0 + mt < S::MT) ? wm0 + mt : S::MT - 1;
-          const float4* ar = reinterpret_cast<const float4*>(A_s + (tr * 32 + i) * WG_LD + 16 * kh);
+          const bool last_m = mt == S::WM - 1, last = last_m && kt == S::WK - 1;
+          if (!last) frag(A_s, a_tile(last_m ? 0 : mt + 1), a_nxt);
+          if (last_m && !last) frag(B_s, b_tile(kt + 1), b_nxt);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { const float4 v = ar[q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+          for (int s = 0; s < 16; ++s) acc[mt][kt] = MFMA(a_cur[s], b_cur[s], acc[mt][kt]);
+          __builtin_amdgcn_sched_barrier(0);   // pin (next reads, 16 MFMAs): keeps the register budget at 256 accumulators + 64
+          if (!last) {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) acc[mt][kt] = MFMA(a[s], b[s], acc[mt][kt]);
-          __builtin_amdgcn_sched_barrier(0);   // keep operand reads next to their MFMAs (register budget: 256 accumulators)
+            for (int s = 0; s < 16; ++s) a_cur[s] = a_nxt[s];
+          }
+          if (last_m && !last) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) b_cur[s] = b_nxt[s];
+          }
         }
       }
     }
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
             out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
           }
     if (S::FILM && tid < H) {
-      float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.nchunk + chunk) * H + tid) * 2;
+      float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + tid) * 2;
       fpart[0] = s0; fpart[1] = s1;
     }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
       for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // over the 32 points of a half
       if ((lane & 31) == 0) {
         const int n = tape_feature(wave * NQ + q, lane >> 5, i);
-        float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.nchunk + chunk) * H + n) * 2;
+        float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + n) * 2;
         fpart[0] = a; fpart[1] = b;
       }
     }
@@ -305,8 +329,8 @@ __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const 
 }
 
 // FiLM sums: film_partial [L][B][nchunk][H][2] -> d_phase / d_freq [B][n*H] (geo | app split), d_bias[l][H] via pointers
-__global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n_geo, int nchunk, const float* fp, float* d_freq_geo,
-                                   float* d_phase_geo, float* d_freq_app, float* d_phase_app, FenerfSirenGrads g) {
+__global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n_geo, int nchunk0, int nchunk, int stride, const float* fp,
+                                   float* d_freq_geo, float* d_phase_geo, float* d_freq_app, float* d_phase_app, FenerfSirenGrads g) {
   const float TWO_PI = 6.28318530717958647692f;
   const int n_color = L - n_geo;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * H; i += gridDim.x * blockDim.x) {
@@ -314,8 +338,8 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
     float db = 0.f;
     for (int b = 0; b < B; ++b) {
       float s0 = 0.f, s1 = 0.f;
-      for (int k = 0; k < nchunk; ++k) {
-        const float* p = part + ((((size_t)l * B + b) * nchunk + k) * H + n) * 2;
+      for (int k = 0; k < (l == 0 ? nchunk0 : nchunk); ++k) {     // layer 0 comes from the (finer-chunked) thin job
+        const float* p = part + ((((size_t)l * B + b) * stride + k) * H + n) * 2;
         s0 += p[0]; s1 += p[1];
       }
       db += s0 * (fp[((size_t)b * L + l) * H + n] * TWO_PI);
@@ -371,36 +395,59 @@ void reduce_mat(float* dst, int dst_ld, int dst_col0, const float* src, int src_
 }  // namespace
 
 int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
-  // ~3 workgroups per CU over the (L-1) * B square jobs; each chunk at least a few tiles
-  long long n = (3LL * m->num_cus + (long long)(m->L - 1) * B - 1) / ((long long)(m->L - 1) * B);
-  if (n < 1) n = 1;
+  // one workgroup per CU (110 KB LDS, 512 registers): size the grid of the (L-1)*B square jobs to whole rounds of the
+  // machine -- 39 chunks gave 780 workgroups = 3.05 rounds on 256 CUs, i.e. a fourth round 5 % full.
+  const long long jobs = (long long)(m->L - 1) * B;
+  long long best = 1;
+  double best_eff = 0.0;
+  for (long long n = 1; n <= 64 && n <= tiles_per_image; ++n) {
+    const long long wgs = jobs * n;
+    const long long rounds = (wgs + m->num_cus - 1) / m->num_cus;
+    const long long t_per = (tiles_per_image + n - 1) / n;
+    // time ~ rounds * tiles per chunk (+ a fixed per-workgroup cost of ~4 tiles: prologue, partial store, reduce traffic)
+    const double eff = (double)tiles_per_image / (double)(rounds * (t_per + 4)) / (double)m->num_cus * (double)jobs;
+    if (eff > best_eff) { best_eff = eff; best = n; }
+  }
+  return (int)best;
+}
+
+// thin jobs (layer 0, colour-layer-0 extras, heads) stream the tapes with almost no MFMA work: one workgroup per CU
+int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
+  long long n = (m->num_cus + B - 1) / B;
   if (n > tiles_per_image) n = tiles_per_image;
-  if (n > 64) n = 64;
-  return (int)n;
+  if (n > 256) n = 256;
+  return (int)(n < 1 ? 1 : n);
 }
 
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
   const long long tiles = (P + 31) / 32;
-  const int nc = wgrad_nchunk(m, B, tiles);
+  const int nc = wgrad_nchunk(m, B, tiles), nt = wgrad_nchunk_thin(m, B, tiles), ncm = nc > nt ? nc : nt;
   const size_t H = m->H;
-  size_t f = (size_t)(m->L - 1) * B * nc * H * H;          // square partials (also reused by the thin jobs)
-  f += (size_t)m->L * B * nc * H * 2;                       // FiLM sums
-  f += (size_t)B * nc * 32;                                 // head row sums
+  size_t sq = (size_t)(m->L - 1) * B * nc * H * H;         // square partials
+  const size_t thin = (size_t)B * nt * H * (H > 64 ? H : 64);   // the thin jobs reuse the buffer: [B][nt][<= H x max(H, 64)]
+  if (thin > sq) sq = thin;
+  size_t f = sq;
+  f += (size_t)m->L * B * ncm * H * 2;                      // FiLM sums
+  f += (size_t)B * ncm * 32;                                // head row sums
   return f * sizeof(float) + 1024;
 }
 
 template <int H>
 static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, bool film_only, hipStream_t st) {
-  const int L = m->L, ng = m->n_geo, B = p.B, nc = p.nchunk;
+  const int L = m->L, ng = m->n_geo, B = p.B;
+  const int nc = p.nchunk, nt = wgrad_nchunk_thin(m, B, p.tiles_per_image), ncm = nc > nt ? nc : nt;
   const int G = m->grid_ch;
   float* sq = ws;
-  float* film = sq + (size_t)(L - 1) * B * nc * H * H;
-  float* rows = film + (size_t)L * B * nc * H * 2;
-  p.film_partial = film; p.rowsum_partial = rows;
+  size_t sq_floats = (size_t)(L - 1) * B * nc * H * H;
+  const size_t thin_floats = (size_t)B * nt * H * (H > 64 ? H : 64);
+  if (thin_floats > sq_floats) sq_floats = thin_floats;
+  float* film = sq + sq_floats;
+  float* rows = film + (size_t)L * B * ncm * H * 2;
+  p.film_partial = film; p.rowsum_partial = rows; p.film_stride = ncm;
   int rc;
   if (film_only) {
     hipLaunchKernelGGL(film_sums_kernel<H>, dim3(nc, B, L), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, p.fp, g.d_freq_geo,
+    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, nc, ncm, p.fp, g.d_freq_geo,
                        g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FENERF_OK : hipfail(e, "film sums launch");
@@ -414,24 +461,25 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
     else if (l == ng) reduce_mat(g.color_w[0], 3 + G + H, 3 + G, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
     else reduce_mat(g.color_w[l - ng], H, 0, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
   }
-  // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above)
+  // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above), with their own chunking
+  p.nchunk = nt;
   p.layer0 = 0;
   if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
-  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nc, p.fp, L, H, 0, st);
-  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, p.fp, g.d_freq_geo,
+  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nt, p.fp, L, H, 0, st);
+  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nt, nc, ncm, p.fp, g.d_freq_geo,
                      g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
   p.layer0 = ng;
   if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
-  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nc, p.fp, L, H, ng, st);          // view direction columns
-  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nc, p.fp, L, H, ng, st);    // grid feature columns
+  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nt, p.fp, L, H, ng, st);          // view direction columns
+  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nt, p.fp, L, H, ng, st);    // grid feature columns
   p.layer0 = ng - 1;
   if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
-  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nc, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nc, 32, g.head_b);
+  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nt, nullptr, L, H, 0, st);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 32, g.head_b);
   p.layer0 = L - 1;
   if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
-  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nc, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nc, 3, g.rgb_b);
+  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nt, nullptr, L, H, 0, st);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 3, g.rgb_b);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
 }
