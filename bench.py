@@ -127,7 +127,7 @@ def main():
             # every algorithmic product is evaluated as 3 fp16 MFMAs (wh*xh + wh*xl + wl*xh, fp32 accumulate): the attainable
             # ceiling of this algorithm on the fp16 pipe is peak/3; `frac` is quoted against the full dense fp16 peak.
             peak, dtype = PEAK_F16_MATRIX_TFLOPS, "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
-            kname, mfma = "siren16s_kernel<256,true>", "v_mfma_f32_32x32x16_f16, 3 per product"
+            kname, mfma = "siren16s_kernel<256,true,false>", "v_mfma_f32_32x32x16_f16, 3 per product"
             extra = {"frac_of_f16x3_ceiling": achieved / (peak / 3)}
         out = {
             "metric": f"rays/s/GPU forward render ({S}x{S}, {N}+{N} samples, H=256 FiLM-SIREN + 32x96^3 grid)",

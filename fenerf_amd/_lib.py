@@ -65,6 +65,7 @@ _SIGS = {
     "fenerf_model_update": (_i, [_vp, C.POINTER(FenerfModelDesc), _vp]),
     "fenerf_model_destroy": (None, [_vp]),
     "fenerf_pack_backward_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_fp), C.POINTER(_sz)]),
+    "fenerf_pack_index_map_f16": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_sz)]),
     "fenerf_model_load_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
@@ -155,9 +156,20 @@ def make_desc(sd, spec, precision="f32", differentiable=False):
     return d, keep
 
 
-def pack_backward_host(sd, spec):
+def pack_index_map_f16(sd, spec):
+    """int32 codes of the f16x3 ring stream for index-valued weights: (1 + flat index) | (is_lo << 30), 0 = padding."""
+    d, keep = make_desc(sd, spec, "f16x3")
+    m, n = C.POINTER(C.c_int32)(), _sz()
+    check(lib().fenerf_pack_index_map_f16(C.byref(d), C.byref(m), C.byref(n)))
+    try:
+        return np.ctypeslib.as_array(m, shape=(n.value,)).copy()
+    finally:
+        lib().fenerf_free_host(m)
+
+
+def pack_backward_host(sd, spec, precision="f32"):
     """numpy copy of the backward-chain stream (CPU only; layout tests and the device-side packing index map)."""
-    d, keep = make_desc(sd, spec, "f32", True)
+    d, keep = make_desc(sd, spec, precision, True)
     blob, nb = _fp(), _sz()
     check(lib().fenerf_pack_backward_host(C.byref(d), C.byref(blob), C.byref(nb)))
     try:

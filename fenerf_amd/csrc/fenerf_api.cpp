@@ -101,7 +101,6 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   m->precision = d->precision;
   m->differentiable = d->differentiable != 0;
   if (d->precision != FENERF_PREC_F32 && d->precision != FENERF_PREC_F16X3) { delete m; return fail(FENERF_E_INVALID, "unknown precision"); }
-  if (m->differentiable && d->precision != FENERF_PREC_F32) { delete m; return fail(FENERF_E_UNSUPPORTED, "differentiable models run at FENERF_PREC_F32"); }
   m->bsh = bwd_stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   m->sh = stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   int dev = 0;
@@ -131,8 +130,12 @@ extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, voi
 extern "C" int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev,
                                         size_t n_consts, const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
-  if (m->precision != FENERF_PREC_F32) return fail(FENERF_E_UNSUPPORTED, "device-side packing is defined for FENERF_PREC_F32 streams");
-  const size_t want_s = (size_t)(m->sh.l0_entries + m->sh.ring_entries) * 256, want_c = (size_t)CONST_FILM_BIAS + (size_t)m->L * m->H;
+  size_t want_s = (size_t)(m->sh.l0_entries + m->sh.ring_entries) * 256, want_c = (size_t)CONST_FILM_BIAS + (size_t)m->L * m->H;
+  if (m->precision == FENERF_PREC_F16X3) {
+    const StreamShape16 s16 = stream_shape16(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
+    want_s = (size_t)s16.l0_entries * 256 + (size_t)s16.ring_entries * 256;   // an f16 entry is 64 x 8 halves = 256 floats' worth
+    want_c = (size_t)CONST_FILM_BIAS + (size_t)2 * m->L * m->H + 36;
+  }
   const size_t want_b = (size_t)(m->bsh.ht_entries + m->bsh.ring_entries) * 256;
   if (!stream_dev || !consts_dev || n_stream != want_s || n_consts != want_c) return fail(FENERF_E_INVALID, "packed stream / consts size mismatch");
   if (m->differentiable && (!bwd_dev || n_bwd != want_b)) return fail(FENERF_E_INVALID, "backward stream size mismatch");

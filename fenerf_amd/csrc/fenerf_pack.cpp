@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -177,6 +178,12 @@ struct KStep16 { int col[2][8]; };   // source column per lane-half and slot, -1
 
 static inline uint16_t f16_bits(_Float16 v) { uint16_t b; memcpy(&b, &v, 2); return b; }
 
+// Index-map mode (fenerf_pack_index_map_f16): the desc's weights hold (1 + flat index) of themselves; instead of fp16
+// halves the packer records, per half of the stream, that index | (is_lo << 30) (0 = padding) and applies no row scales.
+// The caller then builds the stream on the device: scale rows, split hi / lo, gather.
+static std::vector<int32_t>* g_tags = nullptr;
+static std::mutex g_tags_mutex;
+
 // row_scale[row] (power of two) is applied before the hi/lo split; rows >= nrows are zero.
 static void emit_body16(std::vector<uint16_t>& out, const double* W, int nrows, int ncols, int r0,
                         const std::vector<KStep16>& ks, int padded_entries, const std::vector<double>& row_scale) {
@@ -187,15 +194,18 @@ static void emit_body16(std::vector<uint16_t>& out, const double* W, int nrows, 
       const int row = r0 + (lane & 31), h = lane >> 5;
       for (int t = 0; t < 8; ++t) {
         uint16_t bits = 0;
+        int32_t code = 0;
         if (e < real && row < nrows) {
           const int col = ks[s].col[h][t];
           if (col >= 0) {
             const float w = (float)(W[(size_t)row * ncols + col] * row_scale[row]);   // exact: power-of-two scale
             const _Float16 hi = (_Float16)w;
             bits = lo ? f16_bits((_Float16)(w - (float)hi)) : f16_bits(hi);
+            if (g_tags) code = (int32_t)w | (lo << 30);
           }
         }
         out.push_back(bits);
+        if (g_tags) g_tags->push_back(code);
       }
     }
   }
@@ -204,6 +214,7 @@ static void emit_body16(std::vector<uint16_t>& out, const double* W, int nrows, 
 // power of two s with max|row| * s in [0.5, 1)  (1 for an all-zero row)
 static std::vector<double> row_scales(const double* W, int nrows, int ncols) {
   std::vector<double> sc(nrows, 1.0);
+  if (g_tags) return sc;   // index-map mode: tags must pass through unscaled
   for (int r = 0; r < nrows; ++r) {
     double m = 0;
     for (int c = 0; c < ncols; ++c) m = std::fmax(m, std::fabs((double)(float)W[(size_t)r * ncols + c]));
@@ -240,6 +251,7 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
   auto pad_stage_to = [&](size_t stage_begin_halves, int stage_entries) {   // zero entries up to the padded stage size
     const size_t want = stage_begin_halves + (size_t)stage_entries * 512;
     if (ring.size() < want) ring.insert(ring.end(), want - ring.size(), 0);
+    if (g_tags) g_tags->resize(ring.size(), 0);
   };
   for (int l = 1; l < d->n_geo; ++l) {
     const size_t begin = ring.size();
@@ -298,6 +310,7 @@ int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::ve
   if (ring.size() != (size_t)sh.tile_entries * 512) { err = "internal: f16 stream size mismatch"; return FENERF_E_INVALID; }
   // replicated head: the prefetch of the next tile's first chunks reads past the end instead of wrapping
   ring.insert(ring.end(), ring.begin(), ring.begin() + (size_t)FENERF_DPF * FENERF_CH * 512);
+  if (g_tags) g_tags->insert(g_tags->end(), g_tags->begin(), g_tags->begin() + (size_t)FENERF_DPF * FENERF_CH * 512);
   blob = l0;
   const size_t off = blob.size();
   blob.resize(off + ring.size() / 2);
@@ -331,10 +344,23 @@ int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::st
     for (int s = 0; s < H / 2; ++s) ks[s] = {col_off + feat_of(s, 0), col_off + feat_of(s, 1)};
     return ks;
   };
-  auto transposed = [&](const float* W, int rows, int cols, int col0, int ncol) {   // -> [ncol][rows] = W[:, col0:col0+ncol]^T
-    std::vector<double> T((size_t)ncol * rows);
+  // FENERF_PREC_F16X3: the forward evaluates layer l with rows scaled by s_i = 2^e_i * 16 (activations x16, weights 2^e_i),
+  // the FiLM frequencies f'' absorb 1/s_i, and the chain kernel forms dz' = dtheta * 2 pi f'' = dz / s_i.  Scaling row i of
+  // the backward weights by the same (exact, power-of-two) s_i makes W'^T dz' = W^T dz with the kernel unchanged.
+  const bool scaled = d->precision == FENERF_PREC_F16X3;
+  auto film_row_scale = [&](const float* W, int rows, int cols) {
+    std::vector<double> sc(rows, 1.0);
+    if (scaled) {
+      auto W64 = to_f64(W, (size_t)rows * cols);
+      sc = row_scales(W64.data(), rows, cols);
+      for (auto& v : sc) v *= (double)F16_ACT_SCALE;
+    }
+    return sc;
+  };
+  auto transposed = [&](const float* W, int rows, int cols, int col0, int ncol, const std::vector<double>* sc = nullptr) {
+    std::vector<double> T((size_t)ncol * rows);   // -> [ncol][rows] = (diag(sc) W)[:, col0:col0+ncol]^T
     for (int r = 0; r < rows; ++r)
-      for (int c = 0; c < ncol; ++c) T[(size_t)c * rows + r] = W[(size_t)r * cols + col0 + c];
+      for (int c = 0; c < ncol; ++c) T[(size_t)c * rows + r] = (double)W[(size_t)r * cols + col0 + c] * (sc ? (*sc)[r] : 1.0);
     return T;
   };
   {  // rgb head^T: [H][3], k-steps (d_r | d_g), (d_b | 0)
@@ -343,7 +369,8 @@ int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::st
     for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, 3, nb * 32, ks, 1);
   }
   for (int l = d->n_color - 1; l >= 1; --l) {
-    auto T = transposed(d->color_w[l], H, H, 0, H);
+    const auto sc = film_row_scale(d->color_w[l], H, H);
+    auto T = transposed(d->color_w[l], H, H, 0, H, &sc);
     auto ks = x_ksteps(0);
     for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, H, nb * 32, ks, sh.KGXP);
   }
@@ -351,21 +378,23 @@ int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::st
     const int cin = 3 + d->grid_ch + H;
     std::vector<double> Wh, hb;
     fold_head(d, Wh, hb);
+    const auto sc0 = film_row_scale(d->color_w[0], H, cin);
     std::vector<double> M((size_t)H * (H + 32), 0.0);   // row j: [W_c0[:, x_j] (H) | head[:, j] (32)]
     for (int j = 0; j < H; ++j) {
-      for (int i = 0; i < H; ++i) M[(size_t)j * (H + 32) + i] = d->color_w[0][(size_t)i * cin + 3 + d->grid_ch + j];
+      for (int i = 0; i < H; ++i) M[(size_t)j * (H + 32) + i] = (double)d->color_w[0][(size_t)i * cin + 3 + d->grid_ch + j] * sc0[i];
       for (int r = 0; r < 32; ++r) M[(size_t)j * (H + 32) + H + r] = Wh[(size_t)r * H + j];
     }
     auto ks = x_ksteps(0);
     for (int s = 0; s < FENERF_HEAD_KSTEPS; ++s) ks.push_back({H + s, H + 16 + s});
     for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, M.data(), H, H + 32, nb * 32, ks, sh.c0_kgp);
     if (grid) {
-      auto T = transposed(d->color_w[0], H, cin, 3, 32);   // [32][H]
+      auto T = transposed(d->color_w[0], H, cin, 3, 32, &sc0);   // [32][H]
       emit_body(blob, T.data(), 32, H, 0, x_ksteps(0), sh.KGXP);
     }
   }
   for (int l = d->n_geo - 1; l >= 1; --l) {
-    auto T = transposed(d->geo_w[l], H, H, 0, H);
+    const auto sc = film_row_scale(d->geo_w[l], H, H);
+    auto T = transposed(d->geo_w[l], H, H, 0, H, &sc);
     auto ks = x_ksteps(0);
     for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, H, nb * 32, ks, sh.KGXP);
   }
@@ -391,6 +420,23 @@ extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blo
   memcpy(*consts, c.data(), c.size() * sizeof(float));
   *n_floats = b.size();
   *n_consts = c.size();
+  return FENERF_OK;
+}
+
+extern "C" int fenerf_pack_index_map_f16(const FenerfModelDesc* desc, int32_t** map, size_t* n) {
+  if (!map || !n) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
+  std::lock_guard<std::mutex> lock(fenerf::g_tags_mutex);
+  std::vector<int32_t> tags;
+  std::vector<float> b, c;
+  std::string err;
+  fenerf::g_tags = &tags;
+  int rc = fenerf::pack_weights_f16(desc, b, c, err);
+  fenerf::g_tags = nullptr;
+  if (rc) { fenerf::set_error(err); return rc; }
+  *map = (int32_t*)malloc(tags.size() * sizeof(int32_t));
+  if (!*map) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  memcpy(*map, tags.data(), tags.size() * sizeof(int32_t));
+  *n = tags.size();
   return FENERF_OK;
 }
 

@@ -339,10 +339,7 @@ static int launch_siren_h(const FenerfModel* m, const SirenParams& p, void* stre
 
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
-  if (m->precision == FENERF_PREC_F16X3) {
-    if (p.tape) { set_error("the differentiable path runs on the fp32 model (precision FENERF_PREC_F32)"); return FENERF_E_UNSUPPORTED; }
-    return launch_siren16s(m, p, stream);
-  }
+  if (m->precision == FENERF_PREC_F16X3) return launch_siren16s(m, p, stream);
   switch (m->H) {
     case 32: return launch_siren_h<32>(m, p, stream);
     case 64: return launch_siren_h<64>(m, p, stream);

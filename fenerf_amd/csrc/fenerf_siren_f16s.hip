@@ -174,6 +174,13 @@ struct EpiQ {
   float r[4];
   half4 hi;
 };
+// Differentiable mode: keep the quarter's raw accumulators (register dump, fenerf_layout.h "Tape"; here in the scaled
+// units of the f16x3 GEMM, which the FiLM frequencies f'' already absorb).  tp = tape4 + (tile*L + layer)*(H/8)*64 + lane,
+// or nullptr.  One fire-and-forget 1-KiB wave store; stores only make the counted vmcnt waits stricter, never wrong
+// (loads retire in order among themselves).
+__device__ __forceinline__ void tape_q(const f32x16& acc, int nbp, int q, float4* tp) {
+  if (tp) tp[(nbp * 4 + q) * 64] = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+}
 __device__ __forceinline__ void epi_load(EpiQ& e, int nbp, int q, const float* film_f, const float* film_p) {
   e.f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);   // + 4*h folded into the pointer
   e.p = *reinterpret_cast<const float4*>(film_p + 32 * nbp + 8 * q);
@@ -211,7 +218,8 @@ __device__ __forceinline__ void epi_p3(EpiQ& e, int nbp, int q, half8 (&yh)[KS],
 // whole quarter at once (layer tails, layer 0, small-H bodies)
 template <int KS, int NBL>
 __device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab) {
+                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab, float4* tp = nullptr) {
+  tape_q(acc, nbp, q, tp);
   EpiQ e;
   epi_load(e, nbp, q, film_f, film_p);
   epi_p0(e, acc, q);
@@ -222,8 +230,8 @@ __device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, con
 // layer 0 writes straight into x (nothing is reading it yet)
 template <int KS>
 __device__ __forceinline__ void epi_quarter(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                            half8 (&yh)[KS], half8 (&yl)[KS]) {
-  epi_route<KS, 0>(acc, nbp, q, film_f, film_p, yh, yl, nullptr);
+                                            half8 (&yh)[KS], half8 (&yl)[KS], float4* tp) {
+  epi_route<KS, 0>(acc, nbp, q, film_f, film_p, yh, yl, nullptr, tp);
 }
 
 // 3 MFMAs of one k-step: wl*xh + wh*xl + wh*xh
@@ -287,7 +295,7 @@ __device__ __forceinline__ void collect_act(half8 (&xh)[KS], half8 (&xl)[KS], co
 // A square FiLM layer H -> H.  x: input activations (B operands); outputs replace x at the end.
 template <int H>
 __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[H / 16], WStream& ws, AK2& a_cur,
-                                               const float* film_f, const float* film_p, char* slab) {
+                                               const float* film_f, const float* film_p, char* slab, float4* tp) {
   constexpr int NB = H / 32, KS = H / 16, NBL = NB / 2;
   constexpr int QB = (2 * KS + CH - 1) / CH;          // chunks per n-block body (4 at H=256)
   constexpr int STAGE_CHUNKS = pad_stage(NB * QB * CH) / CH;
@@ -306,7 +314,7 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
       // FiLM epilogue of the previous n-block, one quarter per chunk step (QB == 4), piece-wise behind the k-steps
       EpiQ eq;
       const bool fine = nb > 0 && EQ == 1;
-      if (fine) epi_load(eq, nb - 1, qc, film_f, film_p);
+      if (fine) { tape_q(acc_prev, nb - 1, qc, tp); epi_load(eq, nb - 1, qc, film_f, film_p); }
       chunk_step(acc, a_cur, ws, nb * QB + qc, 4 * qc, bop, [&](int j) {
         if (fine) {
           if (j == 0) epi_p0(eq, acc_prev, qc);
@@ -314,7 +322,7 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
           else if (j == 2) epi_p2(eq);
           else epi_p3<KS, NBL>(eq, nb - 1, qc, yh, yl, slab);
         } else if (nb > 0 && j < EQ) {
-          epi_route<KS, NBL>(acc_prev, nb - 1, qc * EQ + j, film_f, film_p, yh, yl, slab);
+          epi_route<KS, NBL>(acc_prev, nb - 1, qc * EQ + j, film_f, film_p, yh, yl, slab, tp);
         }
       });
     }
@@ -323,7 +331,7 @@ __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[
 #pragma unroll
   for (int i = NB * QB; i < STAGE_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, film_f, film_p, yh, yl, slab);
+  for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, film_f, film_p, yh, yl, slab, tp);
   collect_act<KS, NBL>(xh, xl, yh, yl, slab);
 }
 
@@ -346,7 +354,7 @@ __device__ __forceinline__ void head_body_s(f32x16& acc, const half8 (&xh)[H / 1
   for (int i = QB; i < STAGE_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 16;
   constexpr int C0_KS = KS + (GRID ? 2 : 0) + 1;
@@ -465,6 +473,13 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
         }
       }
     }
+    const bool real_tile = tile * 32 < P.P;      // quads are padded with phantom tiles (clamped points)
+    float4* tp0 = (SAVE && real_tile) ? reinterpret_cast<float4*>(P.tape) + tile * L * (long long)((H / 8) * 64) + lane : nullptr;
+    if (SAVE && GRID && real_tile && tile * 32 + m < P.P) {
+      float4* ep = reinterpret_cast<float4*>(P.tape_e + (tile * 32 + m) * 32 + 16 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ep[q] = make_float4(e[4 * q + 0], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+    }
     WAIT_VMCNT(0);      // film 0/1 landed (own buffer, own reads: no barrier needed); once per tile
     LDS_FENCE();
 
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
         acc = MFMA32(w.x, b0, acc);
         acc = MFMA32(w.y, b1, acc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) epi_quarter<KS>(acc, nb, q, film_f0, film_p0, xh, xl);
+        for (int q = 0; q < 4; ++q) epi_quarter<KS>(acc, nb, q, film_f0, film_p0, xh, xl, tp0);
       }
     }
     WAIT_VMCNT(0);      // l0w loads are ordinary loads: keep the compiler's own vmcnt bookkeeping out of the main loop
@@ -493,6 +508,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
     for (int l = 1; l < n_geo + n_color; ++l) {
       const float* ff = (l & 1) ? film_f1 : film_f0;
       const float* fq = (l & 1) ? film_p1 : film_p0;
+      float4* tpl = (SAVE && tp0) ? tp0 + (long long)l * ((H / 8) * 64) : nullptr;
       if (l == n_geo) {
         // ---------------- colour layer 0: [x | grid feats | dir] -> H, then the label/sigma head on the same x -------
         half8 eh[2], el[2], dh, dl;
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
           for (int qc = 0; qc < C0_QB; ++qc) {
             EpiQ eq;
             const bool fine = nb > 0 && qc < 4;
-            if (fine) epi_load(eq, nb - 1, qc, ff, fq);
+            if (fine) { tape_q(acc_prev, nb - 1, qc, tpl); epi_load(eq, nb - 1, qc, ff, fq); }
             chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 4 * qc, bop0, [&](int j) {
               if (fine) {
                 if (j == 0) epi_p0(eq, acc_prev, qc);
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
             });
             if (nb > 0 && C0_QB < 4 && qc == C0_QB - 1) {
 #pragma unroll
-              for (int q = C0_QB; q < 4; ++q) epi_route<KS, NBL>(acc_prev, nb - 1, q, ff, fq, yh, yl, slab);
+              for (int q = C0_QB; q < 4; ++q) epi_route<KS, NBL>(acc_prev, nb - 1, q, ff, fq, yh, yl, slab, tpl);
             }
           }
           acc_prev = acc;
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
 #pragma unroll
         for (int i = NB * C0_QB; i < pad_stage(NB * C0_QB * CH) / CH; ++i) chunk_skip(a_cur, ws, i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, ff, fq, yh, yl, slab);
+        for (int q = 0; q < 4; ++q) epi_route<KS, NBL>(acc_prev, NB - 1, q, ff, fq, yh, yl, slab, tpl);
         // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
         {
           f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
       } else {
         if (l + 1 < L) film_issue(l + 1);
         if (SQ_CHUNKS < DPF) WAIT_VMCNT(0);
-        square_layer_s<H>(xh, xl, ws, a_cur, ff, fq, slab);
+        square_layer_s<H>(xh, xl, ws, a_cur, ff, fq, slab, tpl);
       }
     }
     // ---------------- rgb head + sigmoid ----------------
@@ -608,14 +624,14 @@ static int hip_fail16s(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const int stage_f4 = (32 * m->C + 3) / 4;
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)4 * 2 * (2 * film_f) + (size_t)4 * stage_f4 * 16 +
                      (size_t)4 * (H / 64) * 4 * 1024;   // ring + FiLM buffers + output staging + activation slabs
   static size_t configured = 0;
-  auto kfn = siren16s_kernel<H, GRID>;
+  auto kfn = siren16s_kernel<H, GRID, SAVE>;
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_fail16s(e, "hipFuncSetAttribute(max dynamic LDS)");
@@ -636,11 +652,16 @@ int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
   const bool g = m->grid_ch != 0;
   auto one = [&](const SirenParams& q) -> int {
+    const bool sv = q.tape != nullptr;
     switch (m->H) {
-      case 32: return g ? launch_siren16s_t<32, true>(m, q, stream) : launch_siren16s_t<32, false>(m, q, stream);
-      case 64: return g ? launch_siren16s_t<64, true>(m, q, stream) : launch_siren16s_t<64, false>(m, q, stream);
-      case 128: return g ? launch_siren16s_t<128, true>(m, q, stream) : launch_siren16s_t<128, false>(m, q, stream);
-      case 256: return g ? launch_siren16s_t<256, true>(m, q, stream) : launch_siren16s_t<256, false>(m, q, stream);
+      case 32: return sv ? (g ? launch_siren16s_t<32, true, true>(m, q, stream) : launch_siren16s_t<32, false, true>(m, q, stream))
+                         : (g ? launch_siren16s_t<32, true, false>(m, q, stream) : launch_siren16s_t<32, false, false>(m, q, stream));
+      case 64: return sv ? (g ? launch_siren16s_t<64, true, true>(m, q, stream) : launch_siren16s_t<64, false, true>(m, q, stream))
+                         : (g ? launch_siren16s_t<64, true, false>(m, q, stream) : launch_siren16s_t<64, false, false>(m, q, stream));
+      case 128: return sv ? (g ? launch_siren16s_t<128, true, true>(m, q, stream) : launch_siren16s_t<128, false, true>(m, q, stream))
+                          : (g ? launch_siren16s_t<128, true, false>(m, q, stream) : launch_siren16s_t<128, false, false>(m, q, stream));
+      case 256: return sv ? (g ? launch_siren16s_t<256, true, true>(m, q, stream) : launch_siren16s_t<256, false, true>(m, q, stream))
+                          : (g ? launch_siren16s_t<256, true, false>(m, q, stream) : launch_siren16s_t<256, false, false>(m, q, stream));
     }
     set_error("unsupported hidden_dim");
     return FENERF_E_UNSUPPORTED;

@@ -33,6 +33,7 @@ enum WgJob { WG_SQ = 0, WG_L0 = 1, WG_C0X = 2, WG_HEAD = 3, WG_RGB = 4 };
 struct WgradParams {
   const float* tape; const float* d_t; const float* tape_e; const float* points; const float* dirs;
   const float* out; const float* d_out; const float* fp; const float* pp; const float* bias;
+  const float* inv;            // f16x3 models: [L][H] result scale of the layer's GEMM (tape * inv = W x); nullptr = 1
   float box_scale;
   int B, L, n_geo, n_lab, C, H;
   long long P;                 // points per image (multiple of 32)
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   float* f_s = C_s + (S::FILM ? H * WG_LD : 0);             // f', p' of the B-side layer; bias of layer l
   float* p_s = f_s + H;
   float* b_s = p_s + H;
+  float* i_s = b_s + H;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   const int L = P.L, C = P.C;
 
   if (S::B_DUMP) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
-  if (S::FILM) for (int i = tid; i < H; i += 256) b_s[i] = P.bias[(size_t)l * H + i];
+  if (S::FILM) for (int i = tid; i < H; i += 256) { b_s[i] = P.bias[(size_t)l * H + i]; i_s[i] = P.inv ? P.inv[(size_t)l * H + i] : 1.f; }
   if (!S::A_DUMP) for (int i = tid; i < S::A_ROWS * WG_LD; i += 256) A_s[i] = 0.f;     // padded rows stay zero
   if (!S::B_DUMP) for (int i = tid; i < S::B_ROWS * WG_LD; i += 256) B_s[i] = 0.f;
   __syncthreads();
@@ -188,12 +190,12 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
       if (tid < H) {
         const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
         const float4* cr = reinterpret_cast<const float4*>(C_s + tid * WG_LD);
-        const float bb = b_s[tid];
+        const float bb = b_s[tid], iv = i_s[tid];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float4 a = ar[q], c = cr[q];
           s0 += (a.x + a.y) + (a.z + a.w);
-          s1 += (a.x * (c.x + bb) + a.y * (c.y + bb)) + (a.z * (c.z + bb) + a.w * (c.w + bb));
+          s1 += (a.x * __builtin_fmaf(c.x, iv, bb) + a.y * __builtin_fmaf(c.y, iv, bb)) + (a.z * __builtin_fmaf(c.z, iv, bb) + a.w * __builtin_fmaf(c.w, iv, bb));
         }
       }
     } else if (JOB == WG_HEAD || JOB == WG_RGB) {
@@ -278,13 +280,14 @@ __global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
   const long long tl = (long long)(H / 8) * 64;
   const float4* tape4 = reinterpret_cast<const float4*>(P.tape);
   const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
-  float s0[NQ][4], s1[NQ][4], bb[NQ][4];
+  float s0[NQ][4], s1[NQ][4], bb[NQ][4], iv[NQ][4];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       s0[q][i] = 0.f; s1[q][i] = 0.f;
       bb[q][i] = P.bias[(size_t)l * H + tape_feature(wave * NQ + q, lane >> 5, i)];
+      iv[q][i] = P.inv ? P.inv[(size_t)l * H + tape_feature(wave * NQ + q, lane >> 5, i)] : 1.f;
     }
   for (int t = t0; t < t1; ++t) {
     const long long base = ((tile_base + t) * L + l) * tl;
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
     for (int q = 0; q < NQ; ++q) {
       const float4 d = dt4[base + (wave * NQ + q) * 64 + lane], z = tape4[base + (wave * NQ + q) * 64 + lane];
       s0[q][0] += d.x; s0[q][1] += d.y; s0[q][2] += d.z; s0[q][3] += d.w;
-      s1[q][0] += d.x * (z.x + bb[q][0]); s1[q][1] += d.y * (z.y + bb[q][1]);
-      s1[q][2] += d.z * (z.z + bb[q][2]); s1[q][3] += d.w * (z.w + bb[q][3]);
+      s1[q][0] += d.x * __builtin_fmaf(z.x, iv[q][0], bb[q][0]); s1[q][1] += d.y * __builtin_fmaf(z.y, iv[q][1], bb[q][1]);
+      s1[q][2] += d.z * __builtin_fmaf(z.z, iv[q][2], bb[q][2]); s1[q][3] += d.w * __builtin_fmaf(z.w, iv[q][3], bb[q][3]);
     }
   }
 #pragma unroll
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
 
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
 __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
-                                    int rows, int cols, int B, int nchunk, const float* fp, int L, int H, int layer) {
+                                    int rows, int cols, int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer) {
   const float TWO_PI = 6.28318530717958647692f;
   const int total = rows * cols;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -322,7 +325,7 @@ __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const 
     for (int b = 0; b < B; ++b) {
       float s = 0.f;
       for (int k = 0; k < nchunk; ++k) s += src[(((size_t)b * nchunk + k) * src_rows + r) * src_ld + src_col0 + c];
-      sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI) : s;
+      sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI / (inv ? inv[(size_t)layer * H + r] : 1.f)) : s;
     }
     dst[(size_t)r * dst_ld + dst_col0 + c] = sum;
   }
@@ -330,7 +333,7 @@ __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const 
 
 // FiLM sums: film_partial [L][B][nchunk][H][2] -> d_phase / d_freq [B][n*H] (geo | app split), d_bias[l][H] via pointers
 __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n_geo, int nchunk0, int nchunk, int stride, const float* fp,
-                                   float* d_freq_geo, float* d_phase_geo, float* d_freq_app, float* d_phase_app, FenerfSirenGrads g) {
+                                   const float* inv, float* d_freq_geo, float* d_phase_geo, float* d_freq_app, float* d_phase_app, FenerfSirenGrads g) {
   const float TWO_PI = 6.28318530717958647692f;
   const int n_color = L - n_geo;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * H; i += gridDim.x * blockDim.x) {
@@ -342,7 +345,7 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
         const float* p = part + ((((size_t)l * B + b) * stride + k) * H + n) * 2;
         s0 += p[0]; s1 += p[1];
       }
-      db += s0 * (fp[((size_t)b * L + l) * H + n] * TWO_PI);
+      db += s0 * (fp[((size_t)b * L + l) * H + n] * TWO_PI / (inv ? inv[(size_t)l * H + n] : 1.f));
       if (l < n_geo) { d_phase_geo[((size_t)b * n_geo + l) * H + n] = s0; d_freq_geo[((size_t)b * n_geo + l) * H + n] = 15.f * s1; }
       else { d_phase_app[((size_t)b * n_color + (l - n_geo)) * H + n] = s0; d_freq_app[((size_t)b * n_color + (l - n_geo)) * H + n] = 15.f * s1; }
     }
@@ -368,7 +371,7 @@ int hipfail(hipError_t e, const char* what) {
 template <int H, int JOB>
 size_t wg_lds_bytes() {
   using S = WgShape<H, JOB>;
-  return (size_t)((S::A_ROWS + S::B_ROWS + (S::FILM ? H : 0)) * WG_LD + 3 * H) * sizeof(float);
+  return (size_t)((S::A_ROWS + S::B_ROWS + (S::FILM ? H : 0)) * WG_LD + 4 * H) * sizeof(float);
 }
 
 template <int H, int JOB>
@@ -387,10 +390,10 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
 }
 
 void reduce_mat(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rows, int cols,
-                int B, int nchunk, const float* fp, int L, int H, int layer, hipStream_t st) {
+                int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer, hipStream_t st) {
   const int total = rows * cols;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dst, dst_ld, dst_col0, src, src_rows, src_ld,
-                     src_col0, rows, cols, B, nchunk, fp, L, H, layer);
+                     src_col0, rows, cols, B, nchunk, fp, inv, L, H, layer);
 }
 }  // namespace
 
@@ -447,7 +450,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   int rc;
   if (film_only) {
     hipLaunchKernelGGL(film_sums_kernel<H>, dim3(nc, B, L), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, nc, ncm, p.fp, g.d_freq_geo,
+    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, nc, ncm, p.fp, p.inv, g.d_freq_geo,
                        g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FENERF_OK : hipfail(e, "film sums launch");
@@ -457,28 +460,28 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   if ((rc = launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
   for (int l = 1; l < L; ++l) {
     const float* src = sq + (size_t)(l - 1) * B * nc * H * H;
-    if (l < ng) reduce_mat(g.geo_w[l], H, 0, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
-    else if (l == ng) reduce_mat(g.color_w[0], 3 + G + H, 3 + G, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
-    else reduce_mat(g.color_w[l - ng], H, 0, src, H, H, 0, H, H, B, nc, p.fp, L, H, l, st);
+    if (l < ng) reduce_mat(g.geo_w[l], H, 0, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
+    else if (l == ng) reduce_mat(g.color_w[0], 3 + G + H, 3 + G, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
+    else reduce_mat(g.color_w[l - ng], H, 0, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
   }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above), with their own chunking
   p.nchunk = nt;
   p.layer0 = 0;
   if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
-  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nt, p.fp, L, H, 0, st);
-  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nt, nc, ncm, p.fp, g.d_freq_geo,
+  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nt, p.fp, p.inv, L, H, 0, st);
+  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nt, nc, ncm, p.fp, p.inv, g.d_freq_geo,
                      g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
   p.layer0 = ng;
   if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
-  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nt, p.fp, L, H, ng, st);          // view direction columns
-  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nt, p.fp, L, H, ng, st);    // grid feature columns
+  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nt, p.fp, p.inv, L, H, ng, st);          // view direction columns
+  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nt, p.fp, p.inv, L, H, ng, st);    // grid feature columns
   p.layer0 = ng - 1;
   if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
-  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nt, nullptr, L, H, 0, st);
+  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nt, nullptr, nullptr, L, H, 0, st);
   hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 32, g.head_b);
   p.layer0 = L - 1;
   if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
-  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nt, nullptr, L, H, 0, st);
+  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nt, nullptr, nullptr, L, H, 0, st);
   hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 3, g.rgb_b);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
@@ -491,6 +494,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   memset(&p, 0, sizeof(p));
   p.tape = tape; p.d_t = d_t; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
   p.fp = fp; p.pp = pp; p.bias = m->d_consts + CONST_FILM_BIAS;
+  p.inv = m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr;
   p.box_scale = m->box_scale;
   p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
   p.P = P; p.tiles_per_image = (int)(P / 32);

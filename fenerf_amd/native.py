@@ -65,7 +65,7 @@ class NativeModel:
 
     def _index_maps(self):
         """Packs index-valued weights once on the host: every stream element is then (1 + flat index) of its source
-        parameter element, 0 for padding -- exact in fp32 below 2^24 elements."""
+        parameter element, 0 for padding -- exact in fp32 below 2^24 elements.  -> dict of device index tensors."""
         if getattr(self, "_maps", None) is None:
             items = self._canonical()
             total = sum(int(np.prod(sh)) for _, sh in items)
@@ -79,36 +79,79 @@ class NativeModel:
             spec1 = dict(self.spec, n_label_layers=1 if self.spec["output_dim"] > 4 else 0)
             if self.spec["grid_ch"]:
                 tag["spatial_embeddings"] = np.zeros((1, 32, 2, 2, 2), np.float32)
-            blob, consts = _lib.pack_weights_host(tag, spec1, "f32")
-            bwd = _lib.pack_backward_host(tag, spec1) if self.differentiable else None
             to_idx = lambda a: torch.from_numpy(a.astype(np.int64)).to(self.device)
-            self._maps = (to_idx(blob), to_idx(consts), to_idx(bwd) if bwd is not None else None)
+            blob, consts = _lib.pack_weights_host(tag, spec1, "f32")
+            maps = dict(stream=to_idx(blob), consts=to_idx(consts))
+            if self.differentiable:
+                maps["bwd"] = to_idx(_lib.pack_backward_host(tag, spec1))
+            if self.precision == "f16x3":
+                codes = _lib.pack_index_map_f16(tag, spec1).astype(np.int64)
+                maps["l0"] = maps["stream"][: (self.spec["hidden_dim"] // 32) * 256]      # fp32 layer-0 block, as in the f32 stream
+                maps["h_idx"], maps["h_lo"] = to_idx(codes & 0x3FFFFFFF), to_idx(codes >> 30).bool()
+            self._maps = maps
         return self._maps
 
+    @staticmethod
+    def _row_scale(W):
+        """Power of two s with max|row| * s in [0.5, 1) (1 for an all-zero row) -- row_scales() of fenerf_pack.cpp."""
+        m = W.abs().amax(1)
+        _, ex = torch.frexp(m)
+        return torch.where(m > 0, torch.ldexp(torch.ones_like(m), -ex), torch.ones_like(m))
+
     def load_from_device(self, params):
-        """Re-pack from device-resident parameters {reference name: tensor} without touching the host (fp32 models)."""
-        if self.precision != "f32":
-            raise RuntimeError("device-side packing is defined for the fp32 streams")
-        m_s, m_c, m_b = self._index_maps()
+        """Re-pack from device-resident parameters {reference name: tensor} without touching the host."""
+        stream, consts, bwd, grid = self._pack_on_device(params)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_model_load_packed(self._h, _ptr(stream), stream.numel(), _ptr(consts), consts.numel(), _ptr(bwd),
+                                                           bwd.numel() if bwd is not None else 0, _ptr(grid), _stream()))
+
+    def _pack_on_device(self, params):
+        """(stream, consts, backward stream or None, grid or None) as torch tensors on self.device: gathers through the index
+        maps (f16x3: after scaling rows and splitting into fp16 hi / lo).  Pure torch -- also runs on the CPU (layout tests)."""
+        maps = self._index_maps()
         sp = self.spec
-        n_lab = sp["output_dim"] - 4
-        p = {k: v.detach().to(self.device, torch.float32) for k, v in params.items()}
+        H, ng, nc, n_lab = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["output_dim"] - 4
+        dev = self.device
+        p = {k: v.detach().to(dev, torch.float32) for k, v in params.items()}
         if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
             A, c = p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"]
             for i in range(1, sp["n_label_layers"]):
                 W, b = p[f"label_layer_linear.{i}.weight"], p[f"label_layer_linear.{i}.bias"]
                 c = W @ c + b
                 A = W @ A
-            p = dict(p)
             p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
-        flat = torch.cat([torch.zeros(1, device=self.device)] + [p[name].reshape(-1) for name, _ in self._canonical()])
-        s_, c_ = flat[m_s], flat[m_c]
-        b_ = flat[m_b] if m_b is not None else None
+        items = self._canonical()
+        zero = torch.zeros(1, device=dev)
+        flat = torch.cat([zero] + [p[name].reshape(-1) for name, _ in items])
+        bwd = None
+        if self.precision == "f32":
+            stream, consts = flat[maps["stream"]], flat[maps["consts"]]
+            if self.differentiable:
+                bwd = flat[maps["bwd"]]
+        else:
+            cname = (lambda i: "color_layer_sine.layer") if sp["kind"] == "spatial" else (lambda i: f"color_layer_sine.{i}.layer")
+            film_w = [f"network.{i}.layer.weight" for i in range(1, ng)] + [cname(i) + ".weight" for i in range(nc)]
+            head_w = (["label_layer_linear.0.weight"] if n_lab > 0 else []) + ["final_layer.weight", "color_layer_linear.0.weight"]
+            sc = {k: self._row_scale(p[k]) for k in film_w + head_w}
+            scaled = lambda name, extra=1.0: (p[name] * (sc[name] * extra)[:, None]) if name in sc else p[name]
+            flat_s = torch.cat([zero] + [scaled(name).reshape(-1) for name, _ in items])
+            hi = flat_s.to(torch.float16)
+            lo = (flat_s - hi.float()).to(torch.float16)
+            halves = torch.where(maps["h_lo"], lo[maps["h_idx"]], hi[maps["h_idx"]])
+            stream = torch.cat([flat[maps["l0"]], halves.view(torch.float32)])
+            inv = [torch.ones(H, device=dev)] + [1.0 / (sc[k] * 16.0) for k in film_w]                       # [L][H], layer 0 unscaled
+            head_inv = torch.full((32,), 1.0 / 16.0, device=dev)
+            if n_lab > 0:
+                head_inv[:n_lab] = 1.0 / (sc["label_layer_linear.0.weight"] * 16.0)
+            head_inv[n_lab] = 1.0 / (sc["final_layer.weight"][0] * 16.0)
+            rgb_inv = torch.cat([1.0 / (sc["color_layer_linear.0.weight"] * 16.0), torch.ones(1, device=dev)])
+            consts = torch.cat([flat[maps["consts"]]] + inv + [head_inv, rgb_inv])
+            if self.differentiable:     # backward stream: FiLM-layer rows scaled like the forward's (x 16), heads true
+                flat_b = torch.cat([zero] + [(scaled(name, 16.0) if name in film_w else p[name]).reshape(-1) for name, _ in items])
+                bwd = flat_b[maps["bwd"]]
         grid = p.get("spatial_embeddings")
         grid = grid.contiguous() if grid is not None else None
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().fenerf_model_load_packed(self._h, _ptr(s_), s_.numel(), _ptr(c_), c_.numel(), _ptr(b_),
-                                                           b_.numel() if b_ is not None else 0, _ptr(grid), _stream()))
+        return stream.contiguous(), consts.contiguous(), bwd, grid
 
     def close(self):
         if getattr(self, "_h", None):

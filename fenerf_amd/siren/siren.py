@@ -113,18 +113,22 @@ class _NativeSiren(nn.Module):
             nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision)
             self.__dict__["_native_model"] = nat
         elif self.__dict__.get("_native_version") != ver:
-            nat.update(self._state_numpy())
+            if params[0].is_cuda:      # weights already live on the GPU (training): re-pack there, not through the host
+                nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n})
+            else:
+                nat.update(self._state_numpy())
         self.__dict__["_native_version"] = ver
         return nat
 
     def native_differentiable(self, device=None):
-        """The fp32 FenerfModel with the backward-chain stream resident (generator step / inversion); re-packed lazily."""
+        """The FenerfModel (same precision as the no-grad path) with the backward-chain stream resident (generator step /
+        inversion); re-packed lazily, on the device."""
         params = self._render_params()
         device = torch.device(device if device is not None else params[0].device)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_diff")
-        if nat is None or nat.device != device:
-            nat = native.NativeModel(self._state_numpy(), self._spec(), device, "f32", differentiable=True)
+        if nat is None or nat.device != device or nat.precision != self.precision:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision, differentiable=True)
             self.__dict__["_native_diff"] = nat
         elif self.__dict__.get("_native_diff_version") != ver:
             # weights live on the GPU during training: re-pack there (a gather), never through the host

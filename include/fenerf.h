@@ -111,11 +111,16 @@ void fenerf_model_destroy(FenerfModel* m);
 
 /* Training keeps the weights on the GPU, so re-packing them through the host every optimizer step (fenerf_model_update)
  * costs more than the step itself.  For FENERF_PREC_F32 models the packed streams are pure permutations (plus zero
- * padding) of the parameters: the caller builds them on the device (a gather with an index map obtained ONCE by packing
+ * padding) of the parameters (FENERF_PREC_F16X3: of their scaled fp16 hi / lo halves): the caller builds them on the device (a gather with an index map obtained ONCE by packing
  * index-valued weights with fenerf_pack_weights_host / fenerf_pack_backward_host) and hands them over here with
  * device-to-device copies.  stream_dev / consts_dev as fenerf_pack_weights_host returns them, bwd_dev as
  * fenerf_pack_backward_host (NULL unless the model is differentiable), grid_dev = spatial_embeddings [1,32,D,H,W] or NULL. */
 int fenerf_pack_backward_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats);
+/* FENERF_PREC_F16X3 streams are not permutations (per-row power-of-two scales, fp16 hi / lo splits), but their LAYOUT is:
+ * called with index-valued weights (element = 1 + its flat index) this returns, for every fp16 half of the ring stream
+ * (after the fp32 layer-0 block), that index | (is_lo << 30), 0 for padding.  The caller scales rows, splits and gathers
+ * on the device (fenerf_amd/native.py::NativeModel.load_from_device) and hands the result to fenerf_model_load_packed. */
+int fenerf_pack_index_map_f16(const FenerfModelDesc* desc, int32_t** map, size_t* n);
 int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev, size_t n_consts,
                              const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream);
 

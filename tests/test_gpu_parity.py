@@ -659,7 +659,7 @@ def test_merge_composite_backward_vs_autograd(N):
 # ---------------------------------------------------------------------------------------------------
 # backward: fused SIREN chain kernel + point-axis reductions vs torch autograd of the fp64 restatement
 # ---------------------------------------------------------------------------------------------------
-def _siren_module(kind, H, grid, seed=4, sigma_gain=30.0):
+def _siren_module(kind, H, grid, seed=4, sigma_gain=30.0, precision="f16x3"):
     spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
     sd = proc.make_state_dict(spec, seed=seed, sigma_gain=sigma_gain, with_mapping=False)
     if kind == "spatial":
@@ -671,6 +671,7 @@ def _siren_module(kind, H, grid, seed=4, sigma_gain=30.0):
     if "spatial_embeddings" in tsd:
         mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
     mod.load_state_dict(tsd, strict=False)
+    mod.precision = precision
     return mod.to(DEV), spec, sd
 
 
@@ -678,11 +679,12 @@ def _rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 75), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 33),
                                              ("texture", 256, 6, 2, 200)])
-def test_siren_backward_vs_autograd(kind, H, grid, B, P):
+def test_siren_backward_vs_autograd(kind, H, grid, B, P, precision):
     from oracle import fenerf_oracle_grad as OG
-    mod, spec, sd = _siren_module(kind, H, grid)
+    mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
     rng = np.random.default_rng(7)
     pts = rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)     # some points leave the grid box: zero padding
     dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
@@ -725,15 +727,16 @@ def test_siren_backward_vs_autograd(kind, H, grid, B, P):
         e = _rel_err(N_(named[k].grad), v.grad.numpy())
         worst = max(worst, e)
         assert e <= 2e-4, (k, e)
-    print(f"[parity] SIREN backward {kind} H={H} B={B} P={P}: worst relative error over {len(sd64) + len(film)} gradient tensors {worst:.2e}")
+    print(f"[parity] SIREN backward {precision} {kind} H={H} B={B} P={P}: worst relative error over {len(sd64) + len(film)} gradient tensors {worst:.2e}")
 
 
-def test_generator_gradient_end_to_end():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_generator_gradient_end_to_end(precision):
     """g_loss.backward() through DoubleImplicitGenerator3d.forward (hierarchical 12+12, noise, last_back off): gradients of
     a pixel loss wrt z-mapped FiLM parameters and every render weight vs torch autograd of the fp64 restatement run on the
     SAME rays, resampled depths and noise (those are no_grad constants in the reference too)."""
     from oracle import fenerf_oracle_grad as OG
-    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0)
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision=precision)
     gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
     gen.siren = mod
     gen = gen.to(DEV)
@@ -789,10 +792,11 @@ def test_generator_gradient_end_to_end():
     assert worst <= 5e-4
 
 
-def test_device_side_repack_matches_host_pack():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_device_side_repack_matches_host_pack(precision):
     """optimizer.step() analogue: change the weights on the GPU, re-pack on the device (index-map gather +
     fenerf_model_load_packed) and compare forward outputs and gradients with a model packed on the host from the same values."""
-    mod, spec, sd = _siren_module("texture", 64, 5)
+    mod, spec, sd = _siren_module("texture", 64, 5, precision=precision)
     B, P = 2, 96
     rng = np.random.default_rng(3)
     pts = T(rng.uniform(-0.12, 0.12, (B, P, 3)).astype(np.float32))
@@ -815,7 +819,7 @@ def test_device_side_repack_matches_host_pack():
             p.mul_(1.0 + 0.01 * ((i % 5) - 2)).add_(1e-3)
     out_dev, g_dev = run(mod)                        # device-side re-pack of the same NativeModel
     assert mod.native_differentiable(DEV) is nat
-    fresh, _, _ = _siren_module("texture", 64, 5)
+    fresh, _, _ = _siren_module("texture", 64, 5, precision=precision)
     fresh.load_state_dict(mod.state_dict())
     out_host, g_host = run(fresh)                    # fresh model: host pack
     assert np.abs(out_dev - out_host).max() <= 1e-5 * max(1.0, np.abs(out_host).max())
