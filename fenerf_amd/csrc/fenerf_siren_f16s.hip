@@ -165,13 +165,12 @@ __device__ __forceinline__ void put4(half8& dst, const half4& v, int q /* 0: slo
 // behind the four k-steps of a chunk step: each piece is <= 8 VALU slots, which fit under the 32 cycles the k-step's last
 // MFMA is still executing (a wave issues in order, so VALU placed after a dependent MFMA chain overlaps only its tail).
 //   piece 0: 16 sin(2 pi (f'' acc + p')) for values 0,1      piece 1: values 2,3
-//   piece 2: hi = rn_f16(v), remainder v - hi                  piece 3: lo = rn_f16(remainder); store
+//   piece 2: hi = rn_f16(v)                                    piece 3: lo = rn_f16(v - hi) (v_fma_mixlo_f16); store
 // Outputs are the (hi, lo) halves of k-step 2*nbp + (q>>1), slots 4*(q&1)..+3: the first NBL n-blocks' outputs wait
 // in the wave's LDS slab (unit (2*ks + which) = 64 lanes x 16 B), the rest in the y registers.
 struct EpiQ {
   float4 f, p;
   float v[4];
-  float r[4];
   half4 hi;
 };
 // Differentiable mode: keep the quarter's raw accumulators (register dump, fenerf_layout.h "Tape"; here in the scaled
@@ -195,17 +194,13 @@ __device__ __forceinline__ void epi_p1(EpiQ& e, const f32x16& acc, int q) {
 }
 __device__ __forceinline__ void epi_p2(EpiQ& e) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const _Float16 h = (_Float16)e.v[t];
-    e.hi[t] = h;
-    e.r[t] = e.v[t] - (float)h;
-  }
+  for (int t = 0; t < 4; ++t) e.hi[t] = (_Float16)e.v[t];
 }
 template <int KS, int NBL>
 __device__ __forceinline__ void epi_p3(EpiQ& e, int nbp, int q, half8 (&yh)[KS], half8 (&yl)[KS], char* slab) {
   half4 lo;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) lo[t] = (_Float16)e.r[t];
+  for (int t = 0; t < 4; ++t) lo[t] = (_Float16)(e.v[t] - (float)e.hi[t]);   // one v_fma_mixlo_f16: fp32 difference, rounded once
   const int ks = 2 * nbp + (q >> 1);
   if (nbp < NBL) {
     *reinterpret_cast<half4*>(slab + (2 * ks + 0) * 1024 + (q & 1) * 8) = e.hi;

@@ -266,6 +266,197 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Square weight-gradient job on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), error-compensated like the forward's f16x3 GEMM:
+// each fp32 operand is split into bf16 (hi, lo) -- hi = truncation, lo = truncation of the exact remainder, together 16
+// mantissa bits -- and a product is evaluated as ah*bh + ah*bl + al*bh (3 MFMAs at 16x the fp32 MFMA rate; dropped term
+// and truncations ~2^-15 relative per product, random over 10^5..10^6 points).  bf16 rather than fp16 because dtheta has
+// no a-priori range.  Used for FENERF_PREC_F16X3 models; FENERF_PREC_F32 models keep the exact fp32 job above.
+//
+// LDS image: A_p / B_p rows [feature][32 points] of split-packed dwords (hi | lo << 16), row stride WG_LD -- the lane's 8
+// consecutive points of a k-step are two 128-bit reads and four v_perm_b32 per half; A_f / C_s keep fp32 rows of dtheta_l
+// and tape_l for the (exact) FiLM sums.  With the MFMA time cut 5x the kernel is bound by the three tape reads.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned split_pack_bf16(float v) {
+  const unsigned vb = __builtin_bit_cast(unsigned, v);
+  const float hi = __builtin_bit_cast(float, vb & 0xffff0000u);
+  const unsigned rb = __builtin_bit_cast(unsigned, v - hi);          // exact
+  return (vb >> 16) | (rb & 0xffff0000u);
+}
+
+struct Frag16 { bf16x8 hi, lo; };
+// 8 consecutive split-packed points -> (hi8, lo8)
+__device__ __forceinline__ Frag16 unpack_frag(const unsigned* row8) {
+  const uint4 a = *reinterpret_cast<const uint4*>(row8), b = *reinterpret_cast<const uint4*>(row8 + 4);
+  uint4 h, l;
+  h.x = __builtin_amdgcn_perm(a.y, a.x, 0x05040100u); l.x = __builtin_amdgcn_perm(a.y, a.x, 0x07060302u);
+  h.y = __builtin_amdgcn_perm(a.w, a.z, 0x05040100u); l.y = __builtin_amdgcn_perm(a.w, a.z, 0x07060302u);
+  h.z = __builtin_amdgcn_perm(b.y, b.x, 0x05040100u); l.z = __builtin_amdgcn_perm(b.y, b.x, 0x07060302u);
+  h.w = __builtin_amdgcn_perm(b.w, b.z, 0x05040100u); l.w = __builtin_amdgcn_perm(b.w, b.z, 0x07060302u);
+  Frag16 f;
+  f.hi = __builtin_bit_cast(bf16x8, h);
+  f.lo = __builtin_bit_cast(bf16x8, l);
+  return f;
+}
+
+// 4 waves (2 x 2 over the 8 x 8 output tiles; 4 x 4 tiles = 256 accumulator AGPRs each, one wave per SIMD).
+template <int H>
+__global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams P) {
+  constexpr int NB = H / 32, NG = H / 8;                  // output tiles per side; dump groups per tile
+  constexpr int GPW = NG >= 4 ? NG / 4 : 1;               // dump groups staged per wave
+  constexpr int WGK = 2, WM = (NB + 1) / 2, WK = (NB + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* A_p = reinterpret_cast<unsigned*>(lds);          // [H][WG_LD] split-packed dtheta_l
+  unsigned* B_p = A_p + H * WG_LD;                            // [H][WG_LD] split-packed x_{l-1}
+  float* A_f = reinterpret_cast<float*>(B_p + H * WG_LD);     // [H][WG_LD] fp32 dtheta_l (FiLM sums)
+  float* C_s = A_f + H * WG_LD;                               // [H][WG_LD] fp32 tape_l
+  float* f_s = C_s + H * WG_LD;
+  float* p_s = f_s + H;
+  float* b_s = p_s + H;
+  float* i_s = b_s + H;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x, img = blockIdx.y;
+  const int l = P.layer0 + blockIdx.z, lb = l - 1;
+  const int L = P.L;
+  for (int i = tid; i < H; i += 256) {
+    f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i];
+    b_s[i] = P.bias[(size_t)l * H + i]; i_s[i] = P.inv ? P.inv[(size_t)l * H + i] : 1.f;
+  }
+  __syncthreads();
+
+  const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
+  const int t0 = chunk * t_per, t1 = min(P.tiles_per_image, t0 + t_per);
+  const long long tile_base = (long long)img * P.tiles_per_image;
+  const long long tl = (long long)NG * 64;
+  const float4* tape4 = reinterpret_cast<const float4*>(P.tape);
+  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
+
+  f32x16 acc[WM][WK];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
+  float s0 = 0.f, s1 = 0.f;
+  const int m = lane & 31, half = lane >> 5;
+  const bool stager = wave * GPW < NG;                      // small H: fewer dump groups than waves
+
+  float4 va[GPW], vb[GPW], vc[GPW];
+  auto fetch = [&](int t) {
+    if (!stager) return;
+    const long long tile = tile_base + t;
+#pragma unroll
+    for (int q = 0; q < GPW; ++q) {
+      const int g = wave * GPW + q;
+      va[q] = dt4[(tile * L + l) * tl + g * 64 + lane];
+      vb[q] = tape4[(tile * L + lb) * tl + g * 64 + lane];
+      vc[q] = tape4[(tile * L + l) * tl + g * 64 + lane];
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int t = t0; t < t1; ++t) {
+    // ---- stage: FiLM rows first (LDS reads cannot be moved across LDS writes by the compiler), then the writes
+    if (stager) {
+      constexpr int NH = GPW > 4 ? 4 : GPW;               // groups per staging pass (bounds the f' / p' temporaries)
+#pragma unroll
+      for (int hq = 0; hq < GPW; hq += NH) {
+        float4 f4[NH], p4[NH];
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+          const int row = tape_feature(wave * GPW + hq + q, half, 0);
+          f4[q] = *reinterpret_cast<const float4*>(f_s + row);
+          p4[q] = *reinterpret_cast<const float4*>(p_s + row);
+        }
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+          const int row = tape_feature(wave * GPW + hq + q, half, 0);
+          const float4 a = va[hq + q], b = vb[hq + q], cc = vc[hq + q];
+          const float d[4] = {a.x, a.y, a.z, a.w};
+          const float c[4] = {cc.x, cc.y, cc.z, cc.w};
+          const float x[4] = {sin2pi(__builtin_fmaf(f4[q].x, b.x, p4[q].x)), sin2pi(__builtin_fmaf(f4[q].y, b.y, p4[q].y)),
+                              sin2pi(__builtin_fmaf(f4[q].z, b.z, p4[q].z)), sin2pi(__builtin_fmaf(f4[q].w, b.w, p4[q].w))};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int o = (row + i) * WG_LD + m;
+            A_f[o] = d[i];
+            C_s[o] = c[i];
+            A_p[o] = split_pack_bf16(d[i]);
+            B_p[o] = split_pack_bf16(x[i]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);
+
+    // ---- FiLM sums (thread = row), exact fp32
+    if (tid < H) {
+      const float4* ar = reinterpret_cast<const float4*>(A_f + tid * WG_LD);
+      const float4* cr = reinterpret_cast<const float4*>(C_s + tid * WG_LD);
+      const float bb = b_s[tid], iv = i_s[tid];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 a = ar[q], c = cr[q];
+        s0 += (a.x + a.y) + (a.z + a.w);
+        s1 += (a.x * __builtin_fmaf(c.x, iv, bb) + a.y * __builtin_fmaf(c.y, iv, bb)) + (a.z * __builtin_fmaf(c.z, iv, bb) + a.w * __builtin_fmaf(c.w, iv, bb));
+      }
+    }
+    // ---- MFMA: lane (i, kh) contracts points 16 ks + 8 kh + {0..7} in k-step ks (same order on both operands)
+    {
+      const int i = lane & 31, kh = lane >> 5;
+      auto a_tile = [&](int mt) { return (wm0 + mt < NB) ? wm0 + mt : NB - 1; };   // waves beyond the tile grid recompute the
+      auto b_tile = [&](int kt) { return (wk0 + kt < NB) ? wk0 + kt : NB - 1; };   // last tile (not stored)
+      // Fragments are re-read from LDS per tile pair rather than cached (256 accumulators + the 96-register prefetch leave no
+      // room): the LDS has the bandwidth, and the kernel is bound by the tape reads, not by this loop.
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) {
+        Frag16 af[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[ks] = unpack_frag(A_p + (a_tile(mt) * 32 + i) * WG_LD + 16 * ks + 8 * kh);
+#pragma unroll
+        for (int kt = 0; kt < WK; ++kt) {
+          Frag16 bf[2];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) bf[ks] = unpack_frag(B_p + (b_tile(kt) * 32 + i) * WG_LD + 16 * ks + 8 * kh);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            acc[mt][kt] = MFMA_BF16(af[ks].lo, bf[ks].hi, acc[mt][kt]);
+            acc[mt][kt] = MFMA_BF16(af[ks].hi, bf[ks].lo, acc[mt][kt]);
+            acc[mt][kt] = MFMA_BF16(af[ks].hi, bf[ks].hi, acc[mt][kt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- partials (same layout as the fp32 job)
+  float* out = P.partial + (((size_t)blockIdx.z * P.B + img) * P.nchunk + chunk) * (size_t)(H * H);
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < WK; ++kt)
+      if (wm0 + mt < NB && wk0 + kt < NB)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          out[(size_t)row * H + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
+        }
+  if (tid < H) {
+    float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + tid) * 2;
+    fpart[0] = s0; fpart[1] = s1;
+  }
+}
+
 // Inversion optimises only the FiLM frequencies / phases (inverse_render_double_semantic.py:324-350): the FiLM sums alone,
 // straight from the two dumps -- per-lane partial sums over the block's tiles, one cross-lane reduction at the end.
 template <int H>
@@ -389,6 +580,21 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad launch");
 }
 
+template <int H>
+int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
+  auto kfn = siren_wgrad_sq_bf16_kernel<H>;
+  const size_t lds = (size_t)(4 * H * WG_LD + 4 * H) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(wgrad bf16 LDS)");
+    configured = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16 launch");
+}
+
 void reduce_mat(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rows, int cols,
                 int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer, hipStream_t st) {
   const int total = rows * cols;
@@ -457,7 +663,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   }
   // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch; FiLM sums of layers 1..L-1
   p.partial = sq; p.layer0 = 1;
-  if ((rc = launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
+  if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
   for (int l = 1; l < L; ++l) {
     const float* src = sq + (size_t)(l - 1) * B * nc * H * H;
     if (l < ng) reduce_mat(g.geo_w[l], H, 0, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
