@@ -51,6 +51,27 @@ __device__ __forceinline__ void mfma_x(f32x16& acc, const float (&b)[NIN], Ring&
   }
 }
 
+// mfma_x with a per-k-group hook: piece(kg) is issued behind k-group kg's four MFMAs.  A dependent fp32 MFMA occupies the
+// matrix pipe for 64 cycles but the wave's issue port for 4, so ~50 issue cycles per MFMA are free for other work.
+template <int NIN, int NKG, int NKGP, class PIECE>
+__device__ __forceinline__ void mfma_x_p(f32x16& acc, const float (&b)[NIN], Ring& ring, PIECE piece) {
+  static_assert(NKG * 4 == NIN, "k-groups must cover the activation");
+  static_assert(NKGP % FENERF_PF == 0, "bodies are padded to the ring depth");
+#pragma unroll
+  for (int kg = 0; kg < NKGP; ++kg) {
+    float4 w;
+    RING_NEXT(ring, kg % FENERF_PF, w);
+    if (kg < NKG) {
+      acc = MFMA(w.x, b[4 * kg + 0], acc);
+      acc = MFMA(w.y, b[4 * kg + 1], acc);
+      acc = MFMA(w.z, b[4 * kg + 2], acc);
+      acc = MFMA(w.w, b[4 * kg + 3], acc);
+    }
+    piece(kg);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // FiLM parameters of one n-block for this lane-half: features 32nb + 8j + 4h + {0..3}, j = 0..3.
 // Loaded BEFORE the n-block's MFMAs so the L2 latency hides behind them.
 struct FilmNB { float4 f[4], p[4]; };

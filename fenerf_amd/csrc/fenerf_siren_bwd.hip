@@ -12,6 +12,8 @@
 // fenerf_amd/siren/autograd.py) -- they contract over the point axis and do not belong in a per-tile kernel.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_mfma32.h"
@@ -54,19 +56,77 @@ __device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, c
   }
 }
 
-// dz_l (in registers) -> dz_{l-1}: one transposed square stage
+// The epilogue of one accumulator register (element r of n-block nb), and the stores of a finished group of four:
+// cut this way the epilogue of n-block nb-1 is issued, piece by piece, behind the MFMAs of n-block nb -- run after its own
+// body it serialised (last MFMA done -> 16 cos + stores -> next body's loads) for ~25 % of the kernel.
+struct BwdQuad { float d[4], o[4]; };
+__device__ __forceinline__ void bwd_piece(int r, const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, float4* slab, float4* dtp,
+                                          BwdQuad& q) {
+  const float TWO_PI = 6.28318530717958647692f;
+  const int j = r >> 2, i = r & 3;
+  const float f = i == 0 ? fm.f[j].x : (i == 1 ? fm.f[j].y : (i == 2 ? fm.f[j].z : fm.f[j].w));
+  const float p = i == 0 ? fm.p[j].x : (i == 1 ? fm.p[j].y : (i == 2 ? fm.p[j].z : fm.p[j].w));
+  const float dt = acc[r] * cos2pi(__builtin_fmaf(f, tn.a[r], p));
+  q.d[i] = dt;
+  q.o[i] = dt * (f * TWO_PI);
+  if (i == 3) {
+    dtp[(nb * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
+    slab[(nb * 4 + j) * 64] = make_float4(q.o[0], q.o[1], q.o[2], q.o[3]);
+  }
+}
+
+// One of the 12 loads (8 FiLM float4, 4 tape float4) of n-block nb's epilogue operands: issued one per k-group behind the
+// MFMAs of the body before, instead of all twelve in front of the body's first MFMA.
+__device__ __forceinline__ void prefetch_piece(int i, FilmNB& fm, TapeNB& tn, const float* fpl, const float* ppl, const float4* tp, int nb) {
+  if (i < 4) fm.f[i] = *reinterpret_cast<const float4*>(fpl + 32 * nb + 8 * i);
+  else if (i < 8) fm.p[i - 4] = *reinterpret_cast<const float4*>(ppl + 32 * nb + 8 * (i - 4));
+  else if (i < 12) {
+    const int j = i - 8;
+    const float4 v = tp[(nb * 4 + j) * 64];
+    tn.a[4 * j + 0] = v.x; tn.a[4 * j + 1] = v.y; tn.a[4 * j + 2] = v.z; tn.a[4 * j + 3] = v.w;
+  }
+}
+
+// dz_l (in registers) -> dz_{l-1}: one transposed square stage.  Software pipeline over the n-blocks: behind the MFMAs of
+// body nb run the epilogue of body nb-1 (k-groups 0..15) and the operand loads of body nb+1 (k-groups 16..27).
 template <int H>
 __device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl, float4* slab,
                                            const float4* tp, float4* dtp) {
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
-#pragma unroll 1
-  for (int nb = 0; nb < NB; ++nb) {
-    const FilmNB fm = film_load(fpl, ppl, nb);
-    const TapeNB tn = tape_load(tp, nb);
+  constexpr bool WIDE = KGX >= 28;                       // enough k-groups to spread the pieces (H = 256)
+  FilmNB fm_c = film_load(fpl, ppl, 0), fm_n = fm_c, fm_p = fm_c;
+  TapeNB tn_c = tape_load(tp, 0), tn_n = tn_c, tn_p = tn_c;
+  f32x16 acc_p = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // PREV / NEXT are compile-time per copy of the body (first, middle, last): no branches inside the MFMA stream
+  auto body = [&](int nb, auto has_prev, auto has_next) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    mfma_x<H / 2, KGX, KGXP>(acc, in, ring);
-    bwd_store(acc, fm, tn, nb, slab, dtp);
+    BwdQuad q;
+    mfma_x_p<H / 2, KGX, KGXP>(acc, in, ring, [&](int kg) {
+      if (WIDE) {
+        if (kg < 16) { if (has_prev.value) bwd_piece(kg, acc_p, fm_p, tn_p, nb - 1, slab, dtp, q); }
+        else if (kg < 28) { if (has_next.value) prefetch_piece(kg - 16, fm_n, tn_n, fpl, ppl, tp, nb + 1); }
+      } else if (kg < KGX) {                               // small H: several pieces per k-group
+        if (has_prev.value) {
+#pragma unroll
+          for (int r = kg * (16 / KGX); r < (kg + 1) * (16 / KGX); ++r) bwd_piece(r, acc_p, fm_p, tn_p, nb - 1, slab, dtp, q);
+        }
+        if (has_next.value && kg == KGX - 1) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) prefetch_piece(i, fm_n, tn_n, fpl, ppl, tp, nb + 1);
+        }
+      }
+    });
+    acc_p = acc; fm_p = fm_c; tn_p = tn_c; fm_c = fm_n; tn_c = tn_n;
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (NB == 1) body(0, F{}, F{});
+  else {
+    body(0, F{}, T{});
+#pragma unroll 1
+    for (int nb = 1; nb < NB - 1; ++nb) body(nb, T{}, T{});
+    body(NB - 1, T{}, F{});
   }
+  bwd_store(acc_p, fm_p, tn_p, NB - 1, slab, dtp);
   load_act<H / 2>(in, slab);
 }
 

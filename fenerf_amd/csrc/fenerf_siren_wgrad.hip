@@ -506,6 +506,16 @@ __global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
 }
 
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
+__device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int nchunk) {   // 4 independent partial sums:
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                                                // the loads are latency-bound
+  int k = 0;
+  for (; k + 4 <= nchunk; k += 4) {
+    s0 += src[(size_t)k * stride]; s1 += src[(size_t)(k + 1) * stride]; s2 += src[(size_t)(k + 2) * stride]; s3 += src[(size_t)(k + 3) * stride];
+  }
+  for (; k < nchunk; ++k) s0 += src[(size_t)k * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
                                     int rows, int cols, int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer) {
   const float TWO_PI = 6.28318530717958647692f;
@@ -514,11 +524,31 @@ __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const 
     const int r = i / cols, c = i % cols;
     float sum = 0.f;
     for (int b = 0; b < B; ++b) {
-      float s = 0.f;
-      for (int k = 0; k < nchunk; ++k) s += src[(((size_t)b * nchunk + k) * src_rows + r) * src_ld + src_col0 + c];
+      const float s = sum_chunks(src + ((size_t)b * nchunk * src_rows + r) * src_ld + src_col0 + c, (size_t)src_rows * src_ld, nchunk);
       sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI / (inv ? inv[(size_t)layer * H + r] : 1.f)) : s;
     }
     dst[(size_t)r * dst_ld + dst_col0 + c] = sum;
+  }
+}
+
+// all square jobs in one launch: blockIdx.y = layer - 1; destination by layer (nn.Linear layout, FenerfSirenGrads)
+__global__ void wgrad_reduce_sq_kernel(FenerfSirenGrads g, const float* sq, int B, int nchunk, const float* fp, const float* inv, int L, int H,
+                                       int n_geo, int grid_ch) {
+  const float TWO_PI = 6.28318530717958647692f;
+  const int l = blockIdx.y + 1;
+  const float* src = sq + (size_t)(l - 1) * B * nchunk * H * H;
+  float* dst; int ld, col0 = 0;
+  if (l < n_geo) { dst = g.geo_w[l]; ld = H; }
+  else if (l == n_geo) { dst = g.color_w[0]; ld = 3 + grid_ch + H; col0 = 3 + grid_ch; }
+  else { dst = g.color_w[l - n_geo]; ld = H; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * H; i += gridDim.x * blockDim.x) {
+    const int r = i / H, c = i % H;
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float s = sum_chunks(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk);
+      sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
+    }
+    dst[(size_t)r * ld + col0 + c] = sum;
   }
 }
 
@@ -545,12 +575,19 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
   }
 }
 
-__global__ void rowsum_reduce_kernel(const float* part, int B, int nchunk, int rows, float* dst) {
-  const int r = threadIdx.x;
-  if (r >= rows) return;
+__global__ void rowsum_reduce_kernel(const float* part, int B, int nchunk, int rows, float* dst) {   // one block of 256 threads
+  __shared__ float red[8][32];
+  const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
   float s = 0.f;
-  for (int k = 0; k < B * nchunk; ++k) s += part[(size_t)k * 32 + r];
-  dst[r] = s;
+  for (int k = grp; k < B * nchunk; k += 8) s += part[(size_t)k * 32 + r];
+  red[grp][r] = s;
+  __syncthreads();
+  if (threadIdx.x < rows) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+    dst[threadIdx.x] = t;
+  }
 }
 
 namespace {
@@ -664,12 +701,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch; FiLM sums of layers 1..L-1
   p.partial = sq; p.layer0 = 1;
   if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
-  for (int l = 1; l < L; ++l) {
-    const float* src = sq + (size_t)(l - 1) * B * nc * H * H;
-    if (l < ng) reduce_mat(g.geo_w[l], H, 0, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
-    else if (l == ng) reduce_mat(g.color_w[0], 3 + G + H, 3 + G, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
-    else reduce_mat(g.color_w[l - ng], H, 0, src, H, H, 0, H, H, B, nc, p.fp, p.inv, L, H, l, st);
-  }
+  hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
   // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above), with their own chunking
   p.nchunk = nt;
   p.layer0 = 0;
@@ -684,11 +716,11 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   p.layer0 = ng - 1;
   if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
   reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nt, nullptr, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 32, g.head_b);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(256), 0, st, rows, B, nt, 32, g.head_b);
   p.layer0 = L - 1;
   if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
   reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nt, nullptr, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(32), 0, st, rows, B, nt, 3, g.rgb_b);
+  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(256), 0, st, rows, B, nt, 3, g.rgb_b);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
 }
