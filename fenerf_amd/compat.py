@@ -1,6 +1,8 @@
 """Import-path aliases so code (and pickles) written against the reference resolve to this package:
 `import curriculums`, `from generators import generators`, `from siren import siren`
-(pickled checkpoints embed `generators.generators.DoubleImplicitGenerator3d` / `siren.siren.*`)."""
+(pickled checkpoints embed `generators.generators.DoubleImplicitGenerator3d` / `siren.siren.*`); the pickled
+`*_ema.pth` objects embed `torch_ema.ema.ExponentialMovingAverage`, served by fenerf_amd.ema when torch_ema is absent."""
+import importlib.util
 import sys
 
 
@@ -13,3 +15,7 @@ def install_aliases():
     sys.modules.setdefault("generators.math_utils_torch", generators.math_utils_torch)
     sys.modules.setdefault("siren", siren)
     sys.modules.setdefault("siren.siren", siren.siren)
+    if "torch_ema" not in sys.modules and importlib.util.find_spec("torch_ema") is None:
+        from . import ema
+        sys.modules["torch_ema"] = ema
+        sys.modules["torch_ema.ema"] = ema

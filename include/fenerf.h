@@ -194,7 +194,8 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
  *
  * fenerf_siren_forward_save = fenerf_siren_forward that also keeps the pre-FiLM accumulators (W_l x_{l-1}, no bias) of
  *   every FiLM layer as a tape of fenerf_siren_tape_floats(m, B*P) floats (opaque: 32-point register dumps,
- *   fenerf_amd/csrc/fenerf_layout.h "Tape") and the sampled grid features tape_e [B*P][32] (NULL without a grid).
+ *   fenerf_amd/csrc/fenerf_layout.h "Tape"; for FENERF_PREC_F16X3 models in the row-scaled units of that GEMM) and the
+ *   sampled grid features tape_e [B*P][32] (NULL without a grid).
  * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t (same size and layout as the tape) = dL/dtheta per FiLM layer,
  *   theta = f (W x + b) + p, and d_e [B*P][32] = gradient wrt the sampled grid features (NULL without a grid).
  * fenerf_siren_param_grads: (tape, d_t) -> every parameter gradient, written to the buffers of FenerfSirenGrads.  With all

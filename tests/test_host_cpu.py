@@ -171,3 +171,45 @@ def test_reference_checkpoint_unpickles_into_this_package():
         "print('ok')\n") % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.join(GOLDEN, "ref_generator_tiny.pth"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_ema_shim_matches_the_reference_usage(tmp_path):
+    """train_double_latent_semantic.py:145,456,487-488 / render_multiview_images_double_semantic.py:62-64: an EMA object is
+    pickled whole (torch.save(ema)) under the module path torch_ema.ema and later unpickled and copied into the generator."""
+    import subprocess
+    import sys
+    import textwrap
+    import torch
+    from fenerf_amd import ema as E
+    lin = torch.nn.Linear(3, 2)
+    avg = E.ExponentialMovingAverage(lin.parameters(), decay=0.999)
+    w0 = lin.weight.detach().clone()
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    avg.update(lin.parameters())
+    d = min(0.999, (1 + 1) / (10 + 1))                      # warm-up decay of the first update
+    assert torch.allclose(avg.shadow_params[0], w0 + (1 - d) * 1.0)
+    avg.store(lin.parameters()); avg.copy_to(lin.parameters())
+    assert torch.equal(lin.weight.detach(), avg.shadow_params[0])
+    avg.restore(lin.parameters())
+    assert torch.allclose(lin.weight.detach(), w0 + 1.0)
+    # a pickle that names torch_ema.ema.ExponentialMovingAverage, as the reference's *_ema.pth files do
+    code = textwrap.dedent(f"""
+        import sys, types, torch
+        sys.path.insert(0, {repr(str(__import__('pathlib').Path(__file__).resolve().parents[1]))})
+        from fenerf_amd import compat
+        compat.install_aliases()
+        import torch_ema
+        e = torch_ema.ExponentialMovingAverage(torch.nn.Linear(3, 2).parameters(), decay=0.9)
+        assert type(e).__module__ in ("fenerf_amd.ema", "torch_ema.ema")
+        type(e).__module__ = "torch_ema.ema"
+        torch.save(e, r"{tmp_path}/ema.pth")
+        type(e).__module__ = "fenerf_amd.ema"
+        back = torch.load(r"{tmp_path}/ema.pth", weights_only=False)
+        lin = torch.nn.Linear(3, 2)
+        back.copy_to(lin.parameters())
+        assert torch.equal(lin.weight.detach(), e.shadow_params[0]) and back.decay == 0.9
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
