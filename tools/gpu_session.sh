@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: GPU tests, smoke, bench, rocprof kernel trace.  Everything is logged under gpurun_out/.
-# usage: gpurun --timeout 1500 -- 'bash tools/gpu_session.sh [tests|bench|prof|all]'
+# usage: gpurun --timeout 1500 -- 'bash tools/gpu_session.sh [tests|bench|prof|gstep|pmc|all]'
 set -u
 what=${1:-all}
 mkdir -p gpurun_out
@@ -29,6 +29,13 @@ if [[ $what == all || $what == bench || $what == bench16 ]]; then
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --precision f16x3 --no-cpu-baseline > gpurun_out/bench_f16x3.log 2>&1
   echo "bench16 exit: $?" >> gpurun_out/bench_f16x3.log
   tail -3 gpurun_out/bench_f16x3.log | cut -c1-1500
+fi
+if [[ $what == all || $what == gstep ]]; then
+  timeout 600 python tools/bench_gstep.py --B 2 --size 64 > gpurun_out/gstep.log 2>&1
+  echo "gstep exit: $?" >> gpurun_out/gstep.log
+  rm -rf gpurun_out/prof_gstep
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_gstep -o g -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 2 --size 64 --skip-eager --iters 3) > gpurun_out/prof_gstep.log 2>&1
+  find gpurun_out/prof_gstep -type f ! -name "*stats*" -size +2M -delete
 fi
 if [[ $what == pmc ]]; then
   rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
