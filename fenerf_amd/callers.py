@@ -97,7 +97,7 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
 
 
 def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_psi=0.0, lambda_seg=1.0, lambda_img=1.0,
-                   lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None):
+                   lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None, latent_noise=0.03):
     """GAN inversion in FiLM space (inverse_render_double_semantic.py:306-410): optimise additive offsets on the geometry /
     appearance frequencies and phase shifts with Adam (lr 1e-2, weight_decay 1e-4, StepLR(100, 0.75)) under annealed
     latent noise so that generator.forward_with_frequencies reproduces gt_image [1,3,S,S] and gt_seg [1,18,S,S] (both in
@@ -131,7 +131,7 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
     mse = torch.nn.MSELoss(reduction="mean")
     losses = []
     for i in range(n_iterations):
-        k = 0.03 * (n_iterations - i) / n_iterations
+        k = latent_noise * (n_iterations - i) / n_iterations      # annealed noise on the FiLM parameters (:381-384; 0.03 there)
         frame, _ = generator.forward_with_frequencies(w_gf + k * torch.randn_like(w_gf) + o_gf, w_af + k * torch.randn_like(w_af) + o_af,
                                                       w_gp + k * torch.randn_like(w_gp) + o_gp, w_ap + k * torch.randn_like(w_ap) + o_ap,
                                                       **options)

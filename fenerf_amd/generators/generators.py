@@ -77,14 +77,41 @@ class _Generator3dBase(nn.Module):
         """The differentiable render of generators.py:468-519: same random draws in the same order as _render, same kernels,
         but the two SIREN passes and the final integration are autograd nodes with native backward kernels.  The coarse
         weights and the resampled depths are constants (computed under no_grad in the reference too, :485-503).
-        Returns (pixels [B,R,C-1], depth [B,R], pitch, yaw)."""
-        fg, pg, fa, pa = film
-        B = fg.shape[0]
+        With kwargs['grad_points'] < img_size^2 only a random subset of the rays is differentiable (part_forward, :858-910).
+        Returns (pixels [B,R,C-1], depth [B,R] or None, pitch, yaw)."""
+        B = film[0].shape[0]
         dev = self.device
         R, N = img_size * img_size, num_steps
         d = self.draws
         origins, dirs, z_vals, pitch, yaw = sample_rays(B, N, dev, fov, (img_size, img_size), ray_start, ray_end, h_stddev,
                                                         v_stddev, h_mean, v_mean, sample_dist, draws=d)
+        z_c = z_vals.reshape(B, R, N)
+        grad_points = kwargs.get("grad_points", R)
+        if grad_points == R:
+            rgb, depth = self._render_rays(film, origins, dirs, z_c, hierarchical_sample, lock_view_dependence, kwargs,
+                                           self._wants_grad(film))
+            return rgb, depth, pitch, yaw
+        # part_forward: randperm AFTER the camera draws, then the gradient part's draws, then the rest's (:880-900)
+        assert R > grad_points
+        perm = d.randperm(R, dev)
+        idx_g, idx_n = perm[:grad_points], perm[grad_points:]
+        take = lambda t, idx: t[:, idx].contiguous()
+        rgb_g, _ = self._render_rays(film, take(origins, idx_g), take(dirs, idx_g), take(z_c, idx_g), hierarchical_sample,
+                                     lock_view_dependence, kwargs, self._wants_grad(film))
+        with torch.no_grad():
+            rgb_n, _ = self._render_rays(film, take(origins, idx_n), take(dirs, idx_n), take(z_c, idx_n), hierarchical_sample,
+                                         lock_view_dependence, kwargs, False)
+        pixels = torch.zeros((B, R, rgb_g.shape[-1]), dtype=rgb_g.dtype, device=dev)
+        pixels = pixels.index_copy(1, idx_g, rgb_g).index_copy(1, idx_n, rgb_n)
+        return pixels, None, pitch, yaw
+
+    def _render_rays(self, film, origins, dirs, z_c, hierarchical_sample, lock_view_dependence, kwargs, differentiable):
+        """origins / dirs [B,R,3], z_c [B,R,N] -> (rgb [B,R,C-1], depth [B,R]).  Draws: coarse noise randn [B,R,N,1] and u rand
+        [B*R,N] (hierarchical only), final noise randn [B,R,M,1].  differentiable=False is the fused no-grad call."""
+        fg, pg, fa, pa = film
+        B, R, N = z_c.shape
+        dev = self.device
+        d = self.draws
         noise_std = kwargs["nerf_noise"]
         opts = _lib.composite_opts(kwargs["clamp_mode"], noise_std, kwargs.get("last_back", False), kwargs.get("white_back", False),
                                    kwargs.get("black_back", False), None, kwargs.get("fill_color", "black"))
@@ -96,18 +123,23 @@ class _Generator3dBase(nn.Module):
         noise_f = d.randn((B, R, M, 1), dev)
         use_noise = noise_std != 0
         C = self.siren.output_dim
+        if not differentiable:
+            rgb, depth, _, _ = self.siren.native(dev).render(
+                origins, dirs, z_c, u, noise_c.reshape(B, R, N) if (use_noise and noise_c is not None) else None,
+                noise_f.reshape(B, R, M) if use_noise else None, fg, pg, fa, pa, opts, hierarchical=bool(hierarchical_sample),
+                lock_view=bool(lock_view_dependence))
+            return rgb, depth
 
         def field(z):      # [B,R,N] depths -> [B,R*N,C] radiance-field samples, an autograd node
             pts = origins.unsqueeze(2) + dirs.unsqueeze(2) * z.unsqueeze(-1)              # generators.py:504
             rd = None if lock_view_dependence else dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, R * N, 3)
             return _siren_autograd.siren_apply(self.siren, pts.reshape(B, R * N, 3), rd, fg, pg, fa, pa)
 
-        z_c = z_vals.reshape(B, R, N)
         coarse = field(z_c)
         if not hierarchical_sample:
             rgb, depth = CompositeFunction.apply(coarse.reshape(B * R, N, C), z_c.reshape(B * R, N),
                                                  noise_f.reshape(B * R, M) if use_noise else None, opts)
-            return rgb.reshape(B, R, C - 1), depth.reshape(B, R), pitch, yaw
+            return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
         with torch.no_grad():
             copts = _lib.composite_opts(kwargs["clamp_mode"], noise_std)
             _, _, w_c, _ = native.composite(coarse.detach().reshape(B * R, N, C), z_c.reshape(B * R, N),
@@ -116,7 +148,7 @@ class _Generator3dBase(nn.Module):
         fine = field(z_f.reshape(B, R, N))
         rgb, depth = MergeCompositeFunction.apply(fine.reshape(B * R, N, C), coarse.reshape(B * R, N, C), z_f, z_c.reshape(B * R, N),
                                                   noise_f.reshape(B * R, M) if use_noise else None, opts)
-        return rgb.reshape(B, R, C - 1), depth.reshape(B, R), pitch, yaw
+        return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
 
     def _finish(self, pixels, batch_size, img_size):
         if self.softmax_label:
@@ -163,13 +195,10 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
                 hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
         """-> (pixels [B, output_dim-1, S, S] in [-1,1], cat(pitch, yaw) [B,2])   (generators.py:452-527)."""
         batch_size = z_app.shape[0]
-        grad_points = kwargs.get("grad_points", img_size * img_size)
-        if grad_points != img_size * img_size:
-            raise NotImplementedError("part_forward (grad on a random ray subset, generators.py:858-910) is not provided: "
-                                      "the fused backward has no activation-memory reason to subsample rays")
         fg, pg = self.siren.geo_mapping_network(z_geo)
         fa, pa = self.siren.app_mapping_network(z_app)
-        if self._wants_grad((fg, pg, fa, pa)):
+        part = kwargs.get("grad_points", img_size * img_size) != img_size * img_size     # part_forward (generators.py:459-461)
+        if part or self._wants_grad((fg, pg, fa, pa)):
             pixels, depth, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                           v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                           lock_view_dependence, kwargs)

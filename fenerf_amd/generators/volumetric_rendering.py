@@ -28,6 +28,9 @@ class TorchDraws:
     def randn(self, shape, device):
         return torch.randn(shape, device=device)
 
+    def randperm(self, n, device):
+        return torch.randperm(n, device=device)
+
 
 class RecordedDraws:
     """Replays a list of recorded arrays (tests): each call pops the next one and checks its shape."""
@@ -39,6 +42,12 @@ class RecordedDraws:
         a = self.arrays.pop(0)
         t = torch.as_tensor(np.asarray(a), dtype=torch.float32, device=device)
         assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t
+
+    def randperm(self, n, device):
+        a = self.arrays.pop(0)
+        t = torch.as_tensor(np.asarray(a), dtype=torch.long, device=device)
+        assert tuple(t.shape) == (n,), (tuple(t.shape), n)
         return t
 
     rand = _next
