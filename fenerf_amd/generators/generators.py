@@ -210,6 +210,54 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
         pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
         return pixels, torch.cat([pitch, yaw], -1)
 
+    def part_forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                     hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
+        """Gradient on kwargs['grad_points'] random rays only, the rest rendered without (generators.py:858-910)."""
+        return self.forward(z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                            hierarchical_sample, sample_dist=sample_dist, lock_view_dependence=lock_view_dependence, **kwargs)
+
+    def point_forward(self, transformed_points, transformed_ray_directions_expanded, transformed_ray_origins,
+                      transformed_ray_directions, z_vals, z_geo, z_app, num_steps, hierarchical_sample,
+                      lock_view_dependence=False, **kwargs):
+        """Render explicit samples: points / per-point view directions [B,G,N,3], ray origins / directions [B,G,3], z_vals
+        [B,G,N,1] -> pixels [B,G,C-1] (generators.py:800-855).  Stage by stage on the native kernels (per-point view
+        directions are honoured, as in the reference); differentiable when grad is enabled."""
+        B, Gn = transformed_points.shape[:2]
+        N, C = num_steps, self.siren.output_dim
+        d = self.draws
+        fg, pg = self.siren.geo_mapping_network(z_geo)
+        fa, pa = self.siren.app_mapping_network(z_app)
+        noise_std = kwargs["nerf_noise"]
+        opts = _lib.composite_opts(kwargs["clamp_mode"], noise_std, kwargs.get("last_back", False), kwargs.get("white_back", False),
+                                   kwargs.get("black_back", False), None, kwargs.get("fill_color", "black"))
+        rd = transformed_ray_directions_expanded.reshape(B, Gn * N, 3)
+        siren = self.siren.forward_with_frequencies_phase_shifts
+        coarse = siren(transformed_points.reshape(B, Gn * N, 3), fg, fa, pg, pa, rd)
+        z_c = z_vals.reshape(B * Gn, N)
+        use_noise = noise_std != 0
+        if hierarchical_sample:
+            noise_c = d.randn((B, Gn, N, 1), transformed_points.device)
+            u = d.rand((B * Gn, N), transformed_points.device)
+            with torch.no_grad():
+                _, _, w_c, _ = native.composite(coarse.detach().reshape(B * Gn, N, C), z_c, noise_c.reshape(B * Gn, N) if use_noise else None,
+                                                _lib.composite_opts(kwargs["clamp_mode"], noise_std), want_wsum=False)
+                z_f = native.resample(z_c, w_c, u)
+                fine_pts = transformed_ray_origins.unsqueeze(2) + transformed_ray_directions.unsqueeze(2) * z_f.reshape(B, Gn, N, 1)
+                if lock_view_dependence:
+                    rd = torch.zeros_like(rd)
+                    rd[..., -1] = -1
+            fine = siren(fine_pts.reshape(B, Gn * N, 3), fg, fa, pg, pa, rd)
+            noise_f = d.randn((B, Gn, 2 * N, 1), transformed_points.device)
+            rgb, _ = MergeCompositeFunction.apply(fine.reshape(B * Gn, N, C), coarse.reshape(B * Gn, N, C), z_f, z_c,
+                                                  noise_f.reshape(B * Gn, 2 * N) if use_noise else None, opts)
+        else:
+            noise_f = d.randn((B, Gn, N, 1), transformed_points.device)
+            rgb, _ = CompositeFunction.apply(coarse.reshape(B * Gn, N, C), z_c, noise_f.reshape(B * Gn, N) if use_noise else None, opts)
+        pixels = rgb.reshape(B, Gn, C - 1)
+        if self.softmax_label:
+            pixels = torch.cat([torch.nn.Softmax(dim=-1)(pixels[..., :-3]), pixels[..., -3:]], dim=-1)
+        return pixels
+
     def staged_forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                        psi=1, lock_view_dependence=False, max_batch_size=50000, depth_map=False, near_clip=0, far_clip=2,
                        sample_dist=None, hierarchical_sample=False, **kwargs):

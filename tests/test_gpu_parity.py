@@ -987,3 +987,10 @@ def test_part_forward_gradient_on_a_ray_subset():
     assert worst <= 2e-4
     with torch.no_grad():
         assert np.abs(N_(run(grad_points=Gp)) - N_(px_full)).max() <= 2e-6      # no-grad part_forward renders the same image
+        # point_forward on explicit samples of every ray == the same image (per-point view directions, stage-by-stage path)
+        o, dd, zz, _, _ = VR.sample_rays(B, N, gen.device, kw["fov"], (S_, S_), kw["ray_start"], kw["ray_end"], 0.0, 0.0, np.pi / 2,
+                                         np.pi / 2, "gaussian", draws=gen.draws)
+        pts = o.unsqueeze(2) + dd.unsqueeze(2) * zz.unsqueeze(-1)
+        pf = gen.point_forward(pts, dd.unsqueeze(2).expand(-1, -1, N, -1), o, dd, zz.unsqueeze(-1), z, z, N, False, **{k: kw[k] for k in ("clamp_mode", "nerf_noise")})
+        img = pf.reshape(B, S_, S_, -1).permute(0, 3, 1, 2) * 2 - 1
+        assert np.abs(N_(img) - N_(px_full)).max() <= 2e-6
