@@ -994,3 +994,41 @@ def test_part_forward_gradient_on_a_ray_subset():
         pf = gen.point_forward(pts, dd.unsqueeze(2).expand(-1, -1, N, -1), o, dd, zz.unsqueeze(-1), z, z, N, False, **{k: kw[k] for k in ("clamp_mode", "nerf_noise")})
         img = pf.reshape(B, S_, S_, -1).permute(0, 3, 1, 2) * 2 - 1
         assert np.abs(N_(img) - N_(px_full)).max() <= 2e-6
+
+
+def test_backward_api_rejects_bad_arguments():
+    """Error behaviour of the differentiable entry points: a model created without the backward stream, point counts that
+    are not whole tiles, a half-filled gradient struct -- negative status + message, never a launch."""
+    import ctypes as C
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=4, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=2, sigma_gain=10.0, with_mapping=False)
+    plain = native.NativeModel(sd, spec, DEV, "f16x3")
+    diff = native.NativeModel(sd, spec, DEV, "f16x3", differentiable=True)
+    B, P = 1, 64
+    pts = torch.zeros((B, P, 3), device=DEV)
+    film = {k: T(v) for k, v in proc.film_params(spec, B, seed=2).items()}
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    with pytest.raises(_lib.FenerfError, match="differentiable"):
+        plain.siren_forward_save(pts, None, *args)
+    with pytest.raises(_lib.FenerfError, match="multiple of 32"):
+        diff.siren_forward_save(pts[:, :50].contiguous(), None, *args)
+    out, tape, tape_e = diff.siren_forward_save(pts, None, *args)
+    d_out = torch.ones_like(out)
+    with pytest.raises(_lib.FenerfError, match="differentiable"):
+        plain.siren_backward(B, P, *args, out, d_out, tape)
+    d_t, d_e = diff.siren_backward(B, P, *args, out, d_out, tape)
+    l = _lib.lib()
+    g = _lib.FenerfSirenGrads()
+    scratch = torch.zeros(1 << 16, device=DEV)
+    for k in ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app"):
+        setattr(g, k, scratch.data_ptr())
+    g.geo_w[0] = scratch.data_ptr()                     # some, but not all, weight buffers
+    ws = torch.empty(l.fenerf_siren_grad_workspace_bytes(diff._h, B, P), dtype=torch.uint8, device=DEV)
+    fws = torch.empty(l.fenerf_film_workspace_bytes(diff._h, B), dtype=torch.uint8, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = l.fenerf_siren_param_grads(diff._h, B, P, p(pts), None, p(args[0]), p(args[1]), p(args[2]), p(args[3]), p(out), p(d_out), p(tape),
+                                    p(tape_e), p(d_t), C.byref(g), p(ws), p(fws), None)
+    assert rc == _lib.E_INVALID and b"every weight / bias buffer or none" in l.fenerf_last_error()
+    rc = l.fenerf_grid_backward(plain._h, -1, p(pts), p(d_e), p(scratch), None)
+    assert rc == _lib.E_INVALID
+    torch.cuda.synchronize()
