@@ -10,6 +10,7 @@ from .. import native
 
 class CompositeFunction(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast (the reference's training loop) inputs arrive as fp16
     def forward(ctx, rows, z, noise, opts):
         rgb, depth, _, _ = native.composite(rows, z, noise, opts, want_weights=False, want_wsum=False)
         ctx.opts = opts
@@ -18,6 +19,7 @@ class CompositeFunction(torch.autograd.Function):
         return rgb, depth
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, _g_depth):
         rows, z, noise = ctx.saved_tensors
         lead, M, C = rows.shape[:-2], rows.shape[-2], rows.shape[-1]
@@ -30,6 +32,7 @@ class MergeCompositeFunction(torch.autograd.Function):
     """fine / coarse [BR,N,C] with their own depths [BR,N] -> (rgb [BR,C-1], depth [BR])."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast (the reference's training loop) inputs arrive as fp16
     def forward(ctx, fine, coarse, z_fine, z_coarse, noise, opts):
         rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_fine, z_coarse, noise, opts, want_weights=False,
                                                      want_wsum=False, want_z=False)
@@ -39,6 +42,7 @@ class MergeCompositeFunction(torch.autograd.Function):
         return rgb, depth
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, _g_depth):
         fine, coarse, z_fine, z_coarse, noise = ctx.saved_tensors
         d_f, d_c = native.composite_backward(g_rgb, fine, z_fine, ctx.opts, rows_b=coarse, z_b=z_coarse,

@@ -27,6 +27,7 @@ class SirenFunction(torch.autograd.Function):
     """out = siren(points, dirs; film params, weights).  Non-tensor arg `module` supplies the native model and roles."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast (the reference's training loop) inputs arrive as fp16
     def forward(ctx, module, points, dirs, fg, pg, fa, pa, *params):
         nat = module.native_differentiable(points.device)
         out, tape, tape_e = nat.siren_forward_save(points, dirs, fg, pg, fa, pa)
@@ -37,6 +38,7 @@ class SirenFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_out):
         module, nat = ctx.module, ctx.nat
         points, dirs, fg, pg, fa, pa, out, tape, tape_e, *params = ctx.saved_tensors
