@@ -1073,3 +1073,46 @@ def test_generator_step_under_autocast_and_gradscaler():
            for k in g32 if "mapping_network" not in k and g32[k].size >= 1024}
     print(f"[parity] generator step under autocast + GradScaler: cosine(grad_amp, grad_fp32) over render weights min {min(cos.values()):.3f}")
     assert min(cos.values()) >= 0.7
+
+
+def test_generator_step_through_ddp(tmp_path):
+    """The reference trains DistributedDataParallel(generator, find_unused_parameters=True) (train_double_latent_semantic.py:
+    ~170): the native autograd nodes must feed DDP's gradient hooks like ordinary ops.  One process, world_size 1."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    torch.manual_seed(5)
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=50.0)
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    kw = dict(img_size=8, fov=12, ray_start=0.88, ray_end=1.12, num_steps=12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.0)
+    z = torch.randn(2, 8, device=DEV)
+    w = torch.randn((2, 21, 8, 8), device=DEV)
+
+    def grads(model):
+        for p in gen.parameters():
+            p.grad = None
+        torch.manual_seed(11)
+        px, _ = model(z, z, **kw)
+        (px * w).sum().backward()
+        return {n: N_(p.grad) for n, p in gen.named_parameters() if p.grad is not None}
+
+    plain = grads(gen)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+    try:
+        ddp = DDP(gen, device_ids=[0], find_unused_parameters=True)
+        wrapped = grads(ddp)
+        opt = torch.optim.Adam(ddp.parameters(), lr=1e-4)
+        opt.step()                                         # parameters change in place -> the next render re-packs on the device
+        again = grads(ddp)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert set(plain) == set(wrapped)
+    assert max(_rel_err(wrapped[k], plain[k]) for k in plain) <= 1e-5
+    assert any(np.abs(again[k] - wrapped[k]).max() > 0 for k in plain)
+    print("[parity] generator step through DistributedDataParallel: gradients identical to the bare module; optimizer step picked up")
