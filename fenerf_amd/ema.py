@@ -28,16 +28,18 @@ class ExponentialMovingAverage:
 
     def copy_to(self, parameters):
         live = [p for p in parameters if p.requires_grad]
-        for s, p in zip(self.shadow_params, live):
-            p.data.copy_(s.data)
+        with torch.no_grad():
+            for s, p in zip(self.shadow_params, live):
+                p.copy_(s)            # (not p.data.copy_: keeps the version counter honest for the native re-pack)
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters if p.requires_grad]
 
     def restore(self, parameters):
         live = [p for p in parameters if p.requires_grad]
-        for c, p in zip(self.collected_params, live):
-            p.data.copy_(c.data)
+        with torch.no_grad():
+            for c, p in zip(self.collected_params, live):
+                p.copy_(c)
 
     def state_dict(self):
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow_params,

@@ -136,6 +136,19 @@ class _NativeSiren(nn.Module):
         self.__dict__["_native_diff_version"] = ver
         return nat
 
+    def invalidate_native(self):
+        """Force a re-pack of the native models at the next render.  Parameter changes are normally detected through the
+        tensors' version counters; writes through `param.data` (torch_ema's copy_to / restore do that) bypass them."""
+        self.__dict__.pop("_native_version", None)
+        self.__dict__.pop("_native_diff_version", None)
+
+    def train(self, mode=True):
+        # The reference brackets every EMA swap with generator.eval() / generator.train() (train_double_latent_semantic.py:
+        # 487-489, :522 -> :267), and torch_ema writes through param.data, which no version counter sees: treat a mode switch
+        # as "weights may have changed".
+        self.invalidate_native()
+        return super().train(mode)
+
     def _roles(self, params):
         """`params` = tensors in _render_params() order -> which layer each one is."""
         names = [n for n, _ in self.named_parameters() if "mapping_network" not in n]

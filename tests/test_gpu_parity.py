@@ -1116,3 +1116,26 @@ def test_generator_step_through_ddp(tmp_path):
     assert max(_rel_err(wrapped[k], plain[k]) for k in plain) <= 1e-5
     assert any(np.abs(again[k] - wrapped[k]).max() > 0 for k in plain)
     print("[parity] generator step through DistributedDataParallel: gradients identical to the bare module; optimizer step picked up")
+
+
+def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():
+    """torch_ema's copy_to / restore write through param.data (no version bump).  The reference always follows them with
+    generator.eval() / .train(); a mode switch therefore invalidates the packed weights.  Also: explicit invalidate_native()."""
+    mod, spec, sd = _siren_module("texture", 32, 5)
+    pts = T(np.random.default_rng(0).uniform(-0.1, 0.1, (1, 64, 3)).astype(np.float32))
+    film = {k: T(v) for k, v in proc.film_params(spec, 1, seed=4).items()}
+    args = (film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"])
+    with torch.no_grad():
+        a = N_(mod.forward_with_frequencies_phase_shifts(pts, *args, None))
+        for p in mod._render_params():
+            p.data.mul_(1.05)                       # invisible to the version counters
+        stale = N_(mod.forward_with_frequencies_phase_shifts(pts, *args, None))
+        mod.eval()
+        b = N_(mod.forward_with_frequencies_phase_shifts(pts, *args, None))
+        for p in mod._render_params():
+            p.data.div_(1.05)
+        mod.invalidate_native()
+        c = N_(mod.forward_with_frequencies_phase_shifts(pts, *args, None))
+    assert np.array_equal(stale, a)                 # documents the blind spot the mode switch / invalidate_native() closes
+    assert np.abs(b - a).max() > 1e-3
+    assert np.abs(c - a).max() <= 1e-4 * max(1.0, np.abs(a).max())
