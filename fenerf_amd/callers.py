@@ -6,6 +6,7 @@ reference: mask2color + COLOR_MAP  train_double_latent_semantic.py:35-72
            multi-view loop         render_multiview_images_double_semantic.py:24-85
            voxel-grid evaluation   extract_double_semantic_shapes.py:13-90
            inversion loop          inverse_render_double_semantic.py:306-410
+           latent interpolation    render_video_interpolation_semantic.py:131-187
 """
 import numpy as np
 import torch
@@ -150,3 +151,37 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
     return dict(w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
                 w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
                 w_app_frequency_offsets=o_af.detach(), w_app_phase_shift_offsets=o_ap.detach(), losses=losses)
+
+
+def render_latent_interpolation(generator, z1_geo, z2_geo, z1_app, z2_app, options, n_frames=8, latent_type="both", psi=1.0,
+                                trajectory=None):
+    """Frames of a walk between two identities in FiLM space (render_video_interpolation_semantic.py:131-187, :314-380):
+    truncate both ends towards the mean FiLM parameters, interpolate the geometry and / or appearance side linearly
+    ('geo' | 'app' | 'both' | 'non'; 'app' sweeps t over [-1, 1] like the reference), render every frame with
+    staged_forward_with_frequencies.  trajectory: optional list of (pitch, yaw) per frame overriding v_mean / h_mean.
+    -> (frames [F, C, S, S], depth [F, S, S]) on the CPU."""
+    avg_fg, avg_pg, avg_fa, avg_pa = generator.generate_avg_frequencies()
+    trunc = lambda avg, raw: avg + psi * (raw - avg)
+    with torch.no_grad():
+        ends = []
+        for zg, za in ((z1_geo, z1_app), (z2_geo, z2_app)):
+            fg, pg = generator.siren.geo_mapping_network(zg)
+            fa, pa = generator.siren.app_mapping_network(za)
+            ends.append((trunc(avg_fg, fg), trunc(avg_fa, fa), trunc(avg_pg, pg), trunc(avg_pa, pa)))
+    lerp = lambda a, b, t: a * (1 - t) + b * t
+    frames, depths = [], []
+    for i, t in enumerate(np.linspace(0, 1, n_frames)):
+        t = float(t)
+        if latent_type == "app":
+            t = (t - 0.5) * 2
+        move_geo, move_app = latent_type in ("geo", "both"), latent_type in ("app", "both")
+        (fg1, fa1, pg1, pa1), (fg2, fa2, pg2, pa2) = ends
+        film = (lerp(fg1, fg2, t) if move_geo else fg1, lerp(fa1, fa2, t) if move_app else fa1,
+                lerp(pg1, pg2, t) if move_geo else pg1, lerp(pa1, pa2, t) if move_app else pa1)
+        kw = dict(options)
+        if trajectory is not None:
+            kw["v_mean"], kw["h_mean"] = trajectory[i]
+        img, depth, _ = generator.staged_forward_with_frequencies(*film, **kw)
+        frames.append(img)
+        depths.append(depth)
+    return torch.cat(frames), torch.cat(depths)

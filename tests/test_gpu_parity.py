@@ -565,6 +565,22 @@ def test_callers_multiview_and_voxel_grid():
     lock[..., -1] = -1
     ref = O.siren_forward(sd, spec, samples.numpy(), lock, film[0], film[1], film[2], film[3])
     np.testing.assert_allclose(vol.reshape(-1), ref[0, :, -1], atol=3e-3, rtol=2e-4)
+    # latent interpolation: end frames are the two identities, middle frames differ, 'geo' keeps the appearance side fixed
+    md = {**callers.multiview_kwargs(cur, image_size=8, ray_step_multiplier=1), "fill_mode": None, "sample_dist": None}
+    z1, z2 = torch.randn((1, 16), device=DEV), torch.randn((1, 16), device=DEV)
+    torch.manual_seed(1)
+    frames, depth = callers.render_latent_interpolation(gen, z1, z2, z1, z2, md, n_frames=3, latent_type="both", psi=0.7)
+    assert frames.shape == (3, 21, 8, 8) and depth.shape == (3, 8, 8) and not frames.is_cuda
+    torch.manual_seed(1)
+    gen.generate_avg_frequencies()
+    with torch.no_grad():
+        fg, pg = gen.siren.geo_mapping_network(z1)
+        fa, pa = gen.siren.app_mapping_network(z1)
+        tr = lambda a, r: a + 0.7 * (r - a)
+        first, _, _ = gen.staged_forward_with_frequencies(tr(gen.avg_frequencies_geo, fg), tr(gen.avg_frequencies_app, fa),
+                                                          tr(gen.avg_phase_shifts_geo, pg), tr(gen.avg_phase_shifts_app, pa), **md)
+    assert torch.allclose(frames[0], first[0], atol=1e-5)
+    assert not torch.allclose(frames[0], frames[1]) and not torch.allclose(frames[1], frames[2])
 
 
 def test_reference_checkpoint_renders_like_the_reference():
