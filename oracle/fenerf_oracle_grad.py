@@ -46,14 +46,19 @@ def merge_composite(fine, coarse, z_fine, z_coarse, noise=None, **kw):
 BOX_SCALE = 2 / 0.24
 
 
-def _film(x, w, b, freq, phase):
-    return torch.sin(freq[:, None, :] * (x @ w.T + b) + phase[:, None, :])
+def _film(x, w, b, freq, phase, taps=None):
+    theta = freq[:, None, :] * (x @ w.T + b) + phase[:, None, :]
+    if taps is not None:
+        theta.retain_grad()
+        taps.append(theta)
+    return torch.sin(theta)
 
 
-def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app, phase_app):
+def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app, phase_app, taps=None):
     """Differentiable restatement of siren.py:1509-1530 / :1210-1229 / :227-244.  sd: reference-named torch tensors
     (leaves with requires_grad as wanted); raw FiLM parameters split as (geo [B,n_geo*H], app [B,n_color*H]).
-    points / ray_dirs [B,P,3] -> [B,P,output_dim]."""
+    points / ray_dirs [B,P,3] -> [B,P,output_dim].  taps: optional list that receives every FiLM layer's theta (retain_grad
+    set), so tests can read dL/dtheta -- what fenerf_siren_backward writes."""
     H = spec["hidden_dim"]
     fg, fa = freq_geo * 15 + 30, freq_app * 15 + 30
     x = points * BOX_SCALE
@@ -65,10 +70,10 @@ def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app, pha
         feats = feats.reshape(B, -1, P).permute(0, 2, 1)
     for i in range(spec["n_geo"]):
         x = _film(x, sd[f"network.{i}.layer.weight"], sd[f"network.{i}.layer.bias"], fg[:, i * H:(i + 1) * H],
-                  phase_geo[:, i * H:(i + 1) * H])
+                  phase_geo[:, i * H:(i + 1) * H], taps)
     sigma = x @ sd["final_layer.weight"].T + sd["final_layer.bias"]
     if spec["kind"] == "spatial":
-        c = _film(torch.cat([ray_dirs, x], -1), sd["color_layer_sine.layer.weight"], sd["color_layer_sine.layer.bias"], fa, phase_app)
+        c = _film(torch.cat([ray_dirs, x], -1), sd["color_layer_sine.layer.weight"], sd["color_layer_sine.layer.bias"], fa, phase_app, taps)
         rgb = torch.sigmoid(c @ sd["color_layer_linear.0.weight"].T + sd["color_layer_linear.0.bias"])
         return torch.cat([rgb, sigma], -1)
     labels = x
@@ -77,6 +82,6 @@ def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app, pha
     c = torch.cat([ray_dirs, feats, x], -1) if feats is not None else torch.cat([ray_dirs, x], -1)
     for i in range(spec["n_color"]):
         c = _film(c, sd[f"color_layer_sine.{i}.layer.weight"], sd[f"color_layer_sine.{i}.layer.bias"], fa[:, i * H:(i + 1) * H],
-                  phase_app[:, i * H:(i + 1) * H])
+                  phase_app[:, i * H:(i + 1) * H], taps)
     rgb = torch.sigmoid(c @ sd["color_layer_linear.0.weight"].T + sd["color_layer_linear.0.bias"])
     return torch.cat([labels, rgb, sigma], -1)

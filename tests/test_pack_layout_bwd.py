@@ -1,0 +1,151 @@
+"""CPU check of the backward-chain weight stream (fenerf_pack.cpp::pack_weights_bwd) + the dataflow of
+fenerf_siren_bwd.hip: a numpy emulation of one wave -- same stream walk, same v_mfma_f32_32x32x2_f32 lane maps, same
+stage order (rgb head^T, colour layers, the colour-layer-0 stage with head^T and the grid-feature body, trunk) -- run
+on the blob the C packer produced and compared with dL/dtheta of every FiLM layer from torch fp64 autograd.
+Both packings: exact fp32 rows, and the power-of-two row-scaled rows of FENERF_PREC_F16X3 models (dz' = dz / s)."""
+import numpy as np
+import pytest
+import torch
+
+from fenerf_amd import _lib, procedural as proc
+from oracle import fenerf_oracle_grad as OG
+from test_pack_layout import H_, M_, PF, mfma
+
+
+def emulate_chain(blob, spec, theta, f_true, row_scale, d_out, out):
+    """theta [L][H][32] (reference values), f_true [L][H], row_scale [L][H] (s_i of the packing; ones for fp32),
+    d_out / out [32][C] -> (dtheta [L][H][32], d_e [32 points][32 channels])."""
+    H, NB, KGX = spec["hidden_dim"], spec["hidden_dim"] // 32, spec["hidden_dim"] // 8
+    pad = lambda n: (n + PF - 1) // PF * PF
+    KGXP = pad(KGX)
+    C0_KG = KGX + 4
+    C0_KGP = pad(C0_KG)
+    n_geo, n_color, C = spec["n_geo"], spec["n_color"], spec["output_dim"]
+    n_lab, L = C - 4, spec["n_geo"] + spec["n_color"]
+    entries = blob.reshape(-1, 64, 4).astype(np.float64)
+    cur = [NB]                       # ring cursor; the rgb-head^T block occupies entries [0, NB)
+
+    def next_entry():
+        e = entries[cur[0]]
+        cur[0] += 1
+        return e
+
+    dtheta = np.zeros((L, H, 32))
+    slab = np.zeros((H // 8, 64, 4))
+
+    def store(acc, layer, nb):       # acc[l][r] = dL/dx of feature 32nb + (r&3) + 8(r>>2) + 4h at point l&31
+        for r in range(16):
+            feat = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * H_
+            dt = acc[:, r] * np.cos(theta[layer][feat, M_])
+            dtheta[layer][feat, M_] = dt
+            # the kernel multiplies by f'' * 2 pi = f / s (f16x3) or f (fp32): dz' = dz / s
+            slab[nb * 4 + (r >> 2)][:, r & 3] = dt * f_true[layer][feat] / row_scale[layer][feat]
+
+    def load_act():
+        return slab.transpose(1, 0, 2).reshape(64, H // 2).copy()
+
+    def mfma_x(acc, act):
+        for kg in range(KGXP):
+            w = next_entry()
+            if kg < KGX:
+                for i in range(4):
+                    mfma(w[:, i], act[:, 4 * kg + i], acc)
+
+    # rgb head
+    s = out[M_, C - 4:C - 1]
+    dpre = d_out[M_, C - 4:C - 1] * s * (1 - s)
+    b0 = np.where(H_ == 1, dpre[:, 1], dpre[:, 0])
+    b1 = np.where(H_ == 1, 0.0, dpre[:, 2])
+    for nb in range(NB):
+        w = entries[nb]
+        acc = np.zeros((64, 16))
+        mfma(w[:, 0], b0, acc)
+        mfma(w[:, 1], b1, acc)
+        store(acc, L - 1, nb)
+    act = load_act()
+    for l in range(L - 1, n_geo, -1):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            mfma_x(acc, act)
+            store(acc, l - 1, nb)
+        act = load_act()
+    # colour layer 0 + heads (lane-half h multiplies head row 16h + s)
+    dh = np.zeros((64, 16))
+    for s_ in range(16):
+        row = 16 * H_ + s_
+        ch = np.where(row < n_lab, row, np.where(row == n_lab, C - 1, -1))
+        dh[:, s_] = np.where(ch >= 0, d_out[M_, np.maximum(ch, 0)], 0.0)
+    for nb in range(NB):
+        acc = np.zeros((64, 16))
+        for kg in range(C0_KGP):
+            w = next_entry()
+            if kg < KGX:
+                for i in range(4):
+                    mfma(w[:, i], act[:, 4 * kg + i], acc)
+            elif kg < C0_KG:
+                q = kg - KGX
+                for i in range(4):
+                    mfma(w[:, i], dh[:, 4 * q + i], acc)
+        store(acc, n_geo - 1, nb)
+    d_e = np.zeros((32, 32))
+    if spec["grid_ch"]:
+        acc = np.zeros((64, 16))
+        mfma_x(acc, act)
+        for r in range(16):
+            d_e[M_, (r & 3) + 8 * (r >> 2) + 4 * H_] = acc[:, r]
+    act = load_act()
+    for l in range(n_geo - 1, 0, -1):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            mfma_x(acc, act)
+            store(acc, l - 1, nb)
+        act = load_act()
+    assert cur[0] + PF == entries.shape[0], "backward stream must be consumed exactly (+ the PF tail pad)"
+    return dtheta, d_e
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0)])
+def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=13, sigma_gain=5.0, with_mapping=False)
+    blob = _lib.pack_backward_host(sd, spec, precision)
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-0.11, 0.11, (1, 32, 3))
+    dirs = rng.normal(size=(1, 32, 3)); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, 1, seed=13)
+    if kind == "spatial":
+        film["freq_app"] = proc.normal("film.freq_app", (1, H), 0.4, 13)
+        film["phase_app"] = proc.normal("film.phase_app", (1, H), 0.4, 13)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t(v) for k, v in sd.items()}
+    if grid:
+        sd64["spatial_embeddings"].requires_grad_(True)
+    taps = []
+    fl = {k: t(v).requires_grad_(True) for k, v in film.items()}      # makes every theta part of the autograd graph
+    out = OG.siren_forward(sd64, spec, t(pts), t(dirs), fl["freq_geo"], fl["phase_geo"], fl["freq_app"], fl["phase_app"], taps)
+    C, L = spec["output_dim"], spec["n_geo"] + spec["n_color"]
+    d_out = rng.normal(size=(32, C))
+    (out[0] * t(d_out)).sum().backward()
+    theta = np.stack([tp.detach().numpy()[0].T for tp in taps])               # [L][H][32]
+    ref = np.stack([tp.grad.numpy()[0].T for tp in taps])
+    f_true = np.concatenate([np.float32(film["freq_geo"][0]) * np.float32(15) + np.float32(30),
+                             np.float32(film["freq_app"][0]) * np.float32(15) + np.float32(30)]).astype(np.float64).reshape(L, H)
+    row_scale = np.ones((L, H))
+    if precision == "f16x3":              # s_i = 2^e_i * 16 with max|row| * 2^e_i in [0.5, 1)  (row_scales() of the packer)
+        names = [f"network.{i}.layer.weight" for i in range(spec["n_geo"])] + \
+                (["color_layer_sine.layer.weight"] if kind == "spatial" else [f"color_layer_sine.{i}.layer.weight" for i in range(spec["n_color"])])
+        for l, n in enumerate(names):
+            if l == 0:
+                continue
+            m = np.abs(sd[n].astype(np.float32)).max(1)
+            _, ex = np.frexp(m)
+            row_scale[l] = np.where(m > 0, np.ldexp(1.0, -ex), 1.0) * 16
+    got, d_e = emulate_chain(blob, spec, theta, f_true, row_scale, d_out, out.detach().numpy()[0])
+    # the stream holds fp32 values (the fp64-folded label head is rounded once): agreement to fp32 resolution
+    np.testing.assert_allclose(got, ref, atol=5e-7 * max(1.0, np.abs(ref).max()), rtol=1e-5)
+    if grid:   # d(grid features): check through the grid gradient's total (sum over voxels per channel = sum_p d_e[p][c] * weights ...)
+        # the sampled features enter colour layer 0 linearly: d_e[p] = W_c0[:, 3:35]^T dz_{n_geo}[p]
+        W = sd["color_layer_sine.0.layer.weight"].astype(np.float64)[:, 3:35]
+        dz = ref[spec["n_geo"]] * f_true[spec["n_geo"]][:, None]                 # [H][32]
+        np.testing.assert_allclose(d_e, (W.T @ dz).T, atol=5e-7 * max(1.0, np.abs(dz).max()), rtol=1e-5)
