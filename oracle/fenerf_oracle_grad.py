@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- differentiable (torch autograd, CPU, float64 by default) restatement of the parts of the
 hot path whose gradients the HIP backward kernels produce.  Only tests/ may import it; the product never does.
 
-Forward values are pinned against the numpy oracle (oracle/fenerf_oracle.py, itself pinned against reference golden
+Pinned twice: its gradients reproduce the REFERENCE's own autograd gradients on tests/golden/tiny_texture_grad.npz
+(tests/test_oracle_golden.py::test_grad_oracle_matches_reference_autograd; fixture made by tools/make_golden.py::run_grad_case
+importing the reference), and its forward values are pinned against the numpy oracle (oracle/fenerf_oracle.py, itself pinned against reference golden
 vectors) in tests/test_oracle_golden.py::test_grad_oracle_matches_numpy_oracle; the gradients are then whatever torch
 autograd derives from that forward -- which is exactly what the reference's training loop gets
 (train_double_latent_semantic.py: g_loss.backward() through generators.py:519 / volumetric_rendering.py:23-50).

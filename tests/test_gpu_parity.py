@@ -1155,3 +1155,36 @@ def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():
     assert np.array_equal(stale, a)                 # documents the blind spot the mode switch / invalidate_native() closes
     assert np.abs(b - a).max() > 1e-3
     assert np.abs(c - a).max() <= 1e-4 * max(1.0, np.abs(a).max())
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_generator_gradients_vs_reference_autograd(precision):
+    """tests/golden/tiny_texture_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies
+    (hierarchical 8+8, noise 0.2, white_back).  The native differentiable path on the recorded draws must reproduce the pixels
+    and every gradient (the reference ran fp32 on the CPU: its own rounding is ~1e-4 of the gradient scale)."""
+    g = load_golden("tiny_texture_grad")
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, dict(spec, z_dim=16), precision)
+    gen.train()
+    film, tf = _film(g, spec)
+    tf = [t.clone().requires_grad_(True) for t in tf]           # freq_geo, phase_geo, freq_app, phase_app
+    gen.draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"], g["rand_u_fine"],
+                                  g["rand_noise_fine"]])
+    kw = kwargs_from_golden(g)
+    px, _ = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], img_size=int(g["meta_S"]), fov=12, ray_start=0.88, ray_end=1.12,
+                                         num_steps=int(g["meta_N"]), h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5,
+                                         v_mean=np.pi * 0.5, hierarchical_sample=True, sample_dist="gaussian", **kw)
+    assert not gen.draws.arrays and px.requires_grad
+    assert np.abs(N_(px) - g["pixels"]).max() <= 1e-3
+    (px * T(g["loss_w"])).sum().backward()
+    worst = 0.0
+    for t, k in zip(tf, ("freq_geo", "phase_geo", "freq_app", "phase_app")):
+        worst = max(worst, _rel_err(N_(t.grad), g["gfilm_" + k]))
+    named = dict(gen.siren.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith("gparam_"):
+            worst = max(worst, _rel_err(N_(named[k[7:]].grad), g[k]))
+            n += 1
+    print(f"[parity] generator gradients vs the reference's autograd [{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
+    assert n == 33 and worst <= 2e-3

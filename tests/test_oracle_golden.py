@@ -247,3 +247,48 @@ def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
     got = OG.siren_forward({k: t(v) for k, v in sd.items()}, spec, t(pts), t(dirs), t(film["freq_geo"]), t(film["phase_geo"]),
                            t(film["freq_app"]), t(film["phase_app"]))
     np.testing.assert_allclose(got.numpy(), ref, atol=1e-11, rtol=1e-11)
+
+
+def test_grad_oracle_matches_reference_autograd():
+    """tests/golden/tiny_texture_grad.npz holds gradients computed by the REFERENCE's own autograd through
+    generator.forward_with_frequencies (tools/make_golden.py::run_grad_case).  The torch fp64 restatement used to check the
+    HIP backward kernels reproduces them on the recorded draws: this pins the gradient oracle to the reference directly,
+    not only through its forward values."""
+    import torch
+    from oracle import fenerf_oracle_grad as OG
+    g = load_golden("tiny_texture_grad")
+    spec = spec_from_golden(g)
+    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
+    assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-9
+    B, S, N = int(g["meta_B"]), int(g["meta_S"]), int(g["meta_N"])
+    kw = kwargs_from_golden(g)
+    film = proc.film_params(spec, B, seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]))
+    rd = _rand(g)
+    # constants of the graph (rays, coarse weights -> resampled depths): the numpy oracle in fp64
+    _, _, _, st = O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rd, hierarchical_sample=True, dtype=np.float64,
+                                   return_stages=True, **kw)
+    R = S * S
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t(v).requires_grad_(True) for k, v in sd.items() if "mapping_network" not in k}
+    fl = {k: t(v).requires_grad_(True) for k, v in film.items()}
+    args = (fl["freq_geo"], fl["phase_geo"], fl["freq_app"], fl["phase_app"])
+    dirs = np.broadcast_to(st["dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
+    fine_pts = st["origins"][:, :, None, :] + st["dirs"][:, :, None, :] * st["z_fine"]
+    c = OG.siren_forward(sd64, spec, t(st["points"].reshape(B, R * N, 3)), t(dirs), *args)
+    f = OG.siren_forward(sd64, spec, t(fine_pts.reshape(B, R * N, 3)), t(dirs), *args)
+    C = spec["output_dim"]
+    rgb, _, _ = OG.merge_composite(f.reshape(B * R, N, C), c.reshape(B * R, N, C), t(st["z_fine"].reshape(B * R, N)),
+                                   t(st["z_coarse"].reshape(B * R, N)), t(rd["noise_fine"].reshape(B * R, 2 * N)),
+                                   noise_std=kw["nerf_noise"], clamp_mode=kw["clamp_mode"], white_back=kw.get("white_back", False))
+    px = rgb.reshape(B, S, S, C - 1).permute(0, 3, 1, 2) * 2 - 1
+    np.testing.assert_allclose(px.detach().numpy(), g["pixels"], atol=2e-4)
+    (px * t(g["loss_w"])).sum().backward()
+
+    def rel(a, b):
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+    worst = 0.0
+    for k, v in fl.items():
+        worst = max(worst, rel(v.grad.numpy(), g["gfilm_" + k]))
+    for k, v in sd64.items():
+        worst = max(worst, rel(v.grad.numpy(), g["gparam_" + k]))
+    assert worst <= 2e-3, worst      # the reference ran fp32 on the CPU through a frequency-30 SIREN

@@ -193,6 +193,43 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
     return g, sd, out
 
 
+def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0):
+    """The reference's OWN autograd through generator.forward_with_frequencies (what g_loss.backward() replays,
+    train_double_latent_semantic.py:408-452): loss = sum(pixels * w) with a fixed w; gradients wrt the raw FiLM parameters
+    and every render parameter, plus the draws and the pixels.  fp32 on the CPU (gradient noise ~1e-5 relative)."""
+    siren_mod, gens, vr, cur = refs
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale)
+    tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in film.items()}
+    torch.manual_seed(4321 + seed)
+    common = dict(img_size=S, num_steps=N, hierarchical_sample=True, fov=CURR["fov"], ray_start=CURR["ray_start"],
+                  ray_end=CURR["ray_end"], h_stddev=CURR["h_stddev"], v_stddev=CURR["v_stddev"],
+                  h_mean=CURR["h_mean"], v_mean=CURR["v_mean"], sample_dist=CURR["sample_dist"])
+    common.update(kwargs)
+    with DrawRecorder() as dr:
+        px, poses = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
+    w = torch.from_numpy(np.random.default_rng(seed).normal(size=tuple(px.shape)).astype(np.float32))
+    (px * w).sum().backward()
+    out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_S=S, meta_N=N, meta_hier=1, meta_film_scale=film_scale,
+               meta_weights_checksum=proc.checksum(sd))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    for k, v in kwargs.items():
+        out["kw_" + k] = v
+    for k, v in rand_dict_from_draws(dr.draws, True).items():
+        out["rand_" + k] = v
+    out["pixels"], out["loss_w"] = np_(px), np_(w)
+    for k, t in tf.items():
+        out["gfilm_" + k] = np_(t.grad)
+    for n, p in g.siren.named_parameters():
+        if "mapping_network" not in n:
+            assert p.grad is not None, n
+            out["gparam_" + n] = np_(p.grad)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: pixels {out['pixels'].shape}, {sum(k.startswith('gparam_') for k in out)} parameter gradients -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_integration_variants(refs, base, name):
     """fancy_integration over every flag combination on one fixed (all_out, all_z) block + noise."""
     siren_mod, gens, vr, cur = refs
@@ -365,6 +402,8 @@ def main():
     run_camera_cases(refs, "camera_rays")
     run_mapping_and_full(refs, "tiny_texture_z_full")
     run_caller_helpers()
+    run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
+                  B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
 
     baseline = proc.model_spec("baseline", hidden_dim=32, z_dim=16)
     run_film_case(refs, "tiny_baseline_fwd", baseline, seed=5, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
