@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- differentiable (torch autograd, CPU, float64 by default) restatement of the parts of the
-hot path whose gradients the HIP backward kernels produce.  Only tests/ may import it; the product never does.
+hot path whose gradients the HIP backward kernels produce.  Only tests/ import it as the checker (and tools/bench_gstep.py as
+the eager-PyTorch baseline it times the native path against); the product (fenerf_amd/) never does.
 
 Pinned twice: its gradients reproduce the REFERENCE's own autograd gradients on tests/golden/tiny_texture_grad.npz
 (tests/test_oracle_golden.py::test_grad_oracle_matches_reference_autograd; fixture made by tools/make_golden.py::run_grad_case
