@@ -197,8 +197,12 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
         batch_size = z_app.shape[0]
         fg, pg = self.siren.geo_mapping_network(z_geo)
         fa, pa = self.siren.app_mapping_network(z_app)
-        part = kwargs.get("grad_points", img_size * img_size) != img_size * img_size     # part_forward (generators.py:459-461)
-        if part or self._wants_grad((fg, pg, fa, pa)):
+        if kwargs.get("grad_points", img_size * img_size) != img_size * img_size:
+            # generators.py:459-461 -- NB the reference drops the caller's sample_dist / lock_view_dependence on this path
+            # (camera at the mean pose, view dependence on); kept as is
+            return self.part_forward(z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
+                                     hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs)
+        if self._wants_grad((fg, pg, fa, pa)):
             pixels, depth, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                           v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                           lock_view_dependence, kwargs)
@@ -213,8 +217,12 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
     def part_forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                      hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
         """Gradient on kwargs['grad_points'] random rays only, the rest rendered without (generators.py:858-910)."""
-        return self.forward(z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
-                            hierarchical_sample, sample_dist=sample_dist, lock_view_dependence=lock_view_dependence, **kwargs)
+        batch_size = z_app.shape[0]
+        fg, pg = self.siren.geo_mapping_network(z_geo)
+        fa, pa = self.siren.app_mapping_network(z_app)
+        pixels, _, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
+                                                  h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence, kwargs)
+        return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
 
     def point_forward(self, transformed_points, transformed_ray_directions_expanded, transformed_ray_origins,
                       transformed_ray_directions, z_vals, z_geo, z_app, num_steps, hierarchical_sample,

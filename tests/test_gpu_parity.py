@@ -1188,3 +1188,33 @@ def test_generator_gradients_vs_reference_autograd(precision):
             n += 1
     print(f"[parity] generator gradients vs the reference's autograd [{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
     assert n == 33 and worst <= 2e-3
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_part_forward_vs_reference(precision):
+    """tests/golden/tiny_texture_part_forward.npz: the reference's generator.forward(z_geo, z_app, grad_points=11, ...) --
+    every draw including the randperm that picks the differentiable rays, the pixels, and the render-weight gradients of a
+    fixed loss (only the picked rays carry gradient).  Same draw order, same pixels, same gradients."""
+    g = load_golden("tiny_texture_part_forward")
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, dict(spec, z_dim=16), precision)
+    gen.train()
+    draws = [g[k] for k in sorted(k for k in g if k.startswith("draw"))]
+    gen.draws = VR.RecordedDraws(draws)
+    kw = dict(img_size=int(g["meta_S"]), num_steps=int(g["meta_N"]), hierarchical_sample=True, clamp_mode="relu", nerf_noise=0.1,
+              grad_points=int(g["meta_G"]), fov=12, ray_start=0.88, ray_end=1.12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5,
+              v_mean=np.pi * 0.5, sample_dist="gaussian")
+    px, poses = gen(T(g["z_geo"]), T(g["z_app"]), **kw)
+    assert not gen.draws.arrays, "all recorded draws consumed, in order"
+    np.testing.assert_allclose(N_(poses), g["poses"], atol=1e-6)
+    assert np.abs(N_(px) - g["pixels"]).max() <= 1e-3
+    (px * T(g["loss_w"])).sum().backward()
+    named = dict(gen.siren.named_parameters())
+    worst, n = 0.0, 0
+    for k in g:
+        if k.startswith("gparam_"):
+            worst = max(worst, _rel_err(N_(named[k[7:]].grad), g[k]))
+            n += 1
+    print(f"[parity] part_forward vs the reference [{precision}]: pixels max|err| {np.abs(N_(px) - g['pixels']).max():.1e}, "
+          f"worst relative gradient error over {n} tensors {worst:.2e}")
+    assert n == 33 and worst <= 2e-3

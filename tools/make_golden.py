@@ -230,6 +230,40 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
     print(f"{name}: pixels {out['pixels'].shape}, {sum(k.startswith('gparam_') for k in out)} parameter gradients -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_part_forward_case(refs, name):
+    """generator.forward(..., grad_points=G) = part_forward (generators.py:459-461, :858-910): records every draw including
+    the randperm that picks the differentiable rays, the pixels and the gradient of a fixed loss wrt z-mapped FiLM inputs'
+    source (the render weights) -- only the G picked rays carry gradient."""
+    siren_mod, gens, vr, cur = refs
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16)
+    seed = 2          # chosen so the mean-pose render is not empty (the relu density is dead for some procedural seeds)
+    g, sd = build_ref_generator(refs, spec, seed=seed, sigma_gain=60.0)
+    B, S, N, G = 2, 6, 6, 11
+    zg = torch.from_numpy(proc.normal("z_geo", (B, 16), 1.0, seed))
+    za = torch.from_numpy(proc.normal("z_app", (B, 16), 1.0, seed))
+    kw = dict(img_size=S, num_steps=N, hierarchical_sample=True, clamp_mode="relu", nerf_noise=0.1, grad_points=G, **CURR)
+    torch.manual_seed(77)
+    with DrawRecorder() as dr:
+        px, poses = g.forward(zg, za, **kw)
+    assert float(px.detach().std()) > 0.05, "degenerate (empty) render: pick another seed"
+    w = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(px.shape)).astype(np.float32))
+    (px * w).sum().backward()
+    kinds = [k for k, _ in dr.draws]
+    # forward() calls part_forward with sample_dist=None (generators.py:461): the camera sits at the mean pose, no angle draws
+    assert kinds == ["rand", "randperm", "randn", "rand", "randn", "randn", "rand", "randn"], kinds
+    out = dict(z_geo=np_(zg), z_app=np_(za), meta_weights_checksum=proc.checksum(sd), meta_B=B, meta_S=S, meta_N=N, meta_G=G,
+               meta_seed=seed, meta_sigma_gain=60.0, pixels=np_(px), poses=np_(poses), loss_w=np_(w))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    for i, (kind, v) in enumerate(dr.draws):
+        out[f"draw{i:02d}_{kind}"] = v
+    for n, p in g.siren.named_parameters():
+        if "mapping_network" not in n and p.grad is not None:
+            out["gparam_" + n] = np_(p.grad)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: part_forward with {G} of {S * S} rays differentiable, {len(dr.draws)} draws")
+
+
 def run_integration_variants(refs, base, name):
     """fancy_integration over every flag combination on one fixed (all_out, all_z) block + noise."""
     siren_mod, gens, vr, cur = refs
@@ -402,6 +436,7 @@ def main():
     run_camera_cases(refs, "camera_rays")
     run_mapping_and_full(refs, "tiny_texture_z_full")
     run_caller_helpers()
+    run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
 
