@@ -1158,22 +1158,31 @@ def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_generator_gradients_vs_reference_autograd(precision):
-    """tests/golden/tiny_texture_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies
-    (hierarchical 8+8, noise 0.2, white_back).  The native differentiable path on the recorded draws must reproduce the pixels
-    and every gradient (the reference ran fp32 on the CPU: its own rounding is ~1e-4 of the gradient scale)."""
-    g = load_golden("tiny_texture_grad")
+@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad"])
+def test_generator_gradients_vs_reference_autograd(name, precision):
+    """tests/golden/tiny_*_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies (texture:
+    hierarchical 8+8, noise, white_back; baseline: softplus, noise, last_back; single-latent: locked view direction).  The
+    native differentiable path on the recorded draws must reproduce the pixels and every gradient (the reference ran fp32 on
+    the CPU: its own rounding is ~1e-4 of the gradient scale)."""
+    g = load_golden(name)
     spec = spec_from_golden(g)
-    gen = _make_generator(g, dict(spec, z_dim=16), precision)
+    kind = spec["kind"]
+    gen = (_make_spatial_generator if kind == "spatial" else _make_generator)(g, dict(spec, z_dim=16), precision)
     gen.train()
     film, tf = _film(g, spec)
+    if kind == "spatial":      # the golden's film helper draws the colour slice like the generator test above
+        film = proc.film_params(spec, int(g["meta_B"]), seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]))
+        tf = [T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app")]
     tf = [t.clone().requires_grad_(True) for t in tf]           # freq_geo, phase_geo, freq_app, phase_app
     gen.draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"], g["rand_u_fine"],
                                   g["rand_noise_fine"]])
     kw = kwargs_from_golden(g)
-    px, _ = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], img_size=int(g["meta_S"]), fov=12, ray_start=0.88, ray_end=1.12,
-                                         num_steps=int(g["meta_N"]), h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5,
-                                         v_mean=np.pi * 0.5, hierarchical_sample=True, sample_dist="gaussian", **kw)
+    common = dict(img_size=int(g["meta_S"]), fov=12, ray_start=0.88, ray_end=1.12, num_steps=int(g["meta_N"]), h_stddev=0.3,
+                  v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, hierarchical_sample=True, sample_dist="gaussian", **kw)
+    if kind == "spatial":
+        px, _ = gen.forward_with_frequencies(torch.cat([tf[0], tf[2]], -1), torch.cat([tf[1], tf[3]], -1), **common)
+    else:
+        px, _ = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], **common)
     assert not gen.draws.arrays and px.requires_grad
     assert np.abs(N_(px) - g["pixels"]).max() <= 1e-3
     (px * T(g["loss_w"])).sum().backward()
@@ -1186,8 +1195,10 @@ def test_generator_gradients_vs_reference_autograd(precision):
         if k.startswith("gparam_"):
             worst = max(worst, _rel_err(N_(named[k[7:]].grad), g[k]))
             n += 1
-    print(f"[parity] generator gradients vs the reference's autograd [{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
-    assert n == 33 and worst <= 2e-3
+    print(f"[parity] generator gradients vs the reference's autograd {name}[{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
+    # bound = the reference's own fp32 rounding: the fp64 restatement differs from these fixtures by 1.5e-4 (texture),
+    # 4.8e-3 (baseline: softplus + last_back cancellation in final_layer.weight) and 1.8e-4 (single latent) on the CPU
+    assert n == {"texture": 33, "baseline": 30, "spatial": 22}[kind] and worst <= 5e-3
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -249,14 +249,15 @@ def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
     np.testing.assert_allclose(got.numpy(), ref, atol=1e-11, rtol=1e-11)
 
 
-def test_grad_oracle_matches_reference_autograd():
-    """tests/golden/tiny_texture_grad.npz holds gradients computed by the REFERENCE's own autograd through
+@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad"])
+def test_grad_oracle_matches_reference_autograd(name):
+    """tests/golden/tiny_*_grad.npz hold gradients computed by the REFERENCE's own autograd through
     generator.forward_with_frequencies (tools/make_golden.py::run_grad_case).  The torch fp64 restatement used to check the
     HIP backward kernels reproduces them on the recorded draws: this pins the gradient oracle to the reference directly,
     not only through its forward values."""
     import torch
     from oracle import fenerf_oracle_grad as OG
-    g = load_golden("tiny_texture_grad")
+    g = load_golden(name)
     spec = spec_from_golden(g)
     sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
     assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-9
@@ -264,8 +265,12 @@ def test_grad_oracle_matches_reference_autograd():
     kw = kwargs_from_golden(g)
     film = proc.film_params(spec, B, seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]))
     rd = _rand(g)
+    ofilm = dict(film)
+    if spec["kind"] == "spatial":      # the numpy oracle takes the single-latent [B, 9H] tensors
+        ofilm = dict(freq_geo=np.concatenate([film["freq_geo"], film["freq_app"]], -1),
+                     phase_geo=np.concatenate([film["phase_geo"], film["phase_app"]], -1))
     # constants of the graph (rays, coarse weights -> resampled depths): the numpy oracle in fp64
-    _, _, _, st = O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rd, hierarchical_sample=True, dtype=np.float64,
+    _, _, _, st = O.render_forward(sd, spec, ofilm, S, 12, 0.88, 1.12, N, rd, hierarchical_sample=True, dtype=np.float64,
                                    return_stages=True, **kw)
     R = S * S
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
@@ -273,22 +278,25 @@ def test_grad_oracle_matches_reference_autograd():
     fl = {k: t(v).requires_grad_(True) for k, v in film.items()}
     args = (fl["freq_geo"], fl["phase_geo"], fl["freq_app"], fl["phase_app"])
     dirs = np.broadcast_to(st["dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
+    if kw.get("lock_view_dependence", False):
+        dirs = np.zeros_like(dirs)
+        dirs[..., -1] = -1
     fine_pts = st["origins"][:, :, None, :] + st["dirs"][:, :, None, :] * st["z_fine"]
     c = OG.siren_forward(sd64, spec, t(st["points"].reshape(B, R * N, 3)), t(dirs), *args)
     f = OG.siren_forward(sd64, spec, t(fine_pts.reshape(B, R * N, 3)), t(dirs), *args)
     C = spec["output_dim"]
     rgb, _, _ = OG.merge_composite(f.reshape(B * R, N, C), c.reshape(B * R, N, C), t(st["z_fine"].reshape(B * R, N)),
                                    t(st["z_coarse"].reshape(B * R, N)), t(rd["noise_fine"].reshape(B * R, 2 * N)),
-                                   noise_std=kw["nerf_noise"], clamp_mode=kw["clamp_mode"], white_back=kw.get("white_back", False))
+                                   noise_std=kw["nerf_noise"], clamp_mode=kw["clamp_mode"], white_back=kw.get("white_back", False),
+                                   last_back=kw.get("last_back", False))
     px = rgb.reshape(B, S, S, C - 1).permute(0, 3, 1, 2) * 2 - 1
     np.testing.assert_allclose(px.detach().numpy(), g["pixels"], atol=2e-4)
     (px * t(g["loss_w"])).sum().backward()
 
     def rel(a, b):
         return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
-    worst = 0.0
-    for k, v in fl.items():
-        worst = max(worst, rel(v.grad.numpy(), g["gfilm_" + k]))
-    for k, v in sd64.items():
-        worst = max(worst, rel(v.grad.numpy(), g["gparam_" + k]))
-    assert worst <= 2e-3, worst      # the reference ran fp32 on the CPU through a frequency-30 SIREN
+    errs = {k: rel(v.grad.numpy(), g["gfilm_" + k]) for k, v in fl.items()}
+    errs.update({k: rel(v.grad.numpy(), g["gparam_" + k]) for k, v in sd64.items()})
+    worst = max(errs, key=errs.get)
+    print(f"[oracle] {name}: worst relative gradient error {errs[worst]:.2e} ({worst})")
+    assert errs[worst] <= 5e-3, (worst, errs[worst])      # the reference ran fp32 on the CPU through a frequency-30 SIREN

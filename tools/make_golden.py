@@ -207,7 +207,13 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
                   h_mean=CURR["h_mean"], v_mean=CURR["v_mean"], sample_dist=CURR["sample_dist"])
     common.update(kwargs)
     with DrawRecorder() as dr:
-        px, poses = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
+        if spec["kind"] == "spatial":     # single latent: one [B, 9H] frequency / phase tensor (the colour layer uses the last H)
+            freq = torch.cat([tf["freq_geo"], tf["freq_app"]], -1)
+            phase = torch.cat([tf["phase_geo"], tf["phase_app"]], -1)
+            px, poses = g.forward_with_frequencies(freq, phase, **common)
+        else:
+            px, poses = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
+    assert float(px.detach().std()) > 0.05, "degenerate (empty) render: pick another seed"
     w = torch.from_numpy(np.random.default_rng(seed).normal(size=tuple(px.shape)).astype(np.float32))
     (px * w).sum().backward()
     out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_S=S, meta_N=N, meta_hier=1, meta_film_scale=film_scale,
@@ -439,6 +445,10 @@ def main():
     run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
+    run_grad_case(refs, "tiny_baseline_grad", proc.model_spec("baseline", hidden_dim=32, z_dim=16), seed=5, sigma_gain=60.0,
+                  B=1, S=6, N=6, kwargs=dict(clamp_mode="softplus", nerf_noise=0.3, last_back=True))
+    run_grad_case(refs, "tiny_spatial_grad", proc.model_spec("spatial", hidden_dim=32, z_dim=16), seed=8, sigma_gain=60.0,
+                  B=2, S=5, N=7, kwargs=dict(clamp_mode="relu", nerf_noise=0.0, lock_view_dependence=True))
 
     baseline = proc.model_spec("baseline", hidden_dim=32, z_dim=16)
     run_film_case(refs, "tiny_baseline_fwd", baseline, seed=5, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
