@@ -12,7 +12,8 @@
 
 namespace fenerf {
 
-#define MAX_M 128  // samples per ray handled by one wave (2 per lane)
+#define MAX_M 256  // samples per ray handled by one wave
+#define SLOTS 4    // samples per lane: slot s of lane l is sample 64 s + l (slots past M are skipped)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -56,19 +57,19 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
   const int M = P.M, C = P.C, N = P.N;
   const long long nwaves = (long long)gridDim.x * 4;
   for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
-    float zk[2], sg[2];
-    int src[2];
+    float zk[SLOTS], sg[SLOTS];
+    int src[SLOTS];
     // ---- sorted order
     if (MERGE) {
       // source index i < N: fine sample i, else coarse sample i-N   (cat([fine, coarse]), generators.py:508-509)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) s_z[wv][i] = i < N ? P.z_a[ray * N + i] : P.z_b[ray * N + (i - N)];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) {
           const float zi = s_z[wv][i];
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) { s_ord[wv][i] = i; s_zs[wv][i] = P.z_a[ray * M + i]; }
       }
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- per-sample alpha (volumetric_rendering.py:23-34)
-    float alpha[2], tt[2];
+    float alpha[SLOTS], tt[SLOTS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
       const int k = lane + 64 * s;
       alpha[s] = 0.f; tt[s] = 1.f; zk[s] = 0.f; src[s] = 0; sg[s] = 0.f;
       if (k < M) {
@@ -114,27 +115,30 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
       }
     }
     // ---- exclusive transmittance: T_k = prod_{j<k} (1 - alpha_j + 1e-10)   (cumprod, :36-37)
-    const float inc0 = wave_scan_mul(tt[0], lane);
-    const float tot0 = __shfl(inc0, 63, 64);
-    float ex0 = __shfl_up(inc0, 1, 64);
-    if (lane == 0) ex0 = 1.f;
-    float w[2];
-    w[0] = alpha[0] * ex0;
-    w[1] = 0.f;
-    if (M > 64) {
-      const float inc1 = wave_scan_mul(tt[1], lane);
-      float ex1 = __shfl_up(inc1, 1, 64);
-      if (lane == 0) ex1 = 1.f;
-      w[1] = alpha[1] * (tot0 * ex1);
+    // two-level: wavefront product scan inside a 64-sample slot, running product of the slots before it
+    float w[SLOTS];
+    float carry = 1.f, wacc = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      w[s] = 0.f;
+      if (64 * s < M) {                                  // wave-uniform
+        const float inc = wave_scan_mul(tt[s], lane);
+        float ex = __shfl_up(inc, 1, 64);
+        if (lane == 0) ex = 1.f;
+        w[s] = alpha[s] * (s == 0 ? ex : carry * ex);
+        const float tot = __shfl(inc, 63, 64);
+        carry = s == 0 ? tot : carry * tot;
+      }
+      wacc = s == 0 ? w[0] : wacc + w[s];
     }
-    const float wsum = wave_sum(w[0] + w[1]);
+    const float wsum = wave_sum(wacc);
     if (P.o.last_back) {   // weights[:, :, -1] += (1 - weights_sum)   (:40-41)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < SLOTS; ++s)
         if (lane + 64 * s == M - 1) w[s] += 1.f - wsum;
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
       const int k = lane + 64 * s;
       if (k < M) {
         s_w[wv][k] = w[s];
@@ -143,7 +147,10 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
       }
     }
     if (P.out_wsum && lane == 0) P.out_wsum[ray] = wsum;
-    const float depth = wave_sum(w[0] * zk[0] + w[1] * zk[1]);   // (:44)
+    float dacc = w[0] * zk[0];
+#pragma unroll
+    for (int s = 1; s < SLOTS; ++s) dacc += w[s] * zk[s];
+    const float depth = wave_sum(dacc);   // (:44)
     if (P.out_depth && lane == 0) P.out_depth[ray] = depth;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
@@ -210,13 +217,13 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
     // ---- sorted order (identical to the forward kernel)
     if (MERGE) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) s_z[wv][i] = i < N ? P.z_a[ray * N + i] : P.z_b[ray * N + (i - N)];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) {
           const float zi = s_z[wv][i];
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < M) { s_ord[wv][i] = i; s_zs[wv][i] = P.z_a[ray * M + i]; }
       }
@@ -239,15 +246,15 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- forward quantities per sample + dL/dw'_k = sum_c g_c row_k[c]
-    float alpha[2], tt[2], dact[2], delta[2], gw[2];
-    const float* row[2];
-    float* drow[2];
+    float alpha[SLOTS], tt[SLOTS], dact[SLOTS], delta[SLOTS], gw[SLOTS];
+    const float* row[SLOTS];
+    float* drow[SLOTS];
     const float* g = P.g_rgb + ray * (long long)nch;
     float gsum = 0.f;
     for (int c = lane; c < nch; c += 64) gsum += g[c];
     gsum = wave_sum(gsum);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
       const int k = lane + 64 * s;
       alpha[s] = 0.f; tt[s] = 1.f; dact[s] = 0.f; delta[s] = 0.f; gw[s] = 0.f; row[s] = nullptr; drow[s] = nullptr;
       if (k < M) {
@@ -274,45 +281,57 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
       }
     }
     // exclusive transmittance, weights (as forward)
-    const float inc0 = wave_scan_mul(tt[0], lane);
-    const float tot0 = __shfl(inc0, 63, 64);
-    float T[2];
-    T[0] = __shfl_up(inc0, 1, 64);
-    if (lane == 0) T[0] = 1.f;
-    T[1] = 1.f;
-    if (M > 64) {
-      const float inc1 = wave_scan_mul(tt[1], lane);
-      float ex1 = __shfl_up(inc1, 1, 64);
-      if (lane == 0) ex1 = 1.f;
-      T[1] = tot0 * ex1;
+    float T[SLOTS], w[SLOTS], wp[SLOTS];   // wp: weights actually used in the colour sum (after last_back)
+    float carry = 1.f, wacc = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      T[s] = 1.f; w[s] = 0.f;
+      if (64 * s < M) {
+        const float inc = wave_scan_mul(tt[s], lane);
+        float ex = __shfl_up(inc, 1, 64);
+        if (lane == 0) ex = 1.f;
+        T[s] = s == 0 ? ex : carry * ex;
+        w[s] = alpha[s] * T[s];
+        const float tot = __shfl(inc, 63, 64);
+        carry = s == 0 ? tot : carry * tot;
+      }
+      wp[s] = w[s];
+      wacc = s == 0 ? w[0] : wacc + w[s];
     }
-    float w[2] = {alpha[0] * T[0], (M > 64) ? alpha[1] * T[1] : 0.f};
-    const float wsum = wave_sum(w[0] + w[1]);
-    float wp[2] = {w[0], w[1]};   // weights actually used in the colour sum (after last_back)
+    const float wsum = wave_sum(wacc);
     if (P.o.last_back) {
       // w'_last = w_last + 1 - sum_j w_j  ->  dL/dw_j = dL/dw'_j - dL/dw'_last
       const int ls = (M - 1) >> 6, ll = (M - 1) & 63;
-      const float g_last = __shfl(ls ? gw[1] : gw[0], ll, 64);
+      float gl = gw[0];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 1; s < SLOTS; ++s) gl = ls == s ? gw[s] : gl;
+      const float g_last = __shfl(gl, ll, 64);
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
         if (lane + 64 * s == M - 1) wp[s] += 1.f - wsum;
         gw[s] -= g_last;
       }
     }
     // rgb += (1 - wsum) for white_back, -= for black_back (wsum taken BEFORE the last_back adjustment,
     // volumetric_rendering.py:40-48): d/dw_j = -+ sum_c g_c
-    if (P.o.white_back) { gw[0] -= gsum; gw[1] -= gsum; }
-    if (P.o.black_back) { gw[0] += gsum; gw[1] += gsum; }
-    // S_k = sum_{j>k} gw_j w_j
-    float q[2] = {gw[0] * w[0], gw[1] * w[1]};
-    if (lane + 64 >= M) q[1] = 0.f;
-    if (lane >= M) q[0] = 0.f;
-    const float suf1 = wave_suffix_incl(q[1], lane);
-    const float tot1 = __shfl(suf1, 0, 64);
-    const float suf0 = wave_suffix_incl(q[0], lane) + tot1;
-    const float S[2] = {suf0 - q[0], suf1 - q[1]};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < SLOTS; ++s) {
+      if (P.o.white_back) gw[s] -= gsum;
+      if (P.o.black_back) gw[s] += gsum;
+    }
+    // S_k = sum_{j>k} gw_j w_j
+    float S[SLOTS];
+    float tail = 0.f;                          // sum over all later slots
+#pragma unroll
+    for (int s = SLOTS - 1; s >= 0; --s) {
+      const float q = (lane + 64 * s < M) ? gw[s] * w[s] : 0.f;
+      const float suf = wave_suffix_incl(q, lane);
+      S[s] = (s == SLOTS - 1 ? suf : suf + tail) - q;
+      const float tot = __shfl(suf, 0, 64);
+      tail = s == SLOTS - 1 ? tot : tail + tot;
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
       const int k = lane + 64 * s;
       if (k < M) {
         const float dalpha = T[s] * gw[s] - S[s] / tt[s];

@@ -185,9 +185,9 @@ def test_composite_variants_vs_reference():
 
 
 def test_composite_max_samples_and_empty():
-    """M = 128 (two samples per lane, the documented maximum), M = 1, zero rays."""
+    """M = 256 (four samples per lane, the documented maximum), slot boundaries, M = 1, zero rays."""
     rng = np.random.default_rng(5)
-    for M in (128, 65, 64, 1):
+    for M in (256, 193, 129, 128, 65, 64, 1):
         rs = rng.normal(size=(3, 7, M, 22)).astype(np.float32)
         rs[..., -1] *= 30
         z = np.sort(rng.uniform(0.88, 1.12, (3, 7, M, 1)).astype(np.float32), axis=2)
@@ -203,7 +203,7 @@ def test_composite_max_samples_and_empty():
     e = native.composite(torch.empty((0, 4, 22), device=DEV), torch.empty((0, 4), device=DEV), None, _lib.composite_opts("relu"))
     assert e[0].shape == (0, 21)
     with pytest.raises(_lib.FenerfError):
-        native.composite(torch.zeros((1, 129, 22), device=DEV), torch.zeros((1, 129), device=DEV), None, _lib.composite_opts("relu"))
+        native.composite(torch.zeros((1, 257, 22), device=DEV), torch.zeros((1, 257), device=DEV), None, _lib.composite_opts("relu"))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -638,7 +638,7 @@ def _grad_case(BR, N, C, seed, merge):
 @pytest.mark.parametrize("clamp,last_back,white,black,noise_std", [("relu", False, False, False, 0.0), ("softplus", False, False, False, 0.5),
                                                                     ("relu", True, False, False, 0.3), ("relu", False, True, False, 0.0),
                                                                     ("softplus", True, False, True, 0.2)])
-@pytest.mark.parametrize("N", [1, 7, 24, 64, 100])
+@pytest.mark.parametrize("N", [1, 7, 24, 64, 100, 150, 256])
 def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise_std):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(37, N, 22, 5 + N, False)
@@ -655,7 +655,7 @@ def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise
     assert err <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("N", [12, 24, 64])
+@pytest.mark.parametrize("N", [12, 24, 64, 72, 128])
 def test_merge_composite_backward_vs_autograd(N):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(29, N, 22, 40 + N, True)
@@ -1229,3 +1229,33 @@ def test_part_forward_vs_reference(precision):
     print(f"[parity] part_forward vs the reference [{precision}]: pixels max|err| {np.abs(N_(px) - g['pixels']).max():.1e}, "
           f"worst relative gradient error over {n} tensors {worst:.2e}")
     assert n == 33 and worst <= 2e-3
+
+
+def test_merge_composite_and_render_beyond_128_samples():
+    """72+72 and 128+128 samples per ray (e.g. --ray_step_multiplier 3 on a 24-step curriculum): the merge / composite kernels
+    keep four samples per lane.  Merge vs the numpy oracle; a full hierarchical render runs end to end."""
+    rng = np.random.default_rng(11)
+    for N in (72, 128):
+        BR = 9
+        fine = rng.normal(size=(BR, N, 22)).astype(np.float32); fine[..., -1] *= 20
+        coarse = rng.normal(size=(BR, N, 22)).astype(np.float32); coarse[..., -1] *= 20
+        zf = np.sort(rng.uniform(0.88, 1.12, (BR, N)).astype(np.float32), -1)
+        zc = np.sort(rng.uniform(0.88, 1.12, (BR, N)).astype(np.float32), -1)
+        zf[:, 3] = zc[:, 5]                           # ties: stable order (fine first)
+        zf.sort(-1)
+        opts = _lib.composite_opts("relu", last_back=True)
+        rgb, depth, w, ws, zs = native.merge_composite(T(fine), T(coarse), T(zf), T(zc), None, opts)
+        mo, mz = O.merge_sorted(fine[None], coarse[None], zf[None, ..., None], zc[None, ..., None])
+        r_rgb, r_depth, r_w = O.fancy_integration(mo, mz, clamp_mode="relu", last_back=True)
+        np.testing.assert_array_equal(N_(zs), mz[0, ..., 0])
+        np.testing.assert_allclose(N_(rgb), r_rgb[0], atol=3e-5)
+        np.testing.assert_allclose(N_(w), r_w[0, ..., 0], atol=1e-5)
+        np.testing.assert_allclose(N_(depth), r_depth[0, ..., 0], atol=3e-5)
+    nat, spec, sd = _native_for("tiny_texture_fwd", "f16x3")
+    g = load_golden("tiny_texture_fwd")
+    film, tf = _film(g, spec)
+    B, S_, N = int(g["meta_B"]), 4, 72
+    o, d, z, _, _ = VR.sample_rays(B, N, torch.device(DEV), 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((B * S_ * S_, N), device=DEV)
+    rgb, depth, _, _ = nat.render(o, d, z, u, None, None, *tf, _lib.composite_opts("relu"), hierarchical=True)
+    assert rgb.shape == (B, S_ * S_, 21) and torch.isfinite(rgb).all() and torch.isfinite(depth).all()
