@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
-from .autograd import CompositeFunction, MergeCompositeFunction
+from .autograd import CompositeFunction, HierarchicalRenderFunction, MergeCompositeFunction
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
 
 
@@ -135,20 +135,18 @@ class _Generator3dBase(nn.Module):
             rd = None if lock_view_dependence else dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, R * N, 3)
             return _siren_autograd.siren_apply(self.siren, pts.reshape(B, R * N, 3), rd, fg, pg, fa, pa)
 
-        coarse = field(z_c)
         if not hierarchical_sample:
+            coarse = field(z_c)
             rgb, depth = CompositeFunction.apply(coarse.reshape(B * R, N, C), z_c.reshape(B * R, N),
                                                  noise_f.reshape(B * R, M) if use_noise else None, opts)
             return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
-        with torch.no_grad():
-            copts = _lib.composite_opts(kwargs["clamp_mode"], noise_std)
-            _, _, w_c, _ = native.composite(coarse.detach().reshape(B * R, N, C), z_c.reshape(B * R, N),
-                                            noise_c.reshape(B * R, N) if use_noise else None, copts, want_wsum=False)
-            z_f = native.resample(z_c.reshape(B * R, N), w_c, u)
-        fine = field(z_f.reshape(B, R, N))
-        rgb, depth = MergeCompositeFunction.apply(fine.reshape(B * R, N, C), coarse.reshape(B * R, N, C), z_f, z_c.reshape(B * R, N),
-                                                  noise_f.reshape(B * R, M) if use_noise else None, opts)
-        return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
+        # both SIREN passes + the merged composite as one autograd node (one chain launch and one set of weight-gradient
+        # launches for the two passes)
+        copts = _lib.composite_opts(kwargs["clamp_mode"], noise_std)
+        return HierarchicalRenderFunction.apply(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u,
+                                                noise_c.reshape(B * R, N) if use_noise else None,
+                                                noise_f.reshape(B * R, M) if use_noise else None, fg, pg, fa, pa,
+                                                *self.siren._render_params())
 
     def _finish(self, pixels, batch_size, img_size):
         if self.softmax_label:

@@ -194,17 +194,22 @@ class NativeModel:
                                                        _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
-    def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa):
-        """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators [L,H,B*P]) and the
-        sampled grid features [B*P,32] (None without a grid) that siren_backward consumes."""
+    def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa, out=None, tape=None, tape_e=None):
+        """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators, L*H*B*P floats of
+        32-point register dumps) and the sampled grid features [B*P,32] (None without a grid) that siren_backward consumes.
+        out / tape / tape_e may be preallocated (contiguous views into larger buffers: several passes, one backward)."""
         B, P = points.shape[0], points.shape[1]
         H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
         fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
         points = _f32(points, self.device)
         ray_dirs = _f32(ray_dirs, self.device) if ray_dirs is not None else None
-        out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
-        tape = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
-        tape_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device) if self.spec["grid_ch"] else None
+        if out is None:
+            out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
+        if tape is None:
+            tape = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
+        if tape_e is None and self.spec["grid_ch"]:
+            tape_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device)
+        assert out.numel() == B * P * self.C and tape.numel() == L * H * B * P
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
             _lib.check(_lib.lib().fenerf_siren_forward_save(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa),

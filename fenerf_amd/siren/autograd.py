@@ -23,6 +23,31 @@ def _fold_label_head(label_params):
     return A, c
 
 
+def assemble_param_grads(module, nat, params, r, points, d_e, need_params):
+    """FenerfSirenGrads buffers (dict r) -> gradients in the order of `params` (module._render_params())."""
+    roles = module._roles(params)
+    n_lab = nat.spec["output_dim"] - 4
+    grads = {}
+    for (W, b), gw, gb in zip(roles["geo"] + roles["color"], r["geo_w"] + r["color_w"], r["geo_b"] + r["color_b"]):
+        grads[id(W)], grads[id(b)] = gw, gb
+    sw, sb = roles["sigma"]
+    grads[id(sw)], grads[id(sb)] = r["head_w"][n_lab:n_lab + 1], r["head_b"][n_lab:n_lab + 1]
+    if n_lab > 0:      # back through the fold of the activation-free label head (tiny H x H products)
+        with torch.enable_grad():
+            leaves = [(Wi.detach().requires_grad_(True), bi.detach().requires_grad_(True)) for Wi, bi in roles["label"]]
+            A, c = _fold_label_head(leaves)
+            flat = [t for pair in leaves for t in pair]
+            g = torch.autograd.grad([A, c], flat, [r["head_w"][:n_lab], r["head_b"][:n_lab]], allow_unused=True)
+        for (Wi, bi), gw, gb in zip(roles["label"], g[0::2], g[1::2]):
+            grads[id(Wi)] = gw if gw is not None else torch.zeros_like(Wi)
+            grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
+    rw, rb = roles["rgb"]
+    grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
+    if roles["grid"] is not None:
+        grads[id(roles["grid"])] = nat.grid_backward(points, d_e, roles["grid"].shape[2:]).contiguous()
+    return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
+
+
 class SirenFunction(torch.autograd.Function):
     """out = siren(points, dirs; film params, weights).  Non-tensor arg `module` supplies the native model and roles."""
 
@@ -57,26 +82,7 @@ class SirenFunction(torch.autograd.Function):
                       r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
         if film_only:
             return (None, None, None) + film_grads + (None,) * len(params)
-        grads = {}
-        for (W, b), gw, gb in zip(roles["geo"] + roles["color"], r["geo_w"] + r["color_w"], r["geo_b"] + r["color_b"]):
-            grads[id(W)], grads[id(b)] = gw, gb
-        sw, sb = roles["sigma"]
-        grads[id(sw)], grads[id(sb)] = r["head_w"][n_lab:n_lab + 1], r["head_b"][n_lab:n_lab + 1]
-        if n_lab > 0:      # back through the fold of the activation-free label head (tiny H x H products)
-            with torch.enable_grad():
-                leaves = [(Wi.detach().requires_grad_(True), bi.detach().requires_grad_(True)) for Wi, bi in roles["label"]]
-                A, c = _fold_label_head(leaves)
-                flat = [t for pair in leaves for t in pair]
-                g = torch.autograd.grad([A, c], flat, [r["head_w"][:n_lab], r["head_b"][:n_lab]], allow_unused=True)
-            for (Wi, bi), gw, gb in zip(roles["label"], g[0::2], g[1::2]):
-                grads[id(Wi)] = gw if gw is not None else torch.zeros_like(Wi)
-                grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
-        rw, rb = roles["rgb"]
-        grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
-        if roles["grid"] is not None:
-            grads[id(roles["grid"])] = nat.grid_backward(points, d_e, roles["grid"].shape[2:]).contiguous()
-        g_params = tuple(grads[id(p)].reshape(p.shape) if need[7 + i] else None for i, p in enumerate(params))
-        return (None, None, None) + film_grads + g_params
+        return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, d_e, need[7:])
 
 
 def siren_apply(module, points, dirs, fg, pg, fa, pa):
