@@ -1,5 +1,6 @@
 #!/bin/bash
 # timing-only A/B experiments on the shared-stream kernel (results of the EXP variants are numerically wrong on purpose)
+# build the variants first: make -C fenerf_amd/csrc exp   (they are git-ignored but travel with gpurun)
 for v in "" NOBARRIER NOWAIT NODMA NOLDSREAD; do
   if [ -z "$v" ]; then lib=fenerf_amd/libfenerf_hip.so; else lib=fenerf_amd/libexp_$v.so; fi
   echo -n "variant ${v:-baseline}: "
