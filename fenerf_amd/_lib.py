@@ -66,6 +66,7 @@ _SIGS = {
     "fenerf_model_destroy": (None, [_vp]),
     "fenerf_pack_backward_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_fp), C.POINTER(_sz)]),
     "fenerf_pack_index_map_f16": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_sz)]),
+    "fenerf_pack_backward_index_map_bf16": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_sz)]),
     "fenerf_model_load_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
@@ -161,6 +162,17 @@ def pack_index_map_f16(sd, spec):
     d, keep = make_desc(sd, spec, "f16x3")
     m, n = C.POINTER(C.c_int32)(), _sz()
     check(lib().fenerf_pack_index_map_f16(C.byref(d), C.byref(m), C.byref(n)))
+    try:
+        return np.ctypeslib.as_array(m, shape=(n.value,)).copy()
+    finally:
+        lib().fenerf_free_host(m)
+
+
+def pack_backward_index_map_bf16(sd, spec):
+    """int32 index (1 + flat index, 0 = padding) of every bf16 half of an f16x3 model's backward ring for index-valued weights."""
+    d, keep = make_desc(sd, spec, "f16x3", True)
+    m, n = C.POINTER(C.c_int32)(), _sz()
+    check(lib().fenerf_pack_backward_index_map_bf16(C.byref(d), C.byref(m), C.byref(n)))
     try:
         return np.ctypeslib.as_array(m, shape=(n.value,)).copy()
     finally:

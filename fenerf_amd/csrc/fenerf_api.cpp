@@ -54,7 +54,7 @@ static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t st
   HIP_TRY(hipMemcpyAsync(m->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   std::vector<float> bwd;
   if (m->differentiable) {
-    rc = pack_weights_bwd(d, bwd, err);
+    rc = d->precision == FENERF_PREC_F16X3 ? pack_weights_bwd16(d, bwd, err, nullptr) : pack_weights_bwd(d, bwd, err);
     if (rc) return fail(rc, err);
     if (allocate) HIP_TRY(hipMalloc((void**)&m->d_bwd_stream, bwd.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(m->d_bwd_stream, bwd.data(), bwd.size() * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -136,7 +136,11 @@ extern "C" int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev,
     want_s = (size_t)s16.l0_entries * 256 + (size_t)s16.ring_entries * 256;   // an f16 entry is 64 x 8 halves = 256 floats' worth
     want_c = (size_t)CONST_FILM_BIAS + (size_t)2 * m->L * m->H + 36;
   }
-  const size_t want_b = (size_t)(m->bsh.ht_entries + m->bsh.ring_entries) * 256;
+  size_t want_b = (size_t)(m->bsh.ht_entries + m->bsh.ring_entries) * 256;
+  if (m->precision == FENERF_PREC_F16X3) {
+    const BwdShape16 b16 = bwd_stream_shape16(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
+    want_b = (size_t)(b16.ht_entries + b16.ring_entries) * 256;
+  }
   if (!stream_dev || !consts_dev || n_stream != want_s || n_consts != want_c) return fail(FENERF_E_INVALID, "packed stream / consts size mismatch");
   if (m->differentiable && (!bwd_dev || n_bwd != want_b)) return fail(FENERF_E_INVALID, "backward stream size mismatch");
   hipStream_t st = (hipStream_t)stream;
@@ -366,7 +370,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.fp = fp; bp.pp = pp;
   bp.P = (long long)B * P; bp.pts_per_image = P;
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
-  return launch_siren_backward(m, bp, stream);
+  return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
 
 extern "C" size_t fenerf_siren_grad_workspace_bytes(const FenerfModel* m, int B, int64_t P) {

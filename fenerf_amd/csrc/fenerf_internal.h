@@ -15,6 +15,7 @@ int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err);
+int pack_weights_bwd16(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err, std::vector<int32_t>* index);
 
 }  // namespace fenerf
 
@@ -98,6 +99,7 @@ int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* 
                      float* fp, float* pp, void* stream);
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
+int launch_siren_backward16(const FenerfModel* m, const SirenBwdParams& p, void* stream);   // FENERF_PREC_F16X3 models
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,

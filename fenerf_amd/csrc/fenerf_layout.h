@@ -96,6 +96,39 @@ constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * 
 constexpr int feat16_of(int s16, int h, int t) { return feat_of(16 * (s16 >> 1) + 8 * (s16 & 1) + t, h); }
 constexpr float F16_ACT_SCALE = 16.f;   // activations are carried as x*16 so the lo halves stay normal fp16
 
+// bf16x3 backward chain (fenerf_siren_bwd16.hip, models created with FENERF_PREC_F16X3): the same stages on
+// v_mfma_f32_32x32x16_bf16 with W'^T and dz each split into bf16 (hi, lo) and three MFMAs per k-step (wl*xh + wh*xl + wh*xh).
+// [rgb-head^T block: NB plain fp32 entries, as above] | ring of bf16 entries (64 lanes x 8 bf16 = one A operand; per
+// k-step [hi entry, lo entry], weights split hi = RNE(w), lo = RNE(w - hi)); k-step s16 of an H-wide input reads the features
+// feat16_of(s16, h, t).  The colour-layer-0 bodies append 2 head k-steps (lane-half h, slot t multiplies head row
+// 16 ks' + 8 h + t).  Bodies are padded to whole revolutions of the FENERF_PF16-entry register ring.
+#ifndef FENERF_PF16
+#define FENERF_PF16 16
+#endif
+constexpr int pad_pf16(int e) { return (e + FENERF_PF16 - 1) / FENERF_PF16 * FENERF_PF16; }
+struct BwdShape16 {
+  int H, NB, KS16, body_e, body_ep;   // k-steps of an H-wide input; entries per square body (2 per k-step), padded
+  int c0_ks, c0_e, c0_ep;             // colour-layer-0 body: KS16 + 2 head k-steps
+  int ht_entries;
+  long long ring_entries;
+};
+
+inline BwdShape16 bwd_stream_shape16(int H, int n_geo, int n_color, bool grid) {
+  BwdShape16 s;
+  s.H = H; s.NB = H / 32; s.KS16 = H / 16;
+  s.body_e = 2 * s.KS16; s.body_ep = pad_pf16(s.body_e);
+  s.c0_ks = s.KS16 + 2; s.c0_e = 2 * s.c0_ks; s.c0_ep = pad_pf16(s.c0_e);
+  s.ht_entries = s.NB;
+  long long e = 0;
+  e += (long long)(n_color - 1) * s.NB * s.body_ep;
+  e += (long long)s.NB * s.c0_ep + (grid ? s.body_ep : 0);
+  e += (long long)(n_geo - 1) * s.NB * s.body_ep;
+  e += FENERF_PF16;
+  s.ring_entries = e;
+  return s;
+}
+
+
 // Workgroup-shared stream geometry (fenerf_siren_f16s.hip): chunks of FENERF_CH entries travel through an LDS ring of
 // FENERF_NSLOT slots, FENERF_DPF chunks ahead of the consumer.  Every STAGE (a layer's n-block bodies) is padded to a
 // whole number of ring revolutions, so every stage starts at ring slot 0 and all slot indices are compile-time constants;

@@ -403,6 +403,121 @@ int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::st
   return FENERF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3 backward-chain stream (fenerf_layout.h "bf16x3 backward chain")
+// ------------------------------------------------------------------------------------------------
+static inline uint16_t bf16_rne(float v) {
+  uint32_t b; memcpy(&b, &v, 4);
+  return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f32(uint16_t h) { uint32_t b = (uint32_t)h << 16; float v; memcpy(&v, &b, 4); return v; }
+
+// index != nullptr: record the source VALUE of every half as an integer (index-map mode, weights hold 1 + flat index)
+static void emit_body_bf16(std::vector<uint16_t>& out, std::vector<int32_t>* index, const double* W, int nrows, int ncols, int r0,
+                           const std::vector<KStep16>& ks, int padded_entries) {
+  const int real = 2 * (int)ks.size();
+  for (int e = 0; e < padded_entries; ++e) {
+    const int s = e >> 1, lo = e & 1;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = r0 + (lane & 31), h = lane >> 5;
+      for (int t = 0; t < 8; ++t) {
+        uint16_t bits = 0;
+        int32_t code = 0;
+        if (e < real && row < nrows) {
+          const int col = ks[s].col[h][t];
+          if (col >= 0) {
+            const float w = (float)W[(size_t)row * ncols + col];
+            const uint16_t hi = bf16_rne(w);
+            bits = lo ? bf16_rne(w - bf16_f32(hi)) : hi;
+            code = (int32_t)w;
+          }
+        }
+        out.push_back(bits);
+        if (index) index->push_back(code);
+      }
+    }
+  }
+}
+
+int pack_weights_bwd16(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err, std::vector<int32_t>* index) {
+  int rc = validate_desc(d, err);
+  if (rc) return rc;
+  const int H = d->hidden_dim;
+  const bool grid = d->grid_ch != 0;
+  const BwdShape16 sh = bwd_stream_shape16(H, d->n_geo, d->n_color, grid);
+  blob.clear();
+  std::vector<uint16_t> ring;
+  ring.reserve((size_t)sh.ring_entries * 512);
+  auto x_ksteps = [&]() {
+    std::vector<KStep16> ks(sh.KS16);
+    for (int s = 0; s < sh.KS16; ++s)
+      for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 8; ++t) ks[s].col[h][t] = feat16_of(s, h, t);
+    return ks;
+  };
+  // rows scaled like the forward's f16x3 layers (see pack_weights_bwd); unscaled in index-map mode
+  auto film_row_scale = [&](const float* W, int rows, int cols) {
+    std::vector<double> sc(rows, 1.0);
+    if (!index) {
+      auto W64 = to_f64(W, (size_t)rows * cols);
+      sc = row_scales(W64.data(), rows, cols);
+      for (auto& v : sc) v *= (double)F16_ACT_SCALE;
+    }
+    return sc;
+  };
+  auto transposed = [&](const float* W, int rows, int cols, int col0, int ncol, const std::vector<double>* sc = nullptr) {
+    std::vector<double> T((size_t)ncol * rows);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < ncol; ++c) T[(size_t)c * rows + r] = (double)W[(size_t)r * cols + col0 + c] * (sc ? (*sc)[r] : 1.0);
+    return T;
+  };
+  {  // rgb head^T stays on the fp32 MFMA (two k-steps)
+    auto T = transposed(d->rgb_w, 3, H, 0, H);
+    std::vector<KStep> ks = {{0, 1}, {2, -1}};
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body(blob, T.data(), H, 3, nb * 32, ks, 1);
+  }
+  for (int l = d->n_color - 1; l >= 1; --l) {
+    const auto sc = film_row_scale(d->color_w[l], H, H);
+    auto T = transposed(d->color_w[l], H, H, 0, H, &sc);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body_bf16(ring, index, T.data(), H, H, nb * 32, x_ksteps(), sh.body_ep);
+  }
+  {
+    const int cin = 3 + d->grid_ch + H;
+    std::vector<double> Wh, hb;
+    fold_head(d, Wh, hb);
+    const auto sc0 = film_row_scale(d->color_w[0], H, cin);
+    std::vector<double> M((size_t)H * (H + 32), 0.0);   // row j: [W_c0[:, x_j] (H) | head[:, j] (32)]
+    for (int j = 0; j < H; ++j) {
+      for (int i = 0; i < H; ++i) M[(size_t)j * (H + 32) + i] = (double)d->color_w[0][(size_t)i * cin + 3 + d->grid_ch + j] * sc0[i];
+      for (int r = 0; r < 32; ++r) M[(size_t)j * (H + 32) + H + r] = Wh[(size_t)r * H + j];
+    }
+    auto ks = x_ksteps();
+    for (int s = 0; s < 2; ++s) {
+      KStep16 k;
+      for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 8; ++t) k.col[h][t] = H + 16 * s + 8 * h + t;
+      ks.push_back(k);
+    }
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body_bf16(ring, index, M.data(), H, H + 32, nb * 32, ks, sh.c0_ep);
+    if (grid) {
+      auto T = transposed(d->color_w[0], H, cin, 3, 32, &sc0);   // [32][H]
+      emit_body_bf16(ring, index, T.data(), 32, H, 0, x_ksteps(), sh.body_ep);
+    }
+  }
+  for (int l = d->n_geo - 1; l >= 1; --l) {
+    const auto sc = film_row_scale(d->geo_w[l], H, H);
+    auto T = transposed(d->geo_w[l], H, H, 0, H, &sc);
+    for (int nb = 0; nb < sh.NB; ++nb) emit_body_bf16(ring, index, T.data(), H, H, nb * 32, x_ksteps(), sh.body_ep);
+  }
+  ring.insert(ring.end(), (size_t)FENERF_PF16 * 512, 0);
+  if (index) index->insert(index->end(), (size_t)FENERF_PF16 * 512, 0);
+  if (ring.size() != (size_t)sh.ring_entries * 512) { err = "internal: bf16 backward stream size mismatch"; return FENERF_E_INVALID; }
+  const size_t nf = blob.size();
+  blob.resize(nf + ring.size() / 2);
+  memcpy(blob.data() + nf, ring.data(), ring.size() * 2);
+  return FENERF_OK;
+}
+
 }  // namespace fenerf
 
 extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats, float** consts,
@@ -443,13 +558,28 @@ extern "C" int fenerf_pack_index_map_f16(const FenerfModelDesc* desc, int32_t** 
 extern "C" int fenerf_pack_backward_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats) {
   std::vector<float> b;
   std::string err;
-  int rc = fenerf::pack_weights_bwd(desc, b, err);
+  int rc = (desc && desc->precision == FENERF_PREC_F16X3) ? fenerf::pack_weights_bwd16(desc, b, err, nullptr)
+                                                          : fenerf::pack_weights_bwd(desc, b, err);
   if (rc) { fenerf::set_error(err); return rc; }
   if (!blob || !n_floats) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
   *blob = (float*)malloc(b.size() * sizeof(float));
   if (!*blob) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
   memcpy(*blob, b.data(), b.size() * sizeof(float));
   *n_floats = b.size();
+  return FENERF_OK;
+}
+
+extern "C" int fenerf_pack_backward_index_map_bf16(const FenerfModelDesc* desc, int32_t** map, size_t* n) {
+  if (!map || !n) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
+  std::vector<int32_t> index;
+  std::vector<float> b;
+  std::string err;
+  int rc = fenerf::pack_weights_bwd16(desc, b, err, &index);
+  if (rc) { fenerf::set_error(err); return rc; }
+  *map = (int32_t*)malloc(index.size() * sizeof(int32_t));
+  if (!*map) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  memcpy(*map, index.data(), index.size() * sizeof(int32_t));
+  *n = index.size();
   return FENERF_OK;
 }
 

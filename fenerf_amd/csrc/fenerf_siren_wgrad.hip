@@ -268,9 +268,9 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
 
 // ------------------------------------------------------------------------------------------------
 // Square weight-gradient job on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), error-compensated like the forward's f16x3 GEMM:
-// each fp32 operand is split into bf16 (hi, lo) -- hi = truncation, lo = truncation of the exact remainder, together 16
+// each fp32 operand is split into bf16 (hi, lo) -- hi = truncation, lo = the exact remainder rounded, together 16
 // mantissa bits -- and a product is evaluated as ah*bh + ah*bl + al*bh (3 MFMAs at 16x the fp32 MFMA rate; dropped term
-// and truncations ~2^-15 relative per product, random over 10^5..10^6 points).  bf16 rather than fp16 because dtheta has
+// and roundings ~2^-16 relative per product, unbiased, random over 10^5..10^6 points).  bf16 rather than fp16 because dtheta has
 // no a-priori range.  Used for FENERF_PREC_F16X3 models; FENERF_PREC_F32 models keep the exact fp32 job above.
 //
 // LDS image: A_p / B_p rows [feature][32 points] of split-packed dwords (hi | lo << 16), row stride WG_LD -- the lane's 8
@@ -284,7 +284,7 @@ __device__ __forceinline__ unsigned split_pack_bf16(float v) {
   const unsigned vb = __builtin_bit_cast(unsigned, v);
   const float hi = __builtin_bit_cast(float, vb & 0xffff0000u);
   const unsigned rb = __builtin_bit_cast(unsigned, v - hi);          // exact
-  return (vb >> 16) | (rb & 0xffff0000u);
+  return (vb >> 16) | ((rb + 0x8000u) & 0xffff0000u);               // remainder rounded (a truncated one biases every product by 2^-17)
 }
 
 struct Frag16 { bf16x8 hi, lo; };

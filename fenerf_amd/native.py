@@ -84,6 +84,11 @@ class NativeModel:
             maps = dict(stream=to_idx(blob), consts=to_idx(consts))
             if self.differentiable:
                 maps["bwd"] = to_idx(_lib.pack_backward_host(tag, spec1))
+                if self.precision == "f16x3":     # bf16 (hi, lo) ring behind the fp32 rgb-head block; hi / lo alternate per entry
+                    idx = _lib.pack_backward_index_map_bf16(tag, spec1).astype(np.int64)
+                    maps["bwd_head"] = maps["bwd"][: (self.spec["hidden_dim"] // 32) * 256]
+                    maps["bwd16_idx"] = to_idx(idx)
+                    maps["bwd16_lo"] = to_idx((np.arange(idx.size) // 512) & 1).bool()
             if self.precision == "f16x3":
                 codes = _lib.pack_index_map_f16(tag, spec1).astype(np.int64)
                 maps["l0"] = maps["stream"][: (self.spec["hidden_dim"] // 32) * 256]      # fp32 layer-0 block, as in the f32 stream
@@ -146,9 +151,12 @@ class NativeModel:
             head_inv[n_lab] = 1.0 / (sc["final_layer.weight"][0] * 16.0)
             rgb_inv = torch.cat([1.0 / (sc["color_layer_linear.0.weight"] * 16.0), torch.ones(1, device=dev)])
             consts = torch.cat([flat[maps["consts"]]] + inv + [head_inv, rgb_inv])
-            if self.differentiable:     # backward stream: FiLM-layer rows scaled like the forward's (x 16), heads true
+            if self.differentiable:     # backward stream: FiLM-layer rows scaled like the forward's (x 16), heads true; bf16 hi / lo
                 flat_b = torch.cat([zero] + [(scaled(name, 16.0) if name in film_w else p[name]).reshape(-1) for name, _ in items])
-                bwd = flat_b[maps["bwd"]]
+                bhi = flat_b.to(torch.bfloat16)
+                blo = (flat_b - bhi.float()).to(torch.bfloat16)
+                bhalves = torch.where(maps["bwd16_lo"], blo[maps["bwd16_idx"]], bhi[maps["bwd16_idx"]])
+                bwd = torch.cat([flat_b[maps["bwd_head"]], bhalves.view(torch.float32)])
         grid = p.get("spatial_embeddings")
         grid = grid.contiguous() if grid is not None else None
         return stream.contiguous(), consts.contiguous(), bwd, grid

@@ -121,6 +121,11 @@ int fenerf_pack_backward_host(const FenerfModelDesc* desc, float** blob, size_t*
  * (after the fp32 layer-0 block), that index | (is_lo << 30), 0 for padding.  The caller scales rows, splits and gathers
  * on the device (fenerf_amd/native.py::NativeModel.load_from_device) and hands the result to fenerf_model_load_packed. */
 int fenerf_pack_index_map_f16(const FenerfModelDesc* desc, int32_t** map, size_t* n);
+/* The backward stream of a FENERF_PREC_F16X3 model holds bf16 (hi, lo) pairs of the scaled transposed weights after its fp32
+ * rgb-head block (fenerf_pack_backward_host packs it when desc->precision says so).  Called with index-valued weights
+ * this returns that index for every bf16 half of the ring (0 = padding); hi / lo alternate per 512-half entry
+ * (hi = RNE(w), lo = RNE(w - hi)). */
+int fenerf_pack_backward_index_map_bf16(const FenerfModelDesc* desc, int32_t** map, size_t* n);
 int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev, size_t n_consts,
                              const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream);
 

@@ -1,5 +1,5 @@
-"""CPU check of the backward-chain weight stream (fenerf_pack.cpp::pack_weights_bwd) + the dataflow of
-fenerf_siren_bwd.hip: a numpy emulation of one wave -- same stream walk, same v_mfma_f32_32x32x2_f32 lane maps, same
+"""CPU check of the backward-chain weight streams (fenerf_pack.cpp::pack_weights_bwd / pack_weights_bwd16) + the dataflow
+of fenerf_siren_bwd.hip / fenerf_siren_bwd16.hip: a numpy emulation of one wave -- same stream walk, same v_mfma_f32_32x32x2_f32 lane maps, same
 stage order (rgb head^T, colour layers, the colour-layer-0 stage with head^T and the grid-feature body, trunk) -- run
 on the blob the C packer produced and compared with dL/dtheta of every FiLM layer from torch fp64 autograd.
 Both packings: exact fp32 rows, and the power-of-two row-scaled rows of FENERF_PREC_F16X3 models (dz' = dz / s)."""
@@ -104,6 +104,98 @@ def emulate_chain(blob, spec, theta, f_true, row_scale, d_out, out):
     return dtheta, d_e
 
 
+PF16 = 16
+
+
+def mfma16(a, b, acc):
+    """v_mfma_f32_32x32x16_bf16: a[l][t] = A[i=l&31][k=8(l>>5)+t], b[l][t] = B[k=8(l>>5)+t][j=l&31], acc as mfma()."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for t in range(8):
+        A[M_, 8 * H_ + t] = a[:, t]
+        B[8 * H_ + t, M_] = b[:, t]
+    D = A @ B
+    for r in range(16):
+        acc[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * H_, M_]
+
+
+def emulate_chain16(blob, spec, theta, f_true, row_scale, d_out, out):
+    """The bf16x3 chain (fenerf_siren_bwd16.hip) on its stream: fp32 rgb-head block, then [hi entry, lo entry] per k-step.
+    The emulation multiplies (hi + lo) with exact dz: it checks layout and dataflow, not the split arithmetic."""
+    H, NB, KS = spec["hidden_dim"], spec["hidden_dim"] // 32, spec["hidden_dim"] // 16
+    pad = lambda n: (n + PF16 - 1) // PF16 * PF16
+    EP, C0_EP = pad(2 * KS), pad(2 * (KS + 2))
+    n_geo, n_color, C = spec["n_geo"], spec["n_color"], spec["output_dim"]
+    n_lab, L = C - 4, spec["n_geo"] + spec["n_color"]
+    head = blob[:NB * 256].reshape(NB, 64, 4).astype(np.float64)
+    ring = (blob[NB * 256:].view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64).reshape(-1, 64, 8)
+    cur = [0]
+
+    def next_kstep():
+        w = ring[cur[0]] + ring[cur[0] + 1]
+        cur[0] += 2
+        return w
+
+    dtheta = np.zeros((L, H, 32))
+    slab = np.zeros((KS, 64, 8))
+
+    def store(acc, layer, nb):
+        for r in range(16):
+            feat = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * H_
+            dt = acc[:, r] * np.cos(theta[layer][feat, M_])
+            dtheta[layer][feat, M_] = dt
+            slab[2 * nb + (r >> 3)][:, r & 7] = dt * f_true[layer][feat] / row_scale[layer][feat]
+
+    def body(acc, act, ep, extra=None):
+        for ks in range(ep // 2):
+            w = next_kstep()
+            if ks < KS:
+                mfma16(w, act[ks], acc)
+            elif extra is not None and ks - KS < len(extra):
+                mfma16(w, extra[ks - KS], acc)
+
+    s = out[M_, C - 4:C - 1]
+    dpre = d_out[M_, C - 4:C - 1] * s * (1 - s)
+    b0 = np.where(H_ == 1, dpre[:, 1], dpre[:, 0])
+    b1 = np.where(H_ == 1, 0.0, dpre[:, 2])
+    for nb in range(NB):
+        acc = np.zeros((64, 16))
+        mfma(head[nb][:, 0], b0, acc)
+        mfma(head[nb][:, 1], b1, acc)
+        store(acc, L - 1, nb)
+    act = slab.copy()
+    for l in range(L - 1, n_geo, -1):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            body(acc, act, EP)
+            store(acc, l - 1, nb)
+        act = slab.copy()
+    dh = np.zeros((2, 64, 8))
+    for s_ in range(2):
+        for t in range(8):
+            row = 16 * s_ + 8 * H_ + t
+            ch = np.where(row < n_lab, row, np.where(row == n_lab, C - 1, -1))
+            dh[s_][:, t] = np.where(ch >= 0, d_out[M_, np.maximum(ch, 0)], 0.0)
+    for nb in range(NB):
+        acc = np.zeros((64, 16))
+        body(acc, act, C0_EP, dh)
+        store(acc, n_geo - 1, nb)
+    d_e = np.zeros((32, 32))
+    if spec["grid_ch"]:
+        acc = np.zeros((64, 16))
+        body(acc, act, EP)
+        for r in range(16):
+            d_e[M_, (r & 3) + 8 * (r >> 2) + 4 * H_] = acc[:, r]
+    act = slab.copy()
+    for l in range(n_geo - 1, 0, -1):
+        for nb in range(NB):
+            acc = np.zeros((64, 16))
+            body(acc, act, EP)
+            store(acc, l - 1, nb)
+        act = slab.copy()
+    assert cur[0] + PF16 == ring.shape[0], "bf16 backward stream must be consumed exactly (+ the tail pad)"
+    return dtheta, d_e
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0)])
 def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
@@ -141,11 +233,14 @@ def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
             m = np.abs(sd[n].astype(np.float32)).max(1)
             _, ex = np.frexp(m)
             row_scale[l] = np.where(m > 0, np.ldexp(1.0, -ex), 1.0) * 16
-    got, d_e = emulate_chain(blob, spec, theta, f_true, row_scale, d_out, out.detach().numpy()[0])
-    # the stream holds fp32 values (the fp64-folded label head is rounded once): agreement to fp32 resolution
-    np.testing.assert_allclose(got, ref, atol=5e-7 * max(1.0, np.abs(ref).max()), rtol=1e-5)
+    emu = emulate_chain16 if precision == "f16x3" else emulate_chain
+    got, d_e = emu(blob, spec, theta, f_true, row_scale, d_out, out.detach().numpy()[0])
+    # the fp32 stream holds fp32 values (the fp64-folded label head is rounded once): agreement to fp32 resolution;
+    # the bf16 stream holds hi + lo = 16+ significant bits of each weight
+    tol = 2e-5 if precision == "f16x3" else 5e-7
+    np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=1e-5 if precision == "f32" else 1e-4)
     if grid:   # d(grid features): check through the grid gradient's total (sum over voxels per channel = sum_p d_e[p][c] * weights ...)
         # the sampled features enter colour layer 0 linearly: d_e[p] = W_c0[:, 3:35]^T dz_{n_geo}[p]
         W = sd["color_layer_sine.0.layer.weight"].astype(np.float64)[:, 3:35]
         dz = ref[spec["n_geo"]] * f_true[spec["n_geo"]][:, None]                 # [H][32]
-        np.testing.assert_allclose(d_e, (W.T @ dz).T, atol=5e-7 * max(1.0, np.abs(dz).max()), rtol=1e-5)
+        np.testing.assert_allclose(d_e, (W.T @ dz).T, atol=tol * max(1.0, np.abs(dz).max()), rtol=1e-5 if precision == "f32" else 1e-4)
