@@ -43,6 +43,13 @@ class FenerfSirenGrads(C.Structure):
                 ("d_freq_geo", _vp), ("d_phase_geo", _vp), ("d_freq_app", _vp), ("d_phase_app", _vp)]
 
 
+class FenerfRepackMaps(C.Structure):
+    _fields_ = [("stream_f32", _vp), ("n_stream_f32", C.c_size_t), ("stream_h16", _vp), ("n_stream_h16", C.c_size_t),
+                ("consts", _vp), ("n_consts", C.c_size_t), ("consts_tail", _vp), ("n_tail", C.c_size_t),
+                ("bwd_f32", _vp), ("n_bwd_f32", C.c_size_t), ("bwd_b16", _vp), ("n_bwd_b16", C.c_size_t),
+                ("row_off", _vp), ("row_len", _vp), ("row_film", _vp), ("n_rows", C.c_int32), ("scale_id", _vp)]
+
+
 class FenerfCompositeOpts(C.Structure):
     _fields_ = [("clamp_mode", C.c_int32), ("noise_std", C.c_float), ("last_back", C.c_int32),
                 ("white_back", C.c_int32), ("black_back", C.c_int32), ("fill_mode", C.c_int32),
@@ -68,6 +75,8 @@ _SIGS = {
     "fenerf_pack_index_map_f16": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_sz)]),
     "fenerf_pack_backward_index_map_bf16": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(_sz)]),
     "fenerf_model_load_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "fenerf_model_repack": (_i, [_vp, _vp, _sz, C.POINTER(FenerfRepackMaps), _vp, _vp]),
+    "fenerf_model_export_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
@@ -78,6 +87,7 @@ _SIGS = {
     "fenerf_sample_pdf": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_merge_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_siren_tape_floats": (_sz, [_vp, _i64]),
+    "fenerf_siren_dtheta_floats": (_sz, [_vp, _i64]),
     "fenerf_siren_forward_save": (_i, [_vp, _i, _i64] + [_vp] * 11),
     "fenerf_siren_backward": (_i, [_vp, _i, _i64] + [_vp] * 11),
     "fenerf_siren_grad_workspace_bytes": (_sz, [_vp, _i, _i64]),

@@ -50,12 +50,14 @@ static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t st
     HIP_TRY(hipMalloc((void**)&m->d_stream, blob.size() * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&m->d_consts, consts.size() * sizeof(float)));
   }
+  m->n_stream = blob.size(); m->n_consts = consts.size();
   HIP_TRY(hipMemcpyAsync(m->d_stream, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(m->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   std::vector<float> bwd;
   if (m->differentiable) {
     rc = d->precision == FENERF_PREC_F16X3 ? pack_weights_bwd16(d, bwd, err, nullptr) : pack_weights_bwd(d, bwd, err);
     if (rc) return fail(rc, err);
+    m->n_bwd = bwd.size();
     if (allocate) HIP_TRY(hipMalloc((void**)&m->d_bwd_stream, bwd.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(m->d_bwd_stream, bwd.data(), bwd.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   }
@@ -154,8 +156,48 @@ extern "C" int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev,
   return FENERF_OK;
 }
 
+extern "C" int fenerf_model_repack(FenerfModel* m, const float* flat_dev, size_t n_flat, const FenerfRepackMaps* r, const float* grid_dev,
+                                   void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!flat_dev || !r || n_flat == 0) return fail(FENERF_E_INVALID, "NULL pointer");
+  const bool f16 = m->precision == FENERF_PREC_F16X3;
+  const size_t tail = f16 ? (size_t)m->L * m->H + 36 : 0;
+  if (!r->stream_f32 || !r->consts || r->n_stream_f32 + r->n_stream_h16 / 2 != m->n_stream || (r->n_stream_h16 & 1) ||
+      r->n_consts + r->n_tail != m->n_consts || r->n_tail != tail || (f16 != (r->stream_h16 != nullptr)) || (f16 && !r->consts_tail))
+    return fail(FENERF_E_INVALID, "repack maps do not match the model's forward stream / consts");
+  if (m->differentiable &&
+      (!r->bwd_f32 || r->n_bwd_f32 + r->n_bwd_b16 / 2 != m->n_bwd || (r->n_bwd_b16 & 1) || (f16 != (r->bwd_b16 != nullptr))))
+    return fail(FENERF_E_INVALID, "repack maps do not match the model's backward stream");
+  const size_t cap = (size_t)m->L * m->H + 64;
+  if (f16) {
+    if (!r->row_off || !r->row_len || !r->row_film || !r->scale_id || r->n_rows < 0 || (size_t)r->n_rows + 1 > cap)
+      return fail(FENERF_E_INVALID, "repack maps: row table missing or too long");
+    if (!m->d_row_scale) HIP_TRY(hipMalloc((void**)&m->d_row_scale, 2 * cap * sizeof(float)));
+  }
+  int rc = launch_repack(m, flat_dev, r, m->d_row_scale, m->d_row_scale ? m->d_row_scale + cap : nullptr, stream);
+  if (rc) return rc;
+  if (grid_dev) {
+    if (!m->grid_ch) return fail(FENERF_E_INVALID, "model has no feature grid");
+    return launch_grid_relayout(grid_dev, m->d_grid, m->grid_ch, m->gd, m->gh, m->gw, stream);
+  }
+  return FENERF_OK;
+}
+
+extern "C" int fenerf_model_export_packed(const FenerfModel* m, float* stream_dev, size_t n_stream, float* consts_dev, size_t n_consts,
+                                          float* bwd_dev, size_t n_bwd, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  if ((stream_dev && n_stream != m->n_stream) || (consts_dev && n_consts != m->n_consts) || (bwd_dev && (!m->differentiable || n_bwd != m->n_bwd)))
+    return fail(FENERF_E_INVALID, "export: buffer size mismatch");
+  if (stream_dev) HIP_TRY(hipMemcpyAsync(stream_dev, m->d_stream, n_stream * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (consts_dev) HIP_TRY(hipMemcpyAsync(consts_dev, m->d_consts, n_consts * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (bwd_dev) HIP_TRY(hipMemcpyAsync(bwd_dev, m->d_bwd_stream, n_bwd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return FENERF_OK;
+}
+
 extern "C" void fenerf_model_destroy(FenerfModel* m) {
   if (!m) return;
+  if (m->d_row_scale) (void)hipFree(m->d_row_scale);
   if (m->d_stream) (void)hipFree(m->d_stream);
   if (m->d_consts) (void)hipFree(m->d_consts);
   if (m->d_grid) (void)hipFree(m->d_grid);
@@ -330,6 +372,12 @@ extern "C" size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_p
   return (size_t)m->L * m->H * (size_t)total_points;
 }
 
+extern "C" size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points) {
+  if (!m || total_points <= 0) return 0;
+  const long long tiles = (total_points + 31) / 32;
+  return (size_t)m->L * m->H * (size_t)tiles * 32 + (size_t)film_tile_floats(tiles, m->L, m->H);
+}
+
 extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                                          const float* freq_geo, const float* phase_geo, const float* freq_app,
                                          const float* phase_app, float* out, float* tape, float* tape_e, void* film_ws,
@@ -370,6 +418,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.fp = fp; bp.pp = pp;
   bp.P = (long long)B * P; bp.pts_per_image = P;
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
+  bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;    // appended to the dtheta dump
   return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
 

@@ -33,6 +33,8 @@ struct FenerfModel {
   int differentiable;       // desc->differentiable: the backward-chain stream is resident too
   fenerf::BwdShape bsh;
   float* d_bwd_stream;      // [rgb-head^T entries | backward ring] * 256 floats, or nullptr
+  float* d_row_scale;       // fenerf_model_repack scratch: [2][L*H + 64] row scales (forward | backward), lazily allocated
+  size_t n_stream, n_consts, n_bwd;   // floats resident in d_stream / d_consts / d_bwd_stream
 };
 
 namespace fenerf {
@@ -75,6 +77,7 @@ struct SirenBwdParams {
   const float* tape;       // [L][H][P] from the forward
   float* d_t;              // [L][H][P] out: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
   float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
+  float* film_tiles;       // [tiles][L][2][H] out: per-tile FiLM sums (fenerf_layout.h "FiLM sums")
 };
 
 struct CompositeParams {
@@ -113,6 +116,7 @@ int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const floa
 int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
                      const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch, float* yaw,
                      void* stream);
+int launch_repack(FenerfModel* m, const float* flat, const FenerfRepackMaps* r, float* scale_fwd, float* scale_bwd, void* stream);
 int launch_grid_relayout(const float* src_ncdhw, float* dst_cl, int C, int D, int Hh, int W, void* stream);
 
 }  // namespace fenerf

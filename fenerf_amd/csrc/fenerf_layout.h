@@ -83,6 +83,9 @@ inline BwdShape bwd_stream_shape(int H, int n_geo, int n_color, bool grid) {
 // feature 32 nb + 8 j + 4 half + i of point 32 tile + m.  Every wave store / load is one contiguous 1-KiB transfer and a
 // tile's whole tape is one contiguous L*H*128-byte run (vs 128-B pieces scattered over L*H rows for a feature-major
 // matrix: measured 10x slower).  Point counts are padded to whole tiles by the caller (pad gradients are zero).
+// FiLM sums (backward): per 32-point tile and FiLM layer the chain kernels also emit s0[n] = sum_p dtheta[n][p] and
+// s1[n] = sum_p dtheta[n][p] * tape[n][p] (raw accumulator units), [tile][layer][2][H] floats, appended to the dtheta dump.
+constexpr long long film_tile_floats(long long tiles, int L, int H) { return tiles * L * 2 * H; }
 constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * (g & 3) + 4 * half + i; }
 
 // ---------------------------------------------------------------------------------------------
@@ -103,7 +106,7 @@ constexpr float F16_ACT_SCALE = 16.f;   // activations are carried as x*16 so th
 // feat16_of(s16, h, t).  The colour-layer-0 bodies append 2 head k-steps (lane-half h, slot t multiplies head row
 // 16 ks' + 8 h + t).  Bodies are padded to whole revolutions of the FENERF_PF16-entry register ring.
 #ifndef FENERF_PF16
-#define FENERF_PF16 16
+#define FENERF_PF16 8
 #endif
 constexpr int pad_pf16(int e) { return (e + FENERF_PF16 - 1) / FENERF_PF16 * FENERF_PF16; }
 struct BwdShape16 {

@@ -99,6 +99,72 @@ __device__ __forceinline__ void film_store(const f32x16& acc, const FilmNB& fm, 
   }
 }
 
+// ---- FiLM-gradient sums in the chain kernels --------------------------------------------------------------------
+// d_phase = sum_p dtheta and d_freq ~ sum_p dtheta * (W x + b) contract over the POINT axis, which is the lane axis of the
+// chain kernels.  While dtheta and the tape value are in registers anyway, the 2 x 16 per-lane values of an n-block are
+// summed over the 32 lanes of each wave half with a TRANSPOSING butterfly: at step k every lane keeps, of each register
+// pair, the partial sum its lane bit k selects and receives the partner lane's, so the register count halves per step and
+// after four steps lane i holds the 16-lane sum of register (i & 15); one cross-row exchange finishes it.  ~70 VALU ops
+// per 16 registers (a plain 5-step DPP reduction of every register: 160), results spread over 16 lanes = one small store.
+// The weight-gradient kernels then need neither the layer's own tape nor a FiLM pass (a third of their HBM traffic).
+struct LaneBits { bool b0, b1, b2, b3, store; };   // lane & 1, 2, 4, 8 ; !(lane & 16)
+__device__ __forceinline__ LaneBits lane_bits(int lane) { return LaneBits{(lane & 1) != 0, (lane & 2) != 0, (lane & 4) != 0, (lane & 8) != 0, (lane & 16) == 0}; }
+
+__device__ __forceinline__ float lane_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); }   // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float lane_xor4(float x) {   // row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3
+  const int xi = __builtin_bit_cast(int, x);
+  int t = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xf, 0x5, true);
+  t = __builtin_amdgcn_update_dpp(t, xi, 0x114, 0xf, 0xa, true);
+  return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float lane_xor8(float x) {   // row_shl:8 into banks 0, 1; row_shr:8 into banks 2, 3
+  const int xi = __builtin_bit_cast(int, x);
+  int t = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xf, 0x3, true);
+  t = __builtin_amdgcn_update_dpp(t, xi, 0x118, 0xf, 0xc, true);
+  return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float lane_xor16(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F)); }   // swizzle(SWAP,16)
+
+template <class XCHG>
+__device__ __forceinline__ float fold(bool bit, float a, float b, XCHG xchg) {
+  const float keep = bit ? b : a, send = bit ? a : b;
+  return keep + xchg(send);
+}
+
+// v[0][r] = dtheta, v[1][r] = dtheta * tape of accumulator register r; the butterfly in 8 chunks (so that it can be issued
+// piecewise behind MFMAs).  ftp = film_tiles + ((tile * L + layer) * 2) * H + 32 * nb + feature offset of register (lane & 15)
+// in this lane's half (fenerf_layout.h "FiLM sums").
+constexpr int FILM_RED_CHUNKS = 8;
+struct FilmRed { float v[2][16], w[2][8], x[2][4], y[2][2]; };
+__device__ __forceinline__ void film_red_chunk(int c, FilmRed& R, const LaneBits& lb, float* ftp, int H) {
+  if (c < 4) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int a = 2 * c; a < 2 * c + 2; ++a) R.w[s][a] = fold(lb.b0, R.v[s][2 * a], R.v[s][2 * a + 1], lane_xor1);
+  } else if (c < 6) {
+    const int s = c - 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) R.x[s][a] = fold(lb.b1, R.w[s][2 * a], R.w[s][2 * a + 1], lane_xor2);
+  } else if (c == 6) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) R.y[s][a] = fold(lb.b2, R.x[s][2 * a], R.x[s][2 * a + 1], lane_xor4);
+  } else {
+    float z[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      z[s] = fold(lb.b3, R.y[s][0], R.y[s][1], lane_xor8);   // lane i: 16-lane sum of register (i & 15)
+      z[s] += lane_xor16(z[s]);
+    }
+    if (lb.store) { ftp[0] = z[0]; ftp[H] = z[1]; }
+  }
+}
+// feature offset inside an n-block of accumulator register (lane & 15) for the lane's half
+__device__ __forceinline__ int film_lane_feature(int lane) { const int r = lane & 15; return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
 template <int NIN>
 __device__ __forceinline__ void load_act(float (&in)[NIN], const float4* slab) {
 #pragma unroll

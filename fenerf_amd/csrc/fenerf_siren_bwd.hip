@@ -35,33 +35,16 @@ __device__ __forceinline__ TapeNB tape_load(const float4* tp, int nb) {
   return t;
 }
 
-// acc = dL/dx of n-block nb.  Writes dL/dtheta to d_t and parks dL/dz in the LDS slab.
-__device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, float4* slab,
-                                          float4* dtp) {
-  const float TWO_PI = 6.28318530717958647692f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float f[4] = {fm.f[j].x, fm.f[j].y, fm.f[j].z, fm.f[j].w};
-    const float p[4] = {fm.p[j].x, fm.p[j].y, fm.p[j].z, fm.p[j].w};
-    float o[4], d[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * j + i;
-      const float dt = acc[r] * cos2pi(__builtin_fmaf(f[i], tn.a[r], p[i]));
-      d[i] = dt;
-      o[i] = dt * (f[i] * TWO_PI);
-    }
-    dtp[(nb * 4 + j) * 64] = make_float4(d[0], d[1], d[2], d[3]);
-    slab[(nb * 4 + j) * 64] = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
+// where an epilogue writes: the lane's LDS slab, the dtheta dump and the FiLM sums of (tile, layer)
+struct Sink { float4* slab; float4* dtp; float* ftp; int H; LaneBits lb; };
 
-// The epilogue of one accumulator register (element r of n-block nb), and the stores of a finished group of four:
-// cut this way the epilogue of n-block nb-1 is issued, piece by piece, behind the MFMAs of n-block nb -- run after its own
-// body it serialised (last MFMA done -> 16 cos + stores -> next body's loads) for ~25 % of the kernel.
+// The epilogue of one accumulator register (element r of n-block nb: dL/dx -> dL/dtheta, dL/dz, FiLM sums), and the stores
+// of a finished group of four: cut this way the epilogue of n-block nb-1 is issued, piece by piece, behind the MFMAs of
+// n-block nb -- run after its own body it serialised (last MFMA done -> 16 cos + stores -> next body's loads) for ~25 % of
+// the kernel.
 struct BwdQuad { float d[4], o[4]; };
-__device__ __forceinline__ void bwd_piece(int r, const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, float4* slab, float4* dtp,
-                                          BwdQuad& q) {
+__device__ __forceinline__ void bwd_piece(int r, const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, const Sink& k, BwdQuad& q,
+                                          FilmRed& R) {
   const float TWO_PI = 6.28318530717958647692f;
   const int j = r >> 2, i = r & 3;
   const float f = i == 0 ? fm.f[j].x : (i == 1 ? fm.f[j].y : (i == 2 ? fm.f[j].z : fm.f[j].w));
@@ -69,10 +52,22 @@ __device__ __forceinline__ void bwd_piece(int r, const f32x16& acc, const FilmNB
   const float dt = acc[r] * cos2pi(__builtin_fmaf(f, tn.a[r], p));
   q.d[i] = dt;
   q.o[i] = dt * (f * TWO_PI);
+  R.v[0][r] = dt;
+  R.v[1][r] = dt * tn.a[r];
   if (i == 3) {
-    dtp[(nb * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
-    slab[(nb * 4 + j) * 64] = make_float4(q.o[0], q.o[1], q.o[2], q.o[3]);
+    k.dtp[(nb * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
+    k.slab[(nb * 4 + j) * 64] = make_float4(q.o[0], q.o[1], q.o[2], q.o[3]);
   }
+}
+
+// acc = dL/dx of n-block nb: the whole epilogue at once (stages that are not software-pipelined)
+__device__ __forceinline__ void bwd_store(const f32x16& acc, const FilmNB& fm, const TapeNB& tn, int nb, const Sink& k) {
+  BwdQuad q;
+  FilmRed R;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bwd_piece(r, acc, fm, tn, nb, k, q, R);
+#pragma unroll
+  for (int c = 0; c < FILM_RED_CHUNKS; ++c) film_red_chunk(c, R, k.lb, k.ftp + 32 * nb, k.H);
 }
 
 // One of the 12 loads (8 FiLM float4, 4 tape float4) of n-block nb's epilogue operands: issued one per k-group behind the
@@ -90,10 +85,12 @@ __device__ __forceinline__ void prefetch_piece(int i, FilmNB& fm, TapeNB& tn, co
 // dz_l (in registers) -> dz_{l-1}: one transposed square stage.  Software pipeline over the n-blocks: behind the MFMAs of
 // body nb run the epilogue of body nb-1 (k-groups 0..15) and the operand loads of body nb+1 (k-groups 16..27).
 template <int H>
-__device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl, float4* slab,
-                                           const float4* tp, float4* dtp) {
+__device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const float* fpl, const float* ppl, const float4* tp,
+                                           const Sink& k) {
+  float4* const slab = k.slab;
   constexpr int NB = H / 32, KGX = H / 8, KGXP = pad_pf(KGX);
-  constexpr bool WIDE = KGX >= 28;                       // enough k-groups to spread the pieces (H = 256)
+  constexpr int NPIECE = 28 + FILM_RED_CHUNKS;           // 16 epilogue + 12 operand loads + the FiLM-sum butterfly
+  constexpr int PP = (NPIECE + KGX - 1) / KGX;           // pieces per k-group (H = 256: 2, done by k-group 18 of 32)
   FilmNB fm_c = film_load(fpl, ppl, 0), fm_n = fm_c, fm_p = fm_c;
   TapeNB tn_c = tape_load(tp, 0), tn_n = tn_c, tn_p = tn_c;
   f32x16 acc_p = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -101,18 +98,14 @@ __device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const
   auto body = [&](int nb, auto has_prev, auto has_next) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BwdQuad q;
+    FilmRed R;
     mfma_x_p<H / 2, KGX, KGXP>(acc, in, ring, [&](int kg) {
-      if (WIDE) {
-        if (kg < 16) { if (has_prev.value) bwd_piece(kg, acc_p, fm_p, tn_p, nb - 1, slab, dtp, q); }
-        else if (kg < 28) { if (has_next.value) prefetch_piece(kg - 16, fm_n, tn_n, fpl, ppl, tp, nb + 1); }
-      } else if (kg < KGX) {                               // small H: several pieces per k-group
-        if (has_prev.value) {
+      if (kg < KGX) {
 #pragma unroll
-          for (int r = kg * (16 / KGX); r < (kg + 1) * (16 / KGX); ++r) bwd_piece(r, acc_p, fm_p, tn_p, nb - 1, slab, dtp, q);
-        }
-        if (has_next.value && kg == KGX - 1) {
-#pragma unroll
-          for (int i = 0; i < 12; ++i) prefetch_piece(i, fm_n, tn_n, fpl, ppl, tp, nb + 1);
+        for (int i = kg * PP; i < (kg + 1) * PP; ++i) {
+          if (i < 16) { if (has_prev.value) bwd_piece(i, acc_p, fm_p, tn_p, nb - 1, k, q, R); }
+          else if (i < 28) { if (has_next.value) prefetch_piece(i - 16, fm_n, tn_n, fpl, ppl, tp, nb + 1); }
+          else if (i < NPIECE) { if (has_prev.value) film_red_chunk(i - 28, R, k.lb, k.ftp + 32 * (nb - 1), k.H); }
         }
       }
     });
@@ -126,7 +119,7 @@ __device__ __forceinline__ void bwd_square(float (&in)[H / 2], Ring& ring, const
     for (int nb = 1; nb < NB - 1; ++nb) body(nb, T{}, T{});
     body(NB - 1, T{}, F{});
   }
-  bwd_store(acc_p, fm_p, tn_p, NB - 1, slab, dtp);
+  bwd_store(acc_p, fm_p, tn_p, NB - 1, k);
   load_act<H / 2>(in, slab);
 }
 
@@ -140,6 +133,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
+  const LaneBits lbits = lane_bits(lane);
   float4* slab = smem + wave * SLAB_F4 + lane;
   const int L = n_geo + n_color;
   const float4* htw = reinterpret_cast<const float4*>(P.stream) + lane;
@@ -157,6 +151,10 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
     const float4* tp = reinterpret_cast<const float4*>(P.tape) + tile * L * (long long)tl + lane;   // + layer * tl
     float4* dtp = reinterpret_cast<float4*>(P.d_t) + tile * L * (long long)tl + lane;
+
+    // FiLM sums of this tile: [layer][2][H]; after the butterfly lane i holds the sum of accumulator register i & 15
+    float* ftp = P.film_tiles + tile * L * 2LL * H + film_lane_feature(lane);
+    auto sink = [&](int layer) { return Sink{slab, dtp + layer * tl, ftp + layer * 2 * H, H, lbits}; };
 
     Ring ring;
     ring.ptr = ring_base;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = MFMA(w.x, b0, acc);
         acc = MFMA(w.y, b1, acc);
-        bwd_store(acc, fm, tn, nb, slab, dtp + l * tl);
+        bwd_store(acc, fm, tn, nb, sink(l));
       }
     }
     float in[H / 2];
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     // ---------------- colour layers L-1 .. n_geo+1 ----------------
 #pragma unroll 1
     for (int l = L - 1; l > n_geo; --l)
-      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl, dtp + (l - 1) * tl);
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, tp + (l - 1) * tl, sink(l - 1));
 
     // ---------------- colour layer 0 + heads: dx_{n_geo-1} = W_c0[:, x]^T dz_{n_geo} + head^T d_head; d(grid feats) ----
     {
@@ -226,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        bwd_store(acc, fm, tn, nb, slab, dtp + l * tl);
+        bwd_store(acc, fm, tn, nb, sink(l));
       }
       if (GRID) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -243,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     // ---------------- geometry trunk n_geo-1 .. 1 ----------------
 #pragma unroll 1
     for (int l = n_geo - 1; l >= 1; --l)
-      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl, dtp + (l - 1) * tl);
+      bwd_square<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, tp + (l - 1) * tl, sink(l - 1));
     __builtin_amdgcn_wave_barrier();
   }
 }

@@ -5,7 +5,7 @@
 // -- three 32-cycle MFMAs per 16 features instead of eight 64-cycle fp32 MFMAs.  Weights are split on the host
 // (hi = RNE, lo = RNE of the remainder: 16+ significant bits); dz is split in the epilogue (hi = truncation, lo = the exact
 // remainder rounded: 16 bits, unbiased) and parked in the LDS slab as ready-made B operands.  Each wave streams its own copy of the weights through a
-// 16-entry register ring (tools/probe/stream_probe.hip: a private L2 stream feeds one MFMA triple per ~180 cycles, 53 % of
+// 8-entry register ring (tools/probe/stream_probe.hip: a private L2 stream feeds one MFMA triple per ~180 cycles, 53 % of
 // the matrix pipe, 2.8x the fp32 path).
 #include <hip/hip_runtime.h>
 
@@ -61,14 +61,19 @@ __device__ __forceinline__ Tape16 tape_load16(const float4* tp, int nb) {
 // register-dump layout), dL/dz in groups of eight: registers 8q..8q+7 are the lane's slots of k-step 2 nb + q.
 // Slab layout (float4 units): [(2 s16 + {0: hi, 1: lo}) * 64 + lane].
 struct BwdOct { float d[4]; unsigned sp[8]; };
-__device__ __forceinline__ void bwd_piece16(int r, const f32x16& acc, const FilmNB& fm, const Tape16& tn, int nb, float4* slab, float4* dtp,
-                                            BwdOct& q) {
+// where an epilogue writes: the lane's LDS slab, the dtheta dump and the FiLM sums of (tile, layer) (fenerf_mfma32.h)
+struct Sink16 { float4* slab; float4* dtp; float* ftp; int H; LaneBits lb; };
+__device__ __forceinline__ void bwd_piece16(int r, const f32x16& acc, const FilmNB& fm, const Tape16& tn, int nb, const Sink16& k, BwdOct& q,
+                                            FilmRed& R) {
+  float4* const slab = k.slab; float4* const dtp = k.dtp;
   const float TWO_PI = 6.28318530717958647692f;
   const int j = r >> 2, i = r & 3;
   const float f = i == 0 ? fm.f[j].x : (i == 1 ? fm.f[j].y : (i == 2 ? fm.f[j].z : fm.f[j].w));
   const float p = i == 0 ? fm.p[j].x : (i == 1 ? fm.p[j].y : (i == 2 ? fm.p[j].z : fm.p[j].w));
   const float dt = acc[r] * cos2pi16(__builtin_fmaf(f, tn.a[r], p));
   q.d[i] = dt;
+  R.v[0][r] = dt;
+  R.v[1][r] = dt * tn.a[r];
   q.sp[r & 7] = split_pack(dt * (f * TWO_PI));
 #ifndef EXP_B16_NOSTORE
 #ifdef EXP_B16_STORE_L2
@@ -86,10 +91,13 @@ __device__ __forceinline__ void bwd_piece16(int r, const f32x16& acc, const Film
   }
 }
 
-__device__ __forceinline__ void bwd_store16(const f32x16& acc, const FilmNB& fm, const Tape16& tn, int nb, float4* slab, float4* dtp) {
+__device__ __forceinline__ void bwd_store16(const f32x16& acc, const FilmNB& fm, const Tape16& tn, int nb, const Sink16& k) {
   BwdOct q;
+  FilmRed R;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bwd_piece16(r, acc, fm, tn, nb, slab, dtp, q);
+  for (int r = 0; r < 16; ++r) bwd_piece16(r, acc, fm, tn, nb, k, q, R);
+#pragma unroll
+  for (int c = 0; c < FILM_RED_CHUNKS; ++c) film_red_chunk(c, R, k.lb, k.ftp + 32 * nb, k.H);
 }
 
 // One of the 12 operand loads (4 tape float4 first -- they come from HBM --, then 8 FiLM float4) of n-block nb's epilogue.
@@ -153,16 +161,19 @@ __device__ __forceinline__ void mfma16_x(f32x16& acc, const Act16<KS>& x, Ring16
 // (The vmcnt queue is in order: a tape load must land before the ring entries issued behind it are consumed, 8 k-steps
 // later, whichever registers it targets -- a third operand set would buy no extra latency tolerance.)
 template <int H>
-__device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, const float* fpl, const float* ppl, float4* slab,
-                                             const float4* tp, float4* dtp) {
+__device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, const float* fpl, const float* ppl, const float4* tp,
+                                             const Sink16& k) {
+  float4* const slab = k.slab;
   constexpr int NB = H / 32, KS = H / 16, EP = pad_pf16(2 * KS);
-  constexpr int PP = (28 + 3 * KS - 1) / (3 * KS);       // pieces per MFMA slot
+  constexpr int NPIECE = 28 + FILM_RED_CHUNKS;           // 16 epilogue + 12 operand loads + the FiLM-sum butterfly
+  constexpr int PP = (NPIECE + 3 * KS - 1) / (3 * KS);   // pieces per MFMA slot
   FilmNB fm = film_load(fpl, ppl, 0);
   Tape16 tn = tape_load16(tp, 0);
   f32x16 acc_p = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto body = [&](int nb, auto has_prev) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BwdOct q;
+    FilmRed R;
     mfma16_x<KS, EP>(acc, in, ring, [](int, float4, float4) {}, [&](int slot) {
 #ifdef EXP_B16_NOPIECE
       if (false) {
@@ -171,8 +182,9 @@ __device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, co
 #endif
 #pragma unroll
         for (int i = slot * PP; i < (slot + 1) * PP; ++i) {
-          if (i < 16) bwd_piece16(i, acc_p, fm, tn, nb - 1, slab, dtp, q);
+          if (i < 16) bwd_piece16(i, acc_p, fm, tn, nb - 1, k, q, R);
           else if (i < 28) prefetch_piece16(i - 16, fm, tn, fpl, ppl, tp, nb);
+          else if (i < NPIECE) film_red_chunk(i - 28, R, k.lb, k.ftp + 32 * (nb - 1), k.H);
         }
       }
     });
@@ -181,7 +193,7 @@ __device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, co
   body(0, std::false_type{});
 #pragma unroll 1
   for (int nb = 1; nb < NB; ++nb) body(nb, std::true_type{});
-  bwd_store16(acc_p, fm, tn, NB - 1, slab, dtp);
+  bwd_store16(acc_p, fm, tn, NB - 1, k);
   load_act16<H / 16>(in, slab);
 }
 
@@ -194,6 +206,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
+  const LaneBits lbits = lane_bits(lane);
   float4* slab = smem + wave * SLAB_F4 + lane;
   const int L = n_geo + n_color;
   const float4* htw = reinterpret_cast<const float4*>(P.stream) + lane;
@@ -229,6 +242,10 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
 #else
     float4* dtp = reinterpret_cast<float4*>(P.d_t) + tile * L * (long long)tl + lane;
 #endif
+
+    // FiLM sums of this tile: [layer][2][H]; after the butterfly lane i holds the sum of accumulator register i & 15
+    float* ftp = P.film_tiles + tile * L * 2LL * H + film_lane_feature(lane);
+    auto sink = [&](int layer) { return Sink16{slab, dtp + layer * tl_d, ftp + layer * 2 * H, H, lbits}; };
 
     Ring16 ring;
     ring.ptr = ring_base;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = MFMA(w.x, b0, acc);
         acc = MFMA(w.y, b1, acc);
-        bwd_store16(acc, fm, tn, nb, slab, dtp + l * tl_d);
+        bwd_store16(acc, fm, tn, nb, sink(l));
       }
     }
     Act16<KS> in;
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
     // ---------------- colour layers L-1 .. n_geo+1 ----------------
 #pragma unroll 1
     for (int l = L - 1; l > n_geo; --l)
-      bwd_square16<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl_t, dtp + (l - 1) * tl_d);
+      bwd_square16<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, tp + (l - 1) * tl_t, sink(l - 1));
 
     // ---------------- colour layer 0 + heads: dx_{n_geo-1} = W_c0[:, x]^T dz_{n_geo} + head^T d_head; d(grid feats) ----
     {
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
         }, [](int) {});
         // the slab is this stage's input until every n-block has been computed: park the outputs behind it? no -- the
         // input lives in registers (in), so overwriting the slab n-block by n-block is safe.
-        bwd_store16(acc, fm, tn, nb, slab, dtp + l * tl_d);
+        bwd_store16(acc, fm, tn, nb, sink(l));
       }
       if (GRID) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
     // ---------------- geometry trunk n_geo-1 .. 1 ----------------
 #pragma unroll 1
     for (int l = n_geo - 1; l >= 1; --l)
-      bwd_square16<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, slab, tp + (l - 1) * tl_t, dtp + (l - 1) * tl_d);
+      bwd_square16<H>(in, ring, fpl + (size_t)(l - 1) * H, ppl + (size_t)(l - 1) * H, tp + (l - 1) * tl_t, sink(l - 1));
     __builtin_amdgcn_wave_barrier();
   }
 }

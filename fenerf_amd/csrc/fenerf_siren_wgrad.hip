@@ -41,7 +41,8 @@ struct WgradParams {
   int film_stride;             // chunk slots per (layer, image) in film_partial (>= every launch's nchunk)
   int layer0;                  // WG_SQ: first layer of the launch (blockIdx.z -> layer0 + z); other jobs: the layer
   float* partial;              // [z][b][chunk][MT*32][KT*32]
-  float* film_partial;         // [L][b][chunk][H][2] or nullptr
+  float* film_partial;         // [L][b][chunk][H][2]: the chain kernel's per-tile FiLM sums gathered per chunk
+  const float* film_tiles;     // [tiles][L][2][H] from the chain kernel (fenerf_layout.h "FiLM sums")
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
 };
 
@@ -93,7 +94,6 @@ struct WgShape {
   static constexpr int WK = (KT + WGK - 1) / WGK;
   static constexpr bool A_DUMP = (JOB == WG_SQ || JOB == WG_L0 || JOB == WG_C0X);
   static constexpr bool B_DUMP = (JOB == WG_SQ || JOB == WG_HEAD || JOB == WG_RGB);
-  static constexpr bool FILM = (JOB == WG_SQ || JOB == WG_L0);   // FiLM sums of layer l (needs tape_l as well)
   static constexpr int A_ROWS = MT * 32, B_ROWS = KT * 32;
 };
 
@@ -104,11 +104,8 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* A_s = lds;                                         // [A_ROWS][WG_LD]
   float* B_s = A_s + S::A_ROWS * WG_LD;                     // [B_ROWS][WG_LD]
-  float* C_s = B_s + S::B_ROWS * WG_LD;                     // FILM: tape_l rows [H][WG_LD]
-  float* f_s = C_s + (S::FILM ? H * WG_LD : 0);             // f', p' of the B-side layer; bias of layer l
+  float* f_s = B_s + S::B_ROWS * WG_LD;                     // f', p' of the B-side layer
   float* p_s = f_s + H;
-  float* b_s = p_s + H;
-  float* i_s = b_s + H;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,7 +115,6 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   const int L = P.L, C = P.C;
 
   if (S::B_DUMP) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
-  if (S::FILM) for (int i = tid; i < H; i += 256) { b_s[i] = P.bias[(size_t)l * H + i]; i_s[i] = P.inv ? P.inv[(size_t)l * H + i] : 1.f; }
   if (!S::A_DUMP) for (int i = tid; i < S::A_ROWS * WG_LD; i += 256) A_s[i] = 0.f;     // padded rows stay zero
   if (!S::B_DUMP) for (int i = tid; i < S::B_ROWS * WG_LD; i += 256) B_s[i] = 0.f;
   __syncthreads();
@@ -138,14 +134,13 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / S::WGK) * S::WM, wk0 = (wave % S::WGK) * S::WK;
-  float s0 = 0.f, s1 = 0.f;    // FiLM sums (thread = row) / head row sums
+  float s0 = 0.f;              // head row sums (thread = row)
 
-  float4 va[NQ], vb[NQ], vc[NQ];
+  float4 va[NQ], vb[NQ];
   auto fetch = [&](int t) {
     const long long tile = tile_base + t;
     if (S::A_DUMP) load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
     if (S::B_DUMP) load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
-    if (S::FILM) load_dump<H>(vc, tape4 + (tile * L + l) * tl, wave, lane);
   };
   if (t0 < t1) fetch(t0);
   for (int t = t0; t < t1; ++t) {
@@ -153,7 +148,6 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
     // ---- stage the tile
     if (S::A_DUMP) stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
     if (S::B_DUMP) stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
-    if (S::FILM) stage_dump<H, false>(vc, C_s, wave, lane, nullptr, nullptr);
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
       if (tid < 96) { const int c = tid >> 5, m = tid & 31; B_s[c * WG_LD + m] = P.points[(pt0 + m) * 3 + c] * P.box_scale; }
     }
@@ -186,19 +180,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
     if (t + 1 < t1) fetch(t + 1);          // next tile's global loads fly behind this tile's MFMAs
 
     // ---- row sums (thread = row)
-    if (S::FILM) {
-      if (tid < H) {
-        const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
-        const float4* cr = reinterpret_cast<const float4*>(C_s + tid * WG_LD);
-        const float bb = b_s[tid], iv = i_s[tid];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 a = ar[q], c = cr[q];
-          s0 += (a.x + a.y) + (a.z + a.w);
-          s1 += (a.x * __builtin_fmaf(c.x, iv, bb) + a.y * __builtin_fmaf(c.y, iv, bb)) + (a.z * __builtin_fmaf(c.z, iv, bb) + a.w * __builtin_fmaf(c.w, iv, bb));
-        }
-      }
-    } else if (JOB == WG_HEAD || JOB == WG_RGB) {
+    if (JOB == WG_HEAD || JOB == WG_RGB) {
       if (tid < 32) {
         const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
 #pragma unroll
@@ -258,10 +240,6 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
             const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
           }
-    if (S::FILM && tid < H) {
-      float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + tid) * 2;
-      fpart[0] = s0; fpart[1] = s1;
-    }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
   }
 }
@@ -274,8 +252,8 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
 // no a-priori range.  Used for FENERF_PREC_F16X3 models; FENERF_PREC_F32 models keep the exact fp32 job above.
 //
 // LDS image: A_p / B_p rows [feature][32 points] of split-packed dwords (hi | lo << 16), row stride WG_LD -- the lane's 8
-// consecutive points of a k-step are two 128-bit reads and four v_perm_b32 per half; A_f / C_s keep fp32 rows of dtheta_l
-// and tape_l for the (exact) FiLM sums.  With the MFMA time cut 5x the kernel is bound by the three tape reads.
+// consecutive points of a k-step are two 128-bit reads and four v_perm_b32 per half.  With the MFMA time cut 5x the kernel
+// is bound by its two dump reads (dtheta_l, tape_{l-1}); the FiLM sums come from the chain kernel (film_gather_kernel).
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -311,22 +289,15 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* A_p = reinterpret_cast<unsigned*>(lds);          // [H][WG_LD] split-packed dtheta_l
   unsigned* B_p = A_p + H * WG_LD;                            // [H][WG_LD] split-packed x_{l-1}
-  float* A_f = reinterpret_cast<float*>(B_p + H * WG_LD);     // [H][WG_LD] fp32 dtheta_l (FiLM sums)
-  float* C_s = A_f + H * WG_LD;                               // [H][WG_LD] fp32 tape_l
-  float* f_s = C_s + H * WG_LD;
+  float* f_s = reinterpret_cast<float*>(B_p + H * WG_LD);
   float* p_s = f_s + H;
-  float* b_s = p_s + H;
-  float* i_s = b_s + H;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunk = blockIdx.x, img = blockIdx.y;
   const int l = P.layer0 + blockIdx.z, lb = l - 1;
   const int L = P.L;
-  for (int i = tid; i < H; i += 256) {
-    f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i];
-    b_s[i] = P.bias[(size_t)l * H + i]; i_s[i] = P.inv ? P.inv[(size_t)l * H + i] : 1.f;
-  }
+  for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
   __syncthreads();
 
   const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
@@ -344,11 +315,10 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
-  float s0 = 0.f, s1 = 0.f;
   const int m = lane & 31, half = lane >> 5;
   const bool stager = wave * GPW < NG;                      // small H: fewer dump groups than waves
 
-  float4 va[GPW], vb[GPW], vc[GPW];
+  float4 va[GPW], vb[GPW];
   auto fetch = [&](int t) {
     if (!stager) return;
     const long long tile = tile_base + t;
@@ -357,7 +327,6 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       const int g = wave * GPW + q;
       va[q] = dt4[(tile * L + l) * tl + g * 64 + lane];
       vb[q] = tape4[(tile * L + lb) * tl + g * 64 + lane];
-      vc[q] = tape4[(tile * L + l) * tl + g * 64 + lane];
     }
   };
   if (t0 < t1) fetch(t0);
@@ -377,16 +346,13 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
           const int row = tape_feature(wave * GPW + hq + q, half, 0);
-          const float4 a = va[hq + q], b = vb[hq + q], cc = vc[hq + q];
+          const float4 a = va[hq + q], b = vb[hq + q];
           const float d[4] = {a.x, a.y, a.z, a.w};
-          const float c[4] = {cc.x, cc.y, cc.z, cc.w};
           const float x[4] = {sin2pi(__builtin_fmaf(f4[q].x, b.x, p4[q].x)), sin2pi(__builtin_fmaf(f4[q].y, b.y, p4[q].y)),
                               sin2pi(__builtin_fmaf(f4[q].z, b.z, p4[q].z)), sin2pi(__builtin_fmaf(f4[q].w, b.w, p4[q].w))};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int o = (row + i) * WG_LD + m;
-            A_f[o] = d[i];
-            C_s[o] = c[i];
             A_p[o] = split_pack_bf16(d[i]);
             B_p[o] = split_pack_bf16(x[i]);
           }
@@ -396,18 +362,6 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
     __syncthreads();
     if (t + 1 < t1) fetch(t + 1);
 
-    // ---- FiLM sums (thread = row), exact fp32
-    if (tid < H) {
-      const float4* ar = reinterpret_cast<const float4*>(A_f + tid * WG_LD);
-      const float4* cr = reinterpret_cast<const float4*>(C_s + tid * WG_LD);
-      const float bb = b_s[tid], iv = i_s[tid];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 a = ar[q], c = cr[q];
-        s0 += (a.x + a.y) + (a.z + a.w);
-        s1 += (a.x * __builtin_fmaf(c.x, iv, bb) + a.y * __builtin_fmaf(c.y, iv, bb)) + (a.z * __builtin_fmaf(c.z, iv, bb) + a.w * __builtin_fmaf(c.w, iv, bb));
-      }
-    }
     // ---- MFMA: lane (i, kh) contracts points 16 ks + 8 kh + {0..7} in k-step ks (same order on both operands)
     {
       const int i = lane & 31, kh = lane >> 5;
@@ -451,58 +405,32 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
           out[(size_t)row * H + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
         }
-  if (tid < H) {
-    float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + tid) * 2;
-    fpart[0] = s0; fpart[1] = s1;
-  }
 }
 
-// Inversion optimises only the FiLM frequencies / phases (inverse_render_double_semantic.py:324-350): the FiLM sums alone,
-// straight from the two dumps -- per-lane partial sums over the block's tiles, one cross-lane reduction at the end.
-template <int H>
-__global__ __launch_bounds__(256) void film_sums_kernel(WgradParams P) {
-  constexpr int NQ = H / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// FiLM sums: the chain kernel left s0 = sum_p dtheta, s1 = sum_p dtheta * tape per (tile, layer, feature); this gathers
+// them per (layer, image, chunk of tiles) into film_partial -- with d theta / d f = W x + b = tape * inv + bias applied --
+// for film_reduce_kernel.  Inversion (inverse_render_double_semantic.py:324-350 optimises only the FiLM frequencies /
+// phases) needs nothing else from the weight-gradient stage.
+__global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
+  const int H = P.H, L = P.L;
   const int chunk = blockIdx.x, img = blockIdx.y, l = blockIdx.z;
-  const int L = P.L;
   const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
   const int t0 = chunk * t_per, t1 = min(P.tiles_per_image, t0 + t_per);
   const long long tile_base = (long long)img * P.tiles_per_image;
-  const long long tl = (long long)(H / 8) * 64;
-  const float4* tape4 = reinterpret_cast<const float4*>(P.tape);
-  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
-  float s0[NQ][4], s1[NQ][4], bb[NQ][4], iv[NQ][4];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s0[q][i] = 0.f; s1[q][i] = 0.f;
-      bb[q][i] = P.bias[(size_t)l * H + tape_feature(wave * NQ + q, lane >> 5, i)];
-      iv[q][i] = P.inv ? P.inv[(size_t)l * H + tape_feature(wave * NQ + q, lane >> 5, i)] : 1.f;
+  for (int n = threadIdx.x; n < H; n += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;     // two independent chains: the loads are latency-bound
+    int t = t0;
+    for (; t + 2 <= t1; t += 2) {
+      const float* p0 = P.film_tiles + ((tile_base + t) * L + l) * 2LL * H + n;
+      const float* p1 = p0 + (long long)L * 2 * H;
+      a0 += p0[0]; a1 += p0[H]; b0 += p1[0]; b1 += p1[H];
     }
-  for (int t = t0; t < t1; ++t) {
-    const long long base = ((tile_base + t) * L + l) * tl;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const float4 d = dt4[base + (wave * NQ + q) * 64 + lane], z = tape4[base + (wave * NQ + q) * 64 + lane];
-      s0[q][0] += d.x; s0[q][1] += d.y; s0[q][2] += d.z; s0[q][3] += d.w;
-      s1[q][0] += d.x * __builtin_fmaf(z.x, iv[q][0], bb[q][0]); s1[q][1] += d.y * __builtin_fmaf(z.y, iv[q][1], bb[q][1]);
-      s1[q][2] += d.z * __builtin_fmaf(z.z, iv[q][2], bb[q][2]); s1[q][3] += d.w * __builtin_fmaf(z.w, iv[q][3], bb[q][3]);
-    }
+    if (t < t1) { const float* p0 = P.film_tiles + ((tile_base + t) * L + l) * 2LL * H + n; a0 += p0[0]; a1 += p0[H]; }
+    const float s0 = a0 + b0, s1 = a1 + b1;
+    const float iv = P.inv ? P.inv[(size_t)l * H + n] : 1.f, bb = P.bias[(size_t)l * H + n];
+    float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + n) * 2;
+    fpart[0] = s0; fpart[1] = __builtin_fmaf(s1, iv, s0 * bb);
   }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float a = s0[q][i], b = s1[q][i];
-#pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }   // over the 32 points of a half
-      if ((lane & 31) == 0) {
-        const int n = tape_feature(wave * NQ + q, lane >> 5, i);
-        float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + n) * 2;
-        fpart[0] = a; fpart[1] = b;
-      }
-    }
 }
 
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
@@ -599,7 +527,7 @@ int hipfail(hipError_t e, const char* what) {
 template <int H, int JOB>
 size_t wg_lds_bytes() {
   using S = WgShape<H, JOB>;
-  return (size_t)((S::A_ROWS + S::B_ROWS + (S::FILM ? H : 0)) * WG_LD + 4 * H) * sizeof(float);
+  return (size_t)((S::A_ROWS + S::B_ROWS) * WG_LD + 2 * H) * sizeof(float);
 }
 
 template <int H, int JOB>
@@ -620,7 +548,7 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
 template <int H>
 int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   auto kfn = siren_wgrad_sq_bf16_kernel<H>;
-  const size_t lds = (size_t)(4 * H * WG_LD + 4 * H) * sizeof(float);
+  const size_t lds = (size_t)(2 * H * WG_LD + 2 * H) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -665,9 +593,12 @@ int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
   return (int)(n < 1 ? 1 : n);
 }
 
+// chunks of tiles per (layer, image) of the FiLM-sum gather
+static int film_nchunk(long long tiles_per_image) { return (int)(tiles_per_image < 64 ? tiles_per_image : 64); }
+
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
   const long long tiles = (P + 31) / 32;
-  const int nc = wgrad_nchunk(m, B, tiles), nt = wgrad_nchunk_thin(m, B, tiles), ncm = nc > nt ? nc : nt;
+  const int nc = wgrad_nchunk(m, B, tiles), nt = wgrad_nchunk_thin(m, B, tiles), ncm = film_nchunk(tiles) > nt ? film_nchunk(tiles) : nt;
   const size_t H = m->H;
   size_t sq = (size_t)(m->L - 1) * B * nc * H * H;         // square partials
   const size_t thin = (size_t)B * nt * H * (H > 64 ? H : 64);   // the thin jobs reuse the buffer: [B][nt][<= H x max(H, 64)]
@@ -681,7 +612,7 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
 template <int H>
 static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, bool film_only, hipStream_t st) {
   const int L = m->L, ng = m->n_geo, B = p.B;
-  const int nc = p.nchunk, nt = wgrad_nchunk_thin(m, B, p.tiles_per_image), ncm = nc > nt ? nc : nt;
+  const int nc = p.nchunk, nt = wgrad_nchunk_thin(m, B, p.tiles_per_image), nf = film_nchunk(p.tiles_per_image), ncm = nf > nt ? nf : nt;
   const int G = m->grid_ch;
   float* sq = ws;
   size_t sq_floats = (size_t)(L - 1) * B * nc * H * H;
@@ -689,16 +620,19 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   if (thin_floats > sq_floats) sq_floats = thin_floats;
   float* film = sq + sq_floats;
   float* rows = film + (size_t)L * B * ncm * H * 2;
-  p.film_partial = film; p.rowsum_partial = rows; p.film_stride = ncm;
+  p.film_partial = film; p.rowsum_partial = rows; p.film_stride = nf;
   int rc;
-  if (film_only) {
-    hipLaunchKernelGGL(film_sums_kernel<H>, dim3(nc, B, L), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nc, nc, ncm, p.fp, p.inv, g.d_freq_geo,
+  {  // FiLM frequency / phase gradients and the FiLM-layer biases: gather the chain kernel's per-tile sums, reduce
+    WgradParams pf = p;
+    pf.nchunk = nf;
+    hipLaunchKernelGGL(film_gather_kernel, dim3(nf, B, L), dim3(256), 0, st, pf);
+    hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nf, nf, nf, p.fp, p.inv, g.d_freq_geo,
                        g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? FENERF_OK : hipfail(e, "film sums launch");
+    if (e != hipSuccess) return hipfail(e, "film sums launch");
   }
-  // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch; FiLM sums of layers 1..L-1
+  if (film_only) return FENERF_OK;
+  // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch
   p.partial = sq; p.layer0 = 1;
   if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
   hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
@@ -707,8 +641,6 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   p.layer0 = 0;
   if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
   reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nt, p.fp, p.inv, L, H, 0, st);
-  hipLaunchKernelGGL(film_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, film, B, L, H, ng, nt, nc, ncm, p.fp, p.inv, g.d_freq_geo,
-                     g.d_phase_geo, g.d_freq_app, g.d_phase_app, g);
   p.layer0 = ng;
   if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
   reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nt, p.fp, p.inv, L, H, ng, st);          // view direction columns
@@ -730,7 +662,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream) {
   WgradParams p;
   memset(&p, 0, sizeof(p));
-  p.tape = tape; p.d_t = d_t; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
+  p.tape = tape; p.d_t = d_t; p.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
   p.fp = fp; p.pp = pp; p.bias = m->d_consts + CONST_FILM_BIAS;
   p.inv = m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr;
   p.box_scale = m->box_scale;

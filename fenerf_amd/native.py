@@ -103,19 +103,75 @@ class NativeModel:
         _, ex = torch.frexp(m)
         return torch.where(m > 0, torch.ldexp(torch.ones_like(m), -ex), torch.ones_like(m))
 
-    def load_from_device(self, params):
-        """Re-pack from device-resident parameters {reference name: tensor} without touching the host."""
-        stream, consts, bwd, grid = self._pack_on_device(params)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().fenerf_model_load_packed(self._h, _ptr(stream), stream.numel(), _ptr(consts), consts.numel(), _ptr(bwd),
-                                                           bwd.numel() if bwd is not None else 0, _ptr(grid), _stream()))
-
-    def _pack_on_device(self, params):
-        """(stream, consts, backward stream or None, grid or None) as torch tensors on self.device: gathers through the index
-        maps (f16x3: after scaling rows and splitting into fp16 hi / lo).  Pure torch -- also runs on the CPU (layout tests)."""
-        maps = self._index_maps()
+    def _scaled_rows(self):
+        """(film_w names, head_w names) -- the matrices whose rows get a power-of-two scale at f16x3 (row_scales() of fenerf_pack.cpp)"""
         sp = self.spec
-        H, ng, nc, n_lab = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["output_dim"] - 4
+        ng, nc, n_lab = sp["n_geo"], sp["n_color"], sp["output_dim"] - 4
+        cname = (lambda i: "color_layer_sine.layer") if sp["kind"] == "spatial" else (lambda i: f"color_layer_sine.{i}.layer")
+        film_w = [f"network.{i}.layer.weight" for i in range(1, ng)] + [cname(i) + ".weight" for i in range(nc)]
+        head_w = (["label_layer_linear.0.weight"] if n_lab > 0 else []) + ["final_layer.weight", "color_layer_linear.0.weight"]
+        return film_w, head_w
+
+    def _repack_maps(self):
+        """FenerfRepackMaps for fenerf_model_repack, built once: the index maps as int32 device arrays, plus (f16x3) the table of
+        scaled rows, the per-element scale ids and the layout of the result scales behind the fp32 consts."""
+        if getattr(self, "_rmaps", None) is None:
+            maps = self._index_maps()
+            sp = self.spec
+            H, L, n_lab = sp["hidden_dim"], sp["n_geo"] + sp["n_color"], sp["output_dim"] - 4
+            keep, r = {}, _lib.FenerfRepackMaps()
+
+            def put(field, t, nfield=None):
+                t = (t if torch.is_tensor(t) else torch.from_numpy(np.asarray(t))).to(self.device, torch.int32).contiguous()
+                keep[field] = t
+                setattr(r, field, t.data_ptr())
+                if nfield:
+                    setattr(r, nfield, t.numel())
+
+            if self.precision == "f32":
+                put("stream_f32", maps["stream"], "n_stream_f32")
+                put("consts", maps["consts"], "n_consts")
+                if self.differentiable:
+                    put("bwd_f32", maps["bwd"], "n_bwd_f32")
+            else:
+                put("stream_f32", maps["l0"], "n_stream_f32")
+                put("stream_h16", maps["h_idx"] | (maps["h_lo"].long() << 30), "n_stream_h16")
+                put("consts", maps["consts"], "n_consts")
+                if self.differentiable:
+                    put("bwd_f32", maps["bwd_head"], "n_bwd_f32")
+                    put("bwd_b16", maps["bwd16_idx"], "n_bwd_b16")
+                film_w, head_w = self._scaled_rows()
+                off, start = 1, {}
+                for name, sh in self._canonical():
+                    start[name] = (off, sh)
+                    off += int(np.prod(sh))
+                row_off, row_len, row_film, row0 = [], [], [], {}
+                scale_id = np.zeros(off, np.int32)
+                for name in film_w + head_w:
+                    o, (rows, cols) = start[name]
+                    row0[name] = len(row_off)
+                    for q in range(rows):
+                        scale_id[o + q * cols: o + (q + 1) * cols] = 1 + len(row_off)
+                        row_off.append(o + q * cols); row_len.append(cols); row_film.append(1 if name in film_w else 0)
+                put("row_off", row_off); put("row_len", row_len); put("row_film", row_film); put("scale_id", scale_id)
+                r.n_rows = len(row_off)
+                # result scales behind the fp32 consts: [L][H] per FiLM layer (layer 0 unscaled), head [32], rgb [4]
+                tail = [-1] * H
+                for name in film_w:
+                    tail += [1 + row0[name] + n for n in range(H)]
+                head = [0] * 32
+                if n_lab > 0:
+                    head[:n_lab] = [1 + row0["label_layer_linear.0.weight"] + q for q in range(n_lab)]
+                head[n_lab] = 1 + row0["final_layer.weight"]
+                tail += head + [1 + row0["color_layer_linear.0.weight"] + c for c in range(3)] + [-1]
+                put("consts_tail", tail, "n_tail")
+            self._rmaps = (r, keep)
+        return self._rmaps[0]
+
+    def _flat_params(self, params):
+        """({name: fp32 device tensor} with the label head folded, the canonical flat vector behind a leading 0)"""
+        sp = self.spec
+        n_lab = sp["output_dim"] - 4
         dev = self.device
         p = {k: v.detach().to(dev, torch.float32) for k, v in params.items()}
         if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
@@ -125,18 +181,53 @@ class NativeModel:
                 c = W @ c + b
                 A = W @ A
             p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
+        flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
+        return p, flat
+
+    def load_from_device(self, params):
+        """Re-pack from device-resident parameters {reference name: tensor} without touching the host: one concatenation,
+        then fenerf_model_repack gathers / scales / splits straight into the model's resident streams."""
+        p, flat = self._flat_params(params)
+        grid = p.get("spatial_embeddings")
+        grid = grid.contiguous() if grid is not None else None
+        r = self._repack_maps()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_model_repack(self._h, _ptr(flat), flat.numel(), C.byref(r), _ptr(grid), _stream()))
+
+    def export_packed(self):
+        """(stream, consts, backward stream or None) copies of the resident packed buffers (tests)."""
+        n = lambda key: self._index_maps()[key].numel()
+        if self.precision == "f32":
+            ns, nc, nb = n("stream"), n("consts"), (n("bwd") if self.differentiable else 0)
+        else:
+            H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
+            ns, nc = n("l0") + n("h_idx") // 2, n("consts") + L * H + 36
+            nb = n("bwd_head") + n("bwd16_idx") // 2 if self.differentiable else 0
+        new = lambda k: torch.empty(k, dtype=torch.float32, device=self.device)
+        stream, consts, bwd = new(ns), new(nc), (new(nb) if nb else None)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_model_export_packed(self._h, _ptr(stream), ns, _ptr(consts), nc, _ptr(bwd), nb, _stream()))
+        return stream, consts, bwd
+
+    def _pack_on_device(self, params):
+        """(stream, consts, backward stream or None, grid or None) as torch tensors on self.device: the re-pack of
+        fenerf_model_repack spelled out in torch ops (gathers through the index maps; f16x3: after scaling rows and splitting
+        into fp16 / bf16 hi, lo).  Not on the product path: the layout tests run it on the CPU against the host packer and on
+        the GPU against the native re-pack, bit for bit."""
+        maps = self._index_maps()
+        sp = self.spec
+        H, ng, nc, n_lab = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["output_dim"] - 4
+        dev = self.device
+        p, flat = self._flat_params(params)
         items = self._canonical()
         zero = torch.zeros(1, device=dev)
-        flat = torch.cat([zero] + [p[name].reshape(-1) for name, _ in items])
         bwd = None
         if self.precision == "f32":
             stream, consts = flat[maps["stream"]], flat[maps["consts"]]
             if self.differentiable:
                 bwd = flat[maps["bwd"]]
         else:
-            cname = (lambda i: "color_layer_sine.layer") if sp["kind"] == "spatial" else (lambda i: f"color_layer_sine.{i}.layer")
-            film_w = [f"network.{i}.layer.weight" for i in range(1, ng)] + [cname(i) + ".weight" for i in range(nc)]
-            head_w = (["label_layer_linear.0.weight"] if n_lab > 0 else []) + ["final_layer.weight", "color_layer_linear.0.weight"]
+            film_w, head_w = self._scaled_rows()
             sc = {k: self._row_scale(p[k]) for k in film_w + head_w}
             scaled = lambda name, extra=1.0: (p[name] * (sc[name] * extra)[:, None]) if name in sc else p[name]
             flat_s = torch.cat([zero] + [scaled(name).reshape(-1) for name, _ in items])
@@ -226,11 +317,11 @@ class NativeModel:
         return out, tape, tape_e
 
     def siren_backward(self, B, P, fg, pg, fa, pa, out, d_out, tape):
-        """-> (d_t [L,H,B*P] = dL/dtheta per FiLM layer, d_e [B*P,32] or None)"""
-        H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
+        """-> (d_t = dL/dtheta per FiLM layer in the tape's layout + the per-tile FiLM sums (opaque, fenerf_siren_dtheta_floats),
+        d_e [B*P,32] or None)"""
         fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
         out, d_out = _f32(out, self.device), _f32(d_out, self.device)
-        d_t = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
+        d_t = torch.empty((int(_lib.lib().fenerf_siren_dtheta_floats(self._h, B * P)),), dtype=torch.float32, device=self.device)
         d_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device) if self.spec["grid_ch"] else None
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))

@@ -129,6 +129,34 @@ int fenerf_pack_backward_index_map_bf16(const FenerfModelDesc* desc, int32_t** m
 int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev, size_t n_stream, const float* consts_dev, size_t n_consts,
                              const float* bwd_dev, size_t n_bwd, const float* grid_dev, void* stream);
 
+/* The same re-pack done natively, straight into the model's resident buffers (four small kernels instead of a hundred
+ * framework ops; replaces what optimizer.step() on a resident nn.Module costs the reference: nothing).  flat_dev = every
+ * render parameter concatenated in the caller's canonical order behind a leading 0 (so index 0 = "zero"); the maps are
+ * [dev] int32 arrays built ONCE from the fenerf_pack_*_host / fenerf_pack_*index_map* results on index-valued weights:
+ *   stream_f32 / consts / bwd_f32 : fp32 elements -> flat index (whole streams for FENERF_PREC_F32; the fp32 layer-0 block,
+ *                                    the fp32 consts and the fp32 rgb-head block for FENERF_PREC_F16X3)
+ *   stream_h16 : fp16 halves of the forward ring, flat index | is_lo << 30        (fenerf_pack_index_map_f16)
+ *   bwd_b16    : bf16 halves of the backward ring, hi / lo alternate per 512       (fenerf_pack_backward_index_map_bf16)
+ *   row_off / row_len / row_film : the rows that get a power-of-two scale (FiLM layers >= 1 and the heads): flat offset,
+ *                                    length, 1 for FiLM-layer rows;  scale_id[flat index] = 1 + row, 0 = unscaled
+ *   consts_tail: the f16x3 result scales behind the fp32 consts: k > 0 -> 1 / (16 scale[k]), 0 -> 1/16, < 0 -> 1
+ * Unused maps are NULL / 0.  grid_dev = spatial_embeddings [1,32,D,H,W] or NULL (unchanged). */
+typedef struct FenerfRepackMaps {
+  const int32_t* stream_f32; size_t n_stream_f32;
+  const int32_t* stream_h16; size_t n_stream_h16;
+  const int32_t* consts;     size_t n_consts;
+  const int32_t* consts_tail; size_t n_tail;
+  const int32_t* bwd_f32;    size_t n_bwd_f32;
+  const int32_t* bwd_b16;    size_t n_bwd_b16;
+  const int32_t* row_off; const int32_t* row_len; const int32_t* row_film; int32_t n_rows;
+  const int32_t* scale_id;
+} FenerfRepackMaps;
+int fenerf_model_repack(FenerfModel* m, const float* flat_dev, size_t n_flat, const FenerfRepackMaps* maps, const float* grid_dev,
+                        void* stream);
+/* Copies the resident packed buffers out (device to device): tests compare re-packs bit for bit.  NULL = skip. */
+int fenerf_model_export_packed(const FenerfModel* m, float* stream_dev, size_t n_stream, float* consts_dev, size_t n_consts,
+                               float* bwd_dev, size_t n_bwd, void* stream);
+
 /* Bytes of [dev] scratch the FiLM pre-pass needs for a batch of B images. */
 size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B);
 
@@ -201,8 +229,10 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
  *   every FiLM layer as a tape of fenerf_siren_tape_floats(m, B*P) floats (opaque: 32-point register dumps,
  *   fenerf_amd/csrc/fenerf_layout.h "Tape"; for FENERF_PREC_F16X3 models in the row-scaled units of that GEMM) and the
  *   sampled grid features tape_e [B*P][32] (NULL without a grid).
- * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t (same size and layout as the tape) = dL/dtheta per FiLM layer,
- *   theta = f (W x + b) + p, and d_e [B*P][32] = gradient wrt the sampled grid features (NULL without a grid).
+ * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t = dL/dtheta per FiLM layer in the tape's layout, theta = f (W x + b) + p,
+ *   followed by the per-tile FiLM sums (sum over the tile's points of dtheta and dtheta * tape, which the kernel has in
+ *   registers): fenerf_siren_dtheta_floats(m, B*P) floats in all; and d_e [B*P][32] = gradient wrt the sampled grid
+ *   features (NULL without a grid).
  * fenerf_siren_param_grads: (tape, d_t) -> every parameter gradient, written to the buffers of FenerfSirenGrads.  With all
  *   weight / bias pointers NULL only the FiLM gradients (d_freq_*, d_phase_*) are computed -- what inversion optimises
  *   (inverse_render_double_semantic.py:324-350).
@@ -221,6 +251,7 @@ typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in
 } FenerfSirenGrads;
 
 size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
+size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points);
 int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                               const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
                               float* out, float* tape, float* tape_e, void* film_ws, void* stream);

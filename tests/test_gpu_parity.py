@@ -844,6 +844,31 @@ def test_device_side_repack_matches_host_pack(precision):
     print("[parity] device-side re-pack == host pack: forward max|diff| %.2e" % np.abs(out_dev - out_host).max())
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("kind,H,grid", [("texture", 64, 5), ("baseline", 32, 0), ("spatial", 32, 0), ("texture", 256, 6)])
+def test_native_repack_is_the_torch_repack_bit_for_bit(kind, H, grid, precision):
+    """fenerf_model_repack (row scales, gathers, fp16 / bf16 hi-lo splits in four kernels, written in place) against the same
+    re-pack spelled out in torch ops (NativeModel._pack_on_device, itself pinned to the host packer on the CPU): forward
+    stream, consts and backward stream must be identical bit patterns."""
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=21, sigma_gain=10.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV, precision, differentiable=True)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    params = {k: (torch.from_numpy(v) * (1.0 + 0.05 * torch.randn(v.shape, generator=gen))).float().to(DEV) for k, v in sd.items()}
+    nat.load_from_device(params)
+    got = nat.export_packed()
+    want = nat._pack_on_device(params)[:3]
+    for name, g, w in zip(("stream", "consts", "bwd"), got, want):
+        assert g.numel() == w.numel(), name
+        assert torch.equal(g.view(torch.int32), w.view(torch.int32)), f"{name}: {(g.view(torch.int32) != w.view(torch.int32)).sum().item()} words differ"
+    # and the host packer agrees (but for the fp32- vs fp64-folded label rows)
+    host = native.NativeModel({k: N_(v) for k, v in params.items()}, spec, DEV, precision, differentiable=True).export_packed()
+    for name, g, w in zip(("stream", "consts", "bwd"), got, host):
+        frac = (g.view(torch.int32) != w.view(torch.int32)).float().mean().item()
+        assert frac <= (0.05 if spec["n_label_layers"] > 1 else 0.0), (name, frac)
+    print(f"[parity] native re-pack {kind} H={H} {precision}: {sum(t.numel() for t in got)} words identical to the torch spelling")
+
+
 def test_inversion_film_only_gradients_and_loop():
     """Inversion (inverse_render_double_semantic.py:306-410): with the generator's weights frozen only the FiLM gradients are
     computed (film_sums_kernel); they must equal the FiLM gradients of the full backward, and the optimisation loop must

@@ -104,7 +104,7 @@ def emulate_chain(blob, spec, theta, f_true, row_scale, d_out, out):
     return dtheta, d_e
 
 
-PF16 = 16
+PF16 = 8
 
 
 def mfma16(a, b, acc):
