@@ -93,6 +93,7 @@ _SIGS = {
     "fenerf_siren_grad_workspace_bytes": (_sz, [_vp, _i, _i64]),
     "fenerf_siren_param_grads": (_i, [_vp, _i, _i64] + [_vp] * 11 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_grid_backward": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "fenerf_grid_gradient_ncdhw": (_i, [_vp, _vp, _vp, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),

@@ -462,6 +462,13 @@ extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, 
   return launch_grid_backward(m, total_points, points, d_e, d_grid_cl, stream);
 }
 
+extern "C" int fenerf_grid_gradient_ncdhw(const FenerfModel* m, const float* d_grid_cl, float* d_grid_ncdhw, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "model has no feature grid");
+  if (!d_grid_cl || !d_grid_ncdhw) return fail(FENERF_E_INVALID, "NULL pointer");
+  return launch_grid_unlayout(d_grid_cl, d_grid_ncdhw, m->gd, m->gh, m->gw, stream);
+}
+
 extern "C" int fenerf_composite_backward(int64_t BR, int N, int C, int merge, const float* rows_a, const float* rows_b,
                                          const float* z_a, const float* z_b, const float* noise, const FenerfCompositeOpts* opts,
                                          const float* g_rgb, float* d_rows_a, float* d_rows_b, void* stream) {

@@ -118,5 +118,6 @@ int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ra
                      void* stream);
 int launch_repack(FenerfModel* m, const float* flat, const FenerfRepackMaps* r, float* scale_fwd, float* scale_bwd, void* stream);
 int launch_grid_relayout(const float* src_ncdhw, float* dst_cl, int C, int D, int Hh, int W, void* stream);
+int launch_grid_unlayout(const float* src_cl, float* dst_ncdhw, int D, int Hh, int W, void* stream);
 
 }  // namespace fenerf

@@ -175,11 +175,13 @@ class NativeModel:
         dev = self.device
         p = {k: v.detach().to(dev, torch.float32) for k, v in params.items()}
         if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
-            A, c = p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"]
-            for i in range(1, sp["n_label_layers"]):
-                W, b = p[f"label_layer_linear.{i}.weight"], p[f"label_layer_linear.{i}.bias"]
-                c = W @ c + b
-                A = W @ A
+            nl = sp["n_label_layers"]
+            c = p["label_layer_linear.0.bias"]
+            for i in range(1, nl):
+                c = p[f"label_layer_linear.{i}.weight"] @ c + p[f"label_layer_linear.{i}.bias"]
+            A = p[f"label_layer_linear.{nl - 1}.weight"]          # from the output side: n_lab-row products, not H x H x H
+            for i in range(nl - 2, -1, -1):
+                A = A @ p[f"label_layer_linear.{i}.weight"]
             p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
         flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
         return p, flat
@@ -368,7 +370,9 @@ class NativeModel:
         g = torch.zeros((D, Hh, W, 32), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().fenerf_grid_backward(self._h, points.shape[0], _ptr(points), _ptr(d_e), _ptr(g), _stream()))
-        return g.permute(3, 0, 1, 2).unsqueeze(0)
+            out = torch.empty((1, 32, D, Hh, W), dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().fenerf_grid_gradient_ncdhw(self._h, _ptr(g), _ptr(out), _stream()))
+        return out
 
     def siren_forward_rays(self, origins, dirs, z, fg, pg, fa, pa, lock_view=False):
         """origins/dirs [B,R,3], z [B,R,N] -> [B,R,N,C]"""

@@ -3,12 +3,12 @@ over <siren>.forward_with_frequencies_phase_shifts (siren.py:1509-1530) in the g
 (train_double_latent_semantic.py: g_loss.backward()) and in inversion (inverse_render_double_semantic.py).
 
 Data path on the GPU, all native (include/fenerf.h):
-    forward   fenerf_siren_forward_save   the fused fp32-MFMA kernel; keeps the pre-FiLM accumulators ("tape")
-    backward  fenerf_siren_backward       one fused chain kernel: d_out -> dL/dtheta of every FiLM layer, d(grid features)
+    forward   fenerf_siren_forward_save   the fused MFMA kernel; keeps the pre-FiLM accumulators ("tape")
+    backward  fenerf_siren_backward       one fused chain kernel: d_out -> dL/dtheta of every FiLM layer, the per-tile FiLM
+                                          sums, d(grid features)
+              fenerf_siren_param_grads    weight / bias / FiLM gradients (contractions over the point axis)
               fenerf_grid_backward        trilinear scatter into the feature-grid gradient
-What remains are contractions over the point axis -- weight / bias / FiLM gradients -- which are plain library GEMMs and
-reductions on (d_t, tape); they are issued here through torch (rocBLAS), layer by layer so the transient memory is two
-[H, points] matrices.
+What is left to torch is the fold of the activation-free label head (tiny products) and handing the buffers to autograd.
 """
 import torch
 
@@ -16,10 +16,14 @@ import torch
 def _fold_label_head(label_params):
     """The label head is 2-3 Linear layers with no activation between them (siren.py:1490-1494) = one affine map.
     label_params = [(W1,b1), (W2,b2), ...] in application order -> (A [n_lab,H], c [n_lab])."""
-    A, c = label_params[0]
+    c = label_params[0][1]
     for W, b in label_params[1:]:
         c = W @ c + b
-        A = W @ A
+    # the matrix product from the OUTPUT side: every product (and every product of its backward) then has the n_lab = 18 rows
+    # of the last layer as one dimension instead of being H x H x H -- rocBLAS spends 70 us on each of those
+    A = label_params[-1][0]
+    for W, _ in reversed(label_params[:-1]):
+        A = A @ W
     return A, c
 
 

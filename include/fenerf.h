@@ -265,6 +265,8 @@ int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, const float
                              const FenerfSirenGrads* grads, void* workspace, void* film_ws, void* stream);
 int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e, float* d_grid_cl,
                          void* stream);
+/* channels-last gradient grid [D][H][W][32] -> the parameter's layout [1,32,D,H,W] (spatial_embeddings.grad) */
+int fenerf_grid_gradient_ncdhw(const FenerfModel* m, const float* d_grid_cl, float* d_grid_ncdhw, void* stream);
 
 /* replaces: what torch autograd derives for the final fancy_integration of a differentiable render
  * (generators.py:519 / :790; G-step and inversion): gradient wrt rgb_final g_rgb [BR, C-1] -> gradients wrt the SIREN
