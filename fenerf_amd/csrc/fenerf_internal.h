@@ -60,8 +60,8 @@ struct SirenParams {
   long long pts_per_image;
   float* out;              // [P][C]
   long long ring_offset_floats;  // offset of the ring stream inside `stream`
-  // differentiable evaluation (fenerf_siren_forward_save): pre-FiLM accumulators W x (no bias) of every FiLM layer,
-  // feature-major [L][H][P], and the sampled grid features [P][32]
+  // differentiable evaluation (fenerf_siren_forward_save): pre-FiLM accumulators W x (no bias) of every FiLM layer as
+  // register dumps of the 32-point tiles (fenerf_layout.h "Tape"), and the sampled grid features [P][32]
   float* tape;
   float* tape_e;
 };
@@ -74,8 +74,8 @@ struct SirenBwdParams {
   long long P, pts_per_image;
   const float* out;        // [P][C] forward outputs (sigmoid' of the rgb head)
   const float* d_out;      // [P][C] gradient wrt the outputs
-  const float* tape;       // [L][H][P] from the forward
-  float* d_t;              // [L][H][P] out: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
+  const float* tape;       // from the forward (tape layout)
+  float* d_t;              // out, tape layout: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
   float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
   float* film_tiles;       // [tiles][L][2][H] out: per-tile FiLM sums (fenerf_layout.h "FiLM sums")
 };

@@ -3,13 +3,14 @@
 // in the generator step and in inversion (train_double_latent_semantic.py: g_loss.backward(); inverse_render_double_semantic.py).
 //
 // Per layer l (x_l = sin(theta_l), theta_l = f_l (W_l x_{l-1} + b_l) + p_l):
-//     dL/dtheta_l = dL/dx_l * cos(theta_l)          -> written to d_t[l]   (feature-major [H][P])
+//     dL/dtheta_l = dL/dx_l * cos(theta_l)          -> written to d_t[l]   (the tape's register-dump layout)
 //     dL/dz_l     = dL/dtheta_l * f_l               -> the B operand of the next GEMM
 //     dL/dx_{l-1} = W_l^T dL/dz_l                   -> transposed fp32 MFMA, same register identity as the forward
 // One wave carries 32 points through the whole chain; activations are not recomputed: theta_l comes from the forward's
-// saved pre-FiLM accumulators (tape), one coalesced 128-B read per feature row and lane-half.  What is left for the
-// caller are reductions over points with plain library GEMMs on d_t and the tape (weight / bias / FiLM gradients,
-// fenerf_amd/siren/autograd.py) -- they contract over the point axis and do not belong in a per-tile kernel.
+// saved pre-FiLM accumulators (tape, register dumps of the 32-point tiles).  The kernel also leaves the per-tile FiLM sums
+// (sum_p dtheta, sum_p dtheta * tape: fenerf_mfma32.h "FiLM-gradient sums").  The contractions over the point axis that remain
+// (weight gradients) are fenerf_siren_wgrad.hip.  FENERF_PREC_F32 models run this kernel; FENERF_PREC_F16X3 models the
+// bf16x3 variant in fenerf_siren_bwd16.hip.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

@@ -871,7 +871,7 @@ def test_native_repack_is_the_torch_repack_bit_for_bit(kind, H, grid, precision)
 
 def test_inversion_film_only_gradients_and_loop():
     """Inversion (inverse_render_double_semantic.py:306-410): with the generator's weights frozen only the FiLM gradients are
-    computed (film_sums_kernel); they must equal the FiLM gradients of the full backward, and the optimisation loop must
+    computed (the chain kernel's per-tile FiLM sums, gathered and reduced); they must equal the FiLM gradients of the full backward, and the optimisation loop must
     reduce its loss when the target is a render of the same generator at shifted FiLM parameters."""
     from fenerf_amd import callers
     torch.manual_seed(7)          # the module's mapping networks are randomly initialised
