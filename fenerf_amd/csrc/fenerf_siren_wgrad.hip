@@ -367,26 +367,50 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       const int i = lane & 31, kh = lane >> 5;
       auto a_tile = [&](int mt) { return (wm0 + mt < NB) ? wm0 + mt : NB - 1; };   // waves beyond the tile grid recompute the
       auto b_tile = [&](int kt) { return (wk0 + kt < NB) ? wk0 + kt : NB - 1; };   // last tile (not stored)
-      // Fragments are re-read from LDS per tile pair rather than cached (256 accumulators + the 96-register prefetch leave no
-      // room): the LDS has the bandwidth, and the kernel is bound by the tape reads, not by this loop.
+      // Fragments are re-read from LDS per tile pair rather than cached (no room beside 256 accumulators), software-pipelined:
+      // the raw rows of group (mt, kt + 1) are fetched behind the first MFMA of group (mt, kt) and unpacked (v_perm) between
+      // its later MFMAs -- the six MFMAs of a group are dependent (same accumulator), so whatever sits between them is free,
+      // whereas fetched at the top of its own group every fragment exposed the LDS latency (16 x ~120 cycles per tile).
+      struct Raw { uint4 a[2], b[2]; };                           // two k-steps x (8 points = 2 x 128 bit) of split-packed dwords
+      auto raw_load = [&](const unsigned* base, int tile_idx) {
+        Raw r;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint4* p = reinterpret_cast<const uint4*>(base + (tile_idx * 32 + i) * WG_LD + 16 * ks + 8 * kh);
+          r.a[ks] = p[0]; r.b[ks] = p[1];
+        }
+        return r;
+      };
+      auto unpack = [&](const Raw& r, int ks) {
+        const unsigned row8[8] = {r.a[ks].x, r.a[ks].y, r.a[ks].z, r.a[ks].w, r.b[ks].x, r.b[ks].y, r.b[ks].z, r.b[ks].w};
+        return unpack_frag(row8);
+      };
+      Raw rb = raw_load(B_p, b_tile(0));
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) {
-        Frag16 af[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[ks] = unpack_frag(A_p + (a_tile(mt) * 32 + i) * WG_LD + 16 * ks + 8 * kh);
+        const Raw ra = raw_load(A_p, a_tile(mt));
+        Frag16 af[2] = {unpack(ra, 0), unpack(ra, 1)};
+        Frag16 bf[2] = {unpack(rb, 0), unpack(rb, 1)};
 #pragma unroll
         for (int kt = 0; kt < WK; ++kt) {
-          Frag16 bf[2];
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) bf[ks] = unpack_frag(B_p + (b_tile(kt) * 32 + i) * WG_LD + 16 * ks + 8 * kh);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            acc[mt][kt] = MFMA_BF16(af[ks].lo, bf[ks].hi, acc[mt][kt]);
-            acc[mt][kt] = MFMA_BF16(af[ks].hi, bf[ks].lo, acc[mt][kt]);
-            acc[mt][kt] = MFMA_BF16(af[ks].hi, bf[ks].hi, acc[mt][kt]);
-          }
+          const bool last = mt == WM - 1 && kt == WK - 1;
+          Frag16 bn[2];
+          // sched_barriers pin this order: left alone the scheduler hoists the unpack right behind the loads
+          acc[mt][kt] = MFMA_BF16(af[0].lo, bf[0].hi, acc[mt][kt]);
+          if (!last) rb = raw_load(B_p, b_tile(kt + 1 < WK ? kt + 1 : 0));
+          __builtin_amdgcn_sched_barrier(0);
+          acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].lo, acc[mt][kt]);
+          acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].hi, acc[mt][kt]);
+          acc[mt][kt] = MFMA_BF16(af[1].lo, bf[1].hi, acc[mt][kt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!last && kt + 1 < WK) bn[0] = unpack(rb, 0);
+          acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].lo, acc[mt][kt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!last && kt + 1 < WK) bn[1] = unpack(rb, 1);
+          acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].hi, acc[mt][kt]);
+          if (kt + 1 < WK) { bf[0] = bn[0]; bf[1] = bn[1]; }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
