@@ -281,15 +281,22 @@ __device__ __forceinline__ Frag16 unpack_frag(const unsigned* row8) {
 }
 
 // 4 waves (2 x 2 over the 8 x 8 output tiles; 4 x 4 tiles = 256 accumulator AGPRs each, one wave per SIMD).
+// The LDS image is double-buffered: while the MFMAs of tile t read buffer t & 1, tile t + 1 (already in registers) is staged
+// -- sin, split, LDS writes -- into the other buffer, half a dump group at a time BETWEEN the dependent MFMAs of each
+// accumulator group, and every dump group's registers are refilled with tile t + 2 as soon as they have been staged: one
+// barrier per tile, loads in flight for a whole tile period.  (Staged in a phase of its own, the kernel spent 30 % of a
+// tile in staging and another 30 % waiting for loads that had only the MFMA phase to arrive.)
 template <int H>
 __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams P) {
   constexpr int NB = H / 32, NG = H / 8;                  // output tiles per side; dump groups per tile
   constexpr int GPW = NG >= 4 ? NG / 4 : 1;               // dump groups staged per wave
   constexpr int WGK = 2, WM = (NB + 1) / 2, WK = (NB + 1) / 2;
+  constexpr int NGROUP = WM * WK;                         // accumulator groups (6 dependent MFMAs each) per wave and tile
+  constexpr int HPG = (2 * GPW + NGROUP - 1) / NGROUP;    // staging half-pieces (a dump group's dtheta or tape rows) per group
+  constexpr int IMG = 2 * H * WG_LD;                      // dwords per buffer: [A rows | B rows]
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  unsigned* A_p = reinterpret_cast<unsigned*>(lds);          // [H][WG_LD] split-packed dtheta_l
-  unsigned* B_p = A_p + H * WG_LD;                            // [H][WG_LD] split-packed x_{l-1}
-  float* f_s = reinterpret_cast<float*>(B_p + H * WG_LD);
+  unsigned* img0 = reinterpret_cast<unsigned*>(lds);         // 2 x { A_p [H][WG_LD] split-packed dtheta_l, B_p [H][WG_LD] split-packed x_{l-1} }
+  float* f_s = reinterpret_cast<float*>(img0 + 2 * IMG);
   float* p_s = f_s + H;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -316,52 +323,58 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
   const int m = lane & 31, half = lane >> 5;
-  const bool stager = wave * GPW < NG;                      // small H: fewer dump groups than waves
+  static_assert(4 * GPW == NG, "every wave stages GPW dump groups");
 
-  float4 va[GPW], vb[GPW];
-  auto fetch = [&](int t) {
-    if (!stager) return;
-    const long long tile = tile_base + t;
+  float4 va[GPW], vb[GPW];                                  // dump group q of the tile being staged next: dtheta_l, tape_{l-1}
+  // No branches from here on: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative (it
+  // then waits for the refill loads it has just issued); past the chunk's end the last tile is re-read and never staged.
+  auto fetch_q = [&](int t, int q) {
+    const long long tile = tile_base + (t < t1 ? t : t1 - 1);
+    const int g = wave * GPW + q;
+    va[q] = dt4[(tile * L + l) * tl + g * 64 + lane];
+    vb[q] = tape4[(tile * L + lb) * tl + g * 64 + lane];
+  };
+  // half-piece hp = 2 q + part of the tile in (va, vb) -> buffer dst: part 0 = dtheta rows, part 1 = x = sin(2 pi (f' tape + p')) rows.
+  // f4 / p4 = the FiLM rows of the group, fetched from LDS ahead of time (LDS reads do not move across LDS writes).
+  auto film_rows = [&](int hp, float4& f4, float4& p4) {
+    const int row = tape_feature(wave * GPW + (hp >> 1), half, 0);
+    f4 = *reinterpret_cast<const float4*>(f_s + row);
+    p4 = *reinterpret_cast<const float4*>(p_s + row);
+  };
+  auto stage_half = [&](int hp, unsigned* dst, const float4& f4, const float4& p4) {
+    const int q = hp >> 1;
+    const int row = tape_feature(wave * GPW + q, half, 0);
+    if ((hp & 1) == 0) {
+      const float4 a = va[q];
+      const float d[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-    for (int q = 0; q < GPW; ++q) {
-      const int g = wave * GPW + q;
-      va[q] = dt4[(tile * L + l) * tl + g * 64 + lane];
-      vb[q] = tape4[(tile * L + lb) * tl + g * 64 + lane];
+      for (int i = 0; i < 4; ++i) dst[(row + i) * WG_LD + m] = split_pack_bf16(d[i]);
+    } else {
+      const float4 b = vb[q];
+      const float x[4] = {sin2pi(__builtin_fmaf(f4.x, b.x, p4.x)), sin2pi(__builtin_fmaf(f4.y, b.y, p4.y)),
+                          sin2pi(__builtin_fmaf(f4.z, b.z, p4.z)), sin2pi(__builtin_fmaf(f4.w, b.w, p4.w))};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[H * WG_LD + (row + i) * WG_LD + m] = split_pack_bf16(x[i]);
     }
   };
-  if (t0 < t1) fetch(t0);
-  for (int t = t0; t < t1; ++t) {
-    // ---- stage: FiLM rows first (LDS reads cannot be moved across LDS writes by the compiler), then the writes
-    if (stager) {
-      constexpr int NH = GPW > 4 ? 4 : GPW;               // groups per staging pass (bounds the f' / p' temporaries)
-#pragma unroll
-      for (int hq = 0; hq < GPW; hq += NH) {
-        float4 f4[NH], p4[NH];
-#pragma unroll
-        for (int q = 0; q < NH; ++q) {
-          const int row = tape_feature(wave * GPW + hq + q, half, 0);
-          f4[q] = *reinterpret_cast<const float4*>(f_s + row);
-          p4[q] = *reinterpret_cast<const float4*>(p_s + row);
-        }
-#pragma unroll
-        for (int q = 0; q < NH; ++q) {
-          const int row = tape_feature(wave * GPW + hq + q, half, 0);
-          const float4 a = va[hq + q], b = vb[hq + q];
-          const float d[4] = {a.x, a.y, a.z, a.w};
-          const float x[4] = {sin2pi(__builtin_fmaf(f4[q].x, b.x, p4[q].x)), sin2pi(__builtin_fmaf(f4[q].y, b.y, p4[q].y)),
-                              sin2pi(__builtin_fmaf(f4[q].z, b.z, p4[q].z)), sin2pi(__builtin_fmaf(f4[q].w, b.w, p4[q].w))};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int o = (row + i) * WG_LD + m;
-            A_p[o] = split_pack_bf16(d[i]);
-            B_p[o] = split_pack_bf16(x[i]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (t + 1 < t1) fetch(t + 1);
 
+  // ---- prologue: tile t0 staged into buffer 0, tile t0 + 1 on its way
+#pragma unroll
+  for (int q = 0; q < GPW; ++q) fetch_q(t0, q);
+#pragma unroll
+  for (int hp = 0; hp < 2 * GPW; ++hp) {
+    float4 f4, p4;
+    film_rows(hp, f4, p4);
+    stage_half(hp, img0, f4, p4);
+  }
+#pragma unroll
+  for (int q = 0; q < GPW; ++q) fetch_q(t0 + 1, q);
+  __syncthreads();
+
+  for (int t = t0; t < t1; ++t) {
+    const unsigned* A_p = img0 + ((t - t0) & 1) * IMG;
+    const unsigned* B_p = A_p + H * WG_LD;
+    unsigned* nxt = img0 + (((t - t0) & 1) ^ 1) * IMG;   // after the last tile this stages a re-read tile nobody consumes
     // ---- MFMA: lane (i, kh) contracts points 16 ks + 8 kh + {0..7} in k-step ks (same order on both operands)
     {
       const int i = lane & 31, kh = lane >> 5;
@@ -369,8 +382,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       auto b_tile = [&](int kt) { return (wk0 + kt < NB) ? wk0 + kt : NB - 1; };   // last tile (not stored)
       // Fragments are re-read from LDS per tile pair rather than cached (no room beside 256 accumulators), software-pipelined:
       // the raw rows of group (mt, kt + 1) are fetched behind the first MFMA of group (mt, kt) and unpacked (v_perm) between
-      // its later MFMAs -- the six MFMAs of a group are dependent (same accumulator), so whatever sits between them is free,
-      // whereas fetched at the top of its own group every fragment exposed the LDS latency (16 x ~120 cycles per tile).
+      // its later MFMAs -- the six MFMAs of a group are dependent (same accumulator), so whatever sits between them is free.
       struct Raw { uint4 a[2], b[2]; };                           // two k-steps x (8 points = 2 x 128 bit) of split-packed dwords
       auto raw_load = [&](const unsigned* base, int tile_idx) {
         Raw r;
@@ -394,12 +406,26 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
 #pragma unroll
         for (int kt = 0; kt < WK; ++kt) {
           const bool last = mt == WM - 1 && kt == WK - 1;
+          const int g = mt * WK + kt;
           Frag16 bn[2];
+          float4 f4[HPG], p4[HPG];
           // sched_barriers pin this order: left alone the scheduler hoists the unpack right behind the loads
           acc[mt][kt] = MFMA_BF16(af[0].lo, bf[0].hi, acc[mt][kt]);
           if (!last) rb = raw_load(B_p, b_tile(kt + 1 < WK ? kt + 1 : 0));
+#pragma unroll
+          for (int j = 0; j < HPG; ++j)
+            if (g * HPG + j < 2 * GPW) film_rows(g * HPG + j, f4[j], p4[j]);
           __builtin_amdgcn_sched_barrier(0);
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].lo, acc[mt][kt]);
+#pragma unroll
+          for (int j = 0; j < HPG; ++j) {
+            const int hp = g * HPG + j;
+            if (hp < 2 * GPW) {
+              stage_half(hp, nxt, f4[j], p4[j]);
+              if (hp & 1) fetch_q(t + 2, hp >> 1);          // both halves of dump group hp >> 1 are staged: refill its registers
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].hi, acc[mt][kt]);
           acc[mt][kt] = MFMA_BF16(af[1].lo, bf[1].hi, acc[mt][kt]);
           __builtin_amdgcn_sched_barrier(0);
@@ -572,7 +598,7 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
 template <int H>
 int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   auto kfn = siren_wgrad_sq_bf16_kernel<H>;
-  const size_t lds = (size_t)(2 * H * WG_LD + 2 * H) * sizeof(float);
+  const size_t lds = (size_t)(4 * H * WG_LD + 2 * H) * sizeof(float);     // two [A | B] images + FiLM rows
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
