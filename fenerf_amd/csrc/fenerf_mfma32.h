@@ -107,8 +107,8 @@ __device__ __forceinline__ void film_store(const f32x16& acc, const FilmNB& fm, 
 // after four steps lane i holds the 16-lane sum of register (i & 15); one cross-row exchange finishes it.  ~70 VALU ops
 // per 16 registers (a plain 5-step DPP reduction of every register: 160), results spread over 16 lanes = one small store.
 // The weight-gradient kernels then need neither the layer's own tape nor a FiLM pass (a third of their HBM traffic).
-struct LaneBits { bool b0, b1, b2, b3, store; };   // lane & 1, 2, 4, 8 ; !(lane & 16)
-__device__ __forceinline__ LaneBits lane_bits(int lane) { return LaneBits{(lane & 1) != 0, (lane & 2) != 0, (lane & 4) != 0, (lane & 8) != 0, (lane & 16) == 0}; }
+struct LaneBits { bool b0, b1, b2, b3; };   // lane & 1, 2, 4, 8
+__device__ __forceinline__ LaneBits lane_bits(int lane) { return LaneBits{(lane & 1) != 0, (lane & 2) != 0, (lane & 4) != 0, (lane & 8) != 0}; }
 
 __device__ __forceinline__ float lane_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
 __device__ __forceinline__ float lane_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); }   // quad_perm:[2,3,0,1]
@@ -159,7 +159,7 @@ __device__ __forceinline__ void film_red_chunk(int c, FilmRed& R, const LaneBits
       z[s] = fold(lb.b3, R.y[s][0], R.y[s][1], lane_xor8);   // lane i: 16-lane sum of register (i & 15)
       z[s] += lane_xor16(z[s]);
     }
-    if (lb.store) { ftp[0] = z[0]; ftp[H] = z[1]; }
+    ftp[0] = z[0]; ftp[H] = z[1];     // lanes i and i ^ 16 hold the same sum and write it to the same address: no exec mask, no branch
   }
 }
 // feature offset inside an n-block of accumulator register (lane & 15) for the lane's half
