@@ -369,7 +369,10 @@ extern "C" int fenerf_merge_composite(int64_t BR, int N, int C, const float* fin
 
 extern "C" size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points) {
   if (!m || total_points <= 0) return 0;
-  return (size_t)m->L * m->H * (size_t)total_points;
+  // whole 32-point tiles, rounded up to the 4 tiles a workgroup of the shared-stream kernel walks together: the phantom
+  // tiles that pad its last quad dump their registers too (a guard would put a branch into the MFMA stream)
+  const size_t tiles = ((size_t)total_points + 31) / 32, quads = (tiles + 3) / 4;
+  return (size_t)m->L * m->H * 32 * quads * 4;
 }
 
 extern "C" size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points) {

@@ -177,8 +177,12 @@ struct EpiQ {
 // units of the f16x3 GEMM, which the FiLM frequencies f'' already absorb).  tp = tape4 + (tile*L + layer)*(H/8)*64 + lane,
 // or nullptr.  One fire-and-forget 1-KiB wave store; stores only make the counted vmcnt waits stricter, never wrong
 // (loads retire in order among themselves).
-__device__ __forceinline__ void tape_q(const f32x16& acc, int nbp, int q, float4* tp) {
-  if (tp) tp[(nbp * 4 + q) * 64] = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+// No guard: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative.  The phantom tiles that pad a
+// workgroup's quad write into the (up to 3 tiles of) slack fenerf_siren_tape_floats includes.
+template <bool ON> struct TapeDst { float4* p; };
+template <bool ON>
+__device__ __forceinline__ void tape_q(const f32x16& acc, int nbp, int q, TapeDst<ON> tp) {
+  if (ON) tp.p[(nbp * 4 + q) * 64] = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
 }
 __device__ __forceinline__ void epi_load(EpiQ& e, int nbp, int q, const float* film_f, const float* film_p) {
   e.f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);   // + 4*h folded into the pointer
@@ -211,9 +215,9 @@ __device__ __forceinline__ void epi_p3(EpiQ& e, int nbp, int q, half8 (&yh)[KS],
   }
 }
 // whole quarter at once (layer tails, layer 0, small-H bodies)
-template <int KS, int NBL>
+template <int KS, int NBL, bool ON = false>
 __device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab, float4* tp = nullptr) {
+                                          half8 (&yh)[KS], half8 (&yl)[KS], char* slab, TapeDst<ON> tp = TapeDst<ON>{nullptr}) {
   tape_q(acc, nbp, q, tp);
   EpiQ e;
   epi_load(e, nbp, q, film_f, film_p);
@@ -223,9 +227,9 @@ __device__ __forceinline__ void epi_route(const f32x16& acc, int nbp, int q, con
   epi_p3<KS, NBL>(e, nbp, q, yh, yl, slab);
 }
 // layer 0 writes straight into x (nothing is reading it yet)
-template <int KS>
+template <int KS, bool ON>
 __device__ __forceinline__ void epi_quarter(const f32x16& acc, int nbp, int q, const float* film_f, const float* film_p,
-                                            half8 (&yh)[KS], half8 (&yl)[KS], float4* tp) {
+                                            half8 (&yh)[KS], half8 (&yl)[KS], TapeDst<ON> tp) {
   epi_route<KS, 0>(acc, nbp, q, film_f, film_p, yh, yl, nullptr, tp);
 }
 
@@ -288,9 +292,9 @@ __device__ __forceinline__ void collect_act(half8 (&xh)[KS], half8 (&xl)[KS], co
 }
 
 // A square FiLM layer H -> H.  x: input activations (B operands); outputs replace x at the end.
-template <int H>
+template <int H, bool ON>
 __device__ __forceinline__ void square_layer_s(half8 (&xh)[H / 16], half8 (&xl)[H / 16], WStream& ws, AK2& a_cur,
-                                               const float* film_f, const float* film_p, char* slab, float4* tp) {
+                                               const float* film_f, const float* film_p, char* slab, TapeDst<ON> tp) {
   constexpr int NB = H / 32, KS = H / 16, NBL = NB / 2;
   constexpr int QB = (2 * KS + CH - 1) / CH;          // chunks per n-block body (4 at H=256)
   constexpr int STAGE_CHUNKS = pad_stage(NB * QB * CH) / CH;
@@ -468,9 +472,9 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
         }
       }
     }
-    const bool real_tile = tile * 32 < P.P;      // quads are padded with phantom tiles (clamped points)
-    float4* tp0 = (SAVE && real_tile) ? reinterpret_cast<float4*>(P.tape) + tile * L * (long long)((H / 8) * 64) + lane : nullptr;
-    if (SAVE && GRID && real_tile && tile * 32 + m < P.P) {
+    // quads are padded with phantom tiles (clamped points): their tape goes to the slack behind the last tile
+    const TapeDst<SAVE> tp0{SAVE ? reinterpret_cast<float4*>(P.tape) + tile * L * (long long)((H / 8) * 64) + lane : nullptr};
+    if (SAVE && GRID && tile * 32 + m < P.P) {
       float4* ep = reinterpret_cast<float4*>(P.tape_e + (tile * 32 + m) * 32 + 16 * h);
 #pragma unroll
       for (int q = 0; q < 4; ++q) ep[q] = make_float4(e[4 * q + 0], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void siren16s_kernel(SirenParams P, int n_g
     for (int l = 1; l < n_geo + n_color; ++l) {
       const float* ff = (l & 1) ? film_f1 : film_f0;
       const float* fq = (l & 1) ? film_p1 : film_p0;
-      float4* tpl = (SAVE && tp0) ? tp0 + (long long)l * ((H / 8) * 64) : nullptr;
+      const TapeDst<SAVE> tpl{SAVE ? tp0.p + (long long)l * ((H / 8) * 64) : nullptr};
       if (l == n_geo) {
         // ---------------- colour layer 0: [x | grid feats | dir] -> H, then the label/sigma head on the same x -------
         half8 eh[2], el[2], dh, dl;

@@ -82,7 +82,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
             rd = (torch.cat([rd, rd[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else rd).contiguous()
         pts2 = torch.empty((2 * B, Pp, 3), dtype=torch.float32, device=dev)
         out2 = torch.empty((2 * B, Pp, C), dtype=torch.float32, device=dev)
-        tape2 = torch.empty(2 * L * H * B * Pp, dtype=torch.float32, device=dev)
+        tape2 = torch.empty(L * H * B * Pp + nat.tape_floats(B * Pp), dtype=torch.float32, device=dev)   # pass 1 | pass 2 + slack
         tape_e2 = torch.empty((2 * B * Pp, 32), dtype=torch.float32, device=dev) if G else None
         half = L * H * B * Pp
         pts2[:B] = samples(z_c)

@@ -295,9 +295,13 @@ class NativeModel:
                                                        _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
+    def tape_floats(self, total_points):
+        """floats of a tape for total_points points (L*H per point + the slack the kernel's last workgroup may write)"""
+        return int(_lib.lib().fenerf_siren_tape_floats(self._h, total_points))
+
     def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa, out=None, tape=None, tape_e=None):
-        """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators, L*H*B*P floats of
-        32-point register dumps) and the sampled grid features [B*P,32] (None without a grid) that siren_backward consumes.
+        """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators, tape_floats(B*P) floats
+        of 32-point register dumps) and the sampled grid features [B*P,32] (None without a grid) that siren_backward consumes.
         out / tape / tape_e may be preallocated (contiguous views into larger buffers: several passes, one backward)."""
         B, P = points.shape[0], points.shape[1]
         H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
@@ -307,10 +311,10 @@ class NativeModel:
         if out is None:
             out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
         if tape is None:
-            tape = torch.empty((L, H, B * P), dtype=torch.float32, device=self.device)
+            tape = torch.empty((self.tape_floats(B * P),), dtype=torch.float32, device=self.device)
         if tape_e is None and self.spec["grid_ch"]:
             tape_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device)
-        assert out.numel() == B * P * self.C and tape.numel() == L * H * B * P
+        assert out.numel() == B * P * self.C and tape.numel() >= L * H * B * P    # + tape_floats' slack behind the last pass
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
             _lib.check(_lib.lib().fenerf_siren_forward_save(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa),

@@ -226,7 +226,8 @@ int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const fl
  * be a multiple of 32 (pad with any valid point and give the pads a zero gradient).
  *
  * fenerf_siren_forward_save = fenerf_siren_forward that also keeps the pre-FiLM accumulators (W_l x_{l-1}, no bias) of
- *   every FiLM layer as a tape of fenerf_siren_tape_floats(m, B*P) floats (opaque: 32-point register dumps,
+ *   every FiLM layer as a tape of fenerf_siren_tape_floats(m, B*P) floats (opaque: 32-point register dumps, L*H*B*P floats
+ *   plus up to three tiles of slack the kernel may scribble on,
  *   fenerf_amd/csrc/fenerf_layout.h "Tape"; for FENERF_PREC_F16X3 models in the row-scaled units of that GEMM) and the
  *   sampled grid features tape_e [B*P][32] (NULL without a grid).
  * fenerf_siren_backward: d_out [B,P,output_dim] -> d_t = dL/dtheta per FiLM layer in the tape's layout, theta = f (W x + b) + p,
