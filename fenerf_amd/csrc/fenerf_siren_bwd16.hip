@@ -160,11 +160,13 @@ __device__ __forceinline__ void mfma16_x(f32x16& acc, const Act16<KS>& x, Ring16
 // finished with -- the operand loads of body nb's own epilogue (12 pieces), 28 pieces spread over the body's 3 KS MFMAs.
 // (The vmcnt queue is in order: a tape load must land before the ring entries issued behind it are consumed, 8 k-steps
 // later, whichever registers it targets -- a third operand set would buy no extra latency tolerance.)
-template <int H>
-__device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, const float* fpl, const float* ppl, const float4* tp,
-                                             const Sink16& k) {
+// EP = entries per body (a square body, or the colour-layer-0 body with its two head k-steps, which extra(acc, s, wh, wl)
+// multiplies); RELOAD: fetch the stage's output from the slab as the next stage's input.
+template <int H, int EP, bool RELOAD, class EXTRA>
+__device__ __forceinline__ void bwd_stage16(Act16<H / 16>& in, Ring16& ring, const float* fpl, const float* ppl, const float4* tp,
+                                            const Sink16& k, EXTRA extra) {
   float4* const slab = k.slab;
-  constexpr int NB = H / 32, KS = H / 16, EP = pad_pf16(2 * KS);
+  constexpr int NB = H / 32, KS = H / 16;
   constexpr int NPIECE = 28 + FILM_RED_CHUNKS;           // 16 epilogue + 12 operand loads + the FiLM-sum butterfly
   constexpr int PP = (NPIECE + 3 * KS - 1) / (3 * KS);   // pieces per MFMA slot
   FilmNB fm = film_load(fpl, ppl, 0);
@@ -174,7 +176,7 @@ __device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, co
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BwdOct q;
     FilmRed R;
-    mfma16_x<KS, EP>(acc, in, ring, [](int, float4, float4) {}, [&](int slot) {
+    mfma16_x<KS, EP>(acc, in, ring, [&](int s_, float4 wh, float4 wl) { extra(acc, s_, wh, wl); }, [&](int slot) {
 #ifdef EXP_B16_NOPIECE
       if (false) {
 #else
@@ -194,7 +196,13 @@ __device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, co
 #pragma unroll 1
   for (int nb = 1; nb < NB; ++nb) body(nb, std::true_type{});
   bwd_store16(acc_p, fm, tn, NB - 1, k);
-  load_act16<H / 16>(in, slab);
+  if (RELOAD) load_act16<H / 16>(in, slab);
+}
+
+template <int H>
+__device__ __forceinline__ void bwd_square16(Act16<H / 16>& in, Ring16& ring, const float* fpl, const float* ppl, const float4* tp,
+                                             const Sink16& k) {
+  bwd_stage16<H, pad_pf16(2 * (H / 16)), true>(in, ring, fpl, ppl, tp, k, [](f32x16&, int, float4, float4) {});
 }
 
 template <int H, bool GRID>
@@ -300,23 +308,17 @@ __global__ __launch_bounds__(256, 1) void siren_bwd16_kernel(SirenBwdParams P, i
     // ---------------- colour layer 0 + heads: dx_{n_geo-1} = W_c0[:, x]^T dz_{n_geo} + head^T d_head; d(grid feats) ----
     {
       const int l = n_geo - 1;
-#pragma unroll 1
-      for (int nb = 0; nb < NB; ++nb) {
-        const FilmNB fm = film_load(fpl + (size_t)l * H, ppl + (size_t)l * H, nb);
-        const Tape16 tn = tape_load16(tp + l * tl_t, nb);
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        mfma16_x<KS, C0_EP>(acc, in, ring, [&](int s, float4 wh, float4 wl) {
-          if (s < 2) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), al = __builtin_bit_cast(bf16x8, wl);
-            acc = MFMA_BF16(al, dh_hi[s], acc);
-            acc = MFMA_BF16(ah, dh_lo[s], acc);
-            acc = MFMA_BF16(ah, dh_hi[s], acc);
-          }
-        }, [](int) {});
-        // the slab is this stage's input until every n-block has been computed: park the outputs behind it? no -- the
-        // input lives in registers (in), so overwriting the slab n-block by n-block is safe.
-        bwd_store16(acc, fm, tn, nb, sink(l));
-      }
+      // the slab is overwritten n-block by n-block while this stage's input lives in registers (in); it is re-read only
+      // after the grid-feature body below, which still multiplies the old input
+      bwd_stage16<H, C0_EP, false>(in, ring, fpl + (size_t)l * H, ppl + (size_t)l * H, tp + l * tl_t, sink(l),
+                                   [&](f32x16& acc, int s_, float4 wh, float4 wl) {
+        if (s_ < 2) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), al = __builtin_bit_cast(bf16x8, wl);
+          acc = MFMA_BF16(al, dh_hi[s_], acc);
+          acc = MFMA_BF16(ah, dh_lo[s_], acc);
+          acc = MFMA_BF16(ah, dh_hi[s_], acc);
+        }
+      });
       if (GRID) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         mfma16_x<KS, EP>(acc, in, ring, [](int, float4, float4) {}, [](int) {});
