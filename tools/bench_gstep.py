@@ -85,6 +85,12 @@ def main():
     res["native_peak_GB"] = torch.cuda.max_memory_allocated() / 2**30
     res["native_fwd_bwd_with_repack_ms"] = timed(lambda: native_step(True), a.iters)
     res["native_nograd_render_ms"] = timed(native_fwd_only, a.iters)
+    # inversion step (inverse_render_double_semantic.py:324-410): weights frozen, only the FiLM offsets take gradients
+    for p in params:
+        p.requires_grad_(False)
+    res["native_inversion_fwd_bwd_ms"] = timed(lambda: native_step(False), a.iters)
+    for p in params:
+        p.requires_grad_(True)
 
     if not a.skip_eager:
         sdt = {k: torch.tensor(v, device=DEV).requires_grad_(True) for k, v in sd.items()}
@@ -114,6 +120,16 @@ def main():
             px = rgb.reshape(B, S_, S_, 21).permute(0, 3, 1, 2) * 2 - 1
             (px * w).sum().backward()
 
+        def eager_inversion():
+            for t in sdt.values():
+                t.requires_grad_(False)
+            try:
+                eager_step(True)
+            finally:
+                for t in sdt.values():
+                    t.requires_grad_(True)
+
+        res["eager_amp_inversion_fwd_bwd_ms"] = timed(eager_inversion, max(2, a.iters // 2), warm=1)
         for amp, key in ((False, "eager_fp32_fwd_bwd_ms"), (True, "eager_amp_fwd_bwd_ms")):
             torch.cuda.reset_peak_memory_stats()
             try:
