@@ -26,6 +26,7 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_mfma32.h"
+#include "fenerf_nt.h"
 
 namespace fenerf {
 
@@ -33,7 +34,7 @@ namespace fenerf {
 // tp = tape4 + ((tile*L + layer) * (H/8)) * 64 + lane; one contiguous 1-KiB wave store per 4 accumulator registers.
 __device__ __forceinline__ void tape_store(const f32x16& acc, int nb, float4* tp) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tp[(nb * 4 + j) * 64] = make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+  for (int j = 0; j < 4; ++j) nt_store(tp + (nb * 4 + j) * 64, acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
 }
 
 // A square FiLM layer H -> H.

@@ -18,6 +18,7 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_mfma32.h"
+#include "fenerf_nt.h"
 
 namespace fenerf {
 
@@ -30,7 +31,7 @@ __device__ __forceinline__ TapeNB tape_load(const float4* tp, int nb) {
   TapeNB t;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 v = tp[(nb * 4 + j) * 64];
+    const float4 v = nt_load(tp + (nb * 4 + j) * 64);
     t.a[4 * j + 0] = v.x; t.a[4 * j + 1] = v.y; t.a[4 * j + 2] = v.z; t.a[4 * j + 3] = v.w;
   }
   return t;
@@ -56,7 +57,7 @@ __device__ __forceinline__ void bwd_piece(int r, const f32x16& acc, const FilmNB
   R.v[0][r] = dt;
   R.v[1][r] = dt * tn.a[r];
   if (i == 3) {
-    k.dtp[(nb * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
+    nt_store(k.dtp + (nb * 4 + j) * 64, q.d[0], q.d[1], q.d[2], q.d[3]);
     k.slab[(nb * 4 + j) * 64] = make_float4(q.o[0], q.o[1], q.o[2], q.o[3]);
   }
 }
@@ -78,7 +79,7 @@ __device__ __forceinline__ void prefetch_piece(int i, FilmNB& fm, TapeNB& tn, co
   else if (i < 8) fm.p[i - 4] = *reinterpret_cast<const float4*>(ppl + 32 * nb + 8 * (i - 4));
   else if (i < 12) {
     const int j = i - 8;
-    const float4 v = tp[(nb * 4 + j) * 64];
+    const float4 v = nt_load(tp + (nb * 4 + j) * 64);
     tn.a[4 * j + 0] = v.x; tn.a[4 * j + 1] = v.y; tn.a[4 * j + 2] = v.z; tn.a[4 * j + 3] = v.w;
   }
 }

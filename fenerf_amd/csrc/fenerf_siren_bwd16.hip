@@ -14,6 +14,7 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_mfma32.h"
+#include "fenerf_nt.h"
 
 namespace fenerf {
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ Tape16 tape_load16(const float4* tp, int nb) {
   Tape16 t;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 v = tp[(nb * 4 + j) * 64];
+    const float4 v = nt_load(tp + (nb * 4 + j) * 64);
     t.a[4 * j + 0] = v.x; t.a[4 * j + 1] = v.y; t.a[4 * j + 2] = v.z; t.a[4 * j + 3] = v.w;
   }
   return t;
@@ -79,7 +80,7 @@ __device__ __forceinline__ void bwd_piece16(int r, const f32x16& acc, const Film
 #ifdef EXP_B16_STORE_L2
   if (i == 3) dtp[((nb & 1) * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
 #else
-  if (i == 3) dtp[(nb * 4 + j) * 64] = make_float4(q.d[0], q.d[1], q.d[2], q.d[3]);
+  if (i == 3) nt_store(dtp + (nb * 4 + j) * 64, q.d[0], q.d[1], q.d[2], q.d[3]);
 #endif
 #endif
   if ((r & 7) == 7) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void prefetch_piece16(int i, FilmNB& fm, Tape16& tn, 
 #elif defined(EXP_B16_TAPE_L2)
     const float4 v = tp[((nb & 1) * 4 + i) * 64];
 #else
-    const float4 v = tp[(nb * 4 + i) * 64];
+    const float4 v = nt_load(tp + (nb * 4 + i) * 64);
 #endif
     tn.a[4 * i + 0] = v.x; tn.a[4 * i + 1] = v.y; tn.a[4 * i + 2] = v.z; tn.a[4 * i + 3] = v.w;
   } else if (i < 8) fm.f[i - 4] = *reinterpret_cast<const float4*>(fpl + 32 * nb + 8 * (i - 4));

@@ -24,6 +24,7 @@
 
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_nt.h"
 
 namespace fenerf {
 
@@ -182,7 +183,7 @@ struct EpiQ {
 template <bool ON> struct TapeDst { float4* p; };
 template <bool ON>
 __device__ __forceinline__ void tape_q(const f32x16& acc, int nbp, int q, TapeDst<ON> tp) {
-  if (ON) tp.p[(nbp * 4 + q) * 64] = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  if (ON) nt_store(tp.p + (nbp * 4 + q) * 64, acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
 }
 __device__ __forceinline__ void epi_load(EpiQ& e, int nbp, int q, const float* film_f, const float* film_p) {
   e.f = *reinterpret_cast<const float4*>(film_f + 32 * nbp + 8 * q);   // + 4*h folded into the pointer

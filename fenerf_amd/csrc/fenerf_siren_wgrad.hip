@@ -22,6 +22,7 @@
 
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_nt.h"
 #include "fenerf_mfma32.h"
 
 namespace fenerf {
@@ -78,7 +79,7 @@ __device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst
 template <int H>
 __device__ __forceinline__ void load_dump(float4 (&v)[H / 32], const float4* src /* (tile, layer) base */, int wave, int lane) {
 #pragma unroll
-  for (int q = 0; q < H / 32; ++q) v[q] = src[(wave * (H / 32) + q) * 64 + lane];
+  for (int q = 0; q < H / 32; ++q) v[q] = nt_load(src + (wave * (H / 32) + q) * 64 + lane);
 }
 
 // JOB: which operands.  MT x KT = output tiles (32x32) of the workgroup; WM x WK = tiles per wave.
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
   auto fetch_q = [&](int t, int q) {
     const long long tile = tile_base + (t < t1 ? t : t1 - 1);
     const int g = wave * GPW + q;
-    va[q] = dt4[(tile * L + l) * tl + g * 64 + lane];
-    vb[q] = tape4[(tile * L + lb) * tl + g * 64 + lane];
+    va[q] = nt_load(dt4 + (tile * L + l) * tl + g * 64 + lane);
+    vb[q] = nt_load(tape4 + (tile * L + lb) * tl + g * 64 + lane);
   };
   // half-piece hp = 2 q + part of the tile in (va, vb) -> buffer dst: part 0 = dtheta rows, part 1 = x = sin(2 pi (f' tape + p')) rows.
   // f4 / p4 = the FiLM rows of the group, fetched from LDS ahead of time (LDS reads do not move across LDS writes).
