@@ -12,6 +12,8 @@ TextureEmbeddingPiGAN256SEMANTICDISENTANGLE_DIM_96 (H=256 FiLM-SIREN + 32x96^3 g
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (siren_kernel, MFMA-bound): algorithmic
 FLOPs per launch (1,603,584 FLOP/point x points) / its hipEvent-timed average duration, against the
 fp32-matrix peak.  `cpu_baseline` times the numpy oracle (a port of the reference CPU path) on a bounded sample.
+`gstep` (N=1 only, outside the timed region) is the other half of BASELINE.json's metric: one generator step (forward +
+backward + device re-pack) on the same workload shape through the native differentiable path.
 """
 import argparse
 import json
@@ -52,6 +54,53 @@ def cpu_baseline(spec, sd, film, seed):
                        f"(BLAS GEMMs use all {os.cpu_count()} host cores, elementwise ops 1)")
 
 
+def gstep_leg(spec, sd, dev, B, S, N, precision, iters=5):
+    """BASELINE.json's metric also names the generator step: forward + backward (+ the device-side re-pack an optimizer step
+    forces) through DoubleImplicitGenerator3d.forward_with_frequencies on the same workload shape, native differentiable path
+    (DESIGN.md 4.5).  Reported beside the headline value; never part of the timed region."""
+    import functools
+    from fenerf_amd.generators import generators as G
+    from fenerf_amd.siren import siren as S_
+    from fenerf_amd import procedural as proc
+    H = spec["hidden_dim"]
+    z_dim = spec.get("z_dim", 256)
+    mod = S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE(hidden_dim=H, z_geo_dim=z_dim, z_app_dim=z_dim, output_dim=spec["output_dim"])
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    mod.load_state_dict(tsd, strict=False)
+    mod.precision = precision
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=H), z_dim, z_dim, spec["output_dim"])
+    gen.siren = mod
+    gen = gen.to(dev)
+    gen.device = dev
+    gen.siren.device = dev
+    film = {k: torch.tensor(v, device=dev).requires_grad_(True) for k, v in proc.film_params(spec, B, seed=5).items()}
+    kw = dict(img_size=S, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
+    w = torch.randn((B, spec["output_dim"] - 1, S, S), device=dev)
+    params = [p for n, p in mod.named_parameters() if "mapping_network" not in n]
+
+    def step():
+        for p in params:
+            p.grad = None
+        with torch.no_grad():
+            params[0].add_(0)            # version bump like optimizer.step(): the packed streams are rebuilt on the device
+        px, _ = gen.forward_with_frequencies(film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], **kw)
+        (px * w).sum().backward()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms": ms, "what": f"forward + backward + device re-pack of one generator step, batch {B} x {S}x{S} rays x {N}+{N} samples "
+                              f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}",
+            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +110,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gstep", action="store_true", help="skip the generator-step (forward + backward) leg")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="arithmetic of the dense layers: exact fp32 MFMA, or error-compensated fp16 MFMA (fp32-class accuracy)")
     args = ap.parse_args()
@@ -143,6 +193,11 @@ def main():
                          "flop_per_point_algorithmic": FLOP_PER_POINT, "mfma": mfma, **extra},
             "rays_per_s_per_gpu": value / world,
         }
+        if world == 1 and not args.no_gstep:
+            try:
+                out["gstep"] = gstep_leg(spec, sd, dev, B, S, N, args.precision)
+            except Exception as e:          # the extra leg must never take the headline metric down with it
+                out["gstep"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             film1 = proc.film_params(spec, 1, seed=1000)
             out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7)
