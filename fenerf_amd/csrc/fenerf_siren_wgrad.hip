@@ -540,11 +540,16 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
     const int l = i / H, n = i % H;
     float db = 0.f;
     for (int b = 0; b < B; ++b) {
-      float s0 = 0.f, s1 = 0.f;
-      for (int k = 0; k < (l == 0 ? nchunk0 : nchunk); ++k) {     // layer 0 comes from the (finer-chunked) thin job
-        const float* p = part + ((((size_t)l * B + b) * stride + k) * H + n) * 2;
-        s0 += p[0]; s1 += p[1];
+      const int nk = l == 0 ? nchunk0 : nchunk;
+      const float2* p = reinterpret_cast<const float2*>(part) + (((size_t)l * B + b) * stride) * H + n;   // + k * H
+      float2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;           // four independent chains: the loads are latency-bound
+      int k = 0;
+      for (; k + 4 <= nk; k += 4) {
+        const float2 v0 = p[(size_t)k * H], v1 = p[(size_t)(k + 1) * H], v2 = p[(size_t)(k + 2) * H], v3 = p[(size_t)(k + 3) * H];
+        a0.x += v0.x; a0.y += v0.y; a1.x += v1.x; a1.y += v1.y; a2.x += v2.x; a2.y += v2.y; a3.x += v3.x; a3.y += v3.y;
       }
+      for (; k < nk; ++k) { const float2 v = p[(size_t)k * H]; a0.x += v.x; a0.y += v.y; }
+      const float s0 = (a0.x + a1.x) + (a2.x + a3.x), s1 = (a0.y + a1.y) + (a2.y + a3.y);
       db += s0 * (fp[((size_t)b * L + l) * H + n] * TWO_PI / (inv ? inv[(size_t)l * H + n] : 1.f));
       if (l < n_geo) { d_phase_geo[((size_t)b * n_geo + l) * H + n] = s0; d_freq_geo[((size_t)b * n_geo + l) * H + n] = 15.f * s1; }
       else { d_phase_app[((size_t)b * n_color + (l - n_geo)) * H + n] = s0; d_freq_app[((size_t)b * n_color + (l - n_geo)) * H + n] = 15.f * s1; }
