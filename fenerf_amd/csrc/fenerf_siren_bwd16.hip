@@ -4,9 +4,9 @@
 //     W'^T dz  ~=  wl*xh + wh*xl + wh*xh        (fp32 accumulate; the dropped wl*xl term is 2^-16 relative)
 // -- three 32-cycle MFMAs per 16 features instead of eight 64-cycle fp32 MFMAs.  Weights are split on the host
 // (hi = RNE, lo = RNE of the remainder: 16+ significant bits); dz is split in the epilogue (hi = truncation, lo = the exact
-// remainder rounded: 16 bits, unbiased) and parked in the LDS slab as ready-made B operands.  Each wave streams its own copy of the weights through a
-// 8-entry register ring (tools/probe/stream_probe.hip: a private L2 stream feeds one MFMA triple per ~180 cycles, 53 % of
-// the matrix pipe, 2.8x the fp32 path).
+// remainder rounded: 16 bits, unbiased) and parked in the LDS slab as ready-made B operands.  Each wave streams its own
+// copy of the weights through an 8-entry register ring (tools/probe/stream_probe.hip: a private L2 stream feeds one MFMA
+// triple per ~180 cycles, 53 % of the matrix pipe, 2.8x the fp32 path).  Measurements and what bounds it: DESIGN.md 4.5.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
