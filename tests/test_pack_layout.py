@@ -241,3 +241,42 @@ def test_device_packing_reproduces_the_host_streams(precision):
             dv, hv = bf(bwd.numpy()), bf(hbwd)
             assert (dv != hv).mean() <= (0.05 if fold else 0.0)
             assert np.abs(dv - hv).max() <= 1e-3 * max(1.0, np.abs(hv).max())
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_repack_maps_cover_the_packed_buffers(precision):
+    """FenerfRepackMaps (what fenerf_model_repack consumes; the kernels themselves are compared bit for bit on the GPU): sizes must add
+    up to the host packer's buffers, every index must address the canonical flat parameter vector, every scaled row must be
+    covered exactly once by scale_id, and the result-scale table must point at real rows."""
+    import torch
+    from fenerf_amd import native
+    for kind, H, grid in [("texture", 64, 4), ("baseline", 32, 0), ("spatial", 32, 0)]:
+        spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+        sd = proc.make_state_dict(spec, seed=2, sigma_gain=10.0, with_mapping=False)
+        nm = object.__new__(native.NativeModel)
+        nm.spec, nm.differentiable, nm.device, nm.precision, nm._maps, nm._rmaps, nm._h = dict(spec), True, torch.device("cpu"), precision, None, None, None
+        r = nm._repack_maps()
+        keep = nm._rmaps[1]
+        blob, consts = _lib.pack_weights_host(sd, spec, precision)
+        bwd = _lib.pack_backward_host(sd, spec, precision)
+        n_flat = 1 + sum(int(np.prod(sh)) for _, sh in nm._canonical())
+        assert r.n_stream_f32 + r.n_stream_h16 // 2 == blob.size and r.n_stream_h16 % 2 == 0
+        assert r.n_consts + r.n_tail == consts.size
+        assert r.n_bwd_f32 + r.n_bwd_b16 // 2 == bwd.size and r.n_bwd_b16 % 2 == 0
+        for k in ("stream_f32", "consts", "bwd_f32", "bwd_b16"):
+            if k in keep:
+                assert 0 <= int(keep[k].min()) and int(keep[k].max()) < n_flat, k
+        if precision == "f16x3":
+            idx = keep["stream_h16"] & 0x3FFFFFFF
+            assert int(idx.max()) < n_flat and set(torch.unique(keep["stream_h16"] >> 30).tolist()) <= {0, 1}
+            sid = keep["scale_id"].numpy()
+            assert sid.size == n_flat and sid.max() == r.n_rows
+            off, ln = keep["row_off"].numpy(), keep["row_len"].numpy()
+            for q in (0, r.n_rows // 2, r.n_rows - 1):                       # a row's elements carry its id, its neighbours do not
+                assert (sid[off[q]:off[q] + ln[q]] == q + 1).all() and (sid == q + 1).sum() == ln[q]
+            tail = keep["consts_tail"].numpy()
+            L = spec["n_geo"] + spec["n_color"]
+            assert tail.size == L * H + 36 and tail.max() <= r.n_rows and tail.min() >= -1
+            assert (tail[:H] == -1).all() and (tail[H:L * H] > 0).all() and tail[-1] == -1
+        else:
+            assert r.n_stream_h16 == 0 and r.n_tail == 0 and r.n_rows == 0
