@@ -36,11 +36,11 @@ PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA (v_mf
 
 
 def cpu_baseline(spec, sd, film, seed):
-    """Oracle (numpy port of the reference CPU path) on a bounded sample of the same workload: 96x96 rays,
-    24+24 samples, same model -- sized for ~10-30 s of CPU work."""
+    """Oracle (numpy port of the reference CPU path) on one image of the same workload: 128x128 rays, 24+24 samples, same
+    model -- ~10 s of CPU work on the GPU box's host."""
     from fenerf_amd import procedural as proc
     from oracle import fenerf_oracle as O
-    S, N, B = 96, 24, 1
+    S, N, B = 128, 24, 1
     R = S * S
     rng = np.random.default_rng(seed)
     rand = dict(u_jitter=rng.random((B, R, N, 1), dtype=np.float32), theta=np.full((B, 1), np.pi / 2 + 0.1, np.float32),
