@@ -641,9 +641,12 @@ int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
   return (int)best;
 }
 
-// thin jobs (layer 0, colour-layer-0 extras, heads) stream the tapes with almost no MFMA work: one workgroup per CU
+// thin jobs (layer 0, colour-layer-0 extras, heads) stream the tapes with almost no MFMA work
 int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
-  long long n = (m->num_cus + B - 1) / B;
+  // two workgroups per CU (41-74 KB of LDS, <= 164 registers each): single-buffered, they need the second one to keep
+  // loads in flight while the first stages and multiplies (measured 578 -> 460 us for the four jobs; three: 443 us, but the
+  // partial reductions grow with the chunk count)
+  long long n = (2LL * m->num_cus + B - 1) / B;
   if (n > tiles_per_image) n = tiles_per_image;
   if (n > 256) n = 256;
   return (int)(n < 1 ? 1 : n);
