@@ -1072,6 +1072,21 @@ def test_backward_api_rejects_bad_arguments():
     assert rc == _lib.E_INVALID and b"every weight / bias buffer or none" in l.fenerf_last_error()
     rc = l.fenerf_grid_backward(plain._h, -1, p(pts), p(d_e), p(scratch), None)
     assert rc == _lib.E_INVALID
+    # device re-pack: maps that do not add up to the model's resident buffers are refused before any launch
+    r = diff._repack_maps()
+    clone = lambda x: type(x).from_buffer_copy(x)
+    flat = torch.zeros(1 << 16, device=DEV)
+    bad = clone(r)
+    bad.n_stream_h16 = r.n_stream_h16 - 2
+    assert l.fenerf_model_repack(diff._h, p(flat), flat.numel(), C.byref(bad), None, None) == _lib.E_INVALID
+    assert b"forward stream" in l.fenerf_last_error()
+    bad = clone(r)
+    bad.bwd_b16 = None
+    assert l.fenerf_model_repack(diff._h, p(flat), flat.numel(), C.byref(bad), None, None) == _lib.E_INVALID
+    assert b"backward stream" in l.fenerf_last_error()
+    assert l.fenerf_model_repack(diff._h, None, 0, C.byref(r), None, None) == _lib.E_INVALID
+    rc = l.fenerf_model_export_packed(plain._h, None, 0, None, 0, p(scratch), 5, None)       # no backward stream to export
+    assert rc == _lib.E_INVALID
     torch.cuda.synchronize()
 
 
