@@ -165,7 +165,25 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
         const int c = c0 + (lane & 31), par = lane >> 5;
         float acc = 0.f;
         if (c < nch) {
-          for (int k = par; k < M; k += 2) {
+          // four loads in flight per lane (the loop is a chain of dependent LDS read -> address -> global load otherwise); the
+          // products are still added in sample order, so the result does not change
+          int k = par;
+          for (; k + 6 < M; k += 8) {
+            float v[4], wk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int kk = k + 2 * u;
+              const int sidx = s_ord[wv][kk];
+              const float* row = MERGE ? (sidx < N ? P.rows_a + (ray * N + sidx) * (long long)C
+                                                   : P.rows_b + (ray * N + (sidx - N)) * (long long)C)
+                                       : P.rows_a + (ray * M + kk) * (long long)C;
+              v[u] = row[c];
+              wk[u] = s_w[wv][kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += wk[u] * v[u];
+          }
+          for (; k < M; k += 2) {
             const int sidx = s_ord[wv][k];
             const float* row = MERGE ? (sidx < N ? P.rows_a + (ray * N + sidx) * (long long)C
                                                  : P.rows_b + (ray * N + (sidx - N)) * (long long)C)
