@@ -6,14 +6,18 @@ composite) over one batch of synthetic rays already resident in HBM.  Workload =
 TextureEmbeddingPiGAN256SEMANTICDISENTANGLE_DIM_96 (H=256 FiLM-SIREN + 32x96^3 grid, 22 channels), 128x128 rays,
 24+24 hierarchical samples, batch 1 per GPU, procedural (random-init-range) weights, synthetic latents.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, weak scaling)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (siren_kernel, MFMA-bound): algorithmic
-FLOPs per launch (1,603,584 FLOP/point x points) / its hipEvent-timed average duration, against the
-fp32-matrix peak.  `cpu_baseline` times the numpy oracle (a port of the reference CPU path) on a bounded sample.
-`gstep` (N=1 only, outside the timed region) is the other half of BASELINE.json's metric: one generator step (forward +
-backward + device re-pack) on the same workload shape through the native differentiable path.
+N > 1 without a launcher environment (WORLD_SIZE unset) re-executes itself under `python -m torch.distributed.run
+--nproc-per-node N --master-addr 127.0.0.1`; launched BY torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from
+the environment.  One rank per GPU, every rank renders its own images (weak scaling, no data-path collective); RCCL carries
+the timing barrier, the max-over-ranks reduce and an all-reduce of ones (`n_ranks_seen`).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the SIREN kernel, MFMA-bound): algorithmic
+FLOPs per launch (1,603,584 FLOP/point x points) / its hipEvent-timed average duration.  Extra objects on the
+same line: `f32` (the same step at exact-fp32 precision, N=1), `sweep64` (north_star's 64x64, 24+24 scaling batch),
+`gstep` (one generator step, N=1), `cpu_baseline` (numpy oracle = port of the reference CPU path, 1 warm-up + 3 timed runs
+per shape, N=1).
 """
 import argparse
 import json
@@ -29,29 +33,67 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 1_603_584          # SURVEY.md §8(d) / BASELINE.md §4 (dense layers, 2 FLOP per MAC)
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
-# HBM bytes per siren launch at this workload from rocprofv3 PMC passes (profiles/r01_pmc_*.txt): FETCH_SIZE 173 MiB-equivalent
-# KiB counter (x1024, uncorrected; dominated by the scattered grid gather) + WRITE_SIZE 34.6 MB.  MFMA-bound kernel: context only.
-TRAFFIC_BYTES_PER_LAUNCH = int(177.07e6 + 34.60e6)
-PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA (v_mfma_f32_32x32x16_f16)
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
+# HBM-side bytes per SIREN launch at the default workload (393,216 points).  A PMC pass cannot run inside this process, so the
+# figures are those of the committed rocprofv3 passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/gpu_session.sh pmc):
+TRAFFIC = {
+    "source": "profiles/r01_pmc_siren16s_f16x3_v6.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+    "fetch_raw_bytes": 177.07e6,        # FETCH_SIZE x 1024, as reported
+    "fetch_x2_bytes": 354.14e6,         # MI355X_MICROARCH.md HBM: gfx950 reports 1/2 of wide coalesced reads; upper bound here
+    "write_bytes": 34.60e6,             # = 393,216 points x 22 channels x 4 B exactly
+    # compulsory bytes of one launch: outputs 34.6 MB + z 1.6 MB + rays 0.4 MB + weight stream 2.75 MB
+    "algorithmic_bytes": 34.60e6 + 1.57e6 + 0.39e6 + 2.75e6,
+    "note": "excess over algorithmic = the 8 x 128-B trilinear corner fetches per point (113 MB grid, TCC hit 95.6 %); "
+            "MFMA-bound kernel, 0.15-0.27 TB/s: context, not the limiter",
+}
 
 
-def cpu_baseline(spec, sd, film, seed):
-    """Oracle (numpy port of the reference CPU path) on one image of the same workload: 128x128 rays, 24+24 samples, same
-    model -- ~10 s of CPU work on the GPU box's host."""
-    from fenerf_amd import procedural as proc
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch_command(n, argv, script=None, port=None):
+    """The command `python bench.py --gpus N` turns itself into when no launcher set WORLD_SIZE: one rank per GPU under
+    torch.distributed.run on 127.0.0.1 (reference analogue: mp.spawn over GPUs, train_double_latent_semantic.py:584)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), script or os.path.abspath(__file__)] + list(argv)
+
+
+def _oracle_run(spec, sd, film, S, N, hier, seed):
     from oracle import fenerf_oracle as O
-    S, N, B = 128, 24, 1
-    R = S * S
+    B, R = 1, S * S
     rng = np.random.default_rng(seed)
     rand = dict(u_jitter=rng.random((B, R, N, 1), dtype=np.float32), theta=np.full((B, 1), np.pi / 2 + 0.1, np.float32),
-                phi=np.full((B, 1), np.pi / 2 - 0.05, np.float32), noise_coarse=None, u_fine=rng.random((B * R, N), dtype=np.float32),
-                noise_fine=None)
+                phi=np.full((B, 1), np.pi / 2 - 0.05, np.float32), noise_coarse=None,
+                u_fine=rng.random((B * R, N), dtype=np.float32), noise_fine=None)
     t0 = time.perf_counter()
-    O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rand, hierarchical_sample=True, clamp_mode="relu")
-    dt = time.perf_counter() - t0
-    return dict(value=R / dt, unit="rays/s", cores=os.cpu_count(), kind="port",
-                sample=f"numpy oracle render_forward, {S}x{S} rays, {N}+{N} samples, H=256+96^3 grid, 1 run of {dt:.1f}s "
-                       f"(BLAS GEMMs use all {os.cpu_count()} host cores, elementwise ops 1)")
+    O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rand, hierarchical_sample=hier, clamp_mode="relu")
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(spec, sd, film, seed, full=True):
+    """Oracle (numpy port of the reference CPU path, validated against the reference's own outputs in tests/) on the GPU box's
+    host cores: BASELINE.md §5 = 1 warm-up + 3 timed runs per shape; shapes = configs[0] (64x64, 12 coarse), configs[1] (128x128,
+    24+24: the headline workload, `value`) and the 64x64, 24+24 scaling batch.  `full=False`: headline shape only, 1+1 runs."""
+    cores = os.cpu_count()
+    shapes = [("configs[1]: 128x128 rays, 24+24 samples", 128, 24, True)]
+    if full:
+        shapes += [("configs[0]: 64x64 rays, 12 coarse samples, no resampling", 64, 12, False),
+                   ("scaling batch: 64x64 rays, 24+24 samples", 64, 24, True)]
+    res = []
+    for name, S, N, hier in shapes:
+        _oracle_run(spec, sd, film, S, N, hier, seed)                          # warm-up
+        ts = [_oracle_run(spec, sd, film, S, N, hier, seed + 1 + i) for i in range(3 if full else 1)]
+        res.append({"shape": name, "rays": S * S, "seconds": [round(t, 3) for t in ts], "rays_per_s": S * S / float(np.median(ts))})
+    return dict(value=res[0]["rays_per_s"], unit="rays/s", cores=cores, kind="port",
+                sample=f"numpy oracle render_forward on one image per shape, H=256 + 96^3 grid, 1 warm-up + {len(res[0]['seconds'])} timed "
+                       f"run(s), median (BLAS GEMMs use all {cores} host cores, elementwise ops 1); value = {res[0]['shape']}",
+                runs=res)
 
 
 def gstep_leg(spec, sd, dev, B, S, N, precision, iters=5):
@@ -88,6 +130,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=5):
         px, _ = gen.forward_with_frequencies(film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], **kw)
         (px * w).sum().backward()
 
+    torch.cuda.reset_peak_memory_stats()
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -101,7 +144,24 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=5):
             "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
 
 
-def main():
+def dist_check(args):
+    """Rendezvous only (CPU-capable, backend gloo): proves the self-launch produced `--gpus` ranks that see each other."""
+    import torch.distributed as dist
+    from fenerf_amd import dist as fdist
+    rank, local_rank, world = fdist.init_from_env(backend=args.dist_backend)
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"dist_check": True, "n_gpus": args.gpus, "world_size": world, "n_ranks_seen": int(ones.item()),
+                          "backend": args.dist_backend}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -110,40 +170,45 @@ def main():
     ap.add_argument("--num-steps", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="headline shape only, 1 warm-up + 1 timed run")
     ap.add_argument("--no-gstep", action="store_true", help="skip the generator-step (forward + backward) leg")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 leg")
+    ap.add_argument("--no-sweep64", action="store_true", help="skip the 64x64, 24+24 scaling-batch leg")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="arithmetic of the dense layers: exact fp32 MFMA, or error-compensated fp16 MFMA (fp32-class accuracy)")
-    args = ap.parse_args()
+    ap.add_argument("--dist-check", action="store_true", help="rendezvous + all-reduce of ones only (no GPU needed)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo for the CPU dry run of --dist-check")
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's N=1 command with N changed: become the launcher (one rank per GPU over RCCL)
+        import subprocess
+        sys.exit(subprocess.call(self_launch_command(args.gpus, argv)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; use --nproc-per-node {args.gpus}")
+    if args.dist_check:
+        return dist_check(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     from fenerf_amd import dist as fdist
+    n_ranks_seen = 1
     if world > 1:
-        fdist.init_from_env(backend="nccl", device=dev)   # RCCL over xGMI; used only for the timing barrier / max-reduce
+        fdist.init_from_env(backend="nccl", device=dev)   # RCCL over xGMI; timing barrier / max-reduce / rank census only
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
 
     from fenerf_amd import _lib, native, procedural as proc
     from fenerf_amd.generators import volumetric_rendering as VR
 
     spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
     sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
-    nat = native.NativeModel(sd, spec, dev, args.precision)
-    B, S, N = args.batch, args.img_size, args.num_steps
-    R = S * S
-    # every rank renders its own images (shard by image, no data-path collective): different latents / poses per rank
-    film = proc.film_params(spec, B, seed=1000 + rank)
-    tf = tuple(torch.as_tensor(film[k], device=dev) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
-    torch.manual_seed(1234 + rank)
-    o, d, z, _, _ = VR.sample_rays(B, N, dev, 12, (S, S), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
-    u = torch.rand((B * R, N), device=dev)
     opts = _lib.composite_opts("relu", 0.0, fill_mode="seg_padding_background", fill_color="black")
-
-    def step():
-        return nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,34 +216,70 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = fdist.max_over_ranks(dt, device=dev)
-    rays_total = world * B * R * args.steps
-    value = rays_total / dt
+    def timed_render(nat, B, S, N, steps, warmup, seed):
+        """W untimed + K timed render steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, own seconds,
+        the resident inputs)."""
+        R = S * S
+        # every rank renders its own images (shard by image, no data-path collective): different latents / poses per rank
+        film = proc.film_params(spec, B, seed=seed + rank)
+        tf = tuple(torch.as_tensor(film[k], device=dev) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+        torch.manual_seed(seed + 234 + rank)
+        o, d, z, _, _ = VR.sample_rays(B, N, dev, 12, (S, S), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+        u = torch.rand((B * R, N), device=dev)
+        for _ in range(warmup):
+            nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
+        barrier()
+        own = time.perf_counter() - t0
+        return fdist.max_over_ranks(own, device=dev), own, (o, d, z, tf)
 
-    out = None
-    if rank == 0:
-        # dominant kernel alone (coarse-pass shape == fine-pass shape): hipEvents on the launch stream
-        pts = B * R * N
-        k_ms = nat.time_siren_rays(o, d, z, *tf, iters=max(5, args.steps // 2))
+    def gather_floats(v):
+        if world == 1:
+            return [float(v)]
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [float(x.item()) for x in outs]
+
+    def roofline_of(nat, inputs, pts, precision, iters):
+        o, d, z, tf = inputs
+        k_ms = nat.time_siren_rays(o, d, z, *tf, iters=iters)       # dominant kernel alone, hipEvents on the launch stream
         achieved = pts * FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
-        if args.precision == "f32":
-            peak, dtype = PEAK_FP32_MATRIX_TFLOPS, "f32"
-            kname, mfma = "siren_kernel<256,true>", "v_mfma_f32_32x32x2_f32 (exact fp32)"
-            extra = {}
+        if precision == "f32":
+            peak, kname, mfma, extra = PEAK_FP32_MATRIX_TFLOPS, "siren_kernel<256,true,false>", "v_mfma_f32_32x32x2_f32 (exact fp32)", {}
         else:
             # every algorithmic product is evaluated as 3 fp16 MFMAs (wh*xh + wh*xl + wl*xh, fp32 accumulate): the attainable
             # ceiling of this algorithm on the fp16 pipe is peak/3; `frac` is quoted against the full dense fp16 peak.
-            peak, dtype = PEAK_F16_MATRIX_TFLOPS, "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
-            kname, mfma = "siren16s_kernel<256,true,false>", "v_mfma_f32_32x32x16_f16, 3 per product"
+            peak, kname, mfma = PEAK_F16_MATRIX_TFLOPS, native.forward_kernel_name(nat), "fp16 MFMA, 3 per product (hi/lo error compensation)"
             extra = {"frac_of_f16x3_ceiling": achieved / (peak / 3)}
+        return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "kernel": kname, "kernel_ms": k_ms, "points_per_launch": pts, "flop_per_point_algorithmic": FLOP_PER_POINT,
+                "mfma": mfma, **extra}
+
+    nat = native.NativeModel(sd, spec, dev, args.precision)
+    B, S, N = args.batch, args.img_size, args.num_steps
+    R = S * S
+    dt, own, inputs = timed_render(nat, B, S, N, args.steps, args.warmup, 1000)
+    value = world * B * R * args.steps / dt
+    per_rank = [B * R * args.steps / t for t in gather_floats(own)]
+    roof = roofline_of(nat, inputs, B * R * N, args.precision, max(5, args.steps // 2))
+    roof_frac_ranks = gather_floats(roof["frac"])
+    sweep = None
+    if not args.no_sweep64:
+        # north_star: "rays/s on synthetic 64x64x24-sample batches at 1/2/4/8 GPUs ... as fraction of roofline"
+        sB, sS, sN = 4, 64, 24
+        sdt, _, sin = timed_render(nat, sB, sS, sN, args.steps, args.warmup, 2000)
+        sroof = roofline_of(nat, sin, sB * sS * sS * sN, args.precision, max(5, args.steps // 2))
+        sweep = {"workload": f"{sB} images/GPU x {sS}x{sS} rays x {sN}+{sN} samples", "value": world * sB * sS * sS * args.steps / sdt,
+                 "unit": "rays/s", "ms_per_step": sdt / args.steps * 1e3, "roofline_frac": sroof["frac"],
+                 "roofline_frac_of_f16x3_ceiling": sroof.get("frac_of_f16x3_ceiling"), "kernel_ms": sroof["kernel_ms"]}
+
+    if rank == 0:
+        dtype = "f32" if args.precision == "f32" else "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
+        tr = dict(TRAFFIC) if (args.precision == "f16x3" and (B, S, N) == (1, 128, 24)) else None
         out = {
             "metric": f"rays/s/GPU forward render ({S}x{S}, {N}+{N} samples, H=256 FiLM-SIREN + 32x96^3 grid)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,12 +288,23 @@ def main():
             "config": {"workload": f"configs[1]: CelebA_double_semantic_texture_embedding_256_dim_96 generator, {S}x{S}, "
                                    f"{N}+{N} hierarchical samples, batch {B}/GPU, forward-only render, procedural weights",
                        "img_size": S, "num_steps": N, "batch_per_gpu": B, "sharding": "by image, no collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                         "kernel": kname, "kernel_ms": k_ms, "points_per_launch": pts,
-                         "flop_per_point_algorithmic": FLOP_PER_POINT, "mfma": mfma, **extra},
-            "rays_per_s_per_gpu": value / world,
+            "roofline": {**roof, "traffic": (tr["fetch_x2_bytes"] + tr["write_bytes"]) if tr else None, "traffic_detail": tr,
+                         "frac_per_rank": roof_frac_ranks},
+            "rays_per_s_per_gpu": value / world, "rays_per_s_per_rank": per_rank, "n_ranks_seen": n_ranks_seen,
+            "launcher": "torch.distributed.run, one rank per GPU, backend nccl (RCCL)" if world > 1 else "single process",
         }
+        if sweep:
+            out["sweep64"] = sweep
+        if world == 1 and not args.no_f32 and args.precision != "f32":
+            try:
+                nat32 = native.NativeModel(sd, spec, dev, "f32")
+                fdt, _, fin = timed_render(nat32, B, S, N, args.steps, args.warmup, 1000)
+                out["f32"] = {"value": B * R * args.steps / fdt, "unit": "rays/s", "ms_per_step": fdt / args.steps * 1e3,
+                              "dtype": "f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                              "roofline": roofline_of(nat32, fin, B * R * N, "f32", max(5, args.steps // 2))}
+                del nat32
+            except Exception as e:
+                out["f32"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_gstep:
             try:
                 out["gstep"] = gstep_leg(spec, sd, dev, B, S, N, args.precision)
@@ -200,7 +312,7 @@ def main():
                 out["gstep"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             film1 = proc.film_params(spec, 1, seed=1000)
-            out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7)
+            out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7, full=not args.quick_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -133,8 +133,10 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
     losses = []
     for i in range(n_iterations):
         k = latent_noise * (n_iterations - i) / n_iterations      # annealed noise on the FiLM parameters (:381-384; 0.03 there)
-        frame, _ = generator.forward_with_frequencies(w_gf + k * torch.randn_like(w_gf) + o_gf, w_af + k * torch.randn_like(w_af) + o_af,
-                                                      w_gp + k * torch.randn_like(w_gp) + o_gp, w_ap + k * torch.randn_like(w_ap) + o_ap,
+        # draw order of the reference (:381-384): geo freq, geo phase, app freq, app phase
+        n_gf, n_gp = k * torch.randn_like(w_gf), k * torch.randn_like(w_gp)
+        n_af, n_ap = k * torch.randn_like(w_af), k * torch.randn_like(w_ap)
+        frame, _ = generator.forward_with_frequencies(w_gf + n_gf + o_gf, w_af + n_af + o_af, w_gp + n_gp + o_gp, w_ap + n_ap + o_ap,
                                                       **options)
         loss = lambda_seg * mse(frame[:, :-3], gt_seg) + lambda_img * mse(frame[:, -3:], gt_image)
         if lambda_percept and percept is not None:

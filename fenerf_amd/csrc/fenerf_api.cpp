@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +28,22 @@ static int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_dynamic_lds(const void* kfn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[{kfn, dev}];
+  if (bytes > have) {
+    e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+    have = bytes;
+  }
+  return FENERF_OK;
+}
 
 static int check_opts(const FenerfCompositeOpts* o) {
   if (!o) return fail(FENERF_E_INVALID, "opts is NULL");

@@ -11,6 +11,11 @@
 namespace fenerf {
 
 void set_error(const std::string& msg);
+// Opt-in to > 64 KiB of dynamic LDS for kernel `kfn`.  hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute:
+// what has been granted is remembered per (kernel, current device) under a lock, so a process that renders on several GPUs or
+// from several host threads always launches with the opt-in in place (include/fenerf.h: thread-safe per handle).
+// Returns FENERF_OK or FENERF_E_HIP (error string set).
+int ensure_dynamic_lds(const void* kfn, size_t bytes);
 int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
@@ -109,6 +114,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
+int launch_siren16w_one(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 no-grad forward, 16-point waves (fenerf_siren_f16w.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_composite_backward(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);

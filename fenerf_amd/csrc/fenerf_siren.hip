@@ -338,13 +338,8 @@ template <int H, bool GRID, bool SAVE>
 static int launch_siren_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const int stage_f4 = (32 * m->C + 3) / 4;
   const size_t lds = (size_t)4 * ((H / 8) * 64 + stage_f4) * sizeof(float4);
-  static size_t configured = 0;  // per instantiation
   auto kfn = siren_kernel<H, GRID, SAVE>;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
-    configured = lds;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > m->num_cus) blocks = m->num_cus;

@@ -348,13 +348,8 @@ static int hip_fail_b16(hipError_t e, const char* what) {
 template <int H, bool GRID>
 static int launch_bwd16_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   const size_t lds = (size_t)4 * ((H / 8) * 64) * sizeof(float4);
-  static size_t configured = 0;
   auto kfn = siren_bwd16_kernel<H, GRID>;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hip_fail_b16(e, "hipFuncSetAttribute(max dynamic LDS)");
-    configured = lds;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > m->num_cus) blocks = m->num_cus;

@@ -22,6 +22,8 @@
 //     in 64 VGPRs -- x (128) + y (128) in registers is what made hipcc spill the B operands to scratch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_nt.h"
@@ -630,13 +632,8 @@ static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* s
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)4 * 2 * (2 * film_f) + (size_t)4 * stage_f4 * 16 +
                      (size_t)4 * (H / 64) * 4 * 1024;   // ring + FiLM buffers + output staging + activation slabs
-  static size_t configured = 0;
   auto kfn = siren16s_kernel<H, GRID, SAVE>;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hip_fail16s(e, "hipFuncSetAttribute(max dynamic LDS)");
-    configured = lds;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
   if (blocks > m->num_cus) blocks = m->num_cus;
@@ -651,8 +648,13 @@ static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* s
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
   const bool g = m->grid_ch != 0;
+  // no-grad launches run the 16-point / 2-waves-per-SIMD kernel (fenerf_siren_f16w.hip, same stream); the forward-save
+  // launches stay here (the tape layout is this kernel's register dump).  FENERF_FORWARD_KERNEL=f16s forces this kernel
+  // (A/B timing only).
+  static const bool force_s = [] { const char* v = getenv("FENERF_FORWARD_KERNEL"); return v && std::string(v) == "f16s"; }();
   auto one = [&](const SirenParams& q) -> int {
     const bool sv = q.tape != nullptr;
+    if (!sv && !force_s) return launch_siren16w_one(m, q, stream);
     switch (m->H) {
       case 32: return sv ? (g ? launch_siren16s_t<32, true, true>(m, q, stream) : launch_siren16s_t<32, false, true>(m, q, stream))
                          : (g ? launch_siren16s_t<32, true, false>(m, q, stream) : launch_siren16s_t<32, false, false>(m, q, stream));

@@ -1,0 +1,654 @@
+// FiLM-SIREN radiance field, f16x3 mode, no-grad forward: 16-point waves, two waves per SIMD (gfx950 / MI355X).
+//
+// Same arithmetic as fenerf_siren_f16s.hip (every fp32 product as wl*xh + wh*xl + wh*xh on the fp16 matrix pipe, fp32
+// accumulate; activations never leave their lane) and the SAME packed weight stream, but a different execution shape:
+//
+//   * fenerf_siren_f16s.hip runs one 32-point wave per SIMD at ~450 registers.  Its wave issues in order, so every
+//     global_load_lds (100-185 cycles of issue each in a busy phase), every LDS wait and every barrier sits in the MFMA
+//     stream: 51-53 % matrix-pipe utilisation.
+//   * Here a workgroup is 8 waves = 2 per SIMD, each owning 16 points on v_mfma_f32_16x16x32_f16.  Activations halve to
+//     64 (x) + 64 (y) registers per wave, everything fits 256 registers, and the SIMD's scheduler issues one wave's MFMAs
+//     under the other's DMA / LDS / VALU / barrier time.
+//
+// One stream, two consumers.  The packer lays an entry out for the 32x32x16 MFMA (lane (row, h), 8 halves = k slots of
+// lane-half h).  A 16x16x32 A operand (16 rows x 32 k) is the union of halves of TWO consecutive k16 entries, so the
+// LDS-DMA does the re-tiling: global_load_lds takes a per-lane global address, and each of the 8 waves fetches, per 8-KiB
+// chunk, exactly one ready-made 1-KiB A operand (k32-step spl, row tile rt, hi/lo) by pointing its lanes at the right
+// 16-byte pieces of the old entries.  Ring reads are then linear ds_read_b128 (conflict-free).  Derivation of the maps:
+//
+//   old entry (k16-step s16, hi|lo), piece 32 h + row, slot t  =  W[32 nb + row][feat16_of(s16, h, t)]
+//   16x16x32 MFMA: A lane (i, kg) slot t = A[i][k(kg, t)], B lane (n, kg) slot t = B[k(kg, t)][n], C/D lane (n, g) reg r = D[4 g + r][n]
+//   A operand (k32-step sp, row tile rt): lane (i = 4 gi + r, kg)  <-  old entry s16 = 2 sp + (kg >> 1), piece 32 (kg & 1) + row(rt, i)
+//        row(rt, 4 gi + r) = 16 (gi >> 1) + 4 (gi & 1) + 8 rt + r
+//   so lane group g ends n-block nb holding, in acc[rt][r], feature 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r -- exactly the
+//   features feat16_of(2 nb + (g >> 1), g & 1, 4 rt + r) the packer put into lane group g's k slots of k32-step nb: the
+//   accumulators, FiLM'ed and split, ARE the next layer's B operand {acc[0][0..3], acc[1][0..3]}.
+#include <hip/hip_runtime.h>
+
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+
+// composite timing experiments
+#ifdef EXP_W_NOMFMA_NODMA
+#define EXP_W_NOMFMA
+#define EXP_W_NODMA
+#endif
+#ifdef EXP_W_NOMFMA_NOEPI
+#define EXP_W_NOMFMA
+#define EXP_W_NOEPI
+#endif
+#ifdef EXP_W_NOMFMA_NOEPI_NOBARRIER
+#define EXP_W_NOMFMA
+#define EXP_W_NOEPI
+#define EXP_W_NOBARRIER
+#endif
+#ifdef EXP_W_NOMFMA_HALFLDS
+#define EXP_W_NOMFMA
+#define EXP_W_HALFLDS
+#endif
+#ifdef EXP_W_NODMA_NOEPI
+#define EXP_W_NODMA
+#define EXP_W_NOEPI
+#endif
+
+namespace fenerf {
+namespace w16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+
+#define MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define MFMA32W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int CH = FENERF_CH;        // old entries (KiB) per chunk = one A operand per wave
+constexpr int DPF = FENERF_DPF;      // chunks in flight ahead of the chunk being consumed
+constexpr int NSLOT = FENERF_NSLOT;  // LDS ring slots; every stage is a whole number of ring revolutions (packer)
+constexpr int NWAVE = 8;
+static_assert(CH == NWAVE, "one 1-KiB A operand per wave and chunk");
+static_assert(NSLOT >= DPF + 2, "a slot is refilled two barriers after its last reader issued its reads");
+
+__device__ __forceinline__ half8 as_half8(const float4& v) { return __builtin_bit_cast(half8, v); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// LDS-DMA of one KiB: lane i's 16 bytes at g_lane  ->  lds_uniform + 16 i.  Inline asm on purpose (fenerf_siren_f16s.hip:
+// with the builtin hipcc drains the DMA queue before every ring read).
+__device__ __forceinline__ void glds_1k(const char* g_lane, unsigned lds_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(g_lane), "s"(lds_uniform)
+      : "memory");
+}
+// saddr form: lane i's 16 bytes at g_uniform + voff  ->  lds_uniform + 16 i  (one VGPR of address instead of two)
+__device__ __forceinline__ void glds_1k_s(const void* g_uniform, unsigned voff, unsigned lds_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(g_uniform), "s"(lds_uniform)
+      : "memory");
+}
+// An opaque copy of a lane-derived value.  LICM hoists lane-only address arithmetic out of the tile loop, where it stays live
+// through every layer (58 such registers at first count) until the allocator spills it INTO the stream loop -- and scratch
+// traffic there would break the counted vmcnt waits.  Deriving addresses from a fresh opaque copy at each use site keeps
+// them local.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+struct WStream {
+  unsigned long long g_next;   // global address of the next chunk to issue (uniform)
+  unsigned voff;               // this lane's byte offset inside a chunk (the re-tiling permutation)
+  unsigned ring_lds;           // LDS byte address of ring slot 0 + wave * 1024 (for M0)
+  const char* ring_lane;       // generic pointer to ring slot 0 + lane * 16 (for the ds_reads)
+};
+
+__device__ __forceinline__ void ws_issue(WStream& w, int slot) {
+  const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
+#ifndef EXP_W_NODMA
+#ifdef EXP_W_HALFDMA
+  if (slot & 1)
+#endif
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(w.voff), "s"(w.g_next), "s"(m0)
+      : "memory");
+#endif
+  w.g_next += CH * 1024;
+}
+
+// A operands of one k32-step (both row tiles): ring slot layout = operand index (spl * 2 + rt) * 2 + hl, 1 KiB each
+struct AK { float4 hi[2], lo[2]; };
+// EXP_W_*: timing-only A/B switches (results numerically wrong on purpose), built by `make exp`
+__device__ __forceinline__ void ws_read_lo(AK& a, const WStream& w, int slot, int spl) {
+#if defined(EXP_W_NOLDSREAD) || defined(EXP_W_HALFLDS)
+  asm volatile("" : "+v"(a.lo[0].x), "+v"(a.lo[1].y));
+#else
+  const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
+  a.lo[0] = p[1 * 64]; a.lo[1] = p[3 * 64];
+#endif
+}
+__device__ __forceinline__ void ws_read_hi(AK& a, const WStream& w, int slot, int spl) {
+#ifdef EXP_W_NOLDSREAD
+  asm volatile("" : "+v"(a.hi[0].x), "+v"(a.hi[1].y));
+#else
+  const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
+  a.hi[0] = p[0 * 64]; a.hi[1] = p[2 * 64];
+#endif
+}
+__device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
+  AK a;
+#if defined(EXP_W_NOLDSREAD) || defined(EXP_W_HALFLDS)
+  a.hi[0] = a.hi[1] = a.lo[0] = a.lo[1] = make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f);
+#endif
+  ws_read_lo(a, w, slot, spl);
+  ws_read_hi(a, w, slot, spl);
+  return a;
+}
+
+// Top of pipeline step i of a stage: issue chunk i + D, make chunk i + 1 visible to every wave.
+__device__ __forceinline__ void ws_step(WStream& w, int i) {
+  ws_issue(w, (i + DPF) % NSLOT);
+#ifdef EXP_W_HALFDMA
+  WAIT_VMCNT(DPF / 2 - 1);
+#else
+  WAIT_VMCNT(DPF - 1);                // this wave's operand of chunk i + 1 has landed (loads retire in order)
+#endif
+#ifndef EXP_W_NOBARRIER
+  __builtin_amdgcn_s_barrier();       // ... and every other wave's
+#endif
+  LDS_FENCE();
+}
+
+// 6 MFMAs of one k32-step, the two row tiles interleaved (dependent MFMAs are 2 apart): wl*xh + wh*xl + wh*xh
+__device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[2], const AK& a, const half8& bh, const half8& bl) {
+#ifdef EXP_W_NOMFMA
+  acc[0][0] += a.lo[0].x + (float)bh[0] + a.hi[0].y + a.lo[1].z + a.hi[1].w + (float)bl[1];
+#else
+  acc[0] = MFMA16W(as_half8(a.lo[0]), bh, acc[0]);
+  acc[1] = MFMA16W(as_half8(a.lo[1]), bh, acc[1]);
+  acc[0] = MFMA16W(as_half8(a.hi[0]), bl, acc[0]);
+  acc[1] = MFMA16W(as_half8(a.hi[1]), bl, acc[1]);
+  acc[0] = MFMA16W(as_half8(a.hi[0]), bh, acc[0]);
+  acc[1] = MFMA16W(as_half8(a.hi[1]), bh, acc[1]);
+#endif
+}
+
+// FiLM epilogue of two values: accumulator registers 2 pc, 2 pc + 1 of row tile rt of n-block nbp -> (hi, lo) halves
+// slots 4 rt + 2 pc + {0, 1} of k32-step nbp of the layer's output.  film_f / film_p already point at this lane group's
+// first feature (16 (g >> 1) + 4 (g & 1)).
+struct FilmQ { float2 f, p; };
+template <int PF4>   // PF4: float offset of p' behind f'' in the FiLM buffer
+__device__ __forceinline__ FilmQ epi_load(int nbp, int piece, const float* film) {
+  const int rt = piece >> 1, pc = piece & 1;
+  FilmQ q;
+  q.f = *reinterpret_cast<const float2*>(film + 32 * nbp + 8 * rt + 2 * pc);
+  q.p = *reinterpret_cast<const float2*>(film + PF4 + 32 * nbp + 8 * rt + 2 * pc);
+  return q;
+}
+template <int KS>
+__device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int piece, const FilmQ& q, half8 (&yh)[KS],
+                                            half8 (&yl)[KS]) {
+  const int rt = piece >> 1, pc = piece & 1;
+  const float2 f = q.f, p = q.p;
+#ifdef EXP_W_NOEPI
+  half2 hp = {(_Float16)(f.x + acc[rt][2 * pc + 0]), (_Float16)p.x}, lp = {(_Float16)(f.y + acc[rt][2 * pc + 1]), (_Float16)p.y};
+#else
+  const float v0 = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x)) * F16_ACT_SCALE;
+  const float v1 = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y)) * F16_ACT_SCALE;
+  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+  half2 hp = {h0, h1}, lp = {(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1)};
+#endif
+  // pinned here: without a use in this block the compiler sinks the whole epilogue behind the stage (the outputs are only
+  // consumed after it), keeping 8 n-blocks of accumulators + FiLM values alive -- and spilling them into the stream loop
+  asm volatile("" : "+v"(hp), "+v"(lp));
+  const int s = 4 * rt + 2 * pc;
+  yh[nbp][s] = hp[0]; yh[nbp][s + 1] = hp[1];
+  yl[nbp][s] = lp[0]; yl[nbp][s + 1] = lp[1];
+}
+template <int KS, int PF4>
+__device__ __forceinline__ void epi_piece(const f32x4 (&acc)[2], int nbp, int piece, const float* film, half8 (&yh)[KS],
+                                          half8 (&yl)[KS]) {
+  epi_compute<KS>(acc, nbp, piece, epi_load<PF4>(nbp, piece, film), yh, yl);
+}
+template <int KS, int PF4>
+__device__ __forceinline__ void epi_all(const f32x4 (&acc)[2], int nbp, const float* film, half8 (&yh)[KS], half8 (&yl)[KS]) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) epi_piece<KS, PF4>(acc, nbp, pc, film, yh, yl);
+}
+
+// Chunk step i of a stage: barrier (chunk i + 1 visible), then the chunk's two k32-steps.  bop(sp, bh, bl) supplies the B
+// operands of k32-step sp (false = padding); piece(spl) is the epilogue work issued behind k32-step spl.  A operands are read
+// from the ring TWO k32-steps (one chunk step) ahead of use, at the top of a k32-step: a.c / a.n hold chunk i's two k32-steps
+// on entry and chunk i + 1's on exit.  (Reads issued one MFMA ahead of use, which is where the compiler sinks them if let,
+// leave the whole LDS latency in front of every k32-step -- in both waves of the SIMD at once, they run in phase.)
+struct APipe { AK c, n; };
+struct FilmQ2 { FilmQ q[4]; };
+template <class BOP, class LOADQ, class PIECE>
+__device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& ws, int i, int sp0, BOP bop, LOADQ loadq, PIECE piece) {
+  ws_step(ws, i);
+#pragma unroll
+  for (int spl = 0; spl < 2; ++spl) {
+    FilmQ2 fq;
+    loadq(spl, fq);                      // FiLM parameters of this k32-step's epilogue piece FIRST: LDS returns in order, a
+                                         // read behind the A operands could only be waited for together with them
+    const AK nn = ws_read(ws, (i + 1) % NSLOT, spl);
+    __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
+    half8 bh, bl;
+    if (bop(sp0 + spl, bh, bl)) kstep_mfma(acc, a.c, bh, bl);
+    piece(spl, fq);
+    a.c = a.n;
+    a.n = nn;
+    __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue piece where they are written
+  }
+}
+// Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's k32-steps.
+__device__ __forceinline__ void chunk_skip(APipe& a, WStream& ws, int i) {
+  ws_step(ws, i);
+  a.c = ws_read(ws, (i + 1) % NSLOT, 0);
+  a.n = ws_read(ws, (i + 1) % NSLOT, 1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// epilogue pieces of the previous n-block handled by chunk qc of a body of QB chunks, k32-step slot spl: 4 pieces over
+// min(QB, 4) chunks x 2 slots
+template <int QB>
+__device__ __forceinline__ void piece_range(int qc, int spl, int& p0, int& p1) {
+  constexpr int QBE = QB < 4 ? QB : 4;
+  if (qc >= QBE) { p0 = p1 = 0; return; }
+  const int c0 = 4 * qc / QBE, c1 = 4 * (qc + 1) / QBE;   // this chunk's pieces
+  const int mid = (c1 - c0 + 1) / 2 + c0;                 // first slot gets the larger half
+  p0 = spl == 0 ? c0 : mid;
+  p1 = spl == 0 ? mid : c1;
+}
+
+template <int H, bool GRID>
+__global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
+  constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
+  constexpr int QB = (KS + 1) / 2;                              // chunks per square n-block body
+  constexpr int C0_KS = KS + (GRID ? 1 : 0) + 1;                // colour layer 0: x | grid | dir
+  constexpr int C0_QB = (2 * (2 * KS + (GRID ? 2 : 0) + 1) + CH - 1) / CH;
+  constexpr int SQ_CHUNKS = pad_stage(NB * QB * CH) / CH;
+  constexpr int C0_CHUNKS = pad_stage(NB * C0_QB * CH) / CH;
+  constexpr int HEAD_CHUNKS = pad_stage(QB * CH) / CH;
+  extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int L = n_geo + n_color;
+  const int stage_f4 = (16 * C + 3) / 4;
+  // LDS: [ring NSLOT x 8 KiB][film: 8 waves x 2 buffers x (f'' | p')][layer-0 weights NB KiB][head consts 72 floats][stage 8 x 16*C]
+  char* lds = reinterpret_cast<char*>(smem);
+  char* ring = lds;
+  constexpr int FILM_F = H * 4 < 1024 ? 1024 : H * 4;   // LDS-DMA moves whole KiBs
+  constexpr int FILM_BYTES = 2 * FILM_F;
+  char* film_base = lds + NSLOT * CH * 1024 + wave * (2 * FILM_BYTES);
+  float* l0_lds = reinterpret_cast<float*>(lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES);
+  float* cst = l0_lds + NB * 256;                       // [0,32) head scale, [32,64) head bias, [64,68) rgb scale, [68,72) rgb bias
+  float* stage = cst + 80 + wave * stage_f4 * 4;
+  // colour layer 0's extra B operands [grid hi | grid lo | dir hi | dir lo], 64 lanes x 16 B each, parked here from the tile
+  // prologue until the layer needs them (11 registers less through the trunk)
+  float4* ext_wave = reinterpret_cast<float4*>(cst + 80 + NWAVE * stage_f4 * 4) + wave * 256;
+
+  // ---- tile-invariant constants -> LDS
+  for (int i = threadIdx.x; i < NB * 256; i += 512) l0_lds[i] = P.stream[i];
+  if (threadIdx.x < 32) {
+    cst[threadIdx.x] = P.consts[CONST_FILM_BIAS + (size_t)2 * L * H + threadIdx.x];
+    cst[32 + threadIdx.x] = P.consts[CONST_HEAD_BIAS + threadIdx.x];
+  } else if (threadIdx.x < 36) {
+    cst[64 + threadIdx.x - 32] = P.consts[CONST_FILM_BIAS + (size_t)2 * L * H + threadIdx.x];
+    cst[68 + threadIdx.x - 32] = P.consts[CONST_RGB_BIAS + threadIdx.x - 32];
+  }
+  WAIT_VMCNT(0);
+  __syncthreads();
+
+  // ---- the DMA's re-tiling permutation (header): this wave fetches operand (spl, rt, hl) = wave bits of every chunk
+  WStream ws;
+  {
+    const int spl = wave >> 2, rt = (wave >> 1) & 1, hl = wave & 1;
+    const int gi = n >> 2, r = n & 3;
+    const int row = 16 * (gi >> 1) + 4 * (gi & 1) + 8 * rt + r;
+    const int e_old = 2 * (2 * spl + (g >> 1)) + hl;
+    ws.voff = e_old * 1024 + ((g & 1) * 32 + row) * 16;
+  }
+  const unsigned long long g_stream = reinterpret_cast<unsigned long long>(P.stream + P.ring_offset_floats);
+  ws.g_next = g_stream;
+  ws.ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 1024);
+  ws.ring_lane = ring + lane * 16;
+
+  // ---- prime the shared stream: chunks 0..D-1 in flight, first k32-step of chunk 0 in registers
+#pragma unroll
+  for (int i = 0; i < DPF; ++i) ws_issue(ws, i);
+  WAIT_VMCNT(DPF - 1);
+  __builtin_amdgcn_s_barrier();
+  LDS_FENCE();
+  APipe a_cur;
+  a_cur.c = ws_read(ws, 0, 0);
+  a_cur.n = ws_read(ws, 0, 1);
+
+  // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
+  const long long ntiles = (P.P + 15) / 16;
+  const long long nocts = (ntiles + NWAVE - 1) / NWAVE;
+  const int nblk = gridDim.x;
+  const int nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx;
+  const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
+  const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
+
+  for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
+    // the previous tile ended by issuing the replicated head chunks nchunk..nchunk+D-1 (== this tile's chunks 0..D-1)
+    ws.g_next = g_stream + (unsigned long long)DPF * (CH * 1024);
+    const long long tile = oct * NWAVE + wave;
+    // ---------------- this lane's point ----------------
+    long long pt = tile * 16 + n;
+    if (pt >= P.P) pt = P.P - 1;
+    const long long img = __builtin_amdgcn_readfirstlane((int)(pt / P.pts_per_image));   // tiles do not straddle images (launcher)
+    float px, py, pz, dx, dy, dz;
+    if (P.points) {
+      px = P.points[pt * 3 + 0]; py = P.points[pt * 3 + 1]; pz = P.points[pt * 3 + 2];
+      if (P.pdirs) { dx = P.pdirs[pt * 3 + 0]; dy = P.pdirs[pt * 3 + 1]; dz = P.pdirs[pt * 3 + 2]; }
+      else { dx = 0.f; dy = 0.f; dz = -1.f; }
+    } else {
+      const long long ray = pt / P.n_per_ray;
+      const float zz = P.z[pt];
+      const float ox = P.origins[ray * 3 + 0], oy = P.origins[ray * 3 + 1], oz = P.origins[ray * 3 + 2];
+      dx = P.dirs[ray * 3 + 0]; dy = P.dirs[ray * 3 + 1]; dz = P.dirs[ray * 3 + 2];
+      px = __fadd_rn(ox, __fmul_rn(dx, zz)); py = __fadd_rn(oy, __fmul_rn(dy, zz)); pz = __fadd_rn(oz, __fmul_rn(dz, zz));
+      if (P.lock_view) { dx = 0.f; dy = 0.f; dz = -1.f; }
+    }
+    const float qx = px * P.box_scale, qy = py * P.box_scale, qz = pz * P.box_scale;
+
+    // ---------------- FiLM parameters of layers 0 and 1 -> LDS (DMA), grid gather, then one drain ----------------
+    const float* fp_img = P.fp + (size_t)img * L * H;
+    const float* pp_img = P.pp + (size_t)img * L * H;
+    auto film_issue = [&](int layer) {   // f'' (H floats) then p' (H floats) of `layer` into buffer layer & 1
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(film_base) + (layer & 1) * FILM_BYTES);
+      const float* gf = fp_img + (size_t)layer * H;
+      const float* gp = pp_img + (size_t)layer * H;
+      const unsigned vo = (unsigned)opaque(lane) * 16;
+      for (int off = 0; off < H * 4; off += 1024) {   // H=256: one KiB each; smaller H: lanes beyond H/4 read in-bounds pad
+        glds_1k_s(reinterpret_cast<const char*>(gf) + off, vo, dst + off);
+        glds_1k_s(reinterpret_cast<const char*>(gp) + off, vo, dst + FILM_F + off);
+      }
+    };
+    film_issue(0);
+    if (L > 1) film_issue(1);
+
+    // grid features: lane (n, g) blends channels 16 (g & 1) + 8 (g >> 1) .. + 7 of its point's 8 corners (the k slots the
+    // packer gave lane group g in the grid k32-step)
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = 0.f;
+    if (GRID) {
+      const int ch0 = 16 * (g & 1) + 8 * (g >> 1);
+      const float ix = ((qx + 1.f) / 2.f) * (float)(P.gw - 1);
+      const float iy = ((qy + 1.f) / 2.f) * (float)(P.gh - 1);
+      const float iz = ((qz + 1.f) / 2.f) * (float)(P.gd - 1);
+      const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int cz = c >> 2, cy = (c >> 1) & 1, cx = c & 1;
+        const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
+        const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
+        const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
+        const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
+        const float wgt = wx * wy * wz;
+        const bool ok = xi >= 0.f && xi <= (float)(P.gw - 1) && yi >= 0.f && yi <= (float)(P.gh - 1) && zi >= 0.f &&
+                        zi <= (float)(P.gd - 1);
+        if (ok) {
+          const long long vox = ((long long)(int)zi * P.gh + (int)yi) * P.gw + (int)xi;
+          const float4* gp = reinterpret_cast<const float4*>(P.grid + vox * 32 + ch0);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float4 v = gp[q];
+            e[4 * q + 0] += v.x * wgt; e[4 * q + 1] += v.y * wgt; e[4 * q + 2] += v.z * wgt; e[4 * q + 3] += v.w * wgt;
+          }
+        }
+      }
+    }
+    {
+      half8 eh, el, dh, dl;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = e[t] * F16_ACT_SCALE;
+        const _Float16 hh = (_Float16)v;
+        eh[t] = hh; el[t] = (_Float16)(v - (float)hh);
+      }
+      // the dir k16-step is lane group 0's (slots 0..2); groups 1-3 multiply zero padding
+      const float d3[3] = {dx * F16_ACT_SCALE, dy * F16_ACT_SCALE, dz * F16_ACT_SCALE};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { dh[t] = (_Float16)0.f; dl[t] = (_Float16)0.f; }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float v = g == 0 ? d3[t] : 0.f;
+        const _Float16 hh = (_Float16)v;
+        dh[t] = hh; dl[t] = (_Float16)(v - (float)hh);
+      }
+      float4* ext = ext_wave + lane;
+      ext[0] = __builtin_bit_cast(float4, eh); ext[64] = __builtin_bit_cast(float4, el);
+      ext[128] = __builtin_bit_cast(float4, dh); ext[192] = __builtin_bit_cast(float4, dl);
+    }
+    WAIT_VMCNT(0);      // film 0/1 landed (own buffer, own reads: no barrier needed), point / grid loads done; once per tile
+    LDS_FENCE();
+
+    // f'' of FiLM layer `layer` at this lane group's first feature (p' follows FILM_F bytes behind); derived on the spot
+    auto film_lane = [&](int layer) -> const float* {
+      const int gq = opaque(lane) >> 4;
+      return reinterpret_cast<const float*>(film_base + (layer & 1) * FILM_BYTES) + 16 * (gq >> 1) + 4 * (gq & 1);
+    };
+
+    half8 xh[KS], xl[KS];
+    // ---------------- layer 0: 3 -> H on the exact fp32 MFMA (16x16x4: k = x, y, z, 0) ----------------
+    {
+      const float b = g == 0 ? qx : (g == 1 ? qy : (g == 2 ? qz : 0.f));
+      const int gi = n >> 2, r = n & 3;
+      const float* wl = l0_lds + ((g & 1) * 32 + 16 * (gi >> 1) + 4 * (gi & 1) + r) * 4 + (g >> 1);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 acc[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          acc[rt] = MFMA32W(wl[nb * 256 + 8 * rt * 4], b, z4);
+        }
+        epi_all<KS, FILM_F / 4>(acc, nb, film_lane(0), xh, xl);
+      }
+    }
+    // ---------------- FiLM layers 1 .. L-1 ----------------
+#pragma unroll 1
+    for (int l = 1; l < L; ++l) {
+      const float* ff = film_lane(l);
+      half8 yh[KS], yl[KS];
+      if (l + 1 < L) film_issue(l + 1);
+      if (SQ_CHUNKS < DPF + 2) WAIT_VMCNT(0);
+      if (l == n_geo) {
+        // ---------------- colour layer 0: [x | grid feats | dir] -> H, then the label/sigma head on the same x -------
+        const float4* ext = ext_wave + opaque(lane);
+        auto bop0 = [&](int sp, half8& bh, half8& bl) -> bool {
+          if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
+          if (GRID && sp == KS) { bh = as_half8(ext[0]); bl = as_half8(ext[64]); return true; }
+          if (sp == C0_KS - 1) { bh = as_half8(ext[128]); bl = as_half8(ext[192]); return true; }
+          return false;
+        };
+        f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int qc = 0; qc < C0_QB; ++qc) {
+            chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](int spl, FilmQ2& fq) {
+              if (nb > 0) {
+                int p0, p1;
+                piece_range<C0_QB>(qc, spl, p0, p1);
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                  if (pc >= p0 && pc < p1) fq.q[pc] = epi_load<FILM_F / 4>(nb - 1, pc, ff);
+              }
+            }, [&](int spl, const FilmQ2& fq) {
+              if (nb > 0) {
+                int p0, p1;
+                piece_range<C0_QB>(qc, spl, p0, p1);
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                  if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
+              }
+            });
+          }
+          acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
+        }
+#pragma unroll
+        for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+        epi_all<KS, FILM_F / 4>(acc_prev, NB - 1, ff, yh, yl);
+        // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
+        {
+          f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          auto bop = [&](int sp, half8& bh, half8& bl) -> bool {
+            if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
+            return false;
+          };
+#pragma unroll
+          for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](int, FilmQ2&) {}, [](int, const FilmQ2&) {});
+#pragma unroll
+          for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+          const int lane_o = opaque(lane);
+          const int n_o = lane_o & 15, f_o = 16 * (lane_o >> 5) + 4 * ((lane_o >> 4) & 1);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = f_o + 8 * rt + r;
+              if (row <= n_lab) {
+                const int ch = row < n_lab ? row : C - 1;
+                stage[n_o * C + ch] = acc[rt][r] * cst[row] + cst[32 + row];
+              }
+            }
+          }
+        }
+      } else {
+        auto bop = [&](int sp, half8& bh, half8& bl) -> bool {
+          if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
+          return false;
+        };
+        f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int qc = 0; qc < QB; ++qc) {
+            chunk_step(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](int spl, FilmQ2& fq) {
+              if (nb > 0) {
+                int p0, p1;
+                piece_range<QB>(qc, spl, p0, p1);
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                  if (pc >= p0 && pc < p1) fq.q[pc] = epi_load<FILM_F / 4>(nb - 1, pc, ff);
+              }
+            }, [&](int spl, const FilmQ2& fq) {
+              if (nb > 0) {
+                int p0, p1;
+                piece_range<QB>(qc, spl, p0, p1);
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                  if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
+              }
+            });
+          }
+          acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
+        }
+#pragma unroll
+        for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+        epi_all<KS, FILM_F / 4>(acc_prev, NB - 1, ff, yh, yl);
+      }
+#pragma unroll
+      for (int k = 0; k < KS; ++k) { xh[k] = yh[k]; xl[k] = yl[k]; }
+    }
+    // ---------------- rgb head + sigmoid (rows 0..2 = row tile 0, lane group 0) ----------------
+    {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      auto bop = [&](int sp, half8& bh, half8& bl) -> bool {
+        if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
+        return false;
+      };
+#pragma unroll
+      for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](int, FilmQ2&) {}, [](int, const FilmQ2&) {});
+#pragma unroll
+      for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+      const int lane_o = opaque(lane);
+      const int n_o = lane_o & 15;
+      if ((lane_o >> 4) == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float v = acc[0][r] * cst[64 + r] + cst[68 + r];
+          stage[n_o * C + (C - 4) + r] = 1.f / (1.f + __expf(-v));
+        }
+      }
+    }
+    // ---------------- coalesced write-out of the tile's [16][C] block ----------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const long long base = tile * 16 * C;
+      const long long limit = P.P * C;
+      for (int i = opaque(lane); i < 16 * C; i += 64)
+        if (base + i < limit) P.out[base + i] = stage[i];
+    }
+    WAIT_VMCNT(0);   // stores may retire out of order with the DMA loads: keep them out of the counted waits
+    __builtin_amdgcn_wave_barrier();
+  }
+  WAIT_VMCNT(0);     // no LDS-DMA may land after the workgroup has released its LDS
+  __builtin_amdgcn_s_barrier();
+}
+
+static int hip_fail16w(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+template <int H, bool GRID>
+static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
+  const int stage_f4 = (16 * m->C + 3) / 4;
+  const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
+  const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)(H / 32) * 1024 + 80 * 4 +
+                     (size_t)NWAVE * stage_f4 * 16 + (size_t)NWAVE * 4096;   // ring + FiLM buffers + layer-0 weights + head consts +
+                                                                               // output staging + colour-layer-0 operands
+  auto kfn = siren16w_kernel<H, GRID>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
+  const long long ntiles = (p.P + 15) / 16;
+  long long blocks = (ntiles + NWAVE - 1) / NWAVE;
+  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "siren16w launch");
+}
+
+}  // namespace w16
+
+// One launch over points whose tiles do not straddle images (launch_siren16s splits per image otherwise).
+int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream) {
+  const bool g = m->grid_ch != 0;
+  switch (m->H) {
+    case 32: return g ? w16::launch_t<32, true>(m, q, stream) : w16::launch_t<32, false>(m, q, stream);
+    case 64: return g ? w16::launch_t<64, true>(m, q, stream) : w16::launch_t<64, false>(m, q, stream);
+    case 128: return g ? w16::launch_t<128, true>(m, q, stream) : w16::launch_t<128, false>(m, q, stream);
+    case 256: return g ? w16::launch_t<256, true>(m, q, stream) : w16::launch_t<256, false>(m, q, stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+}  // namespace fenerf

@@ -590,12 +590,7 @@ template <int H, int JOB>
 int launch_job(const WgradParams& p, int nz, hipStream_t st) {
   auto kfn = siren_wgrad_kernel<H, JOB>;
   const size_t lds = wg_lds_bytes<H, JOB>();
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(wgrad LDS)");
-    configured = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad launch");
@@ -605,12 +600,7 @@ template <int H>
 int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   auto kfn = siren_wgrad_sq_bf16_kernel<H>;
   const size_t lds = (size_t)(4 * H * WG_LD + 2 * H) * sizeof(float);     // two [A | B] images + FiLM rows
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hipfail(e, "hipFuncSetAttribute(wgrad bf16 LDS)");
-    configured = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16 launch");

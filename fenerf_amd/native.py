@@ -174,16 +174,20 @@ class NativeModel:
         n_lab = sp["output_dim"] - 4
         dev = self.device
         p = {k: v.detach().to(dev, torch.float32) for k, v in params.items()}
-        if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
-            nl = sp["n_label_layers"]
-            c = p["label_layer_linear.0.bias"]
-            for i in range(1, nl):
-                c = p[f"label_layer_linear.{i}.weight"] @ c + p[f"label_layer_linear.{i}.bias"]
-            A = p[f"label_layer_linear.{nl - 1}.weight"]          # from the output side: n_lab-row products, not H x H x H
-            for i in range(nl - 2, -1, -1):
-                A = A @ p[f"label_layer_linear.{i}.weight"]
-            p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
-        flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
+        # autocast off: the reference's D-step / eval renders run under torch.cuda.amp.autocast (train_double_latent_semantic.py:
+        # 279-290, 466-512); an fp16 fold of ~0.006-magnitude label weights lands in the subnormal range and would differ from
+        # the fold the differentiable path does with autocast off (custom_fwd)
+        with torch.autocast(dev.type, enabled=False):
+            if n_lab > 0:       # fold the activation-free label head (siren.py:1490-1494) on the device
+                nl = sp["n_label_layers"]
+                c = p["label_layer_linear.0.bias"]
+                for i in range(1, nl):
+                    c = p[f"label_layer_linear.{i}.weight"] @ c + p[f"label_layer_linear.{i}.bias"]
+                A = p[f"label_layer_linear.{nl - 1}.weight"]          # from the output side: n_lab-row products, not H x H x H
+                for i in range(nl - 2, -1, -1):
+                    A = A @ p[f"label_layer_linear.{i}.weight"]
+                p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
+            flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
         return p, flat
 
     def load_from_device(self, params):
@@ -433,6 +437,14 @@ class NativeModel:
                                                _ptr(weights), _ptr(wsum), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
                                                _stream()))
         return rgb, depth, weights, wsum
+
+
+def forward_kernel_name(nat):
+    """Name of the no-grad forward SIREN kernel a NativeModel launches (bench / profile labels; fenerf_siren*.hip)."""
+    H, g = nat.spec["hidden_dim"], "true" if nat.spec["grid_ch"] else "false"
+    if nat.precision == "f32":
+        return f"siren_kernel<{H},{g},false>"
+    return f"siren16w_kernel<{H},{g}>"
 
 
 # ----------------------------------------------------------------------

@@ -78,8 +78,8 @@ typedef struct FenerfModelDesc {
   const float* grid;        /* [host] spatial_embeddings or NULL */
   int32_t precision;        /* FENERF_PREC_F32 (exact fp32 MFMA) or FENERF_PREC_F16X3 (error-compensated fp16 MFMA,
                                3 MFMAs per product, fp32-class accuracy, ~2^-22 relative per product) */
-  int32_t differentiable;   /* != 0: also keep the backward-chain weight stream resident (fenerf_siren_backward);
-                               requires FENERF_PREC_F32 */
+  int32_t differentiable;   /* != 0: also keep the backward-chain weight stream resident (fenerf_siren_backward); either
+                               precision: FENERF_PREC_F32 -> exact fp32 MFMA chain, FENERF_PREC_F16X3 -> bf16x3 chain */
 } FenerfModelDesc;
 
 typedef struct FenerfModel FenerfModel;
