@@ -208,6 +208,8 @@ def main(argv=None):
 
     spec = proc.model_spec("texture", hidden_dim=256, grid_size=96)
     sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
+    if os.environ.get("FENERF_BENCH_ZERO_WEIGHTS"):    # DVFS probe only (data-dependent power): same instruction stream, all-zero operands
+        sd = {k: np.zeros_like(v) for k, v in sd.items()}
     opts = _lib.composite_opts("relu", 0.0, fill_mode="seg_padding_background", fill_color="black")
 
     def barrier():

@@ -31,6 +31,14 @@ class TorchDraws:
     def randperm(self, n, device):
         return torch.randperm(n, device=device)
 
+    def normal_candidates(self, shape, device):
+        """truncated_normal_'s candidate block: an uninitialised tensor filled in place, like the reference (:172)"""
+        return torch.empty(shape, device=device).normal_()
+
+    def coin(self):
+        """the host-RNG coin of the 'hybrid' camera mode (random.random(), :196)"""
+        return random.random()
+
 
 class RecordedDraws:
     """Replays a list of recorded arrays (tests): each call pops the next one and checks its shape."""
@@ -52,6 +60,10 @@ class RecordedDraws:
 
     rand = _next
     randn = _next
+    normal_candidates = _next
+
+    def coin(self):
+        return float(np.asarray(self.arrays.pop(0)).reshape(()))
 
 
 _DEFAULT_DRAWS = TorchDraws()
@@ -86,9 +98,9 @@ def perturb_points(points, z_vals, ray_directions, device, draws=_DEFAULT_DRAWS)
     return points + shift * ray_directions.unsqueeze(2), z_vals + shift
 
 
-def truncated_normal_(tensor, mean=0, std=1):
+def truncated_normal_(tensor, mean=0, std=1, draws=_DEFAULT_DRAWS):
     """In place: N(mean, std) truncated to +-2 std by taking the first of 4 candidate draws that falls inside (:170-177)."""
-    cand = tensor.new_empty(tuple(tensor.shape) + (4,)).normal_()
+    cand = draws.normal_candidates(tuple(tensor.shape) + (4,), tensor.device)
     first_ok = ((cand < 2) & (cand > -2)).max(-1, keepdim=True)[1]
     tensor.data.copy_(cand.gather(-1, first_ok).squeeze(-1))
     tensor.data.mul_(std).add_(mean)
@@ -104,15 +116,15 @@ def sample_camera_angles(device, n, horizontal_stddev, vertical_stddev, horizont
         theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
         phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
     elif mode == "hybrid":
-        if random.random() < 0.5:
+        if draws.coin() < 0.5:
             theta = (draws.rand((n, 1), device) - 0.5) * 2 * horizontal_stddev * 2 + horizontal_mean
             phi = (draws.rand((n, 1), device) - 0.5) * 2 * vertical_stddev * 2 + vertical_mean
         else:
             theta = draws.randn((n, 1), device) * horizontal_stddev + horizontal_mean
             phi = draws.randn((n, 1), device) * vertical_stddev + vertical_mean
     elif mode == "truncated_gaussian":
-        theta = truncated_normal_(torch.zeros((n, 1), device=device)) * horizontal_stddev + horizontal_mean
-        phi = truncated_normal_(torch.zeros((n, 1), device=device)) * vertical_stddev + vertical_mean
+        theta = truncated_normal_(torch.zeros((n, 1), device=device), draws=draws) * horizontal_stddev + horizontal_mean
+        phi = truncated_normal_(torch.zeros((n, 1), device=device), draws=draws) * vertical_stddev + vertical_mean
     elif mode == "spherical_uniform":
         theta = (draws.rand((n, 1), device) - .5) * 2 * horizontal_stddev + horizontal_mean
         v_stddev, v_mean = vertical_stddev / math.pi, vertical_mean / math.pi

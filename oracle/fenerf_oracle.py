@@ -72,16 +72,31 @@ def perturb_points(points, z_vals, ray_directions, u_jitter):
 # ---------------------------------------------------------------------------
 # a3  sample_camera_positions           volumetric_rendering.py:179-228
 # ---------------------------------------------------------------------------
-def camera_angles(mode, n, h_stddev, v_stddev, h_mean, v_mean, r_theta=None, r_phi=None, dtype=np.float32):
+def camera_angles(mode, n, h_stddev, v_stddev, h_mean, v_mean, r_theta=None, r_phi=None, dtype=np.float32, coin=None):
     """Turns the reference's raw random draws into (theta, phi) *before* the phi clamp.
     r_theta / r_phi are the [n,1] draws the reference makes, in that order:
       'uniform'            : torch.rand            (:188-190)
       'normal'/'gaussian'  : torch.randn           (:192-194)
       'spherical_uniform'  : torch.rand            (:208-213)
       anything else        : no draw (mean pose)   (:215-218)
-    ('hybrid' and 'truncated_gaussian' consume python-random / rejection draws; host code
-    resolves them to theta/phi directly and the renderer takes angles as inputs.)"""
-    if mode == "uniform":
+      'hybrid'             : coin = random.random() first; < 0.5 -> torch.rand x2 at twice the spread, else randn x2 (:195-201)
+      'truncated_gaussian' : r_theta / r_phi are the [n,1,4] candidate blocks `new_empty(...).normal_()` of truncated_normal_
+                             (:170-177): the first candidate strictly inside (-2, 2), candidate 0 if none is (:203-205)"""
+    if mode == "hybrid":
+        if coin < 0.5:
+            theta = (r_theta - 0.5) * 2 * h_stddev * 2 + h_mean
+            phi = (r_phi - 0.5) * 2 * v_stddev * 2 + v_mean
+        else:
+            theta = r_theta * h_stddev + h_mean
+            phi = r_phi * v_stddev + v_mean
+    elif mode == "truncated_gaussian":
+        def first_inside(c):
+            ok = (c < 2) & (c > -2)
+            idx = ok.argmax(-1)                      # first True; 0 when none (torch .max(-1)[1] on a bool tensor, same rule)
+            return np.take_along_axis(c, idx[..., None], -1)[..., 0]
+        theta = first_inside(r_theta) * h_stddev + h_mean
+        phi = first_inside(r_phi) * v_stddev + v_mean
+    elif mode == "uniform":
         theta = (r_theta - 0.5) * 2 * h_stddev + h_mean
         phi = (r_phi - 0.5) * 2 * v_stddev + v_mean
     elif mode in ("normal", "gaussian"):

@@ -268,16 +268,22 @@ def _make_generator(g, spec, precision="f32"):
     return gen
 
 
-def _e2e_check(tag, px, ref_px, tol=1e-3, max_bad_frac=0.03):
+def _e2e_check(tag, px, ref_px, tol=1e-3, max_flips=0):
+    """north_star's bar, asserted as measured: |RGB / label error| <= tol on every pixel except `max_flips` named threshold flips
+    (0 for every committed fixture -- none shows one), and the label argmax (mask2color, train_double_latent_semantic.py:66-72)
+    identical on every non-flipped pixel that the reference itself decides (near-ties included; only exact reference ties, a
+    margin of a few fp32 ulps between its two best logits, are exempt and counted)."""
     err = np.abs(px - ref_px).max(axis=1)
     bad = err > tol
-    print(f"[parity] {tag}: max|err| over agreeing pixels {err[~bad].max():.3e}; {int(bad.sum())}/{bad.size} pixels differ by "
-          f"more than {tol} (fill-threshold / resampling flips), worst {err.max():.3e}")
-    assert bad.mean() <= max_bad_frac
-    top2 = np.sort(ref_px[:, :-3], axis=1)
-    decided = (top2[:, -1] - top2[:, -2]) > 10 * tol
     am, am_ref = px[:, :-3].argmax(1), ref_px[:, :-3].argmax(1)
-    assert (am == am_ref)[~bad & decided].all(), "exact argmax semantics"
+    top2 = np.sort(ref_px[:, :-3], axis=1)
+    tie = (top2[:, -1] - top2[:, -2]) <= 1e-6
+    mism = (am != am_ref) & ~bad
+    print(f"[parity] {tag}: max|err| {err[~bad].max():.3e} on {int((~bad).sum())}/{bad.size} pixels; {int(bad.sum())} pixels differ by "
+          f"more than {tol} (fill-threshold / resampling flips; allowed {max_flips}); label argmax mismatches on the other pixels: "
+          f"{int(mism.sum())} (reference ties: {int(tie.sum())})")
+    assert int(bad.sum()) <= max_flips, f"{int(bad.sum())} pixels off by more than {tol}, worst {err.max():.3e}"
+    assert not (mism & ~tie).any(), "exact argmax semantics on every pixel the reference itself decides"
     return bad
 
 
@@ -321,7 +327,7 @@ def test_staged_forward_with_frequencies_vs_reference(name):
                                                            v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5,
                                                            hierarchical_sample=True, sample_dist="gaussian", max_batch_size=1000, **kw)
     assert not px.is_cuda and px.shape == g["pixels"].shape and third.shape == g["third"].shape
-    bad = _e2e_check(name, N_(px), g["pixels"], max_bad_frac=0.06)
+    bad = _e2e_check(name, N_(px), g["pixels"])
     np.testing.assert_allclose(N_(depth)[~bad], g["depth"][~bad], atol=1e-4)
     terr = np.abs(N_(third) - g["third"]).max(axis=1)
     assert (terr[~bad] < 2e-3).all()
@@ -343,7 +349,7 @@ def test_forward_and_staged_forward_from_latents():
     with torch.no_grad():
         px, poses = gen(zg, za, **kw)
     np.testing.assert_allclose(N_(poses), g["fwd_poses"], atol=1e-6)
-    _e2e_check("forward(z)", N_(px), g["fwd_pixels"], max_bad_frac=0.06)
+    _e2e_check("forward(z)", N_(px), g["fwd_pixels"])
     # staged_forward: first two draws are the 10000-z avg pass; replace its result by the reference's recorded means
     rd = {k[len("stg_rand_"):]: v for k, v in g.items() if k.startswith("stg_rand_")}
     gen.draws = VR.RecordedDraws([np.zeros((10000, 16), np.float32)] * 2 +
@@ -358,7 +364,7 @@ def test_forward_and_staged_forward_from_latents():
     px, depth = gen.staged_forward(zg, za, psi=float(g["stg_psi"]), max_batch_size=97, fill_mode="seg_padding_background",
                                    fill_color="white", **kw)
     assert px.shape == g["stg_pixels"].shape and not px.is_cuda
-    bad = _e2e_check("staged_forward(z, psi=0.7)", N_(px), g["stg_pixels"], max_bad_frac=0.06)
+    bad = _e2e_check("staged_forward(z, psi=0.7)", N_(px), g["stg_pixels"])
     np.testing.assert_allclose(N_(depth)[~bad], g["stg_depth"][~bad], atol=1e-4)
 
 
@@ -484,6 +490,131 @@ def test_config5_256_48p48_and_config1_64_12():
         bad = err > 1e-3
         print(f"[parity] {S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
         assert bad.mean() <= 0.04
+
+
+def _curriculum_generator(precision="f16x3"):
+    """The generator BASELINE.json names (curriculum CelebA_double_semantic_texture_embedding_256_dim_96: H=256 + 32x96^3 grid,
+    two 256-d latents), random init like the reference's `generator = getattr(generators, ...)(...)` (train...py:150-160)."""
+    from fenerf_amd import curriculums
+    cur = curriculums.CelebA_double_semantic_texture_embedding_256_dim_96
+    torch.manual_seed(11)
+    gen = G.DoubleImplicitGenerator3d(getattr(S, cur["model"]), 256, 256, 22).to(DEV)
+    gen.set_device(torch.device(DEV))
+    gen.siren.precision = precision
+    return gen, cur, curriculums
+
+
+def test_one_model_handle_from_two_threads_and_streams():
+    """include/fenerf.h: "a FenerfModel is immutable after create/update and may be used from several threads/streams".  Two
+    host threads, each on its own HIP stream with its own workspaces, call siren_forward / render on the SAME FenerfModel
+    concurrently; every result must equal the single-threaded one bit for bit (the per-device dynamic-LDS opt-in is taken
+    under a lock, fenerf::ensure_dynamic_lds)."""
+    import threading
+    spec = proc.model_spec("texture", hidden_dim=64, grid_size=6, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=4, sigma_gain=50.0, with_mapping=False)
+    film = proc.film_params(spec, 1, seed=4)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    S_, N = 24, 10
+    torch.manual_seed(1)
+    o, d, z, _, _ = VR.sample_rays(1, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((S_ * S_, N), device=DEV)
+    opts = _lib.composite_opts("relu")
+    for precision in PRECISIONS:
+        nat = native.NativeModel(sd, spec, DEV, precision)        # fresh handle: the threads race for the first launch
+        results, errors = {}, []
+
+        def worker(tid):
+            try:
+                view = native.NativeModel.__new__(native.NativeModel)      # same FenerfModel*, private workspaces
+                view.__dict__.update(nat.__dict__)
+                view._ws = {}
+                st = torch.cuda.Stream(device=DEV)
+                outs = []
+                with torch.cuda.stream(st):
+                    for _ in range(6):
+                        outs.append(view.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)[0])
+                st.synchronize()
+                results[tid] = outs
+                view._h = None                                              # the handle belongs to `nat`
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+
+        torch.cuda.synchronize()
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        ref = nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)[0]
+        torch.cuda.synchronize()
+        for tid in (0, 1):
+            assert all(torch.equal(r, ref) for r in results[tid]), (precision, tid)
+
+
+def test_staged_forward_generator_call_at_configs4_256_48p48():
+    """BASELINE.json configs[4] through the public method (generators.py:546-646), not only nat.render: 256x256 rays, 48+48
+    samples, psi 0.7, the whole image as one fused render (max_batch_size ignored by design)."""
+    gen, cur, curriculums = _curriculum_generator()
+    gen.eval()
+    md = {**curriculums.extract_metadata(cur, 60000), "nerf_noise": 0, "psi": 0.7, "img_size": 256, "num_steps": 48,
+          "max_batch_size": 2400000, "lock_view_dependence": True, "h_stddev": 0, "v_stddev": 0}
+    zg, za = torch.randn(1, 256, device=DEV), torch.randn(1, 256, device=DEV)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        torch.cuda.reset_peak_memory_stats()
+        with torch.no_grad():
+            outs.append(gen.staged_forward(zg, za, **md))
+    (px, depth), (px2, depth2) = outs
+    assert tuple(px.shape) == (1, 22, 256, 256) and tuple(depth.shape) == (1, 256, 256) and not px.is_cuda
+    assert torch.equal(px, px2) and torch.equal(depth, depth2), "same seed, same image (bit-exact)"
+    px, depth = px.numpy(), depth.numpy()
+    assert np.isfinite(px).all() and np.isfinite(depth).all()
+    assert (px >= -1 - 1e-5).all() and (px[:, -3:] <= 1 + 1e-5).all()           # '*2-1' epilogue; rgb in [-1, 1]
+    assert ((depth >= 0) & (depth <= 1.12 * 1.001 + 0.02)).all()
+    filled = px[:, 0] == 1.0                                                     # seg_padding_background: channel 0 = 2*1-1
+    print(f"[parity] staged_forward 256x256 48+48 through the generator call: {int(filled.sum())} background pixels, "
+          f"peak {torch.cuda.max_memory_allocated() / 2**30:.2f} GB")
+    # the second public inference method on the same latents: staged_forward_with_frequencies fed with the truncated FiLM
+    # parameters staged_forward builds (generators.py:558-564) consumes the same six draws and must give the same image
+    torch.manual_seed(5)
+    gen.generate_avg_frequencies()                      # the two randn(10000, z) draws staged_forward makes first
+    with torch.no_grad():
+        rfg, rpg = gen.siren.geo_mapping_network(zg)
+        rfa, rpa = gen.siren.app_mapping_network(za)
+    trunc = lambda avg, raw: avg + 0.7 * (raw - avg)
+    px3, depth3, third = gen.staged_forward_with_frequencies(
+        trunc(gen.avg_frequencies_geo, rfg), trunc(gen.avg_frequencies_app, rfa), trunc(gen.avg_phase_shifts_geo, rpg),
+        trunc(gen.avg_phase_shifts_app, rpa), **md)
+    assert torch.equal(px3, outs[0][0]) and torch.equal(depth3, outs[0][1])
+    assert tuple(third.shape) == (1, 96, 256, 256)      # seg_padding_background: per-sample weights (SURVEY A.7.v)
+
+
+def test_generator_step_at_configs2_shape_B6_128_24p24():
+    """BASELINE.json configs[2]: the reference's G-step micro-batch (batch 24 / batch_split 4 = 6 images, 128x128, 24+24,
+    train_double_latent_semantic.py:402-446) through forward(z) + backward on the native differentiable path: finite gradients on
+    every generator parameter, peak memory reported."""
+    gen, cur, curriculums = _curriculum_generator()
+    gen.train()
+    md = {**curriculums.extract_metadata(cur, 60000), "img_size": 128, "num_steps": 24}
+    B = 6
+    zg, za = torch.randn(B, 256, device=DEV), torch.randn(B, 256, device=DEV)
+    torch.cuda.reset_peak_memory_stats()
+    px, poses = gen(zg, za, **md)
+    assert tuple(px.shape) == (B, 21, 128, 128) and tuple(poses.shape) == (B, 2)
+    w = torch.randn_like(px)
+    (px * w).mean().backward()
+    torch.cuda.synchronize()
+    n, worst = 0, 0.0
+    for name, p in gen.named_parameters():
+        assert p.grad is not None, name
+        assert torch.isfinite(p.grad).all(), name
+        n += 1
+        worst = max(worst, float(p.grad.abs().max()))
+    assert worst > 0
+    print(f"[parity] G-step at configs[2] micro-batch (6 x 128x128 x 24+24 = {B * 128 * 128 * 48} points): {n} parameter gradients "
+          f"finite, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB")
 
 
 # ---------------------------------------------------------------------------------------------------

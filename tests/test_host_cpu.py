@@ -45,6 +45,38 @@ def test_rays_camera_host_functions():
         np.testing.assert_allclose(phi.numpy(), g[f"m{i}_phi"], atol=1e-7)
         c2w = VR.create_cam2world_matrix(VR.normalize_vecs(-o), o, device="cpu")
         np.testing.assert_allclose(c2w.numpy(), g[f"m{i}_cam2world"], atol=1e-7)
+    # 'hybrid' (both branches of the coin) and 'truncated_gaussian', teacher-forced through `draws` like every other mode
+    seen = set()
+    for k in range(int(g["n_extra_modes"])):
+        mode = str(g[f"x{k}_mode"])
+        recorded = [g[f"x{k}_draw{j}"] for j in range(int(g[f"x{k}_n_draws"]))]
+        draws = VR.RecordedDraws(recorded)
+        o, phi, theta = VR.sample_camera_positions("cpu", n=5, r=1, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                   horizontal_mean=np.pi * 0.5, vertical_mean=np.pi * 0.5, mode=mode, draws=draws)
+        assert not draws.arrays, "every recorded draw consumed, in order"
+        np.testing.assert_allclose(o.numpy(), g[f"x{k}_origin"], atol=1e-7)
+        np.testing.assert_allclose(phi.numpy(), g[f"x{k}_phi"], atol=1e-7)
+        np.testing.assert_allclose(theta.numpy(), g[f"x{k}_theta"], atol=1e-7)
+        seen.add((mode, bool(recorded[0] < 0.5)) if mode == "hybrid" else (mode, None))
+    assert {("hybrid", True), ("hybrid", False), ("truncated_gaussian", None)} <= seen
+
+
+def test_default_draws_consume_the_generators_like_the_reference_modes():
+    """hybrid / truncated_gaussian with the default (non-recorded) draws: same torch + python RNG consumption as the reference's
+    statements (:170-177, :195-205), i.e. a seeded run gives what the recorded-draw replay of the same seeds gives."""
+    import random
+    for mode in ("hybrid", "truncated_gaussian"):
+        random.seed(3); torch.manual_seed(7)
+        o1, p1, t1 = VR.sample_camera_positions("cpu", n=4, horizontal_stddev=0.3, vertical_stddev=0.155, mode=mode)
+        random.seed(3); torch.manual_seed(7)
+        if mode == "hybrid":
+            coin = random.random()
+            a, b = (torch.rand((4, 1)), torch.rand((4, 1))) if coin < 0.5 else (torch.randn((4, 1)), torch.randn((4, 1)))
+            rec = [np.float64(coin), a.numpy(), b.numpy()]
+        else:
+            rec = [torch.empty((4, 1, 4)).normal_().numpy(), torch.empty((4, 1, 4)).normal_().numpy()]
+        o2, p2, t2 = VR.sample_camera_positions("cpu", n=4, horizontal_stddev=0.3, vertical_stddev=0.155, mode=mode, draws=VR.RecordedDraws(rec))
+        assert torch.equal(o1, o2) and torch.equal(p1, p2) and torch.equal(t1, t2)
 
 
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier"])

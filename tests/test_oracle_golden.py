@@ -58,6 +58,15 @@ def test_rays_and_camera():
         np.testing.assert_allclose(o, g[f"m{i}_origin"], atol=3e-7)
         c2w = O.create_cam2world_matrix(O.normalize_vecs(-o), o)
         np.testing.assert_allclose(c2w, g[f"m{i}_cam2world"], atol=5e-7)
+    for k in range(int(g["n_extra_modes"])):        # 'hybrid' (coin + two draws) and 'truncated_gaussian' (two candidate blocks)
+        mode = str(g[f"x{k}_mode"])
+        dr = [g[f"x{k}_draw{j}"] for j in range(int(g[f"x{k}_n_draws"]))]
+        coin, (rt, rp) = (float(dr[0]), dr[1:]) if mode == "hybrid" else (None, dr)
+        th, ph = O.camera_angles(mode, 5, 0.3, 0.155, np.pi * 0.5, np.pi * 0.5, rt, rp, coin=coin)
+        o, phi, theta = O.camera_origin(th, ph)
+        np.testing.assert_allclose(theta, g[f"x{k}_theta"], atol=2e-7)
+        np.testing.assert_allclose(phi, g[f"x{k}_phi"], atol=2e-7)
+        np.testing.assert_allclose(o, g[f"x{k}_origin"], atol=3e-7)
     th = np.full((2, 1), 0.3, np.float32)
     ph = np.full((2, 1), -0.2, np.float32)
     o, phi, _ = O.camera_origin(th, ph)
@@ -168,12 +177,16 @@ def test_h256_outputs(name, tol):
     np.testing.assert_allclose(out[..., -1], ref[..., -1], atol=1e-4 * max(1.0, float(g["meta_sigma_gain"]) / 20), rtol=2e-4)
     px, depth, third, st = _render(g)
     bad = np.abs(px - g["pixels"]).max(axis=1) > tol
-    assert bad.mean() <= 0.02, (bad.mean(), np.abs(px - g["pixels"]).max())
-    # exact-argmax semantics of the label channels on the agreeing pixels (mask2color, train...py:66-72)
+    assert not bad.any(), (int(bad.sum()), np.abs(px - g["pixels"]).max())          # no fixture shows a threshold flip
+    # exact-argmax semantics of the label channels (mask2color, train...py:66-72): identical on every pixel whose two best
+    # logits are not TIED in the reference itself (margin <= 1e-6, i.e. a few fp32 ulps: h256_texture_16x16_n12 has two pixels
+    # with margins 0 and 6e-8, where the reference's own argmax is decided by its rounding)
     am, am_ref = O.label_argmax(px), O.label_argmax(g["pixels"])
     top2 = np.sort(g["pixels"][:, :-3], axis=1)
-    decided = (top2[:, -1] - top2[:, -2]) > 10 * tol                                 # ties flip on rounding noise
-    assert (am == am_ref)[~bad & decided].all()
+    tie = (top2[:, -1] - top2[:, -2]) <= 1e-6
+    mism = am != am_ref
+    print(f"[parity] {name}: argmax mismatches {int(mism.sum())}, all on the {int(tie.sum())} reference ties")
+    assert not (mism & ~tie).any(), int((mism & ~tie).sum())
 
 
 def test_mapping_and_truncation():

@@ -362,6 +362,41 @@ def run_camera_cases(refs, name):
         out[f"m{i}_origin"], out[f"m{i}_phi"], out[f"m{i}_theta"] = np_(o), np_(phi), np_(theta)
         fwd = vr.normalize_vecs(-o)
         out[f"m{i}_cam2world"] = np_(vr.create_cam2world_matrix(fwd, o, device="cpu"))
+    # 'hybrid' (host-RNG coin, then uniform x2 or gaussian draws, :195-201) and 'truncated_gaussian' (first of four in-place
+    # normal_() candidates inside +-2, :170-177 / :203-205): the coin and the candidate blocks are recorded as draws too
+    import random as pyrandom
+    k = 0
+    for m, seeds in (("hybrid", (1, 2, 3, 4)), ("truncated_gaussian", (21, 22))):
+        for sd_ in seeds:
+            torch.manual_seed(40 + sd_)
+            pyrandom.seed(sd_)
+            rec = []
+            orig_random, orig_normal = pyrandom.random, torch.Tensor.normal_
+
+            def rec_random():
+                v = orig_random()
+                rec.append(np.float64(v))
+                return v
+
+            def rec_normal(self, *a, **kw):
+                r = orig_normal(self, *a, **kw)
+                rec.append(r.detach().cpu().numpy().copy())
+                return r
+
+            pyrandom.random, torch.Tensor.normal_ = rec_random, rec_normal
+            try:
+                with DrawRecorder() as dr:
+                    o, phi, theta = vr.sample_camera_positions(device="cpu", n=5, r=1, horizontal_stddev=0.3, vertical_stddev=0.155,
+                                                               horizontal_mean=np.pi * 0.5, vertical_mean=np.pi * 0.5, mode=m)
+            finally:
+                pyrandom.random, torch.Tensor.normal_ = orig_random, orig_normal
+            draws = rec[:1] + [d for _, d in dr.draws] if m == "hybrid" else rec      # call order: coin, then the two tensors
+            out[f"x{k}_mode"], out[f"x{k}_n_draws"] = m, len(draws)
+            for j, d in enumerate(draws):
+                out[f"x{k}_draw{j}"] = np.asarray(d)
+            out[f"x{k}_origin"], out[f"x{k}_phi"], out[f"x{k}_theta"] = np_(o), np_(phi), np_(theta)
+            k += 1
+    out["n_extra_modes"] = k
     # extreme pitch (clamp) case
     o, phi, theta = vr.sample_camera_positions(device="cpu", n=2, horizontal_stddev=0, vertical_stddev=0,
                                                horizontal_mean=0.3, vertical_mean=-0.2, mode="fixed")
@@ -422,10 +457,58 @@ def run_mapping_and_full(refs, name):
     print(f"{name}: mapping + forward + staged_forward")
 
 
-def main():
+def run_caller_helpers(name="caller_helpers"):
+    """mask2color (train_double_latent_semantic.py:36-72) and create_samples (extract_double_semantic_shapes.py:13-35):
+    the two function bodies are executed straight from the reference sources (AST-extracted, so the scripts' heavy
+    unrelated imports -- datasets, torch_ema, tensorboard, mrcfile ... -- are never triggered)."""
+    import ast
+    ns = {"torch": torch, "np": np}
+    for fn, wanted in (("train_double_latent_semantic.py", {"COLOR_MAP", "mask2color"}), ("extract_double_semantic_shapes.py", {"create_samples"})):
+        tree = ast.parse(open(os.path.join(ref_import.REFERENCE_ROOT, fn)).read())
+        keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
+                (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in wanted for t in n.targets))]
+        exec(compile(ast.Module(body=keep, type_ignores=[]), fn, "exec"), ns)
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    masks = torch.randn(3, 19, 6, 5, generator=g)
+    masks[0, :, 0, 0] = 0.0          # exact tie -> argmax picks the first index
+    masks[1, 7, 2, 2] = masks[1, 3, 2, 2] = masks[1].max() + 1.0
+    out["masks"] = np_(masks)
+    out["colors"] = np_(ns["mask2color"](masks))
+    out["color_map"] = np.array([ns["COLOR_MAP"][k] for k in range(19)], dtype=np.float32)
+    for N in (4, 5):
+        s, vo, vs = ns["create_samples"](N, [0, 0, 0], 0.3)
+        out[f"samples_{N}"], out[f"voxel_origin_{N}"], out[f"voxel_size_{N}"] = np_(s), np.asarray(vo, np.float64), np.float64(vs)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: mask2color + create_samples")
+
+
+def run_curriculums(refs, name="curriculums"):
+    """tests/golden/curriculums.json: the three curriculum dicts the path is quoted on, as the reference's curriculums.py
+    defines them (integer stage keys spelled "int:<step>", tuples as lists; `extract_metadata` etc. are behaviour, not data,
+    and are pinned by tests/test_host_cpu.py through these values)."""
+    import json
+    cur = refs[3]
+    out = {}
+    for cname in ("CelebA", "CelebA_double_semantic", "CelebA_double_semantic_texture_embedding_256_dim_96"):
+        d = getattr(cur, cname)
+        out[cname] = {(f"int:{k}" if isinstance(k, int) else k): (list(v) if isinstance(v, tuple) else v) for k, v in d.items()}
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print(f"{name}: {len(out)} curriculum dicts")
+
+
+def main(out_dir=None):
+    """Regenerates every fixture into `out_dir` (default tests/golden).  tests/test_golden_recipe.py calls this into a scratch
+    directory when /root/reference is present and compares the result with the committed files bit for bit."""
+    global OUT
+    if out_dir is not None:
+        OUT = out_dir
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     refs = ref_import.import_reference()
+    run_curriculums(refs)
     relu = dict(clamp_mode="relu", nerf_noise=0.0)
 
     tiny = proc.model_spec("texture", hidden_dim=32, grid_size=8, z_dim=16)
@@ -467,30 +550,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
-
-
-def run_caller_helpers(name="caller_helpers"):
-    """mask2color (train_double_latent_semantic.py:36-72) and create_samples (extract_double_semantic_shapes.py:13-35):
-    the two function bodies are executed straight from the reference sources (AST-extracted, so the scripts' heavy
-    unrelated imports -- datasets, torch_ema, tensorboard, mrcfile ... -- are never triggered)."""
-    import ast
-    ns = {"torch": torch, "np": np}
-    for fn, wanted in (("train_double_latent_semantic.py", {"COLOR_MAP", "mask2color"}), ("extract_double_semantic_shapes.py", {"create_samples"})):
-        tree = ast.parse(open(os.path.join(ref_import.REFERENCE_ROOT, fn)).read())
-        keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
-                (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in wanted for t in n.targets))]
-        exec(compile(ast.Module(body=keep, type_ignores=[]), fn, "exec"), ns)
-    out = {}
-    g = torch.Generator().manual_seed(11)
-    masks = torch.randn(3, 19, 6, 5, generator=g)
-    masks[0, :, 0, 0] = 0.0          # exact tie -> argmax picks the first index
-    masks[1, 7, 2, 2] = masks[1, 3, 2, 2] = masks[1].max() + 1.0
-    out["masks"] = np_(masks)
-    out["colors"] = np_(ns["mask2color"](masks))
-    out["color_map"] = np.array([ns["COLOR_MAP"][k] for k in range(19)], dtype=np.float32)
-    for N in (4, 5):
-        s, vo, vs = ns["create_samples"](N, [0, 0, 0], 0.3)
-        out[f"samples_{N}"], out[f"voxel_origin_{N}"], out[f"voxel_size_{N}"] = np_(s), np.asarray(vo, np.float64), np.float64(vs)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    print(f"{name}: mask2color + create_samples")
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
