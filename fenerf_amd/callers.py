@@ -43,18 +43,54 @@ def multiview_kwargs(curriculum, image_size=256, ray_step_multiplier=2, lock_vie
     return {k: v for k, v in c.items() if type(k) is str}
 
 
+def load_generator(path, device, use_ema=True):
+    """What every inference script of the reference does first (render_multiview_images_double_semantic.py:58-66,
+    render_video_interpolation_semantic.py:317-324): unpickle the generator module saved by the training loop
+    (`torch.save(generator_ddp.module, 'generator.pth')`, train...py:524), unpickle the torch_ema object next to it
+    (`<prefix>ema.pth`, the prefix being everything before 'generator' in the path) and copy the averaged weights in, then
+    set_device + eval.  Pickles written by the reference resolve through compat.install_aliases(): its module paths
+    (generators.generators.*, siren.siren.*) map to this package and torch_ema.ema.ExponentialMovingAverage to fenerf_amd.ema
+    when torch_ema is not installed (same attribute layout: decay, num_updates, shadow_params, collected_params)."""
+    import os
+    from . import compat
+    compat.install_aliases()
+    device = torch.device(device)
+    generator = torch.load(path, map_location=device, weights_only=False)
+    generator.softmax_label = False
+    generator.neural_renderer_img = None
+    generator.neural_renderer_seg = None
+    ema_file = path.split("generator")[0] + "ema.pth"
+    if use_ema:
+        if not os.path.exists(ema_file):
+            raise FileNotFoundError(f"{ema_file}: the reference loads the EMA weights next to the generator pickle")
+        ema = torch.load(ema_file, map_location=device, weights_only=False)
+        ema.copy_to(generator.parameters())
+    generator.set_device(device)
+    generator.eval()
+    return generator
+
+
+def _latent_dims(generator, default=256):
+    """(z_geo_dim, z_app_dim): the reference hard-codes 256 (render_multiview...:79-80); read from the module when it says otherwise."""
+    return int(getattr(generator, "z_geo_dim", default)), int(getattr(generator, "z_app_dim", default))
+
+
 def render_multiview(generator, curriculum, seed, device, face_angles=(-0.5, -0.25, 0.0, 0.25, 0.5), image_size=256,
-                     ray_step_multiplier=2, lock_view_dependence=False, z_dim=256):
+                     ray_step_multiplier=2, lock_view_dependence=False, z_dim=None, latents=None):
     """Five yaw angles of one identity (render_multiview_images_double_semantic.py:66-85).
-    -> (images [V,3,S,S] in [-1,1], segmaps [V,3,S,S] in [0,1]) on the CPU."""
+    -> (images [V,3,S,S] in [-1,1], segmaps [V,3,S,S] in [0,1]) on the CPU.
+    latents: optional (z_geo, z_app) instead of the seeded draws (tests teacher-force the reference's CPU-generator values)."""
     kw = multiview_kwargs(curriculum, image_size, ray_step_multiplier, lock_view_dependence)
     h_mean = kw["h_mean"]
+    zg_dim, za_dim = (z_dim, z_dim) if z_dim is not None else _latent_dims(generator)
     images, segmaps = [], []
     for a in face_angles:
         kw["h_mean"] = a + h_mean
         torch.manual_seed(seed)
-        z_geo = torch.randn((1, z_dim), device=device)
-        z_app = torch.randn((1, z_dim), device=device)
+        z_geo = torch.randn((1, zg_dim), device=device)
+        z_app = torch.randn((1, za_dim), device=device)
+        if latents is not None:
+            z_geo, z_app = (torch.as_tensor(t, dtype=torch.float32, device=device) for t in latents)
         with torch.no_grad():
             img, _ = generator.staged_forward(z_geo, z_app, **kw)
         images.append(img[:, -3:])
@@ -187,3 +223,89 @@ def render_latent_interpolation(generator, z1_geo, z2_geo, z1_app, z2_app, optio
         frames.append(img)
         depths.append(depth)
     return torch.cat(frames), torch.cat(depths)
+
+
+# ---------------------------------------------------------------------------------------------------
+# render_video_interpolation_semantic.py: options bag and camera trajectories
+# ---------------------------------------------------------------------------------------------------
+def video_kwargs(curriculum, image_size=256, ray_step_multiplier=2, psi=0.5, lock_view_dependence=False, num_frames=36, fov=12,
+                 fill_color="black"):
+    """The kwargs bag render_video_interpolation_semantic.py:52-69 builds from a curriculum."""
+    c = dict(curriculum)
+    c["num_steps"] = curriculum[0]["num_steps"] * ray_step_multiplier
+    c["img_size"] = image_size
+    c["psi"] = psi
+    c["v_stddev"] = 0
+    c["h_stddev"] = 0
+    c["lock_view_dependence"] = lock_view_dependence
+    c["last_back"] = curriculum.get("eval_last_back", False)
+    c["num_frames"] = num_frames
+    c["nerf_noise"] = 0
+    c["fov"] = fov
+    c["fill_mode"] = curriculum.get("fill_mode", "weight")
+    if c["fill_mode"] == "seg_padding_background":
+        c["fill_mode"] = "eval_seg_padding_background"
+    c["fill_color"] = fill_color
+    return {k: v for k, v in c.items() if type(k) is str}
+
+
+def camera_trajectory(name, num_frames, fov):
+    """[(t, pitch, yaw, fov)] of run_video_double_latent_interpolation (render_video_interpolation_semantic.py:326-379)."""
+    pi = np.pi
+    if name == "front":
+        return [(t, 0.2 * np.cos(t * 2 * pi) + pi / 2, 0.4 * np.sin(t * 2 * pi) + pi / 2, fov + 5 + np.sin(t * 2 * pi) * 5)
+                for t in np.linspace(0, 1, num_frames, endpoint=True)]
+    if name == "orbit":
+        return [(t, pi / 2, t * 2 * pi, fov) for t in np.linspace(0, 0.5, num_frames, endpoint=True)]
+    if name == "rotation_horizontal":
+        return [(t, pi / 2, pi / 2 + t * 0.5, fov) for t in np.linspace(-1, 1, num_frames)]
+    if name == "non_rotation":
+        return [(t, pi / 2, pi / 2, fov) for t in np.linspace(0, 1, num_frames, endpoint=True)]
+    if name == "sphere":
+        return [(t, 0.2 * np.cos(t * 2 * pi) + pi / 2, 0.4 * np.sin(t * 2 * pi) + pi / 2, fov) for t in np.linspace(0, 1, num_frames, endpoint=True)]
+    if name == "zoom":
+        return [(t, pi / 2, pi / 2, fov + np.sin(t * 2 * pi) * 5) for t in np.linspace(0, 1, num_frames)]
+    raise ValueError(f"unknown trajectory {name!r} (front | orbit | rotation_horizontal | non_rotation | sphere | zoom)")
+
+
+def render_double_latent_video(generator, seed, options, trajectory, latent_type="geo", psi=0.5, device=None, latents=None):
+    """The frame loop of run_video_double_latent_interpolation (:381-430): two identities from seeds `seed` and `seed + 1`
+    (z_geo then z_app each), FiLM parameters truncated towards the mean and interpolated on the `latent_type` side
+    (DoubleFrequencyInterpolator, :130-176: 'app' sweeps t over [-1, 1]), one staged_forward_with_frequencies per trajectory
+    entry with v_mean / h_mean / fov from it.  -> dict(images [F,3,S,S], labels [F,3,S,S] (0..255 colours), acc [F,3,S,S],
+    depth [F,S,S]) on the CPU.  latents: optional ((z_geo1, z_app1), (z_geo2, z_app2)) instead of the seeded draws."""
+    device = torch.device(device) if device is not None else generator.device
+    zg_dim, za_dim = _latent_dims(generator)
+    if latents is None:
+        torch.manual_seed(seed)
+        z1 = (torch.randn(1, zg_dim, device=device), torch.randn(1, za_dim, device=device))
+        torch.manual_seed(int(seed) + 1)
+        z2 = (torch.randn(1, zg_dim, device=device), torch.randn(1, za_dim, device=device))
+    else:
+        z1, z2 = (tuple(torch.as_tensor(t, dtype=torch.float32, device=device) for t in pair) for pair in latents)
+    avg_fg, avg_pg, avg_fa, avg_pa = generator.generate_avg_frequencies()
+    trunc = lambda avg, raw: avg + psi * (raw - avg)
+    with torch.no_grad():
+        ends = []
+        for zg, za in (z1, z2):
+            fg, pg = generator.siren.geo_mapping_network(zg)
+            fa, pa = generator.siren.app_mapping_network(za)
+            ends.append((trunc(avg_fg, fg), trunc(avg_fa, fa), trunc(avg_pg, pg), trunc(avg_pa, pa)))
+    lerp = lambda a, b, t: a * (1 - t) + b * t
+    (fg1, fa1, pg1, pa1), (fg2, fa2, pg2, pa2) = ends
+    move_geo, move_app = latent_type in ("geo", "both"), latent_type in ("app", "both")
+    out = dict(images=[], labels=[], acc=[], depth=[])
+    kw = {k: v for k, v in options.items() if k != "num_frames"}
+    for t, pitch, yaw, fov in trajectory:
+        t = float(t)
+        if latent_type == "app":
+            t = (t - 0.5) * 2
+        film = (lerp(fg1, fg2, t) if move_geo else fg1, lerp(fa1, fa2, t) if move_app else fa1,
+                lerp(pg1, pg2, t) if move_geo else pg1, lerp(pa1, pa2, t) if move_app else pa1)
+        kw.update(h_mean=float(yaw), v_mean=float(pitch), fov=float(fov), h_stddev=0, v_stddev=0)
+        frame, depth, weight_sum = generator.staged_forward_with_frequencies(*film, **kw)
+        out["images"].append(frame[:, -3:])
+        out["labels"].append(mask2color(frame[:, :-3]))
+        out["acc"].append(weight_sum[:, -3:])
+        out["depth"].append(depth)
+    return {k: torch.cat(v) for k, v in out.items()}

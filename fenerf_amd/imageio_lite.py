@@ -1,0 +1,109 @@
+"""Image / video writing for the inference front ends without torchvision, cv2 or skvideo (none of them is a dependency of
+this package): the subset of `torchvision.utils.make_grid` / `save_image` the reference's scripts use
+(render_multiview_images_double_semantic.py:84-85, render_video_interpolation_semantic.py:290-312, :411-458), PNG through
+Pillow, and an uncompressed AVI writer for `--save_with_video`.
+
+make_grid semantics kept (torchvision 0.9, the reference's pin): images laid out row-major, `nrow` images per row, `padding`
+pixels of `pad_value` around every image; `normalize=True` maps [low, high] (`value_range`, or the min / max of the WHOLE
+batch) to [0, 1] after clamping; single-channel images are repeated to three channels."""
+import math
+import struct
+
+import numpy as np
+import torch
+
+
+def make_grid(tensor, nrow=8, padding=2, normalize=False, value_range=None, pad_value=0.0):
+    """[B,C,H,W] (or [C,H,W] / [H,W]) float tensor -> [3,Hg,Wg] grid (a single image is returned unpadded, like torchvision)."""
+    t = torch.as_tensor(tensor).detach().float().cpu()
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.shape[1] == 1:
+        t = t.repeat(1, 3, 1, 1)
+    if normalize:
+        t = t.clone()
+        low, high = (float(value_range[0]), float(value_range[1])) if value_range is not None else (float(t.min()), float(t.max()))
+        t = (t.clamp(low, high) - low) / max(high - low, 1e-5)
+    B, C, H, W = t.shape
+    if B == 1:
+        return t[0]
+    xmaps = min(nrow, B)
+    ymaps = int(math.ceil(B / xmaps))
+    hh, ww = H + padding, W + padding
+    grid = torch.full((C, hh * ymaps + padding, ww * xmaps + padding), float(pad_value))
+    for k in range(B):
+        y, x = divmod(k, xmaps)
+        grid[:, y * hh + padding: y * hh + padding + H, x * ww + padding: x * ww + padding + W] = t[k]
+    return grid
+
+
+def to_uint8_hwc(grid):
+    """[3,H,W] in [0,1] -> uint8 [H,W,3], rounded like torchvision.utils.save_image (x*255 + 0.5, clamp, truncate)."""
+    return grid.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+
+
+def save_image(tensor, path, nrow=8, padding=2, normalize=False, value_range=None, pad_value=0.0):
+    """torchvision.utils.save_image for PNG files (Pillow)."""
+    from PIL import Image
+    arr = to_uint8_hwc(make_grid(tensor, nrow=nrow, padding=padding, normalize=normalize, value_range=value_range, pad_value=pad_value))
+    Image.fromarray(arr).save(path)
+    return arr
+
+
+JET = None
+
+
+def jet_colormap(gray_u8):
+    """uint8 [H,W] -> uint8 RGB [H,W,3]: the piecewise-linear 'jet' ramp (what cv2.COLORMAP_JET approximates; the reference
+    colours depth maps with it, render_video_interpolation_semantic.py:424-427).  Not bit-identical to OpenCV's 256-entry table."""
+    global JET
+    if JET is None:
+        x = np.arange(256) / 255.0
+        r = np.clip(1.5 - np.abs(4 * x - 3), 0, 1)
+        g = np.clip(1.5 - np.abs(4 * x - 2), 0, 1)
+        b = np.clip(1.5 - np.abs(4 * x - 1), 0, 1)
+        JET = (np.stack([r, g, b], -1) * 255 + 0.5).astype(np.uint8)
+    return JET[np.asarray(gray_u8, dtype=np.uint8)]
+
+
+class AviWriter:
+    """Uncompressed RGB AVI (RIFF 'AVI ' with one 'vids' stream of BI_RGB 24-bit DIB frames, bottom-up BGR) -- playable by
+    ffmpeg / VLC / OpenCV, written with the standard library only.  Frames are uint8 [H,W,3] RGB of constant size."""
+
+    def __init__(self, path, fps=25):
+        self.path, self.fps, self.frames, self.size = path, int(fps), [], None
+
+    def write(self, rgb):
+        rgb = np.ascontiguousarray(np.asarray(rgb, dtype=np.uint8))
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        if self.size is None:
+            self.size = rgb.shape[:2]
+        assert rgb.shape[:2] == self.size, "all frames must have the same size"
+        H, W = self.size
+        row = (W * 3 + 3) // 4 * 4
+        buf = np.zeros((H, row), np.uint8)
+        buf[:, :W * 3] = rgb[::-1, :, ::-1].reshape(H, W * 3)        # bottom-up, BGR
+        self.frames.append(buf.tobytes())
+
+    def release(self):
+        if not self.frames:
+            return
+        H, W = self.size
+        n, fsz = len(self.frames), len(self.frames[0])
+        chunk = lambda tag, data: tag + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+        lst = lambda tag, data: b"LIST" + struct.pack("<I", len(data) + 4) + tag + data
+        avih = struct.pack("<14I", 1000000 // self.fps, fsz * self.fps, 0, 0x10, n, 0, 1, fsz, W, H, 0, 0, 0, 0)
+        strh = struct.pack("<4s4sIHHIIIIIIIIhhhh", b"vids", b"DIB ", 0, 0, 0, 0, 1, self.fps, 0, n, fsz, 0xFFFFFFFF, 0, 0, 0, W, H)
+        strf = struct.pack("<IiiHHIIiiII", 40, W, H, 1, 24, 0, fsz, 0, 0, 0, 0)
+        hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+        movi_data = b"".join(chunk(b"00db", f) for f in self.frames)
+        idx, off = b"", 4
+        for f in self.frames:
+            idx += struct.pack("<4sIII", b"00db", 0x10, off, len(f))
+            off += 8 + len(f) + (len(f) & 1)
+        body = b"AVI " + hdrl + lst(b"movi", movi_data) + chunk(b"idx1", idx)
+        with open(self.path, "wb") as fh:
+            fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        self.frames = []

@@ -1,0 +1,137 @@
+"""CPU tests of the inference front ends' host pieces: the argparse surfaces mirror the reference scripts, the
+torchvision-free grid / PNG / AVI writers, the options bags and camera trajectories, and a torch_ema-style pickle loading
+through the import aliases."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from fenerf_amd import callers, curriculums, imageio_lite  # noqa: E402
+
+
+def test_make_grid_layout_and_normalisation_like_torchvision():
+    imgs = torch.arange(3 * 3 * 2 * 2, dtype=torch.float32).reshape(3, 3, 2, 2)
+    g = imageio_lite.make_grid(imgs, nrow=2, padding=2, pad_value=0.0)
+    assert tuple(g.shape) == (3, 2 * 4 + 2, 2 * 4 + 2)                      # ymaps * (H + pad) + pad, xmaps * (W + pad) + pad
+    assert torch.equal(g[:, 2:4, 2:4], imgs[0]) and torch.equal(g[:, 2:4, 6:8], imgs[1]) and torch.equal(g[:, 6:8, 2:4], imgs[2])
+    assert (g[:, 6:8, 6:8] == 0).all() and (g[:, :2] == 0).all()             # empty cell and border are pad_value
+    # normalize with a value range: clamp, then (x - low) / (high - low); without: min / max of the whole batch
+    x = torch.tensor([[[[-2.0, -1.0], [0.0, 1.0]]]])
+    n = imageio_lite.make_grid(x, normalize=True, value_range=(-1, 1))
+    assert tuple(n.shape) == (3, 2, 2)                                       # single image: no padding, 1 -> 3 channels
+    np.testing.assert_allclose(n[0].numpy(), [[0.0, 0.0], [0.5, 1.0]], atol=1e-6)
+    n2 = imageio_lite.make_grid(x, normalize=True)
+    np.testing.assert_allclose(n2[0].numpy(), [[0.0, 1 / 3], [2 / 3, 1.0]], atol=1e-6)
+    assert imageio_lite.to_uint8_hwc(torch.full((3, 1, 1), 0.5)).tolist() == [[[128, 128, 128]]]     # x * 255 + 0.5, truncated
+
+
+def test_save_image_png_round_trip(tmp_path):
+    from PIL import Image
+    imgs = torch.rand(5, 3, 8, 8) * 2 - 1
+    arr = imageio_lite.save_image(imgs, str(tmp_path / "g.png"), normalize=True, value_range=(-1, 1))
+    back = np.asarray(Image.open(tmp_path / "g.png"))
+    assert back.shape == (8 + 4, 5 * 10 + 2, 3) and np.array_equal(back, arr)
+    expect = ((imgs[3].clamp(-1, 1) + 1) / 2 * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    assert np.array_equal(back[2:10, 3 * 10 + 2:3 * 10 + 10], expect)
+
+
+def test_avi_writer_container(tmp_path):
+    w = imageio_lite.AviWriter(str(tmp_path / "v.avi"), fps=25)
+    frames = [np.random.default_rng(i).integers(0, 255, (6, 10, 3), dtype=np.uint8) for i in range(4)]
+    for f in frames:
+        w.write(f)
+    w.release()
+    raw = open(tmp_path / "v.avi", "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+    assert raw.count(b"00db") == 2 * 4                                      # four frame chunks + four index entries
+    p = raw.index(b"movi") + 4
+    assert raw[p:p + 4] == b"00db"
+    size = struct.unpack("<I", raw[p + 4:p + 8])[0]
+    assert size == 6 * 32                                                    # rows padded to 4 bytes: 10 * 3 = 30 -> 32
+    first = np.frombuffer(raw[p + 8:p + 8 + size], np.uint8).reshape(6, 32)[:, :30].reshape(6, 10, 3)
+    assert np.array_equal(first[::-1, :, ::-1], frames[0])                   # bottom-up BGR
+
+
+def test_argparse_surfaces_mirror_the_reference_scripts():
+    import render_multiview
+    import render_video_interpolation
+    o = render_multiview.build_parser().parse_args(["ckpt/generator.pth", "--seeds", "0", "7", "--output_dir", "o", "--max_batch_size", "99",
+                                                    "--lock_view_dependence", "--image_size", "128", "--ray_step_multiplier", "3",
+                                                    "--curriculum", "CelebA_double_semantic"])
+    assert (o.path, o.seeds, o.output_dir, o.max_batch_size, o.lock_view_dependence, o.image_size, o.ray_step_multiplier, o.curriculum) == \
+        ("ckpt/generator.pth", ["0", "7"], "o", 99, True, 128, 3, "CelebA_double_semantic")
+    d = render_multiview.build_parser().parse_args(["g.pth"])
+    assert (d.seeds, d.output_dir, d.max_batch_size, d.image_size, d.ray_step_multiplier, d.curriculum) == ([0], "imgs", 2400000, 256, 2, "CelebA")
+    v = render_video_interpolation.build_parser().parse_args(["g.pth"])
+    assert (v.interpolation_type, v.latent_type, v.seeds, v.output_dir, v.batch_size, v.max_batch_size, v.depth_map, v.lock_view_dependence,
+            v.image_size, v.ray_step_multiplier, v.num_frames, v.curriculum, v.trajectory, v.psi, v.fill_color, v.fov, v.save_with_video,
+            v.save_with_latent, v.seed_mode) == \
+        ("video_double_latent_interpolation", "geo", [0], "vids", 1, 2400000, False, False, 256, 2, 36, "CelebA", "front", 0.5, "black", 12,
+         False, False, "single")
+    cur = render_multiview.resolve_curriculum("CelebA_double_semantic_texture_embedding_256_dim_96")
+    assert cur[0]["num_steps"] == curriculums.CelebA_double_semantic_texture_embedding_256_dim_96[0]["num_steps"]
+
+
+def test_options_bags_and_trajectories():
+    cur = curriculums.CelebA_double_semantic_texture_embedding_256_dim_96
+    mv = callers.multiview_kwargs(cur, image_size=256, ray_step_multiplier=2)
+    assert mv["num_steps"] == 2 * cur[0]["num_steps"] and mv["psi"] == 0.7 and mv["h_stddev"] == 0 and mv["last_back"] is False
+    assert all(type(k) is str for k in mv)
+    vk = callers.video_kwargs(cur, image_size=64, ray_step_multiplier=1, psi=0.5, num_frames=6, fov=12, fill_color="white")
+    assert vk["fill_mode"] == "eval_seg_padding_background" and vk["fill_color"] == "white" and vk["num_frames"] == 6
+    assert vk["last_back"] == cur.get("eval_last_back", False)
+    tr = callers.camera_trajectory("front", 5, 12)
+    assert len(tr) == 5 and tr[0][0] == 0 and tr[-1][0] == 1
+    np.testing.assert_allclose(tr[0][1:], (0.2 + np.pi / 2, np.pi / 2, 17.0), atol=1e-12)        # pitch, yaw, fov at t = 0
+    orbit = callers.camera_trajectory("orbit", 3, 12)
+    np.testing.assert_allclose([y for _, _, y, _ in orbit], [0, np.pi / 2, np.pi], atol=1e-12)
+    assert [round(f, 6) for *_, f in callers.camera_trajectory("zoom", 5, 12)] == [12, 17, 12, 7, 12]
+    with pytest.raises(ValueError):
+        callers.camera_trajectory("nope", 3, 12)
+
+
+def test_torch_ema_style_pickle_loads_through_the_aliases(tmp_path):
+    """A pickle whose class path is torch_ema.ema.ExponentialMovingAverage with torch_ema 0.2's attribute layout (decay,
+    num_updates, shadow_params, collected_params -- what `torch.save(ema, 'ema.pth')` wrote in the reference's environment,
+    train_double_latent_semantic.py:525) unpickles, in a process that has no torch_ema, into fenerf_amd.ema and copy_to works."""
+    code = r'''
+import sys, types, torch
+sys.path.insert(0, %r)
+m = types.ModuleType("torch_ema"); e = types.ModuleType("torch_ema.ema")
+class ExponentialMovingAverage:                 # the writer's class: attribute layout of torch_ema 0.2
+    def __init__(self, parameters, decay):
+        self.decay, self.num_updates = decay, 3
+        self.shadow_params = [p.clone().detach() + 1.0 for p in parameters if p.requires_grad]
+        self.collected_params = []
+ExponentialMovingAverage.__module__ = "torch_ema.ema"
+e.ExponentialMovingAverage = ExponentialMovingAverage; m.ema = e; m.ExponentialMovingAverage = ExponentialMovingAverage
+sys.modules["torch_ema"], sys.modules["torch_ema.ema"] = m, e
+lin = torch.nn.Linear(3, 2)
+torch.save(ExponentialMovingAverage(lin.parameters(), 0.999), %r)
+torch.save(lin.state_dict(), %r)
+''' % (ROOT, str(tmp_path / "ema.pth"), str(tmp_path / "lin.pth"))
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).returncode == 0
+    code2 = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from fenerf_amd import compat
+compat.install_aliases()
+ema = torch.load(%r, weights_only=False)
+assert type(ema).__module__ == "fenerf_amd.ema", type(ema)
+lin = torch.nn.Linear(3, 2); lin.load_state_dict(torch.load(%r))
+before = [p.clone() for p in lin.parameters()]
+ema.copy_to(lin.parameters())
+assert all(torch.equal(p, b + 1.0) for p, b in zip(lin.parameters(), before))
+assert ema.decay == 0.999 and ema.num_updates == 3
+ema.store(lin.parameters()); ema.update(lin.parameters()); ema.restore(lin.parameters())
+print("ok")
+''' % (ROOT, str(tmp_path / "ema.pth"), str(tmp_path / "lin.pth"))
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]

@@ -483,6 +483,67 @@ def run_caller_helpers(name="caller_helpers"):
     print(f"{name}: mask2color + create_samples")
 
 
+def run_multiview_case(refs, name="tiny_multiview"):
+    """generate_img of render_multiview_images_double_semantic.py:24-29 (AST-extracted, executed as is) over the script's
+    five yaw angles (:68-83) on the tiny reference generator, with the options bag the script builds (:43-54) from a small
+    curriculum: z from torch.manual_seed(seed) on the CPU generator, every draw recorded (identical for all five angles: the
+    script re-seeds per angle)."""
+    import ast
+    siren_mod, gens, vr, cur = refs
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=8, z_dim=16)
+    g, sd = build_ref_generator(refs, spec, seed=3, sigma_gain=300.0)
+    g.softmax_label = False
+    ns = {"torch": torch, "np": np, "generator": g}
+    for fn, wanted in (("train_double_latent_semantic.py", {"COLOR_MAP", "mask2color"}), ("render_multiview_images_double_semantic.py", {"generate_img"})):
+        tree = ast.parse(open(os.path.join(ref_import.REFERENCE_ROOT, fn)).read())
+        keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
+                (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in wanted for t in n.targets))]
+        exec(compile(ast.Module(body=keep, type_ignores=[]), fn, "exec"), ns)
+    curriculum = {0: dict(batch_size=4, num_steps=3, img_size=8), "fov": 12, "ray_start": 0.88, "ray_end": 1.12, "h_stddev": 0.3,
+                  "v_stddev": 0.155, "h_mean": float(np.pi * 0.5), "v_mean": float(np.pi * 0.5), "sample_dist": "gaussian",
+                  "hierarchical_sample": True, "clamp_mode": "relu", "fill_mode": "seg_padding_background", "white_back": False}
+    image_size, mult, seed = 8, 2, 5
+    c = dict(curriculum)                      # the script's lines :43-54
+    c["num_steps"] = c[0]["num_steps"] * mult
+    c["img_size"] = image_size
+    c["psi"] = 0.7
+    c["v_stddev"] = 0
+    c["h_stddev"] = 0
+    c["lock_view_dependence"] = True
+    c["last_back"] = False
+    c["nerf_noise"] = 0
+    c = {k: v for k, v in c.items() if type(k) is str}
+    face_angles = [a + c["h_mean"] for a in [-0.5, -0.25, 0., 0.25, 0.5]]
+    images, segmaps, first = [], [], None
+    for yaw in face_angles:
+        c["h_mean"] = yaw
+        torch.manual_seed(seed)
+        z_geo = torch.randn((1, 16))
+        z_app = torch.randn((1, 16))
+        with DrawRecorder() as dr:
+            img, segmap = ns["generate_img"](g, z_geo, z_app, **c)
+        rec = dict(avg=[np_(g.avg_frequencies_geo), np_(g.avg_phase_shifts_geo), np_(g.avg_frequencies_app), np_(g.avg_phase_shifts_app)],
+                   draws=list(dr.draws[2:]))
+        if first is None:
+            first = rec
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first["avg"] + [d for _, d in first["draws"]], rec["avg"] + [d for _, d in rec["draws"]]))
+        images.append(np_(img))
+        segmaps.append(np_(segmap))
+    out = dict(z_geo=np_(z_geo), z_app=np_(z_app), images=np.concatenate(images), segmaps=np.concatenate(segmaps), seed=seed,
+               image_size=image_size, ray_step_multiplier=mult, curriculum_json=json_dumps_curriculum(curriculum),
+               avg_freq_geo=first["avg"][0], avg_phase_geo=first["avg"][1], avg_freq_app=first["avg"][2], avg_phase_app=first["avg"][3])
+    for k, v in rand_dict_from_draws(first["draws"], True).items():
+        out["rand_" + k] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: images {out['images'].shape}, segmaps {out['segmaps'].shape}")
+
+
+def json_dumps_curriculum(curriculum):
+    import json
+    return json.dumps({(f"int:{k}" if isinstance(k, int) else k): v for k, v in curriculum.items()}, sort_keys=True)
+
+
 def run_curriculums(refs, name="curriculums"):
     """tests/golden/curriculums.json: the three curriculum dicts the path is quoted on, as the reference's curriculums.py
     defines them (integer stage keys spelled "int:<step>", tuples as lists; `extract_metadata` etc. are behaviour, not data,
@@ -525,6 +586,7 @@ def main(out_dir=None):
     run_camera_cases(refs, "camera_rays")
     run_mapping_and_full(refs, "tiny_texture_z_full")
     run_caller_helpers()
+    run_multiview_case(refs)
     run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
