@@ -598,7 +598,8 @@ def test_generator_step_at_configs2_shape_B6_128_24p24():
     every generator parameter, peak memory reported."""
     gen, cur, curriculums = _curriculum_generator()
     gen.train()
-    md = {**curriculums.extract_metadata(cur, 60000), "img_size": 128, "num_steps": 24}
+    md = {**curriculums.extract_metadata(cur, 60000), "img_size": 128, "num_steps": 24,
+          "nerf_noise": max(0, 1.0 - 2500 / 5000.0)}         # the training loop sets it per step (train...py:276)
     B = 6
     zg, za = torch.randn(B, 256, device=DEV), torch.randn(B, 256, device=DEV)
     torch.cuda.reset_peak_memory_stats()
