@@ -118,9 +118,9 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         d_out2[B:, :P] = d_f.reshape(B, P, C)
         film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
-        d_t, d_e = nat.siren_backward(2 * B, Pp, *film2, out2, d_out2, tape2)
         film_only = not any(need[14:])
-        r = nat.siren_param_grads(pts2, rd2, *film2, out2, d_out2, tape2, tape_e2 if tape_e2.numel() else None, d_t, film_only=film_only)
+        r, d_e = _siren_autograd.chunked_backward(nat, 2 * B, Pp, film2, pts2, rd2, out2, d_out2, tape2,
+                                                  tape_e2 if tape_e2.numel() else None, film_only)
         fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
         film_grads = (fold(r["d_freq_geo"], need[10]), fold(r["d_phase_geo"], need[11]), fold(r["d_freq_app"], need[12]),
                       fold(r["d_phase_app"], need[13]))

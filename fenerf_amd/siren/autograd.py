@@ -52,6 +52,66 @@ def assemble_param_grads(module, nat, params, r, points, d_e, need_params):
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
+# dtheta of a backward chunk: at most this many points (x L*H*4 B = 1.5 GB at L*H = 2816).  The chain kernel writes dL/dtheta of
+# every FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist
+# for more points than one chain launch's worth: peak memory of a generator step = tape + one chunk instead of 2 x tape.
+BACKWARD_CHUNK_POINTS = 131072
+
+
+def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None):
+    """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
+    `max_points` points of ONE image each: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per
+    image, and every gradient is a sum over points, so chunk results simply add.  -> (grads dict like siren_param_grads with
+    [nB]-leading FiLM gradients, d_e [nB*Pp, 32] or None)."""
+    max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
+    max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
+    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    G = nat.spec["grid_ch"]
+    C = nat.C
+    fg, pg, fa, pa = film
+    out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
+    d_e_full = torch.empty((nB * Pp, 32), dtype=torch.float32, device=out.device) if G else None
+    total = None
+    for b in range(nB):
+        film_b = (fg[b:b + 1], pg[b:b + 1], fa[b:b + 1], pa[b:b + 1])
+        acc_b = None
+        for s in range(0, Pp, max_points):
+            n = min(max_points, Pp - s)
+            g0 = b * Pp + s
+            tape_c = tape[g0 * LH:(g0 + n) * LH]
+            out_c, d_out_c = out[b:b + 1, s:s + n], d_out[b:b + 1, s:s + n]
+            d_t, d_e = nat.siren_backward(1, n, *film_b, out_c, d_out_c, tape_c)
+            if G:
+                d_e_full[g0:g0 + n] = d_e
+            r = nat.siren_param_grads(points[b:b + 1, s:s + n], dirs[b:b + 1, s:s + n] if dirs is not None else None, *film_b, out_c,
+                                      d_out_c, tape_c, tape_e[g0:g0 + n] if G else None, d_t, film_only=film_only)
+            del d_t
+            if acc_b is None:
+                acc_b = r
+            else:
+                for k, v in r.items():
+                    if isinstance(v, list):
+                        for a, x in zip(acc_b[k], v):
+                            a.add_(x)
+                    else:
+                        acc_b[k].add_(v)
+        if total is None:
+            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in acc_b.items()}
+            film_rows = {k: [acc_b[k]] for k in ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")}
+        else:
+            for k, v in acc_b.items():
+                if k in film_rows:
+                    film_rows[k].append(v)
+                elif isinstance(v, list):
+                    for a, x in zip(total[k], v):
+                        a.add_(x)
+                else:
+                    total[k].add_(v)
+    for k, rows in film_rows.items():
+        total[k] = torch.cat(rows, 0)
+    return total, d_e_full
+
+
 class SirenFunction(torch.autograd.Function):
     """out = siren(points, dirs; film params, weights).  Non-tensor arg `module` supplies the native model and roles."""
 
@@ -79,9 +139,8 @@ class SirenFunction(torch.autograd.Function):
         d_out = d_out.contiguous().float()
         need = ctx.needs_input_grad
         film_only = not any(need[7:])        # inversion: only the FiLM parameters are optimised
-        d_t, d_e = nat.siren_backward(B, P, fg, pg, fa, pa, out, d_out, tape)
-        r = nat.siren_param_grads(points, dirs if ctx.has_dirs else None, fg, pg, fa, pa, out, d_out, tape,
-                                  tape_e if tape_e.numel() else None, d_t, film_only=film_only)
+        r, d_e = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
+                                  tape_e if tape_e.numel() else None, film_only)
         film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
                       r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
         if film_only:

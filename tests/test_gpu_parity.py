@@ -1033,6 +1033,44 @@ def test_generator_gradient_end_to_end(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+def test_chunked_backward_equals_one_pass(precision):
+    """The backward runs chain + weight-gradient kernels per chunk of points (siren/autograd.py: bounded dtheta); chunk results
+    add.  With 128-point chunks (4-5 chunks per image here, ragged last chunk) every gradient equals the single-chunk one
+    up to fp32 summation order."""
+    from fenerf_amd.siren import autograd as SA
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision=precision)
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    B, S_, N = 2, 7, 11                      # 539 points per image and pass -> padded to 544 = 4 x 128 + 32
+    film = proc.film_params(spec, B, seed=4)
+    kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
+    results = []
+    for chunk in (1 << 30, 128):
+        SA_old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
+        try:
+            film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+            for p_ in mod.parameters():
+                p_.grad = None
+            torch.manual_seed(11)
+            px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+            w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (px * w).sum().backward()
+            grads = {k: N_(v.grad) for k, v in film_t.items()}
+            grads.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
+            results.append(grads)
+        finally:
+            SA.BACKWARD_CHUNK_POINTS = SA_old
+    one, many = results
+    assert one.keys() == many.keys() and len(one) > 30
+    worst = max(_rel_err(many[k], one[k]) for k in one)
+    print(f"[parity] chunked backward (128-point chunks) vs one pass [{precision}]: worst relative difference over {len(one)} tensors {worst:.1e}")
+    assert worst <= 2e-5
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_device_side_repack_matches_host_pack(precision):
     """optimizer.step() analogue: change the weights on the GPU, re-pack on the device (index-map gather +
     fenerf_model_load_packed) and compare forward outputs and gradients with a model packed on the host from the same values."""
