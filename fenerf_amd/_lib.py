@@ -79,6 +79,8 @@ _SIGS = {
     "fenerf_model_export_packed": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     "fenerf_film_workspace_bytes": (_sz, [_vp, _i]),
     "fenerf_siren_forward": (_i, [_vp, _i, _i64] + [_vp] * 9),
+    "fenerf_film_workspace_bytes_pointwise": (_sz, [_vp, _i, _i64]),
+    "fenerf_siren_forward_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 9),
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
     "fenerf_ray_setup": (_i, [_i, _i, _i, C.c_float, C.c_float, C.c_float] + [_vp] * 9),
     "fenerf_siren_time_rays": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_float), _vp]),

@@ -229,7 +229,7 @@ extern "C" size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B) {
   return align_up((size_t)2 * B * m->L * m->H * sizeof(float) + 1024, 256);
 }
 
-static int film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+static int film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
                      void* film_ws, const float** fp, const float** pp, void* stream) {
   if (!fg || !pg) return fail(FENERF_E_INVALID, "freq_geo / phase_geo is NULL");
   if (!fa || !pa) return fail(FENERF_E_INVALID, "freq_app / phase_app is NULL");
@@ -265,6 +265,32 @@ extern "C" int fenerf_siren_forward(const FenerfModel* m, int B, int64_t P, cons
   sp.points = points; sp.pdirs = ray_dirs;
   sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
   sp.out = out;
+  return launch_siren(m, sp, stream);
+}
+
+extern "C" size_t fenerf_film_workspace_bytes_pointwise(const FenerfModel* m, int B, int64_t P) {
+  if (!m || B <= 0 || P <= 0) return 0;
+  return align_up((size_t)2 * (size_t)B * (size_t)P * m->L * m->H * sizeof(float) + 1024, 256);
+}
+
+extern "C" int fenerf_siren_forward_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                              const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                              const float* phase_app, float* out, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (m->precision != FENERF_PREC_F32)
+    return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters need a model created with FENERF_PREC_F32");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P == 0) return FENERF_OK;
+  if (!points || !out) return fail(FENERF_E_INVALID, "points / out is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, (long long)B * P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.points = points; sp.pdirs = ray_dirs;
+  sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
+  sp.out = out;
+  sp.film_per_point = 1;
   return launch_siren(m, sp, stream);
 }
 

@@ -69,6 +69,8 @@ struct SirenParams {
   // register dumps of the 32-point tiles (fenerf_layout.h "Tape"), and the sampled grid features [P][32]
   float* tape;
   float* tape_e;
+  // SPATIALSIRENGRID (siren.py:413-518): fp / pp hold one [L][H] block per POINT instead of per image (fp32 kernel only)
+  int film_per_point;
 };
 
 struct SirenBwdParams {
@@ -103,7 +105,7 @@ struct CompositeParams {
   float* d_rows_b;         // merge: d coarse [BR][N][C]
 };
 
-int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
                      float* fp, float* pp, void* stream);
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);

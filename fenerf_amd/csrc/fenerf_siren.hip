@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
     long long pt = tile * 32 + m;
     const bool valid = pt < P.P;
     if (!valid) pt = P.P - 1;
-    const long long img = pt / P.pts_per_image;
+    // FiLM block of this lane: its image's, or -- per-point modulation (SPATIALSIRENGRID, siren.py:440-477: frequencies and
+    // phase shifts come from a mapping network evaluated per sample point) -- its own point's
+    const long long img = P.film_per_point ? pt : pt / P.pts_per_image;
     float px, py, pz, dx, dy, dz;
     if (P.points) {
       px = P.points[pt * 3 + 0]; py = P.points[pt * 3 + 1]; pz = P.points[pt * 3 + 2];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 // FiLM pre-pass: f' = (15 f + 30) / 2pi, p' = ((15 f + 30) b + p) / 2pi  (double, rounded once).
 // The '*15 + 30' itself is done in fp32 with separate mul and add exactly like siren.py:1510-1511.
 // ------------------------------------------------------------------------------------------------
-__global__ void film_prep_kernel(int B, int H, int n_geo, int n_color, const float* fg, const float* pg, const float* fa,
+__global__ void film_prep_kernel(long long B, int H, int n_geo, int n_color, const float* fg, const float* pg, const float* fa,
                                  const float* pa, const float* bias /* [L][H] */, const float* inv_scale /* [L][H] or null */,
                                  float* fp, float* pp) {
   const int L = n_geo + n_color;
@@ -308,7 +310,7 @@ static int hip_fail(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-int launch_film_prep(const FenerfModel* m, int B, const float* fg, const float* pg, const float* fa, const float* pa,
+int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
                      float* fp, float* pp, void* stream) {
   const long long total = (long long)B * m->L * m->H;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);

@@ -299,6 +299,25 @@ class NativeModel:
                                                        _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
+    def siren_forward_pointwise(self, points, ray_dirs, fg, pg, fa, pa):
+        """Per-point FiLM parameters (SPATIALSIRENGRID, siren.py:464-477): fg / pg [B,P,n_geo*H], fa / pa [B,P,n_color*H]
+        -> [B,P,C].  The model must be precision 'f32'."""
+        B, P = points.shape[0], points.shape[1]
+        H, ng, nc = self.spec["hidden_dim"], self.spec["n_geo"], self.spec["n_color"]
+        dev = self.device
+        fg, pg, fa, pa = (_f32(t, dev) for t in (fg, pg, fa, pa))
+        for t, n in ((fg, ng), (pg, ng), (fa, nc), (pa, nc)):
+            if tuple(t.shape) != (B, P, n * H):
+                raise ValueError(f"per-point film parameter of shape {tuple(t.shape)}, expected {(B, P, n * H)}")
+        points = _f32(points, dev)
+        ray_dirs = _f32(ray_dirs, dev) if ray_dirs is not None else None
+        out = torch.empty((B, P, self.C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = self._workspace("film_pw", _lib.lib().fenerf_film_workspace_bytes_pointwise(self._h, B, P))
+            _lib.check(_lib.lib().fenerf_siren_forward_pointwise(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg),
+                                                                 _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
+        return out
+
     def tape_floats(self, total_points):
         """floats of a tape for total_points points (L*H per point + the slack the kernel's last workgroup may write)"""
         return int(_lib.lib().fenerf_siren_tape_floats(self._h, total_points))

@@ -285,3 +285,62 @@ class SPATIALSIRENBASELINE(_NativeSiren):
         if self._wants_grad(input, ray_directions, frequencies, phase_shifts):
             return _autograd.siren_apply(self, input, ray_directions, fg, pg, fa, pa)
         return self.native(input.device).siren_forward(input, ray_directions, fg, pg, fa, pa)
+
+
+class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
+    """SPATIALSIRENBASELINE whose FiLM parameters are PER SAMPLE POINT (siren.py:413-518): a 2-D grid of local latents
+    (32 channels, from the reference's StyleGAN2-style `grid_latent_network`, siren/latent_grid.py) is sampled bilinearly at
+    every point's (x, z), a one-block mapping network turns the 32-d local latent into that point's frequencies / phase shifts,
+    and the SIREN is evaluated in local cell coordinates.  The SIREN evaluation with per-point FiLM parameters is the native
+    part (fenerf_siren_forward_pointwise, exact-fp32 kernel); local-latent sampling, mapping network and local coordinates are
+    the torch statements of the reference's lines.  The StyleGAN2 grid generator itself is outside the hot path:
+    it is not built, `forward(input, z, ...)` says so, and `forward_with_latent_grid` takes its output as an input."""
+    precision = "f32"      # per-point FiLM blocks are read per lane by the exact kernel
+
+    def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
+        super().__init__(input_dim=input_dim, z_dim=z_dim, hidden_dim=hidden_dim, output_dim=output_dim, device=device)
+        self.local_coordinates = True
+        self.mapping_network = CustomMappingNetwork(32, 256, (len(self.network) + 1) * hidden_dim * 2, n_blocks=1)   # :440
+
+    def forward(self, input, z, ray_directions, **kwargs):
+        raise NotImplementedError("SPATIALSIRENGRID.forward needs the reference's StyleGenerator2D latent-grid generator "
+                                  "(siren/latent_grid.py), which this package does not build; evaluate it elsewhere and call "
+                                  "forward_with_latent_grid(input, latent_grid, ray_directions)")
+
+    def forward_with_latent_grid(self, input, latent_grid, ray_directions, **kwargs):
+        """The body of the reference's forward after `latent_grid = self.grid_latent_network(z)` (siren.py:453-463)."""
+        input_grid = self.gridwarper(input)
+        sampled_latent = self.sample_local_latents(latent_grid, input_grid)
+        frequencies, phase_shifts = self.mapping_network(sampled_latent)
+        if self.local_coordinates:
+            input = self.get_local_coordinates(global_coords=input, local_grid_length=32, preserve_y=False)
+        return self.forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
+
+    def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
+        """frequencies / phase_shifts [B, P, 9H]: one FiLM block per point (siren.py:464-477); [B, 9H] behaves like the parent."""
+        if frequencies.dim() == 2:
+            return super().forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
+        if self._wants_grad(input, ray_directions, frequencies, phase_shifts):
+            raise NotImplementedError("fenerf_amd: per-point FiLM modulation is forward-only (the reference never trains this variant: "
+                                      "it is in no curriculum and its generator-level methods cannot run, SURVEY 0.5)")
+        fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
+        return self.native(input.device).siren_forward_pointwise(input, ray_directions, fg, pg, fa, pa)
+
+    @staticmethod
+    def sample_local_latents(local_latents, xyz):
+        """[B, 32, h, w] latents sampled bilinearly (align_corners=False, zeros padding) at every point's (x, z) -> [B, P, 32]
+        (siren.py:479-499)."""
+        B, local_z_dim, _, _ = local_latents.shape
+        grid = xyz[:, :, [0, 2]].unsqueeze(1)
+        s = nn.functional.grid_sample(input=local_latents, grid=grid, mode="bilinear", align_corners=False, padding_mode="zeros")
+        return s.permute(0, 2, 3, 1).reshape(B, -1, local_z_dim)
+
+    @staticmethod
+    def get_local_coordinates(global_coords, local_grid_length, preserve_y=True):
+        """Global [-1, 1] coordinates -> coordinates inside the latent-grid cell, again in [-1, 1] (siren.py:501-518)."""
+        local = (global_coords + 1) / 2 * local_grid_length
+        local = local - (local - 0.5).round()
+        local = local * 2 - 1
+        if preserve_y:
+            return torch.cat([local[..., 0:1], global_coords[..., 1:2], local[..., 2:3]], dim=-1)
+        return local

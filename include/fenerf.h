@@ -160,6 +160,16 @@ int fenerf_model_export_packed(const FenerfModel* m, float* stream_dev, size_t n
 /* Bytes of [dev] scratch the FiLM pre-pass needs for a batch of B images. */
 size_t fenerf_film_workspace_bytes(const FenerfModel* m, int B);
 
+/* Per-point modulation -- replaces: SPATIALSIRENGRID.forward_with_frequencies_phase_shifts (siren.py:464-477), whose
+ * frequencies / phase shifts come from a mapping network evaluated on a local latent PER SAMPLE POINT (:440-462, FiLMLayer
+ * takes them unbroadcast, :119-122).  Like fenerf_siren_forward, but freq_geo / phase_geo are [B, P, n_geo*H] and freq_app /
+ * phase_app [B, P, n_color*H] (raw mapping outputs, '*15+30' inside).  The model must have FENERF_PREC_F32 (the FiLM blocks
+ * are read per lane by the exact kernel).  film_ws: fenerf_film_workspace_bytes_pointwise(m, B, P) bytes of [dev] scratch. */
+size_t fenerf_film_workspace_bytes_pointwise(const FenerfModel* m, int B, int64_t P);
+int fenerf_siren_forward_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                   const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                   const float* phase_app, float* out, void* film_ws, void* stream);
+
 /* replaces: <siren>.forward_with_frequencies_phase_shifts  (siren.py:1509-1530 / :1210-1229 / :227-244),
  *           incl. UniformBoxWarp (:181-187), sample_from_3dgrid (:314-330) and FiLMLayer (:113-123).
  * points [B,P,3], ray_dirs [B,P,3] (NULL = lock_view_dependence, i.e. (0,0,-1): generators.py:474-476),

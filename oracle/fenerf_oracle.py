@@ -224,11 +224,48 @@ def sample_from_3dgrid(coords, grid):
 
 
 # ---------------------------------------------------------------------------
+# f4 SPATIALSIRENGRID host pieces       siren/siren.py:479-518
+# ---------------------------------------------------------------------------
+def sample_local_latents(latents, xyz):
+    """latents [B,Cz,h,w], xyz [B,P,3] (box-warped) -> [B,P,Cz]: F.grid_sample(bilinear, align_corners=False, zeros padding)
+    at (x, z) -- x indexes the width axis, z the height axis (siren.py:479-499)."""
+    lat = np.asarray(latents, dtype=np.float64)
+    B, Cz, h, w = lat.shape
+    gx, gy = np.asarray(xyz)[..., 0].astype(np.float64), np.asarray(xyz)[..., 2].astype(np.float64)
+    ix, iy = ((gx + 1) * w - 1) / 2, ((gy + 1) * h - 1) / 2          # align_corners=False unnormalisation
+    x0, y0 = np.floor(ix), np.floor(iy)
+    out = np.zeros(gx.shape + (Cz,))
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            wgt = (ix - x0 if dx else x0 + 1 - ix) * (iy - y0 if dy else y0 + 1 - iy)
+            ok = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+            xc, yc = np.clip(xi, 0, w - 1).astype(np.int64), np.clip(yi, 0, h - 1).astype(np.int64)
+            for b in range(B):
+                out[b] += (lat[b][:, yc[b], xc[b]].T * (wgt[b] * ok[b])[:, None])
+    return out.astype(np.float32)
+
+
+def get_local_coordinates(global_coords, local_grid_length, preserve_y=True):
+    """siren.py:501-518; torch.round and np.round both round half to even."""
+    gc = np.asarray(global_coords, dtype=np.float32)
+    local = (gc + np.float32(1)) / np.float32(2) * np.float32(local_grid_length)
+    local = local - np.round(local - np.float32(0.5))
+    local = local * np.float32(2) - np.float32(1)
+    if preserve_y:
+        return np.concatenate([local[..., 0:1], gc[..., 1:2], local[..., 2:3]], -1)
+    return local
+
+
+# ---------------------------------------------------------------------------
 # a10 FiLMLayer                         siren/siren.py:113-123
 # ---------------------------------------------------------------------------
 def film_layer(x, w, b, freq, phase):
-    """sin(freq * (x W^T + b) + phase); freq/phase [B,H] broadcast over the point axis."""
+    """sin(freq * (x W^T + b) + phase); freq/phase [B,H] broadcast over the point axis, or [B,P,H] taken per point
+    (FiLMLayer skips the broadcast when the shapes agree, siren.py:119-122: SPATIALSIRENGRID's per-point modulation)."""
     y = x @ w.T.astype(x.dtype) + b.astype(x.dtype)
+    if freq.ndim == 3:
+        return np.sin(freq * y + phase)
     return np.sin(freq[:, None, :] * y + phase[:, None, :])
 
 
@@ -251,12 +288,12 @@ def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app=None
     feats = sample_from_3dgrid(x, P(sd["spatial_embeddings"])) if spec["grid_ch"] else None
     for i in range(spec["n_geo"]):
         x = film_layer(x, P(sd[f"network.{i}.layer.weight"]), P(sd[f"network.{i}.layer.bias"]),
-                       fg[:, i * H:(i + 1) * H], pg[:, i * H:(i + 1) * H])
+                       fg[..., i * H:(i + 1) * H], pg[..., i * H:(i + 1) * H])
     sigma = x @ P(sd["final_layer.weight"]).T + P(sd["final_layer.bias"])
     if spec["kind"] == "spatial":
         c = np.concatenate([dirs, x], -1)
         c = film_layer(c, P(sd["color_layer_sine.layer.weight"]), P(sd["color_layer_sine.layer.bias"]),
-                       fg[:, -H:], pg[:, -H:])
+                       fg[..., -H:], pg[..., -H:])
         rgb = _sigmoid(c @ P(sd["color_layer_linear.0.weight"]).T + P(sd["color_layer_linear.0.bias"]))
         return np.concatenate([rgb, sigma], -1)
     fa = P(freq_app) * dt.type(15) + dt.type(30)

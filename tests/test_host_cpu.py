@@ -245,3 +245,28 @@ def test_ema_shim_matches_the_reference_usage(tmp_path):
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_spatial_siren_grid_host_pieces_match_the_reference():
+    """fenerf_amd.siren.siren.SPATIALSIRENGRID: state-dict compatible with the reference module (minus its StyleGAN2 grid
+    generator), and its torch-side steps -- local-latent sampling, per-point mapping network, local coordinates -- reproduce
+    the reference's stage outputs; forward(z) says what is not built."""
+    g = load_golden("tiny_spatial_grid")
+    H = int(g["meta_H"])
+    mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4)
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w_")}
+    assert set(sd) == set(mod.state_dict()), set(sd) ^ set(mod.state_dict())
+    mod.load_state_dict(sd, strict=True)
+    pts, lat = torch.from_numpy(g["points"]), torch.from_numpy(g["latent_grid"])
+    sampled = mod.sample_local_latents(lat, mod.gridwarper(pts))
+    np.testing.assert_allclose(sampled.numpy(), g["sampled_latent"], atol=1e-6)
+    with torch.no_grad():
+        f, p = mod.mapping_network(sampled)
+    np.testing.assert_allclose(f.numpy(), g["freq"], atol=2e-6)
+    np.testing.assert_allclose(p.numpy(), g["phase"], atol=2e-6)
+    np.testing.assert_allclose(mod.get_local_coordinates(pts, 32, preserve_y=False).numpy(), g["local_coords"], atol=1e-7)
+    keep_y = mod.get_local_coordinates(pts, 32, preserve_y=True).numpy()
+    np.testing.assert_array_equal(keep_y[..., 1], g["points"][..., 1])
+    with pytest.raises(NotImplementedError):
+        mod(pts, torch.from_numpy(g["z"]), torch.from_numpy(g["dirs"]))
+    assert mod.precision == "f32" and mod._spec()["n_color"] == 1 and mod._spec()["n_geo"] == 8

@@ -313,3 +313,19 @@ def test_grad_oracle_matches_reference_autograd(name):
     worst = max(errs, key=errs.get)
     print(f"[oracle] {name}: worst relative gradient error {errs[worst]:.2e} ({worst})")
     assert errs[worst] <= 5e-3, (worst, errs[worst])      # the reference ran fp32 on the CPU through a frequency-30 SIREN
+
+
+def test_spatial_siren_grid_per_point_modulation():
+    """SPATIALSIRENGRID (siren.py:413-518): oracle restatement of local-latent sampling, local coordinates and the SIREN with one
+    FiLM block per point vs what the reference module produced."""
+    g = load_golden("tiny_spatial_grid")
+    H = int(g["meta_H"])
+    sampled = O.sample_local_latents(g["latent_grid"], g["points"] * np.float32(2 / 0.24))
+    np.testing.assert_allclose(sampled, g["sampled_latent"], atol=2e-6)
+    local = O.get_local_coordinates(g["points"], 32, preserve_y=False)
+    np.testing.assert_allclose(local, g["local_coords"], atol=1e-6)
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("w_")}
+    spec = dict(kind="spatial", hidden_dim=H, n_geo=8, n_color=1, grid_ch=0, n_label_layers=0, output_dim=4)
+    out = O.siren_forward(sd, spec, g["local_coords"], g["dirs"], g["freq"], g["phase"])
+    np.testing.assert_allclose(out[..., :3], g["out"][..., :3], atol=2e-5)
+    np.testing.assert_allclose(out[..., 3], g["out"][..., 3], atol=1e-4, rtol=1e-4)

@@ -544,6 +544,38 @@ def json_dumps_curriculum(curriculum):
     return json.dumps({(f"int:{k}" if isinstance(k, int) else k): v for k, v in curriculum.items()}, sort_keys=True)
 
 
+def run_spatial_grid_case(refs, name="tiny_spatial_grid"):
+    """SPATIALSIRENGRID (siren.py:413-518): per-point FiLM modulation from a 2-D grid of local latents.  The reference module
+    runs here as is (its StyleGenerator2D falls back to native torch ops); recorded: its render / mapping weights, the latent
+    grid its generator produced for two z (an INPUT of the drop-in), points, directions and every stage of forward()."""
+    siren_mod = refs[0]
+    torch.manual_seed(31)
+    H = 32
+    ref = siren_mod.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4)
+    B, P = 2, 70
+    z = torch.randn(B, 16)
+    g = torch.Generator().manual_seed(32)
+    pts = (torch.rand(B, P, 3, generator=g) - 0.5) * 0.24
+    dirs = torch.nn.functional.normalize(torch.randn(B, P, 3, generator=g), dim=-1)
+    out = {}
+    with torch.no_grad():
+        latent_grid = ref.grid_latent_network(z)
+        input_grid = ref.gridwarper(pts)
+        sampled = ref.sample_local_latents(latent_grid, input_grid)
+        freq, phase = ref.mapping_network(sampled)
+        local = ref.get_local_coordinates(global_coords=pts, local_grid_length=32, preserve_y=False)
+        res = ref(pts, z, dirs)
+        res2 = ref.forward_with_frequencies_phase_shifts(local, freq, phase, dirs, box_warp=False)
+    assert torch.equal(res, res2)
+    for n_, p_ in ref.named_parameters():
+        if not n_.startswith("grid_latent_network"):
+            out["w_" + n_] = np_(p_)
+    out.update(z=np_(z), latent_grid=np_(latent_grid), points=np_(pts), dirs=np_(dirs), sampled_latent=np_(sampled), freq=np_(freq),
+               phase=np_(phase), local_coords=np_(local), out=np_(res), meta_H=H)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: out {tuple(res.shape)}, per-point freq {tuple(freq.shape)}")
+
+
 def run_curriculums(refs, name="curriculums"):
     """tests/golden/curriculums.json: the three curriculum dicts the path is quoted on, as the reference's curriculums.py
     defines them (integer stage keys spelled "int:<step>", tuples as lists; `extract_metadata` etc. are behaviour, not data,
@@ -587,6 +619,7 @@ def main(out_dir=None):
     run_mapping_and_full(refs, "tiny_texture_z_full")
     run_caller_helpers()
     run_multiview_case(refs)
+    run_spatial_grid_case(refs)
     run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
