@@ -19,7 +19,46 @@ import torch.nn as nn
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
 from .autograd import CompositeFunction, HierarchicalRenderFunction, MergeCompositeFunction
+from . import volumetric_rendering as VR
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
+
+
+def _rng_state(device):
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    return torch.cuda.get_rng_state(device) if device.type == "cuda" else torch.get_rng_state()
+
+
+def _set_rng_state(device, state):
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if device.type == "cuda":
+        torch.cuda.set_rng_state(state, device)
+    else:
+        torch.set_rng_state(state)
+
+
+def _avg_cache_lookup(gen, nets):
+    """generate_avg_frequencies cache (see DoubleImplicitGenerator3d.generate_avg_frequencies).  Key: the mapping networks'
+    parameter versions / storages, the device, and the device generator's state before the draws.  Only with the default
+    random source (recorded draws in tests are replayed as given).  Writes through `param.data` bypass version counters --
+    the same caveat, and the same remedy (a train()/eval() switch or invalidate_native()), as for the packed render weights."""
+    gen.__dict__.pop("_avg_pending", None)
+    if not isinstance(gen.draws, VR.TorchDraws):
+        return None
+    dev = gen.siren.device
+    params = [p for net in nets for p in net.parameters()]
+    key = (str(dev), tuple((p._version, p.data_ptr()) for p in params), _rng_state(dev).numpy().tobytes())
+    cached = gen.__dict__.get("_avg_cache")
+    if cached is not None and cached[0] == key:
+        _set_rng_state(dev, cached[1])
+        return cached[2]
+    gen.__dict__["_avg_pending"] = key
+    return None
+
+
+def _avg_cache_store(gen, values):
+    key = gen.__dict__.pop("_avg_pending", None)
+    if key is not None:
+        gen.__dict__["_avg_cache"] = (key, _rng_state(gen.siren.device).clone(), values)
 
 
 class _Generator3dBase(nn.Module):
@@ -28,6 +67,12 @@ class _Generator3dBase(nn.Module):
     draws = _DEFAULT_DRAWS   # random source; tests replace it with RecordedDraws
 
     # ---- helpers -------------------------------------------------------------------------------------
+    def __getstate__(self):            # pickled generators (the reference's checkpoint format) carry no caches
+        st = self.__dict__.copy()
+        st.pop("_avg_cache", None)
+        st.pop("_avg_pending", None)
+        return st
+
     def _render(self, film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                 hierarchical_sample, sample_dist, lock_view_dependence, kwargs, use_fill, third):
         """film = (freq_geo, phase_geo, freq_app, phase_app) raw mapping outputs.
@@ -177,7 +222,15 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
         self.generate_avg_frequencies()
 
     def generate_avg_frequencies(self):
-        """Mean FiLM parameters over 10 000 random latents (generators.py:530-543); draws randn twice."""
+        """Mean FiLM parameters over 10 000 random latents (generators.py:530-543); draws randn twice.
+        The reference redoes this on EVERY staged_forward.  It is a pure function of (mapping-network weights, generator state
+        before the two draws), so the result is cached under exactly that key and, on a hit, the generator is advanced to the
+        state the draws would have left it in: a seeded caller (render_multiview_images_double_semantic.py:77 re-seeds per view)
+        gets bit-identical values and identical RNG consumption without re-running 2 x 10 000 latents."""
+        hit = _avg_cache_lookup(self, (self.siren.geo_mapping_network, self.siren.app_mapping_network))
+        if hit is not None:
+            (self.avg_frequencies_geo, self.avg_phase_shifts_geo, self.avg_frequencies_app, self.avg_phase_shifts_app) = hit
+            return hit
         z_geo = self.draws.randn((10000, self.z_geo_dim), self.siren.device)
         z_app = self.draws.randn((10000, self.z_app_dim), self.siren.device)
         with torch.no_grad():
@@ -187,7 +240,9 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
         self.avg_phase_shifts_geo = phase_shifts_geo.mean(0, keepdim=True)
         self.avg_frequencies_app = frequencies_app.mean(0, keepdim=True)
         self.avg_phase_shifts_app = phase_shifts_app.mean(0, keepdim=True)
-        return self.avg_frequencies_geo, self.avg_phase_shifts_geo, self.avg_frequencies_app, self.avg_phase_shifts_app
+        out = (self.avg_frequencies_geo, self.avg_phase_shifts_geo, self.avg_frequencies_app, self.avg_phase_shifts_app)
+        _avg_cache_store(self, out)
+        return out
 
     def forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                 hierarchical_sample, sample_dist=None, lock_view_dependence=False, **kwargs):
@@ -346,12 +401,17 @@ class ImplicitGenerator3d(_Generator3dBase):
         self.generate_avg_frequencies()
 
     def generate_avg_frequencies(self):
-        """(generators.py:121-130)"""
+        """(generators.py:121-130); cached like DoubleImplicitGenerator3d.generate_avg_frequencies"""
+        hit = _avg_cache_lookup(self, (self.siren.mapping_network,))
+        if hit is not None:
+            self.avg_frequencies, self.avg_phase_shifts = hit
+            return hit
         z = self.draws.randn((10000, self.z_dim), self.siren.device)
         with torch.no_grad():
             frequencies, phase_shifts = self.siren.mapping_network(z)
         self.avg_frequencies = frequencies.mean(0, keepdim=True)
         self.avg_phase_shifts = phase_shifts.mean(0, keepdim=True)
+        _avg_cache_store(self, (self.avg_frequencies, self.avg_phase_shifts))
         return self.avg_frequencies, self.avg_phase_shifts
 
     def _film(self, frequencies, phase_shifts):

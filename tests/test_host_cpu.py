@@ -270,3 +270,34 @@ def test_spatial_siren_grid_host_pieces_match_the_reference():
     with pytest.raises(NotImplementedError):
         mod(pts, torch.from_numpy(g["z"]), torch.from_numpy(g["dirs"]))
     assert mod.precision == "f32" and mod._spec()["n_color"] == 1 and mod._spec()["n_geo"] == 8
+
+
+def test_avg_frequency_cache_keeps_values_and_rng_consumption():
+    """generate_avg_frequencies (generators.py:530-543, re-done by every staged_forward) is cached on (mapping weights, generator
+    state before the draws): a re-seeded call returns bit-identical means AND leaves the generator where the two 10000-latent draws
+    would have; another seed or changed weights recompute."""
+    import functools
+    import io
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.SIRENBASELINESEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.device = torch.device("cpu"); gen.siren.device = gen.device
+    calls = []
+    orig = gen.siren.geo_mapping_network.forward
+    gen.siren.geo_mapping_network.forward = lambda z: (calls.append(1), orig(z))[1]
+    torch.manual_seed(3); a = [t.clone() for t in gen.generate_avg_frequencies()]; ra = torch.rand(3)
+    torch.manual_seed(3); b = [t.clone() for t in gen.generate_avg_frequencies()]; rb = torch.rand(3)
+    assert len(calls) == 1 and all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(ra, rb)
+    torch.manual_seed(4); c = [t.clone() for t in gen.generate_avg_frequencies()]
+    assert len(calls) == 2 and not torch.equal(c[0], a[0])
+    with torch.no_grad():
+        next(gen.siren.geo_mapping_network.parameters()).add_(0.1)
+    torch.manual_seed(4); d = gen.generate_avg_frequencies()
+    assert len(calls) == 3 and not torch.equal(d[0], c[0])
+    gen.draws = VR.RecordedDraws([np.zeros((10000, 8), np.float32)] * 2)          # recorded draws are replayed, never cached
+    gen.generate_avg_frequencies()
+    assert len(calls) == 4 and not gen.draws.arrays
+    gen.draws = VR._DEFAULT_DRAWS
+    del gen.siren.geo_mapping_network.forward
+    buf = io.BytesIO()
+    torch.save(gen, buf)
+    buf.seek(0)
+    assert "_avg_cache" not in torch.load(buf, weights_only=False).__dict__
