@@ -37,14 +37,14 @@ PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
 # HBM-side bytes per SIREN launch at the default workload (393,216 points).  A PMC pass cannot run inside this process, so the
 # figures are those of the committed rocprofv3 passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/gpu_session.sh pmc):
 TRAFFIC = {
-    "source": "profiles/r01_pmc_siren16s_f16x3_v6.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-    "fetch_raw_bytes": 177.07e6,        # FETCH_SIZE x 1024, as reported
-    "fetch_x2_bytes": 354.14e6,         # MI355X_MICROARCH.md HBM: gfx950 reports 1/2 of wide coalesced reads; upper bound here
+    "source": "profiles/r02_pmc_siren16w_f16x3.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/gpu_r2.sh pmc)",
+    "fetch_raw_bytes": 182.72e6,        # FETCH_SIZE x 1024, as reported
+    "fetch_x2_bytes": 365.43e6,         # MI355X_MICROARCH.md HBM: gfx950 reports 1/2 of wide coalesced reads; upper bound here
     "write_bytes": 34.60e6,             # = 393,216 points x 22 channels x 4 B exactly
     # compulsory bytes of one launch: outputs 34.6 MB + z 1.6 MB + rays 0.4 MB + weight stream 2.75 MB
     "algorithmic_bytes": 34.60e6 + 1.57e6 + 0.39e6 + 2.75e6,
     "note": "excess over algorithmic = the 8 x 128-B trilinear corner fetches per point (113 MB grid, TCC hit 95.6 %); "
-            "MFMA-bound kernel, 0.15-0.27 TB/s: context, not the limiter",
+            "MFMA-bound kernel, 0.15-0.28 TB/s: context, not the limiter",
 }
 
 
