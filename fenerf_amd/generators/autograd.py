@@ -96,6 +96,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         fine = out2[B:, :P].reshape(B * R, N, C)
         rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
         ctx.module, ctx.nat, ctx.opts, ctx.dims = module, nat, opts, (B, R, N, P, Pp)
+        ctx.pack_generation = nat.pack_generation
         empty = origins.new_empty(0)
         ctx.save_for_backward(pts2, rd if rd is not None else empty, fg, pg, fa, pa, out2, tape2, tape_e2 if G else empty, z_f, zc,
                               noise_f if noise_f is not None else empty, *params)
@@ -106,6 +107,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, _g_depth):
         module, nat, opts = ctx.module, ctx.nat, ctx.opts
+        _siren_autograd.check_same_weights(ctx, nat)
         B, R, N, P, Pp = ctx.dims
         pts2, rd, fg, pg, fa, pa, out2, tape2, tape_e2, z_f, zc, noise_f, *params = ctx.saved_tensors
         C = nat.C

@@ -39,8 +39,10 @@ class NativeModel:
         self.C = spec["output_dim"]
         self.box_scale = 2 / 0.24       # UniformBoxWarp(0.24), siren.py:181-187 (what _lib.make_desc sets)
         self._ws = {}
+        self.pack_generation = 0      # bumped by every re-pack: autograd nodes check that forward and backward saw the same weights
 
     def update(self, sd):
+        self.pack_generation += 1
         with torch.cuda.device(self.device):
             d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
@@ -197,6 +199,7 @@ class NativeModel:
         grid = p.get("spatial_embeddings")
         grid = grid.contiguous() if grid is not None else None
         r = self._repack_maps()
+        self.pack_generation += 1
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().fenerf_model_repack(self._h, _ptr(flat), flat.numel(), C.byref(r), _ptr(grid), _stream()))
 

@@ -121,6 +121,16 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     return total, d_e_full
 
 
+def check_same_weights(ctx, nat):
+    """The backward kernels read the model's resident backward stream, not a snapshot: if the model was re-packed between
+    forward and backward (an optimizer step and a new render of the same module before .backward()), refuse instead of
+    differentiating with the wrong weights."""
+    if nat.pack_generation != ctx.pack_generation:
+        raise RuntimeError("fenerf_amd: the generator's weights were re-packed between this render's forward and its backward "
+                           "(parameters changed and the module rendered again before .backward()); call backward before the "
+                           "next optimizer step + render")
+
+
 class SirenFunction(torch.autograd.Function):
     """out = siren(points, dirs; film params, weights).  Non-tensor arg `module` supplies the native model and roles."""
 
@@ -130,6 +140,7 @@ class SirenFunction(torch.autograd.Function):
         nat = module.native_differentiable(points.device)
         out, tape, tape_e = nat.siren_forward_save(points, dirs, fg, pg, fa, pa)
         ctx.module, ctx.nat = module, nat
+        ctx.pack_generation = nat.pack_generation
         ctx.has_dirs = dirs is not None
         ctx.save_for_backward(points, dirs if dirs is not None else points.new_empty(0), fg, pg, fa, pa, out, tape,
                               tape_e if tape_e is not None else points.new_empty(0), *params)
@@ -139,6 +150,7 @@ class SirenFunction(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_out):
         module, nat = ctx.module, ctx.nat
+        check_same_weights(ctx, nat)
         points, dirs, fg, pg, fa, pa, out, tape, tape_e, *params = ctx.saved_tensors
         roles = module._roles(params)
         spec = nat.spec

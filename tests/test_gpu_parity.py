@@ -1065,6 +1065,25 @@ def test_generator_gradient_end_to_end(precision):
     assert worst <= 5e-4
 
 
+def test_backward_refuses_weights_repacked_after_the_forward():
+    """The backward kernels read the model's resident backward stream: a re-pack between a render's forward and its backward
+    (optimizer step + another render of the same module before .backward()) is refused, not silently differentiated."""
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=50.0)
+    rng = np.random.default_rng(2)
+    pts = T(rng.uniform(-0.1, 0.1, (1, 64, 3)).astype(np.float32))
+    dirs = T(rng.normal(size=(1, 64, 3)).astype(np.float32))
+    film = {k: T(v) for k, v in proc.film_params(spec, 1, seed=4).items()}
+    call = lambda: mod.forward_with_frequencies_phase_shifts(pts, film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], dirs)
+    out = call()
+    out2 = call()                                   # a second render of unchanged weights re-packs nothing
+    out2.sum().backward()
+    with torch.no_grad():
+        next(iter(mod._render_params())).add_(1e-3)   # "optimizer.step()"
+    call()                                          # ... and a new render: the streams are rebuilt on the device
+    with pytest.raises(RuntimeError, match="re-packed"):
+        out.sum().backward()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_chunked_backward_equals_one_pass(precision):
     """The backward runs chain + weight-gradient kernels per chunk of points (siren/autograd.py: bounded dtheta); chunk results
