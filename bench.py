@@ -76,34 +76,6 @@ def _oracle_run(spec, sd, film, S, N, hier, seed):
     return time.perf_counter() - t0
 
 
-def _oracle_run_torch(spec, sd_t, film, S, N, seed):
-    """The same render with the SIREN passes (94 % of the CPU time) as multi-threaded torch CPU ops in fp32 -- the statements of
-    oracle/fenerf_oracle_grad.py, i.e. what the reference's pure-PyTorch CPU path executes; rays, compositing and resampling
-    stay the numpy oracle's."""
-    import torch as th
-    from oracle import fenerf_oracle as O
-    from oracle import fenerf_oracle_grad as OG
-    B, R = 1, S * S
-    rng = np.random.default_rng(seed)
-    u_jitter = rng.random((B, R, N, 1), dtype=np.float32)
-    u_fine = rng.random((B * R, N), dtype=np.float32)
-    theta, phi = np.full((B, 1), np.pi / 2 + 0.1, np.float32), np.full((B, 1), np.pi / 2 - 0.05, np.float32)
-    t0 = time.perf_counter()
-    pts_cam, z_vals, d_cam = O.get_initial_rays_trig(B, N, 12, (S, S), 0.88, 1.12, np.float32)
-    pts, z_vals, dirs, origins, _, _ = O.transform_sampled_points(pts_cam, z_vals, d_cam, u_jitter, theta, phi)
-    dexp = th.from_numpy(np.ascontiguousarray(np.broadcast_to(dirs[:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)))
-    ft = [th.from_numpy(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app")]
-    with th.no_grad():
-        coarse = OG.siren_forward(sd_t, spec, th.from_numpy(pts.reshape(B, R * N, 3)), dexp, *ft).numpy().reshape(B, R, N, -1)
-        _, _, w = O.fancy_integration(coarse, z_vals, clamp_mode="relu")
-        fine_z = O.fine_z_from_coarse(w, z_vals, u_fine)
-        fpts = (origins[:, :, None, :] + dirs[:, :, None, :] * fine_z).astype(np.float32)
-        fine = OG.siren_forward(sd_t, spec, th.from_numpy(fpts.reshape(B, R * N, 3)), dexp, *ft).numpy().reshape(B, R, N, -1)
-    all_out, all_z = O.merge_sorted(fine, coarse, fine_z, z_vals)
-    O.fancy_integration(all_out, all_z, clamp_mode="relu")
-    return time.perf_counter() - t0
-
-
 def cpu_baseline(spec, sd, film, seed, full=True):
     """Oracle (numpy port of the reference CPU path, validated against the reference's own outputs in tests/) on the GPU box's
     host cores: BASELINE.md §5 = 1 warm-up + 3 timed runs per shape; shapes = configs[0] (64x64, 12 coarse), configs[1] (128x128,
@@ -122,22 +94,6 @@ def cpu_baseline(spec, sd, film, seed, full=True):
                sample=f"numpy oracle render_forward on one image per shape, H=256 + 96^3 grid, 1 warm-up + {len(res[0]['seconds'])} timed "
                       f"run(s), median (BLAS GEMMs use all {cores} host cores, elementwise ops 1); value = {res[0]['shape']}",
                runs=res)
-    if full:
-        try:       # a second, stronger port of the same shape: the SIREN passes as multi-threaded torch CPU ops (what the reference's CPU path runs)
-            torch.set_num_threads(cores)
-            sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
-            _oracle_run_torch(spec, sd_t, film, 128, 24, seed)
-            ts = [_oracle_run_torch(spec, sd_t, film, 128, 24, seed + 1 + i) for i in range(3)]
-            tp = {"shape": "configs[1]: 128x128 rays, 24+24 samples, SIREN passes as torch CPU fp32 ops on all cores", "rays": 128 * 128,
-                  "seconds": [round(t, 3) for t in ts], "rays_per_s": 128 * 128 / float(np.median(ts))}
-            out["runs"].append(tp)
-            if tp["rays_per_s"] > out["value"]:
-                out["value"] = tp["rays_per_s"]
-                out["sample"] = (f"port of the reference CPU path, SIREN passes as torch CPU fp32 ops on all {cores} host cores, rays / compositing / "
-                                 f"resampling by the numpy oracle; one 128x128 image, 24+24 samples, 1 warm-up + 3 timed runs, median "
-                                 f"(the all-numpy port of the same image is listed in `runs`)")
-        except Exception as e:
-            out["torch_port_error"] = f"{type(e).__name__}: {e}"
     return out
 
 
