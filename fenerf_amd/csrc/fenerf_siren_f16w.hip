@@ -28,6 +28,13 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 
+// structural alternative kept for A/B timing (numerically exact): both waves of a SIMD issue their LDS-DMA at the same point
+#ifdef EXP_W_DMA_IN_PHASE
+#define W_DMA_IN_PHASE
+#endif
+#ifdef EXP_W_BARRIER_EVERY_CHUNK
+#define W_BARRIER_EVERY_CHUNK
+#endif
 // composite timing experiments
 #ifdef EXP_W_NOMFMA_NODMA
 #define EXP_W_NOMFMA
@@ -110,6 +117,7 @@ struct WStream {
   unsigned voff;               // this lane's byte offset inside a chunk (the re-tiling permutation)
   unsigned ring_lds;           // LDS byte address of ring slot 0 + wave * 1024 (for M0)
   const char* ring_lane;       // generic pointer to ring slot 0 + lane * 16 (for the ds_reads)
+  bool early;                  // waves 0-3: DMA at the top of a chunk step; waves 4-7: half a step later (ws_step)
 };
 
 __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
@@ -158,18 +166,45 @@ __device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
   return a;
 }
 
-// Top of pipeline step i of a stage: issue chunk i + D, make chunk i + 1 visible to every wave.
-__device__ __forceinline__ void ws_step(WStream& w, int i) {
-  ws_issue(w, (i + DPF) % NSLOT);
-#ifdef EXP_W_HALFDMA
-  WAIT_VMCNT(DPF / 2 - 1);
+// Top of pipeline step i of a stage: (waves 0-3) issue chunk i + D, make chunk i + 1 visible to every wave.
+// The two waves of a SIMD (w and w + 4) issue their LDS-DMA half a chunk step apart -- waves 4-7 at the top of the chunk's
+// second k32-step (ws_issue_late): an LDS-DMA blocks its wave's issue for 60-185 cycles, and issued by both waves at the same
+// point of the same program those stalls coincide and the matrix pipe idles under both.  Waves 4-7 therefore have one DMA less
+// in flight at the barrier, and everybody waits with the stricter count (chunk i + 2 of waves 0-3 was issued four steps ago).
+__device__ __forceinline__ void ws_step(WStream& w, int i, bool early) {
+#ifdef W_BARRIER_EVERY_CHUNK
+  const bool sync = true;
 #else
-  WAIT_VMCNT(DPF - 1);                // this wave's operand of chunk i + 1 has landed (loads retire in order)
+  // ONE barrier per TWO chunk steps (even i; stages are whole ring revolutions, so the parity of i is the parity of the global
+  // step).  Chunk i + 1 is read during step i and chunk i + 2 during the odd step i + 1, so barrier i publishes both: every wave
+  // first waits for its own KiB of chunks <= i + 2 (chunks i + 1 .. i + D - 1 are in flight here: vmcnt(D - 3)).  The DMA of
+  // step i (chunk i + D, into the slot of chunk i - 2) is issued BEHIND the barrier: every wave is then past step i - 1; the
+  // DMA of the odd step i + 1 overwrites chunk i - 1, consumed by every wave before it arrived at barrier i.  (The barrier
+  // costs 8 % of the kernel at full clock, profiles/r02_siren16w_experiments.md.)
+  const bool sync = (i & 1) == 0;
+#endif
+  if (sync) {
+#ifdef EXP_W_HALFDMA
+    WAIT_VMCNT(DPF / 2 - 1);
+#elif defined(W_BARRIER_EVERY_CHUNK)
+    WAIT_VMCNT(DPF - 2);          // chunks i + 1 .. i + D - 1 in flight, chunk i + 1 must have landed
+#else
+    WAIT_VMCNT(DPF - 3);
 #endif
 #ifndef EXP_W_NOBARRIER
-  __builtin_amdgcn_s_barrier();       // ... and every other wave's
+    __builtin_amdgcn_s_barrier();
 #endif
+  }
   LDS_FENCE();
+#ifndef W_DMA_IN_PHASE
+  if (early)
+#endif
+    ws_issue(w, (i + DPF) % NSLOT);
+}
+__device__ __forceinline__ void ws_issue_late(WStream& w, int i, bool early) {
+#ifndef W_DMA_IN_PHASE
+  if (!early) ws_issue(w, (i + DPF) % NSLOT);
+#endif
 }
 
 // 6 MFMAs of one k32-step, the two row tiles interleaved (dependent MFMAs are 2 apart): wl*xh + wh*xl + wh*xh
@@ -206,10 +241,13 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
 #ifdef EXP_W_NOEPI
   half2 hp = {(_Float16)(f.x + acc[rt][2 * pc + 0]), (_Float16)p.x}, lp = {(_Float16)(f.y + acc[rt][2 * pc + 1]), (_Float16)p.y};
 #else
-  const float v0 = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x)) * F16_ACT_SCALE;
-  const float v1 = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y)) * F16_ACT_SCALE;
-  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-  half2 hp = {h0, h1}, lp = {(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1)};
+  // x = sin(2 pi theta); carried as hi = rn_f16(16 x), lo = rn_f16(16 x - hi).  Written as fmas on x so that each half is ONE
+  // v_fma_mix{lo,hi}_f16 (fp32 fma, one rounding to f16; 16 x and 16 x - hi are exact in fp32, so the values are those of the
+  // mul / convert / subtract / convert spelling): 8 VALU per two values instead of 14.
+  const float s0 = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x));
+  const float s1 = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y));
+  const _Float16 h0 = (_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, 0.f), h1 = (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, 0.f);
+  half2 hp = {h0, h1}, lp = {(_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, -(float)h0), (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, -(float)h1)};
 #endif
   // pinned here: without a use in this block the compiler sinks the whole epilogue behind the stage (the outputs are only
   // consumed after it), keeping 8 n-blocks of accumulators + FiLM values alive -- and spilling them into the stream loop
@@ -238,40 +276,42 @@ struct APipe { AK c, n; };
 struct FilmQ2 { FilmQ q[4]; };
 template <class BOP, class LOADQ, class PIECE>
 __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& ws, int i, int sp0, BOP bop, LOADQ loadq, PIECE piece) {
-  ws_step(ws, i);
+  ws_step(ws, i, ws.early);
+  FilmQ2 fq;
 #pragma unroll
   for (int spl = 0; spl < 2; ++spl) {
-    FilmQ2 fq;
-    loadq(spl, fq);                      // FiLM parameters of this k32-step's epilogue piece FIRST: LDS returns in order, a
-                                         // read behind the A operands could only be waited for together with them
+    if (spl == 1) ws_issue_late(ws, i, ws.early);
+    // FiLM parameters of the chunk's epilogue pieces: read at the top of k32-step 0 (BEFORE the A operands: LDS returns in
+    // order, a read behind them could only be waited for together with them), used behind k32-step 1's MFMAs -- a read
+    // issued in the k32-step that consumes it put one LDS round trip (~190 cycles of s_waitcnt per chunk step and wave,
+    // SQ_WAIT_ANY) into every chunk step.
+    if (spl == 0) loadq(fq);
     const AK nn = ws_read(ws, (i + 1) % NSLOT, spl);
     __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
     half8 bh, bl;
     if (bop(sp0 + spl, bh, bl)) kstep_mfma(acc, a.c, bh, bl);
-    piece(spl, fq);
+    if (spl == 1) piece(fq);
     a.c = a.n;
     a.n = nn;
-    __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue piece where they are written
+    __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue pieces where they are written
   }
 }
 // Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's k32-steps.
 __device__ __forceinline__ void chunk_skip(APipe& a, WStream& ws, int i) {
-  ws_step(ws, i);
+  ws_step(ws, i, ws.early);
+  ws_issue_late(ws, i, ws.early);
   a.c = ws_read(ws, (i + 1) % NSLOT, 0);
   a.n = ws_read(ws, (i + 1) % NSLOT, 1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// epilogue pieces of the previous n-block handled by chunk qc of a body of QB chunks, k32-step slot spl: 4 pieces over
-// min(QB, 4) chunks x 2 slots
+// epilogue pieces of the previous n-block handled by chunk qc of a body of QB chunks: 4 pieces over min(QB, 4) chunks
 template <int QB>
-__device__ __forceinline__ void piece_range(int qc, int spl, int& p0, int& p1) {
+__device__ __forceinline__ void piece_range(int qc, int& p0, int& p1) {
   constexpr int QBE = QB < 4 ? QB : 4;
   if (qc >= QBE) { p0 = p1 = 0; return; }
-  const int c0 = 4 * qc / QBE, c1 = 4 * (qc + 1) / QBE;   // this chunk's pieces
-  const int mid = (c1 - c0 + 1) / 2 + c0;                 // first slot gets the larger half
-  p0 = spl == 0 ? c0 : mid;
-  p1 = spl == 0 ? mid : c1;
+  p0 = 4 * qc / QBE;
+  p1 = 4 * (qc + 1) / QBE;
 }
 
 template <int H, bool GRID>
@@ -328,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   ws.g_next = g_stream;
   ws.ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 1024);
   ws.ring_lane = ring + lane * 16;
+  ws.early = wave < NWAVE / 2;
 
   // ---- prime the shared stream: chunks 0..D-1 in flight, first k32-step of chunk 0 in registers
 #pragma unroll
@@ -489,18 +530,18 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < C0_QB; ++qc) {
-            chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](int spl, FilmQ2& fq) {
+            chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
-                piece_range<C0_QB>(qc, spl, p0, p1);
+                piece_range<C0_QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
                   if (pc >= p0 && pc < p1) fq.q[pc] = epi_load<FILM_F / 4>(nb - 1, pc, ff);
               }
-            }, [&](int spl, const FilmQ2& fq) {
+            }, [&](const FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
-                piece_range<C0_QB>(qc, spl, p0, p1);
+                piece_range<C0_QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
                   if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
@@ -520,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
             return false;
           };
 #pragma unroll
-          for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](int, FilmQ2&) {}, [](int, const FilmQ2&) {});
+          for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
           for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
           const int lane_o = opaque(lane);
@@ -548,18 +589,18 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < QB; ++qc) {
-            chunk_step(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](int spl, FilmQ2& fq) {
+            chunk_step(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
-                piece_range<QB>(qc, spl, p0, p1);
+                piece_range<QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
                   if (pc >= p0 && pc < p1) fq.q[pc] = epi_load<FILM_F / 4>(nb - 1, pc, ff);
               }
-            }, [&](int spl, const FilmQ2& fq) {
+            }, [&](const FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
-                piece_range<QB>(qc, spl, p0, p1);
+                piece_range<QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
                   if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
@@ -583,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
         return false;
       };
 #pragma unroll
-      for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](int, FilmQ2&) {}, [](int, const FilmQ2&) {});
+      for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
       for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
       const int lane_o = opaque(lane);

@@ -48,7 +48,7 @@ wexp)
     if [ -z "$v" ]; then lib=fenerf_amd/libfenerf_hip.so; else lib=fenerf_amd/libexp_$v.so; fi
     [ -f $lib ] || continue
     echo -n "variant ${v:-baseline}: "
-    FENERF_LIB=$PWD/$lib timeout 200 python bench.py --steps 10 --warmup 2 $Q 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('kernel_ms', round(d['roofline']['kernel_ms'],4), 'rays/s', int(d['value']))"
+    FENERF_BENCH_ZERO_WEIGHTS=${ZERO:-} FENERF_LIB=$PWD/$lib timeout 200 python bench.py --steps 10 --warmup 2 $Q 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('kernel_ms', round(d['roofline']['kernel_ms'],4), 'rays/s', int(d['value']))"
   done > gpurun_out/wexp.log 2>&1
   cat gpurun_out/wexp.log ;;
 dist2)
