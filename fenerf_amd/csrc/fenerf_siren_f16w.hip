@@ -8,7 +8,9 @@
 //     stream: 51-53 % matrix-pipe utilisation.
 //   * Here a workgroup is 8 waves = 2 per SIMD, each owning 16 points on v_mfma_f32_16x16x32_f16.  Activations halve to
 //     64 (x) + 64 (y) registers per wave, everything fits 256 registers, and the SIMD's scheduler issues one wave's MFMAs
-//     under the other's DMA / LDS / VALU / barrier time.
+//     under the other's DMA / LDS / VALU / barrier time.  One workgroup barrier per two 8-KiB chunks; A operands are read
+//     from the ring two k32-steps ahead, FiLM parameters one.  Measurements, the timing experiments (`make wexp`) and why
+//     the kernel ends up 4-5 % (not 30 %) ahead of the 32-point one: DESIGN.md 4.1c, profiles/r02_siren16w_experiments.md.
 //
 // One stream, two consumers.  The packer lays an entry out for the 32x32x16 MFMA (lane (row, h), 8 halves = k slots of
 // lane-half h).  A 16x16x32 A operand (16 rows x 32 k) is the union of halves of TWO consecutive k16 entries, so the
@@ -166,11 +168,11 @@ __device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
   return a;
 }
 
-// Top of pipeline step i of a stage: (waves 0-3) issue chunk i + D, make chunk i + 1 visible to every wave.
+// Top of pipeline step i of a stage: make the next chunks visible to every wave, then (waves 0-3) issue chunk i + D.
 // The two waves of a SIMD (w and w + 4) issue their LDS-DMA half a chunk step apart -- waves 4-7 at the top of the chunk's
 // second k32-step (ws_issue_late): an LDS-DMA blocks its wave's issue for 60-185 cycles, and issued by both waves at the same
-// point of the same program those stalls coincide and the matrix pipe idles under both.  Waves 4-7 therefore have one DMA less
-// in flight at the barrier, and everybody waits with the stricter count (chunk i + 2 of waves 0-3 was issued four steps ago).
+// point of the same program those stalls coincide and the matrix pipe idles under both (+1.3 % on real weights, +2.8 % at
+// full clock, profiles/r02_siren16w_experiments.md section 5).
 __device__ __forceinline__ void ws_step(WStream& w, int i, bool early) {
 #ifdef W_BARRIER_EVERY_CHUNK
   const bool sync = true;
