@@ -422,7 +422,8 @@ extern "C" size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_p
 extern "C" size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points) {
   if (!m || total_points <= 0) return 0;
   const long long tiles = (total_points + 31) / 32;
-  return (size_t)m->L * m->H * (size_t)tiles * 32 + (size_t)film_tile_floats(tiles, m->L, m->H);
+  // d theta dump + the chain kernel's FiLM sums, one [L][2][H] block per 16-point tile (the 32-point kernels use every other one's worth)
+  return (size_t)m->L * m->H * (size_t)tiles * 32 + (size_t)film_tile_floats(2 * tiles, m->L, m->H);
 }
 
 extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,

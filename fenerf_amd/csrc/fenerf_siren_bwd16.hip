@@ -361,6 +361,7 @@ static int launch_bwd16_t(const FenerfModel* m, const SirenBwdParams& p, void* s
 
 int launch_siren_backward16(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
+  if (bwd16w_enabled()) return launch_siren_backward16w(m, p, stream);   // 16-point waves, shared stream (fenerf_siren_bwd16w.hip)
   const bool g = m->grid_ch != 0;
   switch (m->H) {
     case 32: return g ? launch_bwd16_t<32, true>(m, p, stream) : launch_bwd16_t<32, false>(m, p, stream);

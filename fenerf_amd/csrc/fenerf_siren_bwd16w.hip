@@ -1,0 +1,636 @@
+// Backward chain of the FiLM-SIREN radiance field on the bf16 matrix pipe, 16-point waves, two waves per SIMD.
+//
+// Same maths, stream, tape, d(theta) dump and d(grid feature) output as siren_bwd16_kernel (fenerf_siren_bwd16.hip; reference:
+// torch autograd through siren/siren.py:1509-1530), in the execution shape of the no-grad forward (fenerf_siren_f16w.hip):
+//
+//   * a workgroup is 8 waves = 2 per SIMD, each owning 16 points on v_mfma_f32_16x16x32_bf16; dz lives in registers as the next
+//     stage's B operand (64 + 64 registers), never in LDS;
+//   * ONE copy of the packed backward stream per workgroup travels through an LDS ring (8 slots x 8 KiB, 6 chunks ahead); every
+//     wave's LDS-DMA fetches one ready-made 1-KiB A operand per chunk by pointing its lanes at the right 16-byte pieces of the
+//     32x32x16 entries (same re-tiling map as the forward: the two streams have the same entry format and k order);
+//   * the tape is read by LDS-DMA too (1 KiB per wave, n-block and row tile, two n-blocks ahead of its use), so every load of
+//     the stream loop sits in ONE in-order queue whose depth at every wait is a compile-time number (ring_wait below);
+//     d(theta) and the FiLM sums leave by fire-and-forget stores, which are not counted (they only make a wait stricter);
+//   * the epilogue of n-block nb - 1 (cos, d theta, d z split into bf16 hi / lo, FiLM sums) is issued in four items behind the
+//     MFMAs of n-block nb.
+//
+// The private-stream kernel (one 32-point wave per SIMD, every wave its own L2 stream through a register ring) stalls on its
+// tape loads -- the in-order vmcnt queue puts every HBM load in front of ring entries needed 4 k-steps later -- and on
+// everything else it issues between MFMAs; here the other wave of the SIMD fills those slots.  Measurements: DESIGN.md 4.5.
+//
+// FiLM sums are emitted per 16-point tile in register-dump order (film_gather16w_kernel, fenerf_siren_wgrad.hip, decodes it):
+//   [tile16][layer][nb][slot = 4 g + r][rt][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+
+#include "fenerf_internal.h"
+#include "fenerf_layout.h"
+
+namespace fenerf {
+namespace bw16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int CH = FENERF_CH;        // entries (KiB) per chunk = one A operand per wave
+constexpr int DPF = FENERF_DPF;      // chunks in flight ahead of the chunk being consumed
+constexpr int NSLOT = FENERF_NSLOT;  // LDS ring slots
+constexpr int NWAVE = 8;
+static_assert(CH == NWAVE, "one 1-KiB A operand per wave and chunk");
+static_assert(CH == FENERF_PF16, "bodies of the backward stream are whole chunks");
+static_assert(NSLOT == 8 && NSLOT >= DPF + 2, "slot arithmetic below is & 7; a slot is refilled two barriers after its last reads");
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ int opaque(int v) {   // fenerf_siren_f16w.hip: keeps lane-derived address arithmetic local
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// a wave-uniform pointer the compiler computed with vector instructions (64-bit multiplies) -> SGPRs, for the "s" operands below
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+// LDS-DMA of one KiB: lane i's 16 bytes at g_uniform + voff  ->  lds_uniform + 16 i
+__device__ __forceinline__ void glds_1k_s(const void* g_uniform, unsigned voff, unsigned lds_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(g_uniform), "s"(lds_uniform)
+      : "memory");
+}
+__device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned voff, unsigned lds_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 nt"
+      :
+      : "v"(voff), "s"(g_uniform), "s"(lds_uniform)
+      : "memory");
+}
+// fire-and-forget stores, uniform base + 32-bit lane offset.  The s_nop is the hazard slot the compiler would insert behind a
+// store of more than 8 bytes whose data registers the next VALU instruction overwrites -- it does not look inside an asm.
+__device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
+__device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, const f32x2& v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The in-order load queue.  Per chunk step a wave issues the ring DMA of chunk i + DPF, then one tape DMA per epilogue item
+// E scheduled in that step -- items of a body: 0 = E(row tile 0): d theta store, tape DMA;  1 = B(0): FiLM-sum store;
+// 2 = E(1);  3 = B(1); item k runs in chunk k * min(QB, 4) / 4.  Every body issues its two tape DMAs (the last body of the
+// last stage re-fetches a block it does not need), so the number of LOADS behind any ring DMA is a compile-time number.
+// At the top of step i chunk i + 1 must have landed; loads return in order, so everything issued after its DMA may still
+// be in flight: the DMAs of chunks i + 2 .. i + DPF - 1 and the tape DMAs of steps i + 1 - DPF .. i - 1.  Steps before the
+// stage's first count as zero, and the stores are not counted at all (they may retire out of order with the loads): a
+// smaller number, or outstanding stores on top of it, only wait for more.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int item_chunk(int QB, int k) { return k * (QB < 4 ? QB : 4) / 4; }
+constexpr int step_loads(int QB, int qc) {
+  int n = 0;
+  for (int k = 0; k < 4; k += 2)
+    if (item_chunk(QB, k) == qc) n += 1;
+  return n;
+}
+constexpr int ring_wait(int QB, int s) {
+  int n = DPF - 2;
+  for (int j = 1; j <= DPF - 1; ++j) {
+    const int t = s - j;
+    if (t >= 0) n += step_loads(QB, t % QB);
+  }
+  return n;
+}
+
+struct WStream {
+  unsigned long long g_next;   // global address of the next chunk to issue (uniform)
+  unsigned long long g_begin, g_end;
+  unsigned voff;               // this lane's byte offset inside a chunk (the re-tiling permutation)
+  unsigned ring_lds;           // LDS byte address of ring slot 0 + wave * 1024 (for M0)
+  const char* ring_lane;       // ring slot 0 + lane * 16 (for the ds_reads)
+  int cs;                      // ring slot of the chunk being consumed (uniform)
+  bool early;                  // waves 0-3: DMA at the top of a chunk step; waves 4-7: half a step later
+};
+
+__device__ __forceinline__ void ws_issue(WStream& w, int slot) {
+  const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
+#ifndef EXP_BW_NODMA
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(w.voff), "s"(w.g_next), "s"(m0)
+      : "memory");
+#endif
+  const unsigned long long nx = w.g_next + CH * 1024;
+  w.g_next = nx == w.g_end ? w.g_begin : nx;      // the stream restarts for the next tile
+}
+
+// A operands of one k32-step (both row tiles): ring slot layout = operand index (spl * 2 + rt) * 2 + hl, 1 KiB each
+struct AK { float4 hi[2], lo[2]; };
+__device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
+  AK a;
+  const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
+  a.lo[0] = p[1 * 64]; a.lo[1] = p[3 * 64];
+  a.hi[0] = p[0 * 64]; a.hi[1] = p[2 * 64];
+  return a;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// 6 MFMAs of one k32-step, the two row tiles interleaved: wl*xh + wh*xl + wh*xh
+__device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[2], const AK& a, const bf16x8& bh, const bf16x8& bl) {
+#ifdef EXP_BW_NOMFMA
+  acc[0][0] += a.lo[0].x + a.hi[0].y + a.lo[1].z + a.hi[1].w + (float)bh[0] + (float)bl[1];
+#else
+  acc[0] = MFMA16B(as_bf16x8(a.lo[0]), bh, acc[0]);
+  acc[1] = MFMA16B(as_bf16x8(a.lo[1]), bh, acc[1]);
+  acc[0] = MFMA16B(as_bf16x8(a.hi[0]), bl, acc[0]);
+  acc[1] = MFMA16B(as_bf16x8(a.hi[1]), bl, acc[1]);
+  acc[0] = MFMA16B(as_bf16x8(a.hi[0]), bh, acc[0]);
+  acc[1] = MFMA16B(as_bf16x8(a.hi[1]), bh, acc[1]);
+#endif
+}
+
+__device__ __forceinline__ float lane_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); }   // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float lane_ror4(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, true)); }  // row_ror:4
+__device__ __forceinline__ float lane_ror8(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true)); }  // row_ror:8
+
+// Sum of 4 per-lane values over the 16 lanes of a row (= the 16 points of the tile; a lane group IS a DPP row): two transposing
+// steps (lane keeps, of each pair, the partial sum its lane bit selects and receives the partner's), then two rotations.
+// Every lane n ends with the 16-point sum of value n & 3.
+__device__ __forceinline__ float row_sum4(const f32x4& v, bool b0, bool b1) {
+  const float k0 = b0 ? v[1] : v[0], s0 = b0 ? v[0] : v[1];
+  const float k1 = b0 ? v[3] : v[2], s1 = b0 ? v[2] : v[3];
+  const float w0 = k0 + lane_xor1(s0), w1 = k1 + lane_xor1(s1);
+  const float k = b1 ? w1 : w0, s = b1 ? w0 : w1;
+  float x = k + lane_xor2(s);
+  x += lane_ror4(x);
+  x += lane_ror8(x);
+  return x;
+}
+
+// what an epilogue item needs from its stage
+struct Sink {
+  const float* film;        // LDS: f'' of the stage's FiLM layer at this lane group's first feature; p' FILM_F bytes behind
+  const char* tape_lane;    // LDS: this wave's tape staging buffers + lane * 16
+  const char* tape_base;    // global (uniform): tape of (tile32, layer), and of the next stage's FiLM layer
+  const char* tape_next;
+  const char* dt_base;      // global (uniform): d theta dump of (tile32, layer)
+  const char* film_base;    // global (uniform): FiLM sums of (tile16, layer)
+  unsigned toff;            // lane offset inside a (tile32, layer) dump block: the register-dump position of this lane
+  unsigned foff;            // lane offset inside a FiLM-sum n-block
+  bool b0, b1;              // lane & 1, lane & 2
+};
+struct EpiIn { float4 f, p, t; };
+struct EpiOut { f32x4 dt, dtt; };
+
+template <int PF4>
+__device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tbuf) {
+  EpiIn q;
+  q.f = *reinterpret_cast<const float4*>(k.film + 32 * nbp + 8 * rt);
+  q.p = *reinterpret_cast<const float4*>(k.film + PF4 + 32 * nbp + 8 * rt);
+  q.t = *reinterpret_cast<const float4*>(k.tape_lane + (tbuf * 2 + rt) * 1024);
+  return q;
+}
+
+// E(rt) of n-block nbp: d theta = dx cos(2 pi theta), d z = d theta f'' 2 pi split into bf16 (hi = truncation, lo = the
+// remainder rounded to nearest) -> slots 4 rt .. 4 rt + 3 of k32-step nbp of the next stage's B operand; the d theta store.
+__device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, u32x4& yh, u32x4& yl, int rt) {
+  const float TWO_PI = 6.28318530717958647692f;
+  const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w}, p[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, t[4] = {q.t.x, q.t.y, q.t.z, q.t.w};
+  EpiOut o;
+  unsigned hb[4];
+  float rem[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#ifdef EXP_BW_NOEPI
+    const float dt = acc[r] + f[r] + p[r] + t[r];
+    o.dt[r] = dt; o.dtt[r] = dt;
+    hb[r] = __builtin_bit_cast(unsigned, dt); rem[r] = dt;
+#else
+    const float dt = acc[r] * __builtin_amdgcn_cosf(__builtin_fmaf(f[r], t[r], p[r]));
+    o.dt[r] = dt;
+    o.dtt[r] = dt * t[r];
+    const float dz = dt * (f[r] * TWO_PI);
+    hb[r] = __builtin_bit_cast(unsigned, dz);
+    rem[r] = dz - __builtin_bit_cast(float, hb[r] & 0xffff0000u);
+#endif
+  }
+  unsigned h2[2], l2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    h2[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
+    const f32x2 rr = {rem[2 * j], rem[2 * j + 1]};
+    l2[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+  }
+  // pinned here: without a use in this block the compiler sinks the epilogue behind the stage (fenerf_siren_f16w.hip)
+  asm volatile("" : "+v"(h2[0]), "+v"(h2[1]), "+v"(l2[0]), "+v"(l2[1]));
+  yh[2 * rt] = h2[0]; yh[2 * rt + 1] = h2[1];
+  yl[2 * rt] = l2[0]; yl[2 * rt + 1] = l2[1];
+  return o;
+}
+
+template <int H, bool GRID>
+__global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
+  constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
+  constexpr int QB = pad_pf16(2 * (H / 16)) / CH;               // chunks per square body
+  constexpr int C0_QB = pad_pf16(2 * (H / 16 + 2)) / CH;        // colour-layer-0 body: + one k32-step of head rows
+  constexpr int FILM_F = H * 4 < 1024 ? 1024 : H * 4;           // LDS-DMA moves whole KiBs
+  constexpr int FILM_BYTES = 2 * FILM_F;
+  constexpr int TL = H * 128;                                   // bytes of one (tile32, layer) dump block
+  extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int L = n_geo + n_color;
+  // LDS: [ring NSLOT x 8 KiB][film: 8 waves x 2 buffers x (f'' | p')][tape staging: 8 waves x 4 KiB][head^T (rgb) NB KiB][head B operands 8 x 2 KiB]
+  char* lds = reinterpret_cast<char*>(smem);
+  char* ring = lds;
+  char* film_base = lds + NSLOT * CH * 1024 + wave * (2 * FILM_BYTES);
+  char* tape_stage = lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES + wave * 4096;
+  float* ht_lds = reinterpret_cast<float*>(lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES + NWAVE * 4096);
+  float4* ext_wave = reinterpret_cast<float4*>(ht_lds + NB * 256) + wave * 128;
+
+  for (int i = threadIdx.x; i < NB * 256; i += 512) ht_lds[i] = P.stream[i];
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  // ---- the DMA's re-tiling permutation (fenerf_siren_f16w.hip header): this wave fetches operand (spl, rt, hl) of every chunk
+  WStream ws;
+  {
+    const int spl = wave >> 2, rt = (wave >> 1) & 1, hl = wave & 1;
+    const int gi = n >> 2, r = n & 3;
+    const int row = 16 * (gi >> 1) + 4 * (gi & 1) + 8 * rt + r;
+    const int e_old = 2 * (2 * spl + (g >> 1)) + hl;
+    ws.voff = e_old * 1024 + ((g & 1) * 32 + row) * 16;
+  }
+  const long long nchunk = (long long)(n_color - 1 + n_geo - 1) * NB * QB + (long long)NB * C0_QB + (GRID ? QB : 0);
+  ws.g_begin = reinterpret_cast<unsigned long long>(P.stream + P.ring_offset_floats);
+  ws.g_end = ws.g_begin + (unsigned long long)nchunk * (CH * 1024);
+  ws.g_next = ws.g_begin;
+  ws.ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 1024);
+  ws.ring_lane = ring + lane * 16;
+  ws.early = wave < NWAVE / 2;
+  ws.cs = 0;
+
+  // ---- prime the shared stream: chunks 0..D-1 in flight
+#pragma unroll
+  for (int i = 0; i < DPF; ++i) ws_issue(ws, i);
+
+  // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
+  const long long ntiles = (P.P + 15) / 16;
+  const long long nocts = (ntiles + NWAVE - 1) / NWAVE;
+  const int nblk = gridDim.x;
+  const int nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx;
+  const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
+  const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
+
+  int tpar = 0;   // parity of the tape staging buffers (advances per stage when NB is odd)
+  for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
+    // a wave past the last tile repeats the last tile: same loads, same values, same stores (no guard in the stream loop)
+    long long tile = oct * NWAVE + wave;
+    if (tile >= ntiles) tile = ntiles - 1;
+    const long long tile32 = tile >> 1;
+    const long long pt = tile * 16 + n;        // P.P is a multiple of 32 (fenerf_siren_backward)
+    const long long img = __builtin_amdgcn_readfirstlane((int)((tile * 16) / P.pts_per_image));
+    const float* fp_img = P.fp + (size_t)img * L * H;
+    const float* pp_img = P.pp + (size_t)img * L * H;
+    const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TL);
+    const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
+    const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)tile * L * (2 * H * 4));
+
+    auto film_issue = [&](int layer) {   // f'' (H floats) then p' (H floats) of `layer` into buffer layer & 1
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(film_base) + (layer & 1) * FILM_BYTES);
+      const float* gf = fp_img + (size_t)layer * H;
+      const float* gp = pp_img + (size_t)layer * H;
+      const unsigned vo = (unsigned)opaque(lane) * 16;
+      for (int off = 0; off < H * 4; off += 1024) {
+        glds_1k_s(reinterpret_cast<const char*>(gf) + off, vo, dst + off);
+        glds_1k_s(reinterpret_cast<const char*>(gp) + off, vo, dst + FILM_F + off);
+      }
+    };
+    auto film_lane = [&](int layer) -> const float* {
+      const int gq = opaque(lane) >> 4;
+      return reinterpret_cast<const float*>(film_base + (layer & 1) * FILM_BYTES) + 16 * (gq >> 1) + 4 * (gq & 1);
+    };
+    // register-dump position of this lane inside a (tile32, layer) block: float4 index (4 nb + 2 (g >> 1) + rt) * 64 + 32 (g & 1) + 16 (tile & 1) + n
+    auto lane_toff = [&]() -> unsigned {
+      const int lo = opaque(lane);
+      const int nn = lo & 15, gq = lo >> 4;
+      return (unsigned)(((2 * (gq >> 1)) * 64 + (gq & 1) * 32 + 16 * (int)(tile & 1) + nn) * 16);
+    };
+    // tape block (nb, rt) of the (tile32, layer) dump at `base` -> staging buffer.  `base` is in SGPRs long before (make_sink): an
+    // SGPR written by v_readfirstlane must not feed a vector-memory address within 5 wait states, and nothing checks an asm.
+    auto tape_issue = [&](const char* base, int nb, int rt, int tbuf, unsigned toff) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(tape_stage) + (tbuf * 2 + rt) * 1024);
+      glds_1k_s_nt(base + (nb * 4 + rt) * 1024, toff, dst);
+    };
+    auto make_sink = [&](int layer) -> Sink {
+      Sink k;
+      k.film = film_lane(layer);
+      k.tape_lane = tape_stage + opaque(lane) * 16;
+      k.tape_base = uniform_ptr(tape_tile + (size_t)layer * TL);
+      k.tape_next = uniform_ptr(tape_tile + (size_t)(layer > 0 ? layer - 1 : 0) * TL);
+      k.dt_base = uniform_ptr(dt_tile + (size_t)layer * TL);
+      k.film_base = uniform_ptr(film_tile + (size_t)layer * (2 * H * 4));
+      k.toff = lane_toff();
+      const int lo = opaque(lane);
+      k.foff = (unsigned)(((lo >> 4) * 4 + (lo & 3)) * 16);
+      k.b0 = (lo & 1) != 0; k.b1 = (lo & 2) != 0;
+      return k;
+    };
+
+    film_issue(L - 1);
+    film_issue(L - 2);
+
+    // ---------------- gradient wrt the head rows (labels, sigma) as the B operand of the head k32-step: lane (n, kg) slot t = row 8 kg + t
+    {
+      unsigned hb[8];
+      float rem[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = 8 * g + t;
+        const int ch = row < n_lab ? row : (row == n_lab ? C - 1 : -1);
+        const float v = ch >= 0 ? P.d_out[pt * C + ch] : 0.f;
+        hb[t] = __builtin_bit_cast(unsigned, v);
+        rem[t] = v - __builtin_bit_cast(float, hb[t] & 0xffff0000u);
+      }
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
+        const f32x2 rr = {rem[2 * j], rem[2 * j + 1]};
+        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2));
+      }
+      float4* ext = ext_wave + lane;
+      ext[0] = __builtin_bit_cast(float4, hi);
+      ext[64] = __builtin_bit_cast(float4, lo);
+    }
+    // ---------------- rgb head: d(pre-sigmoid) = d_rgb s (1 - s) as the B operand of the fp32 MFMA (k = r, g, b, 0)
+    float brgb;
+    {
+      float dpre[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s = P.out[pt * C + (C - 4) + c];
+        dpre[c] = P.d_out[pt * C + (C - 4) + c] * (s * (1.f - s));
+      }
+      brgb = g == 0 ? dpre[0] : (g == 1 ? dpre[1] : (g == 2 ? dpre[2] : 0.f));
+    }
+    // the tape of layer L - 1 (all n-blocks) for the rgb stage's own epilogue: plain loads, once per tile
+    float4 t_rgb[NB][2];
+    {
+      const float4* tp = reinterpret_cast<const float4*>(tape_tile + (size_t)(L - 1) * TL + lane_toff());
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) t_rgb[nb][rt] = tp[(nb * 4 + rt) * 64];
+    }
+    // tape blocks the first pipelined stage (FiLM layer L - 2) finds in flight: n-block 0 (n-block 1 is issued by its body 0)
+    {
+      const char* tb = uniform_ptr(tape_tile + (size_t)(L - 2) * TL);
+      asm volatile("s_nop 4" ::: "memory");
+      tape_issue(tb, 0, 0, tpar & 1, lane_toff());
+      tape_issue(tb, 0, 1, tpar & 1, lane_toff());
+    }
+    wait_vmcnt<0>();      // once per tile: film L-1 / L-2, the prologue loads, and the ring prefetch have landed
+    __builtin_amdgcn_s_barrier();   // ... in every wave: ring chunks 0 .. D-1 of this tile are visible
+    LDS_FENCE();
+
+    u32x4 zh[KS], zl[KS];
+    // ---------------- rgb head^T on the exact fp32 MFMA (16x16x4: k = r, g, b, 0) -> d theta_{L-1}, d z_{L-1} ----------------
+    {
+      const Sink k = make_sink(L - 1);
+      const int gi = n >> 2, r = n & 3;
+      const float* wl = ht_lds + ((g & 1) * 32 + 16 * (gi >> 1) + 4 * (gi & 1) + r) * 4 + (g >> 1);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 acc = MFMA32W(wl[nb * 256 + 8 * rt * 4], brgb, z4);
+          EpiIn q;
+          q.f = *reinterpret_cast<const float4*>(k.film + 32 * nb + 8 * rt);
+          q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
+          q.t = t_rgb[nb][rt];
+          const EpiOut o = epi_compute(acc, q, zh[nb], zl[nb], rt);
+          st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o.dt);
+          const f32x2 s = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
+          st_f2(k.film_base + nb * 256 + rt * 8, k.foff, s);
+        }
+      }
+    }
+    AK a_cur = ws_read(ws, ws.cs, 0);
+
+    // One stage: NBODY bodies of QBS chunks; bop(sp, bh, bl) supplies the B operand of k32-step sp (false = padding).  With
+    // EPI the bodies carry the epilogue of FiLM layer `lo` (tape layer lo, d theta / FiLM sums of layer lo) into y.
+    auto run_stage = [&](auto nbody_c, auto qbs_c, auto epi_c, int lo, auto bop, u32x4 (&yh)[KS], u32x4 (&yl)[KS], f32x4 (&acc_last)[2]) {
+      constexpr int NBODY = decltype(nbody_c)::value, QBS = decltype(qbs_c)::value;
+      constexpr bool EPI = decltype(epi_c)::value;
+      const Sink k = make_sink(lo);
+      f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      EpiOut eo[2];
+      static_for<0, NBODY>([&](auto nb_c) {
+        constexpr int nb = decltype(nb_c)::value;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        static_for<0, QBS>([&](auto qc_c) {
+          constexpr int qc = decltype(qc_c)::value;
+          constexpr int s = nb * QBS + qc;
+          // ---- top of the step: chunk s + 1 visible to every wave, then (waves 0-3) the DMA of chunk s + D
+          wait_vmcnt<EPI ? ring_wait(QBS, s) : DPF - 2>();
+#ifndef EXP_BW_NOBARRIER
+          __builtin_amdgcn_s_barrier();
+#endif
+          LDS_FENCE();
+          if (ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+          // operands of the items of this chunk: FiLM parameters and tape from LDS, read before the A operands (LDS returns in order)
+          EpiIn q[2];
+          if constexpr (EPI && nb > 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+              if (item_chunk(QBS, 2 * rt) == qc) {
+                if constexpr (2 * QB < DPF) wait_vmcnt<2 * QB>();   // (2 QB >= DPF: implied by the ring waits of the 2 QB steps since)
+                q[rt] = epi_read<FILM_F / 4>(k, nb - 1, rt, ((nb - 1) + tpar) & 1);
+              }
+          }
+#pragma unroll
+          for (int spl = 0; spl < 2; ++spl) {
+            if (spl == 1 && !ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+            const AK nn = spl == 0 ? ws_read(ws, ws.cs, 1) : ws_read(ws, (ws.cs + 1) & 7, 0);
+            __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
+            bf16x8 bh, bl;
+            if (bop(2 * qc + spl, bh, bl)) kstep_mfma(acc, a_cur, bh, bl);
+            if constexpr (EPI) {
+              if (spl == 1) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                  if (item_chunk(QBS, it) != qc) continue;
+                  const int rt = it >> 1;
+                  if ((it & 1) == 0) {
+                    if constexpr (nb > 0) {
+                      eo[rt] = epi_compute(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
+                      st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt);
+                    }
+                    // the tape block two n-blocks ahead of its use: (lo, nb + 1), or the next stage's n-block 0; the last
+                    // stage's last body re-fetches (0, 0) so that ring_wait's count holds
+                    if constexpr (nb + 1 < NBODY) tape_issue(k.tape_base, nb + 1, rt, ((nb + 1) + tpar) & 1, k.toff);
+                    else tape_issue(k.tape_next, 0, rt, (NBODY + tpar) & 1, k.toff);
+                  } else {
+                    if constexpr (nb > 0) {
+                      const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), row_sum4(eo[rt].dtt, k.b0, k.b1)};
+                      st_f2(k.film_base + (nb - 1) * 256 + rt * 8, k.foff, sm);
+                    }
+                  }
+                }
+              }
+            }
+            a_cur = nn;
+            __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue items where they are written
+          }
+          ws.cs = (ws.cs + 1) & 7;
+        });
+        acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
+      });
+      if constexpr (EPI) {
+        // ---- the last n-block's epilogue, behind the stage
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          constexpr int c0 = item_chunk(QBS, 0), c1 = item_chunk(QBS, 2);
+          if (rt == 0) wait_vmcnt<2 * QBS - 1 - c0>(); else wait_vmcnt<2 * QBS - 1 - c1>();
+          LDS_FENCE();
+          const EpiIn q = epi_read<FILM_F / 4>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
+          const EpiOut o = epi_compute(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
+          st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
+          const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
+          st_f2(k.film_base + (NBODY - 1) * 256 + rt * 8, k.foff, sm);
+        }
+      } else {
+        acc_last[0] = acc_prev[0]; acc_last[1] = acc_prev[1];
+      }
+    };
+
+    // ---------------- FiLM layers L-2 .. 0: colour layers, colour layer 0 (+ heads, + grid-feature gradient), trunk ----------------
+#pragma unroll 1
+    for (int lo = L - 2; lo >= 0; --lo) {
+      u32x4 yh[KS], yl[KS];
+      f32x4 unused[2];
+      if (lo >= 1) film_issue(lo - 1);
+      if (NB * QB < DPF + 2) wait_vmcnt<0>();
+      auto bop = [&](int sp, bf16x8& bh, bf16x8& bl) -> bool {
+        if (sp < KS) { bh = as_bf16x8(zh[sp]); bl = as_bf16x8(zl[sp]); return true; }
+        return false;
+      };
+      if (lo == n_geo - 1) {
+        const float4* ext = ext_wave + opaque(lane);
+        auto bop0 = [&](int sp, bf16x8& bh, bf16x8& bl) -> bool {
+          if (sp < KS) { bh = as_bf16x8(zh[sp]); bl = as_bf16x8(zl[sp]); return true; }
+          if (sp == KS) { bh = as_bf16x8(ext[0]); bl = as_bf16x8(ext[64]); return true; }
+          return false;
+        };
+        run_stage(std::integral_constant<int, NB>{}, std::integral_constant<int, C0_QB>{}, std::true_type{}, lo, bop0, yh, yl, unused);
+        if (GRID) {
+          // d(grid features) = W_c0[:, grid]^T dz_{n_geo}: one body on the stage's input, no epilogue
+          f32x4 ge[2];
+          run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, QB>{}, std::false_type{}, lo, bop, yh, yl, ge);
+          const int lq = opaque(lane);
+          float* ep = P.d_e + pt * 32 + 16 * (lq >> 5) + 4 * ((lq >> 4) & 1);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const f32x4 v = ge[rt];
+            *reinterpret_cast<float4*>(ep + 8 * rt) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else {
+        run_stage(std::integral_constant<int, NB>{}, std::integral_constant<int, QB>{}, std::true_type{}, lo, bop, yh, yl, unused);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { zh[s] = yh[s]; zl[s] = yl[s]; }
+      if (NB & 1) tpar ^= 1;
+    }
+    wait_vmcnt<0>();   // stores may retire out of order with the DMA loads: keep them out of the counted waits
+    __builtin_amdgcn_wave_barrier();
+  }
+  wait_vmcnt<0>();     // no LDS-DMA may land after the workgroup has released its LDS
+  __builtin_amdgcn_s_barrier();
+}
+
+static int hip_fail16w(hipError_t e, const char* what) {
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return FENERF_E_HIP;
+}
+
+template <int H, bool GRID>
+static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
+  const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
+                     (size_t)NWAVE * 2048;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands
+  auto kfn = siren_bwd16w_kernel<H, GRID>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
+  const long long ntiles = (p.P + 15) / 16;
+  long long blocks = (ntiles + NWAVE - 1) / NWAVE;
+  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "siren bf16 backward (16-point waves) launch");
+}
+
+}  // namespace bw16
+
+// FENERF_BACKWARD_KERNEL=b16 selects the one-wave-per-SIMD kernel (fenerf_siren_bwd16.hip); the FiLM sums of the two kernels
+// have different tile sizes, so the choice is made once per process and asked for by both the chain and the gather launch.
+bool bwd16w_enabled() {
+  static const bool on = [] { const char* v = getenv("FENERF_BACKWARD_KERNEL"); return !(v && std::string(v) == "b16"); }();
+  return on;
+}
+
+int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  if (p.P <= 0) return FENERF_OK;
+  const bool g = m->grid_ch != 0;
+  switch (m->H) {
+    case 32: return g ? bw16::launch_t<32, true>(m, p, stream) : bw16::launch_t<32, false>(m, p, stream);
+    case 64: return g ? bw16::launch_t<64, true>(m, p, stream) : bw16::launch_t<64, false>(m, p, stream);
+    case 128: return g ? bw16::launch_t<128, true>(m, p, stream) : bw16::launch_t<128, false>(m, p, stream);
+    case 256: return g ? bw16::launch_t<256, true>(m, p, stream) : bw16::launch_t<256, false>(m, p, stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+}  // namespace fenerf

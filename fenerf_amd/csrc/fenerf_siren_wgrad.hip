@@ -44,6 +44,7 @@ struct WgradParams {
   float* partial;              // [z][b][chunk][MT*32][KT*32]
   float* film_partial;         // [L][b][chunk][H][2]: the chain kernel's per-tile FiLM sums gathered per chunk
   const float* film_tiles;     // [tiles][L][2][H] from the chain kernel (fenerf_layout.h "FiLM sums")
+  int film16w;                 // the sums come from siren_bwd16w_kernel: per 16-point tile, register-dump order (fenerf_siren_bwd16w.hip)
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
 };
 
@@ -470,6 +471,17 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
   const long long tile_base = (long long)img * P.tiles_per_image;
   for (int n = threadIdx.x; n < H; n += blockDim.x) {
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;     // two independent chains: the loads are latency-bound
+    if (P.film16w) {
+      // [tile16][layer][nb][slot = 4 g + r][rt][s0, s1] with feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r
+      const int f = n & 31, gq = ((f >> 4) << 1) | ((f >> 2) & 1), rt = (f >> 3) & 1, r = f & 3;
+      const int idx = (n >> 5) * 64 + (gq * 4 + r) * 4 + rt * 2;
+      const long long stride = (long long)L * 2 * H;
+      const float* p0 = P.film_tiles + ((tile_base * 2 + 2 * t0) * L + l) * 2LL * H + idx;
+      for (int t = 2 * t0; t < 2 * t1; t += 2, p0 += 2 * stride) {
+        const float2 u = *reinterpret_cast<const float2*>(p0), v = *reinterpret_cast<const float2*>(p0 + stride);
+        a0 += u.x; a1 += u.y; b0 += v.x; b1 += v.y;
+      }
+    } else {
     int t = t0;
     for (; t + 2 <= t1; t += 2) {
       const float* p0 = P.film_tiles + ((tile_base + t) * L + l) * 2LL * H + n;
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
       a0 += p0[0]; a1 += p0[H]; b0 += p1[0]; b1 += p1[H];
     }
     if (t < t1) { const float* p0 = P.film_tiles + ((tile_base + t) * L + l) * 2LL * H + n; a0 += p0[0]; a1 += p0[H]; }
+    }
     const float s0 = a0 + b0, s1 = a1 + b1;
     const float iv = P.inv ? P.inv[(size_t)l * H + n] : 1.f, bb = P.bias[(size_t)l * H + n];
     float* fpart = P.film_partial + ((((size_t)l * P.B + img) * P.film_stride + chunk) * H + n) * 2;
@@ -717,6 +730,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.box_scale = m->box_scale;
   p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
   p.P = P; p.tiles_per_image = (int)(P / 32);
+  p.film16w = m->precision == FENERF_PREC_F16X3 && bwd16w_enabled();
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {
