@@ -19,7 +19,7 @@
 // everything else it issues between MFMAs; here the other wave of the SIMD fills those slots.  Measurements: DESIGN.md 4.5.
 //
 // FiLM sums are emitted per 16-point tile in register-dump order (film_gather16w_kernel, fenerf_siren_wgrad.hip, decodes it):
-//   [tile16][layer][nb][slot = 4 g + r][rt][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r.
+//   [tile16][layer][nb][rt][slot = 4 g + r][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -92,7 +92,11 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
+#ifdef EXP_BW_TAPE_T
+      "global_load_lds_dwordx4 %0, %1"
+#else
       "global_load_lds_dwordx4 %0, %1 nt"
+#endif
       :
       : "v"(voff), "s"(g_uniform), "s"(lds_uniform)
       : "memory");
@@ -100,6 +104,10 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
 // fire-and-forget stores, uniform base + 32-bit lane offset.  The s_nop is the hazard slot the compiler would insert behind a
 // store of more than 8 bytes whose data registers the next VALU instruction overwrites -- it does not look inside an asm.
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
+#ifdef EXP_BW_NOSTORE
+  asm volatile("" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+  return;
+#endif
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 __device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, const f32x2& v) {
@@ -132,6 +140,17 @@ constexpr int ring_wait(int QB, int s) {
   return n;
 }
 
+// One barrier per TWO chunk steps (stages of an even number of steps): the barrier of even step i publishes chunks i + 1 and
+// i + 2 (read during steps i and i + 1), so every wave first waits for its own KiB of chunks <= i + 2.
+constexpr int ring_wait2(int QB, int s) {
+  int n = DPF - 3;
+  for (int j = 1; j <= DPF - 2; ++j) {
+    const int t = s - j;
+    if (t >= 0) n += step_loads(QB, t % QB);
+  }
+  return n;
+}
+
 struct WStream {
   unsigned long long g_next;   // global address of the next chunk to issue (uniform)
   unsigned long long g_begin, g_end;
@@ -152,6 +171,8 @@ __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
       :
       : "v"(w.voff), "s"(w.g_next), "s"(m0)
       : "memory");
+#else
+  (void)m0;
 #endif
   const unsigned long long nx = w.g_next + CH * 1024;
   w.g_next = nx == w.g_end ? w.g_begin : nx;      // the stream restarts for the next tile
@@ -230,7 +251,7 @@ __device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tb
 // E(rt) of n-block nbp: d theta = dx cos(2 pi theta), d z = d theta f'' 2 pi split into bf16 (hi = truncation, lo = the
 // remainder rounded to nearest) -> slots 4 rt .. 4 rt + 3 of k32-step nbp of the next stage's B operand; the d theta store.
 __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, u32x4& yh, u32x4& yl, int rt) {
-  const float TWO_PI = 6.28318530717958647692f;
+  [[maybe_unused]] const float TWO_PI = 6.28318530717958647692f;
   const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w}, p[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, t[4] = {q.t.x, q.t.y, q.t.z, q.t.w};
   EpiOut o;
   unsigned hb[4];
@@ -272,6 +293,12 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   constexpr int FILM_F = H * 4 < 1024 ? 1024 : H * 4;           // LDS-DMA moves whole KiBs
   constexpr int FILM_BYTES = 2 * FILM_F;
   constexpr int TL = H * 128;                                   // bytes of one (tile32, layer) dump block
+#ifdef EXP_BW_B1
+  constexpr bool B2 = false;
+#else
+  // one barrier per two chunk steps where every stage has an even number of steps (H >= 128)
+  constexpr bool B2 = (NB * QB) % 2 == 0 && (NB * C0_QB) % 2 == 0 && (!GRID || QB % 2 == 0);
+#endif
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
   const int lane = threadIdx.x & 63;
@@ -331,7 +358,11 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     const long long img = __builtin_amdgcn_readfirstlane((int)((tile * 16) / P.pts_per_image));
     const float* fp_img = P.fp + (size_t)img * L * H;
     const float* pp_img = P.pp + (size_t)img * L * H;
+#ifdef EXP_BW_TAPE_L2   // timing only: every tile reads tile 0's tape (L2-resident)
+    const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)(tile32 & 1) * L * TL);
+#else
     const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TL);
+#endif
     const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
     const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)tile * L * (2 * H * 4));
 
@@ -371,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       k.film_base = uniform_ptr(film_tile + (size_t)layer * (2 * H * 4));
       k.toff = lane_toff();
       const int lo = opaque(lane);
-      k.foff = (unsigned)(((lo >> 4) * 4 + (lo & 3)) * 16);
+      k.foff = (unsigned)(((lo >> 4) * 4 + (lo & 3)) * 8);
       k.b0 = (lo & 1) != 0; k.b1 = (lo & 2) != 0;
       return k;
     };
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const EpiOut o = epi_compute(acc, q, zh[nb], zl[nb], rt);
           st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o.dt);
           const f32x2 s = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
-          st_f2(k.film_base + nb * 256 + rt * 8, k.foff, s);
+          st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
         }
       }
     }
@@ -472,13 +503,25 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
         static_for<0, QBS>([&](auto qc_c) {
           constexpr int qc = decltype(qc_c)::value;
           constexpr int s = nb * QBS + qc;
-          // ---- top of the step: chunk s + 1 visible to every wave, then (waves 0-3) the DMA of chunk s + D
-          wait_vmcnt<EPI ? ring_wait(QBS, s) : DPF - 2>();
+          // ---- top of the step: chunk s + 1 (B2: and s + 2) visible to every wave, then (waves 0-3) the DMA of chunk s + D.  The
+          // DMA overwrites the slot of chunk s - 2, whose last reads every wave issued before the barrier (B2: of step s or s - 1)
+          if constexpr (!B2) {
+            wait_vmcnt<EPI ? ring_wait(QBS, s) : DPF - 2>();
 #ifndef EXP_BW_NOBARRIER
-          __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
 #endif
+          } else if constexpr ((s & 1) == 0) {
+            wait_vmcnt<EPI ? ring_wait2(QBS, s) : DPF - 3>();
+#ifndef EXP_BW_NOBARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+          }
           LDS_FENCE();
+#ifdef EXP_BW_INPHASE
+          ws_issue(ws, (ws.cs + DPF) & 7);
+#else
           if (ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+#endif
           // operands of the items of this chunk: FiLM parameters and tape from LDS, read before the A operands (LDS returns in order)
           EpiIn q[2];
           if constexpr (EPI && nb > 0) {
@@ -491,7 +534,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           }
 #pragma unroll
           for (int spl = 0; spl < 2; ++spl) {
+#ifndef EXP_BW_INPHASE
             if (spl == 1 && !ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+#endif
             const AK nn = spl == 0 ? ws_read(ws, ws.cs, 1) : ws_read(ws, (ws.cs + 1) & 7, 0);
             __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
             bf16x8 bh, bl;
@@ -514,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   } else {
                     if constexpr (nb > 0) {
                       const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), row_sum4(eo[rt].dtt, k.b0, k.b1)};
-                      st_f2(k.film_base + (nb - 1) * 256 + rt * 8, k.foff, sm);
+                      st_f2(k.film_base + (nb - 1) * 256 + rt * 128, k.foff, sm);
                     }
                   }
                 }
@@ -538,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const EpiOut o = epi_compute(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
           st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
           const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
-          st_f2(k.film_base + (NBODY - 1) * 256 + rt * 8, k.foff, sm);
+          st_f2(k.film_base + (NBODY - 1) * 256 + rt * 128, k.foff, sm);
         }
       } else {
         acc_last[0] = acc_prev[0]; acc_last[1] = acc_prev[1];

@@ -648,13 +648,12 @@ static int launch_siren16s_t(const FenerfModel* m, const SirenParams& p, void* s
 int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
   const bool g = m->grid_ch != 0;
-  // no-grad launches run the 16-point / 2-waves-per-SIMD kernel (fenerf_siren_f16w.hip, same stream); the forward-save
-  // launches stay here (the tape layout is this kernel's register dump).  FENERF_FORWARD_KERNEL=f16s forces this kernel
-  // (A/B timing only).
+  // all launches run the 16-point / 2-waves-per-SIMD kernel (fenerf_siren_f16w.hip, same stream, same tape layout);
+  // FENERF_FORWARD_KERNEL=f16s forces this kernel (A/B timing only).
   static const bool force_s = [] { const char* v = getenv("FENERF_FORWARD_KERNEL"); return v && std::string(v) == "f16s"; }();
   auto one = [&](const SirenParams& q) -> int {
     const bool sv = q.tape != nullptr;
-    if (!sv && !force_s) return launch_siren16w_one(m, q, stream);
+    if (!force_s) return launch_siren16w_one(m, q, stream);
     switch (m->H) {
       case 32: return sv ? (g ? launch_siren16s_t<32, true, true>(m, q, stream) : launch_siren16s_t<32, false, true>(m, q, stream))
                          : (g ? launch_siren16s_t<32, true, false>(m, q, stream) : launch_siren16s_t<32, false, false>(m, q, stream));

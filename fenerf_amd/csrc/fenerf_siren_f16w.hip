@@ -112,6 +112,22 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// a wave-uniform pointer the compiler computed with vector instructions (64-bit multiplies) -> SGPRs, for "s" asm operands
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// Differentiable mode (forward-save): the raw accumulators of every FiLM layer leave as the tape (fenerf_layout.h "Tape": register
+// dumps of 32-point tiles; wave w of the workgroup owns half (w & 1) of tile32 = tile16 >> 1).  One fire-and-forget 1-KiB wave
+// store per (n-block, row tile): stores are not loads -- they only make the counted vmcnt waits stricter.  asm: uniform base
+// in SGPRs + one VGPR of lane offset; the s_nop is the hazard slot behind a > 8-byte store whose data registers are
+// overwritten next (the compiler does not look inside an asm).
+template <bool ON> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
+__device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
 struct WStream {
@@ -235,11 +251,17 @@ __device__ __forceinline__ FilmQ epi_load(int nbp, int piece, const float* film)
   q.p = *reinterpret_cast<const float2*>(film + PF4 + 32 * nbp + 8 * rt + 2 * pc);
   return q;
 }
-template <int KS>
+template <int KS, bool SAVE>
 __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int piece, const FilmQ& q, half8 (&yh)[KS],
-                                            half8 (&yl)[KS]) {
+                                            half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd) {
   const int rt = piece >> 1, pc = piece & 1;
   const float2 f = q.f, p = q.p;
+  if (SAVE && pc == 0) {
+    // register-dump position of this lane: float4 index (4 nb + 2 (g >> 1) + rt) * 64 + 32 (g & 1) + 16 (tile & 1) + n
+    const int lo = opaque((int)(threadIdx.x & 63));
+    const unsigned toff = (unsigned)(((2 * (lo >> 5)) * 64 + ((lo >> 4) & 1) * 32 + 16 * tile_odd + (lo & 15)) * 16);
+    st_f4_nt(tw.base + (nbp * 4 + rt) * 1024, toff, acc[rt]);
+  }
 #ifdef EXP_W_NOEPI
   half2 hp = {(_Float16)(f.x + acc[rt][2 * pc + 0]), (_Float16)p.x}, lp = {(_Float16)(f.y + acc[rt][2 * pc + 1]), (_Float16)p.y};
 #else
@@ -258,15 +280,16 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
   yh[nbp][s] = hp[0]; yh[nbp][s + 1] = hp[1];
   yl[nbp][s] = lp[0]; yl[nbp][s + 1] = lp[1];
 }
-template <int KS, int PF4>
+template <int KS, int PF4, bool SAVE>
 __device__ __forceinline__ void epi_piece(const f32x4 (&acc)[2], int nbp, int piece, const float* film, half8 (&yh)[KS],
-                                          half8 (&yl)[KS]) {
-  epi_compute<KS>(acc, nbp, piece, epi_load<PF4>(nbp, piece, film), yh, yl);
+                                          half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd) {
+  epi_compute<KS, SAVE>(acc, nbp, piece, epi_load<PF4>(nbp, piece, film), yh, yl, tw, tile_odd);
 }
-template <int KS, int PF4>
-__device__ __forceinline__ void epi_all(const f32x4 (&acc)[2], int nbp, const float* film, half8 (&yh)[KS], half8 (&yl)[KS]) {
+template <int KS, int PF4, bool SAVE>
+__device__ __forceinline__ void epi_all(const f32x4 (&acc)[2], int nbp, const float* film, half8 (&yh)[KS], half8 (&yl)[KS],
+                                        TapeW<SAVE> tw, int tile_odd) {
 #pragma unroll
-  for (int pc = 0; pc < 4; ++pc) epi_piece<KS, PF4>(acc, nbp, pc, film, yh, yl);
+  for (int pc = 0; pc < 4; ++pc) epi_piece<KS, PF4, SAVE>(acc, nbp, pc, film, yh, yl, tw, tile_odd);
 }
 
 // Chunk step i of a stage: barrier (chunk i + 1 visible), then the chunk's two k32-steps.  bop(sp, bh, bl) supplies the B
@@ -316,7 +339,7 @@ __device__ __forceinline__ void piece_range(int qc, int& p0, int& p1) {
   p1 = 4 * (qc + 1) / QBE;
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = (KS + 1) / 2;                              // chunks per square n-block body
@@ -413,6 +436,16 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       if (P.lock_view) { dx = 0.f; dy = 0.f; dz = -1.f; }
     }
     const float qx = px * P.box_scale, qy = py * P.box_scale, qz = pz * P.box_scale;
+    // forward-save: this tile's half of the (tile32) tape block of FiLM layer `layer`; phantom tiles of the last oct (clamped
+    // points) dump into the slack fenerf_siren_tape_floats keeps behind the last tile
+    constexpr int TL = H * 128;
+    const int tile_odd = (int)(tile & 1);
+    const char* tape_tile = SAVE ? uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)(tile >> 1) * L * TL) : nullptr;
+    auto tape_of = [&](int layer) {
+      TapeW<SAVE> t{SAVE ? uniform_ptr(tape_tile + (size_t)layer * TL) : nullptr};
+      if (SAVE) asm volatile("s_nop 4" ::: "memory");   // SGPRs written by v_readfirstlane feed a vector-memory address: 5 wait states
+      return t;
+    };
 
     // ---------------- FiLM parameters of layers 0 and 1 -> LDS (DMA), grid gather, then one drain ----------------
     const float* fp_img = P.fp + (size_t)img * L * H;
@@ -462,6 +495,11 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
         }
       }
     }
+    if (SAVE && GRID) {   // the sampled grid features, [P][32] (a clamped lane rewrites the last point's row with the same values)
+      float4* ep = reinterpret_cast<float4*>(P.tape_e + pt * 32 + 16 * (g & 1) + 8 * (g >> 1));
+      ep[0] = make_float4(e[0], e[1], e[2], e[3]);
+      ep[1] = make_float4(e[4], e[5], e[6], e[7]);
+    }
     {
       half8 eh, el, dh, dl;
 #pragma unroll
@@ -499,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       const float b = g == 0 ? qx : (g == 1 ? qy : (g == 2 ? qz : 0.f));
       const int gi = n >> 2, r = n & 3;
       const float* wl = l0_lds + ((g & 1) * 32 + 16 * (gi >> 1) + 4 * (gi & 1) + r) * 4 + (g >> 1);
+      const TapeW<SAVE> tw0 = tape_of(0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         f32x4 acc[2];
@@ -507,13 +546,14 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
           acc[rt] = MFMA32W(wl[nb * 256 + 8 * rt * 4], b, z4);
         }
-        epi_all<KS, FILM_F / 4>(acc, nb, film_lane(0), xh, xl);
+        epi_all<KS, FILM_F / 4, SAVE>(acc, nb, film_lane(0), xh, xl, tw0, tile_odd);
       }
     }
     // ---------------- FiLM layers 1 .. L-1 ----------------
 #pragma unroll 1
     for (int l = 1; l < L; ++l) {
       const float* ff = film_lane(l);
+      const TapeW<SAVE> tw = tape_of(l);
       half8 yh[KS], yl[KS];
       if (l + 1 < L) film_issue(l + 1);
       if (SQ_CHUNKS < DPF + 2) WAIT_VMCNT(0);
@@ -546,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
                 piece_range<C0_QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
-                  if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
+                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd);
               }
             });
           }
@@ -554,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
         }
 #pragma unroll
         for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
-        epi_all<KS, FILM_F / 4>(acc_prev, NB - 1, ff, yh, yl);
+        epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
         // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
         {
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -605,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
                 piece_range<QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
-                  if (pc >= p0 && pc < p1) epi_compute<KS>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl);
+                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd);
               }
             });
           }
@@ -613,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
         }
 #pragma unroll
         for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
-        epi_all<KS, FILM_F / 4>(acc_prev, NB - 1, ff, yh, yl);
+        epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
       }
 #pragma unroll
       for (int k = 0; k < KS; ++k) { xh[k] = yh[k]; xl[k] = yl[k]; }
@@ -661,14 +701,14 @@ static int hip_fail16w(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool SAVE>
 static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const int stage_f4 = (16 * m->C + 3) / 4;
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)(H / 32) * 1024 + 80 * 4 +
                      (size_t)NWAVE * stage_f4 * 16 + (size_t)NWAVE * 4096;   // ring + FiLM buffers + layer-0 weights + head consts +
                                                                                // output staging + colour-layer-0 operands
-  auto kfn = siren16w_kernel<H, GRID>;
+  auto kfn = siren16w_kernel<H, GRID, SAVE>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -684,11 +724,19 @@ static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
 // One launch over points whose tiles do not straddle images (launch_siren16s splits per image otherwise).
 int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream) {
   const bool g = m->grid_ch != 0;
+  if (q.tape) {   // forward-save: the same kernel also dumps the tape (and the sampled grid features)
+    switch (m->H) {
+      case 32: return g ? w16::launch_t<32, true, true>(m, q, stream) : w16::launch_t<32, false, true>(m, q, stream);
+      case 64: return g ? w16::launch_t<64, true, true>(m, q, stream) : w16::launch_t<64, false, true>(m, q, stream);
+      case 128: return g ? w16::launch_t<128, true, true>(m, q, stream) : w16::launch_t<128, false, true>(m, q, stream);
+      case 256: return g ? w16::launch_t<256, true, true>(m, q, stream) : w16::launch_t<256, false, true>(m, q, stream);
+    }
+  }
   switch (m->H) {
-    case 32: return g ? w16::launch_t<32, true>(m, q, stream) : w16::launch_t<32, false>(m, q, stream);
-    case 64: return g ? w16::launch_t<64, true>(m, q, stream) : w16::launch_t<64, false>(m, q, stream);
-    case 128: return g ? w16::launch_t<128, true>(m, q, stream) : w16::launch_t<128, false>(m, q, stream);
-    case 256: return g ? w16::launch_t<256, true>(m, q, stream) : w16::launch_t<256, false>(m, q, stream);
+    case 32: return g ? w16::launch_t<32, true, false>(m, q, stream) : w16::launch_t<32, false, false>(m, q, stream);
+    case 64: return g ? w16::launch_t<64, true, false>(m, q, stream) : w16::launch_t<64, false, false>(m, q, stream);
+    case 128: return g ? w16::launch_t<128, true, false>(m, q, stream) : w16::launch_t<128, false, false>(m, q, stream);
+    case 256: return g ? w16::launch_t<256, true, false>(m, q, stream) : w16::launch_t<256, false, false>(m, q, stream);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

@@ -472,9 +472,9 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
   for (int n = threadIdx.x; n < H; n += blockDim.x) {
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;     // two independent chains: the loads are latency-bound
     if (P.film16w) {
-      // [tile16][layer][nb][slot = 4 g + r][rt][s0, s1] with feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r
+      // [tile16][layer][nb][rt][slot = 4 g + r][s0, s1] with feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r
       const int f = n & 31, gq = ((f >> 4) << 1) | ((f >> 2) & 1), rt = (f >> 3) & 1, r = f & 3;
-      const int idx = (n >> 5) * 64 + (gq * 4 + r) * 4 + rt * 2;
+      const int idx = (n >> 5) * 64 + rt * 32 + (gq * 4 + r) * 2;
       const long long stride = (long long)L * 2 * H;
       const float* p0 = P.film_tiles + ((tile_base * 2 + 2 * t0) * L + l) * 2LL * H + idx;
       for (int t = 2 * t0; t < 2 * t1; t += 2, p0 += 2 * stride) {
