@@ -10,6 +10,7 @@ Tolerances (north_star: <= 1e-3 max-abs RGB vs the reference CPU path, exact arg
 import ast
 import functools
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1349,6 +1350,20 @@ def test_part_forward_gradient_on_a_ray_subset():
         pf = gen.point_forward(pts, dd.unsqueeze(2).expand(-1, -1, N, -1), o, dd, zz.unsqueeze(-1), z, z, N, False, **{k: kw[k] for k in ("clamp_mode", "nerf_noise")})
         img = pf.reshape(B, S_, S_, -1).permute(0, 3, 1, 2) * 2 - 1
         assert np.abs(N_(img) - N_(px_full)).max() <= 2e-6
+
+
+@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (128, 4, 1, 160), (256, 6, 1, 64)])
+def test_the_two_bf16_chain_kernels_agree(H, grid, B, P):
+    """siren_bwd16w_kernel (16-point waves, workgroup-shared LDS stream: the default) against siren_bwd16_kernel (32-point waves,
+    private streams; FENERF_BACKWARD_KERNEL=b16) on identical inputs: d(theta) of every layer, d(grid features), FiLM and weight
+    gradients.  The choice is per process, so tools/chain_kernels_ab.py runs one child per kernel."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chain_kernels_ab.py")
+    r = subprocess.run([sys.executable, tool, "--H", str(H), "--grid", str(grid), "--B", str(B), "--P", str(P)], capture_output=True, text=True,
+                       timeout=600)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith("worst")]
+    print(f"[parity] chain kernels H={H} B={B} P={P}: {tail[-1] if tail else r.stdout[-400:] + r.stderr[-400:]}")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_backward_api_rejects_bad_arguments():

@@ -196,9 +196,9 @@ def emulate_chain16(blob, spec, theta, f_true, row_scale, d_out, out):
     return dtheta, d_e
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0)])
-def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
+def chain_case(kind, H, grid, precision):
+    """One 32-point tile: the packed backward stream + what torch fp64 autograd says dL/dtheta of every FiLM layer is.
+    -> dict(spec, sd, blob, theta [L][H][32], ref [L][H][32], f_true, row_scale [L][H], d_out, out [32][C])"""
     spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
     sd = proc.make_state_dict(spec, seed=13, sigma_gain=5.0, with_mapping=False)
     blob = _lib.pack_backward_host(sd, spec, precision)
@@ -233,8 +233,11 @@ def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
             m = np.abs(sd[n].astype(np.float32)).max(1)
             _, ex = np.frexp(m)
             row_scale[l] = np.where(m > 0, np.ldexp(1.0, -ex), 1.0) * 16
-    emu = emulate_chain16 if precision == "f16x3" else emulate_chain
-    got, d_e = emu(blob, spec, theta, f_true, row_scale, d_out, out.detach().numpy()[0])
+    return dict(spec=spec, sd=sd, blob=blob, theta=theta, ref=ref, f_true=f_true, row_scale=row_scale, d_out=d_out, out=out.detach().numpy()[0])
+
+
+def check_chain(case, got, d_e, precision, grid):
+    spec, sd, ref, f_true = case["spec"], case["sd"], case["ref"], case["f_true"]
     # the fp32 stream holds fp32 values (the fp64-folded label head is rounded once): agreement to fp32 resolution;
     # the bf16 stream holds hi + lo = 16+ significant bits of each weight
     tol = 2e-5 if precision == "f16x3" else 5e-7
@@ -244,3 +247,12 @@ def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
         W = sd["color_layer_sine.0.layer.weight"].astype(np.float64)[:, 3:35]
         dz = ref[spec["n_geo"]] * f_true[spec["n_geo"]][:, None]                 # [H][32]
         np.testing.assert_allclose(d_e, (W.T @ dz).T, atol=tol * max(1.0, np.abs(dz).max()), rtol=1e-5 if precision == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0)])
+def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
+    case = chain_case(kind, H, grid, precision)
+    emu = emulate_chain16 if precision == "f16x3" else emulate_chain
+    got, d_e = emu(case["blob"], case["spec"], case["theta"], case["f_true"], case["row_scale"], case["d_out"], case["out"])
+    check_chain(case, got, d_e, precision, grid)

@@ -1,7 +1,7 @@
 """A/B of the two bf16x3 chain kernels on identical inputs: runs itself once per kernel (the choice is per process,
 FENERF_BACKWARD_KERNEL), compares the d(theta) dumps layer by layer, d(grid features) and the parameter gradients.
 
-    python tools/debug_bwd16w.py [--H 32] [--grid 5] [--B 2] [--P 96]
+    python tools/chain_kernels_ab.py [--H 32] [--grid 5] [--B 2] [--P 96]
 """
 import argparse
 import os
@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--grid", type=int, default=5)
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--P", type=int, default=96)
+    ap.add_argument("--tol", type=float, default=1e-4, help="both kernels round dz to bf16 pairs (the remainder differently): ~2e-5")
     ap.add_argument("--child", default=None)
     a = ap.parse_args()
     if a.child:
@@ -84,11 +85,18 @@ def main():
             v = dg[t, l, g_, ln, i]
             where = np.argwhere(np.isclose(dr[t, l], v, rtol=1e-3, atol=0))
             print(f"   got[{t},{l},{g_},{ln},{i}] = {v:.5e}; ref has it at", where[:4].tolist(), " ref value there", dr[t, l, g_, ln, i])
+    worst = 0.0
+    for l in range(L):
+        worst = max(worst, float(np.abs(dr[:, l] - dg[:, l]).max() / max(np.abs(dr[:, l]).max(), 1e-30)))
     for k in ref.files:
         if k in ("d_t", "tape"):
             continue
         sc = max(np.abs(ref[k]).max(), 1e-30)
-        print(f"{k}: rel diff {np.abs(ref[k] - got[k]).max() / sc:.3e}")
+        e = float(np.abs(ref[k] - got[k]).max() / sc)
+        worst = max(worst, e)
+        print(f"{k}: rel diff {e:.3e}")
+    print(f"worst relative difference between the two chain kernels: {worst:.3e}")
+    sys.exit(0 if worst <= a.tol else 1)
 
 
 if __name__ == "__main__":
