@@ -6,7 +6,7 @@ rm -rf gpurun_out/pmc_gstep; mkdir -p gpurun_out/pmc_gstep
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_gstep/p$i -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 2 --size 64 --skip-eager --iters 2) > gpurun_out/pmc_gstep/p$i.log 2>&1
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_gstep/p$i -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py ${GSTEP_ARGS:---B 2 --size 64} --skip-eager --iters 2) > gpurun_out/pmc_gstep/p$i.log 2>&1
   echo "pass $i ($set) exit $?" >> gpurun_out/pmc_gstep/summary.txt
 done
 python - <<'PY' > gpurun_out/pmc_gstep/gstep_pmc_summary.txt 2>&1
