@@ -253,34 +253,42 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
 // and roundings ~2^-16 relative per product, unbiased, random over 10^5..10^6 points).  bf16 rather than fp16 because dtheta has
 // no a-priori range.  Used for FENERF_PREC_F16X3 models; FENERF_PREC_F32 models keep the exact fp32 job above.
 //
-// LDS image: A_p / B_p rows [feature][32 points] of split-packed dwords (hi | lo << 16), row stride WG_LD -- the lane's 8
-// consecutive points of a k-step are two 128-bit reads and four v_perm_b32 per half.  With the MFMA time cut 5x the kernel
-// is bound by its two dump reads (dtheta_l, tape_{l-1}); the FiLM sums come from the chain kernel (film_gather_kernel).
+// LDS image: A_p / B_p rows [feature][hi: 32 points bf16 | lo: 32 points bf16 | pad], row stride WG_LD dwords (144 B) -- the
+// lane's 8 consecutive points of a k-step are ONE 128-bit read per half, ready-made MFMA operands.  (Round 1 kept one
+// split-packed dword per point and unpacked with v_perm_b32 at every fragment read: the B fragments are re-read for each of
+// the wave's four row tiles, and the unpacking alone was 320 of the wave's 860 VALU instructions per tile on a kernel whose one
+// wave per SIMD spent 60 % of its time issuing, profiles/r02_pmc_gstep_waits.txt.  Staging now writes the halves with 16-bit LDS
+// stores -- the hi half is the upper half of the fp32 register as it is -- and splits with and / sub / v_cvt_pk_bf16_f32.)
+// With the MFMA time cut 5x the kernel is bound by its two dump reads (dtheta_l, tape_{l-1}); the FiLM sums come from the
+// chain kernel (film_gather_kernel).
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ unsigned split_pack_bf16(float v) {
-  const unsigned vb = __builtin_bit_cast(unsigned, v);
-  const float hi = __builtin_bit_cast(float, vb & 0xffff0000u);
-  const unsigned rb = __builtin_bit_cast(unsigned, v - hi);          // exact
-  return (vb >> 16) | ((rb + 0x8000u) & 0xffff0000u);               // remainder rounded (a truncated one biases every product by 2^-17)
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+// four values of one point -> rows row .. row + 3 of an image: hi = bf16 truncation (the upper half of the fp32 word), lo = the
+// exact remainder rounded to nearest (a truncated remainder would bias every product by 2^-17)
+__device__ __forceinline__ void stage_split4(unsigned short* row0_m, const float (&v)[4]) {
+  unsigned vb[4];
+  float rem[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vb[i] = __builtin_bit_cast(unsigned, v[i]);
+    rem[i] = v[i] - __builtin_bit_cast(float, vb[i] & 0xffff0000u);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x2w rr = {rem[2 * j], rem[2 * j + 1]};
+    const unsigned lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2w));
+    row0_m[(2 * j) * (2 * WG_LD)] = (unsigned short)(vb[2 * j] >> 16);
+    row0_m[(2 * j + 1) * (2 * WG_LD)] = (unsigned short)(vb[2 * j + 1] >> 16);
+    row0_m[(2 * j) * (2 * WG_LD) + 32] = (unsigned short)lo2;
+    row0_m[(2 * j + 1) * (2 * WG_LD) + 32] = (unsigned short)(lo2 >> 16);
+  }
 }
 
 struct Frag16 { bf16x8 hi, lo; };
-// 8 consecutive split-packed points -> (hi8, lo8)
-__device__ __forceinline__ Frag16 unpack_frag(const unsigned* row8) {
-  const uint4 a = *reinterpret_cast<const uint4*>(row8), b = *reinterpret_cast<const uint4*>(row8 + 4);
-  uint4 h, l;
-  h.x = __builtin_amdgcn_perm(a.y, a.x, 0x05040100u); l.x = __builtin_amdgcn_perm(a.y, a.x, 0x07060302u);
-  h.y = __builtin_amdgcn_perm(a.w, a.z, 0x05040100u); l.y = __builtin_amdgcn_perm(a.w, a.z, 0x07060302u);
-  h.z = __builtin_amdgcn_perm(b.y, b.x, 0x05040100u); l.z = __builtin_amdgcn_perm(b.y, b.x, 0x07060302u);
-  h.w = __builtin_amdgcn_perm(b.w, b.z, 0x05040100u); l.w = __builtin_amdgcn_perm(b.w, b.z, 0x07060302u);
-  Frag16 f;
-  f.hi = __builtin_bit_cast(bf16x8, h);
-  f.lo = __builtin_bit_cast(bf16x8, l);
-  return f;
-}
 
 // 4 waves (2 x 2 over the 8 x 8 output tiles; 4 x 4 tiles = 256 accumulator AGPRs each, one wave per SIMD).
 // The LDS image is double-buffered: while the MFMAs of tile t read buffer t & 1, tile t + 1 (already in registers) is staged
@@ -349,14 +357,12 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
     if ((hp & 1) == 0) {
       const float4 a = va[q];
       const float d[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dst[(row + i) * WG_LD + m] = split_pack_bf16(d[i]);
+      stage_split4(reinterpret_cast<unsigned short*>(dst + row * WG_LD) + m, d);
     } else {
       const float4 b = vb[q];
       const float x[4] = {sin2pi(__builtin_fmaf(f4.x, b.x, p4.x)), sin2pi(__builtin_fmaf(f4.y, b.y, p4.y)),
                           sin2pi(__builtin_fmaf(f4.z, b.z, p4.z)), sin2pi(__builtin_fmaf(f4.w, b.w, p4.w))};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dst[H * WG_LD + (row + i) * WG_LD + m] = split_pack_bf16(x[i]);
+      stage_split4(reinterpret_cast<unsigned short*>(dst + H * WG_LD + row * WG_LD) + m, x);
     }
   };
 
@@ -383,28 +389,19 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       auto a_tile = [&](int mt) { return (wm0 + mt < NB) ? wm0 + mt : NB - 1; };   // waves beyond the tile grid recompute the
       auto b_tile = [&](int kt) { return (wk0 + kt < NB) ? wk0 + kt : NB - 1; };   // last tile (not stored)
       // Fragments are re-read from LDS per tile pair rather than cached (no room beside 256 accumulators), software-pipelined:
-      // the raw rows of group (mt, kt + 1) are fetched behind the first MFMA of group (mt, kt) and unpacked (v_perm) between
-      // its later MFMAs -- the six MFMAs of a group are dependent (same accumulator), so whatever sits between them is free.
-      struct Raw { uint4 a[2], b[2]; };                           // two k-steps x (8 points = 2 x 128 bit) of split-packed dwords
-      auto raw_load = [&](const unsigned* base, int tile_idx) {
-        Raw r;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const uint4* p = reinterpret_cast<const uint4*>(base + (tile_idx * 32 + i) * WG_LD + 16 * ks + 8 * kh);
-          r.a[ks] = p[0]; r.b[ks] = p[1];
-        }
-        return r;
+      // the fragments of group (mt, kt + 1) are fetched behind the first MFMA of group (mt, kt) -- the six MFMAs of a group are
+      // dependent (same accumulator), so whatever sits between them is free.
+      auto frag = [&](const unsigned* base, int tile_idx, int ks) {   // row = 9 x 16 B: [hi points 0..31 | lo points 0..31 | pad]
+        const uint4* p = reinterpret_cast<const uint4*>(base + (tile_idx * 32 + i) * WG_LD);
+        Frag16 f;
+        f.hi = __builtin_bit_cast(bf16x8, p[2 * ks + kh]);
+        f.lo = __builtin_bit_cast(bf16x8, p[4 + 2 * ks + kh]);
+        return f;
       };
-      auto unpack = [&](const Raw& r, int ks) {
-        const unsigned row8[8] = {r.a[ks].x, r.a[ks].y, r.a[ks].z, r.a[ks].w, r.b[ks].x, r.b[ks].y, r.b[ks].z, r.b[ks].w};
-        return unpack_frag(row8);
-      };
-      Raw rb = raw_load(B_p, b_tile(0));
+      Frag16 bf[2] = {frag(B_p, b_tile(0), 0), frag(B_p, b_tile(0), 1)};
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) {
-        const Raw ra = raw_load(A_p, a_tile(mt));
-        Frag16 af[2] = {unpack(ra, 0), unpack(ra, 1)};
-        Frag16 bf[2] = {unpack(rb, 0), unpack(rb, 1)};
+        const Frag16 af[2] = {frag(A_p, a_tile(mt), 0), frag(A_p, a_tile(mt), 1)};
 #pragma unroll
         for (int kt = 0; kt < WK; ++kt) {
           const bool last = mt == WM - 1 && kt == WK - 1;
@@ -413,7 +410,10 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           float4 f4[HPG], p4[HPG];
           // sched_barriers pin this order: left alone the scheduler hoists the unpack right behind the loads
           acc[mt][kt] = MFMA_BF16(af[0].lo, bf[0].hi, acc[mt][kt]);
-          if (!last) rb = raw_load(B_p, b_tile(kt + 1 < WK ? kt + 1 : 0));
+          if (!last) {
+            const int nt = b_tile(kt + 1 < WK ? kt + 1 : 0);
+            bn[0] = frag(B_p, nt, 0); bn[1] = frag(B_p, nt, 1);
+          }
 #pragma unroll
           for (int j = 0; j < HPG; ++j)
             if (g * HPG + j < 2 * GPW) film_rows(g * HPG + j, f4[j], p4[j]);
@@ -431,12 +431,9 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].hi, acc[mt][kt]);
           acc[mt][kt] = MFMA_BF16(af[1].lo, bf[1].hi, acc[mt][kt]);
           __builtin_amdgcn_sched_barrier(0);
-          if (!last && kt + 1 < WK) bn[0] = unpack(rb, 0);
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].lo, acc[mt][kt]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (!last && kt + 1 < WK) bn[1] = unpack(rb, 1);
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].hi, acc[mt][kt]);
-          if (kt + 1 < WK) { bf[0] = bn[0]; bf[1] = bn[1]; }
+          if (!last) { bf[0] = bn[0]; bf[1] = bn[1]; }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
