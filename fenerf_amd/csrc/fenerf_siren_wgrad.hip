@@ -495,14 +495,25 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
 }
 
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
-__device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int nchunk) {   // 4 independent partial sums:
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                                                // the loads are latency-bound
+// NC independent partial sums, fixed summation order (deterministic).  The thin jobs' reductions are latency-bound (few elements,
+// up to 256 chunks each: 16 chains, 23 -> 17 us, five of them per backward chunk); the square job's is bandwidth-bound (64 MB:
+// 4 chains, 14 us -- with 16 planes open per thread it drops to 20).
+template <int NC>
+__device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int nchunk) {
+  float s[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) s[j] = 0.f;
   int k = 0;
-  for (; k + 4 <= nchunk; k += 4) {
-    s0 += src[(size_t)k * stride]; s1 += src[(size_t)(k + 1) * stride]; s2 += src[(size_t)(k + 2) * stride]; s3 += src[(size_t)(k + 3) * stride];
+  for (; k + NC <= nchunk; k += NC) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) s[j] += src[(size_t)(k + j) * stride];
   }
-  for (; k < nchunk; ++k) s0 += src[(size_t)k * stride];
-  return (s0 + s1) + (s2 + s3);
+  for (; k < nchunk; ++k) s[0] += src[(size_t)k * stride];
+#pragma unroll
+  for (int w = NC / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int j = 0; j < w; ++j) s[j] += s[j + w];
+  return s[0];
 }
 
 __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
@@ -513,7 +524,7 @@ __global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const 
     const int r = i / cols, c = i % cols;
     float sum = 0.f;
     for (int b = 0; b < B; ++b) {
-      const float s = sum_chunks(src + ((size_t)b * nchunk * src_rows + r) * src_ld + src_col0 + c, (size_t)src_rows * src_ld, nchunk);
+      const float s = sum_chunks<16>(src + ((size_t)b * nchunk * src_rows + r) * src_ld + src_col0 + c, (size_t)src_rows * src_ld, nchunk);
       sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI / (inv ? inv[(size_t)layer * H + r] : 1.f)) : s;
     }
     dst[(size_t)r * dst_ld + dst_col0 + c] = sum;
@@ -534,7 +545,7 @@ __global__ void wgrad_reduce_sq_kernel(FenerfSirenGrads g, const float* sq, int 
     const int r = i / H, c = i % H;
     float sum = 0.f;
     for (int b = 0; b < B; ++b) {
-      const float s = sum_chunks(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk);
+      const float s = sum_chunks<4>(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk);
       sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
     }
     dst[(size_t)r * ld + col0 + c] = sum;
