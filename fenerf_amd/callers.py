@@ -309,3 +309,57 @@ def render_double_latent_video(generator, seed, options, trajectory, latent_type
         out["acc"].append(weight_sum[:, -3:])
         out["depth"].append(depth)
     return {k: torch.cat(v) for k, v in out.items()}
+
+
+def camera_trajectory_single(name, num_frames, fov):
+    """[(t, pitch, yaw, fov)] of run_video_latent_interpolation, the single-latent variant (render_video_interpolation_semantic.py:
+    197-262) -- its 'orbit' and 'rotation_horizontal' differ from the double-latent function's, and it has 'rotation_angles' /
+    'rotation_pi' instead of 'zoom'."""
+    pi = np.pi
+    lin = lambda a, b, n: np.linspace(a, b, n)
+    if name == "front":
+        return [(t, 0.2 * np.cos(t * 2 * pi) + pi / 2, 0.4 * np.sin(t * 2 * pi) + pi / 2, fov + 5 + np.sin(t * 2 * pi) * 5) for t in lin(0, 1, num_frames)]
+    if name == "orbit":
+        return [(t, 0.2 * np.cos(t * 2 * pi) + pi / 4, t * 2 * pi, fov) for t in lin(0, 1, num_frames)]
+    if name == "rotation_horizontal":
+        return [(t, pi / 2, pi / 2 + t * 0.5, fov) for t in list(lin(-1, 1, num_frames // 2)) + list(lin(1, -1, num_frames // 2))]
+    if name == "rotation_angles":
+        return [(t, pi / 2, pi / 2 + a, fov) for t, a in enumerate([-0.5, -0.25, 0.0, 0.25, 0.5])]
+    if name == "rotation_pi":
+        return [(t, pi / 2, pi / 2 + t * 0.5 * pi, fov) for t in lin(-1, 1, num_frames)]
+    if name == "non_rotation":
+        return [(t, pi / 2, pi / 2, fov) for t in lin(0, 1, num_frames)]
+    if name == "sphere":
+        return [(t, 0.2 * np.cos(t * 2 * pi) + pi / 2, 0.4 * np.sin(t * 2 * pi) + pi / 2, fov) for t in lin(0, 1, num_frames)]
+    raise ValueError(f"unknown trajectory {name!r} (front | orbit | rotation_horizontal | rotation_angles | rotation_pi | non_rotation | sphere)")
+
+
+def render_latent_video(generator, seed, options, trajectory, latent_type="geo", psi=0.5, device=None, latents=None):
+    """The frame loop of run_video_latent_interpolation (:264-299) for a single-latent ImplicitGenerator3d: z_current, z_next drawn
+    back to back after torch.manual_seed(seed), FiLM parameters truncated towards the mean (FrequencyInterpolator, :109-128) and
+    interpolated with the trajectory's t (latent_type 'non': the first identity throughout), one
+    staged_forward_with_frequencies per trajectory entry.  -> dict(images [F,C,S,S] on the device, depth [F,S,S] on the CPU)."""
+    device = torch.device(device) if device is not None else generator.device
+    z_dim = int(getattr(generator, "z_dim", 256))
+    if latents is None:
+        torch.manual_seed(seed)
+        z1 = torch.randn(1, z_dim, device=device)
+        z2 = torch.randn(1, z_dim, device=device)
+    else:
+        z1, z2 = (torch.as_tensor(t, dtype=torch.float32, device=device) for t in latents)
+    avg_f, avg_p = generator.generate_avg_frequencies()
+    with torch.no_grad():
+        f1, p1 = generator.siren.mapping_network(z1)
+        f2, p2 = generator.siren.mapping_network(z2)
+    f1, p1, f2, p2 = avg_f + psi * (f1 - avg_f), avg_p + psi * (p1 - avg_p), avg_f + psi * (f2 - avg_f), avg_p + psi * (p2 - avg_p)
+    out = dict(images=[], depth=[])
+    kw = {k: v for k, v in options.items() if k != "num_frames"}
+    for t, pitch, yaw, fov in trajectory:
+        t = float(t)
+        film = (f1, p1) if latent_type == "non" else (f1 * (1 - t) + f2 * t, p1 * (1 - t) + p2 * t)
+        kw.update(h_mean=float(yaw), v_mean=float(pitch), fov=float(fov), h_stddev=0, v_stddev=0)
+        frame, depth = generator.staged_forward_with_frequencies(*film, **kw)
+        out["images"].append(frame)
+        out["depth"].append(depth)
+    return {k: torch.cat(v) for k, v in out.items()}
+

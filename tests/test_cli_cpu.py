@@ -95,6 +95,19 @@ def test_options_bags_and_trajectories():
     assert [round(f, 6) for *_, f in callers.camera_trajectory("zoom", 5, 12)] == [12, 17, 12, 7, 12]
     with pytest.raises(ValueError):
         callers.camera_trajectory("nope", 3, 12)
+    # the single-latent script's own trajectories (render_video_interpolation_semantic.py:197-262)
+    so = callers.camera_trajectory_single("orbit", 5, 12)
+    np.testing.assert_allclose([y for _, _, y, _ in so], np.linspace(0, 2 * np.pi, 5), atol=1e-12)
+    np.testing.assert_allclose(so[0][1], 0.2 + np.pi / 4, atol=1e-12)
+    rh = callers.camera_trajectory_single("rotation_horizontal", 7, 12)          # two sweeps of num_frames // 2
+    assert len(rh) == 6 and [round(t, 6) for t, *_ in rh] == [-1, 0, 1, 1, 0, -1]
+    ra = callers.camera_trajectory_single("rotation_angles", 99, 12)
+    np.testing.assert_allclose([y - np.pi / 2 for _, _, y, _ in ra], [-0.5, -0.25, 0, 0.25, 0.5], atol=1e-12)
+    rp = callers.camera_trajectory_single("rotation_pi", 3, 12)
+    np.testing.assert_allclose([y for _, _, y, _ in rp], [0, np.pi / 2, np.pi], atol=1e-12)
+    assert callers.camera_trajectory_single("front", 4, 12) == callers.camera_trajectory("front", 4, 12)
+    with pytest.raises(ValueError):
+        callers.camera_trajectory_single("zoom", 3, 12)
 
 
 def test_torch_ema_style_pickle_loads_through_the_aliases(tmp_path):

@@ -841,6 +841,62 @@ def test_cli_front_ends_write_what_the_reference_scripts_write(tmp_path):
     assert raw[:4] == b"RIFF" and raw.count(b"00db") == 6                               # 3 frames [image | labels | blend | depth]
 
 
+def test_single_latent_video_interpolation_loop_and_cli(tmp_path):
+    """callers.render_latent_video / --interpolation_type video_latent_interpolation (render_video_interpolation_semantic.py:187-312,
+    the ImplicitGenerator3d variant): frame j is staged_forward_with_frequencies on the truncated FiLM parameters interpolated at the
+    trajectory's t; the command writes the per-frame PNGs, the strip and the video."""
+    import functools
+    import subprocess
+    import json
+    from PIL import Image
+    from conftest import ROOT
+    from fenerf_amd import curriculums
+    torch.manual_seed(0)
+    gen = G.ImplicitGenerator3d(functools.partial(S.SPATIALSIRENBASELINE, hidden_dim=32), 16, 4).to(DEV)
+    gen.set_device(torch.device(DEV))
+    gen.eval()
+    cur = {0: {"batch_size": 1, "num_steps": 4, "img_size": 8}, "fov": 12, "ray_start": 0.88, "ray_end": 1.12, "h_stddev": 0.3,
+           "v_stddev": 0.155, "h_mean": np.pi / 2, "v_mean": np.pi / 2, "sample_dist": "gaussian", "clamp_mode": "relu",
+           "hierarchical_sample": True, "white_back": False, "last_back": False, "z_dist": "gaussian", "fill_mode": "weight"}
+    opts = callers_mod().video_kwargs(cur, image_size=8, ray_step_multiplier=1, psi=0.7, num_frames=3, fov=12)
+    traj = callers_mod().camera_trajectory_single("sphere", 3, 12)
+    out = callers_mod().render_latent_video(gen, 5, opts, traj, latent_type="geo", psi=0.7, device=DEV)
+    assert tuple(out["images"].shape) == (3, 3, 8, 8) and tuple(out["depth"].shape) == (3, 8, 8)
+    torch.manual_seed(5)
+    z1, z2 = torch.randn(1, 16, device=DEV), torch.randn(1, 16, device=DEV)
+    with torch.no_grad():
+        af, ap = gen.generate_avg_frequencies()
+        (f1, p1), (f2, p2) = gen.siren.mapping_network(z1), gen.siren.mapping_network(z2)
+        tr = lambda a, r: a + 0.7 * (r - a)
+        t, pitch, yaw, fov = traj[0]          # same generator state as the loop's first frame: seed, two latents, the avg-frequency pass
+        kw = {k: v for k, v in opts.items() if k != "num_frames"}
+        kw.update(h_mean=float(yaw), v_mean=float(pitch), fov=float(fov), h_stddev=0, v_stddev=0)
+        first, _ = gen.staged_forward_with_frequencies(tr(af, f1) * (1 - t) + tr(af, f2) * t, tr(ap, p1) * (1 - t) + tr(ap, p2) * t, **kw)
+    assert torch.allclose(out["images"][0], first[0], atol=1e-5)
+    non = callers_mod().render_latent_video(gen, 5, opts, traj, latent_type="non", psi=0.7, device=DEV)
+    assert torch.allclose(non["images"][0], out["images"][0], atol=1e-5) and not torch.allclose(non["images"][2], out["images"][2], atol=1e-4)
+    # the command on a pickled single-latent generator
+    from fenerf_amd import ema as ema_mod
+    ckpt = str(tmp_path / "100_generator.pth")
+    gen.avg_frequencies = gen.avg_phase_shifts = None
+    torch.save(gen.cpu(), ckpt)
+    torch.save(ema_mod.ExponentialMovingAverage(gen.parameters(), decay=0.999), str(tmp_path / "100_ema.pth"))
+    cur_file = str(tmp_path / "cur.json")
+    json.dump({("int:0" if k == 0 else k): v for k, v in cur.items()}, open(cur_file, "w"))
+    vids = str(tmp_path / "vids")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render_video_interpolation.py"), ckpt, "--curriculum", cur_file,
+                        "--interpolation_type", "video_latent_interpolation", "--seeds", "5", "--output_dir", vids, "--image_size", "8",
+                        "--ray_step_multiplier", "1", "--num_frames", "3", "--trajectory", "sphere", "--psi", "0.7", "--save_with_video"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = os.path.join(vids, "interpolation_geo_5")
+    assert np.asarray(Image.open(os.path.join(d, "video_latent_interpolation_img_0.png"))).shape[:2] == (8 + 4, 3 * 10 + 2)
+    for j in range(3):
+        assert np.asarray(Image.open(os.path.join(d, "images", "geo_sphere", f"img_{j}.png"))).shape[:2] == (8, 8)
+    raw = open(os.path.join(d, "interp_geo_5.avi"), "rb").read()
+    assert raw[:4] == b"RIFF" and raw.count(b"00db") == 6
+
+
 def test_reference_checkpoint_renders_like_the_reference():
     """A pickled reference generator (whole nn.Module, the reference's checkpoint format) loaded through the import aliases
     renders, on the HIP path, what the reference rendered from it."""

@@ -9,8 +9,8 @@ Per seed, in `<output_dir>/interpolation_<latent_type>_<seed>/`: `images/<latent
 depth_color}_<j>.png` per frame and the strips `interp.png`, `interp_seg.png`, `interp_acc_map.png`, `interp_depth_map.png`
 (or, with --save_with_video, `interp_<latent_type>_<seed>.avi`: frames [image | labels | blend | depth colours] side by side
 at 25 fps -- uncompressed AVI, because neither cv2 nor skvideo is a dependency here; the reference writes the same frames as
-mp4v through cv2.VideoWriter).  `--interpolation_type video_latent_interpolation` (the single-latent ImplicitGenerator3d
-variant, :188-312) is not provided.  --max_batch_size / --batch_size / --seed_mode / --save_with_latent are accepted for
+mp4v through cv2.VideoWriter).  `--interpolation_type video_latent_interpolation` runs the single-latent ImplicitGenerator3d
+variant (:187-312: its own trajectories, per-frame img_<j>.png + one strip, rgb frames in the video).  --max_batch_size / --batch_size / --seed_mode / --save_with_latent are accepted for
 command-line compatibility; the fused renderer needs no chunking.
 """
 import argparse
@@ -45,14 +45,39 @@ def build_parser():
     return parser
 
 
+def run_single_latent(opt, generator, options, device):
+    """run_video_latent_interpolation (render_video_interpolation_semantic.py:187-312): rgb + sigma generator, one latent."""
+    import numpy as np
+    from fenerf_amd import callers, imageio_lite
+    generator.output_dim, generator.channel_dim = 4, 3          # :189-190
+    options = dict(options, output_dim=4)
+    trajectory = callers.camera_trajectory_single(opt.trajectory, options['num_frames'], options['fov'])
+    for i, seed in enumerate(opt.seeds):
+        output_dir = os.path.join(opt.output_dir, f'interpolation_{opt.latent_type}_{seed}')
+        frame_dir = os.path.join(output_dir, "images", f"{opt.latent_type}_{opt.trajectory}")
+        os.makedirs(frame_dir, exist_ok=True)
+        out = callers.render_latent_video(generator, int(seed), dict(options, max_batch_size=opt.max_batch_size, depth_map=opt.depth_map),
+                                          trajectory, latent_type=opt.latent_type, psi=opt.psi, device=device)
+        images = out["images"].cpu()
+        for j in range(images.shape[0]):
+            imageio_lite.save_image(images[j:j + 1], os.path.join(frame_dir, f"img_{j}.png"), nrow=1, normalize=True)
+        imageio_lite.save_image(images, os.path.join(output_dir, f"{opt.interpolation_type}_img_{i}.png"), nrow=opt.num_frames, normalize=True)
+        if opt.save_with_video:
+            writer = imageio_lite.AviWriter(os.path.join(output_dir, f'interp_{opt.latent_type}_{seed}.avi'), fps=25)
+            for j in range(images.shape[0]):
+                writer.write(imageio_lite.to_uint8_hwc(imageio_lite.make_grid(images[j:j + 1], normalize=True)))
+            writer.release()
+        print(f"seed {seed}: {images.shape[0]} frames -> {output_dir}")
+
+
 def main(argv=None):
     opt = build_parser().parse_args(argv)
     import numpy as np
     import torch
     from fenerf_amd import callers, imageio_lite
     from render_multiview import resolve_curriculum
-    if opt.interpolation_type != 'video_double_latent_interpolation':
-        raise SystemExit(f"--interpolation_type {opt.interpolation_type}: only video_double_latent_interpolation is provided")
+    if opt.interpolation_type not in ('video_double_latent_interpolation', 'video_latent_interpolation'):
+        raise SystemExit(f"--interpolation_type {opt.interpolation_type}: video_double_latent_interpolation | video_latent_interpolation")
     if not torch.cuda.is_available():
         raise SystemExit("render_video_interpolation.py renders on the GPU (fenerf_amd has no CPU path)")
     device = torch.device('cuda')
@@ -61,6 +86,8 @@ def main(argv=None):
                                    opt.num_frames, opt.fov, opt.fill_color)
     os.makedirs(opt.output_dir, exist_ok=True)
     generator = callers.load_generator(opt.path, device)
+    if opt.interpolation_type == 'video_latent_interpolation':
+        return run_single_latent(opt, generator, options, device)
     generator.output_dim = options['output_dim']          # :316-317
     generator.channel_dim = options['output_dim'] - 1
     trajectory = callers.camera_trajectory(opt.trajectory, options['num_frames'], options['fov'])
