@@ -12,8 +12,9 @@
 
 namespace fenerf {
 
-#define MAX_M 256  // samples per ray handled by one wave
-#define SLOTS 4    // samples per lane: slot s of lane l is sample 64 s + l (slots past M are skipped)
+// MAXM (template parameter, 256 or 512): samples per ray handled by one wave; SLOTS = MAXM / 64 samples per lane: slot s of lane l
+// is sample 64 s + l (slots past M are skipped).  The launchers pick 256 whenever it fits (half the LDS and registers).
+#define MAX_M_LIMIT 512
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -46,12 +47,13 @@ __device__ __forceinline__ float softplus_f(float x) {  // F.softplus(beta=1, th
 // ------------------------------------------------------------------------------------------------
 // composite (+ optional merge of fine/coarse): one wave per ray
 // ------------------------------------------------------------------------------------------------
-template <bool MERGE>
+template <bool MERGE, int MAXM>
 __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
-  __shared__ float s_z[4][MAX_M];      // z by source index (merge) / sorted z
-  __shared__ float s_zs[4][MAX_M + 1]; // sorted z
-  __shared__ int s_ord[4][MAX_M];      // sorted position -> source index
-  __shared__ float s_w[4][MAX_M];      // weights by sorted position
+  constexpr int SLOTS = MAXM / 64;
+  __shared__ float s_z[4][MAXM];      // z by source index (merge) / sorted z
+  __shared__ float s_zs[4][MAXM + 1]; // sorted z
+  __shared__ int s_ord[4][MAXM];      // sorted position -> source index
+  __shared__ float s_w[4][MAXM];      // weights by sorted position
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int M = P.M, C = P.C, N = P.N;
@@ -223,11 +225,12 @@ __device__ __forceinline__ float wave_suffix_incl(float v, int lane) {   // incl
   return v;
 }
 
-template <bool MERGE>
+template <bool MERGE, int MAXM>
 __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams P) {
-  __shared__ float s_z[4][MAX_M];
-  __shared__ float s_zs[4][MAX_M + 1];
-  __shared__ int s_ord[4][MAX_M];
+  constexpr int SLOTS = MAXM / 64;
+  __shared__ float s_z[4][MAXM];
+  __shared__ float s_zs[4][MAXM + 1];
+  __shared__ int s_ord[4][MAXM];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int M = P.M, C = P.C, N = P.N, nch = C - 1;
   const long long nwaves = (long long)gridDim.x * 4;
@@ -366,8 +369,14 @@ int launch_composite_backward(const CompositeParams& p, bool merge, void* stream
   if (p.BR <= 0) return FENERF_OK;
   long long blocks = (p.BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  if (merge) hipLaunchKernelGGL(composite_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(composite_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  const bool big = p.M > 256;
+  if (merge) {
+    if (big) hipLaunchKernelGGL((composite_backward_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_backward_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    if (big) hipLaunchKernelGGL((composite_backward_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_backward_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error(std::string("composite_backward launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
   return FENERF_OK;
@@ -378,19 +387,20 @@ int launch_composite_backward(const CompositeParams& p, bool merge, void* stream
 // ------------------------------------------------------------------------------------------------
 // RAW = false: zc [BR,N], wc [BR,N] (coarse z / weights), K = N-2, draws N samples      (generators.py:486-499)
 // RAW = true : zc = bins [BR,K+1], wc = weights [BR,K] as the caller passes them to sample_pdf, draws NS samples
-template <bool RAW>
+// RS = 64-sample slots per lane: K + 1 <= 64 RS knots, NS <= 64 RS draws (2: the reference's curricula; 4: up to 256 samples)
+template <bool RAW, int RS>
 __global__ __launch_bounds__(256) void resample_kernel(long long BR, int K, int NS, const float* __restrict__ zc,
                                                        const float* __restrict__ wc, const float* __restrict__ u,
                                                        float* __restrict__ zf) {
-  __shared__ float s_cdf[4][MAX_M];
-  __shared__ float s_bin[4][MAX_M];
+  __shared__ float s_cdf[4][64 * RS];
+  __shared__ float s_bin[4][64 * RS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int N = K + 2;          // RAW=false: coarse samples per ray; pdf bins = weights[:, 1:-1]; cdf has K+1 knots
   const long long nwaves = (long long)gridDim.x * 4;
   for (long long ray = (long long)blockIdx.x * 4 + wv; ray < BR; ray += nwaves) {
-    float ww[2];
+    float ww[RS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < RS; ++s) {
       const int j = lane + 64 * s;   // pdf bin j uses coarse weight j+1
       ww[s] = 0.f;
       if (RAW) {
@@ -401,19 +411,24 @@ __global__ __launch_bounds__(256) void resample_kernel(long long BR, int K, int 
         if (j < K + 1) s_bin[wv][j] = 0.5f * (zc[ray * N + j] + zc[ray * N + j + 1]);  // z_vals_mid (generators.py:494)
       }
     }
-    const float tot = wave_sum(ww[0] + ww[1]);
-    const float pdf0 = ww[0] / tot, pdf1 = ww[1] / tot;                               // (:274)
-    const float inc0 = wave_scan_add(pdf0, lane);
-    const float tot0 = __shfl(inc0, 63, 64);
+    float wsum = ww[0];
+#pragma unroll
+    for (int s = 1; s < RS; ++s) wsum += ww[s];
+    const float tot = wave_sum(wsum);
     if (lane == 0) s_cdf[wv][0] = 0.f;                                                 // (:276)
-    if (lane < K) s_cdf[wv][lane + 1] = inc0;
-    if (K > 64) {
-      const float inc1 = wave_scan_add(pdf1, lane);
-      if (lane + 64 < K) s_cdf[wv][lane + 65] = tot0 + inc1;
+    float base = 0.f;
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      if (64 * s < K) {                                                                // wave-uniform
+        const float inc = wave_scan_add(ww[s] / tot, lane);                            // pdf (:274), cdf = cumsum (:275)
+        if (lane + 64 * s < K) s_cdf[wv][lane + 64 * s + 1] = s == 0 ? inc : base + inc;
+        const float tots = __shfl(inc, 63, 64);
+        base = s == 0 ? tots : base + tots;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < RS; ++s) {
       const int i = lane + 64 * s;
       if (i < NS) {
         const float ui = u[ray * NS + i];
@@ -516,8 +531,14 @@ int launch_composite(const CompositeParams& p, bool merge, void* stream) {
   if (p.BR <= 0) return FENERF_OK;
   long long blocks = (p.BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  if (merge) hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  const bool big = p.M > 256;
+  if (merge) {
+    if (big) hipLaunchKernelGGL((composite_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    if (big) hipLaunchKernelGGL((composite_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((composite_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "composite launch");
 }
@@ -526,7 +547,8 @@ int launch_resample(long long BR, int N, const float* z, const float* w, const f
   if (BR <= 0) return FENERF_OK;
   long long blocks = (BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(resample_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
+  if (N > 128) hipLaunchKernelGGL((resample_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
+  else hipLaunchKernelGGL((resample_kernel<false, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "resample launch");
 }
@@ -535,7 +557,8 @@ int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const floa
   if (BR <= 0) return FENERF_OK;
   long long blocks = (BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(resample_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
+  if (K > 127 || NS > 128) hipLaunchKernelGGL((resample_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
+  else hipLaunchKernelGGL((resample_kernel<true, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "sample_pdf launch");
 }

@@ -203,7 +203,7 @@ int fenerf_siren_time_rays(const FenerfModel* m, int B, int R, int N, const floa
                            const float* phase_app, float* out, void* film_ws, int iters, float* avg_ms, void* stream);
 
 /* replaces: fancy_integration (volumetric_rendering.py:18-106).
- * rgb_sigma [BR, M, C] (M <= 256), z [BR, M], noise [BR, M] N(0,1) draws or NULL.
+ * rgb_sigma [BR, M, C] (M <= 512), z [BR, M], noise [BR, M] N(0,1) draws or NULL.
  * out_rgb [BR, C-1] (or [BR, C] for the two seg-padding fill modes), out_depth [BR],
  * out_weights [BR, M] or NULL, out_wsum [BR] or NULL. */
 int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma, const float* z, const float* noise,
@@ -222,7 +222,7 @@ int fenerf_sample_pdf(int64_t BR, int K, int n_importance, const float* bins, co
                       float* samples, void* stream);
 
 /* replaces: cat([fine, coarse]) -> torch.sort(z) -> gather -> fancy_integration (generators.py:508-519):
- * merges without materialising the sorted [BR,2N,C] tensor.  fine/coarse [BR,N,C] (N <= 128), z_* [BR,N], noise [BR,2N] or NULL
+ * merges without materialising the sorted [BR,2N,C] tensor.  fine/coarse [BR,N,C] (N <= 256), z_* [BR,N], noise [BR,2N] or NULL
  * (indexed by SORTED position, like the reference's noise tensor).  out_weights [BR,2N] in sorted order or NULL;
  * out_z_sorted [BR,2N] or NULL. */
 int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const float* coarse, const float* z_fine,

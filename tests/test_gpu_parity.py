@@ -187,9 +187,9 @@ def test_composite_variants_vs_reference():
 
 
 def test_composite_max_samples_and_empty():
-    """M = 256 (four samples per lane, the documented maximum), slot boundaries, M = 1, zero rays."""
+    """M = 512 (eight samples per lane, the documented maximum; up to 256 the four-slot kernel runs), slot boundaries, M = 1, zero rays."""
     rng = np.random.default_rng(5)
-    for M in (256, 193, 129, 128, 65, 64, 1):
+    for M in (512, 449, 257, 256, 193, 129, 128, 65, 64, 1):
         rs = rng.normal(size=(3, 7, M, 22)).astype(np.float32)
         rs[..., -1] *= 30
         z = np.sort(rng.uniform(0.88, 1.12, (3, 7, M, 1)).astype(np.float32), axis=2)
@@ -205,7 +205,7 @@ def test_composite_max_samples_and_empty():
     e = native.composite(torch.empty((0, 4, 22), device=DEV), torch.empty((0, 4), device=DEV), None, _lib.composite_opts("relu"))
     assert e[0].shape == (0, 21)
     with pytest.raises(_lib.FenerfError):
-        native.composite(torch.zeros((1, 257, 22), device=DEV), torch.zeros((1, 257), device=DEV), None, _lib.composite_opts("relu"))
+        native.composite(torch.zeros((1, 513, 22), device=DEV), torch.zeros((1, 513), device=DEV), None, _lib.composite_opts("relu"))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -232,6 +232,57 @@ def test_sample_pdf_and_resample_vs_reference():
         assert err < (3e-6 if "tiny" in name else 6e-5)
     with pytest.raises(_lib.FenerfError):
         native.resample(torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV))
+
+
+@pytest.mark.parametrize("N", [129, 200, 256])
+def test_more_than_128_samples_per_pass(N):
+    """The reference has no limit on num_steps; one wave per ray handles up to 256 + 256: resample (four 64-sample slots), the
+    rank-merge composite on 2 N <= 512 samples and its backward, against the oracle / torch autograd."""
+    rng = np.random.default_rng(N)
+    BR, C = 9, 22
+    z_c = np.sort(rng.uniform(0.88, 1.12, (BR, N)).astype(np.float32), axis=1)
+    w_c = (rng.random((BR, N)).astype(np.float32) ** 4)
+    w_c[0, 40:90] = 0                                            # a stretch of empty bins
+    u = rng.random((BR, N)).astype(np.float32)
+    zf = native.resample(T(z_c), T(w_c), T(u))
+    ref = O.fine_z_from_coarse(w_c.reshape(1, BR, N, 1), z_c.reshape(1, BR, N, 1), u).reshape(BR, N)
+    # conditioning as in test_sample_pdf_and_resample_vs_reference: cdf rounding x bin_width / denom
+    print(f"[parity] resample N={N}: max|err| {np.abs(N_(zf) - ref).max():.3e}")
+    np.testing.assert_allclose(N_(zf), ref, atol=6e-5)
+    assert np.abs(N_(zf) - ref).mean() < 1e-6
+    fine = rng.normal(size=(BR, N, C)).astype(np.float32); coarse = rng.normal(size=(BR, N, C)).astype(np.float32)
+    fine[..., -1] *= 30; coarse[..., -1] *= 30
+    z_f = N_(zf)
+    opts = _lib.composite_opts("relu")
+    rgb, depth, w, ws, zs = native.merge_composite(T(fine), T(coarse), T(z_f), T(z_c), None, opts)
+    all_out, all_z = O.merge_sorted(fine[None], coarse[None], z_f[None, ..., None], z_c[None, ..., None])
+    r_rgb, r_depth, r_w = O.fancy_integration(all_out, all_z, clamp_mode="relu")
+    np.testing.assert_array_equal(N_(zs), all_z[0, ..., 0])
+    np.testing.assert_allclose(N_(rgb), r_rgb[0], atol=2e-5)
+    np.testing.assert_allclose(N_(depth), r_depth[0, ..., 0], atol=2e-5)
+    np.testing.assert_allclose(N_(w), r_w[0, ..., 0], atol=1e-5)
+    # the fused render (fenerf_render_forward: coarse SIREN, composite, resample, fine SIREN, merge) with N + N samples per ray
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=2, sigma_gain=40.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV, "f32")
+    film = proc.film_params(spec, 1, seed=2)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    torch.manual_seed(N)
+    o, d, z, _, _ = VR.sample_rays(1, N, DEV, 12, (3, 3), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    uu = torch.rand((9, N), device=DEV)
+    rgb, depth, w, _ = nat.render(o, d, z, uu, None, None, *tf, opts, hierarchical=True, want_weights=True)
+    oo, dd, zz, un = N_(o), N_(d), N_(z), N_(uu)
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    dexp = np.broadcast_to(dd[:, :, None, :], (1, 9, N, 3)).reshape(1, -1, 3)
+    coarse_o = O.siren_forward(sd, spec, (oo[:, :, None, :] + dd[:, :, None, :] * zz[..., None]).reshape(1, -1, 3), dexp, *args).reshape(1, 9, N, -1)
+    _, _, cw = O.fancy_integration(coarse_o, zz[..., None], clamp_mode="relu")
+    zfo = O.fine_z_from_coarse(cw, zz[..., None], un)
+    fine_o = O.siren_forward(sd, spec, (oo[:, :, None, :] + dd[:, :, None, :] * zfo).reshape(1, -1, 3), dexp, *args).reshape(1, 9, N, -1)
+    ao, az = O.merge_sorted(fine_o, coarse_o, zfo, zz[..., None])
+    r_rgb, r_depth, _ = O.fancy_integration(ao, az, clamp_mode="relu")
+    err = np.abs(N_(rgb) - r_rgb).max()
+    print(f"[parity] fused render with {N}+{N} samples per ray vs the oracle: max|err| {err:.2e}")
+    assert err <= 1e-3 and np.abs(N_(depth) - r_depth[..., 0]).max() <= 1e-3
 
 
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n24_trained"])
@@ -952,7 +1003,7 @@ def _grad_case(BR, N, C, seed, merge):
 @pytest.mark.parametrize("clamp,last_back,white,black,noise_std", [("relu", False, False, False, 0.0), ("softplus", False, False, False, 0.5),
                                                                     ("relu", True, False, False, 0.3), ("relu", False, True, False, 0.0),
                                                                     ("softplus", True, False, True, 0.2)])
-@pytest.mark.parametrize("N", [1, 7, 24, 64, 100, 150, 256])
+@pytest.mark.parametrize("N", [1, 7, 24, 64, 100, 150, 256, 300, 512])
 def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise_std):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(37, N, 22, 5 + N, False)
@@ -969,7 +1020,7 @@ def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise
     assert err <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("N", [12, 24, 64, 72, 128])
+@pytest.mark.parametrize("N", [12, 24, 64, 72, 128, 200])
 def test_merge_composite_backward_vs_autograd(N):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(29, N, 22, 40 + N, True)
