@@ -496,8 +496,8 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
 
 // dst[r][dst_col0 + c] = sum_b scale(b, r) * sum_chunk src[(b, chunk)][r][src_col0 + c]; scale = 2 pi f'[b][layer][r] or 1
 // NC independent partial sums, fixed summation order (deterministic).  The thin jobs' reductions are latency-bound (few elements,
-// up to 256 chunks each: 16 chains, 23 -> 17 us, five of them per backward chunk); the square job's is bandwidth-bound (64 MB:
-// 4 chains, 14 us -- with 16 planes open per thread it drops to 20).
+// up to 256 chunks each: 16 chains); the square job's is bandwidth-bound (64 MB: 4 chains, 14 us -- with 16 planes open per
+// thread it drops to 20).
 template <int NC>
 __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int nchunk) {
   float s[NC];
@@ -514,21 +514,6 @@ __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int
 #pragma unroll
     for (int j = 0; j < w; ++j) s[j] += s[j + w];
   return s[0];
-}
-
-__global__ void wgrad_reduce_kernel(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0,
-                                    int rows, int cols, int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer) {
-  const float TWO_PI = 6.28318530717958647692f;
-  const int total = rows * cols;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int r = i / cols, c = i % cols;
-    float sum = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float s = sum_chunks<16>(src + ((size_t)b * nchunk * src_rows + r) * src_ld + src_col0 + c, (size_t)src_rows * src_ld, nchunk);
-      sum += fp ? s * (fp[((size_t)b * L + layer) * H + r] * TWO_PI / (inv ? inv[(size_t)layer * H + r] : 1.f)) : s;
-    }
-    dst[(size_t)r * dst_ld + dst_col0 + c] = sum;
-  }
 }
 
 // all square jobs in one launch: blockIdx.y = layer - 1; destination by layer (nn.Linear layout, FenerfSirenGrads)
@@ -580,18 +565,40 @@ __global__ void film_reduce_kernel(const float* part, int B, int L, int H, int n
   }
 }
 
-__global__ void rowsum_reduce_kernel(const float* part, int B, int nchunk, int rows, float* dst) {   // one block of 256 threads
-  __shared__ float red[8][32];
-  const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  float s = 0.f;
-  for (int k = grp; k < B * nchunk; k += 8) s += part[(size_t)k * 32 + r];
-  red[grp][r] = s;
-  __syncthreads();
-  if (threadIdx.x < rows) {
-    float t = 0.f;
+// The thin jobs' reductions in ONE launch (blockIdx.y = which): five small matrices and two row sums, each a latency-bound sum over
+// up to 256 chunk partials.  As seven launches they cost 5 x 17 + 2 x 9 us per backward chunk (5 x 23 with 4 chains); side by side 34 us.
+struct ReduceMat { float* dst; const float* src; int dst_ld, dst_col0, src_rows, src_ld, src_col0, rows, cols, layer, film; };
+struct ReduceSet { ReduceMat m[5]; const float* rs_src[2]; float* rs_dst[2]; int rs_rows[2]; int n_mat; };
+__global__ __launch_bounds__(256) void wgrad_reduce_thin_kernel(ReduceSet J, int B, int nchunk, const float* fp, const float* inv, int L, int H) {
+  const int job = blockIdx.y;
+  if (job < J.n_mat) {
+    const ReduceMat q = J.m[job];
+    const float TWO_PI = 6.28318530717958647692f;
+    const int total = q.rows * q.cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int r = i / q.cols, c = i % q.cols;
+      float sum = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float s = sum_chunks<16>(q.src + ((size_t)b * nchunk * q.src_rows + r) * q.src_ld + q.src_col0 + c, (size_t)q.src_rows * q.src_ld, nchunk);
+        sum += q.film ? s * (fp[((size_t)b * L + q.layer) * H + r] * TWO_PI / (inv ? inv[(size_t)q.layer * H + r] : 1.f)) : s;
+      }
+      q.dst[(size_t)r * q.dst_ld + q.dst_col0 + c] = sum;
+    }
+  } else if (blockIdx.x == 0) {
+    __shared__ float red[8][32];
+    const int k2 = job - J.n_mat;
+    const float* part = J.rs_src[k2];
+    const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float s = 0.f;
+    for (int k = grp; k < B * nchunk; k += 8) s += part[(size_t)k * 32 + r];
+    red[grp][r] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < J.rs_rows[k2]) {
+      float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
-    dst[threadIdx.x] = t;
+      for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+      J.rs_dst[k2][threadIdx.x] = t;
+    }
   }
 }
 
@@ -627,12 +634,6 @@ int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16 launch");
 }
 
-void reduce_mat(float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rows, int cols,
-                int B, int nchunk, const float* fp, const float* inv, int L, int H, int layer, hipStream_t st) {
-  const int total = rows * cols;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dst, dst_ld, dst_col0, src, src_rows, src_ld,
-                     src_col0, rows, cols, B, nchunk, fp, inv, L, H, layer);
-}
 }  // namespace
 
 int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
@@ -671,11 +672,11 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
   const int nc = wgrad_nchunk(m, B, tiles), nt = wgrad_nchunk_thin(m, B, tiles), ncm = film_nchunk(tiles) > nt ? film_nchunk(tiles) : nt;
   const size_t H = m->H;
   size_t sq = (size_t)(m->L - 1) * B * nc * H * H;         // square partials
-  const size_t thin = (size_t)B * nt * H * (H > 64 ? H : 64);   // the thin jobs reuse the buffer: [B][nt][<= H x max(H, 64)]
+  const size_t thin = (size_t)B * nt * H * 160;                 // the thin jobs reuse the buffer, side by side: [B][nt][H x 32 | H x 64 | 32 x H | 32 x H]
   if (thin > sq) sq = thin;
   size_t f = sq;
   f += (size_t)m->L * B * ncm * H * 2;                      // FiLM sums
-  f += (size_t)B * ncm * 32;                                // head row sums
+  f += (size_t)2 * B * ncm * 32;                            // head / rgb row sums
   return f * sizeof(float) + 1024;
 }
 
@@ -686,7 +687,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   const int G = m->grid_ch;
   float* sq = ws;
   size_t sq_floats = (size_t)(L - 1) * B * nc * H * H;
-  const size_t thin_floats = (size_t)B * nt * H * (H > 64 ? H : 64);
+  const size_t thin_floats = (size_t)B * nt * H * 160;
   if (thin_floats > sq_floats) sq_floats = thin_floats;
   float* film = sq + sq_floats;
   float* rows = film + (size_t)L * B * ncm * H * 2;
@@ -706,23 +707,37 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   p.partial = sq; p.layer0 = 1;
   if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
   hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
-  // the thin jobs reuse the square partial buffer (stream-ordered after the reductions above), with their own chunking
+  // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
+  // side: [H x 32 | H x 64 | 32 x H | 32 x H] per (image, chunk) -- so that ONE launch reduces all of them
   p.nchunk = nt;
-  p.layer0 = 0;
+  float* const p_l0 = sq;
+  float* const p_c0 = p_l0 + (size_t)B * nt * H * 32;
+  float* const p_hd = p_c0 + (size_t)B * nt * H * 64;
+  float* const p_rgb = p_hd + (size_t)B * nt * 32 * H;
+  float* const rows_rgb = rows + (size_t)B * ncm * 32;
+  p.layer0 = 0; p.partial = p_l0;
   if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
-  reduce_mat(g.geo_w[0], 3, 0, sq, H, 32, 0, H, 3, B, nt, p.fp, p.inv, L, H, 0, st);
-  p.layer0 = ng;
+  p.layer0 = ng; p.partial = p_c0;
   if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
-  reduce_mat(g.color_w[0], 3 + G + H, 0, sq, H, 64, 32, H, 3, B, nt, p.fp, p.inv, L, H, ng, st);          // view direction columns
-  if (G) reduce_mat(g.color_w[0], 3 + G + H, 3, sq, H, 64, 0, H, G, B, nt, p.fp, p.inv, L, H, ng, st);    // grid feature columns
-  p.layer0 = ng - 1;
+  p.layer0 = ng - 1; p.partial = p_hd; p.rowsum_partial = rows;
   if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
-  reduce_mat(g.head_w, H, 0, sq, 32, H, 0, 32, H, B, nt, nullptr, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(256), 0, st, rows, B, nt, 32, g.head_b);
-  p.layer0 = L - 1;
+  p.layer0 = L - 1; p.partial = p_rgb; p.rowsum_partial = rows_rgb;
   if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
-  reduce_mat(g.rgb_w, H, 0, sq, 32, H, 0, 3, H, B, nt, nullptr, nullptr, L, H, 0, st);
-  hipLaunchKernelGGL(rowsum_reduce_kernel, dim3(1), dim3(256), 0, st, rows, B, nt, 3, g.rgb_b);
+  ReduceSet J;
+  memset(&J, 0, sizeof(J));
+  int nm = 0;
+  auto mat = [&](float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rws, int cols, int layer, int film) {
+    J.m[nm++] = ReduceMat{dst, src, dst_ld, dst_col0, src_rows, src_ld, src_col0, rws, cols, layer, film};
+  };
+  mat(g.geo_w[0], 3, 0, p_l0, H, 32, 0, H, 3, 0, 1);
+  mat(g.color_w[0], 3 + G + H, 0, p_c0, H, 64, 32, H, 3, ng, 1);          // view direction columns
+  if (G) mat(g.color_w[0], 3 + G + H, 3, p_c0, H, 64, 0, H, G, ng, 1);    // grid feature columns
+  mat(g.head_w, H, 0, p_hd, 32, H, 0, 32, H, 0, 0);
+  mat(g.rgb_w, H, 0, p_rgb, 32, H, 0, 3, H, 0, 0);
+  J.n_mat = nm;
+  J.rs_src[0] = rows; J.rs_dst[0] = g.head_b; J.rs_rows[0] = 32;
+  J.rs_src[1] = rows_rgb; J.rs_dst[1] = g.rgb_b; J.rs_rows[1] = 3;
+  hipLaunchKernelGGL(wgrad_reduce_thin_kernel, dim3((32 * H + 255) / 256, nm + 2), dim3(256), 0, st, J, B, nt, p.fp, p.inv, L, H);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
 }
