@@ -1459,7 +1459,9 @@ def test_part_forward_gradient_on_a_ray_subset():
         assert np.abs(N_(img) - N_(px_full)).max() <= 2e-6
 
 
-@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (128, 4, 1, 160), (256, 6, 1, 64)])
+# the two large cases give every workgroup of the 16-point kernel more than one oct of tiles (256 CUs x 128 points): the stream
+# wraps for the next tile, the ring slot counter and the tape-buffer parity carry over, the last oct is ragged
+@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (128, 4, 1, 160), (256, 6, 1, 64), (256, 6, 1, 65536), (32, 5, 1, 40000), (64, 0, 2, 33024)])
 def test_the_two_bf16_chain_kernels_agree(H, grid, B, P):
     """siren_bwd16w_kernel (16-point waves, workgroup-shared LDS stream: the default) against siren_bwd16_kernel (32-point waves,
     private streams; FENERF_BACKWARD_KERNEL=b16) on identical inputs: d(theta) of every layer, d(grid features), FiLM and weight
@@ -1470,6 +1472,20 @@ def test_the_two_bf16_chain_kernels_agree(H, grid, B, P):
                        timeout=600)
     tail = [ln for ln in r.stdout.splitlines() if ln.startswith("worst")]
     print(f"[parity] chain kernels H={H} B={B} P={P}: {tail[-1] if tail else r.stdout[-400:] + r.stderr[-400:]}")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (256, 6, 1, 65536), (64, 0, 2, 33024)])
+def test_the_two_f16x3_forward_save_kernels_agree(H, grid, B, P):
+    """siren16w_kernel<.., SAVE> (16-point waves: the default) against siren16s_kernel<.., SAVE> (FENERF_FORWARD_KERNEL=f16s): outputs, the
+    tape of every FiLM layer in the shared register-dump layout, the sampled grid features; sizes with several octs per workgroup
+    and a ragged last one.  The two accumulate in different MFMA shapes: fp32 rounding apart."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chain_kernels_ab.py")
+    r = subprocess.run([sys.executable, tool, "--ab", "forward", "--H", str(H), "--grid", str(grid), "--B", str(B), "--P", str(P), "--tol", "2e-5"],
+                       capture_output=True, text=True, timeout=600)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith("worst")]
+    print(f"[parity] forward-save kernels H={H} B={B} P={P}: {tail[-1] if tail else r.stdout[-400:] + r.stderr[-400:]}")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -1,7 +1,9 @@
 """A/B of the two bf16x3 chain kernels on identical inputs: runs itself once per kernel (the choice is per process,
 FENERF_BACKWARD_KERNEL), compares the d(theta) dumps layer by layer, d(grid features) and the parameter gradients.
+--ab forward: the two f16x3 forward-save kernels instead (FENERF_FORWARD_KERNEL=f16s vs the 16-point default): outputs, tape,
+sampled grid features.
 
-    python tools/chain_kernels_ab.py [--H 32] [--grid 5] [--B 2] [--P 96]
+    python tools/chain_kernels_ab.py [--H 32] [--grid 5] [--B 2] [--P 96] [--ab backward|forward]
 """
 import argparse
 import os
@@ -35,7 +37,10 @@ def run(a, out_path):
     grads = nat.siren_param_grads(pts, dirs, *args, out, g_out, tape, tape_e, d_t)
     torch.cuda.synchronize()
     H, L = spec["hidden_dim"], spec["n_geo"] + spec["n_color"]
-    res = {"d_t": d_t[: L * H * B * P].cpu().numpy().reshape(B * P // 32, L, H // 8, 64, 4), "tape": tape[: L * H * B * P].cpu().numpy().reshape(B * P // 32, L, H // 8, 64, 4)}
+    res = {"d_t": d_t[: L * H * B * P].cpu().numpy().reshape(B * P // 32, L, H // 8, 64, 4), "tape": tape[: L * H * B * P].cpu().numpy().reshape(B * P // 32, L, H // 8, 64, 4),
+           "out": out.cpu().numpy()}
+    if tape_e is not None:
+        res["tape_e"] = tape_e.cpu().numpy()
     if d_e is not None:
         res["d_e"] = d_e.cpu().numpy()
     for k, v in grads.items():
@@ -54,6 +59,7 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--P", type=int, default=96)
     ap.add_argument("--tol", type=float, default=1e-4, help="both kernels round dz to bf16 pairs (the remainder differently): ~2e-5")
+    ap.add_argument("--ab", default="backward", choices=["backward", "forward"])
     ap.add_argument("--child", default=None)
     a = ap.parse_args()
     if a.child:
@@ -61,13 +67,27 @@ def main():
         return
     os.makedirs("gpurun_out", exist_ok=True)
     paths = {}
-    for k in ("b16", "b16w"):
+    var = "FENERF_BACKWARD_KERNEL" if a.ab == "backward" else "FENERF_FORWARD_KERNEL"
+    names = ("b16", "b16w") if a.ab == "backward" else ("f16s", "f16w")
+    for k in names:
         paths[k] = f"/tmp/dbg_{k}.npz"
-        env = dict(os.environ, FENERF_BACKWARD_KERNEL=k)
+        env = dict(os.environ)
+        env[var] = k
         subprocess.run([sys.executable, os.path.abspath(__file__), "--H", str(a.H), "--grid", str(a.grid), "--B", str(a.B), "--P", str(a.P),
-                        "--child", paths[k]], env=env, check=True, timeout=300)
-    ref, got = np.load(paths["b16"]), np.load(paths["b16w"])
+                        "--ab", a.ab, "--child", paths[k]], env=env, check=True, timeout=300)
+    ref, got = np.load(paths[names[0]]), np.load(paths[names[1]])
     print("tape identical:", np.array_equal(ref["tape"], got["tape"]))
+    if a.ab == "forward":
+        worst = 0.0
+        for k in ("out", "tape", "tape_e"):
+            if k not in ref.files:
+                continue
+            sc = max(np.abs(ref[k]).max(), 1e-30)
+            e = float(np.abs(ref[k] - got[k]).max() / sc)
+            worst = max(worst, e)
+            print(f"{k}: rel diff {e:.3e} (scale {sc:.3e})")
+        print(f"worst relative difference between the two forward-save kernels: {worst:.3e}")
+        sys.exit(0 if worst <= a.tol else 1)
     dr, dg = ref["d_t"], got["d_t"]
     T, L = dr.shape[0], dr.shape[1]
     for l in range(L - 1, -1, -1):
