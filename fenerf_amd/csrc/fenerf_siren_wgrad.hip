@@ -660,7 +660,10 @@ int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
   // partial reductions grow with the chunk count)
   long long n = (2LL * m->num_cus + B - 1) / B;
   if (n > tiles_per_image) n = tiles_per_image;
-  if (n > 256) n = 256;
+#ifndef FENERF_THIN_CAP
+#define FENERF_THIN_CAP 256
+#endif
+  if (n > FENERF_THIN_CAP) n = FENERF_THIN_CAP;
   return (int)(n < 1 ? 1 : n);
 }
 

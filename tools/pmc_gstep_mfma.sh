@@ -2,7 +2,7 @@
 # MFMA-pipe utilisation of the generator-step kernels (one rocprofv3 --pmc pass over tools/bench_gstep.py)
 export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_gstep_mfma; mkdir -p gpurun_out/pmc_gstep_mfma
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_gstep_mfma/p1 -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 2 --size 64 --skip-eager --iters 2) > gpurun_out/pmc_gstep_mfma/p1.log 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_gstep_mfma/p1 -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py ${GSTEP_ARGS:---B 2 --size 64} --skip-eager --iters 2) > gpurun_out/pmc_gstep_mfma/p1.log 2>&1
 python - <<'PY' > gpurun_out/pmc_gstep_mfma/summary.txt 2>&1
 import csv, glob
 from collections import defaultdict
@@ -10,7 +10,7 @@ agg = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob("gpurun_out/pmc_gstep_mfma/p*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if "fenerf::siren" not in name:
+        if "siren" not in name or "fenerf::" not in name:
             continue
         short = name.split("fenerf::")[1].split("(")[0][:60]
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
