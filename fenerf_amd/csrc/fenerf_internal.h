@@ -111,6 +111,7 @@ int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
 int launch_siren_backward16(const FenerfModel* m, const SirenBwdParams& p, void* stream);   // FENERF_PREC_F16X3 models
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream);  // the same on 16-point waves (fenerf_siren_bwd16w.hip)
+int bwd16w_film_unit(long long total_points, long long pts_per_image);   // points per FiLM-sum unit of that kernel: 128 (workgroup) or 16 (wave)
 bool bwd16w_enabled();   // which of the two FENERF_PREC_F16X3 chain kernels runs (their FiLM-sum tiles differ: 16 / 32 points)
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,

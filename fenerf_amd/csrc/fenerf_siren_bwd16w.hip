@@ -18,8 +18,13 @@
 // tape loads -- the in-order vmcnt queue puts every HBM load in front of ring entries needed 4 k-steps later -- and on
 // everything else it issues between MFMAs; here the other wave of the SIMD fills those slots.  Measurements: DESIGN.md 4.5.
 //
-// FiLM sums are emitted per 16-point tile in register-dump order (film_gather16w_kernel, fenerf_siren_wgrad.hip, decodes it):
-//   [tile16][layer][nb][rt][slot = 4 g + r][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r.
+// FiLM sums are emitted in register-dump order (film_gather_kernel, fenerf_siren_wgrad.hip, decodes it):
+//   [unit][layer][nb][rt][slot = 4 g + r][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r,
+// unit = the workgroup's oct of eight 16-point tiles (128 points) when an oct cannot straddle images (WGS: one image per launch,
+// or points per image a multiple of 128) -- the eight waves' sums meet in LDS (three rotating 2-KiB buffers; the wave whose
+// turn it is adds them in wave order, deterministic, one step of workgroup barriers after they were written) and leave as
+// ONE 256-B store per n-block instead of eight: 23 MB instead of 184 MB per 131,072-point launch, written here and read by the
+// gather -- otherwise unit = the 16-point tile, each wave storing its own sums.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -285,7 +290,7 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   return o;
 }
 
-template <int H, bool GRID>
+template <int H, bool GRID, bool WGS>
 __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = pad_pf16(2 * (H / 16)) / CH;               // chunks per square body
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   char* tape_stage = lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES + wave * 4096;
   float* ht_lds = reinterpret_cast<float*>(lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES + NWAVE * 4096);
   float4* ext_wave = reinterpret_cast<float4*>(ht_lds + NB * 256) + wave * 128;
+  f32x2* fsum = reinterpret_cast<f32x2*>(reinterpret_cast<float4*>(ht_lds + NB * 256) + NWAVE * 128);   // WGS: [3 buffers][8 waves][rt][16 slots]
 
   for (int i = threadIdx.x; i < NB * 256; i += 512) ht_lds[i] = P.stream[i];
   wait_vmcnt<0>();
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
     // a wave past the last tile repeats the last tile: same loads, same values, same stores (no guard in the stream loop)
     long long tile = oct * NWAVE + wave;
+    const float vf = tile < ntiles ? 1.f : 0.f;     // WGS: a wave that repeats the last tile adds nothing to the oct's sums
     if (tile >= ntiles) tile = ntiles - 1;
     const long long tile32 = tile >> 1;
     const long long pt = tile * 16 + n;        // P.P is a multiple of 32 (fenerf_siren_backward)
@@ -364,7 +371,41 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TL);
 #endif
     const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
-    const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)tile * L * (2 * H * 4));
+    const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)(WGS ? oct : tile) * L * (2 * H * 4));
+    // ---- WGS: per-wave sums -> LDS buffer kb; one step of barriers later the wave whose turn it is combines and stores them
+    auto fs_write = [&](int kb, int rt, const f32x2& sm) {
+      const int lo = opaque(lane);
+      const f32x2 v = {sm[0] * vf, sm[1] * vf};
+      fsum[(kb * NWAVE + wave) * 32 + rt * 16 + (lo >> 4) * 4 + (lo & 3)] = v;
+    };
+    auto fs_combine = [&](int kb, int who, const char* dst) {
+      if (wave == who) {
+        const int lo = opaque(lane);
+        if (lo < 32) {
+          const f32x2* src = fsum + kb * NWAVE * 32 + lo;
+          f32x2 a = src[0];
+#pragma unroll
+          for (int w = 1; w < NWAVE; ++w) { const f32x2 b = src[w * 32]; a[0] += b[0]; a[1] += b[1]; }
+          st_f2(dst, (unsigned)lo * 8, a);
+        }
+      }
+    };
+    // n-blocks whose sums sit in LDS, oldest first (at most two), and the rotating buffer / combiner-wave counters
+    const char* pend_dst[2] = {nullptr, nullptr};
+    int pend_kb[2] = {0, 0}, pend_who[2] = {0, 0}, npend = 0, kb_next = 0, who_next = 0;
+    auto fs_push = [&](const char* dst) {
+      pend_dst[npend] = dst; pend_kb[npend] = kb_next; pend_who[npend] = who_next;
+      npend += 1;
+      kb_next = kb_next == 2 ? 0 : kb_next + 1;
+      who_next = (who_next + 1) & 7;
+    };
+    auto fs_pop = [&]() {
+      if (npend > 0) {
+        fs_combine(pend_kb[0], pend_who[0], pend_dst[0]);
+        pend_dst[0] = pend_dst[1]; pend_kb[0] = pend_kb[1]; pend_who[0] = pend_who[1];
+        npend -= 1;
+      }
+    };
 
     auto film_issue = [&](int layer) {   // f'' (H floats) then p' (H floats) of `layer` into buffer layer & 1
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(film_base) + (layer & 1) * FILM_BYTES);
@@ -483,9 +524,16 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const EpiOut o = epi_compute(acc, q, zh[nb], zl[nb], rt);
           st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o.dt);
           const f32x2 s = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
-          st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
+          if (WGS) fs_write(nb % 3, rt, s);
+          else st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
+        }
+        if (WGS) {   // once per tile and n-block: every wave's sums of this n-block are in buffer nb % 3; buffer reuse is three barriers away
+          __builtin_amdgcn_s_barrier();
+          LDS_FENCE();
+          fs_combine(nb % 3, nb & 7, k.film_base + nb * 256);
         }
       }
+      kb_next = NB % 3; who_next = NB & 7;
     }
     AK a_cur = ws_read(ws, ws.cs, 0);
 
@@ -543,6 +591,10 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
             if (bop(2 * qc + spl, bh, bl)) kstep_mfma(acc, a_cur, bh, bl);
             if constexpr (EPI) {
               if (spl == 1) {
+                // WGS: the oldest n-block whose sums sit in LDS was completed (second B item or a stage-trailing epilogue) at least one
+                // workgroup barrier ago -- bodies are >= 1 step, barriers at most 2 steps apart, this is the body's second chunk
+                // (first of a one-chunk body), in front of the items that may complete another
+                if constexpr (WGS && qc == (QBS > 1 ? 1 : 0)) fs_pop();
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                   if (item_chunk(QBS, it) != qc) continue;
@@ -559,7 +611,12 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   } else {
                     if constexpr (nb > 0) {
                       const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), row_sum4(eo[rt].dtt, k.b0, k.b1)};
-                      st_f2(k.film_base + (nb - 1) * 256 + rt * 128, k.foff, sm);
+                      if (WGS) {
+                        fs_write(kb_next, rt, sm);
+                        if (rt == 1) fs_push(k.film_base + (nb - 1) * 256);
+                      } else {
+                        st_f2(k.film_base + (nb - 1) * 256 + rt * 128, k.foff, sm);
+                      }
                     }
                   }
                 }
@@ -583,7 +640,12 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const EpiOut o = epi_compute(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
           st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
           const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
-          st_f2(k.film_base + (NBODY - 1) * 256 + rt * 128, k.foff, sm);
+          if (WGS) {
+            fs_write(kb_next, rt, sm);
+            if (rt == 1) fs_push(k.film_base + (NBODY - 1) * 256);
+          } else {
+            st_f2(k.film_base + (NBODY - 1) * 256 + rt * 128, k.foff, sm);
+          }
         }
       } else {
         acc_last[0] = acc_prev[0]; acc_last[1] = acc_prev[1];
@@ -628,6 +690,12 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       for (int s = 0; s < KS; ++s) { zh[s] = yh[s]; zl[s] = yl[s]; }
       if (NB & 1) tpar ^= 1;
     }
+    if (WGS) {   // the last two n-blocks' sums
+      __builtin_amdgcn_s_barrier();
+      LDS_FENCE();
+      fs_pop();
+      fs_pop();
+    }
     wait_vmcnt<0>();   // stores may retire out of order with the DMA loads: keep them out of the counted waits
     __builtin_amdgcn_wave_barrier();
   }
@@ -640,12 +708,12 @@ static int hip_fail16w(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-template <int H, bool GRID>
-static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+template <int H, bool GRID, bool WGS>
+static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
-                     (size_t)NWAVE * 2048;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands
-  auto kfn = siren_bwd16w_kernel<H, GRID>;
+                     (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0);   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers
+  auto kfn = siren_bwd16w_kernel<H, GRID, WGS>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -655,6 +723,10 @@ static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream)
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "siren bf16 backward (16-point waves) launch");
 }
+template <int H, bool GRID>
+static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  return bwd16w_film_unit(p.P, p.pts_per_image) == 128 ? launch_w<H, GRID, true>(m, p, stream) : launch_w<H, GRID, false>(m, p, stream);
+}
 
 }  // namespace bw16
 
@@ -663,6 +735,11 @@ static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream)
 bool bwd16w_enabled() {
   static const bool on = [] { const char* v = getenv("FENERF_BACKWARD_KERNEL"); return !(v && std::string(v) == "b16"); }();
   return on;
+}
+
+// points per FiLM-sum unit of siren_bwd16w_kernel: the workgroup's 128 when an oct cannot straddle images, else the wave's 16
+int bwd16w_film_unit(long long total_points, long long pts_per_image) {
+  return (total_points == pts_per_image || pts_per_image % 128 == 0) ? 128 : 16;
 }
 
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {

@@ -44,7 +44,7 @@ struct WgradParams {
   float* partial;              // [z][b][chunk][MT*32][KT*32]
   float* film_partial;         // [L][b][chunk][H][2]: the chain kernel's per-tile FiLM sums gathered per chunk
   const float* film_tiles;     // [tiles][L][2][H] from the chain kernel (fenerf_layout.h "FiLM sums")
-  int film16w;                 // the sums come from siren_bwd16w_kernel: per 16-point tile, register-dump order (fenerf_siren_bwd16w.hip)
+  int film16w;                 // the sums come from siren_bwd16w_kernel, register-dump order (fenerf_siren_bwd16w.hip): points per unit (16 / 128), 0 = no
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
 };
 
@@ -469,15 +469,24 @@ __global__ __launch_bounds__(256) void film_gather_kernel(WgradParams P) {
   for (int n = threadIdx.x; n < H; n += blockDim.x) {
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;     // two independent chains: the loads are latency-bound
     if (P.film16w) {
-      // [tile16][layer][nb][rt][slot = 4 g + r][s0, s1] with feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r
+      // [unit][layer][nb][rt][slot = 4 g + r][s0, s1] with feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r; unit = 16 or 128 points
       const int f = n & 31, gq = ((f >> 4) << 1) | ((f >> 2) & 1), rt = (f >> 3) & 1, r = f & 3;
       const int idx = (n >> 5) * 64 + rt * 32 + (gq * 4 + r) * 2;
       const long long stride = (long long)L * 2 * H;
-      const float* p0 = P.film_tiles + ((tile_base * 2 + 2 * t0) * L + l) * 2LL * H + idx;
-      for (int t = 2 * t0; t < 2 * t1; t += 2, p0 += 2 * stride) {
-        const float2 u = *reinterpret_cast<const float2*>(p0), v = *reinterpret_cast<const float2*>(p0 + stride);
-        a0 += u.x; a1 += u.y; b0 += v.x; b1 += v.y;
+      // this chunk's units: 32-point tiles [t0, t1) hold two 16-point units each; 128-point units are split evenly over the chunks
+      long long u0, u1, ubase;
+      if (P.film16w == 16) { ubase = tile_base * 2; u0 = 2LL * t0; u1 = 2LL * t1; }
+      else {
+        const long long nu = (P.P + 127) / 128, per = (nu + P.nchunk - 1) / P.nchunk;
+        ubase = (long long)img * nu; u0 = chunk * per; u1 = u0 + per < nu ? u0 + per : nu;
       }
+      const float* p0 = P.film_tiles + ((ubase + u0) * L + l) * 2LL * H + idx;
+      long long u = u0;
+      for (; u + 2 <= u1; u += 2, p0 += 2 * stride) {
+        const float2 x = *reinterpret_cast<const float2*>(p0), v = *reinterpret_cast<const float2*>(p0 + stride);
+        a0 += x.x; a1 += x.y; b0 += v.x; b1 += v.y;
+      }
+      if (u < u1) { const float2 x = *reinterpret_cast<const float2*>(p0); a0 += x.x; a1 += x.y; }
     } else {
     int t = t0;
     for (; t + 2 <= t1; t += 2) {
@@ -756,7 +765,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.box_scale = m->box_scale;
   p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
   p.P = P; p.tiles_per_image = (int)(P / 32);
-  p.film16w = m->precision == FENERF_PREC_F16X3 && bwd16w_enabled();
+  p.film16w = (m->precision == FENERF_PREC_F16X3 && bwd16w_enabled()) ? bwd16w_film_unit((long long)B * P, P) : 0;
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {
