@@ -739,6 +739,9 @@ bool bwd16w_enabled() {
 
 // points per FiLM-sum unit of siren_bwd16w_kernel: the workgroup's 128 when an oct cannot straddle images, else the wave's 16
 int bwd16w_film_unit(long long total_points, long long pts_per_image) {
+#ifdef EXP_BW_NOWGS   // timing only: per-wave FiLM sums everywhere
+  return 16;
+#endif
   return (total_points == pts_per_image || pts_per_image % 128 == 0) ? 128 : 16;
 }
 
