@@ -100,10 +100,9 @@ struct WgShape {
 };
 
 template <int H, int JOB>
-__global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
+__device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int bz) {
   using S = WgShape<H, JOB>;
   constexpr int NQ = H / 32;                   // dump groups per wave
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* A_s = lds;                                         // [A_ROWS][WG_LD]
   float* B_s = A_s + S::A_ROWS * WG_LD;                     // [B_ROWS][WG_LD]
   float* f_s = B_s + S::B_ROWS * WG_LD;                     // f', p' of the B-side layer
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunk = blockIdx.x, img = blockIdx.y;
-  const int l = (JOB == WG_SQ) ? P.layer0 + blockIdx.z : P.layer0;   // layer whose dtheta is the A side (SQ/L0/C0X)
+  const int l = (JOB == WG_SQ) ? P.layer0 + bz : P.layer0;   // layer whose dtheta is the A side (SQ/L0/C0X)
   const int lb = (JOB == WG_SQ) ? l - 1 : ((JOB == WG_HEAD) ? P.n_geo - 1 : P.L - 1);   // B-side activation layer
   const int L = P.L, C = P.C;
 
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
 
   // ---- partials
   {
-    const int zi = (JOB == WG_SQ) ? blockIdx.z : 0;
+    const int zi = (JOB == WG_SQ) ? bz : 0;
     float* out = P.partial + (((size_t)zi * P.B + img) * P.nchunk + chunk) * (size_t)(S::A_ROWS * S::B_ROWS);
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -243,6 +242,27 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
             out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
           }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
+  }
+}
+
+template <int H, int JOB>
+__global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  wgrad_job<H, JOB>(P, lds, blockIdx.z);
+}
+
+// The four thin jobs of one backward chunk in ONE launch (blockIdx.z = which): each is a chain of load -> stage -> barrier -> exact-fp32
+// MFMAs per 32-point tile with one workgroup per CU and chunk, i.e. latency-bound (30-40 us each with the MFMAs removed); side by
+// side their workgroups fill each other's waits.
+struct ThinJobs { WgradParams j[4]; };
+template <int H>
+__global__ __launch_bounds__(256, 1) void siren_wgrad_thin_kernel(ThinJobs T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  switch (blockIdx.z) {
+    case 0: wgrad_job<H, WG_C0X>(T.j[0], lds, 0); break;     // longest first
+    case 1: wgrad_job<H, WG_HEAD>(T.j[1], lds, 0); break;
+    case 2: wgrad_job<H, WG_RGB>(T.j[2], lds, 0); break;
+    default: wgrad_job<H, WG_L0>(T.j[3], lds, 0); break;
   }
 }
 
@@ -727,14 +747,21 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   float* const p_hd = p_c0 + (size_t)B * nt * H * 64;
   float* const p_rgb = p_hd + (size_t)B * nt * 32 * H;
   float* const rows_rgb = rows + (size_t)B * ncm * 32;
-  p.layer0 = 0; p.partial = p_l0;
-  if ((rc = launch_job<H, WG_L0>(p, 1, st))) return rc;
-  p.layer0 = ng; p.partial = p_c0;
-  if ((rc = launch_job<H, WG_C0X>(p, 1, st))) return rc;
-  p.layer0 = ng - 1; p.partial = p_hd; p.rowsum_partial = rows;
-  if ((rc = launch_job<H, WG_HEAD>(p, 1, st))) return rc;
-  p.layer0 = L - 1; p.partial = p_rgb; p.rowsum_partial = rows_rgb;
-  if ((rc = launch_job<H, WG_RGB>(p, 1, st))) return rc;
+  {
+    ThinJobs T;
+    T.j[0] = p; T.j[0].layer0 = ng; T.j[0].partial = p_c0;
+    T.j[1] = p; T.j[1].layer0 = ng - 1; T.j[1].partial = p_hd; T.j[1].rowsum_partial = rows;
+    T.j[2] = p; T.j[2].layer0 = L - 1; T.j[2].partial = p_rgb; T.j[2].rowsum_partial = rows_rgb;
+    T.j[3] = p; T.j[3].layer0 = 0; T.j[3].partial = p_l0;
+    auto kfn = siren_wgrad_thin_kernel<H>;
+    size_t lds = wg_lds_bytes<H, WG_C0X>();
+    if (wg_lds_bytes<H, WG_HEAD>() > lds) lds = wg_lds_bytes<H, WG_HEAD>();
+    if (wg_lds_bytes<H, WG_L0>() > lds) lds = wg_lds_bytes<H, WG_L0>();
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds))) return rc;
+    hipLaunchKernelGGL(kfn, dim3(nt, B, 4), dim3(256), lds, st, T);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return hipfail(e2, "thin wgrad launch");
+  }
   ReduceSet J;
   memset(&J, 0, sizeof(J));
   int nm = 0;
