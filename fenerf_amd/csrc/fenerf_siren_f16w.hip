@@ -126,7 +126,11 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // overwritten next (the compiler does not look inside an asm).
 template <bool ON> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
+#ifdef EXP_W_TAPE_T   // timing only: temporal tape stores
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+#else
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+#endif
 }
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
