@@ -528,6 +528,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           else st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
         }
         if (WGS) {   // once per tile and n-block: every wave's sums of this n-block are in buffer nb % 3; buffer reuse is three barriers away
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes have completed before it arrives
           __builtin_amdgcn_s_barrier();
           LDS_FENCE();
           fs_combine(nb % 3, nb & 7, k.film_base + nb * 256);
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       if (NB & 1) tpar ^= 1;
     }
     if (WGS) {   // the last two n-blocks' sums
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       LDS_FENCE();
       fs_pop();
