@@ -643,7 +643,10 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
           if (WGS) {
             fs_write(kb_next, rt, sm);
-            if (rt == 1) fs_push(k.film_base + (NBODY - 1) * 256);
+            if (rt == 1) {
+              fs_push(k.film_base + (NBODY - 1) * 256);
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // complete before the next stage's first barrier (in the bodies, later LDS reads are waited for first)
+            }
           } else {
             st_f2(k.film_base + (NBODY - 1) * 256 + rt * 128, k.foff, sm);
           }
