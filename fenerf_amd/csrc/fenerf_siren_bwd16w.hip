@@ -742,6 +742,24 @@ bool bwd16w_enabled() {
   return on;
 }
 
+}  // namespace fenerf
+
+// Test hook (not part of include/fenerf.h): the compile-time wait counts of the chain kernel's stream loop and the schedule they are
+// derived from, so that tests/test_bwd16w_wait_counts.py can replay the in-order load queue on the CPU and check that no wait ever
+// allows more loads in flight than were issued behind the chunk it waits for.  what: 0 = ring_wait(qb, step) (a barrier every step),
+// 1 = ring_wait2(qb, step) (a barrier every second step), 2 = tape DMAs issued in chunk `step` of a body of qb chunks, 3 = DPF.
+extern "C" int fenerf_internal_bwd16w_schedule(int what, int qb, int step) {
+  using namespace fenerf::bw16;
+  switch (what) {
+    case 0: return ring_wait(qb, step);
+    case 1: return ring_wait2(qb, step);
+    case 2: return step_loads(qb, step);
+    case 3: return DPF;
+  }
+  return -1;
+}
+
+namespace fenerf {
 // points per FiLM-sum unit of siren_bwd16w_kernel: the workgroup's 128 when an oct cannot straddle images, else the wave's 16
 int bwd16w_film_unit(long long total_points, long long pts_per_image) {
 #ifdef EXP_BW_NOWGS   // timing only: per-wave FiLM sums everywhere
