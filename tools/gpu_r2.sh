@@ -12,7 +12,7 @@ tests)
   echo "pytest exit: $?" >> gpurun_out/tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
   echo "smoke exit: $?" >> gpurun_out/smoke.log
-  tail -4 gpurun_out/tests.log gpurun_out/smoke.log ;;
+  tail -n 4 gpurun_out/tests.log; tail -n 4 gpurun_out/smoke.log ;;
 ab)
   for k in f16w f16s f16w f16s; do
     FENERF_FORWARD_KERNEL=$k timeout 300 python bench.py --steps 20 --warmup 3 $Q 2>&1 | tail -1 | python -c "
