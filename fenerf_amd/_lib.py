@@ -95,6 +95,8 @@ _SIGS = {
     "fenerf_siren_grad_workspace_bytes": (_sz, [_vp, _i, _i64]),
     "fenerf_siren_param_grads": (_i, [_vp, _i, _i64] + [_vp] * 11 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_grid_backward": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "fenerf_siren_backward_fuses_grid": (_i, [_vp]),
+    "fenerf_siren_backward_grid": (_i, [_vp, _i, _i64] + [_vp] * 13),
     "fenerf_grid_gradient_ncdhw": (_i, [_vp, _vp, _vp, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

@@ -470,6 +470,43 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
 
+extern "C" int fenerf_siren_backward_fuses_grid(const FenerfModel* m) {
+  return m && m->differentiable && m->grid_ch && m->precision == FENERF_PREC_F16X3 && bwd16w_enabled();
+}
+
+extern "C" int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                          const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                          const float* tape, const float* points, float* d_t, float* d_grid_cl, float* scratch_d_e,
+                                          void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "model has no feature grid");
+  if (!points || !d_grid_cl) return fail(FENERF_E_INVALID, "points / d_grid_cl is NULL");
+  if (!fenerf_siren_backward_fuses_grid(m)) {
+    if (!scratch_d_e) return fail(FENERF_E_INVALID, "this model's chain kernel does not scatter in place: scratch_d_e is required");
+    int rc = fenerf_siren_backward(m, B, P, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, d_t, scratch_d_e, film_ws, stream);
+    if (rc || P == 0) return rc;
+    return launch_grid_backward(m, (long long)B * P, points, scratch_d_e, d_grid_cl, stream);
+  }
+  if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (P == 0) return FENERF_OK;
+  if (!out || !d_out || !tape || !d_t) return fail(FENERF_E_INVALID, "NULL pointer");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenBwdParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.stream = m->d_bwd_stream;
+  bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
+  bp.fp = fp; bp.pp = pp;
+  bp.P = (long long)B * P; bp.pts_per_image = P;
+  bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = nullptr;
+  bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;
+  bp.points = points; bp.d_grid_cl = d_grid_cl; bp.box_scale = m->box_scale; bp.gd = m->gd; bp.gh = m->gh; bp.gw = m->gw;
+  return launch_siren_backward16(m, bp, stream);
+}
+
 extern "C" size_t fenerf_siren_grad_workspace_bytes(const FenerfModel* m, int B, int64_t P) {
   if (!m || B <= 0 || P <= 0) return 0;
   return align_up(wgrad_workspace_bytes(m, B, P), 256);

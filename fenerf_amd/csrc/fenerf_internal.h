@@ -85,6 +85,12 @@ struct SirenBwdParams {
   float* d_t;              // out, tape layout: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
   float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
   float* film_tiles;       // [tiles][L][2][H] out: per-tile FiLM sums (fenerf_layout.h "FiLM sums")
+  // fused grid scatter (siren_bwd16w_kernel only): when d_grid_cl != nullptr the gradient wrt the sampled grid features is not
+  // written to d_e but scattered straight into the channels-last gradient grid (the transpose of sample_from_3dgrid)
+  const float* points;     // [P][3]
+  float* d_grid_cl;        // [gd][gh][gw][32], accumulated into
+  float box_scale;
+  int gd, gh, gw;
 };
 
 struct CompositeParams {

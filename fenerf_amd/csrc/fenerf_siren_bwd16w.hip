@@ -318,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   float* ht_lds = reinterpret_cast<float*>(lds + NSLOT * CH * 1024 + NWAVE * 2 * FILM_BYTES + NWAVE * 4096);
   float4* ext_wave = reinterpret_cast<float4*>(ht_lds + NB * 256) + wave * 128;
   f32x2* fsum = reinterpret_cast<f32x2*>(reinterpret_cast<float4*>(ht_lds + NB * 256) + NWAVE * 128);   // WGS: [3 buffers][8 waves][rt][16 slots]
+  float* pts_wave = reinterpret_cast<float*>(fsum + (WGS ? 3 * NWAVE * 32 : 0)) + wave * 48;             // fused grid scatter: this tile's 16 points
 
   for (int i = threadIdx.x; i < NB * 256; i += 512) ht_lds[i] = P.stream[i];
   wait_vmcnt<0>();
@@ -474,6 +475,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       ext[0] = __builtin_bit_cast(float4, hi);
       ext[64] = __builtin_bit_cast(float4, lo);
     }
+    if (GRID && P.d_grid_cl) {   // the tile's points, for the scatter of d(grid features) behind the colour-layer-0 stage
+      if (lane < 48) pts_wave[lane] = P.points[tile * 48 + lane];
+    }
     // ---------------- rgb head: d(pre-sigmoid) = d_rgb s (1 - s) as the B operand of the fp32 MFMA (k = r, g, b, 0)
     float brgb;
     {
@@ -538,6 +542,40 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     }
     AK a_cur = ws_read(ws, ws.cs, 0);
 
+    // Fused grid scatter (P.d_grid_cl != nullptr): the colour-layer-0 stage parks the tile's d(grid features) [16 points][32 channels]
+    // in the head-operand area of LDS; one point pair (2 points x 32 channels = two whole 128-B lines per atomic instruction, 8
+    // corners) is scattered per body of the following stage, so that the 64 atomic instructions of a tile never sit as one burst in
+    // front of a ring wait (stores and atomics are not counted, they only make a wait stricter).  The scatter costs the kernel 50 us
+    // per 131,072-point launch either way (201 M float atomics per step contend with its own HBM streams); the separate scatter
+    // kernel it replaces took 115 us per such chunk plus the d_e round trip.
+    int scat_next = 8;       // next point pair to scatter (8 = none pending)
+    auto scatter_pairs = [&](int count) {
+      const int lq = opaque(lane);
+      const float* eblk = reinterpret_cast<const float*>(ext_wave);
+      const int ch = lq & 31;
+      const float gwf = (float)(P.gw - 1), ghf = (float)(P.gh - 1), gdf = (float)(P.gd - 1);
+      for (int it = 0; it < count && scat_next < 8; ++it, ++scat_next) {
+        const int pi = 2 * scat_next + (lq >> 5);
+        const float gv = eblk[pi * 32 + ch];
+        const float qx = pts_wave[pi * 3 + 0] * P.box_scale, qy = pts_wave[pi * 3 + 1] * P.box_scale, qz = pts_wave[pi * 3 + 2] * P.box_scale;
+        const float ix = ((qx + 1.f) / 2.f) * gwf, iy = ((qy + 1.f) / 2.f) * ghf, iz = ((qz + 1.f) / 2.f) * gdf;
+        const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int cz = c >> 2, cy = (c >> 1) & 1, cx = c & 1;
+          const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
+          const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
+          const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
+          const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
+          const bool ok = xi >= 0.f && xi <= gwf && yi >= 0.f && yi <= ghf && zi >= 0.f && zi <= gdf;
+          if (ok) {
+            const long long vox = ((long long)(int)zi * P.gh + (int)yi) * P.gw + (int)xi;
+            unsafeAtomicAdd(P.d_grid_cl + vox * 32 + ch, gv * (wx * wy * wz));
+          }
+        }
+      }
+    };
+
     // One stage: NBODY bodies of QBS chunks; bop(sp, bh, bl) supplies the B operand of k32-step sp (false = padding).  With
     // EPI the bodies carry the epilogue of FiLM layer `lo` (tape layer lo, d theta / FiLM sums of layer lo) into y.
     auto run_stage = [&](auto nbody_c, auto qbs_c, auto epi_c, int lo, auto bop, u32x4 (&yh)[KS], u32x4 (&yl)[KS], f32x4 (&acc_last)[2]) {
@@ -596,6 +634,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                 // workgroup barrier ago -- bodies are >= 1 step, barriers at most 2 steps apart, this is the body's second chunk
                 // (first of a one-chunk body), in front of the items that may complete another
                 if constexpr (WGS && qc == (QBS > 1 ? 1 : 0)) fs_pop();
+                if constexpr (GRID && qc == QBS - 1) {
+                  if (scat_next < 8) scatter_pairs((8 + NBODY - 1) / NBODY);
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                   if (item_chunk(QBS, it) != qc) continue;
@@ -680,11 +721,27 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           f32x4 ge[2];
           run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, QB>{}, std::false_type{}, lo, bop, yh, yl, ge);
           const int lq = opaque(lane);
-          float* ep = P.d_e + pt * 32 + 16 * (lq >> 5) + 4 * ((lq >> 4) & 1);
+          if (P.d_grid_cl) {
+            // Fused scatter (grid_backward_kernel's arithmetic): the tile's [16 points][32 channels] block goes through the head-operand
+            // area of LDS (free since the last colour-layer-0 body).  A wave that repeats the last tile must not scatter twice.
+            float* eblk = reinterpret_cast<float*>(ext_wave);
+            float4* ew = reinterpret_cast<float4*>(eblk + (lq & 15) * 32 + 16 * (lq >> 5) + 4 * ((lq >> 4) & 1));
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
-            const f32x4 v = ge[rt];
-            *reinterpret_cast<float4*>(ep + 8 * rt) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int rt = 0; rt < 2; ++rt) {
+              const f32x4 v = ge[rt];
+              ew[2 * rt] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (vf != 0.f) scat_next = 0;     // scattered by the bodies of the next stage (run_stage) / the tile's end
+            __builtin_amdgcn_wave_barrier();
+          } else {
+            float* ep = P.d_e + pt * 32 + 16 * (lq >> 5) + 4 * ((lq >> 4) & 1);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+              const f32x4 v = ge[rt];
+              *reinterpret_cast<float4*>(ep + 8 * rt) = make_float4(v[0], v[1], v[2], v[3]);
+            }
           }
         }
       } else {
@@ -694,6 +751,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       for (int s = 0; s < KS; ++s) { zh[s] = yh[s]; zl[s] = yl[s]; }
       if (NB & 1) tpar ^= 1;
     }
+    if (GRID) scatter_pairs(8);   // whatever no later stage picked up (a model without trunk layers behind colour layer 0)
     if (WGS) {   // the last two n-blocks' sums
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -717,7 +775,7 @@ template <int H, bool GRID, bool WGS>
 static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
-                     (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0);   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers
+                     (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0) + (size_t)NWAVE * 48 * 4;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers + tile points
   auto kfn = siren_bwd16w_kernel<H, GRID, WGS>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;

@@ -121,7 +121,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         film_only = not any(need[14:])
-        r, d_e = _siren_autograd.chunked_backward(nat, 2 * B, Pp, film2, pts2, rd2, out2, d_out2, tape2,
+        r, d_grid = _siren_autograd.chunked_backward(nat, 2 * B, Pp, film2, pts2, rd2, out2, d_out2, tape2,
                                                   tape_e2 if tape_e2.numel() else None, film_only)
         fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
         film_grads = (fold(r["d_freq_geo"], need[10]), fold(r["d_phase_geo"], need[11]), fold(r["d_freq_app"], need[12]),
@@ -129,4 +129,4 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         head = (None,) * 10
         if film_only:
             return head + film_grads + (None,) * len(params)
-        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, pts2, d_e, need[14:])
+        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, pts2, d_grid, need[14:])

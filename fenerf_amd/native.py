@@ -37,6 +37,7 @@ class NativeModel:
             d, keep = _lib.make_desc(sd, spec, precision, differentiable)
             _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
         self.C = spec["output_dim"]
+        self.grid_shape = tuple(int(v) for v in sd["spatial_embeddings"].shape[2:]) if spec.get("grid_ch") else None   # (D, H, W)
         self.box_scale = 2 / 0.24       # UniformBoxWarp(0.24), siren.py:181-187 (what _lib.make_desc sets)
         self._ws = {}
         self.pack_generation = 0      # bumped by every re-pack: autograd nodes check that forward and backward saw the same weights
@@ -360,6 +361,31 @@ class NativeModel:
             _lib.check(_lib.lib().fenerf_siren_backward(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
                                                         _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
+
+    def siren_backward_grid(self, B, P, fg, pg, fa, pa, out, d_out, tape, points, d_grid_cl):
+        """siren_backward whose gradient wrt the sampled grid features is scattered (accumulated) straight into d_grid_cl
+        [D,H,W,32] (zero-initialised by the caller before the first chunk) -> d_t.  f16x3 models scatter inside the chain kernel;
+        others run the chain and the scatter kernel over a scratch d_e."""
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        out, d_out = _f32(out, self.device), _f32(d_out, self.device)
+        points = _f32(points, self.device).reshape(B * P, 3)
+        d_t = torch.empty((int(_lib.lib().fenerf_siren_dtheta_floats(self._h, B * P)),), dtype=torch.float32, device=self.device)
+        fused = bool(_lib.lib().fenerf_siren_backward_fuses_grid(self._h))
+        scratch = None if fused else torch.empty((B * P, 32), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_backward_grid(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
+                                                             _ptr(tape), _ptr(points), _ptr(d_t), _ptr(d_grid_cl), _ptr(scratch),
+                                                             C.c_void_p(ws.data_ptr()), _stream()))
+        return d_t
+
+    def grid_gradient_ncdhw(self, d_grid_cl):
+        """channels-last gradient grid [D,H,W,32] -> the parameter's layout [1,32,D,H,W]"""
+        D, Hh, W = d_grid_cl.shape[:3]
+        out = torch.empty((1, 32, D, Hh, W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fenerf_grid_gradient_ncdhw(self._h, _ptr(d_grid_cl), _ptr(out), _stream()))
+        return out
 
     def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t, film_only=False):
         """(tape, d_t) -> dict of parameter gradients in nn.Linear layout: geo_w/geo_b/color_w/color_b lists, head_w [32,H]

@@ -27,8 +27,9 @@ def _fold_label_head(label_params):
     return A, c
 
 
-def assemble_param_grads(module, nat, params, r, points, d_e, need_params):
-    """FenerfSirenGrads buffers (dict r) -> gradients in the order of `params` (module._render_params())."""
+def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params):
+    """FenerfSirenGrads buffers (dict r) + the channels-last grid gradient chunked_backward accumulated -> gradients in the order of
+    `params` (module._render_params())."""
     roles = module._roles(params)
     n_lab = nat.spec["output_dim"] - 4
     grads = {}
@@ -48,7 +49,7 @@ def assemble_param_grads(module, nat, params, r, points, d_e, need_params):
     rw, rb = roles["rgb"]
     grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
     if roles["grid"] is not None:
-        grads[id(roles["grid"])] = nat.grid_backward(points, d_e, roles["grid"].shape[2:]).contiguous()
+        grads[id(roles["grid"])] = nat.grid_gradient_ncdhw(d_grid_cl).contiguous()
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
@@ -80,8 +81,9 @@ def _add_all(dst, src):
 def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
     `max_points` points of ONE image each: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per
-    image, and every gradient is a sum over points, so chunk results simply add.  -> (grads dict like siren_param_grads with
-    [nB]-leading FiLM gradients, d_e [nB*Pp, 32] or None)."""
+    image, and every gradient is a sum over points, so chunk results simply add.  The gradient wrt the sampled grid features never
+    exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid; inside the chain
+    kernel for f16x3 models).  -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
     LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
@@ -89,7 +91,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     C = nat.C
     fg, pg, fa, pa = film
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
-    d_e_full = torch.empty((nB * Pp, 32), dtype=torch.float32, device=out.device) if G else None
+    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G else None
     total = None
     for b in range(nB):
         film_b = (fg[b:b + 1], pg[b:b + 1], fa[b:b + 1], pa[b:b + 1])
@@ -99,9 +101,10 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             g0 = b * Pp + s
             tape_c = tape[g0 * LH:(g0 + n) * LH]
             out_c, d_out_c = out[b:b + 1, s:s + n], d_out[b:b + 1, s:s + n]
-            d_t, d_e = nat.siren_backward(1, n, *film_b, out_c, d_out_c, tape_c)
             if G:
-                d_e_full[g0:g0 + n] = d_e
+                d_t = nat.siren_backward_grid(1, n, *film_b, out_c, d_out_c, tape_c, points[b:b + 1, s:s + n], d_grid)
+            else:
+                d_t, _ = nat.siren_backward(1, n, *film_b, out_c, d_out_c, tape_c)
             r = nat.siren_param_grads(points[b:b + 1, s:s + n], dirs[b:b + 1, s:s + n] if dirs is not None else None, *film_b, out_c,
                                       d_out_c, tape_c, tape_e[g0:g0 + n] if G else None, d_t, film_only=film_only)
             del d_t
@@ -119,7 +122,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             _add_all(_flat(total, FILM_KEYS), _flat(acc_b, FILM_KEYS))
     for k, rows in film_rows.items():
         total[k] = torch.cat(rows, 0)
-    return total, d_e_full
+    return total, d_grid
 
 
 def check_same_weights(ctx, nat):
@@ -161,13 +164,13 @@ class SirenFunction(torch.autograd.Function):
         d_out = d_out.contiguous().float()
         need = ctx.needs_input_grad
         film_only = not any(need[7:])        # inversion: only the FiLM parameters are optimised
-        r, d_e = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
-                                  tape_e if tape_e.numel() else None, film_only)
+        r, d_grid = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
+                                     tape_e if tape_e.numel() else None, film_only)
         film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
                       r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
         if film_only:
             return (None, None, None) + film_grads + (None,) * len(params)
-        return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, d_e, need[7:])
+        return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, d_grid, need[7:])
 
 
 def siren_apply(module, points, dirs, fg, pg, fa, pa):

@@ -276,6 +276,15 @@ int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, const float
                              const FenerfSirenGrads* grads, void* workspace, void* film_ws, void* stream);
 int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e, float* d_grid_cl,
                          void* stream);
+/* fenerf_siren_backward + fenerf_grid_backward in one call: d_t as above, and the gradient wrt the sampled grid features is
+ * scattered (accumulated) into d_grid_cl [D][H][W][32] -- grid_sample's backward (siren.py:314-330) -- instead of being returned.
+ * points [B*P][3] as given to the forward.  Models whose chain kernel scatters in place (fenerf_siren_backward_fuses_grid != 0:
+ * FENERF_PREC_F16X3 with a grid) need no scratch; otherwise scratch_d_e [B*P][32] is required and the call runs the two steps. */
+int fenerf_siren_backward_fuses_grid(const FenerfModel* m);
+int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                               const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                               const float* tape, const float* points, float* d_t, float* d_grid_cl, float* scratch_d_e,
+                               void* film_ws, void* stream);
 /* channels-last gradient grid [D][H][W][32] -> the parameter's layout [1,32,D,H,W] (spatial_embeddings.grad) */
 int fenerf_grid_gradient_ncdhw(const FenerfModel* m, const float* d_grid_cl, float* d_grid_ncdhw, void* stream);
 
