@@ -1489,6 +1489,39 @@ def test_the_two_f16x3_forward_save_kernels_agree(H, grid, B, P):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("H,B,P", [(32, 2, 96), (256, 1, 4224)])
+def test_backward_with_fused_grid_scatter_equals_backward_then_scatter(H, B, P, precision):
+    """fenerf_siren_backward_grid (f16x3: the chain kernel scatters d(grid features) into the channels-last gradient grid itself;
+    f32: chain + scatter kernel over a scratch) == fenerf_siren_backward + fenerf_grid_backward, and d_t is the same dump."""
+    spec = proc.model_spec("texture", hidden_dim=H, grid_size=7, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=11, sigma_gain=30.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV, precision, differentiable=True)
+    assert bool(_lib.lib().fenerf_siren_backward_fuses_grid(nat._h)) == (precision == "f16x3")
+    rng = np.random.default_rng(3)
+    pts = T(rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32))          # some points leave the box: zero padding
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs = T(dirs / np.linalg.norm(dirs, axis=-1, keepdims=True))
+    film = {k: T(v) for k, v in proc.film_params(spec, B, seed=4).items()}
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    out, tape, tape_e = nat.siren_forward_save(pts, dirs, *args)
+    g_out = T(rng.normal(size=(B, P, spec["output_dim"])).astype(np.float32))
+    d_t0, d_e = nat.siren_backward(B, P, *args, out, g_out, tape)
+    ref = torch.zeros((7, 7, 7, 32), device=DEV)
+    with torch.cuda.device(nat.device):
+        _lib.check(_lib.lib().fenerf_grid_backward(nat._h, B * P, native._ptr(pts.reshape(-1, 3).contiguous()), native._ptr(d_e), native._ptr(ref), None))
+    got = torch.zeros((7, 7, 7, 32), device=DEV)
+    d_t1 = nat.siren_backward_grid(B, P, *args, out, g_out, tape, pts, got)
+    n = (spec["n_geo"] + spec["n_color"]) * H * B * P
+    assert torch.equal(d_t0[:n], d_t1[:n])
+    err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+    print(f"[parity] fused grid scatter H={H} B={B} P={P} [{precision}]: relative difference {err:.2e} (float atomics in a different order)")
+    assert err <= 2e-6 and ref.abs().max().item() > 0
+    # accumulates: a second call doubles the grid
+    nat.siren_backward_grid(B, P, *args, out, g_out, tape, pts, got)
+    assert (got - 2 * ref).abs().max().item() / ref.abs().max().item() <= 4e-6
+
+
 def test_backward_api_rejects_bad_arguments():
     """Error behaviour of the differentiable entry points: a model created without the backward stream, point counts that
     are not whole tiles, a half-filled gradient struct -- negative status + message, never a launch."""
