@@ -91,7 +91,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     C = nat.C
     fg, pg, fa, pa = film
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
-    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G else None
+    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G and not film_only else None
     total = None
     for b in range(nB):
         film_b = (fg[b:b + 1], pg[b:b + 1], fa[b:b + 1], pa[b:b + 1])
@@ -101,9 +101,9 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             g0 = b * Pp + s
             tape_c = tape[g0 * LH:(g0 + n) * LH]
             out_c, d_out_c = out[b:b + 1, s:s + n], d_out[b:b + 1, s:s + n]
-            if G:
+            if G and not film_only:
                 d_t = nat.siren_backward_grid(1, n, *film_b, out_c, d_out_c, tape_c, points[b:b + 1, s:s + n], d_grid)
-            else:
+            else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
                 d_t, _ = nat.siren_backward(1, n, *film_b, out_c, d_out_c, tape_c)
             r = nat.siren_param_grads(points[b:b + 1, s:s + n], dirs[b:b + 1, s:s + n] if dirs is not None else None, *film_b, out_c,
                                       d_out_c, tape_c, tape_e[g0:g0 + n] if G else None, d_t, film_only=film_only)
