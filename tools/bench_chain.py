@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--points", type=int, default=131072)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--H", type=int, default=256)
+    ap.add_argument("--determinism", type=int, default=0, help="repeat forward-save + chain this many times and compare bit for bit")
     a = ap.parse_args()
     spec = proc.model_spec("texture", hidden_dim=a.H, grid_size=96)
     sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
@@ -43,6 +44,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
+    if a.determinism:
+        # the stream loop's synchronisation (counted vmcnt waits, barriers, LDS rings) has no data-dependent path: any race shows up
+        # as run-to-run differences.  Forward-save and chain are repeated and compared bit for bit with the first run.
+        LHP = (spec["n_geo"] + spec["n_color"]) * a.H * P
+        film_grads = lambda dt: nat.siren_param_grads(pts, dirs, *args, out, g_out, tape, tape_e, dt, film_only=True)   # consumes the FiLM sums
+        ref_t, ref_o = tape[:LHP].clone(), out.clone()
+        ref_d, ref_e = d_t[:LHP].clone(), d_e.clone()
+        ref_f = {k: v.clone() for k, v in film_grads(d_t).items()}
+        bad = 0
+        for i in range(a.determinism):
+            o2, t2, _ = nat.siren_forward_save(pts, dirs, *args)
+            d2, e2 = nat.siren_backward(1, P, *args, out, g_out, tape)
+            f2 = film_grads(d2)
+            same = torch.equal(o2, ref_o) and torch.equal(t2[:LHP], ref_t) and torch.equal(d2[:LHP], ref_d) and torch.equal(e2, ref_e) and \
+                all(torch.equal(f2[k], ref_f[k]) for k in ref_f)
+            bad += 0 if same else 1
+        print(json.dumps({"determinism_runs": a.determinism, "runs_that_differ": bad}))
+        sys.exit(1 if bad else 0)
     L, H = spec["n_geo"] + spec["n_color"], a.H
     n = L * H * P
     print(json.dumps({"points": P, "ms_median": float(np.median(ts)), "ms_min": float(np.min(ts)),
