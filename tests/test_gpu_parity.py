@@ -1522,6 +1522,18 @@ def test_backward_with_fused_grid_scatter_equals_backward_then_scatter(H, B, P, 
     assert (got - 2 * ref).abs().max().item() / ref.abs().max().item() <= 4e-6
 
 
+def test_forward_save_and_chain_kernels_are_run_to_run_deterministic():
+    """The stream loops of the 16-point kernels synchronise with counted vmcnt waits, workgroup barriers and LDS rings and have no
+    data-dependent path: a race would show up as run-to-run differences.  40 repetitions of forward-save + chain (+ the FiLM
+    gradients, which consume the workgroup-combined sums) on 33,024 points (several octs per workgroup, ragged last one), bit for bit."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_chain.py")
+    r = subprocess.run([sys.executable, tool, "--determinism", "40", "--H", "64", "--points", "33024", "--iters", "2"], capture_output=True, text=True,
+                       timeout=600)
+    print("[parity] determinism:", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+
+
 def test_backward_api_rejects_bad_arguments():
     """Error behaviour of the differentiable entry points: a model created without the backward stream, point counts that
     are not whole tiles, a half-filled gradient struct -- negative status + message, never a launch."""
