@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           for (int j = 0; j < HPG; ++j)
             if (g * HPG + j < 2 * GPW) film_rows(g * HPG + j, f4[j], p4[j]);
           __builtin_amdgcn_sched_barrier(0);
+          // The staging of this group (sin / split, 16-bit LDS stores, the refill loads) is spread behind ALL five remaining MFMAs:
+          // issued as one block behind the second it left the matrix pipe idle for ~130 cycles per group (0.600 -> 0.561 ms per
+          // launch, same box; the exact split -- 5..12 VALU per slot, the fragment reads spread too -- makes no difference).
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].lo, acc[mt][kt]);
 #pragma unroll
           for (int j = 0; j < HPG; ++j) {
@@ -447,12 +450,17 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
               if (hp & 1) fetch_q(t + 2, hp >> 1);          // both halves of dump group hp >> 1 are staged: refill its registers
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].hi, acc[mt][kt]);
           acc[mt][kt] = MFMA_BF16(af[1].lo, bf[1].hi, acc[mt][kt]);
-          __builtin_amdgcn_sched_barrier(0);
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].lo, acc[mt][kt]);
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].hi, acc[mt][kt]);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);    // up to 9 VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);    // up to 2 LDS writes
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // up to 1 global load
+          }
           if (!last) { bf[0] = bn[0]; bf[1] = bn[1]; }
           __builtin_amdgcn_sched_barrier(0);
         }
