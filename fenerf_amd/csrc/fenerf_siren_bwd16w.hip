@@ -664,6 +664,16 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                 }
               }
             }
+            if constexpr (EPI) {
+              if (spl == 1) {   // the items' VALU work between the six MFMAs of this k32-step rather than behind them (- 1 %)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                }
+              }
+            }
             a_cur = nn;
             __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue items where they are written
           }
