@@ -25,6 +25,10 @@
 // turn it is adds them in wave order, deterministic, one step of workgroup barriers after they were written) and leave as
 // ONE 256-B store per n-block instead of eight: 23 MB instead of 184 MB per 131,072-point launch, written here and read by the
 // gather -- otherwise unit = the 16-point tile, each wave storing its own sums.
+//
+// With P.d_grid_cl set (fenerf_siren_backward_grid) the gradient wrt the sampled grid features is not written to d_e: the kernel
+// scatters it into the channels-last gradient grid itself (scatter_pairs below: float atomics, the arithmetic of
+// grid_backward_kernel), two points x 32 channels per atomic instruction, one point pair per body of the following stage.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
