@@ -1516,10 +1516,10 @@ def test_backward_with_fused_grid_scatter_equals_backward_then_scatter(H, B, P, 
     assert torch.equal(d_t0[:n], d_t1[:n])
     err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
     print(f"[parity] fused grid scatter H={H} B={B} P={P} [{precision}]: relative difference {err:.2e} (float atomics in a different order)")
-    assert err <= 2e-6 and ref.abs().max().item() > 0
+    assert err <= 5e-6 and ref.abs().max().item() > 0          # fp32 sums of up to a few hundred terms in arbitrary order
     # accumulates: a second call doubles the grid
     nat.siren_backward_grid(B, P, *args, out, g_out, tape, pts, got)
-    assert (got - 2 * ref).abs().max().item() / ref.abs().max().item() <= 4e-6
+    assert (got - 2 * ref).abs().max().item() / ref.abs().max().item() <= 1e-5
 
 
 def test_forward_save_and_chain_kernels_are_run_to_run_deterministic():
