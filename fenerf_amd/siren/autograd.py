@@ -53,11 +53,12 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
-# dtheta of a backward chunk: at most this many points (x L*H*4 B = 1.5 GB at L*H = 2816; 196,608-point chunks measured the same
-# step time at 0.7 GB more).  The chain kernel writes dL/dtheta of
+# dtheta of a backward chunk: at most this many points (x L*H*4 B = 2.2 GB at L*H = 2816).  With the round-2 kernels a generator step
+# at 1 x 128^2 x 24+24 takes 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for chunks of 98,304 / 131,072 /
+# 196,608 / 393,216 points (tools/chunk_sweep.py): half a pass per chunk keeps the peak under 12 GB.  The chain kernel writes dL/dtheta of
 # every FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist
 # for more points than one chain launch's worth: peak memory of a generator step = tape + one chunk instead of 2 x tape.
-BACKWARD_CHUNK_POINTS = 131072
+BACKWARD_CHUNK_POINTS = 196608
 
 
 FILM_KEYS = ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")
