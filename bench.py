@@ -34,18 +34,35 @@ sys.path.insert(0, ROOT)
 FLOP_PER_POINT = 1_603_584          # SURVEY.md §8(d) / BASELINE.md §4 (dense layers, 2 FLOP per MAC)
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
-# HBM-side bytes per SIREN launch at the default workload (393,216 points).  A PMC pass cannot run inside this process, so the
-# figures are those of the committed rocprofv3 passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/gpu_session.sh pmc):
-TRAFFIC = {
-    "source": "profiles/r02_pmc_siren16w_f16x3.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/gpu_r2.sh pmc)",
-    "fetch_raw_bytes": 182.72e6,        # FETCH_SIZE x 1024, as reported
-    "fetch_x2_bytes": 365.43e6,         # MI355X_MICROARCH.md HBM: gfx950 reports 1/2 of wide coalesced reads; upper bound here
-    "write_bytes": 34.60e6,             # = 393,216 points x 22 channels x 4 B exactly
-    # compulsory bytes of one launch: outputs 34.6 MB + z 1.6 MB + rays 0.4 MB + weight stream 2.75 MB
-    "algorithmic_bytes": 34.60e6 + 1.57e6 + 0.39e6 + 2.75e6,
-    "note": "excess over algorithmic = the 8 x 128-B trilinear corner fetches per point (113 MB grid, TCC hit 95.6 %); "
-            "MFMA-bound kernel, 0.15-0.28 TB/s: context, not the limiter",
-}
+PEAK_HBM_TBPS = 8.0                 # MI355X_MICROARCH.md: HBM3E
+SPEC_CLOCK_GHZ = 2.4                # the clock the matrix peaks above are quoted at
+
+
+def pmc_traffic():
+    """HBM-side bytes per SIREN launch at the default workload (393,216 points) from the newest committed rocprofv3 PMC summary
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes over this file's default command, tools/gpu_r3.sh pmc -> tools/pmc_summary.py):
+    a counter pass cannot run inside the bench process, so the file is parsed at run time -- nothing is typed in."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_siren16w_f16x3.txt")))
+    if not files:
+        return None
+    vals = {}
+    for line in open(files[-1]):
+        parts = line.strip().split(",")
+        if len(parts) == 3 and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[parts[0]] = float(parts[1]) * 1024.0                 # both counters are in KiB
+    if len(vals) != 2:
+        return None
+    return {
+        "source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; parsed at run time)",
+        "fetch_raw_bytes": vals["FETCH_SIZE"],
+        "fetch_x2_bytes": 2 * vals["FETCH_SIZE"],     # MI355X_MICROARCH.md HBM: gfx950 reports 1/2 of wide coalesced reads; upper bound here
+        "write_bytes": vals["WRITE_SIZE"],            # = 393,216 points x 22 channels x 4 B
+        # compulsory bytes of one launch: outputs 34.6 MB + z 1.57 MB + rays 0.39 MB + weight stream 2.75 MB
+        "algorithmic_bytes": 393216 * 22 * 4 + 1.57e6 + 0.39e6 + 2.75e6,
+        "note": "excess over algorithmic = the 8 x 128-B trilinear corner fetches per point (113 MB grid, TCC hit ~96 %); "
+                "MFMA-bound kernel, 0.15-0.28 TB/s: context, not the limiter",
+    }
 
 
 def _free_port():
@@ -97,14 +114,21 @@ def cpu_baseline(spec, sd, film, seed, full=True):
     return out
 
 
-def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8):
+def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True):
     """BASELINE.json's metric also names the generator step: forward + backward (+ the device-side re-pack an optimizer step
     forces) through DoubleImplicitGenerator3d.forward_with_frequencies on the same workload shape, native differentiable path
-    (DESIGN.md 4.5).  Reported beside the headline value; never part of the timed region."""
+    (DESIGN.md 4.5).  Reported beside the headline value; never part of the timed region.
+
+    `roofline`: the step is HBM-bound -- the forward-save passes write the tape (pre-FiLM accumulators of all L FiLM layers), the
+    backward chain reads it and writes the d(theta) dump, the weight-gradient kernels read the dump and the tape again.  algorithmic
+    bytes = those streams plus the per-point inputs / outputs of each kernel (formulas below, sizes from the library:
+    fenerf_siren_tape_floats / fenerf_siren_dtheta_floats); `achieved` = bytes / step time against 8 TB/s; `per_kernel` = the same per
+    launch group with device times from hipEvent pairs around every launch (fenerf_phase_timing), measured in separate instrumented
+    steps."""
     import functools
     from fenerf_amd.generators import generators as G
     from fenerf_amd.siren import siren as S_
-    from fenerf_amd import procedural as proc
+    from fenerf_amd import native, procedural as proc
     H = spec["hidden_dim"]
     z_dim = spec.get("z_dim", 256)
     mod = S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE(hidden_dim=H, z_geo_dim=z_dim, z_app_dim=z_dim, output_dim=spec["output_dim"])
@@ -140,9 +164,48 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"ms": ms, "what": f"forward + backward + device re-pack of one generator step, batch {B} x {S}x{S} rays x {N}+{N} samples "
-                              f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}",
-            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
+    out = {"ms": ms, "what": f"forward + backward + device re-pack of one generator step, batch {B} x {S}x{S} rays x {N}+{N} samples "
+                             f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}",
+           "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
+    if not breakdown:
+        return out
+    # ---- HBM roofline of the step: algorithmic bytes per launch group (all sizes per sample point, x points of the step)
+    nat = mod.native_differentiable(dev)
+    L, C, G_ = spec["n_geo"] + spec["n_color"], spec["output_dim"], spec["grid_ch"]
+    pts = B * ((S * S * N + 31) // 32 * 32) * 2                         # coarse + fine pass, whole 32-point tiles per image
+    tape_b = nat.tape_floats(pts) * 4.0 / pts                            # fp32 pre-FiLM accumulators of L layers
+    dump = nat.dump_bytes_per_point()                                    # what the chain writes / the weight gradients read, per layer-feature
+    row, xyz = 4.0 * C, 12.0
+    model = {
+        "forward_save": tape_b + (128.0 if G_ else 0.0) + row + 2 * xyz,                        # tape + grid features + outputs written; points, dirs read
+        "chain": tape_b + 2 * row + xyz + dump["chain_write"] * L * H,                           # tape, out, d_out read; dump written
+        "wgrad_square": dump["square_read"] * (L - 1) * H,                                       # d(theta)_l and x_{l-1} (or tape_{l-1}) of the L-1 square layers
+        "wgrad_thin": dump["thin_read"] * H + (128.0 if G_ else 0.0) + 2 * xyz + 3 * row,        # four thin jobs: two dumps, two tape layers, points / dirs / features, rows
+    }
+    steps_b = 3
+    with native.phase_timing() as t:
+        for _ in range(steps_b):
+            step()
+    per_kernel, accounted = [], 0.0
+    for name, b_pt in model.items():
+        k_ms = t.ms.get(name, 0.0) / steps_b
+        nbytes = b_pt * pts
+        accounted += k_ms
+        per_kernel.append({"name": name, "ms": k_ms, "launches": t.calls.get(name, 0) // steps_b, "algorithmic_bytes": nbytes,
+                           "achieved_TBps": nbytes / (k_ms * 1e-3) / 1e12 if k_ms else None,
+                           "frac": nbytes / (k_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS if k_ms else None})
+    rest = {k: v / steps_b for k, v in t.ms.items() if k not in model}
+    total_bytes = sum(k["algorithmic_bytes"] for k in per_kernel)
+    out["roofline"] = {"bound": "hbm", "algorithmic_bytes": total_bytes, "achieved": total_bytes / (ms * 1e-3) / 1e12, "achieved_TBps": total_bytes / (ms * 1e-3) / 1e12,
+                       "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": total_bytes / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS,
+                       "per_kernel": per_kernel, "other_library_launches_ms": rest,
+                       "ms_not_in_library_kernels": ms - accounted - sum(rest.values()),
+                       "launch_groups_per_step": sum(t.calls.values()) // steps_b,
+                       "bytes_per_point": {"tape": tape_b, **dump},     # tape per point; the others per (point x layer-feature)
+                       "note": "algorithmic bytes = tape written once and read by the chain, the chain's dump written once and read once, the "
+                               "tape layers the weight-gradient kernels re-read, per-point rows; `frac` = bytes / whole step time / 8 TB/s; "
+                               "per_kernel times from hipEvent pairs in instrumented steps (their sum + torch glue = ms)"}
+    return out
 
 
 def dist_check(args):
@@ -173,6 +236,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="headline shape only, 1 warm-up + 1 timed run")
     ap.add_argument("--no-gstep", action="store_true", help="skip the generator-step (forward + backward) leg")
+    ap.add_argument("--no-gstep-b6", action="store_true", help="skip the 6-image generator micro-batch (configs[2]) leg")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-sweep64", action="store_true", help="skip the 64x64, 24+24 scaling-batch leg")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
@@ -198,8 +262,11 @@ def main(argv=None):
     import torch.distributed as dist
     from fenerf_amd import dist as fdist
     n_ranks_seen = 1
-    if world > 1:
-        fdist.init_from_env(backend="nccl", device=dev)   # RCCL over xGMI; timing barrier / max-reduce / rank census only
+    # FENERF_BENCH_FORCE_DIST=1: take the N > 1 branch (RCCL process group, barrier, max-reduce, all-gather) with a single rank too,
+    # so that a one-GPU box exercises the code the driver's 2/4/8-GPU runs depend on (tests/test_gpu_parity.py)
+    use_dist = world > 1 or bool(os.environ.get("FENERF_BENCH_FORCE_DIST"))
+    if use_dist:
+        fdist.init_from_env(backend="nccl", device=dev, force=True)   # RCCL over xGMI; timing barrier / max-reduce / rank census only
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         n_ranks_seen = int(ones.item())
@@ -215,7 +282,7 @@ def main(argv=None):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -240,7 +307,7 @@ def main(argv=None):
         return fdist.max_over_ranks(own, device=dev), own, (o, d, z, tf)
 
     def gather_floats(v):
-        if world == 1:
+        if not use_dist:
             return [float(v)]
         t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
         outs = [torch.zeros_like(t) for _ in range(world)]
@@ -258,6 +325,22 @@ def main(argv=None):
             # ceiling of this algorithm on the fp16 pipe is peak/3; `frac` is quoted against the full dense fp16 peak.
             peak, kname, mfma = PEAK_F16_MATRIX_TFLOPS, native.forward_kernel_name(nat), "fp16 MFMA, 3 per product (hi/lo error compensation)"
             extra = {"frac_of_f16x3_ceiling": achieved / (peak / 3)}
+        # what the matrix pipe really executes (static MFMA count of the kernel: 3 MFMAs per product at f16x3, label head folded)
+        ex_flop = nat.executed_flop_per_point()
+        extra.update({"flop_per_point_executed": ex_flop, "mfma_executed_tflops": pts * ex_flop / (k_ms * 1e-3) / 1e12,
+                      "frac_executed": pts * ex_flop / (k_ms * 1e-3) / 1e12 / peak})
+        # the power wall from inside the kernel: every workgroup stamps s_memtime / s_memrealtime at its first and
+        # last instruction -> shader cycles per launch and the clock granted while it ran; the same cycles at the 2.4 GHz the peak is
+        # quoted at give frac_at_spec_clock
+        try:
+            cp = nat.clock_probe(o, d, z, *tf, iters=iters)
+            t_spec = cp["cycles_per_launch"] / (SPEC_CLOCK_GHZ * 1e9)
+            extra.update({"cycles_per_launch": cp["cycles_per_launch"], "clock_ghz_effective": cp["clock_ghz"],
+                          "kernel_ms_with_clock_stamps": cp["kernel_ms"], "spec_clock_ghz": SPEC_CLOCK_GHZ,
+                          "kernel_ms_at_spec_clock": t_spec * 1e3, "frac_at_spec_clock": pts * FLOP_PER_POINT / t_spec / 1e12 / peak,
+                          "wall_clock_khz": cp["wall_clock_khz"]})
+        except Exception as e:
+            extra["clock_probe_error"] = f"{type(e).__name__}: {e}"
         return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "kernel": kname, "kernel_ms": k_ms, "points_per_launch": pts, "flop_per_point_algorithmic": FLOP_PER_POINT,
                 "mfma": mfma, **extra}
@@ -267,6 +350,10 @@ def main(argv=None):
     R = S * S
     dt, own, inputs = timed_render(nat, B, S, N, args.steps, args.warmup, 1000)
     value = world * B * R * args.steps / dt
+    o_, d_, z_, tf_ = inputs
+    with native.phase_timing() as one:          # launch groups of one render (every kernel launch of the library is one)
+        nat.render(o_, d_, z_, torch.rand((B * R, N), device=dev), None, None, *tf_, opts, hierarchical=True)
+    render_launches = sum(one.calls.values())
     per_rank = [B * R * args.steps / t for t in gather_floats(own)]
     roof = roofline_of(nat, inputs, B * R * N, args.precision, max(5, args.steps // 2))
     roof_frac_ranks = gather_floats(roof["frac"])
@@ -282,7 +369,7 @@ def main(argv=None):
 
     if rank == 0:
         dtype = "f32" if args.precision == "f32" else "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
-        tr = dict(TRAFFIC) if (args.precision == "f16x3" and (B, S, N) == (1, 128, 24)) else None
+        tr = pmc_traffic() if (args.precision == "f16x3" and (B, S, N) == (1, 128, 24)) else None
         out = {
             "metric": f"rays/s/GPU forward render ({S}x{S}, {N}+{N} samples, H=256 FiLM-SIREN + 32x96^3 grid)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -294,7 +381,13 @@ def main(argv=None):
             "roofline": {**roof, "traffic": (tr["fetch_x2_bytes"] + tr["write_bytes"]) if tr else None, "traffic_detail": tr,
                          "frac_per_rank": roof_frac_ranks},
             "rays_per_s_per_gpu": value / world, "rays_per_s_per_rank": per_rank, "n_ranks_seen": n_ranks_seen,
-            "launcher": "torch.distributed.run, one rank per GPU, backend nccl (RCCL)" if world > 1 else "single process",
+            "timed_region": "fenerf_render_forward on rays resident in HBM (coarse SIREN, composite, resample, fine SIREN, merge + composite: "
+                            f"{render_launches} kernel launches per step); the mapping networks, ray setup and the NCHW epilogue of a full "
+                            "generator call (0.05-0.18 ms, tools/time_call_overhead.py) are outside it",
+            "launches_per_step": render_launches,
+            "launcher": ("torch.distributed.run, one rank per GPU, backend nccl (RCCL)" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1
+                         else "single process") + (" [process group forced at world 1]" if use_dist and world == 1 else ""),
+            "dist_backend": dist.get_backend() if use_dist else None,
         }
         if sweep:
             out["sweep64"] = sweep
@@ -313,11 +406,21 @@ def main(argv=None):
                 out["gstep"] = gstep_leg(spec, sd, dev, B, S, N, args.precision)
             except Exception as e:          # the extra leg must never take the headline metric down with it
                 out["gstep"] = {"error": f"{type(e).__name__}: {e}"}
-        if not args.no_cpu_baseline and world == 1:
+            if not args.no_gstep_b6 and (B, S, N) == (1, 128, 24):
+                try:   # BASELINE.json configs[2]: the reference's generator micro-batch (batch 24 split 4 -> 6 images of 128x128 x 24+24 per GPU)
+                    torch.cuda.empty_cache()
+                    out["gstep_b6"] = gstep_leg(spec, sd, dev, 6, S, N, args.precision, iters=3, breakdown=False)
+                    out["gstep_b6"]["ms_per_image"] = out["gstep_b6"]["ms"] / 6
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    out["gstep_b6"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_cpu_baseline:
+            # N = 1: BASELINE.md's plan (1 warm-up + 3 timed runs x 3 shapes); N > 1: the headline shape once, so that every line of
+            # the driver's scaling sweep is self-contained while the other ranks wait at the final barrier for ~20 s, not a minute
             film1 = proc.film_params(spec, 1, seed=1000)
-            out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7, full=not args.quick_cpu_baseline)
+            out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7, full=(world == 1 and not args.quick_cpu_baseline))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -84,6 +84,12 @@ _SIGS = {
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
     "fenerf_ray_setup": (_i, [_i, _i, _i, C.c_float, C.c_float, C.c_float] + [_vp] * 9),
     "fenerf_siren_time_rays": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_float), _vp]),
+    "fenerf_siren_backward_stream_bytes": (_i, [_vp, _i64, C.POINTER(C.c_double)]),
+    "fenerf_siren_clock_probe": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_double), _vp]),
+    "fenerf_siren_executed_flop_per_point": (C.c_double, [_vp]),
+    "fenerf_phase_timing": (_i, [_i]),
+    "fenerf_phase_times": (_i, [C.POINTER(C.c_double), C.POINTER(_i), _i]),
+    "fenerf_phase_name": (C.c_char_p, [_i]),
     "fenerf_composite": (_i, [_i64, _i, _i, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp, _vp]),
     "fenerf_resample": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "fenerf_sample_pdf": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -103,6 +109,7 @@ _SIGS = {
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
 }
 EXPORTS = tuple(_SIGS)
+N_PHASES = 16        # include/fenerf.h FENERF_N_PHASES
 
 _lib = None
 

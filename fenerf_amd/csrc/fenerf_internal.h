@@ -16,6 +16,16 @@ void set_error(const std::string& msg);
 // from several host threads always launches with the opt-in in place (include/fenerf.h: thread-safe per handle).
 // Returns FENERF_OK or FENERF_E_HIP (error string set).
 int ensure_dynamic_lds(const void* kfn, size_t bytes);
+// Per-phase device timing (fenerf_phase_timing / fenerf_phase_times): a PhaseScope around a launch group records a hipEvent pair on
+// the stream when timing is on, and is two loads of a flag when it is off.
+enum Phase { PH_FILM_PREP = 0, PH_SIREN, PH_SIREN_SAVE, PH_CHAIN, PH_WGRAD_FILM, PH_WGRAD_SQ, PH_WGRAD_SQ_REDUCE, PH_WGRAD_THIN,
+             PH_WGRAD_THIN_REDUCE, PH_COMPOSITE, PH_RESAMPLE, PH_COMPOSITE_BWD, PH_REPACK, PH_GRID, PH_RAY_SETUP, PH_OTHER, PH_COUNT };
+static_assert(PH_COUNT == FENERF_N_PHASES, "include/fenerf.h FENERF_N_PHASES");
+struct PhaseScope {
+  PhaseScope(int phase, void* stream);
+  ~PhaseScope();
+  void* rec;
+};
 int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
@@ -71,6 +81,8 @@ struct SirenParams {
   float* tape_e;
   // SPATIALSIRENGRID (siren.py:413-518): fp / pp hold one [L][H] block per POINT instead of per image (fp32 kernel only)
   int film_per_point;
+  // fenerf_siren_clock_probe: [gridDim.x][4] = s_memtime / s_memrealtime at a workgroup's first and last instruction, or nullptr
+  unsigned long long* clk;
 };
 
 struct SirenBwdParams {
@@ -115,17 +127,14 @@ int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const f
                      float* fp, float* pp, void* stream);
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
-int launch_siren_backward16(const FenerfModel* m, const SirenBwdParams& p, void* stream);   // FENERF_PREC_F16X3 models
-int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream);  // the same on 16-point waves (fenerf_siren_bwd16w.hip)
+int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream);  // FENERF_PREC_F16X3 models: bf16x3 chain on 16-point waves (fenerf_siren_bwd16w.hip)
 int bwd16w_film_unit(long long total_points, long long pts_per_image);   // points per FiLM-sum unit of that kernel: 128 (workgroup) or 16 (wave)
-bool bwd16w_enabled();   // which of the two FENERF_PREC_F16X3 chain kernels runs (their FiLM-sum tiles differ: 16 / 32 points)
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
-int launch_siren16s(const FenerfModel* m, const SirenParams& p, void* stream);  // f16x3, workgroup-shared stream (fenerf_siren_f16s.hip)
-int launch_siren16w_one(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 no-grad forward, 16-point waves (fenerf_siren_f16w.hip)
+int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_composite_backward(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);

@@ -99,7 +99,7 @@ constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * 
 constexpr int feat16_of(int s16, int h, int t) { return feat_of(16 * (s16 >> 1) + 8 * (s16 & 1) + t, h); }
 constexpr float F16_ACT_SCALE = 16.f;   // activations are carried as x*16 so the lo halves stay normal fp16
 
-// bf16x3 backward chain (fenerf_siren_bwd16.hip, models created with FENERF_PREC_F16X3): the same stages on
+// bf16x3 backward chain (fenerf_siren_bwd16w.hip, models created with FENERF_PREC_F16X3): the same stages on
 // v_mfma_f32_32x32x16_bf16 with W'^T and dz each split into bf16 (hi, lo) and three MFMAs per k-step (wl*xh + wh*xl + wh*xh).
 // [rgb-head^T block: NB plain fp32 entries, as above] | ring of bf16 entries (64 lanes x 8 bf16 = one A operand; per
 // k-step [hi entry, lo entry], weights split hi = RNE(w), lo = RNE(w - hi)); k-step s16 of an H-wide input reads the features
@@ -132,7 +132,7 @@ inline BwdShape16 bwd_stream_shape16(int H, int n_geo, int n_color, bool grid) {
 }
 
 
-// Workgroup-shared stream geometry (fenerf_siren_f16s.hip): chunks of FENERF_CH entries travel through an LDS ring of
+// Workgroup-shared stream geometry (fenerf_siren_f16w.hip, fenerf_siren_bwd16w.hip): chunks of FENERF_CH entries travel through an LDS ring of
 // FENERF_NSLOT slots, FENERF_DPF chunks ahead of the consumer.  Every STAGE (a layer's n-block bodies) is padded to a
 // whole number of ring revolutions, so every stage starts at ring slot 0 and all slot indices are compile-time constants;
 // the first FENERF_DPF chunks are replicated after the end, so the prefetch pointer never wraps inside a tile.

@@ -9,20 +9,12 @@ namespace fenerf {
 typedef float nfloat4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 nt_load(const float4* p) {
-#ifdef EXP_TEMPORAL
-  return *p;
-#else
   const nfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const nfloat4*>(p));
   return make_float4(v.x, v.y, v.z, v.w);
-#endif
 }
 __device__ __forceinline__ void nt_store(float4* p, float a, float b, float c, float d) {
-#ifdef EXP_TEMPORAL
-  *p = make_float4(a, b, c, d);
-#else
   const nfloat4 v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<nfloat4*>(p));
-#endif
 }
 
 }  // namespace fenerf

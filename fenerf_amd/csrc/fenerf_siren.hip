@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
   constexpr int SLAB_F4 = (H / 8) * 64;        // activation slab per wave, float4 units
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
+  if (P.clk && threadIdx.x == 0) {   // fenerf_siren_clock_probe: shader-clock and wall-clock stamps of this workgroup's first instruction
+    P.clk[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    P.clk[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
@@ -254,6 +258,13 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (P.clk) {                       // ... and of its last (the waves are independent: meet first)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      P.clk[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+      P.clk[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,7 +371,7 @@ static int launch_siren_h(const FenerfModel* m, const SirenParams& p, void* stre
 
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
-  if (m->precision == FENERF_PREC_F16X3) return launch_siren16s(m, p, stream);
+  if (m->precision == FENERF_PREC_F16X3) return launch_siren16w(m, p, stream);
   switch (m->H) {
     case 32: return launch_siren_h<32>(m, p, stream);
     case 64: return launch_siren_h<64>(m, p, stream);

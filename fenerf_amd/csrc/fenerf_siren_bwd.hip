@@ -10,7 +10,7 @@
 // saved pre-FiLM accumulators (tape, register dumps of the 32-point tiles).  The kernel also leaves the per-tile FiLM sums
 // (sum_p dtheta, sum_p dtheta * tape: fenerf_mfma32.h "FiLM-gradient sums").  The contractions over the point axis that remain
 // (weight gradients) are fenerf_siren_wgrad.hip.  FENERF_PREC_F32 models run this kernel; FENERF_PREC_F16X3 models the
-// bf16x3 variant in fenerf_siren_bwd16.hip.
+// bf16x3 variant in fenerf_siren_bwd16w.hip.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

@@ -1,7 +1,7 @@
 // Backward chain of the FiLM-SIREN radiance field on the bf16 matrix pipe, 16-point waves, two waves per SIMD.
 //
-// Same maths, stream, tape, d(theta) dump and d(grid feature) output as siren_bwd16_kernel (fenerf_siren_bwd16.hip; reference:
-// torch autograd through siren/siren.py:1509-1530), in the execution shape of the no-grad forward (fenerf_siren_f16w.hip):
+// The maths of the fp32 chain kernel (fenerf_siren_bwd.hip; reference: torch autograd through siren/siren.py:1509-1530) on bf16
+// (hi, lo) operand splits -- three MFMAs per product, fp32 accumulate -- in the execution shape of the forward (fenerf_siren_f16w.hip):
 //
 //   * a workgroup is 8 waves = 2 per SIMD, each owning 16 points on v_mfma_f32_16x16x32_bf16; dz lives in registers as the next
 //     stage's B operand (64 + 64 registers), never in LDS;
@@ -14,9 +14,9 @@
 //   * the epilogue of n-block nb - 1 (cos, d theta, d z split into bf16 hi / lo, FiLM sums) is issued in four items behind the
 //     MFMAs of n-block nb.
 //
-// The private-stream kernel (one 32-point wave per SIMD, every wave its own L2 stream through a register ring) stalls on its
-// tape loads -- the in-order vmcnt queue puts every HBM load in front of ring entries needed 4 k-steps later -- and on
-// everything else it issues between MFMAs; here the other wave of the SIMD fills those slots.  Measurements: DESIGN.md 4.5.
+// (Round 1's private-stream kernel -- one 32-point wave per SIMD, every wave its own L2 stream through a register ring; retired in
+// round 3, git history -- stalled on its tape loads: the in-order vmcnt queue put every HBM load in front of ring entries needed 4
+// k-steps later.  Here the other wave of the SIMD fills those slots.  Measurements: DESIGN.md 4.5.)
 //
 // FiLM sums are emitted in register-dump order (film_gather_kernel, fenerf_siren_wgrad.hip, decodes it):
 //   [unit][layer][nb][rt][slot = 4 g + r][s0, s1],  feature = 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r,
@@ -101,11 +101,7 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-#ifdef EXP_BW_TAPE_T
-      "global_load_lds_dwordx4 %0, %1"
-#else
       "global_load_lds_dwordx4 %0, %1 nt"
-#endif
       :
       : "v"(voff), "s"(g_uniform), "s"(lds_uniform)
       : "memory");
@@ -113,10 +109,6 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
 // fire-and-forget stores, uniform base + 32-bit lane offset.  The s_nop is the hazard slot the compiler would insert behind a
 // store of more than 8 bytes whose data registers the next VALU instruction overwrites -- it does not look inside an asm.
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
-#ifdef EXP_BW_NOSTORE
-  asm volatile("" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
-  return;
-#endif
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 __device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, const f32x2& v) {
@@ -172,7 +164,6 @@ struct WStream {
 
 __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
   const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
-#ifndef EXP_BW_NODMA
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
@@ -180,9 +171,6 @@ __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
       :
       : "v"(w.voff), "s"(w.g_next), "s"(m0)
       : "memory");
-#else
-  (void)m0;
-#endif
   const unsigned long long nx = w.g_next + CH * 1024;
   w.g_next = nx == w.g_end ? w.g_begin : nx;      // the stream restarts for the next tile
 }
@@ -202,16 +190,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_b
 
 // 6 MFMAs of one k32-step, the two row tiles interleaved: wl*xh + wh*xl + wh*xh
 __device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[2], const AK& a, const bf16x8& bh, const bf16x8& bl) {
-#ifdef EXP_BW_NOMFMA
-  acc[0][0] += a.lo[0].x + a.hi[0].y + a.lo[1].z + a.hi[1].w + (float)bh[0] + (float)bl[1];
-#else
   acc[0] = MFMA16B(as_bf16x8(a.lo[0]), bh, acc[0]);
   acc[1] = MFMA16B(as_bf16x8(a.lo[1]), bh, acc[1]);
   acc[0] = MFMA16B(as_bf16x8(a.hi[0]), bl, acc[0]);
   acc[1] = MFMA16B(as_bf16x8(a.hi[1]), bl, acc[1]);
   acc[0] = MFMA16B(as_bf16x8(a.hi[0]), bh, acc[0]);
   acc[1] = MFMA16B(as_bf16x8(a.hi[1]), bh, acc[1]);
-#endif
 }
 
 __device__ __forceinline__ float lane_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
@@ -267,18 +251,12 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   float rem[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-#ifdef EXP_BW_NOEPI
-    const float dt = acc[r] + f[r] + p[r] + t[r];
-    o.dt[r] = dt; o.dtt[r] = dt;
-    hb[r] = __builtin_bit_cast(unsigned, dt); rem[r] = dt;
-#else
     const float dt = acc[r] * __builtin_amdgcn_cosf(__builtin_fmaf(f[r], t[r], p[r]));
     o.dt[r] = dt;
     o.dtt[r] = dt * t[r];
     const float dz = dt * (f[r] * TWO_PI);
     hb[r] = __builtin_bit_cast(unsigned, dz);
     rem[r] = dz - __builtin_bit_cast(float, hb[r] & 0xffff0000u);
-#endif
   }
   unsigned h2[2], l2[2];
 #pragma unroll
@@ -302,12 +280,8 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   constexpr int FILM_F = H * 4 < 1024 ? 1024 : H * 4;           // LDS-DMA moves whole KiBs
   constexpr int FILM_BYTES = 2 * FILM_F;
   constexpr int TL = H * 128;                                   // bytes of one (tile32, layer) dump block
-#ifdef EXP_BW_B1
-  constexpr bool B2 = false;
-#else
   // one barrier per two chunk steps where every stage has an even number of steps (H >= 128)
   constexpr bool B2 = (NB * QB) % 2 == 0 && (NB * C0_QB) % 2 == 0 && (!GRID || QB % 2 == 0);
-#endif
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
   const int lane = threadIdx.x & 63;
@@ -370,11 +344,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     const long long img = __builtin_amdgcn_readfirstlane((int)((tile * 16) / P.pts_per_image));
     const float* fp_img = P.fp + (size_t)img * L * H;
     const float* pp_img = P.pp + (size_t)img * L * H;
-#ifdef EXP_BW_TAPE_L2   // timing only: every tile reads tile 0's tape (L2-resident)
-    const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)(tile32 & 1) * L * TL);
-#else
     const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TL);
-#endif
     const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
     const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)(WGS ? oct : tile) * L * (2 * H * 4));
     // ---- WGS: per-wave sums -> LDS buffer kb; one step of barriers later the wave whose turn it is combines and stores them
@@ -598,21 +568,13 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           // DMA overwrites the slot of chunk s - 2, whose last reads every wave issued before the barrier (B2: of step s or s - 1)
           if constexpr (!B2) {
             wait_vmcnt<EPI ? ring_wait(QBS, s) : DPF - 2>();
-#ifndef EXP_BW_NOBARRIER
             __builtin_amdgcn_s_barrier();
-#endif
           } else if constexpr ((s & 1) == 0) {
             wait_vmcnt<EPI ? ring_wait2(QBS, s) : DPF - 3>();
-#ifndef EXP_BW_NOBARRIER
             __builtin_amdgcn_s_barrier();
-#endif
           }
           LDS_FENCE();
-#ifdef EXP_BW_INPHASE
-          ws_issue(ws, (ws.cs + DPF) & 7);
-#else
           if (ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
-#endif
           // operands of the items of this chunk: FiLM parameters and tape from LDS, read before the A operands (LDS returns in order)
           EpiIn q[2];
           if constexpr (EPI && nb > 0) {
@@ -625,9 +587,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           }
 #pragma unroll
           for (int spl = 0; spl < 2; ++spl) {
-#ifndef EXP_BW_INPHASE
             if (spl == 1 && !ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
-#endif
             const AK nn = spl == 0 ? ws_read(ws, ws.cs, 1) : ws_read(ws, (ws.cs + 1) & 7, 0);
             __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
             bf16x8 bh, bl;
@@ -807,13 +767,6 @@ static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream)
 
 }  // namespace bw16
 
-// FENERF_BACKWARD_KERNEL=b16 selects the one-wave-per-SIMD kernel (fenerf_siren_bwd16.hip); the FiLM sums of the two kernels
-// have different tile sizes, so the choice is made once per process and asked for by both the chain and the gather launch.
-bool bwd16w_enabled() {
-  static const bool on = [] { const char* v = getenv("FENERF_BACKWARD_KERNEL"); return !(v && std::string(v) == "b16"); }();
-  return on;
-}
-
 }  // namespace fenerf
 
 // Test hook (not part of include/fenerf.h): the compile-time wait counts of the chain kernel's stream loop and the schedule they are
@@ -834,9 +787,6 @@ extern "C" int fenerf_internal_bwd16w_schedule(int what, int qb, int step) {
 namespace fenerf {
 // points per FiLM-sum unit of siren_bwd16w_kernel: the workgroup's 128 when an oct cannot straddle images, else the wave's 16
 int bwd16w_film_unit(long long total_points, long long pts_per_image) {
-#ifdef EXP_BW_NOWGS   // timing only: per-wave FiLM sums everywhere
-  return 16;
-#endif
   return (total_points == pts_per_image || pts_per_image % 128 == 0) ? 128 : 16;
 }
 

@@ -1,9 +1,10 @@
 // FiLM-SIREN radiance field, f16x3 mode, no-grad forward: 16-point waves, two waves per SIMD (gfx950 / MI355X).
 //
-// Same arithmetic as fenerf_siren_f16s.hip (every fp32 product as wl*xh + wh*xl + wh*xh on the fp16 matrix pipe, fp32
-// accumulate; activations never leave their lane) and the SAME packed weight stream, but a different execution shape:
+// Every fp32 product of the dense layers is evaluated as wl*xh + wh*xl + wh*xh on the fp16 matrix pipe with fp32 accumulate
+// (activations never leave their lane).  Round 1 ran this arithmetic, on the SAME packed weight stream, in a different execution
+// shape (fenerf_siren_f16s.hip, retired in round 3: git history):
 //
-//   * fenerf_siren_f16s.hip runs one 32-point wave per SIMD at ~450 registers.  Its wave issues in order, so every
+//   * that kernel ran one 32-point wave per SIMD at ~450 registers.  Its wave issues in order, so every
 //     global_load_lds (100-185 cycles of issue each in a busy phase), every LDS wait and every barrier sits in the MFMA
 //     stream: 51-53 % matrix-pipe utilisation.
 //   * Here a workgroup is 8 waves = 2 per SIMD, each owning 16 points on v_mfma_f32_16x16x32_f16.  Activations halve to
@@ -30,35 +31,6 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 
-// structural alternative kept for A/B timing (numerically exact): both waves of a SIMD issue their LDS-DMA at the same point
-#ifdef EXP_W_DMA_IN_PHASE
-#define W_DMA_IN_PHASE
-#endif
-#ifdef EXP_W_BARRIER_EVERY_CHUNK
-#define W_BARRIER_EVERY_CHUNK
-#endif
-// composite timing experiments
-#ifdef EXP_W_NOMFMA_NODMA
-#define EXP_W_NOMFMA
-#define EXP_W_NODMA
-#endif
-#ifdef EXP_W_NOMFMA_NOEPI
-#define EXP_W_NOMFMA
-#define EXP_W_NOEPI
-#endif
-#ifdef EXP_W_NOMFMA_NOEPI_NOBARRIER
-#define EXP_W_NOMFMA
-#define EXP_W_NOEPI
-#define EXP_W_NOBARRIER
-#endif
-#ifdef EXP_W_NOMFMA_HALFLDS
-#define EXP_W_NOMFMA
-#define EXP_W_HALFLDS
-#endif
-#ifdef EXP_W_NODMA_NOEPI
-#define EXP_W_NODMA
-#define EXP_W_NOEPI
-#endif
 
 namespace fenerf {
 namespace w16 {
@@ -82,8 +54,8 @@ __device__ __forceinline__ half8 as_half8(const float4& v) { return __builtin_bi
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
-// LDS-DMA of one KiB: lane i's 16 bytes at g_lane  ->  lds_uniform + 16 i.  Inline asm on purpose (fenerf_siren_f16s.hip:
-// with the builtin hipcc drains the DMA queue before every ring read).
+// LDS-DMA of one KiB: lane i's 16 bytes at g_lane  ->  lds_uniform + 16 i.  Inline asm on purpose: with the builtin hipcc
+// tracks the DMA as a pending LDS write and drains the queue (vmcnt(0)) before every ring read.
 __device__ __forceinline__ void glds_1k(const char* g_lane, unsigned lds_uniform) {
   asm volatile(
       "s_mov_b32 m0, %1\n\t"
@@ -126,11 +98,7 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // overwritten next (the compiler does not look inside an asm).
 template <bool ON> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
-#ifdef EXP_W_TAPE_T   // timing only: temporal tape stores
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
-#else
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
-#endif
 }
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
@@ -144,10 +112,6 @@ struct WStream {
 
 __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
   const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
-#ifndef EXP_W_NODMA
-#ifdef EXP_W_HALFDMA
-  if (slot & 1)
-#endif
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
@@ -155,34 +119,21 @@ __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
       :
       : "v"(w.voff), "s"(w.g_next), "s"(m0)
       : "memory");
-#endif
   w.g_next += CH * 1024;
 }
 
 // A operands of one k32-step (both row tiles): ring slot layout = operand index (spl * 2 + rt) * 2 + hl, 1 KiB each
 struct AK { float4 hi[2], lo[2]; };
-// EXP_W_*: timing-only A/B switches (results numerically wrong on purpose), built by `make exp`
 __device__ __forceinline__ void ws_read_lo(AK& a, const WStream& w, int slot, int spl) {
-#if defined(EXP_W_NOLDSREAD) || defined(EXP_W_HALFLDS)
-  asm volatile("" : "+v"(a.lo[0].x), "+v"(a.lo[1].y));
-#else
   const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
   a.lo[0] = p[1 * 64]; a.lo[1] = p[3 * 64];
-#endif
 }
 __device__ __forceinline__ void ws_read_hi(AK& a, const WStream& w, int slot, int spl) {
-#ifdef EXP_W_NOLDSREAD
-  asm volatile("" : "+v"(a.hi[0].x), "+v"(a.hi[1].y));
-#else
   const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
   a.hi[0] = p[0 * 64]; a.hi[1] = p[2 * 64];
-#endif
 }
 __device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
   AK a;
-#if defined(EXP_W_NOLDSREAD) || defined(EXP_W_HALFLDS)
-  a.hi[0] = a.hi[1] = a.lo[0] = a.lo[1] = make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f);
-#endif
   ws_read_lo(a, w, slot, spl);
   ws_read_hi(a, w, slot, spl);
   return a;
@@ -194,9 +145,6 @@ __device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
 // point of the same program those stalls coincide and the matrix pipe idles under both (+1.3 % on real weights, +2.8 % at
 // full clock, profiles/r02_siren16w_experiments.md section 5).
 __device__ __forceinline__ void ws_step(WStream& w, int i, bool early) {
-#ifdef W_BARRIER_EVERY_CHUNK
-  const bool sync = true;
-#else
   // ONE barrier per TWO chunk steps (even i; stages are whole ring revolutions, so the parity of i is the parity of the global
   // step).  Chunk i + 1 is read during step i and chunk i + 2 during the odd step i + 1, so barrier i publishes both: every wave
   // first waits for its own KiB of chunks <= i + 2 (chunks i + 1 .. i + D - 1 are in flight here: vmcnt(D - 3)).  The DMA of
@@ -204,43 +152,26 @@ __device__ __forceinline__ void ws_step(WStream& w, int i, bool early) {
   // DMA of the odd step i + 1 overwrites chunk i - 1, consumed by every wave before it arrived at barrier i.  (The barrier
   // costs 8 % of the kernel at full clock, profiles/r02_siren16w_experiments.md.)
   const bool sync = (i & 1) == 0;
-#endif
   if (sync) {
-#ifdef EXP_W_HALFDMA
-    WAIT_VMCNT(DPF / 2 - 1);
-#elif defined(W_BARRIER_EVERY_CHUNK)
-    WAIT_VMCNT(DPF - 2);          // chunks i + 1 .. i + D - 1 in flight, chunk i + 1 must have landed
-#else
     WAIT_VMCNT(DPF - 3);
-#endif
-#ifndef EXP_W_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
   }
   LDS_FENCE();
-#ifndef W_DMA_IN_PHASE
   if (early)
-#endif
     ws_issue(w, (i + DPF) % NSLOT);
 }
 __device__ __forceinline__ void ws_issue_late(WStream& w, int i, bool early) {
-#ifndef W_DMA_IN_PHASE
   if (!early) ws_issue(w, (i + DPF) % NSLOT);
-#endif
 }
 
 // 6 MFMAs of one k32-step, the two row tiles interleaved (dependent MFMAs are 2 apart): wl*xh + wh*xl + wh*xh
 __device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[2], const AK& a, const half8& bh, const half8& bl) {
-#ifdef EXP_W_NOMFMA
-  acc[0][0] += a.lo[0].x + (float)bh[0] + a.hi[0].y + a.lo[1].z + a.hi[1].w + (float)bl[1];
-#else
   acc[0] = MFMA16W(as_half8(a.lo[0]), bh, acc[0]);
   acc[1] = MFMA16W(as_half8(a.lo[1]), bh, acc[1]);
   acc[0] = MFMA16W(as_half8(a.hi[0]), bl, acc[0]);
   acc[1] = MFMA16W(as_half8(a.hi[1]), bl, acc[1]);
   acc[0] = MFMA16W(as_half8(a.hi[0]), bh, acc[0]);
   acc[1] = MFMA16W(as_half8(a.hi[1]), bh, acc[1]);
-#endif
 }
 
 // FiLM epilogue of two values: accumulator registers 2 pc, 2 pc + 1 of row tile rt of n-block nbp -> (hi, lo) halves
@@ -266,9 +197,6 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
     const unsigned toff = (unsigned)(((2 * (lo >> 5)) * 64 + ((lo >> 4) & 1) * 32 + 16 * tile_odd + (lo & 15)) * 16);
     st_f4_nt(tw.base + (nbp * 4 + rt) * 1024, toff, acc[rt]);
   }
-#ifdef EXP_W_NOEPI
-  half2 hp = {(_Float16)(f.x + acc[rt][2 * pc + 0]), (_Float16)p.x}, lp = {(_Float16)(f.y + acc[rt][2 * pc + 1]), (_Float16)p.y};
-#else
   // x = sin(2 pi theta); carried as hi = rn_f16(16 x), lo = rn_f16(16 x - hi).  Written as fmas on x so that each half is ONE
   // v_fma_mix{lo,hi}_f16 (fp32 fma, one rounding to f16; 16 x and 16 x - hi are exact in fp32, so the values are those of the
   // mul / convert / subtract / convert spelling): 8 VALU per two values instead of 14.
@@ -276,7 +204,6 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
   const float s1 = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y));
   const _Float16 h0 = (_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, 0.f), h1 = (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, 0.f);
   half2 hp = {h0, h1}, lp = {(_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, -(float)h0), (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, -(float)h1)};
-#endif
   // pinned here: without a use in this block the compiler sinks the whole epilogue behind the stage (the outputs are only
   // consumed after it), keeping 8 n-blocks of accumulators + FiLM values alive -- and spilling them into the stream loop
   asm volatile("" : "+v"(hp), "+v"(lp));
@@ -354,6 +281,10 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   constexpr int HEAD_CHUNKS = pad_stage(QB * CH) / CH;
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
+  if (P.clk && threadIdx.x == 0) {   // fenerf_siren_clock_probe: shader-clock and wall-clock stamps of this workgroup's first instruction
+    P.clk[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    P.clk[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -698,6 +629,10 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   }
   WAIT_VMCNT(0);     // no LDS-DMA may land after the workgroup has released its LDS
   __builtin_amdgcn_s_barrier();
+  if (P.clk && threadIdx.x == 0) {   // ... and of its last
+    P.clk[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+    P.clk[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 static int hip_fail16w(hipError_t e, const char* what) {
@@ -725,8 +660,8 @@ static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
 
 }  // namespace w16
 
-// One launch over points whose tiles do not straddle images (launch_siren16s splits per image otherwise).
-int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream) {
+// One launch over points whose tiles do not straddle images.
+static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream) {
   const bool g = m->grid_ch != 0;
   if (q.tape) {   // forward-save: the same kernel also dumps the tape (and the sampled grid features)
     switch (m->H) {
@@ -744,6 +679,35 @@ int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;
+}
+
+// FENERF_PREC_F16X3 models, forward and forward-save.  Tiles must not straddle images (FiLM parameters are fetched per wave, the
+// tape is laid out in 32-point tiles per image): when points-per-image is not a multiple of 32, launch image by image (each
+// launch ends in a ragged tile).
+int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream) {
+  if (p.P <= 0) return FENERF_OK;
+  if (p.pts_per_image % 32 == 0 || p.P == p.pts_per_image) return launch_siren16w_one(m, p, stream);
+  const long long nimg = p.P / p.pts_per_image;
+  const int L = m->L, H = m->H;
+  for (long long b = 0; b < nimg; ++b) {
+    SirenParams q = p;
+    q.P = p.pts_per_image;
+    q.fp = p.fp + (size_t)b * L * H;
+    q.pp = p.pp + (size_t)b * L * H;
+    q.out = p.out + (size_t)b * p.pts_per_image * m->C;
+    if (p.points) {
+      q.points = p.points + (size_t)b * p.pts_per_image * 3;
+      if (p.pdirs) q.pdirs = p.pdirs + (size_t)b * p.pts_per_image * 3;
+    } else {
+      const long long rays = p.pts_per_image / p.n_per_ray;
+      q.origins = p.origins + (size_t)b * rays * 3;
+      q.dirs = p.dirs + (size_t)b * rays * 3;
+      q.z = p.z + (size_t)b * p.pts_per_image;
+    }
+    int rc = launch_siren16w_one(m, q, stream);
+    if (rc) return rc;
+  }
+  return FENERF_OK;
 }
 
 }  // namespace fenerf

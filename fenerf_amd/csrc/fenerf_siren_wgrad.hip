@@ -734,6 +734,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   p.film_partial = film; p.rowsum_partial = rows; p.film_stride = nf;
   int rc;
   {  // FiLM frequency / phase gradients and the FiLM-layer biases: gather the chain kernel's per-tile sums, reduce
+    PhaseScope ph(PH_WGRAD_FILM, st);
     WgradParams pf = p;
     pf.nchunk = nf;
     hipLaunchKernelGGL(film_gather_kernel, dim3(nf, B, L), dim3(256), 0, st, pf);
@@ -745,8 +746,14 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   if (film_only) return FENERF_OK;
   // ---- square products dtheta_l x_{l-1}^T, l = 1..L-1, one launch
   p.partial = sq; p.layer0 = 1;
-  if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
+  {
+    PhaseScope ph(PH_WGRAD_SQ, st);
+    if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
+  }
+  {
+    PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
+    hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
+  }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
   // side: [H x 32 | H x 64 | 32 x H | 32 x H] per (image, chunk) -- so that ONE launch reduces all of them
   p.nchunk = nt;
@@ -756,6 +763,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   float* const p_rgb = p_hd + (size_t)B * nt * 32 * H;
   float* const rows_rgb = rows + (size_t)B * ncm * 32;
   {
+    PhaseScope ph(PH_WGRAD_THIN, st);
     ThinJobs T;
     T.j[0] = p; T.j[0].layer0 = ng; T.j[0].partial = p_c0;
     T.j[1] = p; T.j[1].layer0 = ng - 1; T.j[1].partial = p_hd; T.j[1].rowsum_partial = rows;
@@ -784,6 +792,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   J.n_mat = nm;
   J.rs_src[0] = rows; J.rs_dst[0] = g.head_b; J.rs_rows[0] = 32;
   J.rs_src[1] = rows_rgb; J.rs_dst[1] = g.rgb_b; J.rs_rows[1] = 3;
+  PhaseScope ph(PH_WGRAD_THIN_REDUCE, st);
   hipLaunchKernelGGL(wgrad_reduce_thin_kernel, dim3((32 * H + 255) / 256, nm + 2), dim3(256), 0, st, J, B, nt, p.fp, p.inv, L, H);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
@@ -800,7 +809,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.box_scale = m->box_scale;
   p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
   p.P = P; p.tiles_per_image = (int)(P / 32);
-  p.film16w = (m->precision == FENERF_PREC_F16X3 && bwd16w_enabled()) ? bwd16w_film_unit((long long)B * P, P) : 0;
+  p.film16w = m->precision == FENERF_PREC_F16X3 ? bwd16w_film_unit((long long)B * P, P) : 0;
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {

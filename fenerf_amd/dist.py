@@ -12,10 +12,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device=None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run).  Returns (rank, local_rank, world)."""
+def init_from_env(backend=None, device=None, force=False):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torch.distributed.run).  Returns (rank, local_rank, world).
+    A process group is created for world > 1, or for a single rank too with `force` (a one-GPU box can then exercise the RCCL
+    initialisation, barrier and reductions of the N > 1 path)."""
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -38,7 +40,7 @@ def contiguous_shard(total, rank, world):
 
 def max_over_ranks(value, device="cpu"):
     """Wall-clock agreement for benchmarks: MAX of a python float over all ranks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

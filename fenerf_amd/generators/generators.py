@@ -39,8 +39,9 @@ def _set_rng_state(device, state):
 def _avg_cache_lookup(gen, nets):
     """generate_avg_frequencies cache (see DoubleImplicitGenerator3d.generate_avg_frequencies).  Key: the mapping networks'
     parameter versions / storages, the device, and the device generator's state before the draws.  Only with the default
-    random source (recorded draws in tests are replayed as given).  Writes through `param.data` bypass version counters --
-    the same caveat, and the same remedy (a train()/eval() switch or invalidate_native()), as for the packed render weights."""
+    random source (recorded draws in tests are replayed as given).  Writes through `param.data` (torch_ema's copy_to / restore)
+    bypass version counters -- the same caveat as for the packed render weights, and the same remedy: the generator's train() /
+    eval() (which the reference calls around every EMA swap) and invalidate_native() drop this cache too."""
     gen.__dict__.pop("_avg_pending", None)
     if not isinstance(gen.draws, VR.TorchDraws):
         return None
@@ -72,6 +73,21 @@ class _Generator3dBase(nn.Module):
         st.pop("_avg_cache", None)
         st.pop("_avg_pending", None)
         return st
+
+    def invalidate_native(self):
+        """Weights may have changed behind the version counters (writes through `param.data`): drop the cached average FiLM
+        parameters and force a re-pack of the SIREN's native models at the next render."""
+        self.__dict__.pop("_avg_cache", None)
+        self.__dict__.pop("_avg_pending", None)
+        if hasattr(self.siren, "invalidate_native"):
+            self.siren.invalidate_native()
+
+    def train(self, mode=True):
+        # a mode switch = "weights may have changed" (train_double_latent_semantic.py:487-489, :522 -> :267 bracket every EMA swap
+        # with eval() / train()); nn.Module.train recurses into self.siren, whose own train() invalidates the packed weights
+        self.__dict__.pop("_avg_cache", None)
+        self.__dict__.pop("_avg_pending", None)
+        return super().train(mode)
 
     def _render(self, film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                 hierarchical_sample, sample_dist, lock_view_dependence, kwargs, use_fill, third):

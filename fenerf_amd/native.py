@@ -193,12 +193,28 @@ class NativeModel:
             flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
         return p, flat
 
-    def load_from_device(self, params):
+    @staticmethod
+    def _grid_checksum(grid):
+        """int64 sum of the grid's fp32 bit patterns (one pass over 113 MB, ~25 us, no temporaries, no sync)"""
+        return grid.reshape(-1).view(torch.int32).sum(dtype=torch.int64)
+
+    def load_from_device(self, params, maybe_unchanged=False):
         """Re-pack from device-resident parameters {reference name: tensor} without touching the host: one concatenation,
-        then fenerf_model_repack gathers / scales / splits straight into the model's resident streams."""
+        then fenerf_model_repack gathers / scales / splits straight into the model's resident streams.
+        `maybe_unchanged`: the caller was told to re-pack without seeing a parameter version change (train() / eval() switch,
+        invalidate_native()).  A differentiable model then compares the content with what is resident (the flat MLP vector and a
+        checksum of the grid; one host sync) and skips an identical re-pack WITHOUT advancing pack_generation, so that autograd
+        nodes between their forward and backward stay valid across a mode switch."""
         p, flat = self._flat_params(params)
         grid = p.get("spatial_embeddings")
         grid = grid.contiguous() if grid is not None else None
+        if self.differentiable:
+            last = getattr(self, "_resident", None)
+            csum = self._grid_checksum(grid) if grid is not None else None
+            if maybe_unchanged and last is not None and last[0].shape == flat.shape and torch.equal(last[0], flat) and \
+                    (csum is None or torch.equal(last[1], csum)):
+                return
+            self._resident = (flat, csum)
         r = self._repack_maps()
         self.pack_generation += 1
         with torch.cuda.device(self.device):
@@ -325,6 +341,14 @@ class NativeModel:
     def tape_floats(self, total_points):
         """floats of a tape for total_points points (L*H per point + the slack the kernel's last workgroup may write)"""
         return int(_lib.lib().fenerf_siren_tape_floats(self._h, total_points))
+
+    def dump_bytes_per_point(self, chunk_points=None):
+        """HBM bytes per (point x layer-feature) of the backward streams of a chunk (fenerf_siren_backward_stream_bytes):
+        dict(chain_write, square_read, thin_read, tape)."""
+        from .siren import autograd as _sa
+        res = (C.c_double * 4)()
+        _lib.check(_lib.lib().fenerf_siren_backward_stream_bytes(self._h, int(chunk_points or _sa.BACKWARD_CHUNK_POINTS), res))
+        return dict(chain_write=res[0], square_read=res[1], thin_read=res[2], tape_layer=res[3])
 
     def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa, out=None, tape=None, tape_e=None):
         """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators, tape_floats(B*P) floats
@@ -457,6 +481,25 @@ class NativeModel:
                                                          C.byref(ms), _stream()))
         return float(ms.value)
 
+    def clock_probe(self, origins, dirs, z, fg, pg, fa, pa, iters=10):
+        """time_siren_rays with in-kernel clock stamps -> dict(kernel_ms, cycles_per_launch, clock_ghz, wall_clock_khz): the shader
+        cycles a launch takes and the clock the power manager granted while it ran (fenerf_siren_clock_probe)."""
+        B, R, N = z.shape
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        origins, dirs, z = _f32(origins, self.device), _f32(dirs, self.device), _f32(z, self.device)
+        out = torch.empty((B, R, N, self.C), dtype=torch.float32, device=self.device)
+        res = (C.c_double * 4)()
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(_lib.lib().fenerf_siren_clock_probe(self._h, B, R, N, _ptr(origins), _ptr(dirs), _ptr(z), _ptr(fg), _ptr(pg),
+                                                           _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), int(iters), res,
+                                                           _stream()))
+        return dict(kernel_ms=res[0], cycles_per_launch=res[1], clock_ghz=res[2], wall_clock_khz=res[3])
+
+    def executed_flop_per_point(self):
+        """FLOPs the SIREN kernel issues on the matrix pipe per point (static MFMA count), next to the algorithmic 1,603,584"""
+        return float(_lib.lib().fenerf_siren_executed_flop_per_point(self._h))
+
     def render(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, hierarchical=True,
                lock_view=False, want_weights=False, want_wsum=False):
         """The fused coarse->resample->fine->merge->composite pipeline (generators.py:479-519).
@@ -485,6 +528,31 @@ class NativeModel:
                                                _ptr(weights), _ptr(wsum), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
                                                _stream()))
         return rgb, depth, weights, wsum
+
+
+class phase_timing:
+    """with native.phase_timing() as t: ...   ->  t.ms / t.calls: {phase name: device ms / launch groups} of everything the library
+    launched inside the block (hipEvent pairs around each launch group, include/fenerf.h fenerf_phase_timing).  Synchronises on exit."""
+
+    def __enter__(self):
+        l = _lib.lib()
+        ms, calls = (C.c_double * _lib.N_PHASES)(), (C.c_int * _lib.N_PHASES)()
+        _lib.check(l.fenerf_phase_times(ms, calls, _lib.N_PHASES))      # drop whatever an earlier block left behind
+        self._prev = l.fenerf_phase_timing(1)
+        self.ms, self.calls = {}, {}
+        return self
+
+    def __exit__(self, *exc):
+        l = _lib.lib()
+        l.fenerf_phase_timing(self._prev)
+        torch.cuda.synchronize()
+        ms, calls = (C.c_double * _lib.N_PHASES)(), (C.c_int * _lib.N_PHASES)()
+        _lib.check(l.fenerf_phase_times(ms, calls, _lib.N_PHASES))
+        for i in range(_lib.N_PHASES):
+            if calls[i]:
+                name = l.fenerf_phase_name(i).decode()
+                self.ms[name], self.calls[name] = float(ms[i]), int(calls[i])
+        return False
 
 
 def forward_kernel_name(nat):

@@ -81,48 +81,52 @@ def _add_all(dst, src):
 
 def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
-    `max_points` points of ONE image each: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per
-    image, and every gradient is a sum over points, so chunk results simply add.  The gradient wrt the sampled grid features never
-    exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid; inside the chain
-    kernel for f16x3 models).  -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
+    `max_points` points: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per image, and every gradient
+    is a sum over points, so chunk results simply add.  A chunk is a run of WHOLE images while those fit (the curriculum's early
+    stages: 6-12 images of 32x32x24 = 24,576 points per pass -- one launch of 8 images fills the 256 CUs, eight launches of 192
+    workgroups do not); an image larger than `max_points` is split into point ranges of its own.  The gradient wrt the sampled grid
+    features never exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid;
+    inside the chain kernel for f16x3 models).
+    -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
     LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
     G = nat.spec["grid_ch"]
     C = nat.C
-    fg, pg, fa, pa = film
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
     d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G and not film_only else None
-    total = None
-    for b in range(nB):
-        film_b = (fg[b:b + 1], pg[b:b + 1], fa[b:b + 1], pa[b:b + 1])
-        acc_b = None
-        for s in range(0, Pp, max_points):
-            n = min(max_points, Pp - s)
-            g0 = b * Pp + s
-            tape_c = tape[g0 * LH:(g0 + n) * LH]
-            out_c, d_out_c = out[b:b + 1, s:s + n], d_out[b:b + 1, s:s + n]
-            if G and not film_only:
-                d_t = nat.siren_backward_grid(1, n, *film_b, out_c, d_out_c, tape_c, points[b:b + 1, s:s + n], d_grid)
-            else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
-                d_t, _ = nat.siren_backward(1, n, *film_b, out_c, d_out_c, tape_c)
-            r = nat.siren_param_grads(points[b:b + 1, s:s + n], dirs[b:b + 1, s:s + n] if dirs is not None else None, *film_b, out_c,
-                                      d_out_c, tape_c, tape_e[g0:g0 + n] if G else None, d_t, film_only=film_only)
-            del d_t
-            if acc_b is None:
-                acc_b = r
-            else:
-                _add_all(_flat(acc_b, FILM_KEYS), _flat(r, FILM_KEYS))      # one fused launch for all ~40 tensors
-                _add_all([acc_b[k] for k in FILM_KEYS], [r[k] for k in FILM_KEYS])
+    # (first image, images, first point, points) per launch
+    if Pp <= max_points:
+        per = max(1, max_points // Pp)
+        chunks = [(b, min(per, nB - b), 0, Pp) for b in range(0, nB, per)]
+    else:
+        chunks = [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
+    total, film_rows = None, {k: [] for k in FILM_KEYS}
+    acc_img = None           # FiLM gradients of the image whose point ranges are being walked
+    for b, nb, s, n in chunks:
+        film_c = tuple(t[b:b + nb] for t in film)
+        g0 = b * Pp + s
+        tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
+        out_c, d_out_c, pts_c = out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], points[b:b + nb, s:s + n]
+        if G and not film_only:
+            d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid)
+        else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
+            d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c)
+        r = nat.siren_param_grads(pts_c, dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c, out_c, d_out_c, tape_c,
+                                  tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only)
+        del d_t
         if total is None:
-            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in acc_b.items()}
-            film_rows = {k: [acc_b[k]] for k in FILM_KEYS}
+            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
         else:
-            for k in FILM_KEYS:
-                film_rows[k].append(acc_b[k])
-            _add_all(_flat(total, FILM_KEYS), _flat(acc_b, FILM_KEYS))
+            _add_all(_flat(total), _flat(r, FILM_KEYS))      # one fused launch for all ~40 tensors
+        if s == 0:
+            acc_img = [r[k] for k in FILM_KEYS]
+            for k, t in zip(FILM_KEYS, acc_img):
+                film_rows[k].append(t)
+        else:
+            _add_all(acc_img, [r[k] for k in FILM_KEYS])
     for k, rows in film_rows.items():
-        total[k] = torch.cat(rows, 0)
+        total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
     return total, d_grid
 
 

@@ -114,10 +114,11 @@ class _NativeSiren(nn.Module):
             self.__dict__["_native_model"] = nat
         elif self.__dict__.get("_native_version") != ver:
             if params[0].is_cuda:      # weights already live on the GPU (training): re-pack there, not through the host
-                nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n})
+                nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n},
+                                     maybe_unchanged=self.__dict__.get("_native_packed") == ver)
             else:
                 nat.update(self._state_numpy())
-        self.__dict__["_native_version"] = ver
+        self.__dict__["_native_version"] = self.__dict__["_native_packed"] = ver
         return nat
 
     def native_differentiable(self, device=None):
@@ -131,9 +132,12 @@ class _NativeSiren(nn.Module):
             nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision, differentiable=True)
             self.__dict__["_native_diff"] = nat
         elif self.__dict__.get("_native_diff_version") != ver:
-            # weights live on the GPU during training: re-pack there (a gather), never through the host
-            nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n})
-        self.__dict__["_native_diff_version"] = ver
+            # weights live on the GPU during training: re-pack there (a gather), never through the host.  Same version counters as
+            # at the last pack = a forced invalidation (mode switch, invalidate_native()): the content is compared first, so that a
+            # train() / eval() round trip between a forward and its backward does not make the backward refuse (pack_generation)
+            nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n},
+                                 maybe_unchanged=self.__dict__.get("_native_diff_packed") == ver)
+        self.__dict__["_native_diff_version"] = self.__dict__["_native_diff_packed"] = ver
         return nat
 
     def invalidate_native(self):
@@ -169,7 +173,7 @@ class _NativeSiren(nn.Module):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_native_model", "_native_version", "_native_diff", "_native_diff_version"):
+        for k in ("_native_model", "_native_version", "_native_packed", "_native_diff", "_native_diff_version", "_native_diff_packed"):
             st.pop(k, None)
         return st
 

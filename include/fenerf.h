@@ -202,6 +202,27 @@ int fenerf_siren_time_rays(const FenerfModel* m, int B, int R, int N, const floa
                            const float* z, const float* freq_geo, const float* phase_geo, const float* freq_app,
                            const float* phase_app, float* out, void* film_ws, int iters, float* avg_ms, void* stream);
 
+/* Measurement hooks (bench.py; replace nothing).
+ * fenerf_siren_clock_probe: like fenerf_siren_time_rays, but every workgroup of every timed launch also stamps the shader-clock
+ * counter (s_memtime) and the constant-rate wall clock (s_memrealtime) at its first and last instruction.  result[0] = average
+ * kernel ms (hipEvents), [1] = shader cycles per launch (average over launches of the longest workgroup), [2] = effective shader
+ * clock in GHz over those workgroups (cycles / wall-clock ticks x the device's wall-clock rate), [3] = that rate in kHz.
+ * fenerf_siren_executed_flop_per_point: FLOPs the model's SIREN kernel ISSUES on the matrix pipe per sample point (static count of
+ * its MFMA instructions: 3 fp16 MFMAs per product at FENERF_PREC_F16X3, the label head folded to one 18-row map) -- next to the
+ * ALGORITHMIC 2 x MAC count of the reference network that roofline figures are quoted on. */
+int fenerf_siren_clock_probe(const FenerfModel* m, int B, int R, int N, const float* origins, const float* dirs, const float* z,
+                             const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                             float* out, void* film_ws, int iters, double* result4, void* stream);
+double fenerf_siren_executed_flop_per_point(const FenerfModel* m);
+/* Per-phase device times of everything the library launches (bench.py's generator-step breakdown).  fenerf_phase_timing(1)
+ * makes every launch group record a hipEvent pair on its stream (off by default: no events, no cost); fenerf_phase_times
+ * synchronises those events, ADDS the elapsed milliseconds / launch-group counts per phase into ms[] / calls[] (n >=
+ * FENERF_N_PHASES entries, caller-zeroed) and forgets them.  fenerf_phase_name(i) names phase i ("forward_save", "chain", ...). */
+#define FENERF_N_PHASES 16
+int fenerf_phase_timing(int enable);
+int fenerf_phase_times(double* ms, int* calls, int n);
+const char* fenerf_phase_name(int phase);
+
 /* replaces: fancy_integration (volumetric_rendering.py:18-106).
  * rgb_sigma [BR, M, C] (M <= 512), z [BR, M], noise [BR, M] N(0,1) draws or NULL.
  * out_rgb [BR, C-1] (or [BR, C] for the two seg-padding fill modes), out_depth [BR],
@@ -263,6 +284,11 @@ typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in
 
 size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
 size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points);
+/* HBM bytes per (sample point x FiLM-layer feature) of the backward streams of a chunk of `chunk_points` points (bench.py's generator-step
+ * roofline): out[0] = what the chain kernel writes into the dump, out[1] = what the square weight-gradient job reads for one of its L - 1
+ * layers (the dump of layer l + the input activations of layer l), out[2] = the four thin jobs together (two dump layers + two
+ * tape layers), out[3] = the tape (fp32 pre-FiLM accumulators). */
+int fenerf_siren_backward_stream_bytes(const FenerfModel* m, int64_t chunk_points, double* out4);
 int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                               const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
                               float* out, float* tape, float* tape_e, void* film_ws, void* stream);

@@ -57,3 +57,29 @@ def test_single_process_passthrough():
     assert fdist.contiguous_shard(10, 0, 1) == (0, 10)
     x = torch.zeros(2, 3)
     assert fdist.gather_images(x) is x
+
+
+def test_bench_self_launch_rendezvous_world_size_2():
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run (the driver's N > 1
+    command is that launcher line itself); --dist-check stops after the rendezvous + all-reduce of ones, backend gloo on the CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-check", "--dist-backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dist_check"] and d["world_size"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo"
+
+
+def test_self_launch_command_is_the_drivers_launcher_line():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "5"], port=12345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")

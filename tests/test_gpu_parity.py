@@ -430,8 +430,32 @@ def _full_weights():
     return spec, proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
 
 
+def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, slab=2048):
+    """numpy oracle of the fused render on explicit rays: oo / dd [B,R,3], zz [B,R,N], uu [B*R,N] -> (pixels [B,R,22], depth [B,R])"""
+    B, R, N = zz.shape
+    assert B == 1
+    px, dp = [], []
+    for s0 in range(0, R, slab):
+        sl = slice(s0, min(R, s0 + slab))
+        o_, d_, z_ = oo[:, sl], dd[:, sl], zz[:, sl]
+        n = z_.shape[1]
+        pts = (o_[:, :, None, :] + d_[:, :, None, :] * z_[..., None]).reshape(B, -1, 3)
+        dexp = np.broadcast_to(d_[:, :, None, :], (B, n, N, 3)).reshape(B, -1, 3)
+        coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(B, n, N, -1)
+        if hier:
+            _, _, cw = O.fancy_integration(coarse, z_[..., None], clamp_mode="relu")
+            zf = O.fine_z_from_coarse(cw, z_[..., None], uu[sl])
+            fine = O.siren_forward(sd, spec, (o_[:, :, None, :] + d_[:, :, None, :] * zf).reshape(B, -1, 3), dexp, *args).reshape(B, n, N, -1)
+            ao, az = O.merge_sorted(fine, coarse, zf, z_[..., None])
+        else:
+            ao, az = coarse, z_[..., None]
+        r_rgb, r_depth, _ = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color=fill_color)
+        px.append(r_rgb); dp.append(r_depth[..., 0])
+    return np.concatenate(px, 1), np.concatenate(dp, 1)
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_full_size_128_24p24_properties_and_oracle_subset(precision):
+def test_full_size_128_24p24_properties_and_oracle_all_rays(precision):
     spec, sd = _full_weights()
     nat = native.NativeModel(sd, spec, DEV, precision)
     B, S_, N = 1, 128, 24
@@ -459,24 +483,20 @@ def test_full_size_128_24p24_properties_and_oracle_subset(precision):
     r3, d3, w3, _ = nat.render(o[:, sl].contiguous(), d[:, sl].contiguous(), z[:, sl].contiguous(), u[sl].contiguous(), None, None, *tf,
                                opts, hierarchical=True, want_weights=True)
     assert np.array_equal(N_(r3), rgb[:, sl]) and np.array_equal(N_(w3), w[:, sl])
-    # oracle on a random subset of rays (same inputs), stage-wise teacher forcing avoided: plain end-to-end
-    idx = np.sort(np.random.default_rng(1).choice(R, 192, replace=False))
-    oo, dd, zz, uu = N_(o)[:, idx], N_(d)[:, idx], N_(z)[:, idx], N_(u)[idx]
+    # the oracle on ALL 16,384 rays of the bench workload (same inputs, plain end to end: coarse -> weights -> resample -> fine ->
+    # merge -> composite), in slabs of 2,048 rays to bound the numpy activations; ~10 s on the GPU box's host cores
     args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
-    pts = (oo[:, :, None, :] + dd[:, :, None, :] * zz[..., None]).reshape(B, -1, 3)
-    dexp = np.broadcast_to(dd[:, :, None, :], (B, len(idx), N, 3)).reshape(B, -1, 3)
-    coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(B, len(idx), N, -1)
-    _, _, cw = O.fancy_integration(coarse, zz[..., None], clamp_mode="relu")
-    zf = O.fine_z_from_coarse(cw, zz[..., None], uu)
-    fpts = (oo[:, :, None, :] + dd[:, :, None, :] * zf).reshape(B, -1, 3)
-    fine = O.siren_forward(sd, spec, fpts, dexp, *args).reshape(B, len(idx), N, -1)
-    ao, az = O.merge_sorted(fine, coarse, zf, zz[..., None])
-    r_rgb, r_depth, r_w = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color="white")
-    err = np.abs(rgb[:, idx] - r_rgb).max(-1)
+    r_rgb, r_depth = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white")
+    err = np.abs(rgb - r_rgb).max(-1)
     bad = err > 1e-3
-    print(f"[parity] 128x128 24+24 H=256 [{precision}] vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
-    assert bad.mean() <= 0.03
-    np.testing.assert_allclose(depth[:, idx][~bad], r_depth[..., 0][~bad], atol=5e-4)
+    print(f"[parity] 128x128 24+24 H=256 [{precision}] vs oracle on ALL {R} rays: max|err| {err.max():.3e}, {int(bad.sum())} rays > 1e-3, "
+          f"fill decisions differing {int(((rgb[..., 0] == 1) != (r_rgb[..., 0] == 1)).sum())}")
+    assert int(bad.sum()) == 0, f"{int(bad.sum())} rays off by more than 1e-3 (worst {err.max():.3e})"
+    lab, r_lab = rgb[..., 1:-3], r_rgb[..., 1:-3]
+    top2 = np.sort(r_lab, axis=-1)
+    decided = (top2[..., -1] - top2[..., -2]) > 1e-6
+    assert (lab.argmax(-1) == r_lab.argmax(-1))[decided].all(), "exact argmax semantics on every ray the oracle itself decides"
+    np.testing.assert_allclose(depth, r_depth, atol=5e-4)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -526,23 +546,14 @@ def test_config5_256_48p48_and_config1_64_12():
         assert rgb.shape == (1, R, 22) and w.shape == (1, R, M) and np.isfinite(rgb).all()
         np.testing.assert_allclose(w.sum(-1), ws, atol=2e-5)
         assert ((ws < 0.9) == (rgb[..., 0] == 1)).all()
-        idx = np.sort(np.random.default_rng(2).choice(R, 96, replace=False))
-        oo, dd, zz = N_(o)[:, idx], N_(d)[:, idx], N_(z)[:, idx]
-        pts = (oo[:, :, None, :] + dd[:, :, None, :] * zz[..., None]).reshape(1, -1, 3)
-        dexp = np.broadcast_to(dd[:, :, None, :], (1, len(idx), N, 3)).reshape(1, -1, 3)
-        coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(1, len(idx), N, -1)
-        if hier:
-            _, _, cw = O.fancy_integration(coarse, zz[..., None], clamp_mode="relu")
-            zf = O.fine_z_from_coarse(cw, zz[..., None], N_(u)[idx])
-            fine = O.siren_forward(sd, spec, (oo[:, :, None, :] + dd[:, :, None, :] * zf).reshape(1, -1, 3), dexp, *args).reshape(1, len(idx), N, -1)
-            ao, az = O.merge_sorted(fine, coarse, zf, zz[..., None])
-        else:
-            ao, az = coarse, zz[..., None]
-        r_rgb, r_depth, _ = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color="black")
+        # oracle: every ray of the 64x64 image; 4,096 of the 65,536 rays of the 256x256 one (6 %; the whole image is 6.3 M points)
+        idx = np.arange(R) if R <= 4096 else np.sort(np.random.default_rng(2).choice(R, 4096, replace=False))
+        r_rgb, r_depth = _oracle_render_rays(sd, spec, args, N_(o)[:, idx], N_(d)[:, idx], N_(z)[:, idx], N_(u)[idx] if hier else None, "black", hier=hier)
         err = np.abs(rgb[:, idx] - r_rgb).max(-1)
         bad = err > 1e-3
-        print(f"[parity] {S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
-        assert bad.mean() <= 0.04
+        print(f"[parity] {S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays: max|err| {err.max():.3e}, {int(bad.sum())} rays > 1e-3")
+        assert int(bad.sum()) == 0, f"{int(bad.sum())} rays off by more than 1e-3 (worst {err.max():.3e})"
+        np.testing.assert_allclose(depth[:, idx], r_depth, atol=5e-4)
 
 
 def test_spatial_siren_grid_vs_reference():
@@ -735,7 +746,7 @@ def test_single_latent_generator_vs_reference(precision):
     assert px.shape == g["pixels"].shape == (2, 3, 8, 8)
     err = np.abs(N_(px) - g["pixels"]).max(axis=1)
     print(f"[parity] single-latent forward_with_frequencies[{precision}]: max|err| {err.max():.3e}")
-    assert (err > 1e-3).mean() <= 0.05
+    assert err.max() <= 1e-3
     np.testing.assert_allclose(N_(poses), g["poses"], atol=1e-6)
     # staged variant, eval_white_back fill (3-channel model), returns (pixels on device, depth.cpu()) -- two values
     g2 = load_golden("tiny_spatial_staged")
@@ -745,8 +756,8 @@ def test_single_latent_generator_vs_reference(precision):
     assert len(res) == 2 and res[0].is_cuda and not res[1].is_cuda
     err = np.abs(N_(res[0]) - g2["pixels"]).max(axis=1)
     bad = err > 1e-3
-    print(f"[parity] single-latent staged_forward_with_frequencies[{precision}]: max|err| {err[~bad].max():.3e}, {int(bad.sum())} flips")
-    assert bad.mean() <= 0.05
+    print(f"[parity] single-latent staged_forward_with_frequencies[{precision}]: max|err| {err.max():.3e}, {int(bad.sum())} flips")
+    assert int(bad.sum()) == 0
     np.testing.assert_allclose(N_(res[1])[~bad], g2["depth"][~bad], atol=1e-4)
 
 
@@ -975,8 +986,8 @@ def test_reference_checkpoint_renders_like_the_reference():
         "          h_stddev=0.3, v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, sample_dist='gaussian')\n"
         "px, depth = gen.staged_forward(T(g['z_geo']), T(g['z_app']), psi=float(g['stg_psi']), fill_mode='seg_padding_background', fill_color='white', **kw)\n"
         "err = np.abs(px.numpy() - g['stg_pixels']).max(axis=1)\n"
-        "assert (err > 1e-3).mean() <= 0.06, err.max()\n"
-        "print('ok', float(err[err <= 1e-3].max()))\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "tiny_texture_z_full.npz"),
+        "assert err.max() <= 1e-3, err.max()\n"
+        "print('ok', float(err.max()))\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "tiny_texture_z_full.npz"),
                                                                  os.path.join(GOLDEN, "ref_generator_tiny.pth"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
@@ -1190,13 +1201,34 @@ def test_backward_refuses_weights_repacked_after_the_forward():
     call()                                          # ... and a new render: the streams are rebuilt on the device
     with pytest.raises(RuntimeError, match="re-packed"):
         out.sum().backward()
+    # ... but a forced re-pack of UNCHANGED weights (train() / eval() round trip, invalidate_native()) between a forward and its
+    # backward is recognised as such (content compare) and leaves the node valid
+    for p_ in mod.parameters():
+        p_.grad = None
+    out3 = call()
+    mod.eval(); mod.train(); mod.invalidate_native()
+    out4 = call()
+    out3.sum().backward()
+    g3 = {k: N_(p_.grad).copy() for k, p_ in mod.named_parameters() if p_.grad is not None}
+    for p_ in mod.parameters():
+        p_.grad = None
+    out4.sum().backward()
+    assert all(np.array_equal(g3[k], N_(p_.grad)) for k, p_ in mod.named_parameters() if p_.grad is not None)
+    # a write through param.data followed by the mode switch IS a change: refused again
+    out5 = call()
+    next(iter(mod._render_params())).data.mul_(1.001)
+    mod.eval(); mod.train()
+    call()
+    with pytest.raises(RuntimeError, match="re-packed"):
+        out5.sum().backward()
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_chunked_backward_equals_one_pass(precision):
     """The backward runs chain + weight-gradient kernels per chunk of points (siren/autograd.py: bounded dtheta); chunk results
-    add.  With 128-point chunks (4-5 chunks per image here, ragged last chunk) every gradient equals the single-chunk one
-    up to fp32 summation order."""
+    add.  One launch over all 2 x 2 (pass, image) "images" (B > 1 kernels, per-image FiLM blocks) against 128-point chunks (4-5
+    chunks per image here, ragged last chunk) and against chunks of whole images (1,700 points: 3 images + 1): every gradient
+    equals the single-launch one up to fp32 summation order."""
     from fenerf_amd.siren import autograd as SA
     mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision=precision)
     gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
@@ -1208,7 +1240,7 @@ def test_chunked_backward_equals_one_pass(precision):
     kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
               v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
     results = []
-    for chunk in (1 << 30, 128):
+    for chunk in (1 << 30, 128, 1700):
         SA_old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
         try:
             film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
@@ -1223,11 +1255,13 @@ def test_chunked_backward_equals_one_pass(precision):
             results.append(grads)
         finally:
             SA.BACKWARD_CHUNK_POINTS = SA_old
-    one, many = results
-    assert one.keys() == many.keys() and len(one) > 30
+    one, many, grouped = results
+    assert one.keys() == many.keys() == grouped.keys() and len(one) > 30
     worst = max(_rel_err(many[k], one[k]) for k in one)
-    print(f"[parity] chunked backward (128-point chunks) vs one pass [{precision}]: worst relative difference over {len(one)} tensors {worst:.1e}")
-    assert worst <= 2e-5
+    worst_g = max(_rel_err(grouped[k], one[k]) for k in one)
+    print(f"[parity] chunked backward vs ONE launch over all images [{precision}]: worst relative difference over {len(one)} tensors "
+          f"{worst:.1e} (128-point chunks), {worst_g:.1e} (whole-image chunks)")
+    assert worst <= 2e-5 and worst_g <= 2e-5
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -1459,34 +1493,49 @@ def test_part_forward_gradient_on_a_ray_subset():
         assert np.abs(N_(img) - N_(px_full)).max() <= 2e-6
 
 
-# the two large cases give every workgroup of the 16-point kernel more than one oct of tiles (256 CUs x 128 points): the stream
-# wraps for the next tile, the ring slot counter and the tape-buffer parity carry over, the last oct is ragged
-@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (128, 4, 1, 160), (256, 6, 1, 64), (256, 6, 1, 65536), (32, 5, 1, 40000), (64, 0, 2, 33024)])
-def test_the_two_bf16_chain_kernels_agree(H, grid, B, P):
-    """siren_bwd16w_kernel (16-point waves, workgroup-shared LDS stream: the default) against siren_bwd16_kernel (32-point waves,
-    private streams; FENERF_BACKWARD_KERNEL=b16) on identical inputs: d(theta) of every layer, d(grid features), FiLM and weight
-    gradients.  The choice is per process, so tools/chain_kernels_ab.py runs one child per kernel."""
-    import subprocess
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chain_kernels_ab.py")
-    r = subprocess.run([sys.executable, tool, "--H", str(H), "--grid", str(grid), "--B", str(B), "--P", str(P)], capture_output=True, text=True,
-                       timeout=600)
-    tail = [ln for ln in r.stdout.splitlines() if ln.startswith("worst")]
-    print(f"[parity] chain kernels H={H} B={B} P={P}: {tail[-1] if tail else r.stdout[-400:] + r.stderr[-400:]}")
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+# Sizes that give every workgroup of the 16-point kernels more than one oct of tiles (256 CUs x 128 points): the stream wraps for
+# the next tile, the ring slot counter and the tape-buffer parity carry over, the last oct is ragged -- and, last, the generator
+# step's own shape: H = 256, 393,216 points of one image = two backward chunks of the production size (196,608).  Checked against
+# torch autograd of the fp64 restatement (oracle/fenerf_oracle_grad.py, pinned to the reference's autograd), which walks the points
+# in slabs of 32,768 (every gradient is a sum over points) to bound the host memory.
+@pytest.mark.parametrize("precision,H,grid,B,P", [("f16x3", 32, 5, 1, 40000), ("f32", 32, 5, 1, 40000), ("f16x3", 64, 0, 2, 33024),
+                                                  ("f16x3", 256, 6, 1, 65536), ("f32", 256, 6, 1, 65536), ("f16x3", 256, 6, 1, 393216)])
+def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
+    from oracle import fenerf_oracle_grad as OG
+    from fenerf_amd.siren import autograd as SA
+    kind = "texture" if grid else "baseline"
+    mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
+    rng = np.random.default_rng(17)
+    pts = rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, B, seed=4)
+    Cc = spec["output_dim"]
+    g_out = rng.normal(size=(B, P, Cc)).astype(np.float32)
+    g_out[..., -1] *= 0.02
+    film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+    out = mod.forward_with_frequencies_phase_shifts(T(pts), film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], T(dirs))
+    (out * T(g_out)).sum().backward()
+    nchunks = -(-P // SA.BACKWARD_CHUNK_POINTS) * B if P > SA.BACKWARD_CHUNK_POINTS else -(-B // max(1, SA.BACKWARD_CHUNK_POINTS // P))
 
-
-@pytest.mark.parametrize("H,grid,B,P", [(32, 5, 2, 96), (256, 6, 1, 65536), (64, 0, 2, 33024)])
-def test_the_two_f16x3_forward_save_kernels_agree(H, grid, B, P):
-    """siren16w_kernel<.., SAVE> (16-point waves: the default) against siren16s_kernel<.., SAVE> (FENERF_FORWARD_KERNEL=f16s): outputs, the
-    tape of every FiLM layer in the shared register-dump layout, the sampled grid features; sizes with several octs per workgroup
-    and a ragged last one.  The two accumulate in different MFMA shapes: fp32 rounding apart."""
-    import subprocess
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chain_kernels_ab.py")
-    r = subprocess.run([sys.executable, tool, "--ab", "forward", "--H", str(H), "--grid", str(grid), "--B", str(B), "--P", str(P), "--tol", "2e-5"],
-                       capture_output=True, text=True, timeout=600)
-    tail = [ln for ln in r.stdout.splitlines() if ln.startswith("worst")]
-    print(f"[parity] forward-save kernels H={H} B={B} P={P}: {tail[-1] if tail else r.stdout[-400:] + r.stderr[-400:]}")
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
+    film64 = {k: t64(v).requires_grad_(True) for k, v in film.items()}
+    fwd_err = 0.0
+    for s0 in range(0, P, 32768):
+        sl = slice(s0, min(P, s0 + 32768))
+        ref = OG.siren_forward(sd64, spec, t64(pts[:, sl]), t64(dirs[:, sl]), film64["freq_geo"], film64["phase_geo"], film64["freq_app"],
+                               film64["phase_app"])
+        (ref * t64(g_out[:, sl])).sum().backward()           # .grad accumulates over the slabs
+        fwd_err = max(fwd_err, float(np.abs(N_(out[:, sl]) - ref.detach().numpy())[..., :-1].max()))
+    assert fwd_err <= 1e-4
+    errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film}
+    named = dict(mod.named_parameters())
+    errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
+    worst = max(errs, key=errs.get)
+    print(f"[parity] SIREN backward at scale [{precision}] H={H} B={B} P={P} ({nchunks} backward launch(es)): worst relative error over "
+          f"{len(errs)} gradient tensors {errs[worst]:.2e} ({worst}); forward max|err| {fwd_err:.1e}")
+    assert errs[worst] <= (2e-5 if precision == "f32" else 1e-4), (worst, errs[worst])
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -1655,8 +1704,12 @@ def test_generator_step_through_ddp(tmp_path):
     plain = grads(gen)
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
+        assert dist.get_backend() == "nccl"
+        probe = torch.full((4,), 3.0, device=DEV)
+        dist.all_reduce(probe)                             # RCCL all-reduce on the GPU (world 1: identity)
+        assert probe.tolist() == [3.0] * 4
         ddp = DDP(gen, device_ids=[0], find_unused_parameters=True)
         wrapped = grads(ddp)
         opt = torch.optim.Adam(ddp.parameters(), lr=1e-4)
@@ -1668,7 +1721,32 @@ def test_generator_step_through_ddp(tmp_path):
     assert set(plain) == set(wrapped)
     assert max(_rel_err(wrapped[k], plain[k]) for k in plain) <= 1e-5
     assert any(np.abs(again[k] - wrapped[k]).max() > 0 for k in plain)
-    print("[parity] generator step through DistributedDataParallel: gradients identical to the bare module; optimizer step picked up")
+    print("[parity] generator step through DistributedDataParallel over RCCL (backend nccl, world 1): gradients identical to the bare "
+          "module; optimizer step picked up")
+
+
+def test_bench_under_torch_distributed_run_initialises_rccl():
+    """The driver's N > 1 command line at N = 1: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...` with
+    FENERF_BENCH_FORCE_DIST=1, which makes bench.py take its N > 1 branch (init_process_group("nccl", device_id=...), barrier,
+    max-over-ranks all-reduce, all-gathers) with a single rank -- so the first RCCL initialisation of this code base does not happen
+    inside the driver's scaling run (reference: train_double_latent_semantic.py:58-63,148-150,584)."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.self_launch_command(1, ["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-f32", "--no-gstep",
+                                        "--no-sweep64"], script=os.path.join(ROOT, "bench.py"))
+    env = dict(os.environ, FENERF_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["dist_backend"] == "nccl"
+    assert d["launcher"].startswith("torch.distributed.run") and "forced" in d["launcher"]
+    assert d["value"] > 1e6 and len(d["rays_per_s_per_rank"]) == 1 and len(d["roofline"]["frac_per_rank"]) == 1
+    print(f"[dist] bench.py under torch.distributed.run, RCCL process group at world 1: {d['value']:.3e} rays/s, n_ranks_seen 1")
 
 
 def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():

@@ -292,6 +292,18 @@ def test_avg_frequency_cache_keeps_values_and_rng_consumption():
         next(gen.siren.geo_mapping_network.parameters()).add_(0.1)
     torch.manual_seed(4); d = gen.generate_avg_frequencies()
     assert len(calls) == 3 and not torch.equal(d[0], c[0])
+    # writes through param.data (torch_ema's copy_to / restore) bypass the version counters: the same seed would hit the cache
+    # with the OLD weights' averages -- the generator's eval() / train() (the reference brackets every EMA swap with them) and
+    # invalidate_native() drop the cache
+    w0 = next(gen.siren.geo_mapping_network.parameters())
+    for how in ("eval", "train", "invalidate_native"):
+        before = len(calls)
+        torch.manual_seed(4); e0 = [t.clone() for t in gen.generate_avg_frequencies()]
+        w0.data.copy_(w0.data * 1.5 + 0.01)
+        getattr(gen, how)()
+        torch.manual_seed(4); e1 = gen.generate_avg_frequencies()
+        assert len(calls) - before >= 1 and not torch.equal(e1[0], e0[0]), how
+    calls.clear(); calls.extend([1] * 3)
     gen.draws = VR.RecordedDraws([np.zeros((10000, 8), np.float32)] * 2)          # recorded draws are replayed, never cached
     gen.generate_avg_frequencies()
     assert len(calls) == 4 and not gen.draws.arrays

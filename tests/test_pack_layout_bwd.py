@@ -1,5 +1,5 @@
 """CPU check of the backward-chain weight streams (fenerf_pack.cpp::pack_weights_bwd / pack_weights_bwd16) + the dataflow
-of fenerf_siren_bwd.hip / fenerf_siren_bwd16.hip: a numpy emulation of one wave -- same stream walk, same v_mfma_f32_32x32x2_f32 lane maps, same
+of fenerf_siren_bwd.hip / the 32x32x16 reading of the bf16 stream (fenerf_siren_bwd16w.hip re-tiles it, tests/test_pack_layout_bwd16w.py): a numpy emulation of one wave -- same stream walk, same v_mfma_f32_32x32x2_f32 lane maps, same
 stage order (rgb head^T, colour layers, the colour-layer-0 stage with head^T and the grid-feature body, trunk) -- run
 on the blob the C packer produced and compared with dL/dtheta of every FiLM layer from torch fp64 autograd.
 Both packings: exact fp32 rows, and the power-of-two row-scaled rows of FENERF_PREC_F16X3 models (dz' = dz / s)."""
@@ -119,7 +119,7 @@ def mfma16(a, b, acc):
 
 
 def emulate_chain16(blob, spec, theta, f_true, row_scale, d_out, out):
-    """The bf16x3 chain (fenerf_siren_bwd16.hip) on its stream: fp32 rgb-head block, then [hi entry, lo entry] per k-step.
+    """The bf16x3 chain (the stream of fenerf_siren_bwd16w.hip, read entry by entry) on its stream: fp32 rgb-head block, then [hi entry, lo entry] per k-step.
     The emulation multiplies (hi + lo) with exact dz: it checks layout and dataflow, not the split arithmetic."""
     H, NB, KS = spec["hidden_dim"], spec["hidden_dim"] // 32, spec["hidden_dim"] // 16
     pad = lambda n: (n + PF16 - 1) // PF16 * PF16

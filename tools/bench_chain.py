@@ -1,5 +1,5 @@
 """Times the backward chain kernel alone (fenerf_siren_backward) on one chunk of the generator step's backward:
-131,072 points of one image, H=256 + 96^3 grid.  FENERF_LIB / FENERF_BACKWARD_KERNEL select the build / kernel.
+131,072 points of one image, H=256 + 96^3 grid.  FENERF_LIB selects the build.
 
     python tools/bench_chain.py [--points 131072] [--iters 20]
 """
