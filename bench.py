@@ -114,7 +114,7 @@ def cpu_baseline(spec, sd, film, seed, full=True):
     return out
 
 
-def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True):
+def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_precision="f32"):
     """BASELINE.json's metric also names the generator step: forward + backward (+ the device-side re-pack an optimizer step
     forces) through DoubleImplicitGenerator3d.forward_with_frequencies on the same workload shape, native differentiable path
     (DESIGN.md 4.5).  Reported beside the headline value; never part of the timed region.
@@ -136,6 +136,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True):
     mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
     mod.load_state_dict(tsd, strict=False)
     mod.precision = precision
+    mod.grad_precision = grad_precision
     gen = G.DoubleImplicitGenerator3d(functools.partial(S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=H), z_dim, z_dim, spec["output_dim"])
     gen.siren = mod
     gen = gen.to(dev)
@@ -165,7 +166,8 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     out = {"ms": ms, "what": f"forward + backward + device re-pack of one generator step, batch {B} x {S}x{S} rays x {N}+{N} samples "
-                             f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}",
+                             f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}, weight-gradient operands "
+                             + ("fp32 class (default)" if grad_precision == "f32" else "bf16, one MFMA per product: AMP class, opt-in (siren.grad_precision = 'amp')"),
            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
     if not breakdown:
         return out
@@ -406,6 +408,11 @@ def main(argv=None):
                 out["gstep"] = gstep_leg(spec, sd, dev, B, S, N, args.precision)
             except Exception as e:          # the extra leg must never take the headline metric down with it
                 out["gstep"] = {"error": f"{type(e).__name__}: {e}"}
+            if args.precision == "f16x3":
+                try:   # opt-in AMP-class weight-gradient operands (the class of the reference's own autocast training): reported beside, never instead
+                    out["gstep_amp"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision="amp")
+                except Exception as e:
+                    out["gstep_amp"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_gstep_b6 and (B, S, N) == (1, 128, 24):
                 try:   # BASELINE.json configs[2]: the reference's generator micro-batch (batch 24 split 4 -> 6 images of 128x128 x 24+24 per GPU)
                     torch.cuda.empty_cache()

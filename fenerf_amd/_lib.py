@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FENERF_LIB", os.path.join(_HERE, "libfenerf_hip.so"))   # FENERF_LIB: kernel A/B experiments only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_GEO, MAX_COLOR, MAX_LABEL = 8, 4, 3
 
 OK, E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_CLAMP_MODE = 0, -1, -2, -3, -4, -5
@@ -33,7 +33,7 @@ class FenerfModelDesc(C.Structure):
         ("color_w", _fp * MAX_COLOR), ("color_b", _fp * MAX_COLOR),
         ("label_w", _fp * MAX_LABEL), ("label_b", _fp * MAX_LABEL),
         ("sigma_w", _fp), ("sigma_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp), ("grid", _fp),
-        ("precision", C.c_int32), ("differentiable", C.c_int32),
+        ("precision", C.c_int32), ("differentiable", C.c_int32), ("wgrad_bf16_min_points", C.c_int32),
     ]
 
 
@@ -144,7 +144,7 @@ def _as_f32(a):
 PRECISION = {"f32": 0, "f16x3": 1}
 
 
-def make_desc(sd, spec, precision="f32", differentiable=False):
+def make_desc(sd, spec, precision="f32", differentiable=False, wgrad_bf16_min_points=0):
     """Builds a FenerfModelDesc from a reference-named state dict of numpy arrays.
     Returns (desc, keepalive) -- keepalive holds the host arrays the desc points into."""
     keep = []
@@ -161,6 +161,7 @@ def make_desc(sd, spec, precision="f32", differentiable=False):
     d.box_scale = 2 / 0.24
     d.precision = PRECISION[precision]
     d.differentiable = int(bool(differentiable))
+    d.wgrad_bf16_min_points = int(wgrad_bf16_min_points)
     for i in range(spec["n_geo"]):
         d.geo_w[i], d.geo_b[i] = P(f"network.{i}.layer.weight"), P(f"network.{i}.layer.bias")
     if spec["kind"] == "spatial":

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -71,6 +72,11 @@ PhaseScope::~PhaseScope() {
   (void)hipEventRecord(r->e1, r->st);
   std::lock_guard<std::mutex> lock(g_phase_mu);
   g_phase_recs.push_back(r);
+}
+
+// the dump format of a backward chunk (fenerf_layout.h "bf16 dump"): opt-in per model (FenerfModelDesc.wgrad_bf16_min_points)
+bool use_bf16_dump(const FenerfModel* m, long long total_points) {
+  return m && m->precision == FENERF_PREC_F16X3 && m->wgrad_bf16_min_points > 0 && total_points >= m->wgrad_bf16_min_points;
 }
 
 static int check_opts(const FenerfCompositeOpts* o) {
@@ -171,6 +177,7 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   m->box_scale = d->box_scale;
   m->precision = d->precision;
   m->differentiable = d->differentiable != 0;
+  m->wgrad_bf16_min_points = d->wgrad_bf16_min_points > 0 ? d->wgrad_bf16_min_points : 0;
   if (d->precision != FENERF_PREC_F32 && d->precision != FENERF_PREC_F16X3) { delete m; return fail(FENERF_E_INVALID, "unknown precision"); }
   m->bsh = bwd_stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
   m->sh = stream_shape(m->H, m->n_geo, m->n_color, m->grid_ch != 0);
@@ -192,7 +199,8 @@ extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, voi
   int rc = validate_desc(d, err);
   if (rc) return fail(rc, err);
   if (d->hidden_dim != m->H || d->n_geo != m->n_geo || d->n_color != m->n_color || d->output_dim != m->C ||
-      d->grid_ch != m->grid_ch || d->precision != m->precision || (d->differentiable != 0) != (m->differentiable != 0) || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
+      d->grid_ch != m->grid_ch || d->precision != m->precision || (d->differentiable != 0) != (m->differentiable != 0) ||
+      (d->wgrad_bf16_min_points > 0 ? d->wgrad_bf16_min_points : 0) != m->wgrad_bf16_min_points || (d->grid && (d->grid_d != m->gd || d->grid_h != m->gh || d->grid_w != m->gw)))
     return fail(FENERF_E_INVALID, "fenerf_model_update: architecture differs from the created model");
   m->box_scale = d->box_scale;
   return upload_model(m, d, (hipStream_t)stream, false);
@@ -569,8 +577,14 @@ extern "C" size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total
 
 extern "C" int fenerf_siren_backward_stream_bytes(const FenerfModel* m, int64_t chunk_points, double* out4) {
   if (!m || !out4 || chunk_points <= 0) return fail(FENERF_E_INVALID, "model / out is NULL or chunk_points <= 0");
-  // fp32 dump: d(theta) 4 B written and read once; the weight gradients recompute their input activations from the fp32 tape
-  out4[0] = 4.0; out4[1] = 4.0 + 4.0; out4[2] = 2 * 4.0 + 2 * 4.0; out4[3] = 4.0;
+  if (use_bf16_dump(m, chunk_points)) {
+    // bf16 dump (fenerf_layout.h): d(theta) and x = sin(2 pi theta) 2 B each, written by the chain and read once by the square job
+    // (the last layer's x is not written: 1 / L less); the thin jobs read two bf16 d(theta) layers and two fp32 tape layers
+    out4[0] = 2.0 + 2.0 * (m->L - 1) / m->L; out4[1] = 2.0 + 2.0; out4[2] = 2 * 2.0 + 2 * 4.0; out4[3] = 4.0;
+  } else {
+    // fp32 dump: d(theta) 4 B written and read once; the weight gradients recompute their input activations from the fp32 tape
+    out4[0] = 4.0; out4[1] = 4.0 + 4.0; out4[2] = 2 * 4.0 + 2 * 4.0; out4[3] = 4.0;
+  }
   return FENERF_OK;
 }
 
@@ -615,6 +629,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.P = (long long)B * P; bp.pts_per_image = P;
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;    // appended to the dtheta dump
+  bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
   PhaseScope ph(PH_CHAIN, stream);
   return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16w(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
@@ -653,6 +668,7 @@ extern "C" int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = nullptr;
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;
   bp.points = points; bp.d_grid_cl = d_grid_cl; bp.box_scale = m->box_scale; bp.gd = m->gd; bp.gh = m->gh; bp.gw = m->gw;
+  bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
   { PhaseScope ph(PH_CHAIN, stream); return launch_siren_backward16w(m, bp, stream); }
 }
 

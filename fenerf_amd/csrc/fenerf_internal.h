@@ -46,6 +46,7 @@ struct FenerfModel {
   int num_cus;
   int precision;    // FENERF_PREC_*
   int differentiable;       // desc->differentiable: the backward-chain stream is resident too
+  int wgrad_bf16_min_points; // desc->wgrad_bf16_min_points: 0 = fp32-class weight gradients; > 0 = bf16 dump for chunks of at least that many points
   fenerf::BwdShape bsh;
   float* d_bwd_stream;      // [rgb-head^T entries | backward ring] * 256 floats, or nullptr
   float* d_row_scale;       // fenerf_model_repack scratch: [2][L*H + 64] row scales (forward | backward), lazily allocated
@@ -95,6 +96,7 @@ struct SirenBwdParams {
   const float* d_out;      // [P][C] gradient wrt the outputs
   const float* tape;       // from the forward (tape layout)
   float* d_t;              // out, tape layout: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
+  int bf16_dump;           // siren_bwd16w_kernel: write the dump as bf16 [d theta | x = sin(2 pi theta)] halves instead (fenerf_layout.h "bf16 dump")
   float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
   float* film_tiles;       // [tiles][L][2][H] out: per-tile FiLM sums (fenerf_layout.h "FiLM sums")
   // fused grid scatter (siren_bwd16w_kernel only): when d_grid_cl != nullptr the gradient wrt the sampled grid features is not
@@ -128,6 +130,7 @@ int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const f
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream);  // FENERF_PREC_F16X3 models: bf16x3 chain on 16-point waves (fenerf_siren_bwd16w.hip)
+bool use_bf16_dump(const FenerfModel* m, long long total_points);   // the dump format of a backward chunk (fenerf_layout.h "bf16 dump"); chain and weight-gradient launches ask the same question
 int bwd16w_film_unit(long long total_points, long long pts_per_image);   // points per FiLM-sum unit of that kernel: 128 (workgroup) or 16 (wave)
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,

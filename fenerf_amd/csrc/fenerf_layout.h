@@ -86,6 +86,18 @@ inline BwdShape bwd_stream_shape(int H, int n_geo, int n_color, bool grid) {
 // FiLM sums (backward): per 32-point tile and FiLM layer the chain kernels also emit s0[n] = sum_p dtheta[n][p] and
 // s1[n] = sum_p dtheta[n][p] * tape[n][p] (raw accumulator units), [tile][layer][2][H] floats, appended to the dtheta dump.
 constexpr long long film_tile_floats(long long tiles, int L, int H) { return tiles * L * 2 * H; }
+// bf16 dump (round 3; opt-in per model, FenerfModelDesc.wgrad_bf16_min_points: AMP-class weight gradients): the chain kernel writes,
+// into the SAME (tile32, layer) block of H*128 bytes, first d theta_l and then x_l = sin(2 pi theta_l) -- which it has in registers
+// anyway -- rounded to nearest-even bf16:
+//     [which: d theta | x][nb (H/32)][16-point tile (2)][lane (64)][8 bf16],  lane (n, g) slot t = 4 rt + r:
+//     feature 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r of point 32 tile32 + 16 (tile & 1) + n
+// (a 16-point wave's accumulator registers of one n-block, both row tiles, as one 16-byte store per lane).  The square
+// weight-gradient job then reads 2 + 2 bytes per (point, feature) instead of 4 + 4 and never touches the tape.  Rounding errors are
+// unbiased and independent over points, i.e. ~1e-3 of the NOISE FLOOR sqrt(sum_p (dtheta x)^2) of a gradient entry: measured 2.5e-3
+// (max-norm relative) against fp64 autograd for point-wise random upstream gradients at 65,536 and at 393,216 points alike -- it does
+// not average down with the point count, which is why this is an opt-in training precision and not the default
+// (tests/test_gpu_parity.py::test_siren_backward_at_scale_vs_fp64_autograd).  FiLM sums and dz keep full precision (registers).
+constexpr int dump16_feature(int nb, int g, int t) { return 32 * nb + 16 * (g >> 1) + 4 * (g & 1) + 8 * (t >> 2) + (t & 3); }
 constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * (g & 3) + 4 * half + i; }
 
 // ---------------------------------------------------------------------------------------------

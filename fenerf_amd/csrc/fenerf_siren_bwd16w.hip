@@ -111,6 +111,9 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
+__device__ __forceinline__ void st_u4_nt(const void* g_uniform, unsigned voff, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
 __device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, const f32x2& v) {
   asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
@@ -226,11 +229,12 @@ struct Sink {
   const char* dt_base;      // global (uniform): d theta dump of (tile32, layer)
   const char* film_base;    // global (uniform): FiLM sums of (tile16, layer)
   unsigned toff;            // lane offset inside a (tile32, layer) dump block: the register-dump position of this lane
+  unsigned doff;            // bf16 dump: lane offset inside an n-block's 2 KiB = 1024 (tile & 1) + 16 lane
   unsigned foff;            // lane offset inside a FiLM-sum n-block
   bool b0, b1;              // lane & 1, lane & 2
 };
 struct EpiIn { float4 f, p, t; };
-struct EpiOut { f32x4 dt, dtt; };
+struct EpiOut { f32x4 dt, dtt; unsigned pd[2], px[2]; };   // pd / px (bf16 dump): d theta and x = sin(2 pi theta) as bf16 pairs
 
 template <int PF4>
 __device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tbuf) {
@@ -243,20 +247,33 @@ __device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tb
 
 // E(rt) of n-block nbp: d theta = dx cos(2 pi theta), d z = d theta f'' 2 pi split into bf16 (hi = truncation, lo = the
 // remainder rounded to nearest) -> slots 4 rt .. 4 rt + 3 of k32-step nbp of the next stage's B operand; the d theta store.
+// BD (bf16 dump, header of this file): also x = sin(2 pi theta) -- bitwise the forward's activation -- and both rounded to bf16.
+template <bool BD>
 __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, u32x4& yh, u32x4& yl, int rt) {
   [[maybe_unused]] const float TWO_PI = 6.28318530717958647692f;
   const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w}, p[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, t[4] = {q.t.x, q.t.y, q.t.z, q.t.w};
   EpiOut o;
   unsigned hb[4];
   float rem[4];
+  [[maybe_unused]] float xs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float dt = acc[r] * __builtin_amdgcn_cosf(__builtin_fmaf(f[r], t[r], p[r]));
+    const float th = __builtin_fmaf(f[r], t[r], p[r]);
+    const float dt = acc[r] * __builtin_amdgcn_cosf(th);
+    if (BD) xs[r] = __builtin_amdgcn_sinf(th);
     o.dt[r] = dt;
     o.dtt[r] = dt * t[r];
     const float dz = dt * (f[r] * TWO_PI);
     hb[r] = __builtin_bit_cast(unsigned, dz);
     rem[r] = dz - __builtin_bit_cast(float, hb[r] & 0xffff0000u);
+  }
+  if (BD) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x2 dd = {o.dt[2 * j], o.dt[2 * j + 1]}, xx = {xs[2 * j], xs[2 * j + 1]};
+      o.pd[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(dd, bf16x2));     // v_cvt_pk_bf16_f32: round to nearest even
+      o.px[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, bf16x2));
+    }
   }
   unsigned h2[2], l2[2];
 #pragma unroll
@@ -272,7 +289,7 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   return o;
 }
 
-template <int H, bool GRID, bool WGS>
+template <int H, bool GRID, bool WGS, bool BD>
 __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = pad_pf16(2 * (H / 16)) / CH;               // chunks per square body
@@ -418,9 +435,21 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       k.film_base = uniform_ptr(film_tile + (size_t)layer * (2 * H * 4));
       k.toff = lane_toff();
       const int lo = opaque(lane);
+      k.doff = (unsigned)(1024 * (int)(tile & 1) + 16 * lo);
       k.foff = (unsigned)(((lo >> 4) * 4 + (lo & 3)) * 8);
       k.b0 = (lo & 1) != 0; k.b1 = (lo & 2) != 0;
       return k;
+    };
+
+    // bf16 dump of n-block nbp: both row tiles' d theta in ONE 16-byte store per lane (slot 4 rt + r), and their x likewise into the
+    // second half of the (tile32, layer) block
+    auto dump_bf16 = [&](const Sink& k, int nbp, const EpiOut (&e2)[2], bool with_x) {
+      const u32x4 dd = {e2[0].pd[0], e2[0].pd[1], e2[1].pd[0], e2[1].pd[1]};
+      st_u4_nt(k.dt_base + nbp * 2048, k.doff, dd);
+      if (with_x) {
+        const u32x4 xx = {e2[0].px[0], e2[0].px[1], e2[1].px[0], e2[1].px[1]};
+        st_u4_nt(k.dt_base + TL / 2 + nbp * 2048, k.doff, xx);
+      }
     };
 
     film_issue(L - 1);
@@ -491,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       const float* wl = ht_lds + ((g & 1) * 32 + 16 * (gi >> 1) + 4 * (gi & 1) + r) * 4 + (g >> 1);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
+        EpiOut o2[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -499,12 +529,13 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           q.f = *reinterpret_cast<const float4*>(k.film + 32 * nb + 8 * rt);
           q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
           q.t = t_rgb[nb][rt];
-          const EpiOut o = epi_compute(acc, q, zh[nb], zl[nb], rt);
-          st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o.dt);
-          const f32x2 s = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
+          o2[rt] = epi_compute<BD>(acc, q, zh[nb], zl[nb], rt);
+          if (!BD) st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o2[rt].dt);
+          const f32x2 s = {row_sum4(o2[rt].dt, k.b0, k.b1), row_sum4(o2[rt].dtt, k.b0, k.b1)};
           if (WGS) fs_write(nb % 3, rt, s);
           else st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
         }
+        if (BD) dump_bf16(k, nb, o2, false);    // x of the last FiLM layer has no consumer in the dump (the rgb-head job reads the tape)
         if (WGS) {   // once per tile and n-block: every wave's sums of this n-block are in buffer nb % 3; buffer reuse is three barriers away
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes have completed before it arrives
           __builtin_amdgcn_s_barrier();
@@ -607,8 +638,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   const int rt = it >> 1;
                   if ((it & 1) == 0) {
                     if constexpr (nb > 0) {
-                      eo[rt] = epi_compute(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
-                      st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt);
+                      eo[rt] = epi_compute<BD>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
+                      if constexpr (!BD) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt);
+                      else if (rt == 1) dump_bf16(k, nb - 1, eo, true);
                     }
                     // the tape block two n-blocks ahead of its use: (lo, nb + 1), or the next stage's n-block 0; the last
                     // stage's last body re-fetches (0, 0) so that ring_wait's count holds
@@ -647,14 +679,17 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       });
       if constexpr (EPI) {
         // ---- the last n-block's epilogue, behind the stage
+        EpiOut o2[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           constexpr int c0 = item_chunk(QBS, 0), c1 = item_chunk(QBS, 2);
           if (rt == 0) wait_vmcnt<2 * QBS - 1 - c0>(); else wait_vmcnt<2 * QBS - 1 - c1>();
           LDS_FENCE();
           const EpiIn q = epi_read<FILM_F / 4>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
-          const EpiOut o = epi_compute(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
-          st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
+          o2[rt] = epi_compute<BD>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
+          const EpiOut& o = o2[rt];
+          if (!BD) st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
+          else if (rt == 1) dump_bf16(k, NBODY - 1, o2, true);
           const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
           if (WGS) {
             fs_write(kb_next, rt, sm);
@@ -745,12 +780,12 @@ static int hip_fail16w(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-template <int H, bool GRID, bool WGS>
+template <int H, bool GRID, bool WGS, bool BD>
 static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
                      (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0) + (size_t)NWAVE * 48 * 4;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers + tile points
-  auto kfn = siren_bwd16w_kernel<H, GRID, WGS>;
+  auto kfn = siren_bwd16w_kernel<H, GRID, WGS, BD>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -762,7 +797,9 @@ static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream)
 }
 template <int H, bool GRID>
 static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
-  return bwd16w_film_unit(p.P, p.pts_per_image) == 128 ? launch_w<H, GRID, true>(m, p, stream) : launch_w<H, GRID, false>(m, p, stream);
+  const bool wgs = bwd16w_film_unit(p.P, p.pts_per_image) == 128;
+  if (p.bf16_dump) return wgs ? launch_w<H, GRID, true, true>(m, p, stream) : launch_w<H, GRID, false, true>(m, p, stream);
+  return wgs ? launch_w<H, GRID, true, false>(m, p, stream) : launch_w<H, GRID, false, false>(m, p, stream);
 }
 
 }  // namespace bw16

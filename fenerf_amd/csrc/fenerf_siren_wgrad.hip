@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
@@ -46,6 +47,7 @@ struct WgradParams {
   const float* film_tiles;     // [tiles][L][2][H] from the chain kernel (fenerf_layout.h "FiLM sums")
   int film16w;                 // the sums come from siren_bwd16w_kernel, register-dump order (fenerf_siren_bwd16w.hip): points per unit (16 / 128), 0 = no
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
+  int bf16_dump;               // d_t holds the chain kernel's bf16 dump [d theta | x] (fenerf_layout.h "bf16 dump") instead of fp32 d theta
 };
 
 // Stage one register-dump tile into LDS rows [H][WG_LD]; optional FiLM transform to activations.  The f' / p' rows are
@@ -81,6 +83,39 @@ template <int H>
 __device__ __forceinline__ void load_dump(float4 (&v)[H / 32], const float4* src /* (tile, layer) base */, int wave, int lane) {
 #pragma unroll
   for (int q = 0; q < H / 32; ++q) v[q] = nt_load(src + (wave * (H / 32) + q) * 64 + lane);
+}
+
+// bf16 dump (fenerf_layout.h): the d theta half of a (tile32, layer) block is H*4 16-byte pieces; piece s = (nb, 16-point tile, lane
+// (n, g)) holds 8 features of one point.  256 threads take pieces tid + 256 q.
+template <int H>
+struct Dump16 {
+  static constexpr int PIECES = H * 4;                          // per operand half and 32-point tile
+  static constexpr int PER_THREAD = (PIECES + 255) / 256;
+};
+template <int H>
+__device__ __forceinline__ void load_dump16(uint4 (&v)[Dump16<H>::PER_THREAD], const char* half_base, int tid) {
+#pragma unroll
+  for (int q = 0; q < Dump16<H>::PER_THREAD; ++q) {
+    const int s_ = tid + 256 * q;
+    if (Dump16<H>::PIECES % 256 == 0 || s_ < Dump16<H>::PIECES)
+      v[q] = __builtin_bit_cast(uint4, nt_load(reinterpret_cast<const float4*>(half_base) + s_));
+  }
+}
+// -> fp32 rows [feature][WG_LD] (the exact-fp32 thin jobs): bf16 -> fp32 is a shift
+template <int H>
+__device__ __forceinline__ void stage_dump16_f32(const uint4 (&v)[Dump16<H>::PER_THREAD], float* dst, int tid) {
+#pragma unroll
+  for (int q = 0; q < Dump16<H>::PER_THREAD; ++q) {
+    const int s_ = tid + 256 * q;
+    if (Dump16<H>::PIECES % 256 != 0 && s_ >= Dump16<H>::PIECES) continue;
+    const int nb = s_ >> 7, odd = (s_ >> 6) & 1, n = s_ & 15, g = (s_ >> 4) & 3;
+    const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const unsigned bits = (t & 1) ? (w[t >> 1] & 0xffff0000u) : (w[t >> 1] << 16);
+      dst[dump16_feature(nb, g, t) * WG_LD + 16 * odd + n] = __builtin_bit_cast(float, bits);
+    }
+  }
 }
 
 // JOB: which operands.  MT x KT = output tiles (32x32) of the workgroup; WM x WK = tiles per wave.
@@ -138,16 +173,23 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   float s0 = 0.f;              // head row sums (thread = row)
 
   float4 va[NQ], vb[NQ];
+  uint4 va16[Dump16<H>::PER_THREAD];
   auto fetch = [&](int t) {
     const long long tile = tile_base + t;
-    if (S::A_DUMP) load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
+    if (S::A_DUMP) {
+      if (P.bf16_dump) load_dump16<H>(va16, reinterpret_cast<const char*>(dt4 + (tile * L + l) * tl), tid);
+      else load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
+    }
     if (S::B_DUMP) load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
   };
   if (t0 < t1) fetch(t0);
   for (int t = t0; t < t1; ++t) {
     const long long pt0 = (tile_base + t) * 32;
     // ---- stage the tile
-    if (S::A_DUMP) stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
+    if (S::A_DUMP) {
+      if (P.bf16_dump) stage_dump16_f32<H>(va16, A_s, tid);
+      else stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
+    }
     if (S::B_DUMP) stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
       if (tid < 96) { const int c = tid >> 5, m = tid & 31; B_s[c * WG_LD + m] = P.points[(pt0 + m) * 3 + c] * P.box_scale; }
@@ -484,6 +526,154 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Square weight-gradient job on the chain kernel's bf16 dump (fenerf_layout.h "bf16 dump"; backward chunks of >=
+// FENERF_BF16_DUMP_MIN_POINTS points): d theta_l and x_{l-1} arrive as bf16, a product is ONE v_mfma_f32_32x32x16_bf16, nothing is
+// recomputed (no sin, no split) and the tape is not read: 2 + 2 bytes per (point, feature), the kernel is a pure two-stream reader.
+// Same workgroup shape, partial layout and reduction as the kernels above.  LDS image per operand: [feature][32 points bf16 | pad],
+// row stride 80 B (an odd multiple of 16 B: the ds_read_b128 fragment reads of 16 consecutive rows hit 16 different 16-byte bank
+// groups); double-buffered; the transpose between the dump (lane = point, slots = features) and the MFMA operand (lane = feature,
+// slots = points) is the staging's 16-bit LDS stores -- lower / upper half of a register as they are (ds_write_b16 / _d16_hi).
+// ------------------------------------------------------------------------------------------------
+constexpr int WD_LD = 40;   // u16 per image row
+template <int H>
+__global__ __launch_bounds__(256, 1) void siren_wgrad_sq_b16d_kernel(WgradParams P) {
+  constexpr int NB = H / 32;
+  constexpr int WGK = 2, WM = (NB + 1) / 2, WK = (NB + 1) / 2;
+  constexpr int NGROUP = WM * WK;                         // accumulator groups (2 dependent MFMAs each) per wave and tile
+  constexpr int NP = Dump16<H>::PER_THREAD;               // 16-byte pieces per thread, operand and tile
+  constexpr int PPG = (2 * NP + NGROUP - 1) / NGROUP;     // pieces staged per group
+  constexpr int OPER = H * WD_LD;                         // u16 per operand image
+  constexpr long long TLB = (long long)H * 128;           // bytes of a (tile32, layer) dump block
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned short* img0 = reinterpret_cast<unsigned short*>(lds);     // 2 buffers x { A: d theta_l rows, B: x_{l-1} rows }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x, img = blockIdx.y;
+  const int l = P.layer0 + blockIdx.z, lb = l - 1;
+  const int L = P.L;
+
+  const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
+  const int t0 = chunk * t_per, t1 = min(P.tiles_per_image, t0 + t_per);
+  const long long tile_base = (long long)img * P.tiles_per_image;
+  const char* dump = reinterpret_cast<const char*>(P.d_t);
+
+  f32x16 acc[WM][WK];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WK; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
+
+  // Two register sets of dump pieces: while tile t multiplies out of LDS buffer (t - t0) & 1, tile t + 1 is staged from set
+  // (t - t0) & 1 into the other buffer and every staged piece's registers are refilled with tile t + 3 -- loads stay in flight for
+  // TWO tile periods (a tile is only 32 KiB per workgroup here: one period of ~1.5 us would not cover the loaded HBM latency).
+  uint4 va[2][NP], vb[2][NP];
+  // No branches inside a tile (fenerf_siren_wgrad.hip, the kernel above): past the chunk's end the last tile is re-read.
+  auto fetch_q = [&](auto set_c, int t, int q) {
+    constexpr int SET = decltype(set_c)::value;
+    const long long tile = tile_base + (t < t1 ? t : t1 - 1);
+    const int s_ = tid + 256 * q;
+    if (Dump16<H>::PIECES % 256 == 0 || s_ < Dump16<H>::PIECES) {
+      va[SET][q] = __builtin_bit_cast(uint4, nt_load(reinterpret_cast<const float4*>(dump + (tile * L + l) * TLB) + s_));
+      vb[SET][q] = __builtin_bit_cast(uint4, nt_load(reinterpret_cast<const float4*>(dump + (tile * L + lb) * TLB + TLB / 2) + s_));
+    }
+  };
+  // piece pc = 2 q + which (0 = d theta, 1 = x) of the tile in register set SET -> buffer dst
+  auto stage_piece = [&](auto set_c, int pc, unsigned short* dst) {
+    constexpr int SET = decltype(set_c)::value;
+    const int q = pc >> 1;
+    const int s_ = tid + 256 * q;
+    if (Dump16<H>::PIECES % 256 != 0 && s_ >= Dump16<H>::PIECES) return;
+    const int nb = s_ >> 7, odd = (s_ >> 6) & 1, n = s_ & 15, g = (s_ >> 4) & 3;
+    const uint4 v = (pc & 1) ? vb[SET][q] : va[SET][q];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned short* col = dst + ((pc & 1) ? OPER : 0) + 16 * odd + n;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      col[dump16_feature(nb, g, t) * WD_LD] = (t & 1) ? (unsigned short)(w[t >> 1] >> 16) : (unsigned short)w[t >> 1];
+  };
+  const std::integral_constant<int, 0> set0;
+  const std::integral_constant<int, 1> set1;
+
+  // ---- prologue: tile t0 staged into buffer 0; tiles t0 + 1 / t0 + 2 on their way in sets 0 / 1
+#pragma unroll
+  for (int q = 0; q < NP; ++q) fetch_q(set0, t0, q);
+#pragma unroll
+  for (int pc = 0; pc < 2 * NP; ++pc) stage_piece(set0, pc, img0);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) fetch_q(set0, t0 + 1, q);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) fetch_q(set1, t0 + 2, q);
+  __syncthreads();
+
+  const int i = lane & 31, kh = lane >> 5;
+  auto a_tile = [&](int mt) { return (wm0 + mt < NB) ? wm0 + mt : NB - 1; };   // waves beyond the tile grid recompute the
+  auto b_tile = [&](int kt) { return (wk0 + kt < NB) ? wk0 + kt : NB - 1; };   // last tile (not stored)
+  // tile t out of buffer PAR = (t - t0) & 1; stages tile t + 1 from register set PAR, refills it with tile t + 3
+  auto tile_body = [&](auto par_c, int t) {
+    constexpr int PAR = decltype(par_c)::value;
+    const unsigned short* A_p = img0 + PAR * (2 * OPER);
+    const unsigned short* B_p = A_p + OPER;
+    unsigned short* nxt = img0 + (PAR ^ 1) * (2 * OPER);   // after the last tile this stages a re-read tile nobody consumes
+    // lane (i, kh) of k-step ks holds points 16 ks + 8 kh .. + 7 of feature row i: one 16-byte read
+    auto frag = [&](const unsigned short* base, int tile_idx, int ks) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (tile_idx * 32 + i) * WD_LD + 16 * ks + 8 * kh));
+    };
+    bf16x8 bf[2] = {frag(B_p, b_tile(0), 0), frag(B_p, b_tile(0), 1)};
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+      const bf16x8 af[2] = {frag(A_p, a_tile(mt), 0), frag(A_p, a_tile(mt), 1)};
+#pragma unroll
+      for (int kt = 0; kt < WK; ++kt) {
+        const bool last = mt == WM - 1 && kt == WK - 1;
+        const int g = mt * WK + kt;
+        bf16x8 bn[2];
+        acc[mt][kt] = MFMA_BF16(af[0], bf[0], acc[mt][kt]);
+        if (!last) {
+          const int nt = b_tile(kt + 1 < WK ? kt + 1 : 0);
+          bn[0] = frag(B_p, nt, 0); bn[1] = frag(B_p, nt, 1);
+        }
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) {
+          const int pc = g * PPG + j;
+          if (pc < 2 * NP) {
+            stage_piece(par_c, pc, nxt);
+            if (pc & 1) fetch_q(par_c, t + 3, pc >> 1);          // both operands' piece q are staged: refill its registers
+          }
+        }
+        acc[mt][kt] = MFMA_BF16(af[1], bf[1], acc[mt][kt]);
+        if (!last) { bf[0] = bn[0]; bf[1] = bn[1]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  };
+  int t = t0;
+  for (; t + 1 < t1; t += 2) {
+    tile_body(set0, t);
+    tile_body(set1, t + 1);
+  }
+  if (t < t1) tile_body(set0, t);      // odd tile count: the pairs consumed an even number, so the tail has parity 0
+
+  // ---- partials (same layout as the jobs above)
+  float* out = P.partial + (((size_t)blockIdx.z * P.B + img) * P.nchunk + chunk) * (size_t)(H * H);
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < WK; ++kt)
+      if (wm0 + mt < NB && wk0 + kt < NB)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          out[(size_t)row * H + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
+        }
+}
+
 // FiLM sums: the chain kernel left s0 = sum_p dtheta, s1 = sum_p dtheta * tape per (tile, layer, feature); this gathers
 // them per (layer, image, chunk of tiles) into film_partial -- with d theta / d f = W x + b = tape * inv + bias applied --
 // for film_reduce_kernel.  Inversion (inverse_render_double_semantic.py:324-350 optimises only the FiLM frequencies /
@@ -671,6 +861,16 @@ int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16 launch");
 }
 
+template <int H>
+int launch_sq_b16d(const WgradParams& p, int nz, hipStream_t st) {
+  auto kfn = siren_wgrad_sq_b16d_kernel<H>;
+  const size_t lds = (size_t)4 * H * WD_LD * sizeof(unsigned short);     // two [A | B] images
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
+  hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16-dump launch");
+}
+
 }  // namespace
 
 int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
@@ -748,7 +948,8 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   p.partial = sq; p.layer0 = 1;
   {
     PhaseScope ph(PH_WGRAD_SQ, st);
-    if ((rc = (m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))) return rc;
+    if ((rc = p.bf16_dump ? launch_sq_b16d<H>(p, L - 1, st)
+                          : ((m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st)))) return rc;
   }
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
@@ -810,6 +1011,7 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.B = B; p.L = m->L; p.n_geo = m->n_geo; p.n_lab = m->n_lab; p.C = m->C; p.H = m->H;
   p.P = P; p.tiles_per_image = (int)(P / 32);
   p.film16w = m->precision == FENERF_PREC_F16X3 ? bwd16w_film_unit((long long)B * P, P) : 0;
+  p.bf16_dump = use_bf16_dump(m, (long long)B * P);
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {

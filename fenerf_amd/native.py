@@ -25,16 +25,18 @@ def _f32(t, device):
 class NativeModel:
     """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
 
-    def __init__(self, sd, spec, device, precision="f32", differentiable=False):
+    def __init__(self, sd, spec, device, precision="f32", differentiable=False, wgrad_bf16_min_points=0):
         self.spec = dict(spec)
         self.precision = precision
         self.differentiable = bool(differentiable)
+        # > 0: AMP-class weight gradients (bf16 operands, include/fenerf.h FenerfModelDesc.wgrad_bf16_min_points); 0 = fp32 class
+        self.wgrad_bf16_min_points = int(wgrad_bf16_min_points) if precision == "f16x3" else 0
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % device)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, spec, precision, differentiable)
+            d, keep = _lib.make_desc(sd, spec, precision, differentiable, self.wgrad_bf16_min_points)
             _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
         self.C = spec["output_dim"]
         self.grid_shape = tuple(int(v) for v in sd["spatial_embeddings"].shape[2:]) if spec.get("grid_ch") else None   # (D, H, W)
@@ -45,7 +47,7 @@ class NativeModel:
     def update(self, sd):
         self.pack_generation += 1
         with torch.cuda.device(self.device):
-            d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable)
+            d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable, self.wgrad_bf16_min_points)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
 
     # ---- device-side packing (training): the fp32 streams are permutations of the parameters -------------------------

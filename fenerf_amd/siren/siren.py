@@ -89,6 +89,12 @@ class _NativeSiren(nn.Module):
     # "f16x3": error-compensated fp16 MFMA (3 MFMAs per product, fp32 accumulate) -- measured accuracy equal to the exact
     # kernel (rgb 3e-7 vs reference) and ~2.7x faster; "f32": exact fp32 MFMA (bitwise an fmaf chain).
     precision = "f16x3"
+    # Weight-gradient operands of the differentiable path: "f32" (default) = fp32-class gradients everywhere; "amp" = in backward
+    # chunks of >= AMP_MIN_POINTS points the chain kernel hands d theta and the layer inputs to the weight-gradient kernel as bf16 (one
+    # MFMA per product, fp32 accumulate) -- unbiased, ~1e-3 of a gradient entry's per-point noise floor: the class of the reference's
+    # own autocast training loop (train_double_latent_semantic.py:402-446), 13 % less step time.  Never the default.
+    grad_precision = "f32"
+    AMP_MIN_POINTS = 65536
 
     def _spec(self):
         H = self.hidden_dim
@@ -96,12 +102,20 @@ class _NativeSiren(nn.Module):
         return dict(kind=self.KIND, hidden_dim=H, n_geo=len(self.network), n_color=n_color, grid_ch=self.GRID_CH,
                     n_label_layers=self.N_LABEL_LAYERS, output_dim=self.output_dim)
 
+    @staticmethod
+    def _is_render_param(name):
+        """parameters the native SIREN kernels consume: everything but the mapping networks and (SPATIALSIRENGRID) the latent-grid
+        generator, which run in PyTorch per image"""
+        return "mapping_network" not in name and not name.startswith("grid_latent_network")
+
+    def _named_render_params(self):
+        return [(n, p) for n, p in self.named_parameters() if self._is_render_param(n)]
+
     def _render_params(self):
-        return [p for n, p in self.named_parameters() if "mapping_network" not in n]
+        return [p for _, p in self._named_render_params()]
 
     def _state_numpy(self):
-        return {n: p.detach().to("cpu", torch.float32).contiguous().numpy() for n, p in self.named_parameters()
-                if "mapping_network" not in n}
+        return {n: p.detach().to("cpu", torch.float32).contiguous().numpy() for n, p in self._named_render_params()}
 
     def native(self, device=None):
         """The FenerfModel for the current parameter values on `device` (re-packed lazily after updates)."""
@@ -114,7 +128,7 @@ class _NativeSiren(nn.Module):
             self.__dict__["_native_model"] = nat
         elif self.__dict__.get("_native_version") != ver:
             if params[0].is_cuda:      # weights already live on the GPU (training): re-pack there, not through the host
-                nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n},
+                nat.load_from_device(dict(self._named_render_params()),
                                      maybe_unchanged=self.__dict__.get("_native_packed") == ver)
             else:
                 nat.update(self._state_numpy())
@@ -128,14 +142,16 @@ class _NativeSiren(nn.Module):
         device = torch.device(device if device is not None else params[0].device)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_diff")
-        if nat is None or nat.device != device or nat.precision != self.precision:
-            nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision, differentiable=True)
+        amp = self.AMP_MIN_POINTS if (self.grad_precision == "amp" and self.precision == "f16x3") else 0
+        if nat is None or nat.device != device or nat.precision != self.precision or nat.wgrad_bf16_min_points != amp:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision, differentiable=True,
+                                     wgrad_bf16_min_points=amp)
             self.__dict__["_native_diff"] = nat
         elif self.__dict__.get("_native_diff_version") != ver:
             # weights live on the GPU during training: re-pack there (a gather), never through the host.  Same version counters as
             # at the last pack = a forced invalidation (mode switch, invalidate_native()): the content is compared first, so that a
             # train() / eval() round trip between a forward and its backward does not make the backward refuse (pack_generation)
-            nat.load_from_device({n: p for n, p in self.named_parameters() if "mapping_network" not in n},
+            nat.load_from_device(dict(self._named_render_params()),
                                  maybe_unchanged=self.__dict__.get("_native_diff_packed") == ver)
         self.__dict__["_native_diff_version"] = self.__dict__["_native_diff_packed"] = ver
         return nat
@@ -155,7 +171,7 @@ class _NativeSiren(nn.Module):
 
     def _roles(self, params):
         """`params` = tensors in _render_params() order -> which layer each one is."""
-        names = [n for n, _ in self.named_parameters() if "mapping_network" not in n]
+        names = [n for n, _ in self._named_render_params()]
         t = dict(zip(names, params))
         n_geo = len(self.network)
         if self.KIND == "spatial":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FENERF_ABI_VERSION 1
+#define FENERF_ABI_VERSION 2   /* 2: FenerfModelDesc.wgrad_bf16_min_points (round 3) */
 
 enum {
   FENERF_OK = 0,
@@ -80,6 +80,13 @@ typedef struct FenerfModelDesc {
                                3 MFMAs per product, fp32-class accuracy, ~2^-22 relative per product) */
   int32_t differentiable;   /* != 0: also keep the backward-chain weight stream resident (fenerf_siren_backward); either
                                precision: FENERF_PREC_F32 -> exact fp32 MFMA chain, FENERF_PREC_F16X3 -> bf16x3 chain */
+  int32_t wgrad_bf16_min_points; /* 0 (default): fp32-class weight gradients everywhere.  > 0 (FENERF_PREC_F16X3 models only):
+                               AMP-CLASS weight gradients -- in backward chunks of at least this many points fenerf_siren_backward writes
+                               d theta and the layer inputs as bf16 and fenerf_siren_param_grads multiplies them with ONE bf16 MFMA per
+                               product, fp32 accumulate (half the dump bytes, no tape re-read).  Rounding is unbiased; the error of a
+                               weight gradient is ~1e-3 of its per-point noise floor sqrt(sum_p (dtheta x)^2), whatever the point
+                               count -- the class of the reference's own autocast training (train_double_latent_semantic.py:402-446),
+                               not the fp32 class of the default.  FiLM / bias / grid / head gradients and dz are unaffected. */
 } FenerfModelDesc;
 
 typedef struct FenerfModel FenerfModel;

@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round-3 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r3.sh [tests] [newtests] [bench] [prof] [pmc] [probe] [saveexp] [gstep]'
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+Q="--no-cpu-baseline --no-gstep --no-f32 --no-sweep64"
+for what in "$@"; do
+case $what in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=10 2>&1 | tail -400 > gpurun_out/tests.log
+  echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+  echo "smoke exit: $?" >> gpurun_out/smoke.log
+  tail -n 5 gpurun_out/tests.log; tail -n 4 gpurun_out/smoke.log ;;
+newtests)   # the tests added this round, without -x, verbose: what they measure decides their asserts
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "${NEWTESTS:-all_rays or config5 or at_scale or rccl or ddp or repacked or chunked_backward or single_latent_generator or reference_checkpoint}" 2>&1 | tail -120 > gpurun_out/newtests.log
+  grep -E "parity|dist|passed|failed|Error|assert" gpurun_out/newtests.log | tail -60 ;;
+bench)
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1
+  echo "bench exit: $?" >> gpurun_out/bench.log
+  tail -2 gpurun_out/bench.log | cut -c1-6000 ;;
+benchq)
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-f32 --no-sweep64 --no-gstep-b6 > gpurun_out/benchq.log 2>&1
+  echo "benchq exit: $?" >> gpurun_out/benchq.log
+  tail -2 gpurun_out/benchq.log | cut -c1-6000 ;;
+prof)
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 3) > gpurun_out/prof.log 2>&1
+  echo "prof exit: $?" >> gpurun_out/prof.log
+  find gpurun_out/prof -type f ! -name "*stats*" -size +2M -delete
+  find gpurun_out/prof -name "*kernel_stats*" | head -1 | xargs head -12 | cut -c1-200 ;;
+pmc)
+  rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 3 --warmup 1 $Q) > gpurun_out/pmc/p$i.log 2>&1
+    echo "pass $i ($set) exit $?" >> gpurun_out/pmc/summary.txt
+  done
+  find gpurun_out/pmc -type f -size +4M -delete
+  python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc/siren_pmc_summary.txt 2>&1
+  cat gpurun_out/pmc/siren_pmc_summary.txt ;;
+probe)
+  ./tools/probe/tr_probe > gpurun_out/tr_probe.log 2>&1; head -40 gpurun_out/tr_probe.log ;;
+saveexp)   # tools/exp/save_store_variants.sh: forward-save with the tape stores removed / redirected / re-hinted
+  for v in "" S_L2 S_NOSTORE S_TEMPORAL S_WAIT2 ""; do
+    lib=fenerf_amd/libfenerf_hip.so; [ -n "$v" ] && lib=fenerf_amd/libexp_$v.so
+    [ -f $lib ] || continue
+    echo -n "variant ${v:-shipped}: "
+    FENERF_LIB=$PWD/$lib timeout 200 python tools/time_bwd.py 196608 2>&1 | grep -E "forward|chain" | tr '\n' ' '; echo
+  done > gpurun_out/saveexp.log 2>&1
+  cat gpurun_out/saveexp.log ;;
+gstep)
+  timeout 600 python tools/chunk_sweep.py > gpurun_out/chunk_sweep.log 2>&1; cat gpurun_out/chunk_sweep.log ;;
+esac
+done
+exit 0
