@@ -37,6 +37,11 @@ class FenerfModelDesc(C.Structure):
     ]
 
 
+class FenerfLocalMapDesc(C.Structure):
+    _fields_ = [("latent_dim", C.c_int32), ("map_hidden", C.c_int32), ("w0", _fp), ("b0", _fp), ("w1", _fp), ("b1", _fp),
+                ("w2", _fp), ("b2", _fp)]
+
+
 class FenerfSirenGrads(C.Structure):
     _fields_ = [("geo_w", _vp * MAX_GEO), ("geo_b", _vp * MAX_GEO), ("color_w", _vp * MAX_COLOR), ("color_b", _vp * MAX_COLOR),
                 ("head_w", _vp), ("head_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp),
@@ -84,6 +89,11 @@ _SIGS = {
     "fenerf_siren_forward_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i] + [_vp] * 7),
     "fenerf_ray_setup": (_i, [_i, _i, _i, C.c_float, C.c_float, C.c_float] + [_vp] * 9),
     "fenerf_siren_time_rays": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_float), _vp]),
+    "fenerf_local_model_create": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(FenerfLocalMapDesc), C.POINTER(_vp)]),
+    "fenerf_local_model_destroy": (None, [_vp]),
+    "fenerf_siren_forward_local": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "fenerf_pack_local_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(FenerfLocalMapDesc), C.POINTER(_fp), C.POINTER(_sz),
+                               C.POINTER(_fp), C.POINTER(_sz)]),
     "fenerf_siren_backward_stream_bytes": (_i, [_vp, _i64, C.POINTER(C.c_double)]),
     "fenerf_siren_clock_probe": (_i, [_vp, _i, _i, _i] + [_vp] * 9 + [_i, C.POINTER(C.c_double), _vp]),
     "fenerf_siren_executed_flop_per_point": (C.c_double, [_vp]),
@@ -178,6 +188,38 @@ def make_desc(sd, spec, precision="f32", differentiable=False, wgrad_bf16_min_po
         d.grid_d, d.grid_h, d.grid_w = int(g.shape[2]), int(g.shape[3]), int(g.shape[4])
         d.grid = P("spatial_embeddings")
     return d, keep
+
+
+def make_local_map_desc(mp):
+    """mp = {'0.weight', '0.bias', '2.weight', '2.bias', '4.weight', '4.bias'} of CustomMappingNetwork(32, 256, 2 L H, n_blocks=1).network
+    (numpy) -> (FenerfLocalMapDesc, keepalive)"""
+    keep = []
+
+    def P(name):
+        a, p = _as_f32(mp[name])
+        keep.append(a)
+        return p
+
+    d = FenerfLocalMapDesc()
+    d.map_hidden, d.latent_dim = (int(v) for v in np.asarray(mp["0.weight"]).shape)
+    d.w0, d.b0, d.w1, d.b1, d.w2, d.b2 = P("0.weight"), P("0.bias"), P("2.weight"), P("2.bias"), P("4.weight"), P("4.bias")
+    return d, keep
+
+
+def pack_local_host(sd, spec, mp):
+    """(blob, consts) numpy copies of the SPATIALSIRENGRID stream (mapping network + SIREN interleaved; CPU only, layout tests)."""
+    d, keep = make_desc(sd, spec, "f32")
+    md, keep2 = make_local_map_desc(mp)
+    blob, consts = _fp(), _fp()
+    nb, nc = _sz(), _sz()
+    check(lib().fenerf_pack_local_host(C.byref(d), C.byref(md), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc)))
+    try:
+        b = np.ctypeslib.as_array(blob, shape=(nb.value,)).copy()
+        c = np.ctypeslib.as_array(consts, shape=(nc.value,)).copy()
+    finally:
+        lib().fenerf_free_host(blob)
+        lib().fenerf_free_host(consts)
+    return b, c
 
 
 def pack_index_map_f16(sd, spec):

@@ -15,6 +15,12 @@ def install_aliases():
     sys.modules.setdefault("generators.math_utils_torch", generators.math_utils_torch)
     sys.modules.setdefault("siren", siren)
     sys.modules.setdefault("siren.siren", siren.siren)
+    # pickled SPATIALSIRENGRID modules embed siren.latent_grid.StyleGenerator2D and the siren.layers classes it is built from
+    from .siren import latent_grid
+    sys.modules.setdefault("siren.latent_grid", latent_grid)
+    sys.modules.setdefault("siren.layers", latent_grid)
+    sys.modules.setdefault("siren.op", latent_grid)
+    sys.modules.setdefault("siren.op.native_ops", latent_grid)
     if "torch_ema" not in sys.modules and importlib.util.find_spec("torch_ema") is None:
         from . import ema
         sys.modules["torch_ema"] = ema

@@ -105,6 +105,19 @@ static int upload_model(FenerfModel* m, const FenerfModelDesc* d, hipStream_t st
   m->n_stream = blob.size(); m->n_consts = consts.size();
   HIP_TRY(hipMemcpyAsync(m->d_stream, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(m->d_consts, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  if (d->precision == FENERF_PREC_F16X3) {   // the exact-fp32 stream too: fenerf_siren_forward_pointwise (per-point FiLM blocks)
+    std::vector<float> blob32, consts32;
+    rc = pack_weights(d, blob32, consts32, err);
+    if (rc) return fail(rc, err);
+    if (allocate) {
+      HIP_TRY(hipMalloc((void**)&m->d_stream32, blob32.size() * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&m->d_consts32, consts32.size() * sizeof(float)));
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_stream32, blob32.data(), blob32.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(m->d_consts32, consts32.data(), consts32.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // host vectors go out of scope
+    m->stream32_valid = 1;
+  }
   std::vector<float> bwd;
   if (m->differentiable) {
     rc = d->precision == FENERF_PREC_F16X3 ? pack_weights_bwd16(d, bwd, err, nullptr) : pack_weights_bwd(d, bwd, err);
@@ -223,6 +236,7 @@ extern "C" int fenerf_model_load_packed(FenerfModel* m, const float* stream_dev,
   if (!stream_dev || !consts_dev || n_stream != want_s || n_consts != want_c) return fail(FENERF_E_INVALID, "packed stream / consts size mismatch");
   if (m->differentiable && (!bwd_dev || n_bwd != want_b)) return fail(FENERF_E_INVALID, "backward stream size mismatch");
   hipStream_t st = (hipStream_t)stream;
+  m->stream32_valid = 0;
   HIP_TRY(hipMemcpyAsync(m->d_stream, stream_dev, n_stream * sizeof(float), hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(m->d_consts, consts_dev, n_consts * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (m->differentiable) HIP_TRY(hipMemcpyAsync(m->d_bwd_stream, bwd_dev, n_bwd * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -251,6 +265,7 @@ extern "C" int fenerf_model_repack(FenerfModel* m, const float* flat_dev, size_t
       return fail(FENERF_E_INVALID, "repack maps: row table missing or too long");
     if (!m->d_row_scale) HIP_TRY(hipMalloc((void**)&m->d_row_scale, 2 * cap * sizeof(float)));
   }
+  m->stream32_valid = 0;
   int rc = [&] { PhaseScope ph(PH_REPACK, stream); return launch_repack(m, flat_dev, r, m->d_row_scale, m->d_row_scale ? m->d_row_scale + cap : nullptr, stream); }();
   if (rc) return rc;
   if (grid_dev) {
@@ -275,6 +290,8 @@ extern "C" int fenerf_model_export_packed(const FenerfModel* m, float* stream_de
 extern "C" void fenerf_model_destroy(FenerfModel* m) {
   if (!m) return;
   if (m->d_row_scale) (void)hipFree(m->d_row_scale);
+  if (m->d_stream32) (void)hipFree(m->d_stream32);
+  if (m->d_consts32) (void)hipFree(m->d_consts32);
   if (m->d_stream) (void)hipFree(m->d_stream);
   if (m->d_consts) (void)hipFree(m->d_consts);
   if (m->d_grid) (void)hipFree(m->d_grid);

@@ -31,6 +31,8 @@ int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_bwd(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err);
 int pack_weights_bwd16(const FenerfModelDesc* d, std::vector<float>& blob, std::string& err, std::vector<int32_t>* index);
+int pack_local_weights(const FenerfModelDesc* d, const FenerfLocalMapDesc* mp, std::vector<float>& blob, std::vector<float>& consts,
+                       std::string& err);   // SPATIALSIRENGRID: per-point mapping network + SIREN in one stream (fenerf_siren_local.hip)
 
 }  // namespace fenerf
 
@@ -51,6 +53,11 @@ struct FenerfModel {
   float* d_bwd_stream;      // [rgb-head^T entries | backward ring] * 256 floats, or nullptr
   float* d_row_scale;       // fenerf_model_repack scratch: [2][L*H + 64] row scales (forward | backward), lazily allocated
   size_t n_stream, n_consts, n_bwd;   // floats resident in d_stream / d_consts / d_bwd_stream
+  // FENERF_PREC_F16X3 models: the exact-fp32 stream / consts too (host-packed at create / update), for fenerf_siren_forward_pointwise --
+  // per-point FiLM blocks are read per lane by the fp32 kernel; a device-side re-pack does not refresh them (stream32_valid = 0)
+  float* d_stream32;
+  float* d_consts32;
+  int stream32_valid;
 };
 
 namespace fenerf {
@@ -126,8 +133,9 @@ struct CompositeParams {
 };
 
 int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
-                     float* fp, float* pp, void* stream);
+                     float* fp, float* pp, void* stream, bool for_f32_kernel = false);   // for_f32_kernel: biases of d_consts32, no GEMM result scale
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
+int launch_siren_f32(const FenerfModel* m, const SirenParams& p, void* stream); // the exact-fp32 kernel on whatever stream `p` points at
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream);  // FENERF_PREC_F16X3 models: bf16x3 chain on 16-point waves (fenerf_siren_bwd16w.hip)
 bool use_bf16_dump(const FenerfModel* m, long long total_points);   // the dump format of a backward chunk (fenerf_layout.h "bf16 dump"); chain and weight-gradient launches ask the same question

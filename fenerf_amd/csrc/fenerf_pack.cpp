@@ -172,6 +172,90 @@ int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector
 }
 
 // ------------------------------------------------------------------------------------------------
+// SPATIALSIRENGRID in one kernel (fenerf_siren_local.hip): the per-point mapping network and the SIREN interleaved in ONE ring
+// stream, in the kernel's consumption order (every body padded to whole ring revolutions):
+//   M0: MH/32 bodies of network.0 [MH][32], k-steps (latent 2 s | latent 2 s + 1)
+//   M1: MH/32 bodies of network.2 [MH][MH] over h1 in MFMA C/D order
+//   per FiLM layer l and n-block nb: F = network.4 rows l H + 32 nb .. (frequencies), P = rows L H + l H + 32 nb .. (phase shifts), both
+//       over h2; then Z = the layer's own rows over its input (layer 0: (x | y), (z | 0); first colour layer: x then (dir.x | dir.y), (dir.z | 0))
+//   sigma head (one body, row 0) between the trunk and the colour layers; rgb head (rows 0..2) last; tail pad.
+// consts: b0 [MH] | b1 [MH] | b2 [2 L H] | FiLM-layer biases [L H] | sigma bias [4] | rgb bias [4].
+// ------------------------------------------------------------------------------------------------
+int pack_local_weights(const FenerfModelDesc* d, const FenerfLocalMapDesc* mp, std::vector<float>& blob, std::vector<float>& consts,
+                       std::string& err) {
+  int rc = validate_desc(d, err);
+  if (rc) return rc;
+  if (!mp) { err = "map desc is NULL"; return FENERF_E_INVALID; }
+  if (mp->latent_dim != 32 || mp->map_hidden != 256) { err = "local mapping network must be 32 -> 256 -> 256 -> 2 L H (siren.py:440)"; return FENERF_E_UNSUPPORTED; }
+  if (d->grid_ch != 0 || d->n_label_layers != 0 || d->output_dim != 4) { err = "per-point modulation is defined for the rgb + sigma model without feature grid (SPATIALSIRENGRID)"; return FENERF_E_UNSUPPORTED; }
+  if (!mp->w0 || !mp->b0 || !mp->w1 || !mp->b1 || !mp->w2 || !mp->b2) { err = "map desc: NULL weight pointer"; return FENERF_E_INVALID; }
+  const int H = d->hidden_dim, MH = 256, ZL = 32, NB = H / 32, L = d->n_geo + d->n_color;
+  const int KGM = MH / 8, KGXP = pad_pf(H / 8), KGCP = pad_pf(H / 8 + 1);
+  auto ksteps = [&](int width, int col_off) {
+    std::vector<KStep> ks(width / 2);
+    for (int s = 0; s < width / 2; ++s) ks[s] = {col_off + feat_of(s, 0), col_off + feat_of(s, 1)};
+    return ks;
+  };
+  blob.clear();
+  {
+    auto W = to_f64(mp->w0, (size_t)MH * ZL);
+    std::vector<KStep> ks(ZL / 2);
+    for (int s = 0; s < ZL / 2; ++s) ks[s] = {2 * s, 2 * s + 1};
+    for (int nb = 0; nb < MH / 32; ++nb) emit_body(blob, W.data(), MH, ZL, nb * 32, ks, FENERF_PF);
+  }
+  {
+    auto W = to_f64(mp->w1, (size_t)MH * MH);
+    const auto ks = ksteps(MH, 0);
+    for (int nb = 0; nb < MH / 32; ++nb) emit_body(blob, W.data(), MH, MH, nb * 32, ks, KGM);
+  }
+  const auto W2 = to_f64(mp->w2, (size_t)2 * L * H * MH);
+  const auto ksm = ksteps(MH, 0);
+  auto film_bodies = [&](int l, int nb) {
+    emit_body(blob, W2.data(), 2 * L * H, MH, l * H + nb * 32, ksm, KGM);            // frequencies of (l, nb)
+    emit_body(blob, W2.data(), 2 * L * H, MH, L * H + l * H + nb * 32, ksm, KGM);    // phase shifts
+  };
+  // rows r0 .. r0 + 31 of a matrix whose row count is r0 + 32 at most: emit_body zero-fills rows >= nrows, so pass the true count
+  {
+    auto W = to_f64(d->geo_w[0], (size_t)H * 3);
+    const std::vector<KStep> ks = {{0, 1}, {2, -1}};
+    for (int nb = 0; nb < NB; ++nb) { film_bodies(0, nb); emit_body(blob, W.data(), H, 3, nb * 32, ks, FENERF_PF); }
+  }
+  for (int l = 1; l < d->n_geo; ++l) {
+    auto W = to_f64(d->geo_w[l], (size_t)H * H);
+    const auto ks = ksteps(H, 0);
+    for (int nb = 0; nb < NB; ++nb) { film_bodies(l, nb); emit_body(blob, W.data(), H, H, nb * 32, ks, KGXP); }
+  }
+  {
+    std::vector<double> Wh((size_t)32 * H, 0.0);
+    for (int x = 0; x < H; ++x) Wh[x] = d->sigma_w[x];
+    emit_body(blob, Wh.data(), 32, H, 0, ksteps(H, 0), KGXP);
+  }
+  for (int c = 0; c < d->n_color; ++c) {
+    const int cin = c == 0 ? 3 + H : H;
+    auto W = to_f64(d->color_w[c], (size_t)H * cin);
+    auto ks = ksteps(H, c == 0 ? 3 : 0);
+    if (c == 0) { ks.push_back({0, 1}); ks.push_back({2, -1}); }
+    for (int nb = 0; nb < NB; ++nb) { film_bodies(d->n_geo + c, nb); emit_body(blob, W.data(), H, cin, nb * 32, ks, c == 0 ? KGCP : KGXP); }
+  }
+  {
+    auto W = to_f64(d->rgb_w, (size_t)3 * H);
+    emit_body(blob, W.data(), 3, H, 0, ksteps(H, 0), KGXP);
+  }
+  blob.insert(blob.end(), (size_t)FENERF_PF * 256, 0.f);
+  consts.assign((size_t)2 * MH + (size_t)3 * L * H + 8, 0.f);
+  memcpy(&consts[0], mp->b0, sizeof(float) * MH);
+  memcpy(&consts[MH], mp->b1, sizeof(float) * MH);
+  memcpy(&consts[2 * MH], mp->b2, sizeof(float) * 2 * L * H);
+  float* fb = &consts[(size_t)2 * MH + (size_t)2 * L * H];
+  for (int l = 0; l < d->n_geo; ++l) memcpy(fb + (size_t)l * H, d->geo_b[l], sizeof(float) * H);
+  for (int c = 0; c < d->n_color; ++c) memcpy(fb + (size_t)(d->n_geo + c) * H, d->color_b[c], sizeof(float) * H);
+  float* hb = fb + (size_t)L * H;
+  hb[0] = d->sigma_b[0];
+  for (int i = 0; i < 3; ++i) hb[4 + i] = d->rgb_b[i];
+  return FENERF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // f16x3 packing (fenerf_layout.h "f16x3 mode")
 // ------------------------------------------------------------------------------------------------
 struct KStep16 { int col[2][8]; };   // source column per lane-half and slot, -1 = zero
@@ -526,6 +610,23 @@ extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blo
   std::string err;
   int rc = (desc && desc->precision == FENERF_PREC_F16X3) ? fenerf::pack_weights_f16(desc, b, c, err)
                                                           : fenerf::pack_weights(desc, b, c, err);
+  if (rc) { fenerf::set_error(err); return rc; }
+  if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
+  *blob = (float*)malloc(b.size() * sizeof(float));
+  *consts = (float*)malloc(c.size() * sizeof(float));
+  if (!*blob || !*consts) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  memcpy(*blob, b.data(), b.size() * sizeof(float));
+  memcpy(*consts, c.data(), c.size() * sizeof(float));
+  *n_floats = b.size();
+  *n_consts = c.size();
+  return FENERF_OK;
+}
+
+extern "C" int fenerf_pack_local_host(const FenerfModelDesc* desc, const FenerfLocalMapDesc* map, float** blob, size_t* n_floats,
+                                      float** consts, size_t* n_consts) {
+  std::vector<float> b, c;
+  std::string err;
+  int rc = fenerf::pack_local_weights(desc, map, b, c, err);
   if (rc) { fenerf::set_error(err); return rc; }
   if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
   *blob = (float*)malloc(b.size() * sizeof(float));

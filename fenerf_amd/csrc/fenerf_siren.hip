@@ -322,12 +322,13 @@ static int hip_fail(hipError_t e, const char* what) {
 }
 
 int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
-                     float* fp, float* pp, void* stream) {
+                     float* fp, float* pp, void* stream, bool for_f32_kernel) {
   const long long total = (long long)B * m->L * m->H;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  const bool f16 = m->precision == FENERF_PREC_F16X3 && !for_f32_kernel;
+  const float* cst = (for_f32_kernel && m->precision == FENERF_PREC_F16X3) ? m->d_consts32 : m->d_consts;
   hipLaunchKernelGGL(film_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, m->H, m->n_geo, m->n_color, fg,
-                     pg, fa, pa, m->d_consts + CONST_FILM_BIAS,
-                     m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr, fp, pp);
+                     pg, fa, pa, cst + CONST_FILM_BIAS, f16 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr, fp, pp);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail(e, "film_prep launch");
 }
@@ -372,6 +373,11 @@ static int launch_siren_h(const FenerfModel* m, const SirenParams& p, void* stre
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream) {
   if (p.P <= 0) return FENERF_OK;
   if (m->precision == FENERF_PREC_F16X3) return launch_siren16w(m, p, stream);
+  return launch_siren_f32(m, p, stream);
+}
+
+int launch_siren_f32(const FenerfModel* m, const SirenParams& p, void* stream) {
+  if (p.P <= 0) return FENERF_OK;
   switch (m->H) {
     case 32: return launch_siren_h<32>(m, p, stream);
     case 64: return launch_siren_h<64>(m, p, stream);

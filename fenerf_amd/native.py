@@ -334,10 +334,17 @@ class NativeModel:
         points = _f32(points, dev)
         ray_dirs = _f32(ray_dirs, dev) if ray_dirs is not None else None
         out = torch.empty((B, P, self.C), dtype=torch.float32, device=dev)
+        # the FiLM pre-pass writes 2 L H floats per point (18 KB at H = 256): walk the points in slabs so that the scratch stays
+        # below ~300 MB whatever P is
+        slab = max(32, (1 << 28) // (8 * (ng + nc) * H) // 32 * 32)
         with torch.cuda.device(dev):
-            ws = self._workspace("film_pw", _lib.lib().fenerf_film_workspace_bytes_pointwise(self._h, B, P))
-            _lib.check(_lib.lib().fenerf_siren_forward_pointwise(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg),
-                                                                 _ptr(fa), _ptr(pa), _ptr(out), C.c_void_p(ws.data_ptr()), _stream()))
+            for b in range(B):
+                for s in range(0, P, slab):
+                    n = min(slab, P - s)
+                    ws = self._workspace("film_pw", _lib.lib().fenerf_film_workspace_bytes_pointwise(self._h, 1, n))
+                    sl = lambda t: _ptr(t[b, s:s + n].contiguous()) if t is not None else None
+                    _lib.check(_lib.lib().fenerf_siren_forward_pointwise(self._h, 1, n, sl(points), sl(ray_dirs), sl(fg), sl(pg), sl(fa),
+                                                                         sl(pa), _ptr(out[b, s:s + n]), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
     def tape_floats(self, total_points):
@@ -530,6 +537,46 @@ class NativeModel:
                                                _ptr(weights), _ptr(wsum), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
                                                _stream()))
         return rgb, depth, weights, wsum
+
+
+class NativeLocalModel:
+    """Owns a FenerfLocalModel*: SPATIALSIRENGRID's SIREN and its per-point mapping network packed into one fp32 stream; forward()
+    evaluates both in one launch (fenerf_siren_forward_local).  sd / spec as NativeModel, mp = the mapping network's six tensors."""
+
+    def __init__(self, sd, spec, mp, device):
+        self.spec = dict(spec)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % device)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            d, keep = _lib.make_desc(sd, spec, "f32")
+            md, keep2 = _lib.make_local_map_desc(mp)
+            _lib.check(_lib.lib().fenerf_local_model_create(C.byref(d), C.byref(md), C.byref(self._h)))
+
+    def forward(self, points, ray_dirs, latents):
+        """points [B,P,3] local coordinates, ray_dirs [B,P,3] or None, latents [B,P,32] -> [B,P,4] = [rgb | sigma]"""
+        B, P = points.shape[0], points.shape[1]
+        dev = self.device
+        points, latents = _f32(points, dev), _f32(latents, dev)
+        ray_dirs = _f32(ray_dirs, dev) if ray_dirs is not None else None
+        if tuple(latents.shape) != (B, P, 32):
+            raise ValueError(f"local latents of shape {tuple(latents.shape)}, expected {(B, P, 32)}")
+        out = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().fenerf_siren_forward_local(self._h, B * P, _ptr(points), _ptr(ray_dirs), _ptr(latents), _ptr(out), _stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fenerf_local_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class phase_timing:

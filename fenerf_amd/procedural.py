@@ -144,3 +144,21 @@ def checksum(sd) -> float:
         w = np.cos(np.arange(a.size, dtype=np.float64) * 0.37 + (zlib.crc32(k.encode()) % 1000))
         tot += float(np.dot(a, w))
     return tot
+
+
+def latent_grid_state(shapes, seed=0):
+    """Procedural parameters for the StyleGAN2-style latent-grid generator of SPATIALSIRENGRID (siren/latent_grid.py): `shapes` =
+    {parameter name: shape} of its state dict (buffers excluded).  Magnitudes follow the reference initialisers (layers.py): N(0, 1)
+    weights (the lr_mul = 0.01 mapping layers store weight / lr_mul), modulation biases around 1, small activation / output biases."""
+    out = {}
+    for name, shape in shapes.items():
+        tag = "slg." + name
+        if name.endswith("modulation.bias"):
+            out[name] = (1.0 + normal(tag, shape, 0.1, seed)).astype(np.float32)
+        elif name.endswith("bias"):
+            out[name] = normal(tag, shape, 0.1, seed)
+        elif name.startswith("mapping_network") and name.endswith("weight"):
+            out[name] = normal(tag, shape, 100.0, seed)
+        else:
+            out[name] = normal(tag, shape, 1.0, seed)
+    return out

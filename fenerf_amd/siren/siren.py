@@ -309,32 +309,77 @@ class SPATIALSIRENBASELINE(_NativeSiren):
 
 class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
     """SPATIALSIRENBASELINE whose FiLM parameters are PER SAMPLE POINT (siren.py:413-518): a 2-D grid of local latents
-    (32 channels, from the reference's StyleGAN2-style `grid_latent_network`, siren/latent_grid.py) is sampled bilinearly at
-    every point's (x, z), a one-block mapping network turns the 32-d local latent into that point's frequencies / phase shifts,
-    and the SIREN is evaluated in local cell coordinates.  The SIREN evaluation with per-point FiLM parameters is the native
-    part (fenerf_siren_forward_pointwise, exact-fp32 kernel); local-latent sampling, mapping network and local coordinates are
-    the torch statements of the reference's lines.  The StyleGAN2 grid generator itself is outside the hot path:
-    it is not built, `forward(input, z, ...)` says so, and `forward_with_latent_grid` takes its output as an input."""
-    precision = "f32"      # per-point FiLM blocks are read per lane by the exact kernel
+    (32 channels, from the StyleGAN2-style `grid_latent_network`, siren/latent_grid.py -> fenerf_amd/siren/latent_grid.py) is sampled
+    bilinearly at every point's (x, z), a one-block mapping network turns the 32-d local latent into that point's frequencies / phase
+    shifts, and the SIREN is evaluated in local cell coordinates.
+    forward(input, z, ray_directions) is the reference's: latent grid (PyTorch, once per image) -> local latents and local
+    coordinates (torch statements of :479-518, 128 B per point) -> ONE native launch that evaluates the per-point mapping network AND
+    the FiLM-SIREN (fenerf_siren_forward_local: the 18 KB of FiLM parameters per point never exist in memory).
+    forward_with_frequencies_phase_shifts with explicit per-point [B, P, 9H] parameters (the reference's signature, :464) runs
+    fenerf_siren_forward_pointwise on the caller's tensors.  Both are exact-fp32 kernels whatever `precision` says -- fp32-class
+    results is what "f16x3" promises too."""
 
     def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
         super().__init__(input_dim=input_dim, z_dim=z_dim, hidden_dim=hidden_dim, output_dim=output_dim, device=device)
+        from .latent_grid import StyleGenerator2D
         self.local_coordinates = True
         self.mapping_network = CustomMappingNetwork(32, 256, (len(self.network) + 1) * hidden_dim * 2, n_blocks=1)   # :440
+        self.grid_latent_network = StyleGenerator2D(out_res=32, out_ch=32, z_dim=z_dim, ch_mul=1, ch_max=256, skip_conn=False)   # :442
 
     def forward(self, input, z, ray_directions, **kwargs):
-        raise NotImplementedError("SPATIALSIRENGRID.forward needs the reference's StyleGenerator2D latent-grid generator "
-                                  "(siren/latent_grid.py), which this package does not build; evaluate it elsewhere and call "
-                                  "forward_with_latent_grid(input, latent_grid, ray_directions)")
+        return self.forward_with_latent_grid(input, self.grid_latent_network(z), ray_directions, **kwargs)   # :453
 
     def forward_with_latent_grid(self, input, latent_grid, ray_directions, **kwargs):
         """The body of the reference's forward after `latent_grid = self.grid_latent_network(z)` (siren.py:453-463)."""
         input_grid = self.gridwarper(input)
         sampled_latent = self.sample_local_latents(latent_grid, input_grid)
-        frequencies, phase_shifts = self.mapping_network(sampled_latent)
         if self.local_coordinates:
             input = self.get_local_coordinates(global_coords=input, local_grid_length=32, preserve_y=False)
-        return self.forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
+        if self._wants_grad(input, ray_directions, sampled_latent):
+            raise NotImplementedError("fenerf_amd: per-point FiLM modulation is forward-only (the reference never trains this variant: "
+                                      "it is in no curriculum and its generator-level methods cannot run, SURVEY 0.5)")
+        return self.native_local(input.device).forward(input, ray_directions, sampled_latent)
+
+    def native_local(self, device=None):
+        """The FenerfLocalModel (SIREN + per-point mapping network in one packed fp32 stream) for the current parameter values."""
+        params = [p for n, p in self.named_parameters() if not n.startswith("grid_latent_network")]
+        device = torch.device(device if device is not None else params[0].device)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        nat = self.__dict__.get("_native_local")
+        if nat is None or nat.device != device or self.__dict__.get("_native_local_version") != ver:
+            if nat is not None:
+                nat.close()
+            mp = {n[len("mapping_network.network."):]: p.detach().to("cpu", torch.float32).contiguous().numpy()
+                  for n, p in self.named_parameters() if n.startswith("mapping_network.network.")}
+            nat = native.NativeLocalModel(self._state_numpy(), self._spec(), mp, device)
+            self.__dict__["_native_local"] = nat
+            self.__dict__["_native_local_version"] = ver
+        return nat
+
+    def native(self, device=None):
+        """explicit per-point FiLM tensors run on the exact-fp32 kernel (fenerf_siren_forward_pointwise)"""
+        params = self._render_params()
+        device = torch.device(device if device is not None else params[0].device)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        nat = self.__dict__.get("_native_pw")
+        if nat is None or nat.device != device:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, "f32")
+            self.__dict__["_native_pw"] = nat
+        elif self.__dict__.get("_native_pw_version") != ver:
+            nat.update(self._state_numpy())
+        self.__dict__["_native_pw_version"] = ver
+        return nat
+
+    def invalidate_native(self):
+        super().invalidate_native()
+        self.__dict__.pop("_native_local_version", None)
+        self.__dict__.pop("_native_pw_version", None)
+
+    def __getstate__(self):
+        st = super().__getstate__()
+        for k in ("_native_local", "_native_local_version", "_native_pw", "_native_pw_version"):
+            st.pop(k, None)
+        return st
 
     def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
         """frequencies / phase_shifts [B, P, 9H]: one FiLM block per point (siren.py:464-477); [B, 9H] behaves like the parent."""

@@ -177,6 +177,31 @@ int fenerf_siren_forward_pointwise(const FenerfModel* m, int B, int64_t P, const
                                    const float* freq_geo, const float* phase_geo, const float* freq_app,
                                    const float* phase_app, float* out, void* film_ws, void* stream);
 
+/* SPATIALSIRENGRID (siren.py:413-518) as ONE launch: per-point mapping network + FiLM-SIREN.
+ * replaces: self.mapping_network(sampled_latent) + forward_with_frequencies_phase_shifts with per-point parameters (siren.py:455-477).
+ * FenerfLocalMapDesc = the weights of CustomMappingNetwork(32, 256, 2 L H, n_blocks = 1) (siren.py:440), [host], nn.Linear layout:
+ * frequencies are rows [0, L H) of w2, phase shifts rows [L H, 2 L H) (CustomMappingNetwork.forward, siren.py:98-102), FiLM layer l =
+ * rows l H .. (l + 1) H of either half, the colour layer last (siren.py:468-475).  `siren` must describe the rgb + sigma model without
+ * feature grid (grid_ch 0, n_label_layers 0, output_dim 4); its precision / differentiable fields are ignored: the kernel is exact fp32
+ * (v_mfma_f32_32x32x2_f32), forward only.  fenerf_siren_forward_local: points [P,3] (the caller's LOCAL cell coordinates, :458-461;
+ * the kernel applies box_scale like :466), ray_dirs [P,3] or NULL (lock), latents [P,32] (sample_local_latents, :479-499) -> out [P,4]
+ * = [rgb | sigma].  Per point 152 B in, 16 B out; frequencies / phase shifts never exist in memory. */
+typedef struct FenerfLocalMapDesc {
+  int32_t latent_dim;                 /* 32 */
+  int32_t map_hidden;                 /* 256 */
+  const float* w0; const float* b0;   /* mapping_network.network.0: [map_hidden][latent_dim], [map_hidden] */
+  const float* w1; const float* b1;   /* mapping_network.network.2: [map_hidden][map_hidden] */
+  const float* w2; const float* b2;   /* mapping_network.network.4: [2 L H][map_hidden], [2 L H] */
+} FenerfLocalMapDesc;
+typedef struct FenerfLocalModel FenerfLocalModel;
+int fenerf_local_model_create(const FenerfModelDesc* siren, const FenerfLocalMapDesc* map, FenerfLocalModel** out);
+/* the packed stream / constants fenerf_local_model_create uploads (host side, no GPU needed: layout tests); free with fenerf_free_host */
+int fenerf_pack_local_host(const FenerfModelDesc* siren, const FenerfLocalMapDesc* map, float** blob, size_t* n_floats, float** consts,
+                           size_t* n_consts);
+void fenerf_local_model_destroy(FenerfLocalModel* m);
+int fenerf_siren_forward_local(const FenerfLocalModel* m, int64_t total_points, const float* points, const float* ray_dirs,
+                               const float* latents, float* out, void* stream);
+
 /* replaces: <siren>.forward_with_frequencies_phase_shifts  (siren.py:1509-1530 / :1210-1229 / :227-244),
  *           incl. UniformBoxWarp (:181-187), sample_from_3dgrid (:314-330) and FiLMLayer (:113-123).
  * points [B,P,3], ray_dirs [B,P,3] (NULL = lock_view_dependence, i.e. (0,0,-1): generators.py:474-476),

@@ -52,3 +52,36 @@ def test_reference_itself_rejects_hierarchical_resampling_of_fewer_than_three_sa
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split("\n")[:3] == ["raises 1", "raises 2", "three (1, 3)"], r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference only exists in the build container")
+def test_reference_spatial_siren_grid_state_dict_and_pickle_load_into_this_package(tmp_path):
+    """a reference SPATIALSIRENGRID -- its StyleGenerator2D latent-grid generator included -- (a) loads into this package's
+    class with load_state_dict(strict=True) and then produces the reference's latent grid, and (b) unpickles, as a whole nn.Module (the
+    reference's checkpoint format), through fenerf_amd.compat's import aliases.  The reference runs in one child process (it writes
+    the state dict, the pickle and its own latent grid), this package in another: their module names collide."""
+    ref_code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import ref_import\n"
+                "siren_mod = ref_import.import_reference()[0]\n"
+                "torch.manual_seed(5)\n"
+                "ref = siren_mod.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=32, output_dim=4)\n"
+                "z = torch.randn(2, 16)\n"
+                "with torch.no_grad(): lat = ref.grid_latent_network(z)\n"
+                "torch.save({'sd': ref.state_dict(), 'z': z, 'lat': lat}, %r)\n"
+                "torch.save(ref, %r)\n") % (os.path.join(ROOT, "tools"), ROOT, str(tmp_path / "sd.pth"), str(tmp_path / "module.pth"))
+    r = subprocess.run([sys.executable, "-c", ref_code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    mine = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from fenerf_amd import compat; compat.install_aliases()\n"
+            "from fenerf_amd.siren import siren as S, latent_grid as LG\n"
+            "d = torch.load(%r, weights_only=False)\n"
+            "mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=32, output_dim=4)\n"
+            "mod.load_state_dict(d['sd'], strict=True)\n"
+            "with torch.no_grad(): e1 = (mod.grid_latent_network(d['z']) - d['lat']).abs().max().item() / d['lat'].abs().max().item()\n"
+            "pk = torch.load(%r, weights_only=False)\n"
+            "assert type(pk) is S.SPATIALSIRENGRID and type(pk.grid_latent_network) is LG.StyleGenerator2D, type(pk)\n"
+            "with torch.no_grad(): e2 = (pk.grid_latent_network(d['z']) - d['lat']).abs().max().item() / d['lat'].abs().max().item()\n"
+            "print('ok %%.2e %%.2e' %% (e1, e2))\n"
+            "assert e1 <= 1e-5 and e2 <= 1e-5\n") % (ROOT, str(tmp_path / "sd.pth"), str(tmp_path / "module.pth"))
+    r = subprocess.run([sys.executable, "-c", mine], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-500:], r.stderr[-3000:])

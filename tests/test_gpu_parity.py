@@ -578,23 +578,25 @@ def test_config5_256_48p48_and_config1_64_12():
 
 
 def test_spatial_siren_grid_vs_reference():
-    """SPATIALSIRENGRID: per-point FiLM modulation through fenerf_siren_forward_pointwise vs the reference module's
-    own forward() on the same weights, latent grid, points and directions (70 points per image: ragged tiles)."""
+    """SPATIALSIRENGRID vs the reference module's own forward(input, z, ray_directions) on the same weights: the
+    latent-grid generator (PyTorch), then ONE native launch that evaluates the per-point mapping network and the FiLM-SIREN
+    (fenerf_siren_forward_local; 70 points per image: ragged tiles).  Also the explicit per-point FiLM entry
+    (fenerf_siren_forward_pointwise), on F32 and on F16X3 model handles."""
+    from test_host_cpu import _spatial_grid_module
     g = load_golden("tiny_spatial_grid")
     H = int(g["meta_H"])
-    mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4)
-    mod.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w_")}, strict=True)
-    mod = mod.to(DEV).eval()
+    mod = _spatial_grid_module(g).to(DEV).eval()
     mod.device = torch.device(DEV)
     with torch.no_grad():
-        out = mod.forward_with_latent_grid(T(g["points"]), T(g["latent_grid"]), T(g["dirs"]))
+        full = mod(T(g["points"]), T(g["z"]), T(g["dirs"]))                                             # the reference's forward, from z
+        out = mod.forward_with_latent_grid(T(g["points"]), T(g["latent_grid"]), T(g["dirs"]))            # teacher-forced latent grid
         out2 = mod.forward_with_frequencies_phase_shifts(T(g["local_coords"]), T(g["freq"]), T(g["phase"]), T(g["dirs"]))
-    assert out.shape == g["out"].shape and out.is_cuda
-    e_rgb = np.abs(N_(out)[..., :3] - g["out"][..., :3]).max()
-    e_sig = np.abs(N_(out)[..., 3] - g["out"][..., 3]).max() / max(1.0, np.abs(g["out"][..., 3]).max())
-    e2 = np.abs(N_(out2) - g["out"]).max()
-    print(f"[parity] SPATIALSIRENGRID per-point modulation vs the reference: rgb {e_rgb:.2e}, sigma rel {e_sig:.2e}; teacher-forced FiLM {e2:.2e}")
-    assert e_rgb <= 5e-6 and e_sig <= 2e-5 and e2 <= 1e-4
+    assert full.shape == out.shape == g["out"].shape and out.is_cuda
+    rel = lambda a: (np.abs(N_(a)[..., :3] - g["out"][..., :3]).max(), np.abs(N_(a)[..., 3] - g["out"][..., 3]).max() / max(1.0, np.abs(g["out"][..., 3]).max()))
+    (e_rgb0, e_sig0), (e_rgb, e_sig), e2 = rel(full), rel(out), np.abs(N_(out2) - g["out"]).max()
+    print(f"[parity] SPATIALSIRENGRID vs the reference: forward(z) rgb {e_rgb0:.2e} sigma rel {e_sig0:.2e}; given the latent grid rgb {e_rgb:.2e} "
+          f"sigma rel {e_sig:.2e} (one launch: mapping network + SIREN); explicit per-point FiLM {e2:.2e}")
+    assert e_rgb <= 5e-6 and e_sig <= 2e-5 and e_rgb0 <= 2e-5 and e_sig0 <= 5e-5 and e2 <= 1e-4
     # a [B, 9H] FiLM block (one per image) still takes the ordinary path and equals broadcasting it to every point
     f1, p1 = T(g["freq"][:, 0]), T(g["phase"][:, 0])
     with torch.no_grad():
@@ -602,12 +604,42 @@ def test_spatial_siren_grid_vs_reference():
         b = mod.forward_with_frequencies_phase_shifts(T(g["local_coords"]), f1[:, None].expand(-1, 70, -1).contiguous(),
                                                       p1[:, None].expand(-1, 70, -1).contiguous(), T(g["dirs"]))
     assert torch.equal(a, b)
-    # an f16x3 model refuses per-point parameters loudly (the FiLM blocks are staged per wave there)
-    spec = proc.model_spec("spatial", hidden_dim=32, z_dim=16)
-    nat = native.NativeModel(proc.make_state_dict(spec, seed=8, sigma_gain=10.0, with_mapping=False), spec, DEV, "f16x3")
-    with pytest.raises(_lib.FenerfError):
-        nat.siren_forward_pointwise(T(g["local_coords"]), T(g["dirs"]), T(g["freq"][..., :8 * H]), T(g["phase"][..., :8 * H]),
-                                    T(g["freq"][..., -H:]), T(g["phase"][..., -H:]))
+    # an F16X3 handle evaluates explicit per-point parameters on its resident exact-fp32 stream: same values as an F32 handle
+    spec = mod._spec()
+    sd = mod._state_numpy()
+    args = (T(g["local_coords"]), T(g["dirs"]), T(g["freq"][..., :8 * H]), T(g["phase"][..., :8 * H]), T(g["freq"][..., -H:]), T(g["phase"][..., -H:]))
+    r32 = native.NativeModel(sd, spec, DEV, "f32").siren_forward_pointwise(*args)
+    n16 = native.NativeModel(sd, spec, DEV, "f16x3")
+    assert torch.equal(n16.siren_forward_pointwise(*args), r32) and np.abs(N_(r32) - g["out"]).max() <= 1e-4
+    n16.load_from_device({k: T(v) for k, v in sd.items()})         # a device-side re-pack does not refresh the fp32 stream: refused, loudly
+    with pytest.raises(_lib.FenerfError, match="fenerf_model_update"):
+        n16.siren_forward_pointwise(*args)
+    n16.update(sd)
+    assert torch.equal(n16.siren_forward_pointwise(*args), r32)
+
+
+def test_spatial_siren_grid_at_h256_one_launch_vs_explicit_film():
+    """The same at the paper's width (H = 256, 9 FiLM layers, 4,608 modulation values per point) and 20,000 points: the fused launch
+    (local latents in, 152 B per point) against torch mapping network + fenerf_siren_forward_pointwise (18 KB of FiLM parameters per
+    point through HBM) -- two independent routes to the same numbers."""
+    torch.manual_seed(3)
+    mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=256, output_dim=4).to(DEV).eval()
+    mod.device = torch.device(DEV)
+    B, P = 2, 10000
+    g_ = torch.Generator(device=DEV).manual_seed(4)
+    pts = (torch.rand((B, P, 3), device=DEV, generator=g_) - 0.5) * 0.24
+    dirs = torch.nn.functional.normalize(torch.randn((B, P, 3), device=DEV, generator=g_), dim=-1)
+    lat = torch.randn((B, 32, 32, 32), device=DEV, generator=g_)
+    with torch.no_grad():
+        fused = mod.forward_with_latent_grid(pts, lat, dirs)
+        sampled = mod.sample_local_latents(lat, mod.gridwarper(pts))
+        f, p = mod.mapping_network(sampled)
+        local = mod.get_local_coordinates(pts, 32, preserve_y=False)
+        explicit = mod.forward_with_frequencies_phase_shifts(local, f, p, dirs)
+    e = (fused - explicit).abs()
+    print(f"[parity] SPATIALSIRENGRID H=256, {B * P} points: fused launch vs torch mapping network + explicit per-point FiLM: rgb {e[..., :3].max().item():.2e}, "
+          f"sigma {e[..., 3].max().item():.2e} (|sigma| max {explicit[..., 3].abs().max().item():.2f})")
+    assert e[..., :3].max().item() <= 2e-5 and e[..., 3].max().item() <= 2e-5 * max(1.0, explicit[..., 3].abs().max().item())
 
 
 def _curriculum_generator(precision="f16x3"):

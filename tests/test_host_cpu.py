@@ -12,6 +12,7 @@ from conftest import GOLDEN, load_golden
 from fenerf_amd import curriculums, _lib
 from fenerf_amd.generators import generators as G
 from fenerf_amd.generators import volumetric_rendering as VR
+from fenerf_amd import procedural as proc
 from fenerf_amd.siren import siren as S
 
 
@@ -247,18 +248,34 @@ def test_ema_shim_matches_the_reference_usage(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
-def test_spatial_siren_grid_host_pieces_match_the_reference():
-    """fenerf_amd.siren.siren.SPATIALSIRENGRID: state-dict compatible with the reference module (minus its StyleGAN2 grid
-    generator), and its torch-side steps -- local-latent sampling, per-point mapping network, local coordinates -- reproduce
-    the reference's stage outputs; forward(z) says what is not built."""
-    g = load_golden("tiny_spatial_grid")
+def _spatial_grid_module(g):
     H = int(g["meta_H"])
     mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4)
     sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w_")}
-    assert set(sd) == set(mod.state_dict()), set(sd) ^ set(mod.state_dict())
+    gshapes = {n: tuple(p.shape) for n, p in mod.grid_latent_network.named_parameters()}
+    sd.update({"grid_latent_network." + n: torch.from_numpy(v) for n, v in proc.latent_grid_state(gshapes, seed=31).items()})
+    sd.update({k: v for k, v in mod.state_dict().items() if k.endswith("blur.kernel") or k.endswith("upsample.kernel")})   # buffers
     mod.load_state_dict(sd, strict=True)
-    pts, lat = torch.from_numpy(g["points"]), torch.from_numpy(g["latent_grid"])
-    sampled = mod.sample_local_latents(lat, mod.gridwarper(pts))
+    return mod
+
+
+def test_spatial_siren_grid_host_pieces_match_the_reference():
+    """fenerf_amd.siren.siren.SPATIALSIRENGRID: state dict identical in names and shapes to the reference module's (the StyleGAN2-style
+    latent-grid generator included), its StyleGenerator2D reproduces the reference's latent grid from z, and the torch-side steps of
+    forward() -- local-latent sampling, per-point mapping network, local coordinates -- reproduce the reference's stage outputs."""
+    import json
+    g = load_golden("tiny_spatial_grid")
+    mod = _spatial_grid_module(g)
+    ref_sd = json.loads(str(g["meta_state_dict"]))
+    assert {k: list(v.shape) for k, v in mod.state_dict().items()} == ref_sd        # load_state_dict(reference, strict=True) compatible
+    np.testing.assert_array_equal(mod.grid_latent_network.convs[0].blur.kernel.numpy(), g["blur_kernel"])
+    with torch.no_grad():
+        lat = mod.grid_latent_network(torch.from_numpy(g["z"]))
+    err = np.abs(lat.numpy() - g["latent_grid"]).max() / np.abs(g["latent_grid"]).max()
+    print(f"StyleGenerator2D vs the reference's latent grid: relative max error {err:.2e}")
+    assert lat.shape == (2, 32, 32, 32) and err <= 1e-5
+    pts = torch.from_numpy(g["points"])
+    sampled = mod.sample_local_latents(torch.from_numpy(g["latent_grid"]), mod.gridwarper(pts))
     np.testing.assert_allclose(sampled.numpy(), g["sampled_latent"], atol=1e-6)
     with torch.no_grad():
         f, p = mod.mapping_network(sampled)
@@ -267,9 +284,39 @@ def test_spatial_siren_grid_host_pieces_match_the_reference():
     np.testing.assert_allclose(mod.get_local_coordinates(pts, 32, preserve_y=False).numpy(), g["local_coords"], atol=1e-7)
     keep_y = mod.get_local_coordinates(pts, 32, preserve_y=True).numpy()
     np.testing.assert_array_equal(keep_y[..., 1], g["points"][..., 1])
-    with pytest.raises(NotImplementedError):
-        mod(pts, torch.from_numpy(g["z"]), torch.from_numpy(g["dirs"]))
-    assert mod.precision == "f32" and mod._spec()["n_color"] == 1 and mod._spec()["n_geo"] == 8
+    with pytest.raises(RuntimeError, match="GPU only"):          # the render itself has no CPU path
+        with torch.no_grad():
+            mod(pts, torch.from_numpy(g["z"]), torch.from_numpy(g["dirs"]))
+    assert mod._spec()["n_color"] == 1 and mod._spec()["n_geo"] == 8
+    assert not any(n.startswith("grid_latent_network") or "mapping_network" in n for n, _ in mod._named_render_params())
+
+
+def test_style_generator_2d_variants_and_latent_formats():
+    """skip_conn on / off, per-layer latent lists and [B, n_layers, z] latents (latent_grid.py:95-137), against the same algebra spelled
+    with per-sample weights and a grouped convolution (the reference's formulation of modulated convolution)."""
+    from fenerf_amd.siren import latent_grid as LG
+    torch.manual_seed(0)
+    for skip in (False, True):
+        gen = LG.StyleGenerator2D(out_res=16, out_ch=5, z_dim=8, ch_mul=1, ch_max=16, skip_conn=skip).eval()
+        z = torch.randn(3, 8)
+        with torch.no_grad():
+            a = gen(z)
+            b = gen(gen.process_latents(z))                         # the list form passes through
+            c = gen(z[:, None, :].expand(-1, gen.n_layers, -1))     # per-layer latents (normalised after the mapping network)
+        assert a.shape == (3, 5, 16, 16) and torch.equal(a, b) and c.shape == a.shape
+        assert gen.n_layers == len(gen.convs) + 2 + (len(gen.to_rgbs) if skip else 0)
+    conv = LG.ModulatedConv2d(6, 4, 3, 8, upsample=True).eval()
+    x, z = torch.randn(2, 6, 5, 5), torch.randn(2, 8)
+    with torch.no_grad():
+        got = conv(x, z)
+        gamma = conv.modulation(z).view(2, 1, 6, 1, 1)
+        w = conv.scale * conv.weight * gamma
+        w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).view(2, 4, 1, 1, 1)
+        wt = w.transpose(1, 2).reshape(12, 4, 3, 3)
+        ref = torch.nn.functional.conv_transpose2d(x.view(1, 12, 5, 5), wt, stride=2, groups=2).view(2, 4, 11, 11)
+        ref = conv.activate(conv.blur(ref))
+    assert got.shape == (2, 4, 10, 10)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-6)
 
 
 def test_avg_frequency_cache_keeps_values_and_rng_consumption():

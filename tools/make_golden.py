@@ -552,6 +552,11 @@ def run_spatial_grid_case(refs, name="tiny_spatial_grid"):
     torch.manual_seed(31)
     H = 32
     ref = siren_mod.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4)
+    # the latent-grid generator (4.1 M parameters: too large for a fixture) gets procedural weights the tests can re-create
+    gshapes = {n_: tuple(p_.shape) for n_, p_ in ref.grid_latent_network.named_parameters()}
+    with torch.no_grad():
+        for n_, v in proc.latent_grid_state(gshapes, seed=31).items():
+            dict(ref.grid_latent_network.named_parameters())[n_].copy_(torch.from_numpy(v))
     B, P = 2, 70
     z = torch.randn(B, 16)
     g = torch.Generator().manual_seed(32)
@@ -570,8 +575,13 @@ def run_spatial_grid_case(refs, name="tiny_spatial_grid"):
     for n_, p_ in ref.named_parameters():
         if not n_.startswith("grid_latent_network"):
             out["w_" + n_] = np_(p_)
+    import json
+    full = ref.state_dict()
     out.update(z=np_(z), latent_grid=np_(latent_grid), points=np_(pts), dirs=np_(dirs), sampled_latent=np_(sampled), freq=np_(freq),
-               phase=np_(phase), local_coords=np_(local), out=np_(res), meta_H=H)
+               phase=np_(phase), local_coords=np_(local), out=np_(res), meta_H=H,
+               # the reference module's complete state dict as names + shapes (strict state-dict compatibility), the two blur kernels
+               meta_state_dict=json.dumps({k: list(v.shape) for k, v in full.items()}, sort_keys=True),
+               blur_kernel=np_(full["grid_latent_network.convs.0.blur.kernel"]))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: out {tuple(res.shape)}, per-point freq {tuple(freq.shape)}")
 
