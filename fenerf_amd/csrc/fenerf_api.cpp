@@ -363,21 +363,28 @@ extern "C" int fenerf_siren_forward_pointwise(const FenerfModel* m, int B, int64
                                               const float* freq_geo, const float* phase_geo, const float* freq_app,
                                               const float* phase_app, float* out, void* film_ws, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
-  if (m->precision != FENERF_PREC_F32)
-    return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters need a model created with FENERF_PREC_F32");
+  const bool f16 = m->precision == FENERF_PREC_F16X3;
+  if (f16 && !m->stream32_valid)
+    return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters run on the exact-fp32 stream, which a device-side re-pack "
+                                      "(fenerf_model_repack / fenerf_model_load_packed) does not refresh: fenerf_model_update first");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
   if (P == 0) return FENERF_OK;
   if (!points || !out) return fail(FENERF_E_INVALID, "points / out is NULL");
-  const float *fp, *pp;
-  int rc = film_prep(m, (long long)B * P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (!freq_geo || !phase_geo || !freq_app || !phase_app || !film_ws) return fail(FENERF_E_INVALID, "film parameter / workspace pointer is NULL");
+  // every lane reads its own point's FiLM block: the exact-fp32 kernel, for FENERF_PREC_F16X3 models too (their fp32-class promise holds)
+  float* fp = (float*)film_ws;
+  float* pp = fp + (size_t)B * (size_t)P * m->L * m->H;
+  int rc = [&] { PhaseScope ph(PH_FILM_PREP, stream); return launch_film_prep(m, (long long)B * P, freq_geo, phase_geo, freq_app, phase_app, fp, pp, stream, true); }();
   if (rc) return rc;
   SirenParams sp;
   fill_common(m, sp, fp, pp);
+  if (f16) { sp.stream = m->d_stream32; sp.consts = m->d_consts32; }
   sp.points = points; sp.pdirs = ray_dirs;
   sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
   sp.out = out;
   sp.film_per_point = 1;
-  return run_siren(m, sp, stream);
+  PhaseScope ph(PH_SIREN, stream);
+  return launch_siren_f32(m, sp, stream);
 }
 
 extern "C" int fenerf_siren_forward_rays(const FenerfModel* m, int B, int R, int N, const float* origins,
@@ -798,9 +805,11 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   const RenderWs ws = render_ws(m, B, R, N, hierarchical);
   if (!workspace || workspace_bytes < ws.total) return fail(FENERF_E_INVALID, "workspace too small (see fenerf_render_workspace_bytes)");
   char* base = (char*)workspace;
-  const float *fp, *pp;
-  rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, base + ws.film, &fp, &pp, stream);
-  if (rc) return rc;
+  if (!freq_geo || !phase_geo || !freq_app || !phase_app) return fail(FENERF_E_INVALID, "film parameter pointer is NULL");
+  // FiLM pre-pass (f' / p' of every image, [B][L][H] each): computed by the coarse SIREN launch itself -- every workgroup prepares the
+  // blocks of the images its tiles belong to before its first tile (fenerf_film.h) -- and reused by the fine launch
+  float* fp = (float*)(base + ws.film);
+  float* pp = fp + (size_t)B * m->L * m->H;
   float* coarse = (float*)(base + ws.coarse);
   const long long BR = (long long)B * R;
 
@@ -809,8 +818,13 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   sp.origins = origins; sp.dirs = dirs; sp.n_per_ray = N; sp.lock_view = lock_view;
   sp.P = BR * N; sp.pts_per_image = (long long)R * N;
   sp.z = z_coarse; sp.out = coarse;
+  sp.raw_fg = freq_geo; sp.raw_pg = phase_geo; sp.raw_fa = freq_app; sp.raw_pa = phase_app;
+  sp.film_bias = m->d_consts + CONST_FILM_BIAS;
+  sp.film_inv_scale = m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr;
+  sp.n_images = B;
   rc = run_siren(m, sp, stream);                       // coarse pass   (generators.py:479)
   if (rc) return rc;
+  sp.raw_fg = nullptr;                                    // the fine pass finds f' / p' in the workspace
 
   CompositeParams cp;
   if (!hierarchical) {
@@ -822,16 +836,14 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
     return run_composite(cp, false, stream);           // (generators.py:519)
   }
   float* fine = (float*)(base + ws.fine);
-  float* wts = (float*)(base + ws.wts);
   float* zf = (float*)(base + ws.zf);
-  memset(&cp, 0, sizeof(cp));                             // coarse weights only (generators.py:487)
-  cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;
+  memset(&cp, 0, sizeof(cp));                             // coarse weights (generators.py:487) and, in the same wave per ray, the
+  cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;            // inverse-CDF resampling from them (generators.py:489-499): one launch
   cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_coarse;
   cp.o.clamp_mode = opts->clamp_mode; cp.o.noise_std = opts->noise_std;
-  cp.out_weights = wts; cp.sigma_only = 1; cp.out_ch = m->C - 1;
+  cp.sigma_only = 1; cp.out_ch = m->C - 1;
+  cp.u = u; cp.z_fine = zf;
   rc = run_composite(cp, false, stream);
-  if (rc) return rc;
-  rc = [&] { PhaseScope ph(PH_RESAMPLE, stream); return launch_resample(BR, N, z_coarse, wts, u, zf, stream); }();   // (generators.py:489-499)
   if (rc) return rc;
   sp.z = zf; sp.out = fine;
   rc = run_siren(m, sp, stream);                       // fine pass     (generators.py:505)

@@ -149,6 +149,49 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
       }
     }
     if (P.out_wsum && lane == 0) P.out_wsum[ray] = wsum;
+    if (!MERGE && P.z_fine) {
+      // ---- fused importance resampling of the coarse pass (generators.py:486-499 + sample_pdf, volumetric_rendering.py:259-300):
+      //      the arithmetic of resample_kernel<false, .> below on the weights in s_w and the depths in s_zs; s_z holds the cdf
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int K = M - 2;
+      float ww[SLOTS];
+      float wtot = 0.f;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;   // pdf bin j uses coarse weight j + 1
+        ww[s] = j < K ? __fadd_rn(__fadd_rn(s_w[wv][j + 1], 1e-5f), 1e-5f) : 0.f;
+        wtot = s == 0 ? ww[0] : wtot + ww[s];
+      }
+      const float tot = wave_sum(wtot);
+      if (lane == 0) s_z[wv][0] = 0.f;
+      float base = 0.f;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (64 * s < K) {                                                                // wave-uniform
+          const float inc = wave_scan_add(ww[s] / tot, lane);
+          if (lane + 64 * s < K) s_z[wv][lane + 64 * s + 1] = s == 0 ? inc : base + inc;
+          const float tots = __shfl(inc, 63, 64);
+          base = s == 0 ? tots : base + tots;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int i = lane + 64 * s;
+        if (i < M) {
+          const float ui = P.u[ray * M + i];
+          int inds = 0;
+          for (int j = 0; j <= K; ++j) inds += s_z[wv][j] < ui ? 1 : 0;
+          const int below = inds - 1 > 0 ? inds - 1 : 0;
+          const int above = inds < K ? inds : K;
+          const float c0 = s_z[wv][below], c1 = s_z[wv][above];
+          const float b0 = 0.5f * (s_zs[wv][below] + s_zs[wv][below + 1]), b1 = 0.5f * (s_zs[wv][above] + s_zs[wv][above + 1]);   // z_vals_mid
+          float denom = c1 - c0;
+          if (denom < 1e-5f) denom = 1.f;
+          P.z_fine[ray * M + i] = b0 + (ui - c0) / denom * (b1 - b0);
+        }
+      }
+    }
     float dacc = w[0] * zk[0];
 #pragma unroll
     for (int s = 1; s < SLOTS; ++s) dacc += w[s] * zk[s];

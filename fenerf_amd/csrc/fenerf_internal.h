@@ -91,6 +91,12 @@ struct SirenParams {
   int film_per_point;
   // fenerf_siren_clock_probe: [gridDim.x][4] = s_memtime / s_memrealtime at a workgroup's first and last instruction, or nullptr
   unsigned long long* clk;
+  // FiLM pre-pass inside the launch (fenerf_film.h): with raw_fg != nullptr fp / pp are OUTPUTS first -- every workgroup computes
+  // the blocks of the images its tiles belong to from the raw mapping-network outputs [n_images][n_geo*H] / [n_images][n_color*H]
+  const float* raw_fg; const float* raw_pg; const float* raw_fa; const float* raw_pa;
+  const float* film_bias;        // [L][H] FiLM-layer biases
+  const float* film_inv_scale;   // [L][H] result scale of the layer's GEMM (FENERF_PREC_F16X3) or nullptr
+  int n_images;
 };
 
 struct SirenBwdParams {
@@ -126,6 +132,10 @@ struct CompositeParams {
   float* out_rgb; float* out_depth; float* out_weights; float* out_wsum; float* out_z;
   int out_ch;              // channels written per ray (C-1 or C)
   int sigma_only;          // coarse pass: only weights wanted, skip colour accumulation
+  // fused inverse-CDF resampling (non-merge, generators.py:486-499): with z_fine != nullptr the wave that has just computed the
+  // ray's coarse weights also draws the N fine depths from them (u [BR][N]) -- the weights never leave LDS
+  const float* u;
+  float* z_fine;
   // backward (fenerf_composite_backward): gradient of the loss wrt out_rgb [BR][C-1] in, wrt the rows out
   const float* g_rgb;
   float* d_rows_a;         // non-merge: [BR][M][C]; merge: d fine [BR][N][C]

@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 
+#include "fenerf_film.h"
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_mfma32.h"
@@ -83,6 +84,12 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
   const int blocks_in_x = nblk / nx + (x < nblk % nx ? 1 : 0);
   const long long t_begin = ntiles * x / nx, t_end = ntiles * (x + 1) / nx;
   const int wstride = blocks_in_x * 4;
+
+  if (P.raw_fg && t_begin + bi * 4 < t_end) {   // FiLM pre-pass in the launch (fenerf_film.h): the images of this workgroup's tiles
+    long long p_last = t_end * 32 - 1;
+    if (p_last >= P.P) p_last = P.P - 1;
+    film_prep_prologue(P, (t_begin + bi * 4) * 32 / P.pts_per_image, p_last / P.pts_per_image, H, n_geo, n_color);
+  }
 
   for (long long tile = t_begin + bi * 4 + wave; tile < t_end; tile += wstride) {
     // ---------------- this lane's point ----------------

@@ -28,6 +28,7 @@
 //   accumulators, FiLM'ed and split, ARE the next layer's B operand {acc[0][0..3], acc[1][0..3]}.
 #include <hip/hip_runtime.h>
 
+#include "fenerf_film.h"
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 
@@ -330,6 +331,24 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   ws.ring_lane = ring + lane * 16;
   ws.early = wave < NWAVE / 2;
 
+  // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
+  const long long ntiles = (P.P + 15) / 16;
+  const long long nocts = (ntiles + NWAVE - 1) / NWAVE;
+  const int nblk = gridDim.x;
+  const int nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx;
+  const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
+  const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
+
+  if (P.raw_fg && o_begin + bi < o_end) {
+    // FiLM pre-pass in the launch (fenerf_film.h): the images of this workgroup's octs, before the first LDS-DMA of the stream is
+    // issued (ordinary loads and stores: nothing of theirs is left in flight behind the fence + barrier that ends the prologue)
+    const long long p_first = (o_begin + bi) * (NWAVE * 16);
+    long long p_last = o_end * (NWAVE * 16) - 1;
+    if (p_last >= P.P) p_last = P.P - 1;
+    film_prep_prologue(P, p_first / P.pts_per_image, p_last / P.pts_per_image, H, n_geo, n_color);
+  }
+
   // ---- prime the shared stream: chunks 0..D-1 in flight, first k32-step of chunk 0 in registers
 #pragma unroll
   for (int i = 0; i < DPF; ++i) ws_issue(ws, i);
@@ -340,14 +359,6 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   a_cur.c = ws_read(ws, 0, 0);
   a_cur.n = ws_read(ws, 0, 1);
 
-  // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
-  const long long ntiles = (P.P + 15) / 16;
-  const long long nocts = (ntiles + NWAVE - 1) / NWAVE;
-  const int nblk = gridDim.x;
-  const int nx = nblk < 8 ? nblk : 8;
-  const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx;
-  const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
-  const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
 
   for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
     // the previous tile ended by issuing the replicated head chunks nchunk..nchunk+D-1 (== this tile's chunks 0..D-1)
@@ -694,6 +705,11 @@ int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream) {
     q.P = p.pts_per_image;
     q.fp = p.fp + (size_t)b * L * H;
     q.pp = p.pp + (size_t)b * L * H;
+    if (p.raw_fg) {   // FiLM pre-pass in the launch: this image's raw blocks
+      q.raw_fg = p.raw_fg + (size_t)b * m->n_geo * H; q.raw_pg = p.raw_pg + (size_t)b * m->n_geo * H;
+      q.raw_fa = p.raw_fa + (size_t)b * m->n_color * H; q.raw_pa = p.raw_pa + (size_t)b * m->n_color * H;
+      q.n_images = 1;
+    }
     q.out = p.out + (size_t)b * p.pts_per_image * m->C;
     if (p.points) {
       q.points = p.points + (size_t)b * p.pts_per_image * 3;

@@ -7,14 +7,14 @@ Q="--no-cpu-baseline --no-gstep --no-f32 --no-sweep64"
 for what in "$@"; do
 case $what in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=10 2>&1 | tail -400 > gpurun_out/tests.log
-  echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/tests.log
+  timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=10 > gpurun_out/tests_full.log 2>&1; grep -h 'parity\]\|dist\]' gpurun_out/tests_full.log | grep -v 'print(' > gpurun_out/tests_parity.log; tail -300 gpurun_out/tests_full.log > gpurun_out/tests.log
+  echo "pytest exit: $?" >> gpurun_out/tests.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
   echo "smoke exit: $?" >> gpurun_out/smoke.log
   tail -n 5 gpurun_out/tests.log; tail -n 4 gpurun_out/smoke.log ;;
 newtests)   # the tests added this round, without -x, verbose: what they measure decides their asserts
-  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "${NEWTESTS:-all_rays or config5 or at_scale or rccl or ddp or repacked or chunked_backward or single_latent_generator or reference_checkpoint}" 2>&1 | tail -120 > gpurun_out/newtests.log
-  grep -E "parity|dist|passed|failed|Error|assert" gpurun_out/newtests.log | tail -60 ;;
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "${NEWTESTS:-all_rays or config5 or at_scale or rccl or ddp or repacked or chunked_backward or single_latent_generator or reference_checkpoint}" > gpurun_out/newtests_full.log 2>&1; grep -h 'parity\]\|dist\]' gpurun_out/newtests_full.log | grep -v 'print(' > gpurun_out/newtests_parity.log; tail -150 gpurun_out/newtests_full.log > gpurun_out/newtests.log
+  cat gpurun_out/newtests_parity.log | cut -c1-400; grep -E "passed|failed|^E  |FAILED" gpurun_out/newtests.log | tail -40 ;;
 bench)
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1
   echo "bench exit: $?" >> gpurun_out/bench.log
