@@ -43,22 +43,27 @@ def multiview_kwargs(curriculum, image_size=256, ray_step_multiplier=2, lock_vie
     return {k: v for k, v in c.items() if type(k) is str}
 
 
-def load_generator(path, device, use_ema=True):
+def load_generator(path, device, use_ema=True, reset_render_options=True):
     """What every inference script of the reference does first (render_multiview_images_double_semantic.py:58-66,
     render_video_interpolation_semantic.py:317-324): unpickle the generator module saved by the training loop
     (`torch.save(generator_ddp.module, 'generator.pth')`, train...py:524), unpickle the torch_ema object next to it
     (`<prefix>ema.pth`, the prefix being everything before 'generator' in the path) and copy the averaged weights in, then
     set_device + eval.  Pickles written by the reference resolve through compat.install_aliases(): its module paths
     (generators.generators.*, siren.siren.*) map to this package and torch_ema.ema.ExponentialMovingAverage to fenerf_amd.ema
-    when torch_ema is not installed (same attribute layout: decay, num_updates, shadow_params, collected_params)."""
+    when torch_ema is not installed (same attribute layout: decay, num_updates, shadow_params, collected_params).
+    `reset_render_options`: the multi-view and inversion scripts overwrite three attributes of the pickled module
+    (softmax_label = False, neural_renderer_img / _seg = None; render_multiview...:60-62, inverse_render...), the video script keeps
+    what the pickle says (render_video_interpolation_semantic.py:317-324) -- its front end passes False.  `use_ema=False` (the tools'
+    --no_ema) renders the raw generator weights; the reference has no such switch and fails without the ema file."""
     import os
     from . import compat
     compat.install_aliases()
     device = torch.device(device)
     generator = torch.load(path, map_location=device, weights_only=False)
-    generator.softmax_label = False
-    generator.neural_renderer_img = None
-    generator.neural_renderer_seg = None
+    if reset_render_options:
+        generator.softmax_label = False
+        generator.neural_renderer_img = None
+        generator.neural_renderer_seg = None
     ema_file = path.split("generator")[0] + "ema.pth"
     if use_ema:
         if not os.path.exists(ema_file):

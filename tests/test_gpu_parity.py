@@ -637,8 +637,20 @@ def test_spatial_siren_grid_at_h256_one_launch_vs_explicit_film():
         local = mod.get_local_coordinates(pts, 32, preserve_y=False)
         explicit = mod.forward_with_frequencies_phase_shifts(local, f, p, dirs)
     e = (fused - explicit).abs()
+    nat = mod.native_local(DEV)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    big = (torch.rand((1, 196608, 3), device=DEV, generator=g_) - 0.5) * 0.24
+    lat_b = mod.sample_local_latents(lat[:1], mod.gridwarper(big))
+    nat.forward(big, None, lat_b)
+    ev[0].record()
+    for _ in range(3):
+        nat.forward(big, None, lat_b)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / 3
     print(f"[parity] SPATIALSIRENGRID H=256, {B * P} points: fused launch vs torch mapping network + explicit per-point FiLM: rgb {e[..., :3].max().item():.2e}, "
-          f"sigma {e[..., 3].max().item():.2e} (|sigma| max {explicit[..., 3].abs().max().item():.2f})")
+          f"sigma {e[..., 3].max().item():.2e} (|sigma| max {explicit[..., 3].abs().max().item():.2f}); fused launch on 196,608 points: {ms:.2f} ms = "
+          f"{196608 * 3.56e6 / ms / 1e9:.0f} TFLOP/s of exact-fp32 MFMA work (3.56 MFLOP per point: 2.5 mapping network + 1.06 SIREN)")
     assert e[..., :3].max().item() <= 2e-5 and e[..., 3].max().item() <= 2e-5 * max(1.0, explicit[..., 3].abs().max().item())
 
 

@@ -29,6 +29,7 @@ def build_parser():
     parser.add_argument('--image_size', type=int, default=256)
     parser.add_argument('--ray_step_multiplier', type=int, default=2)
     parser.add_argument('--curriculum', type=str, default='CelebA')
+    parser.add_argument('--no_ema', action='store_true', help='render the raw generator weights (not in the reference: it always loads <prefix>ema.pth)')
     return parser
 
 
@@ -54,7 +55,7 @@ def main(argv=None):
     device = torch.device('cuda')
     curriculum = resolve_curriculum(opt.curriculum)
     os.makedirs(opt.output_dir, exist_ok=True)
-    generator = callers.load_generator(opt.path, device)
+    generator = callers.load_generator(opt.path, device, use_ema=not opt.no_ema)
     for seed in opt.seeds:
         images, segmaps = callers.render_multiview(generator, curriculum, int(seed), device, image_size=opt.image_size,
                                                    ray_step_multiplier=opt.ray_step_multiplier,

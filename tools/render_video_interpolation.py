@@ -35,6 +35,7 @@ def build_parser():
     parser.add_argument('--ray_step_multiplier', type=int, default=2)
     parser.add_argument('--num_frames', type=int, default=36)
     parser.add_argument('--curriculum', type=str, default='CelebA')
+    parser.add_argument('--no_ema', action='store_true', help='render the raw generator weights (not in the reference: it always loads <prefix>ema.pth)')
     parser.add_argument('--trajectory', type=str, default='front')
     parser.add_argument('--psi', type=float, default=0.5)
     parser.add_argument("--fill_color", type=str, default='black')
@@ -85,7 +86,7 @@ def main(argv=None):
     options = callers.video_kwargs(curriculum, opt.image_size, opt.ray_step_multiplier, opt.psi, opt.lock_view_dependence,
                                    opt.num_frames, opt.fov, opt.fill_color)
     os.makedirs(opt.output_dir, exist_ok=True)
-    generator = callers.load_generator(opt.path, device)
+    generator = callers.load_generator(opt.path, device, use_ema=not opt.no_ema, reset_render_options=False)
     if opt.interpolation_type == 'video_latent_interpolation':
         return run_single_latent(opt, generator, options, device)
     generator.output_dim = options['output_dim']          # :316-317
