@@ -28,9 +28,6 @@
 
 namespace fenerf {
 
-#ifndef FENERF_WGRAD_GPW2
-#define FENERF_WGRAD_GPW2 6     // dump groups per wave (of 8 at H = 256) with a second prefetch register set (siren_wgrad_sq_bf16_kernel): 252 VGPRs, no scratch; 8 spills
-#endif
 constexpr int WG_LD = 36;   // LDS row stride (floats): 16-B aligned rows, conflict-free 128-bit reads across 8 rows
 
 enum WgJob { WG_SQ = 0, WG_L0 = 1, WG_C0X = 2, WG_HEAD = 3, WG_RGB = 4 };
@@ -400,68 +397,54 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
   const int m = lane & 31, half = lane >> 5;
   static_assert(4 * GPW == NG, "every wave stages GPW dump groups");
 
-  // Two register sets of dump groups: while tile t multiplies out of LDS buffer (t - t0) & 1, tile t + 1 is staged from set
-  // (t - t0) & 1 into the other buffer and every staged group's registers are refilled with tile t + 3 -- loads stay in flight for TWO
-  // tile periods (round 3: one period left the kernel at 5.4-5.5 TB/s; the bf16-dump kernel below, built this way, reads at 6.6).
-  // (Dump groups q < GPW2 only: a full second set does not fit beside 256 accumulators at H = 256 -- 36 bytes of scratch per lane.)
-  constexpr int GPW2 = FENERF_WGRAD_GPW2 < GPW ? FENERF_WGRAD_GPW2 : GPW;
-  float4 va[2][GPW], vb[2][GPW];                            // dump group q: dtheta_l, tape_{l-1}
-  // No branches inside a tile: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative (it
+  float4 va[GPW], vb[GPW];                                  // dump group q of the tile being staged next: dtheta_l, tape_{l-1}
+  // No branches from here on: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative (it
   // then waits for the refill loads it has just issued); past the chunk's end the last tile is re-read and never staged.
-  auto fetch_q = [&](auto set_c, int t, int q) {
-    constexpr int SET = decltype(set_c)::value;
+  auto fetch_q = [&](int t, int q) {
     const long long tile = tile_base + (t < t1 ? t : t1 - 1);
     const int g = wave * GPW + q;
-    va[SET][q] = nt_load(dt4 + (tile * L + l) * tl + g * 64 + lane);
-    vb[SET][q] = nt_load(tape4 + (tile * L + lb) * tl + g * 64 + lane);
+    va[q] = nt_load(dt4 + (tile * L + l) * tl + g * 64 + lane);
+    vb[q] = nt_load(tape4 + (tile * L + lb) * tl + g * 64 + lane);
   };
-  // half-piece hp = 2 q + part of the tile in register set SET -> buffer dst: part 0 = dtheta rows, part 1 = x = sin(2 pi (f' tape + p')) rows.
+  // half-piece hp = 2 q + part of the tile in (va, vb) -> buffer dst: part 0 = dtheta rows, part 1 = x = sin(2 pi (f' tape + p')) rows.
   // f4 / p4 = the FiLM rows of the group, fetched from LDS ahead of time (LDS reads do not move across LDS writes).
   auto film_rows = [&](int hp, float4& f4, float4& p4) {
     const int row = tape_feature(wave * GPW + (hp >> 1), half, 0);
     f4 = *reinterpret_cast<const float4*>(f_s + row);
     p4 = *reinterpret_cast<const float4*>(p_s + row);
   };
-  auto stage_half = [&](auto set_c, int hp, unsigned* dst, const float4& f4, const float4& p4) {
-    constexpr int SET = decltype(set_c)::value;
+  auto stage_half = [&](int hp, unsigned* dst, const float4& f4, const float4& p4) {
     const int q = hp >> 1;
     const int row = tape_feature(wave * GPW + q, half, 0);
     if ((hp & 1) == 0) {
-      const float4 a = va[SET][q];
+      const float4 a = va[q];
       const float d[4] = {a.x, a.y, a.z, a.w};
       stage_split4(reinterpret_cast<unsigned short*>(dst + row * WG_LD) + m, d);
     } else {
-      const float4 b = vb[SET][q];
+      const float4 b = vb[q];
       const float x[4] = {sin2pi(__builtin_fmaf(f4.x, b.x, p4.x)), sin2pi(__builtin_fmaf(f4.y, b.y, p4.y)),
                           sin2pi(__builtin_fmaf(f4.z, b.z, p4.z)), sin2pi(__builtin_fmaf(f4.w, b.w, p4.w))};
       stage_split4(reinterpret_cast<unsigned short*>(dst + H * WG_LD + row * WG_LD) + m, x);
     }
   };
-  const std::integral_constant<int, 0> set0;
-  const std::integral_constant<int, 1> set1;
 
-  // ---- prologue: tile t0 staged into buffer 0; tiles t0 + 1 / t0 + 2 on their way in sets 0 / 1
+  // ---- prologue: tile t0 staged into buffer 0, tile t0 + 1 on its way
 #pragma unroll
-  for (int q = 0; q < GPW; ++q) fetch_q(set0, t0, q);
+  for (int q = 0; q < GPW; ++q) fetch_q(t0, q);
 #pragma unroll
   for (int hp = 0; hp < 2 * GPW; ++hp) {
     float4 f4, p4;
     film_rows(hp, f4, p4);
-    stage_half(set0, hp, img0, f4, p4);
+    stage_half(hp, img0, f4, p4);
   }
 #pragma unroll
-  for (int q = 0; q < GPW; ++q) fetch_q(set0, t0 + 1, q);
-#pragma unroll
-  for (int q = 0; q < GPW2; ++q) fetch_q(set1, t0 + 2, q);
+  for (int q = 0; q < GPW; ++q) fetch_q(t0 + 1, q);
   __syncthreads();
 
-  // tile t out of buffer PAR = (t - t0) & 1; stages tile t + 1 -- groups q < GPW2 from register set PAR, refilled with tile t + 3; the
-  // others from set 0, refilled with tile t + 2
-  auto tile_body = [&](auto par_c, int t) {
-    constexpr int PAR = decltype(par_c)::value;
-    const unsigned* A_p = img0 + PAR * IMG;
+  for (int t = t0; t < t1; ++t) {
+    const unsigned* A_p = img0 + ((t - t0) & 1) * IMG;
     const unsigned* B_p = A_p + H * WG_LD;
-    unsigned* nxt = img0 + (PAR ^ 1) * IMG;   // after the last tile this stages a re-read tile nobody consumes
+    unsigned* nxt = img0 + (((t - t0) & 1) ^ 1) * IMG;   // after the last tile this stages a re-read tile nobody consumes
     // ---- MFMA: lane (i, kh) contracts points 16 ks + 8 kh + {0..7} in k-step ks (same order on both operands)
     {
       const int i = lane & 31, kh = lane >> 5;
@@ -505,13 +488,8 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           for (int j = 0; j < HPG; ++j) {
             const int hp = g * HPG + j;
             if (hp < 2 * GPW) {
-              if ((hp >> 1) < GPW2) {
-                stage_half(par_c, hp, nxt, f4[j], p4[j]);
-                if (hp & 1) fetch_q(par_c, t + 3, hp >> 1);        // both halves of dump group hp >> 1 are staged: refill its registers
-              } else {
-                stage_half(set0, hp, nxt, f4[j], p4[j]);
-                if (hp & 1) fetch_q(set0, t + 2, hp >> 1);
-              }
+              stage_half(hp, nxt, f4[j], p4[j]);
+              if (hp & 1) fetch_q(t + 2, hp >> 1);          // both halves of dump group hp >> 1 are staged: refill its registers
             }
           }
           acc[mt][kt] = MFMA_BF16(af[0].hi, bf[0].hi, acc[mt][kt]);
@@ -519,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].lo, acc[mt][kt]);
           acc[mt][kt] = MFMA_BF16(af[1].hi, bf[1].hi, acc[mt][kt]);
 #pragma unroll
-          for (int i2 = 0; i2 < 5; ++i2) {
+          for (int i = 0; i < 5; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);    // up to 9 VALU
             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);    // up to 2 LDS writes
@@ -531,13 +509,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       }
     }
     __syncthreads();
-  };
-  int t = t0;
-  for (; t + 1 < t1; t += 2) {
-    tile_body(set0, t);
-    tile_body(set1, t + 1);
   }
-  if (t < t1) tile_body(set0, t);      // odd tile count: the pairs consumed an even number, so the tail has parity 0
 
   // ---- partials (same layout as the fp32 job)
   float* out = P.partial + (((size_t)blockIdx.z * P.B + img) * P.nchunk + chunk) * (size_t)(H * H);
