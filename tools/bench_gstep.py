@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--grid", type=int, default=96)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-eager", action="store_true")
+    ap.add_argument("--grad-precision", choices=["f32", "amp"], default="f32", help="weight-gradient operands (siren.grad_precision)")
     a = ap.parse_args()
     B, S_, N, H = a.B, a.size, a.steps, a.H
     spec = proc.model_spec("texture", hidden_dim=H, grid_size=a.grid, z_dim=8)
@@ -55,6 +56,7 @@ def main():
     mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
     mod.load_state_dict(tsd, strict=False)
     mod = mod.to(DEV)
+    mod.grad_precision = a.grad_precision
     gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=H), 8, 8, 22)
     gen.siren = mod
     gen = gen.to(DEV)

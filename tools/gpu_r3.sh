@@ -40,6 +40,32 @@ pmc)
   find gpurun_out/pmc -type f -size +4M -delete
   python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc/siren_pmc_summary.txt 2>&1
   cat gpurun_out/pmc/siren_pmc_summary.txt ;;
+pmcgstep)   # HBM bytes of the generator-step kernels (default and AMP weight-gradient operands) and of the SPATIALSIRENGRID launch
+  for gp in f32 amp; do
+    GSTEP_ARGS="--B 1 --size 128 --grad-precision $gp" bash tools/pmc_gstep.sh > /dev/null 2>&1
+    cp gpurun_out/pmc_gstep/gstep_pmc_summary.txt gpurun_out/pmc_gstep_$gp.txt
+  done
+  rm -rf gpurun_out/pmc_local; mkdir -p gpurun_out/pmc_local
+  for set in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_local/$set -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_local.py --iters 2 --explicit) > gpurun_out/pmc_local/$set.log 2>&1
+  done
+  python - <<'PY' > gpurun_out/pmc_local.txt 2>&1
+import csv, glob
+from collections import defaultdict
+agg = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob("gpurun_out/pmc_local/*/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        n = row["Kernel_Name"]
+        if "siren_local_kernel" in n or "siren_kernel" in n or "film_prep" in n:
+            agg[n.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("kernel,counter,avg_KiB_per_dispatch,bytes_per_point_at_196608_points,n")
+for k in sorted(agg):
+    for c, v in sorted(agg[k].items()):
+        a = sum(v) / len(v)
+        print(f"{k},{c},{a:.6g},{a * 1024 / 196608:.1f},{len(v)}")
+PY
+  find gpurun_out/pmc_local -type f -size +2M -delete
+  head -20 gpurun_out/pmc_gstep_f32.txt; grep -E "wgrad|bwd16w" gpurun_out/pmc_gstep_amp.txt; cat gpurun_out/pmc_local.txt; tail -3 gpurun_out/pmc_local/FETCH_SIZE.log ;;
 probe)
   ./tools/probe/tr_probe > gpurun_out/tr_probe.log 2>&1; head -40 gpurun_out/tr_probe.log ;;
 saveexp)   # tools/exp/save_store_variants.sh: forward-save with the tape stores removed / redirected / re-hinted
