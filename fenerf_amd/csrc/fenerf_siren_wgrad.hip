@@ -174,17 +174,44 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
 
   float4 va[NQ], vb[NQ];
   uint4 va16[Dump16<H>::PER_THREAD];
+  // The per-point side inputs of a tile (warped coordinates, grid features + view direction, output-gradient rows) are fetched into
+  // registers ONE TILE AHEAD like the dumps (round 3: loaded inside the staging they put one HBM round trip per tile in front of the
+  // barrier -- 24 tiles per workgroup, 20-40 % of its time).  Past the chunk's end the last tile is re-read (no branch around loads).
+  float4 side4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float side_a[4] = {0.f, 0.f, 0.f, 0.f}, side_b = 0.f, side_c = 0.f;
   auto fetch = [&](int t) {
-    const long long tile = tile_base + t;
+    const long long tile = tile_base + (t < t1 ? t : t1 - 1);
+    const long long pt0 = tile * 32;
     if (S::A_DUMP) {
       if (P.bf16_dump) load_dump16<H>(va16, reinterpret_cast<const char*>(dt4 + (tile * L + l) * tl), tid);
       else load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
     }
     if (S::B_DUMP) load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
+    if (JOB == WG_L0) {
+      if (tid < 96) side_b = P.points[(pt0 + (tid & 31)) * 3 + (tid >> 5)];
+    }
+    if (JOB == WG_C0X) {
+      if (P.tape_e) side4 = *reinterpret_cast<const float4*>(P.tape_e + (pt0 + (tid >> 3)) * 32 + (tid & 7) * 4);
+      if (tid < 96 && P.dirs) side_b = P.dirs[(pt0 + (tid & 31)) * 3 + (tid >> 5)];
+    }
+    if (JOB == WG_HEAD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q, r = i >> 5, m = i & 31;
+        const int ch = r < P.n_lab ? r : (r == P.n_lab ? C - 1 : -1);
+        side_a[q] = ch >= 0 ? P.d_out[(pt0 + m) * C + ch] : 0.f;
+      }
+    }
+    if (JOB == WG_RGB) {
+      if (tid < 96) {
+        const int c = tid >> 5, m = tid & 31;
+        side_b = P.out[(pt0 + m) * C + (C - 4) + c];
+        side_c = P.d_out[(pt0 + m) * C + (C - 4) + c];
+      }
+    }
   };
-  if (t0 < t1) fetch(t0);
+  fetch(t0);
   for (int t = t0; t < t1; ++t) {
-    const long long pt0 = (tile_base + t) * 32;
     // ---- stage the tile
     if (S::A_DUMP) {
       if (P.bf16_dump) stage_dump16_f32<H>(va16, A_s, tid);
@@ -192,35 +219,30 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
     }
     if (S::B_DUMP) stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
-      if (tid < 96) { const int c = tid >> 5, m = tid & 31; B_s[c * WG_LD + m] = P.points[(pt0 + m) * 3 + c] * P.box_scale; }
+      if (tid < 96) B_s[(tid >> 5) * WG_LD + (tid & 31)] = side_b * P.box_scale;
     }
     if (JOB == WG_C0X) {           // B rows 0..31 = grid features, 32..34 = view direction
       if (P.tape_e) {
         const int m = tid >> 3, c4 = (tid & 7) * 4;
-        const float4 e = *reinterpret_cast<const float4*>(P.tape_e + (pt0 + m) * 32 + c4);
-        B_s[(c4 + 0) * WG_LD + m] = e.x; B_s[(c4 + 1) * WG_LD + m] = e.y; B_s[(c4 + 2) * WG_LD + m] = e.z; B_s[(c4 + 3) * WG_LD + m] = e.w;
+        B_s[(c4 + 0) * WG_LD + m] = side4.x; B_s[(c4 + 1) * WG_LD + m] = side4.y; B_s[(c4 + 2) * WG_LD + m] = side4.z; B_s[(c4 + 3) * WG_LD + m] = side4.w;
       }
       if (tid < 96) {
         const int c = tid >> 5, m = tid & 31;
-        B_s[(32 + c) * WG_LD + m] = P.dirs ? P.dirs[(pt0 + m) * 3 + c] : (c == 2 ? -1.f : 0.f);
+        B_s[(32 + c) * WG_LD + m] = P.dirs ? side_b : (c == 2 ? -1.f : 0.f);
       }
     }
     if (JOB == WG_HEAD) {          // A row r = gradient wrt head row r: labels [0,n_lab), sigma n_lab
-      for (int i = tid; i < 32 * 32; i += 256) {
-        const int r = i >> 5, m = i & 31;
-        const int ch = r < P.n_lab ? r : (r == P.n_lab ? C - 1 : -1);
-        A_s[r * WG_LD + m] = ch >= 0 ? P.d_out[(pt0 + m) * C + ch] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q;
+        A_s[(i >> 5) * WG_LD + (i & 31)] = side_a[q];
       }
     }
     if (JOB == WG_RGB) {
-      if (tid < 96) {
-        const int c = tid >> 5, m = tid & 31;
-        const float s = P.out[(pt0 + m) * C + (C - 4) + c];
-        A_s[c * WG_LD + m] = P.d_out[(pt0 + m) * C + (C - 4) + c] * (s * (1.f - s));
-      }
+      if (tid < 96) A_s[(tid >> 5) * WG_LD + (tid & 31)] = side_c * (side_b * (1.f - side_b));
     }
     __syncthreads();
-    if (t + 1 < t1) fetch(t + 1);          // next tile's global loads fly behind this tile's MFMAs
+    fetch(t + 1);                          // next tile's global loads (dump and side inputs) fly behind this tile's MFMAs
 
     // ---- row sums (thread = row)
     if (JOB == WG_HEAD || JOB == WG_RGB) {
