@@ -274,8 +274,13 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
   __shared__ float s_z[4][MAXM];
   __shared__ float s_zs[4][MAXM + 1];
   __shared__ int s_ord[4][MAXM];
+  // gradient rows of one ray, by SOURCE index, for a coalesced write-out (round 3: every lane writing its own 88-byte row channel by
+  // channel cost 5x the bytes at the memory side -- PMC WRITE_SIZE 369 MB for 69 MB of gradients); rays of up to CB_STAGE_M samples
+  constexpr int CB_STAGE_M = 64, CB_STAGE_C = 24;
+  __shared__ float s_out[4][MAXM <= 256 ? CB_STAGE_M * CB_STAGE_C : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int M = P.M, C = P.C, N = P.N, nch = C - 1;
+  const bool staged = MAXM <= 256 && M <= CB_STAGE_M && C <= CB_STAGE_C;
   const long long nwaves = (long long)gridDim.x * 4;
   for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
     // ---- sorted order (identical to the forward kernel)
@@ -400,8 +405,25 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
       if (k < M) {
         const float dalpha = T[s] * gw[s] - S[s] / tt[s];
         const float dsigma = (M > 1) ? dalpha * delta[s] * (1.f - alpha[s]) * dact[s] : 0.f;
-        for (int c = 0; c < nch; ++c) drow[s][c] = wp[s] * g[c];
-        drow[s][C - 1] = dsigma;
+        if (staged) {
+          float* o = s_out[wv] + s_ord[wv][k] * C;
+          for (int c = 0; c < nch; ++c) o[c] = wp[s] * g[c];
+          o[C - 1] = dsigma;
+        } else {
+          for (int c = 0; c < nch; ++c) drow[s][c] = wp[s] * g[c];
+          drow[s][C - 1] = dsigma;
+        }
+      }
+    }
+    if (staged) {
+      // source index i < N: row i of d_rows_a (fine / the only input), else row i - N of d_rows_b (coarse): two contiguous runs
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int na = (MERGE ? N : M) * C;
+      float* oa = P.d_rows_a + ray * (long long)na;
+      for (int i = lane; i < na; i += 64) oa[i] = s_out[wv][i];
+      if (MERGE) {
+        float* ob = P.d_rows_b + ray * (long long)na;
+        for (int i = lane; i < na; i += 64) ob[i] = s_out[wv][na + i];
       }
     }
     __builtin_amdgcn_wave_barrier();
