@@ -29,6 +29,11 @@ def test_committed_fixtures_regenerate_from_the_reference(tmp_path):
         a, b = np.load(f, allow_pickle=True), np.load(g, allow_pickle=True)
         assert set(a.files) == set(b.files), os.path.basename(f)
         for k in a.files:
+            if os.path.basename(f) == "tiny_texture_grad_autocast16.npz" and a[k].dtype.kind == "f":
+                # the reference under autocast(float16) on the CPU: fp16 kernels are not guaranteed bit-stable across thread counts;
+                # the fixture is a yardstick (errors of 0.2 .. 1 relative), compared to 2 % of each tensor's largest magnitude
+                assert np.abs(a[k] - b[k]).max() <= 0.02 * max(np.abs(a[k]).max(), 1e-30), f"{os.path.basename(f)}:{k}"
+                continue
             assert np.array_equal(a[k], b[k]), f"{os.path.basename(f)}:{k} differs from what the reference produces today"
     assert json.load(open(os.path.join(GOLDEN, "curriculums.json"))) == json.load(open(os.path.join(out, "curriculums.json")))
     assert os.path.exists(os.path.join(out, "ref_generator_tiny.pth"))

@@ -1937,6 +1937,38 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
     assert n == {"texture": 33, "baseline": 30, "spatial": 22}[kind] and worst <= 5e-3
 
 
+def test_amp_class_weight_gradients_against_the_references_own_autocast_step():
+    """The opt-in AMP-class weight-gradient operands (siren.grad_precision = "amp") are labelled "the class of the
+    reference's own training arithmetic".  tests/golden/tiny_texture_grad_autocast16.npz is that arithmetic: the reference's generator
+    step under torch.autocast(float16) on the draws of tiny_texture_grad.npz (tools/make_golden.py::run_grad_autocast_case).  Measured
+    against the reference's fp32 gradients, its own autocast step is off by 0.23 (median) .. 0.98 (worst) over the FiLM-layer weight
+    gradients and by 0.03 in the pixels; this package's AMP mode (forced here at 576 points per pass: AMP_MIN_POINTS = 1) must be at
+    least an order of magnitude closer on every one of those tensors, with fp32-class pixels."""
+    g, ga = load_golden("tiny_texture_grad"), load_golden("tiny_texture_grad_autocast16")
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, dict(spec, z_dim=16), "f16x3")
+    gen.train()
+    gen.siren.grad_precision, gen.siren.AMP_MIN_POINTS = "amp", 1
+    film, tf = _film(g, spec)
+    tf = [t.clone().requires_grad_(True) for t in tf]
+    gen.draws = VR.RecordedDraws([g["rand_u_jitter"], g["rand_r_theta"], g["rand_r_phi"], g["rand_noise_coarse"], g["rand_u_fine"],
+                                  g["rand_noise_fine"]])
+    common = dict(img_size=int(g["meta_S"]), fov=12, ray_start=0.88, ray_end=1.12, num_steps=int(g["meta_N"]), h_stddev=0.3,
+                  v_stddev=0.155, h_mean=np.pi * 0.5, v_mean=np.pi * 0.5, hierarchical_sample=True, sample_dist="gaussian", **kwargs_from_golden(g))
+    px, _ = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], **common)
+    (px * T(g["loss_w"])).sum().backward()
+    named = dict(gen.siren.named_parameters())
+    keys = [k for k in g if k.startswith("gparam_") and k.endswith("layer.weight")]
+    mine = {k: _rel_err(N_(named[k[7:]].grad), g[k]) for k in keys}
+    theirs = {k: _rel_err(ga[k], g[k]) for k in keys}
+    e_px, e_px_ref = np.abs(N_(px) - g["pixels"]).max(), np.abs(ga["pixels"] - g["pixels"]).max()
+    print(f"[parity] AMP-class weight gradients vs the reference's fp32 autograd over {len(keys)} FiLM-layer weights: worst {max(mine.values()):.2e} "
+          f"(pixels {e_px:.1e}); the reference's own autocast(float16) step: median {np.median(list(theirs.values())):.2f}, worst "
+          f"{max(theirs.values()):.2f} (pixels {e_px_ref:.3f})")
+    assert e_px <= 1e-3 and max(mine.values()) <= 1e-2
+    assert all(mine[k] <= 0.1 * theirs[k] for k in keys)
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_part_forward_vs_reference(precision):
     """tests/golden/tiny_texture_part_forward.npz: the reference's generator.forward(z_geo, z_app, grad_points=11, ...) --

@@ -236,6 +236,37 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
     print(f"{name}: pixels {out['pixels'].shape}, {sum(k.startswith('gparam_') for k in out)} parameter gradients -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_grad_autocast_case(refs, name, base, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0):
+    """The same generator step as run_grad_case(`base`), run by the reference under torch.autocast(float16) -- the arithmetic its training
+    loop uses (torch.cuda.amp.autocast, train_double_latent_semantic.py:402-446; here the CPU autocast of this torch build) -- on the same
+    draws.  Records the pixels and the render-parameter gradients: how far the reference's OWN mixed-precision training arithmetic is from its
+    fp32 gradients is the yardstick for this package's opt-in AMP-class weight gradients (tests/test_gpu_parity.py).  fp16 CPU kernels are
+    not guaranteed bit-stable, so tests/test_golden_recipe.py compares this one fixture with a tolerance."""
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale)
+    tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in film.items()}
+    torch.manual_seed(4321 + seed)
+    common = dict(img_size=S, num_steps=N, hierarchical_sample=True, fov=CURR["fov"], ray_start=CURR["ray_start"],
+                  ray_end=CURR["ray_end"], h_stddev=CURR["h_stddev"], v_stddev=CURR["v_stddev"],
+                  h_mean=CURR["h_mean"], v_mean=CURR["v_mean"], sample_dist=CURR["sample_dist"])
+    common.update(kwargs)
+    with torch.autocast("cpu", dtype=torch.float16):
+        px, poses = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
+    w = torch.from_numpy(np.load(os.path.join(OUT, base + ".npz"))["loss_w"])
+    (px.float() * w).sum().backward()
+    out = dict(meta_base=base, pixels=np_(px.float()))
+    for n, p in g.siren.named_parameters():
+        if "mapping_network" not in n:
+            out["gparam_" + n] = np_(p.grad.float())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    ref = np.load(os.path.join(OUT, base + ".npz"))
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    errs = [rel(out[k], ref[k]) for k in out if k.startswith("gparam_") and k.endswith("layer.weight")]
+    print(f"{name}: reference under autocast(float16): pixels off by {np.abs(out['pixels'] - ref['pixels']).max():.3f}, FiLM-layer weight "
+          f"gradients off by {np.median(errs):.2f} (median) .. {max(errs):.2f} (worst) relative to its own fp32 gradients")
+
+
 def run_part_forward_case(refs, name):
     """generator.forward(..., grad_points=G) = part_forward (generators.py:459-461, :858-910): records every draw including
     the randperm that picks the differentiable rays, the pixels and the gradient of a fixed loss wrt z-mapped FiLM inputs'
@@ -633,6 +664,8 @@ def main(out_dir=None):
     run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
+    run_grad_autocast_case(refs, "tiny_texture_grad_autocast16", "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16),
+                           seed=3, sigma_gain=60.0, B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
     run_grad_case(refs, "tiny_baseline_grad", proc.model_spec("baseline", hidden_dim=32, z_dim=16), seed=5, sigma_gain=60.0,
                   B=1, S=6, N=6, kwargs=dict(clamp_mode="softplus", nerf_noise=0.3, last_back=True))
     run_grad_case(refs, "tiny_spatial_grad", proc.model_spec("spatial", hidden_dim=32, z_dim=16), seed=8, sigma_gain=60.0,
