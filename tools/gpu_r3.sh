@@ -76,6 +76,9 @@ saveexp)   # tools/exp/save_store_variants.sh: forward-save with the tape stores
     FENERF_LIB=$PWD/$lib timeout 200 python tools/time_bwd.py 196608 2>&1 | grep -E "forward|chain" | tr '\n' ' '; echo
   done > gpurun_out/saveexp.log 2>&1
   cat gpurun_out/saveexp.log ;;
+soak)      # determinism / race soak of the fused render and of the generator step (default and AMP-class)
+  timeout 900 python tools/soak_render.py --iters ${SOAK_ITERS:-100} > gpurun_out/soak_render.log 2>&1; tail -12 gpurun_out/soak_render.log
+  timeout 600 python tools/soak_gstep.py ${SOAK_STEPS:-300} > gpurun_out/soak_gstep.log 2>&1; tail -3 gpurun_out/soak_gstep.log ;;
 gstep)
   timeout 600 python tools/chunk_sweep.py > gpurun_out/chunk_sweep.log 2>&1; cat gpurun_out/chunk_sweep.log ;;
 esac
