@@ -79,6 +79,12 @@ saveexp)   # tools/exp/save_store_variants.sh: forward-save with the tape stores
 soak)      # determinism / race soak of the fused render and of the generator step (default and AMP-class)
   timeout 900 python tools/soak_render.py --iters ${SOAK_ITERS:-100} > gpurun_out/soak_render.log 2>&1; tail -12 gpurun_out/soak_render.log
   timeout 600 python tools/soak_gstep.py ${SOAK_STEPS:-300} > gpurun_out/soak_gstep.log 2>&1; tail -3 gpurun_out/soak_gstep.log ;;
+gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
+  rm -rf gpurun_out/gtl; mkdir -p gpurun_out/gtl
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtl -o gtl -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 1 --size 128 --skip-eager --iters 4 ${GTL_ARGS:-}) > gpurun_out/gtl/run.log 2>&1
+  python tools/gstep_timeline.py gpurun_out/gtl ${GTL_STEP:-4} > gpurun_out/gstep_timeline.txt 2>&1
+  find gpurun_out/gtl -type f -size +2M -delete
+  tail -45 gpurun_out/gstep_timeline.txt ;;
 gstep)
   timeout 600 python tools/chunk_sweep.py > gpurun_out/chunk_sweep.log 2>&1; cat gpurun_out/chunk_sweep.log ;;
 esac
