@@ -85,6 +85,13 @@ gtimeline)   # per-launch timeline of one generator step (kernel trace only, no 
   python tools/gstep_timeline.py gpurun_out/gtl ${GTL_STEP:-4} > gpurun_out/gstep_timeline.txt 2>&1
   find gpurun_out/gtl -type f -size +2M -delete
   tail -45 gpurun_out/gstep_timeline.txt ;;
+wgradexp)   # tools/exp/wgrad_sq_variants.sh built the libexp_Q_*.so here; time them on one backward chunk
+  for v in "" Q_NOSTORE Q_NOSIN Q_NOMFMA Q_NOFRAG ""; do
+    if [ -z "$v" ]; then lib=$PWD/fenerf_amd/libfenerf_hip.so; else lib=$PWD/fenerf_amd/libexp_$v.so; fi
+    [ -f "$lib" ] || continue
+    echo -n "variant ${v:-shipped}: "; FENERF_LIB=$lib timeout 200 python tools/time_wgrad.py 2>&1 | tail -1
+  done > gpurun_out/wgradexp.log 2>&1
+  cat gpurun_out/wgradexp.log ;;
 gstep)
   timeout 600 python tools/chunk_sweep.py > gpurun_out/chunk_sweep.log 2>&1; cat gpurun_out/chunk_sweep.log ;;
 esac
