@@ -374,17 +374,26 @@ __device__ __forceinline__ void stage_split4(unsigned short* row0_m, const float
 
 struct Frag16 { bf16x8 hi, lo; };
 
-// 4 waves (2 x 2 over the 8 x 8 output tiles; 4 x 4 tiles = 256 accumulator AGPRs each, one wave per SIMD).
+// waves per workgroup of the kernel below (see its header)
+template <int H> struct SqWaves { static constexpr int value = H >= 256 ? 8 : 4; };
+
+// NW waves over the NB x NB output tiles.  H = 256: EIGHT waves (4 x 2; 2 x 4 tiles = 128 accumulator registers each, 246 in all), two
+// per SIMD.  Rounds 1-2 ran four waves (2 x 2; 4 x 4 tiles = 256 accumulator AGPRs, one wave per SIMD): measured on one backward chunk,
+// that kernel's time was its MFMA time PLUS its read time (no MFMAs: - 32 %; profiles/r03_wgrad_sq_experiment.txt) -- a single in-order
+// wave per SIMD lets the matrix pipe and the memory pipe take turns.  With a second wave on the SIMD one multiplies while the other
+// stages or waits: 1.00 -> 0.91 ms on noise gradients, 0.75 -> 0.68 ms per chunk inside the generator step (5.4 -> 5.9 TB/s), same LDS
+// traffic (fragment reads per MFMA unchanged), bit-identical sums per output element (same k order).  H < 256: four waves.
 // The LDS image is double-buffered: while the MFMAs of tile t read buffer t & 1, tile t + 1 (already in registers) is staged
 // -- sin, split, LDS writes -- into the other buffer, half a dump group at a time BETWEEN the dependent MFMAs of each
 // accumulator group, and every dump group's registers are refilled with tile t + 2 as soon as they have been staged: one
 // barrier per tile, loads in flight for a whole tile period.  (Staged in a phase of its own, the kernel spent 30 % of a
 // tile in staging and another 30 % waiting for loads that had only the MFMA phase to arrive.)
-template <int H>
-__global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams P) {
+template <int H, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradParams P) {
   constexpr int NB = H / 32, NG = H / 8;                  // output tiles per side; dump groups per tile
-  constexpr int GPW = NG >= 4 ? NG / 4 : 1;               // dump groups staged per wave
-  constexpr int WGK = 2, WM = (NB + 1) / 2, WK = (NB + 1) / 2;
+  constexpr int GPW = NG >= NW ? NG / NW : 1;             // dump groups staged per wave
+  constexpr int WGM = NW / 2, WGK = 2;                    // wave grid over the NB x NB output tiles
+  constexpr int WM = (NB + WGM - 1) / WGM, WK = (NB + 1) / 2;
   constexpr int NGROUP = WM * WK;                         // accumulator groups (6 dependent MFMAs each) per wave and tile
   constexpr int HPG = (2 * GPW + NGROUP - 1) / NGROUP;    // staging half-pieces (a dump group's dtheta or tape rows) per group
   constexpr int IMG = 2 * H * WG_LD;                      // dwords per buffer: [A rows | B rows]
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
   const int chunk = blockIdx.x, img = blockIdx.y;
   const int l = P.layer0 + blockIdx.z, lb = l - 1;
   const int L = P.L;
-  for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
+  for (int i = tid; i < H; i += NW * 64) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
   __syncthreads();
 
   const int t_per = (P.tiles_per_image + P.nchunk - 1) / P.nchunk;
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_sq_bf16_kernel(WgradParams
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
   const int m = lane & 31, half = lane >> 5;
-  static_assert(4 * GPW == NG, "every wave stages GPW dump groups");
+  static_assert(NW * GPW == NG, "every wave stages GPW dump groups");
 
   float4 va[GPW], vb[GPW];                                  // dump group q of the tile being staged next: dtheta_l, tape_{l-1}
   // No branches from here on: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative (it
@@ -875,10 +884,11 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
 
 template <int H>
 int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
-  auto kfn = siren_wgrad_sq_bf16_kernel<H>;
+  constexpr int NW = SqWaves<H>::value;
+  auto kfn = siren_wgrad_sq_bf16_kernel<H, NW>;
   const size_t lds = (size_t)(4 * H * WG_LD + 2 * H) * sizeof(float);     // two [A | B] images + FiLM rows
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
-  hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(NW * 64), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad bf16 launch");
 }
@@ -896,7 +906,7 @@ int launch_sq_b16d(const WgradParams& p, int nz, hipStream_t st) {
 }  // namespace
 
 int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
-  // one workgroup per CU (110 KB LDS, 512 registers): size the grid of the (L-1)*B square jobs to whole rounds of the
+  // one workgroup per CU (110 KB LDS, the whole register file): size the grid of the (L-1)*B square jobs to whole rounds of the
   // machine -- 39 chunks gave 780 workgroups = 3.05 rounds on 256 CUs, i.e. a fourth round 5 % full.
   const long long jobs = (long long)(m->L - 1) * B;
   long long best = 1;
