@@ -124,11 +124,20 @@ struct WgShape {
   static constexpr int NB = H / 32;
   static constexpr int MT = (JOB == WG_HEAD || JOB == WG_RGB) ? 1 : NB;
   static constexpr int KT = (JOB == WG_SQ || JOB == WG_HEAD || JOB == WG_RGB) ? NB : (JOB == WG_C0X ? 2 : 1);
+  // Three-row operands (warped coordinates, view direction, rgb gradient rows) are contracted on the VALU -- thread = the H-side row,
+  // three dot products over the tile's 32 points (~100 FMAs + 32 LDS reads per thread).  On the matrix pipe they are padded to a 32-row
+  // tile: 128 exact-fp32 MFMAs = 2,048 cycles per wave and tile for 24,576 useful MACs.  L0 / RGB have no MFMA left; colour layer 0
+  // keeps one column tile (the 32 grid features) instead of two.
+  static constexpr bool V3 = (JOB == WG_L0 || JOB == WG_RGB || JOB == WG_C0X) && H <= 256;
+  static constexpr bool V3_ONLY = V3 && JOB != WG_C0X;
+  static constexpr bool V3_OWN_A = JOB != WG_RGB;                // the thread's own row comes from the A image (d theta); RGB: from B (x)
+  static constexpr int V3_ROW0 = JOB == WG_C0X ? 32 : 0;         // first of the three rows in the other image
+  static constexpr int KT_MFMA = (V3 && JOB == WG_C0X) ? 1 : KT;
   // wave grid: SQ 2x2 (big tiles); A-tall thin jobs 4x1; B-wide thin jobs 1x4
   static constexpr int WGM = (JOB == WG_SQ) ? 2 : ((MT >= 4) ? 4 : 1);
   static constexpr int WGK = 4 / WGM;
   static constexpr int WM = (MT + WGM - 1) / WGM;
-  static constexpr int WK = (KT + WGK - 1) / WGK;
+  static constexpr int WK = (KT_MFMA + WGK - 1) / WGK;
   static constexpr bool A_DUMP = (JOB == WG_SQ || JOB == WG_L0 || JOB == WG_C0X);
   static constexpr bool B_DUMP = (JOB == WG_SQ || JOB == WG_HEAD || JOB == WG_RGB);
   static constexpr int A_ROWS = MT * 32, B_ROWS = KT * 32;
@@ -171,6 +180,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / S::WGK) * S::WM, wk0 = (wave % S::WGK) * S::WK;
   float s0 = 0.f;              // head row sums (thread = row)
+  float acc3[3] = {0.f, 0.f, 0.f};   // V3 jobs: this thread's three dot products
 
   float4 va[NQ], vb[NQ];
   uint4 va16[Dump16<H>::PER_THREAD];
@@ -252,6 +262,24 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
         for (int q = 0; q < 8; ++q) { const float4 a = ar[q]; s0 += (a.x + a.y) + (a.z + a.w); }
       }
     }
+    // ---- three-row operands on the VALU (WgShape::V3)
+    if constexpr (S::V3) {
+      if (tid < H) {
+        const float4* own = reinterpret_cast<const float4*>((S::V3_OWN_A ? A_s : B_s) + tid * WG_LD);
+        const float4* thin = reinterpret_cast<const float4*>((S::V3_OWN_A ? B_s : A_s) + S::V3_ROW0 * WG_LD);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 o = own[q];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 w = thin[c * (WG_LD / 4) + q];
+            acc3[c] = __builtin_fmaf(o.x, w.x, acc3[c]); acc3[c] = __builtin_fmaf(o.y, w.y, acc3[c]);
+            acc3[c] = __builtin_fmaf(o.z, w.z, acc3[c]); acc3[c] = __builtin_fmaf(o.w, w.w, acc3[c]);
+          }
+        }
+      }
+    }
+    if constexpr (!S::V3_ONLY)
     // ---- MFMA: lane (i, kh) contracts points 16 kh + s, s = 0..15.  Operand fragments are read from LDS one
     //      (mt, kt) group ahead of their 16 MFMAs (1024 cycles), so no LDS latency is exposed.
     {
@@ -262,7 +290,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
         for (int q = 0; q < 4; ++q) { const float4 v = r[q]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
       };
       auto a_tile = [&](int mt) { return (wm0 + mt < S::MT) ? wm0 + mt : S::MT - 1; };   // waves beyond the tile grid recompute
-      auto b_tile = [&](int kt) { return (wk0 + kt < S::KT) ? wk0 + kt : S::KT - 1; };   // the last tile (not stored)
+      auto b_tile = [&](int kt) { return (wk0 + kt < S::KT_MFMA) ? wk0 + kt : S::KT_MFMA - 1; };   // the last tile (not stored)
       float a_cur[16], b_cur[16], a_nxt[16], b_nxt[16];
       frag(A_s, a_tile(0), a_cur);
       frag(B_s, b_tile(0), b_cur);
@@ -295,16 +323,27 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
     const int zi = (JOB == WG_SQ) ? bz : 0;
     float* out = P.partial + (((size_t)zi * P.B + img) * P.nchunk + chunk) * (size_t)(S::A_ROWS * S::B_ROWS);
     const int col = lane & 31, hh = lane >> 5;
+    if constexpr (S::V3) {
+      if (tid < H) {
 #pragma unroll
-    for (int mt = 0; mt < S::WM; ++mt)
+        for (int c = 0; c < 3; ++c) {
+          if (S::V3_OWN_A) out[(size_t)tid * S::B_ROWS + S::V3_ROW0 + c] = acc3[c];   // [H rows][B_ROWS]: three columns (the reduction reads no padding)
+          else out[(size_t)c * S::B_ROWS + tid] = acc3[c];                             // [32][H columns]: rows 0..2
+        }
+      }
+    }
+    if constexpr (!S::V3_ONLY) {
 #pragma unroll
-      for (int kt = 0; kt < S::WK; ++kt)
-        if (wm0 + mt < S::MT && wk0 + kt < S::KT)
+      for (int mt = 0; mt < S::WM; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
-          }
+        for (int kt = 0; kt < S::WK; ++kt)
+          if (wm0 + mt < S::MT && wk0 + kt < S::KT_MFMA)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (wm0 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              out[(size_t)row * S::B_ROWS + (wk0 + kt) * 32 + col] = acc[mt][kt][r];
+            }
+    }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
   }
 }
