@@ -966,7 +966,10 @@ int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
   // two workgroups per CU (41-74 KB of LDS, <= 164 registers each): single-buffered, they need the second one to keep
   // loads in flight while the first stages and multiplies (measured 578 -> 460 us for the four jobs; three: 443 us, but the
   // partial reductions grow with the chunk count)
-  long long n = (2LL * m->num_cus + B - 1) / B;
+#ifndef FENERF_THIN_WGS
+#define FENERF_THIN_WGS 2
+#endif
+  long long n = ((long long)FENERF_THIN_WGS * m->num_cus + B - 1) / B;
   if (n > tiles_per_image) n = tiles_per_image;
 #ifndef FENERF_THIN_CAP
 #define FENERF_THIN_CAP 256
