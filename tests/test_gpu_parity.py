@@ -1704,6 +1704,36 @@ def test_forward_save_and_chain_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
 
 
+def test_weight_gradient_kernels_are_run_to_run_deterministic():
+    """fenerf_siren_param_grads sums in a fixed order (per-chunk partials, then one reduction: no atomics).  With the eight-wave square
+    kernel (two waves per SIMD, double-buffered LDS image, one barrier per tile) and the thin jobs' VALU rows a missing barrier or a
+    buffer reused too early would show as run-to-run differences: 12 repetitions at H = 256, two images of 2,112 points (66 tiles each,
+    ragged chunks), every gradient tensor bit for bit -- default operands and the bf16 dump."""
+    spec = proc.model_spec("texture", hidden_dim=256, grid_size=8, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=3, sigma_gain=40.0, with_mapping=False)
+    B, P = 2, 2112
+    g = torch.Generator(device=DEV).manual_seed(7)
+    pts = (torch.rand((B, P, 3), device=DEV, generator=g) - 0.5) * 0.24
+    dirs = torch.randn((B, P, 3), device=DEV, generator=g)
+    film = {k: torch.tensor(v, device=DEV) for k, v in proc.film_params(spec, B, seed=4).items()}
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    for min_pts in (0, 1):
+        nat = native.NativeModel(sd, spec, DEV, "f16x3", differentiable=True, wgrad_bf16_min_points=min_pts)
+        out, tape, tape_e = nat.siren_forward_save(pts, dirs, *args)
+        d_out = torch.randn(out.shape, device=DEV, generator=g)
+        d_t, _ = nat.siren_backward(B, P, *args, out, d_out, tape)
+        flat = lambda r: [t for k in sorted(r) for t in (r[k] if isinstance(r[k], list) else [r[k]])]
+        ref = [t.clone() for t in flat(nat.siren_param_grads(pts, dirs, *args, out, d_out, tape, tape_e, d_t))]
+        assert all(torch.isfinite(t).all() for t in ref) and sum(float(t.abs().sum()) for t in ref) > 0
+        bad = 0
+        for _ in range(12):
+            got = flat(nat.siren_param_grads(pts, dirs, *args, out, d_out, tape, tape_e, d_t))
+            bad += 0 if all(torch.equal(a, b) for a, b in zip(got, ref)) else 1
+        print(f"[parity] weight-gradient determinism ({'bf16 dump' if min_pts else 'fp32-class operands'}): {bad} of 12 repetitions differ over {len(ref)} tensors")
+        assert bad == 0
+        nat.close()
+
+
 def test_backward_api_rejects_bad_arguments():
     """Error behaviour of the differentiable entry points: a model created without the backward stream, point counts that
     are not whole tiles, a half-filled gradient struct -- negative status + message, never a launch."""
