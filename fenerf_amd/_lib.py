@@ -110,6 +110,9 @@ _SIGS = {
     "fenerf_siren_backward": (_i, [_vp, _i, _i64] + [_vp] * 11),
     "fenerf_siren_grad_workspace_bytes": (_sz, [_vp, _i, _i64]),
     "fenerf_siren_param_grads": (_i, [_vp, _i, _i64] + [_vp] * 11 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
+    "fenerf_siren_film_sums_floats": (_sz, [_vp, _i, _i64]),
+    "fenerf_siren_backward_film": (_i, [_vp, _i, _i64] + [_vp] * 10),
+    "fenerf_siren_film_grads": (_i, [_vp, _i, _i64] + [_vp] * 5 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_grid_backward": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "fenerf_siren_backward_fuses_grid": (_i, [_vp]),
     "fenerf_siren_backward_grid": (_i, [_vp, _i, _i64] + [_vp] * 13),

@@ -658,6 +658,59 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16w(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
 
+extern "C" size_t fenerf_siren_film_sums_floats(const FenerfModel* m, int B, int64_t P) {
+  if (!m || B <= 0 || P <= 0) return 0;
+  // one [L][2][H] block per unit of the chain kernel's FiLM sums: its workgroup's 128 points where an oct cannot straddle images, else a wave's 16
+  const long long total = (long long)B * P, unit = bwd16w_film_unit(total, P);
+  return (size_t)film_tile_floats((total + unit - 1) / unit, m->L, m->H);
+}
+
+// Inversion (inverse_render_double_semantic.py:324-410 optimises only the FiLM offsets): the chain without its d(theta) dump and without
+// d(grid features) -- the per-tile FiLM sums are all fenerf_siren_film_grads needs.
+extern "C" int fenerf_siren_backward_film(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                          const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                          const float* tape, float* film_sums, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (m->precision != FENERF_PREC_F16X3)
+    return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_backward_film: FENERF_PREC_F16X3 models only (the exact-fp32 jobs take their FiLM sums from the dump)");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (P == 0) return FENERF_OK;
+  if (!out || !d_out || !tape || !film_sums) return fail(FENERF_E_INVALID, "NULL pointer");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  SirenBwdParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.stream = m->d_bwd_stream;
+  bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
+  bp.fp = fp; bp.pp = pp;
+  bp.P = (long long)B * P; bp.pts_per_image = P;
+  bp.out = out; bp.d_out = d_out; bp.tape = tape;
+  bp.d_t = nullptr; bp.d_e = nullptr;          // no dump, no d(grid features)
+  bp.film_tiles = film_sums;
+  PhaseScope ph(PH_CHAIN, stream);
+  return launch_siren_backward16w(m, bp, stream);
+}
+
+extern "C" int fenerf_siren_film_grads(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                       const float* freq_app, const float* phase_app, const float* film_sums,
+                                       const FenerfSirenGrads* g, void* workspace, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (m->precision != FENERF_PREC_F16X3) return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_film_grads: FENERF_PREC_F16X3 models only");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (P == 0) return FENERF_OK;
+  if (!film_sums || !g || !workspace) return fail(FENERF_E_INVALID, "NULL pointer");
+  if (!g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
+  const float *fp, *pp;
+  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  return launch_param_grads(m, B, P, nullptr, nullptr, fp, pp, nullptr, nullptr, nullptr, nullptr, nullptr, *g, true, workspace, stream, film_sums);
+}
+
 extern "C" int fenerf_siren_backward_fuses_grid(const FenerfModel* m) {
   return m && m->differentiable && m->grid_ch && m->precision == FENERF_PREC_F16X3;
 }

@@ -153,7 +153,7 @@ int bwd16w_film_unit(long long total_points, long long pts_per_image);   // poin
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream);
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles = nullptr);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
 int launch_composite(const CompositeParams& p, bool merge, void* stream);

@@ -350,6 +350,8 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
   const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
 
+  // fenerf_siren_backward_film (inversion: only the FiLM sums are wanted): no d(theta) dump, no d(grid features)
+  const bool dump = P.d_t != nullptr;
   int tpar = 0;   // parity of the tape staging buffers (advances per stage when NB is odd)
   for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
     // a wave past the last tile repeats the last tile: same loads, same values, same stores (no guard in the stream loop)
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
           q.t = t_rgb[nb][rt];
           o2[rt] = epi_compute<BD>(acc, q, zh[nb], zl[nb], rt);
-          if (!BD) st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o2[rt].dt);
+          if (!BD && dump) st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o2[rt].dt);
           const f32x2 s = {row_sum4(o2[rt].dt, k.b0, k.b1), row_sum4(o2[rt].dtt, k.b0, k.b1)};
           if (WGS) fs_write(nb % 3, rt, s);
           else st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   if ((it & 1) == 0) {
                     if constexpr (nb > 0) {
                       eo[rt] = epi_compute<BD>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
-                      if constexpr (!BD) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt);
+                      if constexpr (!BD) { if (dump) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt); }
                       else if (rt == 1) dump_bf16(k, nb - 1, eo, true);
                     }
                     // the tape block two n-blocks ahead of its use: (lo, nb + 1), or the next stage's n-block 0; the last
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const EpiIn q = epi_read<FILM_F / 4>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
           o2[rt] = epi_compute<BD>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
           const EpiOut& o = o2[rt];
-          if (!BD) st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt);
+          if (!BD) { if (dump) st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt); }
           else if (rt == 1) dump_bf16(k, NBODY - 1, o2, true);
           const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
           if (WGS) {
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
             __builtin_amdgcn_wave_barrier();
             if (vf != 0.f) scat_next = 0;     // scattered by the bodies of the next stage (run_stage) / the tile's end
             __builtin_amdgcn_wave_barrier();
-          } else {
+          } else if (P.d_e) {
             float* ep = P.d_e + pt * 32 + 16 * (lq >> 5) + 4 * ((lq >> 4) & 1);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {

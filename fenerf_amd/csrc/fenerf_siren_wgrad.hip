@@ -1075,10 +1075,10 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
 
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream) {
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles) {
   WgradParams p;
   memset(&p, 0, sizeof(p));
-  p.tape = tape; p.d_t = d_t; p.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
+  p.tape = tape; p.d_t = d_t; p.film_tiles = film_tiles ? film_tiles : d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
   p.fp = fp; p.pp = pp; p.bias = m->d_consts + CONST_FILM_BIAS;
   p.inv = m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr;
   p.box_scale = m->box_scale;

@@ -395,6 +395,41 @@ class NativeModel:
                                                         _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
 
+    def film_only_native(self):
+        """fenerf_siren_backward_film / fenerf_siren_film_grads exist for this model (f16x3 handles)"""
+        return self.precision == "f16x3" and self.differentiable
+
+    def siren_backward_film(self, B, P, fg, pg, fa, pa, out, d_out, tape):
+        """Inversion: the chain without its d(theta) dump -> the per-tile FiLM sums (opaque; for siren_film_grads)."""
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        out, d_out = _f32(out, self.device), _f32(d_out, self.device)
+        l = _lib.lib()
+        sums = torch.empty((int(l.fenerf_siren_film_sums_floats(self._h, B, P)),), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(l.fenerf_siren_backward_film(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape),
+                                                    _ptr(sums), C.c_void_p(ws.data_ptr()), _stream()))
+        return sums
+
+    def siren_film_grads(self, B, P, fg, pg, fa, pa, film_sums):
+        """FiLM sums -> {d_freq_geo, d_phase_geo [B, n_geo*H], d_freq_app, d_phase_app [B, n_color*H]} (gradients wrt the RAW parameters)."""
+        sp = self.spec
+        H, ng, nc = sp["hidden_dim"], sp["n_geo"], sp["n_color"]
+        dev = self.device
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        res = dict(d_freq_geo=new(B, ng * H), d_phase_geo=new(B, ng * H), d_freq_app=new(B, nc * H), d_phase_app=new(B, nc * H))
+        g = _lib.FenerfSirenGrads()
+        for k in res:
+            setattr(g, k, res[k].data_ptr())
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
+            ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
+            _lib.check(l.fenerf_siren_film_grads(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(film_sums), C.byref(g),
+                                                 C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
+        return res
+
     def siren_backward_grid(self, B, P, fg, pg, fa, pa, out, d_out, tape, points, d_grid_cl):
         """siren_backward whose gradient wrt the sampled grid features is scattered (accumulated) straight into d_grid_cl
         [D,H,W,32] (zero-initialised by the caller before the first chunk) -> d_t.  f16x3 models scatter inside the chain kernel;

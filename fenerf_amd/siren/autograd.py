@@ -101,6 +101,20 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
         chunks = [(b, min(per, nB - b), 0, Pp) for b in range(0, nB, per)]
     else:
         chunks = [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
+    if film_only and nat.film_only_native():
+        # Inversion on an f16x3 model: the chain writes only its per-tile FiLM sums (fenerf_siren_backward_film) -- no d(theta) dump,
+        # so there is nothing to bound and every launch covers as many whole images as the kernel's 32-bit tile arithmetic allows
+        per = max(1, (1 << 24) // Pp)
+        rows = {k: [] for k in FILM_KEYS}
+        for b in range(0, nB, per):
+            nb = min(per, nB - b)
+            film_c = tuple(t[b:b + nb] for t in film)
+            tape_c = tape[b * Pp * LH:(b + nb) * Pp * LH]
+            sums = nat.siren_backward_film(nb, Pp, *film_c, out[b:b + nb], d_out[b:b + nb], tape_c)
+            r = nat.siren_film_grads(nb, Pp, *film_c, sums)
+            for k in FILM_KEYS:
+                rows[k].append(r[k])
+        return {k: (torch.cat(v, 0) if len(v) > 1 else v[0]) for k, v in rows.items()}, None
     total, film_rows = None, {k: [] for k in FILM_KEYS}
     acc_img = None           # FiLM gradients of the image whose point ranges are being walked
     for b, nb, s, n in chunks:

@@ -334,6 +334,21 @@ int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, const float
                              const FenerfSirenGrads* grads, void* workspace, void* film_ws, void* stream);
 int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e, float* d_grid_cl,
                          void* stream);
+/* Inversion steps (inverse_render_double_semantic.py:324-410: the weights are frozen, only the per-image FiLM offsets take gradients;
+ * what torch autograd does there is the same backward as in training with the weight-gradient products dropped).  FENERF_PREC_F16X3
+ * models only (FENERF_E_UNSUPPORTED otherwise -- use fenerf_siren_backward + fenerf_siren_param_grads with NULL weight pointers):
+ *   fenerf_siren_backward_film   the backward chain WITHOUT its d(theta) dump and without d(grid features): writes only the per-tile
+ *                                FiLM sums, film_sums [fenerf_siren_film_sums_floats(m, B, P)] floats (opaque) -- no 11-KB-per-point
+ *                                buffer, so a whole pass can be one launch;
+ *   fenerf_siren_film_grads      film_sums -> d_freq_* / d_phase_* of `grads` (its weight / bias pointers are ignored); workspace as for
+ *                                fenerf_siren_param_grads. */
+size_t fenerf_siren_film_sums_floats(const FenerfModel* m, int B, int64_t P);
+int fenerf_siren_backward_film(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                               const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                               const float* tape, float* film_sums, void* film_ws, void* stream);
+int fenerf_siren_film_grads(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                            const float* freq_app, const float* phase_app, const float* film_sums,
+                            const FenerfSirenGrads* grads, void* workspace, void* film_ws, void* stream);
 /* fenerf_siren_backward + fenerf_grid_backward in one call: d_t as above, and the gradient wrt the sampled grid features is
  * scattered (accumulated) into d_grid_cl [D][H][W][32] -- grid_sample's backward (siren.py:314-330) -- instead of being returned.
  * points [B*P][3] as given to the forward.  Models whose chain kernel scatters in place (fenerf_siren_backward_fuses_grid != 0:

@@ -1704,6 +1704,38 @@ def test_forward_save_and_chain_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("H,B,P", [(256, 1, 4224), (256, 2, 2080), (64, 3, 1024)])
+def test_inversion_chain_without_the_dump_equals_the_full_backward(H, B, P):
+    """fenerf_siren_backward_film + fenerf_siren_film_grads (inversion: no d(theta) dump, no d(grid features)) against
+    fenerf_siren_backward + fenerf_siren_param_grads with NULL weight pointers: the FiLM sums are produced by the same instructions and
+    gathered by the same kernels, so the four FiLM gradients must be BIT-identical -- with workgroup-combined sums (one image, or points per
+    image a multiple of 128) and with per-wave sums (2,080 points per image).  An exact-fp32 model refuses (its FiLM sums come from the dump)."""
+    spec = proc.model_spec("texture", hidden_dim=H, grid_size=8, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=6, sigma_gain=60.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV, "f16x3", differentiable=True)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    pts = (torch.rand((B, P, 3), device=DEV, generator=g) - 0.5) * 0.24
+    dirs = torch.randn((B, P, 3), device=DEV, generator=g)
+    film = {k: torch.tensor(v, device=DEV) for k, v in proc.film_params(spec, B, seed=2).items()}
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    out, tape, tape_e = nat.siren_forward_save(pts, dirs, *args)
+    d_out = torch.randn(out.shape, device=DEV, generator=g)
+    d_t, _ = nat.siren_backward(B, P, *args, out, d_out, tape)
+    ref = nat.siren_param_grads(pts, dirs, *args, out, d_out, tape, tape_e, d_t, film_only=True)
+    assert nat.film_only_native()
+    sums = nat.siren_backward_film(B, P, *args, out, d_out, tape)
+    got = nat.siren_film_grads(B, P, *args, sums)
+    for k in ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app"):
+        assert torch.isfinite(got[k]).all() and float(ref[k].abs().max()) > 0
+        assert torch.equal(got[k], ref[k]), k
+    print(f"[parity] inversion chain without the dump H={H} B={B} P={P}: FiLM gradients bit-identical; FiLM sums {sums.numel() * 4 / 1e6:.2f} MB "
+          f"instead of a {d_t.numel() * 4 / 1e6:.1f} MB dump")
+    exact = native.NativeModel(sd, spec, DEV, "f32", differentiable=True)
+    assert not exact.film_only_native()
+    with pytest.raises(RuntimeError, match="F16X3"):
+        exact.siren_backward_film(B, P, *args, out, d_out, tape)
+
+
 def test_weight_gradient_kernels_are_run_to_run_deterministic():
     """fenerf_siren_param_grads sums in a fixed order (per-chunk partials, then one reduction: no atomics).  With the eight-wave square
     kernel (two waves per SIMD, double-buffered LDS image, one barrier per tile) and the thin jobs' VALU rows a missing barrier or a
