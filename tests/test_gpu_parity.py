@@ -780,6 +780,91 @@ def test_generator_step_at_configs2_shape_B6_128_24p24():
           f"finite, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB")
 
 
+class _PerImageDraws(VR.TorchDraws):
+    """Every draw is generated image by image from a seed of (call number, global image id): image b of a batch sees exactly the draws
+    it sees when rendered alone (`images` = the global ids of the batch being rendered)."""
+
+    def __init__(self):
+        self.images, self.calls = [0], 0
+
+    def _blocks(self, shape, device, fn):
+        self.calls += 1
+        n = len(self.images)
+        assert shape[0] % n == 0, (shape, n)
+        out = []
+        for b in self.images:
+            g = torch.Generator(device=device).manual_seed(1000003 * self.calls + b)
+            out.append(fn((shape[0] // n,) + tuple(shape[1:]), g))
+        return torch.cat(out, 0)
+
+    def rand(self, shape, device):
+        return self._blocks(tuple(shape), device, lambda sh, g: torch.rand(sh, device=device, generator=g))
+
+    def randn(self, shape, device):
+        return self._blocks(tuple(shape), device, lambda sh, g: torch.randn(sh, device=device, generator=g))
+
+    def normal_candidates(self, shape, device):
+        return self.randn(shape, device)
+
+    def coin(self):
+        return 0.25
+
+
+def test_generator_step_at_configs2_is_the_sum_of_its_six_images():
+    """A size-independent property that pins VALUES at configs[2]'s full size: the micro-batch step (6 images in one forward_save /
+    chain / weight-gradient pass each, 24 backward chunks) must equal the six single-image steps -- pixels of image b bit for bit (the
+    arithmetic of a sample does not depend on which workgroup evaluates it), every parameter gradient the sum of the six (fp32 sums in a
+    different grouping: <= 5e-6 of the tensor's largest entry)."""
+    gen, cur, curriculums = _curriculum_generator()
+    gen.train()
+    md = {**curriculums.extract_metadata(cur, 60000), "img_size": 128, "num_steps": 24, "nerf_noise": 0.5}
+    B = 6
+    g0 = torch.Generator(device=DEV).manual_seed(5)
+    zg, za = torch.randn(B, 256, device=DEV, generator=g0), torch.randn(B, 256, device=DEV, generator=g0)
+    w = torch.randn((B, 21, 128, 128), device=DEV, generator=g0)
+    with torch.no_grad():       # the mapping networks are torch GEMMs (batch-size dependent rounding): one evaluation, sliced per image
+        fg, pg = gen.siren.geo_mapping_network(zg)
+        fa, pa = gen.siren.app_mapping_network(za)
+    draws = _PerImageDraws()
+    gen.draws = draws
+    params = {k: p for k, p in gen.named_parameters() if "mapping_network" not in k}
+
+    def step(ids):
+        for p in params.values():
+            p.grad = None
+        draws.images, draws.calls = list(ids), 0
+        film = [t[ids].clone().requires_grad_(True) for t in (fg, fa, pg, pa)]
+        px, _ = gen.forward_with_frequencies(*film, **md)
+        (px * w[ids]).sum().backward()
+        grads = {k: p.grad.detach().clone() for k, p in params.items()}
+        for name, t in zip(("film.freq_geo", "film.freq_app", "film.phase_geo", "film.phase_app"), film):
+            grads[name] = t.grad.detach().clone()
+        return px.detach().clone(), grads
+
+    px6, g6 = step(list(range(B)))
+    calls6 = draws.calls
+    acc = None
+    for b in range(B):
+        px1, g1 = step([b])
+        assert draws.calls == calls6
+        assert torch.equal(px1[0], px6[b]), f"image {b}: pixels differ between the batch render and the single render"
+        for k in [k for k in g1 if k.startswith("film.")]:      # per-image gradients: row b of the batch's
+            full = torch.zeros_like(g6[k])
+            full[b] = g1[k][0]
+            g1[k] = full
+        acc = g1 if acc is None else {k: acc[k] + g1[k] for k in acc}
+    worst, wk = 0.0, None
+    for k in g6:
+        scale = float(g6[k].abs().max())
+        assert scale > 0, k
+        e = float((g6[k] - acc[k]).abs().max()) / scale
+        if e > worst:
+            worst, wk = e, k
+    print(f"[parity] configs[2] micro-batch (6 x 128x128 x 24+24) = sum of its six single-image steps: pixels bit-identical per image, "
+          f"worst gradient difference over {len(g6)} tensors {worst:.2e} ({wk})")
+    assert worst <= 5e-6
+
+
 # ---------------------------------------------------------------------------------------------------
 # single-latent pi-GAN generator (ImplicitGenerator3d + SPATIALSIRENBASELINE, curriculum `CelebA`) end to end
 # ---------------------------------------------------------------------------------------------------
