@@ -148,11 +148,14 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
     w = torch.randn((B, spec["output_dim"] - 1, S, S), device=dev)
     params = [p for n, p in mod.named_parameters() if "mapping_network" not in n]
 
+    bump = min(params, key=lambda t: t.numel())
+
     def step():
         for p in params:
             p.grad = None
         with torch.no_grad():
-            params[0].add_(0)            # version bump like optimizer.step(): the packed streams are rebuilt on the device
+            bump.add_(0)                 # version bump like optimizer.step() (on the smallest tensor: the optimizer itself is not timed):
+                                         # the packed streams are rebuilt on the device
         px, _ = gen.forward_with_frequencies(film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], **kw)
         (px * w).sum().backward()
 
