@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r3.sh [tests] [newtests] [bench] [prof] [pmc] [probe] [saveexp] [gstep]'
+# Round-3 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r3.sh [tests] [newtests] [bench] [benchq] [prof] [pmc] [pmcgstep] [probe] [saveexp] [wgradexp] [soak] [gtimeline] [gstep]'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
