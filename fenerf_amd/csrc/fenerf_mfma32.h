@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fenerf_layout.h"
+#include "fenerf_trig.h"
 
 namespace fenerf {
 
@@ -12,10 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// sin(2*pi*t), t in revolutions: v_sin_f32 (does its own range reduction).  Measured on MI355X
-// (tools/probe/probe.hip): max abs error 1.2e-7 for |t| <= 45 revolutions -- tighter than a degree-9 polynomial
-// evaluated in fp32 (2.1e-7) and one quarter-rate instruction instead of thirteen.
-__device__ __forceinline__ float sin2pi(float t) { return __builtin_amdgcn_sinf(t); }
+// sin2pi / cos2pi (revolutions, any finite magnitude): fenerf_trig.h
 
 struct Ring {
   float4 w[FENERF_PF];

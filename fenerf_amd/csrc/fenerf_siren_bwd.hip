@@ -22,7 +22,6 @@
 
 namespace fenerf {
 
-__device__ __forceinline__ float cos2pi(float t) { return __builtin_amdgcn_cosf(t); }   // v_cos_f32, revolutions
 
 struct TapeNB { float a[16]; };
 // pre-FiLM accumulators of n-block nb for this lane from the forward's register dump (fenerf_layout.h "Tape"):

@@ -37,6 +37,7 @@
 
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_trig.h"
 
 namespace fenerf {
 namespace bw16 {
@@ -258,9 +259,9 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   [[maybe_unused]] float xs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float th = __builtin_fmaf(f[r], t[r], p[r]);
-    const float dt = acc[r] * __builtin_amdgcn_cosf(th);
-    if (BD) xs[r] = __builtin_amdgcn_sinf(th);
+    const float th = rev_reduce(__builtin_fmaf(f[r], t[r], p[r]));      // fenerf_trig.h: the forward's reduction, bit for bit
+    const float dt = acc[r] * cos_rev_reduced(th);
+    if (BD) xs[r] = sin_rev_reduced(th);
     o.dt[r] = dt;
     o.dtt[r] = dt * t[r];
     const float dz = dt * (f[r] * TWO_PI);

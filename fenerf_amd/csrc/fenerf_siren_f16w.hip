@@ -31,6 +31,7 @@
 #include "fenerf_film.h"
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_trig.h"
 
 
 namespace fenerf {
@@ -201,8 +202,8 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
   // x = sin(2 pi theta); carried as hi = rn_f16(16 x), lo = rn_f16(16 x - hi).  Written as fmas on x so that each half is ONE
   // v_fma_mix{lo,hi}_f16 (fp32 fma, one rounding to f16; 16 x and 16 x - hi are exact in fp32, so the values are those of the
   // mul / convert / subtract / convert spelling): 8 VALU per two values instead of 14.
-  const float s0 = __builtin_amdgcn_sinf(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x));
-  const float s1 = __builtin_amdgcn_sinf(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y));
+  const float s0 = sin2pi(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x));
+  const float s1 = sin2pi(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y));
   const _Float16 h0 = (_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, 0.f), h1 = (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, 0.f);
   half2 hp = {h0, h1}, lp = {(_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, -(float)h0), (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, -(float)h1)};
   // pinned here: without a use in this block the compiler sinks the whole epilogue behind the stage (the outputs are only

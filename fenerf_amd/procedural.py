@@ -125,14 +125,26 @@ def make_state_dict(spec, seed=0, sigma_gain=1.0, with_mapping=True):
     return sd
 
 
-def film_params(spec, batch, seed=0, scale=1.0):
+def film_params(spec, batch, seed=0, scale=1.0, phase_rev=0.0, freq0_gain=1.0):
     """Raw (pre '*15+30') frequencies / phase shifts in the range the mapping nets emit
-    at init (f = 15 f_raw + 30 in ~[13, 49])."""
+    at init (f = 15 f_raw + 30 in ~[13, 49]).
+
+    Beyond init -- what inversion (inverse_render_double_semantic.py:370-410: Adam on unconstrained offsets) or a trained
+    checkpoint may produce, and what torch.sin in the reference's FiLMLayer (siren.py:113-123) takes in its stride:
+    `phase_rev` > 0 adds a uniform phase shift of up to +-phase_rev REVOLUTIONS (2 pi phase_rev radians) to every FiLM layer;
+    `freq0_gain` multiplies the effective frequency 15 f + 30 of the first FiLM layer (whose pre-activation W0 x + b is O(1),
+    so its sine argument reaches ~ freq0_gain * 6 revolutions; the deeper layers' pre-activations are O(0.1))."""
     H = spec["hidden_dim"]
     ng, nc = spec["n_geo"] * H, spec["n_color"] * H
     out = {}
     for name, n in (("freq_geo", ng), ("phase_geo", ng), ("freq_app", nc), ("phase_app", nc)):
         out[name] = normal(f"film.{name}", (batch, n), 0.4 * scale, seed)
+    if phase_rev:
+        for name, n in (("phase_geo", ng), ("phase_app", nc)):
+            out[name] = (out[name] + uniform(f"film.{name}.rev", (batch, n), -2.0 * np.pi * phase_rev, 2.0 * np.pi * phase_rev, seed)).astype(np.float32)
+    if freq0_gain != 1.0:
+        f0 = out["freq_geo"][:, :H].astype(np.float64)
+        out["freq_geo"][:, :H] = (((15.0 * f0 + 30.0) * freq0_gain - 30.0) / 15.0).astype(np.float32)
     return out
 
 

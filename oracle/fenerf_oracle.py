@@ -260,13 +260,15 @@ def get_local_coordinates(global_coords, local_grid_length, preserve_y=True):
 # ---------------------------------------------------------------------------
 # a10 FiLMLayer                         siren/siren.py:113-123
 # ---------------------------------------------------------------------------
-def film_layer(x, w, b, freq, phase):
+def film_layer(x, w, b, freq, phase, rev_tap=None):
     """sin(freq * (x W^T + b) + phase); freq/phase [B,H] broadcast over the point axis, or [B,P,H] taken per point
-    (FiLMLayer skips the broadcast when the shapes agree, siren.py:119-122: SPATIALSIRENGRID's per-point modulation)."""
+    (FiLMLayer skips the broadcast when the shapes agree, siren.py:119-122: SPATIALSIRENGRID's per-point modulation).
+    rev_tap: optional list that receives max|sine argument| of the layer in REVOLUTIONS (tests: how far beyond the init range)."""
     y = x @ w.T.astype(x.dtype) + b.astype(x.dtype)
-    if freq.ndim == 3:
-        return np.sin(freq * y + phase)
-    return np.sin(freq[:, None, :] * y + phase[:, None, :])
+    th = freq * y + phase if freq.ndim == 3 else freq[:, None, :] * y + phase[:, None, :]
+    if rev_tap is not None:
+        rev_tap.append(float(np.abs(th).max() / (2 * math.pi)))
+    return np.sin(th)
 
 
 # ---------------------------------------------------------------------------
@@ -275,9 +277,10 @@ def film_layer(x, w, b, freq, phase):
 BOX_SCALE = 2 / 0.24  # UniformBoxWarp(0.24), siren.py:181-187
 
 
-def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app=None, phase_app=None, dtype=np.float32):
+def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app=None, phase_app=None, dtype=np.float32, rev_tap=None):
     """points, ray_dirs [B,P,3]; raw frequencies/phases [B, n*H] (pre '*15+30').
-    Returns [B,P,output_dim] = [labels(18) | rgb(3) | sigma(1)] ('spatial': [rgb | sigma])."""
+    Returns [B,P,output_dim] = [labels(18) | rgb(3) | sigma(1)] ('spatial': [rgb | sigma]).
+    rev_tap: optional list, gets one max|sine argument| (revolutions) per FiLM layer."""
     H = spec["hidden_dim"]
     dt = np.dtype(dtype)
     P = lambda a: np.asarray(a).astype(dt)
@@ -288,12 +291,12 @@ def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app=None
     feats = sample_from_3dgrid(x, P(sd["spatial_embeddings"])) if spec["grid_ch"] else None
     for i in range(spec["n_geo"]):
         x = film_layer(x, P(sd[f"network.{i}.layer.weight"]), P(sd[f"network.{i}.layer.bias"]),
-                       fg[..., i * H:(i + 1) * H], pg[..., i * H:(i + 1) * H])
+                       fg[..., i * H:(i + 1) * H], pg[..., i * H:(i + 1) * H], rev_tap)
     sigma = x @ P(sd["final_layer.weight"]).T + P(sd["final_layer.bias"])
     if spec["kind"] == "spatial":
         c = np.concatenate([dirs, x], -1)
         c = film_layer(c, P(sd["color_layer_sine.layer.weight"]), P(sd["color_layer_sine.layer.bias"]),
-                       fg[..., -H:], pg[..., -H:])
+                       fg[..., -H:], pg[..., -H:], rev_tap)
         rgb = _sigmoid(c @ P(sd["color_layer_linear.0.weight"]).T + P(sd["color_layer_linear.0.bias"]))
         return np.concatenate([rgb, sigma], -1)
     fa = P(freq_app) * dt.type(15) + dt.type(30)
@@ -304,7 +307,7 @@ def siren_forward(sd, spec, points, ray_dirs, freq_geo, phase_geo, freq_app=None
     c = np.concatenate([dirs, feats, x], -1) if feats is not None else np.concatenate([dirs, x], -1)
     for i in range(spec["n_color"]):
         c = film_layer(c, P(sd[f"color_layer_sine.{i}.layer.weight"]), P(sd[f"color_layer_sine.{i}.layer.bias"]),
-                       fa[:, i * H:(i + 1) * H], pa[:, i * H:(i + 1) * H])
+                       fa[:, i * H:(i + 1) * H], pa[:, i * H:(i + 1) * H], rev_tap)
     rgb = _sigmoid(c @ P(sd["color_layer_linear.0.weight"]).T + P(sd["color_layer_linear.0.bias"]))
     return np.concatenate([labels, rgb, sigma], -1)
 

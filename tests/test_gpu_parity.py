@@ -430,11 +430,15 @@ def _full_weights():
     return spec, proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
 
 
-def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, slab=2048):
+def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, slab=2048, dtype=np.float32):
     """numpy oracle of the fused render on explicit rays: oo / dd [B,R,3], zz [B,R,N], uu [B*R,N] -> (pixels [B,R,22], depth [B,R],
-    the composited sample depths [B,R,M])"""
+    the composited sample depths [B,R,M]).  dtype=np.float64: the same statements in double precision on the same fp32 inputs (the
+    arbiter of test_resampling_flips_against_an_fp64_arbiter)."""
     B, R, N = zz.shape
     assert B == 1
+    if np.dtype(dtype) != np.float32:
+        oo, dd, zz = (a.astype(dtype) for a in (oo, dd, zz))
+        uu = uu.astype(dtype) if uu is not None else None
     px, dp, zs = [], [], []
     for s0 in range(0, R, slab):
         sl = slice(s0, min(R, s0 + slab))
@@ -442,11 +446,11 @@ def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, s
         n = z_.shape[1]
         pts = (o_[:, :, None, :] + d_[:, :, None, :] * z_[..., None]).reshape(B, -1, 3)
         dexp = np.broadcast_to(d_[:, :, None, :], (B, n, N, 3)).reshape(B, -1, 3)
-        coarse = O.siren_forward(sd, spec, pts, dexp, *args).reshape(B, n, N, -1)
+        coarse = O.siren_forward(sd, spec, pts, dexp, *args, dtype=dtype).reshape(B, n, N, -1)
         if hier:
             _, _, cw = O.fancy_integration(coarse, z_[..., None], clamp_mode="relu")
             zf = O.fine_z_from_coarse(cw, z_[..., None], uu[sl])
-            fine = O.siren_forward(sd, spec, (o_[:, :, None, :] + d_[:, :, None, :] * zf).reshape(B, -1, 3), dexp, *args).reshape(B, n, N, -1)
+            fine = O.siren_forward(sd, spec, (o_[:, :, None, :] + d_[:, :, None, :] * zf).reshape(B, -1, 3), dexp, *args, dtype=dtype).reshape(B, n, N, -1)
             ao, az = O.merge_sorted(fine, coarse, zf, z_[..., None])
         else:
             ao, az = coarse, z_[..., None]
@@ -521,6 +525,56 @@ def test_full_size_128_24p24_properties_and_oracle_all_rays(precision):
     _check_render_vs_oracle(f"128x128 24+24 H=256 [{precision}] vs oracle on ALL {R} rays", nat, (o, d, z, u), tf, opts, rgb, depth, r_rgb, r_depth, r_z)
 
 
+def test_resampling_flips_against_an_fp64_arbiter():
+    """DESIGN.md 2 says of a ray whose fine samples land in other bins than the fp32 oracle's: "both are valid evaluations of the same
+    algorithm".  That needs an arbiter: the oracle in fp64 on the same fp32 inputs (rays, draws, weights, FiLM parameters).  On the bench
+    image (all 16,384 rays, 128x128, 24+24, H = 256 + 96^3 grid, |sigma| ~ 2000) a ray FLIPS against fp64 when its merged sample depths
+    differ from the fp64 ones by more than 1e-5.  Asserted, for both precisions:
+      * the native pipeline flips no more rays against fp64 than the fp32 oracle (= the reference's arithmetic) does, + 10 %;
+      * every native ray beyond 1e-3 of the fp64 pixel is a flip against fp64 (and there are at most 2, none beyond 2e-3);
+      * on rays that agree with fp64 in their sample positions: pixels <= 1e-3 and depth <= 2e-3, ALL of them;
+      * on rays that flip: the depth error stays below two coarse bins, and is no larger than the fp32 oracle's own worst flip + 10 %."""
+    import __graft_entry__ as ge
+    spec, sd = _full_weights()
+    B, S_, N = 1, 128, 24
+    R = S_ * S_
+    film = proc.film_params(spec, B, seed=0)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+    torch.manual_seed(0)
+    o, d, z, _, _ = VR.sample_rays(B, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((B * R, N), device=DEV)
+    opts = _lib.composite_opts("relu", fill_mode="seg_padding_background", fill_color="white")
+    px32, dp32, z32 = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white")
+    px64, dp64, z64 = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white", dtype=np.float64)
+    bin_w = (1.12 - 0.88) / (N - 1)
+    flip32 = np.abs(z32 - z64).max(-1) > 1e-5
+    e32, d32 = np.abs(px32 - px64).max(-1), np.abs(dp32 - dp64)
+    print(f"[parity] fp64 arbiter, fp32 oracle (the reference's arithmetic): {int(flip32.sum())} of {R} rays resample differently from fp64; "
+          f"pixel error on them {e32[flip32].max() if flip32.any() else 0:.2e}, elsewhere {e32[~flip32].max():.2e}; depth error on them "
+          f"{d32[flip32].max() if flip32.any() else 0:.2e}, elsewhere {d32[~flip32].max():.2e}")
+    for precision in PRECISIONS:
+        nat = native.NativeModel(sd, spec, DEV, precision)
+        rgb, depth, _, _ = nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
+        rgb, depth = N_(rgb), N_(depth)
+        zs = ge.nat_sorted_z(nat, o, d, z, u, tf, opts)
+        flip = np.abs(zs - z64).max(-1) > 1e-5
+        both = flip & flip32
+        err, derr = np.abs(rgb - px64).max(-1), np.abs(depth - dp64)
+        over = err > 1e-3
+        print(f"[parity] fp64 arbiter, native {precision}: {int(flip.sum())} rays resample differently from fp64 ({int(both.sum())} of them are the fp32 "
+              f"oracle's flips too); pixel error on them {err[flip].max() if flip.any() else 0:.2e}, elsewhere {err[~flip].max():.2e} "
+              f"({int(over.sum())} rays > 1e-3, {int((over & flip).sum())} of them flips); depth error on them {derr[flip].max() if flip.any() else 0:.2e} "
+              f"(one coarse bin = {bin_w:.4f}), elsewhere {derr[~flip].max():.2e}")
+        assert int(flip.sum()) <= int(1.1 * flip32.sum()) + 8, "the native pipeline resamples differently from fp64 more often than the reference's fp32 arithmetic does"
+        assert int(over.sum()) <= 2 and err.max() <= 2e-3 and not (over & ~flip).any()
+        assert err[~flip].max() <= 1e-3 and derr[~flip].max() <= 2e-3
+        if flip.any():
+            assert derr[flip].max() <= 2 * bin_w
+            assert derr[flip].max() <= 1.1 * (d32[flip32].max() if flip32.any() else 0.0) + 0.5 * bin_w
+        assert ((rgb[..., 0] == 1) == (px64[..., 0] == 1)).all(), "fill decisions agree with fp64 on every ray"
+
+
 # ---------------------------------------------------------------------------------------------------
 # a1-a5: HIP ray setup (fenerf_ray_setup) vs the reference's recorded rays
 # ---------------------------------------------------------------------------------------------------
@@ -568,8 +622,9 @@ def test_config5_256_48p48_and_config1_64_12():
         assert rgb.shape == (1, R, 22) and w.shape == (1, R, M) and np.isfinite(rgb).all()
         np.testing.assert_allclose(w.sum(-1), ws, atol=2e-5)
         assert ((ws < 0.9) == (rgb[..., 0] == 1)).all()
-        # oracle: every ray of the 64x64 image; 4,096 of the 65,536 rays of the 256x256 one (6 %; the whole image is 6.3 M points)
-        idx = np.arange(R) if R <= 4096 else np.sort(np.random.default_rng(2).choice(R, 4096, replace=False))
+        # oracle: EVERY ray of both images (round 4; the 256x256 one is 6.3 M points: ~80 s of numpy on the GPU box's host cores, in
+        # slabs of 2,048 rays)
+        idx = np.arange(R)
         ti = torch.as_tensor(idx, device=DEV)
         o_i, d_i, z_i, u_i = o[:, ti].contiguous(), d[:, ti].contiguous(), z[:, ti].contiguous(), (u[ti].contiguous() if hier else None)
         r_rgb, r_depth, r_z = _oracle_render_rays(sd, spec, args, N_(o_i), N_(d_i), N_(z_i), N_(u_i) if hier else None, "black", hier=hier)
@@ -1704,6 +1759,64 @@ def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
         assert max(errs[k] for k in through_dump) <= 6e-3 and rest <= 6e-5
 
 
+def test_grid_gradient_values_at_full_size_96cubed_grid():
+    """The 96^3 grid-gradient scatter (113 MB of float atomics fused into the chain kernel, siren.py:314-330's grid_sample backward) VALUE-
+    checked at the generator step's own size: bench model (H = 256 + 32 x 96^3 grid), the two passes of a 128 x 128 x 24 image = 786,432
+    points = four production backward chunks.  The upstream gradient is non-zero only on a 2,048-ray slab that straddles a chunk
+    boundary (98,304 points over both passes), so the full-size backward must reproduce, voxel for voxel, the fp64 autograd gradient of
+    that slab alone -- and leave every voxel the slab does not touch at exactly zero.  All other gradient tensors ride along."""
+    from oracle import fenerf_oracle_grad as OG
+    from fenerf_amd.siren import autograd as SA
+    spec, sd = _full_weights()
+    mod = S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE(hidden_dim=256, z_geo_dim=8, z_app_dim=8, output_dim=22)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    mod.load_state_dict(tsd, strict=False)
+    mod.precision = "f16x3"
+    mod = mod.to(DEV)
+    S_, N = 128, 24
+    R = S_ * S_
+    torch.manual_seed(0)
+    o, d, z, _, _ = VR.sample_rays(1, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    zf = torch.sort(0.88 + 0.24 * torch.rand((1, R, N), device=DEV), -1)[0]             # stand-in fine depths (any depths do)
+    pts = torch.cat([(o[:, :, None, :] + d[:, :, None, :] * zz[..., None]).reshape(1, R * N, 3) for zz in (z, zf)], 0)   # [2 passes, R N, 3]
+    dirs = d[:, :, None, :].expand(1, R, N, 3).reshape(1, R * N, 3).expand(2, -1, -1).contiguous()
+    film = proc.film_params(spec, 1, seed=0)
+    film2 = {k: np.repeat(v, 2, 0) for k, v in film.items()}                          # both passes of one image share its FiLM block
+    film_t = {k: T(v).requires_grad_(True) for k, v in film2.items()}
+    r0, r1 = 7168, 9216                                                                # rays of the slab: points [172,032, 221,184) of each pass
+    assert r0 * N < SA.BACKWARD_CHUNK_POINTS < r1 * N
+    rng = np.random.default_rng(5)
+    g_slab = rng.normal(size=(2, (r1 - r0) * N, 22)).astype(np.float32)
+    g_slab[..., -1] *= 1e-3                                                            # sigma is ~2000 x the other outputs in this model
+    g_out = torch.zeros((2, R * N, 22), device=DEV)
+    g_out[:, r0 * N:r1 * N] = T(g_slab)
+    out = mod.forward_with_frequencies_phase_shifts(pts, film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], dirs)
+    (out * g_out).sum().backward()
+    g_nat = N_(mod.spatial_embeddings.grad)
+    # fp64 autograd on the slab alone, in pieces of 8,192 points (gradients are sums over points)
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
+    film64 = {k: t64(v).requires_grad_(True) for k, v in film2.items()}
+    p_slab, d_slab = N_(pts[:, r0 * N:r1 * N]), N_(dirs[:, r0 * N:r1 * N])
+    for s0 in range(0, p_slab.shape[1], 8192):
+        sl = slice(s0, s0 + 8192)
+        ref = OG.siren_forward(sd64, spec, t64(p_slab[:, sl]), t64(d_slab[:, sl]), film64["freq_geo"], film64["phase_geo"], film64["freq_app"], film64["phase_app"])
+        (ref * t64(g_slab[:, sl])).sum().backward()
+    g_ref = sd64["spatial_embeddings"].grad.numpy()
+    touched_ref, touched_nat = np.abs(g_ref).max(1) > 0, np.abs(g_nat).max(1) > 0
+    e_grid = _rel_err(g_nat, g_ref)
+    named = dict(mod.named_parameters())
+    errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film2}
+    errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
+    worst = max(errs, key=errs.get)
+    print(f"[parity] 96^3 grid gradient at full size (786,432 points, 4 backward chunks, upstream gradient on a 2,048-ray slab): "
+          f"{int(touched_nat.sum())} voxels touched (fp64 autograd of the slab alone: {int(touched_ref.sum())}), relative error (max-norm) "
+          f"{e_grid:.2e}; stray non-zero voxels {int((touched_nat & ~touched_ref).sum())}; worst of all {len(errs)} gradient tensors {errs[worst]:.2e} ({worst})")
+    assert not (touched_nat & ~touched_ref).any(), "a voxel the slab does not touch received gradient"
+    assert e_grid <= 6e-5 and errs[worst] <= 6e-5
+
+
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 96), ("baseline", 64, 0, 1, 64), ("texture", 128, 4, 3, 160),
                                              ("texture", 256, 6, 2, 224), ("texture", 256, 6, 1, 4224)])
 def test_bf16_dump_layout_at_small_point_counts(kind, H, grid, B, P):
@@ -2174,3 +2287,122 @@ def test_merge_composite_and_render_beyond_128_samples():
     u = torch.rand((B * S_ * S_, N), device=DEV)
     rgb, depth, _, _ = nat.render(o, d, z, u, None, None, *tf, _lib.composite_opts("relu"), hierarchical=True)
     assert rgb.shape == (B, S_ * S_, 21) and torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# FiLM arguments beyond the init range (round 4): torch.sin in the reference's FiLMLayer (siren.py:113-123) takes fp32 radians of any
+# magnitude; v_sin_f32 / v_cos_f32 are only defined on +-256 revolutions (beyond: sin = 0, cos = 1, silently).  Every kernel family
+# reduces its argument exactly first (fenerf_trig.h).  Bar: |native - fp64| <= ulp_fp32(largest sine argument) * 2 pi -- the error
+# one fp32 rounding of the argument makes, which the reference's own fp32 radians carry too (the fp32 numpy oracle is reported beside).
+# ---------------------------------------------------------------------------------------------------
+REVS = [45, 120, 250, 257, 400, 1000]
+
+
+def _big_film(spec, B, rev, seed=1):
+    """FiLM parameters whose sine arguments reach ~rev revolutions in EVERY layer (phase shifts) and in layer 0 through its frequency too"""
+    return proc.film_params(spec, B, seed=seed, phase_rev=float(rev), freq0_gain=max(1.0, rev / 10.0))
+
+
+def _arg_ulp_2pi(rev_max):
+    return float(np.spacing(np.float32(rev_max))) * 2 * np.pi
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("rev", REVS)
+def test_siren_forward_with_sine_arguments_far_beyond_init(rev, precision):
+    """f32 forward (siren_kernel) and f16x3 forward (siren16w_kernel), H = 256 + grid, 2,000 points (ragged tiles), vs the fp64 oracle."""
+    spec = proc.model_spec("texture", hidden_dim=256, grid_size=16)
+    sd = proc.make_state_dict(spec, seed=1, sigma_gain=1.0, with_mapping=False)
+    nat = native.NativeModel(sd, spec, DEV, precision)
+    rng = np.random.default_rng(rev)
+    B, P = 2, 1000
+    pts = rng.uniform(-0.12, 0.12, (B, P, 3)).astype(np.float32)
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = _big_film(spec, B, rev)
+    a = tuple(film[k] for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    out = N_(nat.siren_forward(T(pts), T(dirs), *(T(v) for v in a)))
+    tap = []
+    o64 = O.siren_forward(sd, spec, pts, dirs, *a, dtype=np.float64, rev_tap=tap)
+    o32 = O.siren_forward(sd, spec, pts, dirs, *a)
+    bound = _arg_ulp_2pi(max(tap))
+    e, e32 = np.abs(out - o64), np.abs(o32 - o64)
+    print(f"[parity] sine domain {precision} forward, arguments up to {max(tap):.0f} rev (layer 0) / {sorted(tap)[-2]:.0f} rev (others): "
+          f"max|err| vs fp64 rgb {e[..., -4:-1].max():.2e} labels {e[..., :-4].max():.2e} sigma {e[..., -1].max():.2e}; fp32 numpy oracle "
+          f"{e32.max():.2e}; bound ulp(arg) 2 pi = {bound:.2e}")
+    assert np.isfinite(out).all() and e.max() <= bound
+
+
+@pytest.mark.parametrize("rev", REVS)
+def test_pointwise_and_local_kernels_with_sine_arguments_far_beyond_init(rev):
+    """fenerf_siren_forward_pointwise (explicit per-point FiLM) and fenerf_siren_forward_local (per-point mapping network + SIREN in
+    one launch): SPATIALSIRENGRID whose mapping network emits phase shifts of up to +-rev revolutions (its output bias), vs fp64."""
+    torch.manual_seed(3)
+    H = 64
+    mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=16, hidden_dim=H, output_dim=4).to(DEV).eval()
+    mod.device = torch.device(DEV)
+    last = mod.mapping_network.network[-1]
+    half = last.bias.numel() // 2
+    with torch.no_grad():
+        last.bias[half:] += T(proc.uniform("map.bias.rev", (half,), -2 * np.pi * rev, 2 * np.pi * rev, seed=rev))
+    B, P = 2, 700
+    g_ = torch.Generator(device=DEV).manual_seed(4)
+    pts = (torch.rand((B, P, 3), device=DEV, generator=g_) - 0.5) * 0.24
+    dirs = torch.nn.functional.normalize(torch.randn((B, P, 3), device=DEV, generator=g_), dim=-1)
+    lat = torch.randn((B, 32, 32, 32), device=DEV, generator=g_)
+    with torch.no_grad():
+        fused = mod.forward_with_latent_grid(pts, lat, dirs)
+        sampled = mod.sample_local_latents(lat, mod.gridwarper(pts))
+        f, p = mod.mapping_network(sampled)
+        local = mod.get_local_coordinates(pts, 32, preserve_y=False)
+        explicit = mod.forward_with_frequencies_phase_shifts(local, f, p, dirs)
+    # fp64: the mapping network and the SIREN on the same fp32 inputs (sampled latents, local coordinates)
+    sd = mod._state_numpy()
+    spec = mod._spec()
+    msd = {"m.network." + n: N_(q) for n, q in mod.mapping_network.network.named_parameters()}
+    f64, p64 = O.mapping_network({k: v.astype(np.float64) for k, v in msd.items()}, "m", N_(sampled).astype(np.float64))
+    tap = []
+    o_fused = O.siren_forward(sd, spec, N_(local), N_(dirs), f64, p64, dtype=np.float64, rev_tap=tap)
+    # the explicit route is given the fp32 FiLM tensors torch computed: its fp64 reference takes exactly those
+    o_expl = O.siren_forward(sd, spec, N_(local), N_(dirs), N_(f), N_(p), dtype=np.float64)
+    bound = _arg_ulp_2pi(max(tap))
+    e_f, e_x = np.abs(N_(fused) - o_fused).max(), np.abs(N_(explicit) - o_expl).max()
+    print(f"[parity] sine domain per-point FiLM, arguments up to {max(tap):.0f} rev: pointwise kernel vs fp64 {e_x:.2e}, one-launch local kernel "
+          f"(phase shifts computed in-kernel in fp32: one more rounding of a ~{max(tap):.0f}-rev value) {e_f:.2e}; bound ulp(arg) 2 pi = {bound:.2e}")
+    assert e_x <= bound and e_f <= 2 * bound
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("rev", REVS)
+def test_siren_backward_with_sine_arguments_far_beyond_init(rev, precision):
+    """Chain kernels (cos of the recomputed phase) and weight-gradient kernels (sin recomputed from the tape) -- fp32 and bf16x3
+    families -- vs fp64 autograd of the restatement, FiLM arguments up to ~rev revolutions.  A gradient carries the argument error
+    through cos / sin like the forward does: bound = the suite's fp32-class 2e-4 + 4 ulp(arg) 2 pi, relative (max-norm)."""
+    from oracle import fenerf_oracle_grad as OG
+    kind, H, grid, B, P = "texture", 64, 5, 2, 300
+    mod, spec, sd = _siren_module(kind, H, grid, precision=precision, sigma_gain=1.0)
+    rng = np.random.default_rng(rev)
+    pts = rng.uniform(-0.12, 0.12, (B, P, 3)).astype(np.float32)
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = _big_film(spec, B, rev, seed=4)
+    g_out = rng.normal(size=(B, P, spec["output_dim"])).astype(np.float32)
+    film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+    out = mod.forward_with_frequencies_phase_shifts(T(pts), film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], T(dirs))
+    (out * T(g_out)).sum().backward()
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
+    film64 = {k: t64(v).requires_grad_(True) for k, v in film.items()}
+    ref = OG.siren_forward(sd64, spec, t64(pts), t64(dirs), film64["freq_geo"], film64["phase_geo"], film64["freq_app"], film64["phase_app"])
+    (ref * t64(g_out)).sum().backward()
+    tap = []
+    O.siren_forward(sd, spec, pts, dirs, film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"], dtype=np.float64, rev_tap=tap)
+    bound = 2e-4 + 4 * _arg_ulp_2pi(max(tap))
+    named = dict(mod.named_parameters())
+    errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film}
+    errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
+    worst = max(errs, key=errs.get)
+    fe = np.abs(N_(out) - ref.detach().numpy()).max()
+    print(f"[parity] sine domain {precision} backward, arguments up to {max(tap):.0f} rev: forward-save vs fp64 {fe:.2e}; worst relative gradient "
+          f"error over {len(errs)} tensors {errs[worst]:.2e} ({worst}); bound {bound:.2e}")
+    assert fe <= _arg_ulp_2pi(max(tap)) and errs[worst] <= bound
