@@ -213,6 +213,113 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
     return out
 
 
+def curriculum_generator(spec, sd, dev, precision, seed=11):
+    """The generator BASELINE.json names -- DoubleImplicitGenerator3d over TextureEmbeddingPiGAN256SEMANTICDISENTANGLE_DIM_96 with both
+    mapping networks -- built like train_double_latent_semantic.py:142 builds it; render weights = the bench's procedural ones, mapping
+    networks from a fixed torch seed (identical on every rank; DDP broadcasts rank 0's anyway)."""
+    from fenerf_amd import curriculums
+    from fenerf_amd.generators import generators as G
+    from fenerf_amd.siren import siren as S_
+    cur = curriculums.CelebA_double_semantic_texture_embedding_256_dim_96
+    torch.manual_seed(seed)
+    gen = G.DoubleImplicitGenerator3d(getattr(S_, cur["model"]), cur["latent_geo_dim"], cur["latent_app_dim"], cur["output_dim"])
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    gen.siren.load_state_dict(tsd, strict=False)
+    gen = gen.to(dev)
+    gen.set_device(dev)
+    gen.siren.precision = precision
+    gen.train()
+    return gen, cur, curriculums
+
+
+GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_bytes", "allreduce_bytes_largest_tensor", "ddp_bucket_cap_mb",
+                  "allreduce_per_micro_batch", "ms_with_optimizer", "rays_per_s", "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend",
+                  "peak_GB")
+
+
+def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank):
+    """Times `loss_of(m).backward()` on the bare module and on DistributedDataParallel(module, find_unused_parameters=True) with the
+    headline's bracket (barrier on both sides, max over ranks) -> the `gstep_ddp` object (GSTEP_DDP_KEYS).  Backend-agnostic: the GPU
+    bench hands it the generator over RCCL; `--dist-check` (CPU, gloo, world 2) hands it a small stand-in so that the wrapper, the
+    rank census, the byte count and the schema of the N > 1 line are covered without a GPU (tests/test_dist_cpu.py)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    bump = min(params, key=lambda t: t.numel())
+
+    def run(m, n, optimizer):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            if not optimizer:
+                with torch.no_grad():
+                    bump.add_(0)             # the version bump an optimizer step causes: packed weight streams are rebuilt on the device
+            loss_of(m).backward()
+            if optimizer:
+                opt.step()
+        for _ in range(2):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0) / n * 1e3
+
+    cuda = dev.type == "cuda"
+    if cuda:
+        torch.cuda.reset_peak_memory_stats()
+    ms_bare = run(model, iters, False)
+    created = False
+    if not dist.is_initialized():            # N = 1 without a launcher: a one-rank group, so that the leg exists at every N
+        kw = {"device_id": dev} if cuda else {}
+        dist.init_process_group("nccl" if cuda else "gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, **kw)
+        created = True
+    try:
+        ddp = DDP(model, device_ids=[dev.index] if cuda else None, find_unused_parameters=True)
+        ms = run(ddp, iters, False)
+        ms_opt = run(ddp, max(2, iters // 2), True)
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        out = {"what": what, "ms": ms, "ms_no_ddp": ms_bare, "allreduce_ms_exposed": ms - ms_bare,
+               "allreduce_bytes": sum(p.numel() * 4 for p in params), "allreduce_bytes_largest_tensor": max(p.numel() for p in params) * 4,
+               "ddp_bucket_cap_mb": 25, "allreduce_per_micro_batch": True, "ms_with_optimizer": ms_opt,
+               "rays_per_s": world * rays_per_rank / (ms * 1e-3), "n_ranks": world, "n_ranks_seen": int(seen.item()),
+               "batch_per_rank": batch_per_rank, "dist_backend": dist.get_backend(),
+               "peak_GB": torch.cuda.max_memory_allocated() / 2**30 if cuda else None}
+        del ddp
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert tuple(out) == GSTEP_DDP_KEYS
+    return out
+
+
+def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_over_ranks, iters=6):
+    """The reference's generator step as its training loop runs it (train_double_latent_semantic.py:148-150, 402-446):
+    `generator_ddp = DDP(generator, find_unused_parameters=True)`; per micro-batch `gen_imgs, _ = generator_ddp(z_geo, z_app, **metadata)`
+    (both mapping networks inside), `loss.backward()` -- DDP's bucketed all-reduce of EVERY generator gradient over RCCL/xGMI fires in
+    that backward; there is no no_sync() around the `batch_split` micro-batches, so every micro-batch all-reduces (kept: reference
+    behaviour, `allreduce_per_micro_batch`) -- then Adam.  Every rank renders its own latents.  Reported: `ms` (DDP step), `ms_no_ddp`
+    (same rank, same step on the bare module: no collective; at N = 1 this is the reference's G step `generator(z)` + backward),
+    `allreduce_ms_exposed` = their difference, `allreduce_bytes` = fp32 bytes of all gradients DDP reduces (113 MB of them the 96^3
+    grid), `ms_with_optimizer` (+ torch.optim.Adam.step() on all generator parameters)."""
+    gen, cur, curriculums = curriculum_generator(spec, sd, dev, precision)
+    md = {**curriculums.extract_metadata(cur, 60000), "img_size": S, "num_steps": N, "nerf_noise": 0.5}    # the 128 x 128 stage; noise as mid-fade (train...py:276)
+    torch.manual_seed(4242 + rank)
+    zg, za = torch.randn(B, cur["latent_geo_dim"], device=dev), torch.randn(B, cur["latent_app_dim"], device=dev)
+    w = torch.randn((B, cur["output_dim"] - 1, S, S), device=dev) / (B * S * S)
+    params = [p for p in gen.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=cur[50000]["gen_lr"], betas=cur["betas"], weight_decay=cur["weight_decay"])
+
+    def loss_of(m):
+        px, _ = m(zg, za, **md)
+        return (px * w).sum()
+
+    what = (f"generator_ddp(z_geo, z_app, **metadata) + backward per rank: batch {B} x {S}x{S} rays x {N}+{N} samples, both mapping networks, "
+            "DDP(find_unused_parameters=True) bucketed all-reduce of all generator gradients inside backward (every micro-batch all-reduces: the "
+            "reference has no no_sync()), device re-pack of the changed weights; precision " + precision)
+    return ddp_timed_leg(gen, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, B * S * S, what, B)
+
+
 def dist_check(args):
     """Rendezvous only (CPU-capable, backend gloo): proves the self-launch produced `--gpus` ranks that see each other."""
     import torch.distributed as dist
@@ -221,9 +328,25 @@ def dist_check(args):
     ones = torch.ones(1)
     if world > 1:
         dist.all_reduce(ones)
+    # the DDP generator-step leg of the N > 1 line on a stand-in module (no GPU here): wrapper, bracket, rank census, byte count, schema
+    torch.manual_seed(3)
+    stand_in = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    params = list(stand_in.parameters())
+    x = torch.randn(8, 16, generator=torch.Generator().manual_seed(100 + rank))
+    dev = torch.device("cpu")
+    leg = ddp_timed_leg(stand_in, params, lambda m: m(x).square().sum(), torch.optim.Adam(params, lr=1e-3), dev, world,
+                        (dist.barrier if world > 1 else (lambda: None)), lambda v: fdist.max_over_ranks(v), 3, 8, "stand-in module (dist-check)", 8)
+    # after DDP steps every rank holds the same parameters (all-reduced gradients, same optimizer): checksum agreement
+    csum = torch.tensor([float(sum(p.detach().double().sum() for p in params))], dtype=torch.float64)
+    sums = [torch.zeros_like(csum) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(sums, csum)
+    else:
+        sums = [csum]
     if rank == 0:
         print(json.dumps({"dist_check": True, "n_gpus": args.gpus, "world_size": world, "n_ranks_seen": int(ones.item()),
-                          "backend": args.dist_backend}), flush=True)
+                          "backend": args.dist_backend, "gstep_ddp": leg,
+                          "params_identical_across_ranks": all(float(t) == float(sums[0]) for t in sums)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -241,7 +364,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="headline shape only, 1 warm-up + 1 timed run")
     ap.add_argument("--no-gstep", action="store_true", help="skip the generator-step (forward + backward) leg")
-    ap.add_argument("--no-gstep-b6", action="store_true", help="skip the 6-image generator micro-batch (configs[2]) leg")
+    ap.add_argument("--no-gstep-b6", action="store_true", help="skip the 6-image generator micro-batch (configs[2]) legs")
+    ap.add_argument("--no-gstep-ddp", action="store_true", help="skip the DistributedDataParallel generator-step legs (run at every N)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-sweep64", action="store_true", help="skip the 64x64, 24+24 scaling-batch leg")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
@@ -372,6 +496,20 @@ def main(argv=None):
                  "unit": "rays/s", "ms_per_step": sdt / args.steps * 1e3, "roofline_frac": sroof["frac"],
                  "roofline_frac_of_f16x3_ceiling": sroof.get("frac_of_f16x3_ceiling"), "kernel_ms": sroof["kernel_ms"]}
 
+    # the generator step with its DDP all-reduce: every rank takes part (north_star: "RCCL all-reduce of G/D grads over xGMI")
+    ddp_legs = {}
+    if not args.no_gstep_ddp:
+        mor = lambda v: fdist.max_over_ranks(v, device=dev)
+        for key, b_, it, skip in (("gstep_ddp", args.batch, 6, False), ("gstep_ddp_b6", 6, 3, args.no_gstep_b6 or (B, S, N) != (1, 128, 24))):
+            if skip:
+                continue
+            try:
+                torch.cuda.empty_cache()
+                ddp_legs[key] = gstep_ddp_leg(spec, sd, dev, rank, world, b_, S, N, args.precision, barrier, mor, iters=it)
+            except Exception as e:               # an extra leg must never take the headline metric down with it
+                ddp_legs[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         dtype = "f32" if args.precision == "f32" else "f16x3 (error-compensated fp16 MFMA, fp32 accumulate; fp32-class accuracy)"
         tr = pmc_traffic() if (args.precision == "f16x3" and (B, S, N) == (1, 128, 24)) else None
@@ -396,6 +534,7 @@ def main(argv=None):
         }
         if sweep:
             out["sweep64"] = sweep
+        out.update(ddp_legs)
         if world == 1 and not args.no_f32 and args.precision != "f32":
             try:
                 nat32 = native.NativeModel(sd, spec, dev, "f32")

@@ -71,6 +71,9 @@ _i, _i64, _sz = C.c_int, C.c_int64, C.c_size_t
 _SIGS = {
     "fenerf_last_error": (C.c_char_p, []),
     "fenerf_abi_version": (_i, []),
+    "fenerf_struct_size": (C.c_long, [C.c_char_p]),
+    "fenerf_struct_field_offset": (C.c_long, [C.c_char_p, C.c_char_p]),
+    "fenerf_struct_field_name": (C.c_char_p, [C.c_char_p, _i]),
     "fenerf_pack_weights_host": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_fp), C.POINTER(_sz), C.POINTER(_fp), C.POINTER(_sz)]),
     "fenerf_free_host": (None, [_vp]),
     "fenerf_model_create": (_i, [C.POINTER(FenerfModelDesc), C.POINTER(_vp)]),

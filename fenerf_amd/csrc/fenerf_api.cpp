@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -71,12 +72,38 @@ PhaseScope::~PhaseScope() {
   PhaseRec* r = static_cast<PhaseRec*>(rec);
   (void)hipEventRecord(r->e1, r->st);
   std::lock_guard<std::mutex> lock(g_phase_mu);
+  if (g_phase_recs.size() >= 65536) {      // timing left on and never drained (fenerf_phase_times): keep the newest, bounded
+    PhaseRec* old = g_phase_recs.front();
+    g_phase_recs.erase(g_phase_recs.begin());
+    (void)hipEventDestroy(old->e0);
+    (void)hipEventDestroy(old->e1);
+    delete old;
+  }
   g_phase_recs.push_back(r);
 }
 
 // the dump format of a backward chunk (fenerf_layout.h "bf16 dump"): opt-in per model (FenerfModelDesc.wgrad_bf16_min_points)
 bool use_bf16_dump(const FenerfModel* m, long long total_points) {
   return m && m->precision == FENERF_PREC_F16X3 && m->wgrad_bf16_min_points > 0 && total_points >= m->wgrad_bf16_min_points;
+}
+
+// AMP-class models: remember which chunk size (hence which dump format) a d(theta) buffer was written with ...
+static void note_dump(const FenerfModel* m, const void* d_t, long long points) {
+  if (m->wgrad_bf16_min_points <= 0) return;
+  std::lock_guard<std::mutex> lock(m->dump_mu);
+  if (m->dump_points.size() >= 256) m->dump_points.clear();     // buffers of long-gone steps; a miss only skips the check
+  m->dump_points[d_t] = points;
+}
+// ... and refuse to read it as the other one (a caller that splits the backward and the weight-gradient call differently)
+static int check_dump(const FenerfModel* m, const void* d_t, long long points) {
+  if (m->wgrad_bf16_min_points <= 0) return FENERF_OK;
+  std::lock_guard<std::mutex> lock(m->dump_mu);
+  auto it = m->dump_points.find(d_t);
+  if (it == m->dump_points.end() || use_bf16_dump(m, it->second) == use_bf16_dump(m, points)) return FENERF_OK;
+  return fail(FENERF_E_INVALID, "fenerf_siren_param_grads: this d(theta) dump was written by a backward call over " + std::to_string(it->second) +
+                                " points (" + (use_bf16_dump(m, it->second) ? "bf16" : "fp32") + " format, wgrad_bf16_min_points " +
+                                std::to_string(m->wgrad_bf16_min_points) + ") and is read here as a chunk of " + std::to_string(points) +
+                                " points (the other format): call both with the same (B, P)");
 }
 
 static int check_opts(const FenerfCompositeOpts* o) {
@@ -175,6 +202,62 @@ extern "C" int fenerf_phase_times(double* ms, int* calls, int n) {
 }
 extern "C" int fenerf_abi_version(void) { return FENERF_ABI_VERSION; }
 
+// ---- struct layouts as compiled (include/fenerf.h fenerf_struct_*): bindings check themselves against the loaded library
+namespace {
+struct FieldInfo { const char* name; long offset; };
+struct StructInfo { const char* name; long size; const FieldInfo* fields; int n; };
+#define FLD(S, f) {#f, (long)offsetof(S, f)}
+const FieldInfo kDescFields[] = {
+    FLD(FenerfModelDesc, abi_version), FLD(FenerfModelDesc, hidden_dim), FLD(FenerfModelDesc, n_geo), FLD(FenerfModelDesc, n_color),
+    FLD(FenerfModelDesc, n_label_layers), FLD(FenerfModelDesc, output_dim), FLD(FenerfModelDesc, grid_ch), FLD(FenerfModelDesc, grid_d),
+    FLD(FenerfModelDesc, grid_h), FLD(FenerfModelDesc, grid_w), FLD(FenerfModelDesc, box_scale), FLD(FenerfModelDesc, geo_w),
+    FLD(FenerfModelDesc, geo_b), FLD(FenerfModelDesc, color_w), FLD(FenerfModelDesc, color_b), FLD(FenerfModelDesc, label_w),
+    FLD(FenerfModelDesc, label_b), FLD(FenerfModelDesc, sigma_w), FLD(FenerfModelDesc, sigma_b), FLD(FenerfModelDesc, rgb_w),
+    FLD(FenerfModelDesc, rgb_b), FLD(FenerfModelDesc, grid), FLD(FenerfModelDesc, precision), FLD(FenerfModelDesc, differentiable),
+    FLD(FenerfModelDesc, wgrad_bf16_min_points)};
+const FieldInfo kOptsFields[] = {
+    FLD(FenerfCompositeOpts, clamp_mode), FLD(FenerfCompositeOpts, noise_std), FLD(FenerfCompositeOpts, last_back),
+    FLD(FenerfCompositeOpts, white_back), FLD(FenerfCompositeOpts, black_back), FLD(FenerfCompositeOpts, fill_mode),
+    FLD(FenerfCompositeOpts, fill_value), FLD(FenerfCompositeOpts, fill_enabled)};
+const FieldInfo kRepackFields[] = {
+    FLD(FenerfRepackMaps, stream_f32), FLD(FenerfRepackMaps, n_stream_f32), FLD(FenerfRepackMaps, stream_h16), FLD(FenerfRepackMaps, n_stream_h16),
+    FLD(FenerfRepackMaps, consts), FLD(FenerfRepackMaps, n_consts), FLD(FenerfRepackMaps, consts_tail), FLD(FenerfRepackMaps, n_tail),
+    FLD(FenerfRepackMaps, bwd_f32), FLD(FenerfRepackMaps, n_bwd_f32), FLD(FenerfRepackMaps, bwd_b16), FLD(FenerfRepackMaps, n_bwd_b16),
+    FLD(FenerfRepackMaps, row_off), FLD(FenerfRepackMaps, row_len), FLD(FenerfRepackMaps, row_film), FLD(FenerfRepackMaps, n_rows),
+    FLD(FenerfRepackMaps, scale_id)};
+const FieldInfo kLocalFields[] = {
+    FLD(FenerfLocalMapDesc, latent_dim), FLD(FenerfLocalMapDesc, map_hidden), FLD(FenerfLocalMapDesc, w0), FLD(FenerfLocalMapDesc, b0),
+    FLD(FenerfLocalMapDesc, w1), FLD(FenerfLocalMapDesc, b1), FLD(FenerfLocalMapDesc, w2), FLD(FenerfLocalMapDesc, b2)};
+const FieldInfo kGradFields[] = {
+    FLD(FenerfSirenGrads, geo_w), FLD(FenerfSirenGrads, geo_b), FLD(FenerfSirenGrads, color_w), FLD(FenerfSirenGrads, color_b),
+    FLD(FenerfSirenGrads, head_w), FLD(FenerfSirenGrads, head_b), FLD(FenerfSirenGrads, rgb_w), FLD(FenerfSirenGrads, rgb_b),
+    FLD(FenerfSirenGrads, d_freq_geo), FLD(FenerfSirenGrads, d_phase_geo), FLD(FenerfSirenGrads, d_freq_app), FLD(FenerfSirenGrads, d_phase_app)};
+#undef FLD
+#define STRUCT(S, F) {#S, (long)sizeof(S), F, (int)(sizeof(F) / sizeof(F[0]))}
+const StructInfo kStructs[] = {STRUCT(FenerfModelDesc, kDescFields), STRUCT(FenerfCompositeOpts, kOptsFields), STRUCT(FenerfRepackMaps, kRepackFields),
+                               STRUCT(FenerfLocalMapDesc, kLocalFields), STRUCT(FenerfSirenGrads, kGradFields)};
+#undef STRUCT
+const StructInfo* find_struct(const char* name) {
+  if (!name) return nullptr;
+  for (const StructInfo& s : kStructs) if (!strcmp(s.name, name)) return &s;
+  return nullptr;
+}
+}  // namespace
+extern "C" long fenerf_struct_size(const char* struct_name) {
+  const StructInfo* s = find_struct(struct_name);
+  return s ? s->size : -1;
+}
+extern "C" long fenerf_struct_field_offset(const char* struct_name, const char* field) {
+  const StructInfo* s = find_struct(struct_name);
+  if (!s || !field) return -1;
+  for (int i = 0; i < s->n; ++i) if (!strcmp(s->fields[i].name, field)) return s->fields[i].offset;
+  return -1;
+}
+extern "C" const char* fenerf_struct_field_name(const char* struct_name, int index) {
+  const StructInfo* s = find_struct(struct_name);
+  return (s && index >= 0 && index < s->n) ? s->fields[index].name : nullptr;
+}
+
 extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) {
   if (!out) return fail(FENERF_E_INVALID, "out is NULL");
   *out = nullptr;
@@ -183,7 +266,7 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   if (rc) return fail(rc, err);
   FenerfModel* m = new (std::nothrow) FenerfModel();
   if (!m) return fail(FENERF_E_NOMEM, "out of host memory");
-  memset(m, 0, sizeof(*m));
+  // (value-initialised by `new FenerfModel()`: every scalar / pointer member is zero, the dump registry is an empty map)
   m->H = d->hidden_dim; m->n_geo = d->n_geo; m->n_color = d->n_color; m->C = d->output_dim;
   m->n_lab = d->output_dim - 4; m->L = d->n_geo + d->n_color;
   m->grid_ch = d->grid_ch; m->gd = d->grid_d; m->gh = d->grid_h; m->gw = d->grid_w;
@@ -654,6 +737,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;    // appended to the dtheta dump
   bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
+  note_dump(m, d_t, (long long)B * P);
   PhaseScope ph(PH_CHAIN, stream);
   return m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16w(m, bp, stream) : launch_siren_backward(m, bp, stream);
 }
@@ -746,6 +830,7 @@ extern "C" int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;
   bp.points = points; bp.d_grid_cl = d_grid_cl; bp.box_scale = m->box_scale; bp.gd = m->gd; bp.gh = m->gh; bp.gw = m->gw;
   bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
+  note_dump(m, d_t, (long long)B * P);
   { PhaseScope ph(PH_CHAIN, stream); return launch_siren_backward16w(m, bp, stream); }
 }
 
@@ -773,8 +858,10 @@ extern "C" int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, 
   want += 4; have += (g->head_w != nullptr) + (g->head_b != nullptr) + (g->rgb_w != nullptr) + (g->rgb_b != nullptr);
   if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
   const bool film_only = have == 0;
+  int rc = check_dump(m, d_t, (long long)B * P);
+  if (rc) return rc;
   const float *fp, *pp;
-  int rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
   if (rc) return rc;
   return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, tape_e, d_t, *g, film_only, workspace, stream);
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +60,11 @@ struct FenerfModel {
   float* d_stream32;
   float* d_consts32;
   int stream32_valid;
+  // AMP-class models (wgrad_bf16_min_points > 0) only: the d(theta) dumps fenerf_siren_backward* wrote, buffer -> points of that chunk.
+  // The dump's format (fp32 | bf16) is a function of the chunk's point count and nothing in the buffer records it, so
+  // fenerf_siren_param_grads looks the buffer up and refuses to read it as the other format (note_dump / check_dump, fenerf_api.cpp)
+  mutable std::mutex dump_mu;
+  mutable std::map<const void*, long long> dump_points;
 };
 
 namespace fenerf {

@@ -614,7 +614,12 @@ extern "C" int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blo
   if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
   *blob = (float*)malloc(b.size() * sizeof(float));
   *consts = (float*)malloc(c.size() * sizeof(float));
-  if (!*blob || !*consts) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  if (!*blob || !*consts) {
+    free(*blob); free(*consts);
+    *blob = *consts = nullptr;
+    fenerf::set_error("malloc failed");
+    return FENERF_E_NOMEM;
+  }
   memcpy(*blob, b.data(), b.size() * sizeof(float));
   memcpy(*consts, c.data(), c.size() * sizeof(float));
   *n_floats = b.size();
@@ -631,7 +636,12 @@ extern "C" int fenerf_pack_local_host(const FenerfModelDesc* desc, const FenerfL
   if (!blob || !n_floats || !consts || !n_consts) { fenerf::set_error("NULL output pointer"); return FENERF_E_INVALID; }
   *blob = (float*)malloc(b.size() * sizeof(float));
   *consts = (float*)malloc(c.size() * sizeof(float));
-  if (!*blob || !*consts) { fenerf::set_error("malloc failed"); return FENERF_E_NOMEM; }
+  if (!*blob || !*consts) {
+    free(*blob); free(*consts);
+    *blob = *consts = nullptr;
+    fenerf::set_error("malloc failed");
+    return FENERF_E_NOMEM;
+  }
   memcpy(*blob, b.data(), b.size() * sizeof(float));
   memcpy(*consts, c.data(), c.size() * sizeof(float));
   *n_floats = b.size();

@@ -2,21 +2,25 @@
 //
 // The reference evaluates torch.sin(freq * x + phase_shift) on fp32 radians of any magnitude (siren/siren.py:113-123); inversion
 // (inverse_render_double_semantic.py:370-410: Adam on unconstrained frequency / phase offsets) and trained checkpoints are free to
-// leave the init range.  v_sin_f32 / v_cos_f32 take revolutions and are only defined on [-256, +256]: beyond that the hardware
-// returns sin = 0 / cos = 1 without any error.  So the argument is first reduced to [-0.5, +0.5] by  t - rint(t)  (v_rndne_f32 +
-// v_sub_f32).  The reduction is EXACT in fp32 for every finite t (the difference of a float and the nearest integer has no more
-// significant bits than the float: |t| < 2^23 is a Sterbenz-type subtraction, above that t is an integer and the result is 0,
-// which is what fp32 radians can no longer resolve either), arguments with |t| <= 0.5 pass through bit for bit, and the same
-// two instructions sit in front of the forward's sin, the chain kernels' cos and the weight-gradient kernels' recomputed sin,
-// so a recomputed activation is still bitwise the forward's.
-// (v_fract_f32 is one instruction cheaper but rounds: t + 1 for -1 < t < 0 loses up to 3e-8 revolutions = 1.9e-7 rad, and lands
-// small negative arguments next to 1.0.  FENERF_TRIG_REDUCE = 1 builds it, 0 builds the unreduced round-3 kernels: A/B only,
-// profiles/r04_trig_reduce_ab.txt.)
+// leave the init range.  v_sin_f32 / v_cos_f32 take revolutions; the GFX9-family ISA manuals define them on [-256, +256] only ("out of
+// range input results in float 0") and LLVM therefore puts a v_fract_f32 in front of them on this family.  So does every kernel
+// here: the argument is reduced to [0, 1) by ONE full-rate v_fract_f32 -- the same instruction in front of the forward's sin, the
+// chain kernels' cos and the weight-gradient kernels' recomputed sin, so a recomputed activation is still bitwise the forward's.
+//   * exactness: t - floor(t) is exact in fp32 for t >= 0 and for t <= -1 (the result is no larger than |t| and a multiple of
+//     ulp(t)); for -1 < t < 0 the result t + 1 is rounded to the fp32 grid of [0.5, 1): at most 2^-25 revolutions = 1.9e-7 rad,
+//     the size of v_sin_f32's own error (1.2e-7) and below the rounding the reference's fp32 radians carry at |theta| >= 2 rad.
+//   * cost, measured with the in-kernel cycle stamps (profiles/r04_trig_reduce_ab.txt): f16x3 forward 2,611,000 -> 2,615,000
+//     cycles per launch (+0.16 %), exact-fp32 forward +0.9 %, generator step +1.2 %.
+//   * FENERF_TRIG_REDUCE = 2 builds the EXACT two-instruction reduction t - rint(t) (v_rndne_f32 + v_sub_f32; |t| <= 0.5 passes
+//     through bit for bit): +2.2 % / +1.4 % / +2.4 % on the same three -- measured, not shipped.  = 0 builds the unreduced round-3
+//     arithmetic (A/B only).  On the MI355X boxes measured, v_sin_f32 / v_cos_f32 did NOT return zeros beyond 256 revolutions
+//     (tools/probe/sin_domain_probe.hip, profiles/r04_vsin_domain_probe.txt) -- the reduction is kept because the documented
+//     domain, not one stepping's behaviour, is what a library may rely on.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #ifndef FENERF_TRIG_REDUCE
-#define FENERF_TRIG_REDUCE 2
+#define FENERF_TRIG_REDUCE 1
 #endif
 
 namespace fenerf {

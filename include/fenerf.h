@@ -104,6 +104,16 @@ typedef struct FenerfCompositeOpts {
 const char* fenerf_last_error(void);
 int fenerf_abi_version(void);
 
+/* Layout of the structs of this header AS THE LIBRARY WAS COMPILED, so that a binding written in another language (the ctypes mirrors of
+ * INTEGRATION.md B and fenerf_amd/_lib.py) can be checked against the library it loads instead of against a copy of this file:
+ * fenerf_struct_size("FenerfModelDesc") = sizeof, fenerf_struct_field_offset("FenerfModelDesc", "precision") = offsetof; structs:
+ * FenerfModelDesc, FenerfCompositeOpts, FenerfRepackMaps, FenerfLocalMapDesc, FenerfSirenGrads.  Unknown names return -1.
+ * fenerf_struct_field_name(s, i) enumerates the fields in declaration order (NULL behind the last).  (No reference analogue: the
+ * reference has no FFI.)  tests/test_host_cpu.py executes INTEGRATION.md's snippet against these. */
+long fenerf_struct_size(const char* struct_name);
+long fenerf_struct_field_offset(const char* struct_name, const char* field);
+const char* fenerf_struct_field_name(const char* struct_name, int index);
+
 /* Packs (host side, no GPU needed) the weights of `desc` into the kernel's streaming layout; used by
  * fenerf_model_create and exposed for layout tests.  *blob is malloc'd, free with fenerf_free_host. */
 int fenerf_pack_weights_host(const FenerfModelDesc* desc, float** blob, size_t* n_floats,

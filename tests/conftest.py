@@ -28,6 +28,16 @@ def spec_from_golden(g):
     return spec
 
 
+def film_from_golden(g, spec, batch=None):
+    """The raw FiLM parameters a fixture was recorded with: procedural.film_params at the fixture's seed / scale and, for the
+    fixtures made beyond the init range (round 4), its phase_rev / freq0_gain."""
+    from fenerf_amd import procedural as proc
+    extra = {}
+    if "meta_film_phase_rev" in g:
+        extra = dict(phase_rev=float(g["meta_film_phase_rev"]), freq0_gain=float(g["meta_film_freq0_gain"]))
+    return proc.film_params(spec, int(g["meta_B"]) if batch is None else batch, seed=int(g["meta_seed"]), scale=float(g["meta_film_scale"]), **extra)
+
+
 def kwargs_from_golden(g):
     kw = {}
     for k, v in g.items():

@@ -72,6 +72,16 @@ def test_bench_self_launch_rendezvous_world_size_2():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["dist_check"] and d["world_size"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo"
+    # the N > 1 line's generator-step leg (bench.ddp_timed_leg: DistributedDataParallel wrapper, barrier / max-over-ranks bracket, rank
+    # census, byte count) on a stand-in module over gloo: the schema the GPU line carries, and DDP really synchronised the two ranks
+    sys.path.insert(0, root)
+    import bench
+    leg = d["gstep_ddp"]
+    assert tuple(leg) == bench.GSTEP_DDP_KEYS
+    assert leg["n_ranks"] == leg["n_ranks_seen"] == 2 and leg["dist_backend"] == "gloo" and leg["allreduce_per_micro_batch"] is True
+    assert leg["allreduce_bytes"] == 4 * (16 * 32 + 32 + 32 * 4 + 4) and leg["allreduce_bytes_largest_tensor"] == 4 * 16 * 32
+    assert leg["ms"] > 0 and leg["ms_no_ddp"] > 0 and abs(leg["allreduce_ms_exposed"] - (leg["ms"] - leg["ms_no_ddp"])) < 1e-9
+    assert d["params_identical_across_ranks"] is True
 
 
 def test_self_launch_command_is_the_drivers_launcher_line():

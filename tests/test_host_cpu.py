@@ -360,3 +360,91 @@ def test_avg_frequency_cache_keeps_values_and_rng_consumption():
     torch.save(gen, buf)
     buf.seek(0)
     assert "_avg_cache" not in torch.load(buf, weights_only=False).__dict__
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference-side ctypes binding shown there is EXECUTED (round 4: the round-3 text built a description with
+# abi_version=1 that the ABI-2 library rejects, and nothing noticed)
+# ---------------------------------------------------------------------------------------------------
+def integration_md_binding():
+    """The ```python block of INTEGRATION.md that starts with '# reference: generators/fenerf_hip.py', executed as written against
+    the in-tree library (FENERF_LIB).  -> its namespace"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if b.startswith("# reference: generators/fenerf_hip.py")]
+    assert len(blocks) == 1
+    old = os.environ.get("FENERF_LIB")
+    os.environ["FENERF_LIB"] = _lib.LIB_PATH
+    try:
+        ns = {}
+        exec(compile(blocks[0], "INTEGRATION.md#B", "exec"), ns)
+    finally:
+        if old is None:
+            del os.environ["FENERF_LIB"]
+        else:
+            os.environ["FENERF_LIB"] = old
+    return ns
+
+
+def _check_mirror(cls, struct_name):
+    import ctypes as C
+    l = _lib.lib()
+    sname = struct_name.encode()
+    assert C.sizeof(cls) == l.fenerf_struct_size(sname), struct_name
+    names = []
+    while l.fenerf_struct_field_name(sname, len(names)) is not None:
+        names.append(l.fenerf_struct_field_name(sname, len(names)).decode())
+    assert [f[0] for f in cls._fields_] == names, (struct_name, names)
+    for n in names:
+        assert getattr(cls, n).offset == l.fenerf_struct_field_offset(sname, n.encode()), (struct_name, n)
+
+
+def test_integration_md_binding_structs_match_the_loaded_library():
+    ns = integration_md_binding()
+    assert ns["FENERF_ABI_VERSION"] == _lib.lib().fenerf_abi_version() == _lib.ABI_VERSION
+    _check_mirror(ns["Desc"], "FenerfModelDesc")
+    _check_mirror(ns["Opts"], "FenerfCompositeOpts")
+    # the package's own mirrors, all five structs of include/fenerf.h
+    for cls, name in ((_lib.FenerfModelDesc, "FenerfModelDesc"), (_lib.FenerfCompositeOpts, "FenerfCompositeOpts"), (_lib.FenerfRepackMaps, "FenerfRepackMaps"),
+                      (_lib.FenerfLocalMapDesc, "FenerfLocalMapDesc"), (_lib.FenerfSirenGrads, "FenerfSirenGrads")):
+        _check_mirror(cls, name)
+    l = _lib.lib()
+    assert l.fenerf_struct_size(b"NoSuchStruct") == -1 and l.fenerf_struct_field_offset(b"FenerfModelDesc", b"nope") == -1
+    assert l.fenerf_struct_field_name(b"FenerfModelDesc", 999) is None
+
+
+@pytest.mark.parametrize("kind,precision", [("texture", 1), ("texture", 0), ("baseline", 1)])
+def test_integration_md_binding_describes_the_model_the_package_packs(kind, precision):
+    """desc_from_siren of the documented binding, on a module with the reference's attribute names, is accepted by the library
+    (abi_version, field layout) and packs to exactly the stream the package's own binding packs from the same weights."""
+    import ctypes as C
+    ns = integration_md_binding()
+    spec = proc.model_spec(kind, hidden_dim=32, grid_size=6, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=9, with_mapping=False)
+    cls = {"texture": S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, "baseline": S.SIRENBASELINESEMANTICDISENTANGLE}[kind]
+    mod = cls(hidden_dim=32, z_geo_dim=8, z_app_dim=8, output_dim=22)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    if "spatial_embeddings" in tsd:
+        mod.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
+    mod.load_state_dict(tsd, strict=False)
+    d, keep = ns["desc_from_siren"](mod, precision=precision)
+    assert (d.abi_version, d.hidden_dim, d.n_geo, d.n_color, d.n_label_layers, d.output_dim, d.grid_ch) == \
+        (2, 32, 8, 3, spec["n_label_layers"], 22, spec["grid_ch"])
+    l = ns["_l"]
+    fp, sz = C.POINTER(C.c_float), C.c_size_t
+    blob, consts, nb, nc = fp(), fp(), sz(), sz()
+    rc = l.fenerf_pack_weights_host(C.byref(d), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc))
+    assert rc == 0, l.fenerf_last_error()
+    try:
+        got = np.ctypeslib.as_array(blob, shape=(nb.value,)).copy(), np.ctypeslib.as_array(consts, shape=(nc.value,)).copy()
+    finally:
+        l.fenerf_free_host.argtypes = [C.c_void_p]
+        l.fenerf_free_host(blob)
+        l.fenerf_free_host(consts)
+    mine = _lib.pack_weights_host(sd, spec, "f16x3" if precision else "f32")
+    assert np.array_equal(got[0], mine[0]) and np.array_equal(got[1], mine[1])
+    # a stale ABI number -- the round-3 text -- is refused
+    d.abi_version = 1
+    assert l.fenerf_pack_weights_host(C.byref(d), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc)) == _lib.E_INVALID
+    assert b"abi_version" in l.fenerf_last_error()

@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-gstep --no-f32 --no-sweep64"
+Q="--no-cpu-baseline --no-gstep --no-gstep-ddp --no-f32 --no-sweep64"
 parity() { grep -h 'parity\]\|dist\]' "$1" | grep -v 'print(' ; }
 for what in "$@"; do
 case $what in
@@ -29,7 +29,7 @@ trigab)     # cost of the range reduction: in-kernel cycle stamps of the forward
     lib=$PWD/fenerf_amd/libfenerf_hip.so; [ -n "$v" ] && lib=$PWD/fenerf_amd/libexp_$v.so
     [ -f "$lib" ] || continue
     echo -n "${v:-shipped(rndne+sub)} run $rep: "
-    FENERF_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep64 --no-gstep-b6 2>/dev/null | python -c "
+    FENERF_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep64 --no-gstep-b6 --no-gstep-ddp 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -117,11 +117,12 @@ def rand_dict_from_draws(draws, hierarchical):
     return rd
 
 
-def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, film_scale=1.0, stages=True, staged=False):
-    """forward_with_frequencies / staged_forward_with_frequencies with explicit film params."""
+def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, film_scale=1.0, stages=True, staged=False, film_kw=None):
+    """forward_with_frequencies / staged_forward_with_frequencies with explicit film params.  film_kw: procedural.film_params'
+    phase_rev / freq0_gain -- FiLM parameters far beyond the init range (sine arguments of hundreds of revolutions)."""
     siren_mod, gens, vr, cur = refs
     g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
-    film = proc.film_params(spec, B, seed=seed, scale=film_scale)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {}))
     tf = {k: torch.from_numpy(v) for k, v in film.items()}
     if spec["kind"] == "spatial":   # single latent: one [B, 9H] frequency / phase tensor; the colour layer uses the last H
         tf["freq_geo"] = torch.cat([tf["freq_geo"], tf["freq_app"]], -1)
@@ -154,6 +155,8 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
                 res = g.forward_with_frequencies(tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], **common)
     out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_S=S, meta_N=N, meta_hier=int(hier),
                meta_film_scale=film_scale, meta_staged=int(staged), meta_weights_checksum=proc.checksum(sd))
+    if film_kw:
+        out.update(meta_film_phase_rev=float(film_kw["phase_rev"]), meta_film_freq0_gain=float(film_kw["freq0_gain"]))
     for k, v in spec.items():
         out["spec_" + k] = v
     for k, v in kwargs.items():
@@ -193,13 +196,13 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
     return g, sd, out
 
 
-def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0):
+def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0, film_kw=None):
     """The reference's OWN autograd through generator.forward_with_frequencies (what g_loss.backward() replays,
     train_double_latent_semantic.py:408-452): loss = sum(pixels * w) with a fixed w; gradients wrt the raw FiLM parameters
     and every render parameter, plus the draws and the pixels.  fp32 on the CPU (gradient noise ~1e-5 relative)."""
     siren_mod, gens, vr, cur = refs
     g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
-    film = proc.film_params(spec, B, seed=seed, scale=film_scale)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {}))
     tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in film.items()}
     torch.manual_seed(4321 + seed)
     common = dict(img_size=S, num_steps=N, hierarchical_sample=True, fov=CURR["fov"], ray_start=CURR["ray_start"],
@@ -218,6 +221,8 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
     (px * w).sum().backward()
     out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_S=S, meta_N=N, meta_hier=1, meta_film_scale=film_scale,
                meta_weights_checksum=proc.checksum(sd))
+    if film_kw:
+        out.update(meta_film_phase_rev=float(film_kw["phase_rev"]), meta_film_freq0_gain=float(film_kw["freq0_gain"]))
     for k, v in spec.items():
         out["spec_" + k] = v
     for k, v in kwargs.items():
@@ -685,6 +690,16 @@ def main(out_dir=None):
                   kwargs=dict(clamp_mode="relu", nerf_noise=0.0, fill_mode="eval_white_back"))
     fullb = proc.model_spec("baseline", hidden_dim=256)
     run_film_case(refs, "h256_baseline_8x8_n12", fullb, seed=6, sigma_gain=2000.0, B=2, S=8, N=12, hier=True, kwargs=relu)
+
+    # FiLM parameters far beyond the init range (round 4): phase shifts of up to +-300 revolutions in every layer, the first layer's
+    # frequency x 30 (its sine argument reaches ~450 revolutions) -- what torch.sin in the reference's FiLMLayer takes in its stride
+    # (siren.py:113-123) and a hardware sine defined on +-256 revolutions does not: pins the oracle (and through it the kernels'
+    # range reduction, fenerf_trig.h) to the reference there, forward and backward
+    big = dict(phase_rev=300.0, freq0_gain=30.0)
+    run_film_case(refs, "tiny_texture_fwd_bigfilm", tiny, seed=1, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu, film_kw=big)
+    run_film_case(refs, "h256_texture_8x8_n12_bigfilm", full, seed=0, sigma_gain=30.0, B=1, S=8, N=12, hier=True, kwargs=relu, film_kw=big)
+    run_grad_case(refs, "tiny_texture_grad_bigfilm", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
+                  B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True), film_kw=big)
 
 
 if __name__ == "__main__":
