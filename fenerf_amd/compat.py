@@ -21,6 +21,10 @@ def install_aliases():
     sys.modules.setdefault("siren.layers", latent_grid)
     sys.modules.setdefault("siren.op", latent_grid)
     sys.modules.setdefault("siren.op.native_ops", latent_grid)
+    # a checkpoint pickled where the reference's CUDA ops did import (siren/op/__init__.py:1-4) names FusedLeakyReLU under
+    # siren.op.fused_act; the only nn.Module those two files define is that one (the autograd Functions are never pickled)
+    sys.modules.setdefault("siren.op.fused_act", latent_grid)
+    sys.modules.setdefault("siren.op.upfirdn2d", latent_grid)
     if "torch_ema" not in sys.modules and importlib.util.find_spec("torch_ema") is None:
         from . import ema
         sys.modules["torch_ema"] = ema

@@ -46,6 +46,7 @@ class NativeModel:
 
     def update(self, sd):
         self.pack_generation += 1
+        self._resident = None         # what a later load_from_device(maybe_unchanged=True) compares against is no longer what is resident
         with torch.cuda.device(self.device):
             d, keep = _lib.make_desc(sd, self.spec, self.precision, self.differentiable, self.wgrad_bf16_min_points)
             _lib.check(_lib.lib().fenerf_model_update(self._h, C.byref(d), _stream()))
@@ -197,10 +198,16 @@ class NativeModel:
 
     @staticmethod
     def _grid_checksum(grid):
-        """Wrap-around int32 sum of the grid's fp32 bit patterns: one pass over 113 MB, 27 us, no temporaries, no sync; deterministic, and
-        any single changed word changes it.  (Accumulated in int64 the same sum costs 129 us -- torch converts the tensor first --
-        which was 1 % of every generator step: tools/exp/checksum_probe.py.)"""
-        return grid.reshape(-1).view(torch.int32).sum(dtype=torch.int32)
+        """Digest of the grid's fp32 bit patterns: wrap-around int32 sums of runs of (up to) 1,024 consecutive words -- 27,648 sums for the
+        96^3 grid.  One pass over 113 MB (~27 us), no temporaries, no sync, deterministic; any single changed word changes it, and edits
+        that compensate each other (permuted or offsetting values written through .data) collide only inside one 4-KiB run instead of
+        anywhere in the tensor.  (Accumulated in int64 a sum costs 129 us -- torch converts the tensor first -- which was 1 % of every
+        generator step: tools/exp/checksum_probe.py.)"""
+        words = grid.reshape(-1).view(torch.int32)
+        run = 1024
+        while words.numel() % run:
+            run //= 2
+        return words.view(-1, run).sum(1, dtype=torch.int32)
 
     def load_from_device(self, params, maybe_unchanged=False):
         """Re-pack from device-resident parameters {reference name: tensor} without touching the host: one concatenation,
@@ -216,13 +223,15 @@ class NativeModel:
             last = getattr(self, "_resident", None)
             csum = self._grid_checksum(grid) if grid is not None else None
             if maybe_unchanged and last is not None and last[0].shape == flat.shape and torch.equal(last[0], flat) and \
-                    (csum is None or torch.equal(last[1], csum)):
+                    (csum is None or (last[1] is not None and last[1].shape == csum.shape and torch.equal(last[1], csum))):
                 return
-            self._resident = (flat, csum)
+            self._resident = None     # until the re-pack below has succeeded nothing is known to be resident
         r = self._repack_maps()
         self.pack_generation += 1
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().fenerf_model_repack(self._h, _ptr(flat), flat.numel(), C.byref(r), _ptr(grid), _stream()))
+        if self.differentiable:
+            self._resident = (flat, csum)
 
     def export_packed(self):
         """(stream, consts, backward stream or None) copies of the resident packed buffers (tests)."""
@@ -397,6 +406,10 @@ class NativeModel:
                                                         _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
 
+    def film_sums_floats(self, B, P):
+        """floats of the per-tile FiLM sums fenerf_siren_backward_film writes for B images of P points"""
+        return int(_lib.lib().fenerf_siren_film_sums_floats(self._h, int(B), int(P)))
+
     def film_only_native(self):
         """fenerf_siren_backward_film / fenerf_siren_film_grads exist for this model (f16x3 handles)"""
         return self.precision == "f16x3" and self.differentiable
@@ -406,7 +419,7 @@ class NativeModel:
         fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
         out, d_out = _f32(out, self.device), _f32(d_out, self.device)
         l = _lib.lib()
-        sums = torch.empty((int(l.fenerf_siren_film_sums_floats(self._h, B, P)),), dtype=torch.float32, device=self.device)
+        sums = torch.empty((self.film_sums_floats(B, P),), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
             _lib.check(l.fenerf_siren_backward_film(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape),

@@ -59,6 +59,8 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
 # every FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist
 # for more points than one chain launch's worth: peak memory of a generator step = tape + one chunk instead of 2 x tape.
 BACKWARD_CHUNK_POINTS = 196608
+# inversion (FiLM gradients only, no dump): bytes of per-tile FiLM sums one chain launch may allocate
+FILM_SUMS_BUDGET_BYTES = 1 << 30
 
 
 FILM_KEYS = ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")
@@ -102,18 +104,30 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     else:
         chunks = [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
     if film_only and nat.film_only_native():
-        # Inversion on an f16x3 model: the chain writes only its per-tile FiLM sums (fenerf_siren_backward_film) -- no d(theta) dump,
-        # so there is nothing to bound and every launch covers as many whole images as the kernel's 32-bit tile arithmetic allows
-        per = max(1, (1 << 24) // Pp)
-        rows = {k: [] for k in FILM_KEYS}
-        for b in range(0, nB, per):
-            nb = min(per, nB - b)
+        # Inversion on an f16x3 model: the chain writes only its per-tile FiLM sums (fenerf_siren_backward_film) -- no d(theta) dump.
+        # A launch is bounded by the kernel's 32-bit tile arithmetic (2^24 points) and by FILM_SUMS_BUDGET_BYTES of FiLM sums (one
+        # [L][2][H] block per 128 points, or per 16 points when an image is not a multiple of 128 points: 176 B / 1.4 KB per point at
+        # H = 256); an image larger than that is walked in point ranges whose FiLM gradients add.
+        sums_bytes_pp = 4.0 * nat.film_sums_floats(1, Pp) / Pp
+        cap = int(max(128, min(1 << 24, FILM_SUMS_BUDGET_BYTES / sums_bytes_pp)) // 128 * 128)
+        if Pp <= cap:
+            per = max(1, cap // Pp)
+            fchunks = [(b, min(per, nB - b), 0, Pp) for b in range(0, nB, per)]
+        else:
+            fchunks = [(b, 1, s, min(cap, Pp - s)) for b in range(nB) for s in range(0, Pp, cap)]
+        rows, acc = {k: [] for k in FILM_KEYS}, None
+        for b, nb, s, n in fchunks:
             film_c = tuple(t[b:b + nb] for t in film)
-            tape_c = tape[b * Pp * LH:(b + nb) * Pp * LH]
-            sums = nat.siren_backward_film(nb, Pp, *film_c, out[b:b + nb], d_out[b:b + nb], tape_c)
-            r = nat.siren_film_grads(nb, Pp, *film_c, sums)
-            for k in FILM_KEYS:
-                rows[k].append(r[k])
+            g0 = b * Pp + s
+            tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
+            sums = nat.siren_backward_film(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c)
+            r = nat.siren_film_grads(nb, n, *film_c, sums)
+            if s == 0:
+                acc = [r[k] for k in FILM_KEYS]
+                for k, t in zip(FILM_KEYS, acc):
+                    rows[k].append(t)
+            else:
+                _add_all(acc, [r[k] for k in FILM_KEYS])
         return {k: (torch.cat(v, 0) if len(v) > 1 else v[0]) for k, v in rows.items()}, None
     total, film_rows = None, {k: [] for k in FILM_KEYS}
     acc_img = None           # FiLM gradients of the image whose point ranges are being walked

@@ -317,7 +317,13 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
     the FiLM-SIREN (fenerf_siren_forward_local: the 18 KB of FiLM parameters per point never exist in memory).
     forward_with_frequencies_phase_shifts with explicit per-point [B, P, 9H] parameters (the reference's signature, :464) runs
     fenerf_siren_forward_pointwise on the caller's tensors.  Both are exact-fp32 kernels whatever `precision` says -- fp32-class
-    results is what "f16x3" promises too."""
+    results is what "f16x3" promises too.
+    Under autograd (an input, latent or parameter requires grad in grad mode) the module is what the reference's is: an ordinary
+    differentiable nn.Module.  The per-point-modulated SIREN then runs as PyTorch-ROCm ops on the device (`_film_siren_torch`) so that
+    torch autograd reaches the SIREN weights, the per-point mapping network, the latent grid and, through StyleGenerator2D, z.  It is
+    NOT routed through the native chain / weight-gradient kernels: those factor a layer's weight gradient as
+    sum_images diag(f_image) sum_points d(theta) x^T, which holds only when the frequencies are per image.  The variant is in no
+    curriculum and the reference never trains it; pinned to the reference module's own autograd (tiny_spatial_grid.npz)."""
 
     def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
         super().__init__(input_dim=input_dim, z_dim=z_dim, hidden_dim=hidden_dim, output_dim=output_dim, device=device)
@@ -335,10 +341,26 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
         sampled_latent = self.sample_local_latents(latent_grid, input_grid)
         if self.local_coordinates:
             input = self.get_local_coordinates(global_coords=input, local_grid_length=32, preserve_y=False)
-        if self._wants_grad(input, ray_directions, sampled_latent):
-            raise NotImplementedError("fenerf_amd: per-point FiLM modulation is forward-only (the reference never trains this variant: "
-                                      "it is in no curriculum and its generator-level methods cannot run, SURVEY 0.5)")
+        if self._wants_grad(input, ray_directions, sampled_latent, *self.mapping_network.parameters()):
+            frequencies, phase_shifts = self.mapping_network(sampled_latent)
+            return self._film_siren_torch(input, frequencies, phase_shifts, ray_directions)
         return self.native_local(input.device).forward(input, ray_directions, sampled_latent)
+
+    def _film_siren_torch(self, input, frequencies, phase_shifts, ray_directions):
+        """siren.py:464-477 as differentiable PyTorch-ROCm ops (per-point [B, P, 9H] or per-image [B, 9H] FiLM blocks): the autograd
+        route of this variant -- see the class docstring for why it is not the native chain."""
+        if input.device.type != "cuda":
+            raise RuntimeError("fenerf_amd renders on the GPU only (there is no CPU path); got device %s" % input.device)
+        H = self.hidden_dim
+        if frequencies.dim() == 2:
+            frequencies, phase_shifts = frequencies[:, None, :], phase_shifts[:, None, :]
+        frequencies = frequencies * 15 + 30
+        x = self.gridwarper(input)
+        for i, layer in enumerate(self.network):
+            x = torch.sin(frequencies[..., i * H:(i + 1) * H] * layer.layer(x) + phase_shifts[..., i * H:(i + 1) * H])
+        sigma = self.final_layer(x)
+        c = torch.sin(frequencies[..., -H:] * self.color_layer_sine.layer(torch.cat([ray_directions, x], dim=-1)) + phase_shifts[..., -H:])
+        return torch.cat([torch.sigmoid(self.color_layer_linear(c)), sigma], dim=-1)
 
     def native_local(self, device=None):
         """The FenerfLocalModel (SIREN + per-point mapping network in one packed fp32 stream) for the current parameter values."""
@@ -386,8 +408,7 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
         if frequencies.dim() == 2:
             return super().forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
         if self._wants_grad(input, ray_directions, frequencies, phase_shifts):
-            raise NotImplementedError("fenerf_amd: per-point FiLM modulation is forward-only (the reference never trains this variant: "
-                                      "it is in no curriculum and its generator-level methods cannot run, SURVEY 0.5)")
+            return self._film_siren_torch(input, frequencies, phase_shifts, ray_directions)
         fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
         return self.native(input.device).siren_forward_pointwise(input, ray_directions, fg, pg, fa, pa)
 

@@ -448,3 +448,34 @@ def test_integration_md_binding_describes_the_model_the_package_packs(kind, prec
     d.abi_version = 1
     assert l.fenerf_pack_weights_host(C.byref(d), C.byref(blob), C.byref(nb), C.byref(consts), C.byref(nc)) == _lib.E_INVALID
     assert b"abi_version" in l.fenerf_last_error()
+
+
+def test_pickles_made_where_the_reference_cuda_ops_imported_still_load(tmp_path):
+    """siren/op/__init__.py:1-4 of the reference imports FusedLeakyReLU from siren.op.fused_act when its CUDA extensions build, from
+    siren.op.native_ops otherwise: a SPATIALSIRENGRID checkpoint pickled on the first kind of machine names the class under
+    siren.op.fused_act.  compat.install_aliases() serves both paths (round-3 advisory)."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {repr(str(__import__('pathlib').Path(__file__).resolve().parents[1]))})
+        from fenerf_amd import compat
+        compat.install_aliases()
+        from fenerf_amd.siren import latent_grid as LG
+        act = LG.FusedLeakyReLU(5)
+        with torch.no_grad():
+            act.bias.copy_(torch.arange(5.0))
+        x = torch.randn(2, 5, 3, 3)
+        for path in ("siren.op.fused_act", "siren.op.native_ops"):
+            LG.FusedLeakyReLU.__module__ = path            # what the reference's pickle records on the two kinds of machine
+            torch.save(act, r"{tmp_path}/act.pth")
+            LG.FusedLeakyReLU.__module__ = "fenerf_amd.siren.latent_grid"
+            back = torch.load(r"{tmp_path}/act.pth", weights_only=False)
+            assert type(back) is LG.FusedLeakyReLU and torch.equal(back(x), act(x)), path
+        import importlib
+        assert importlib.import_module("siren.op.upfirdn2d") is LG
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

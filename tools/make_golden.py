@@ -618,8 +618,31 @@ def run_spatial_grid_case(refs, name="tiny_spatial_grid"):
                # the reference module's complete state dict as names + shapes (strict state-dict compatibility), the two blur kernels
                meta_state_dict=json.dumps({k: list(v.shape) for k, v in full.items()}, sort_keys=True),
                blur_kernel=np_(full["grid_latent_network.convs.0.blur.kernel"]))
+    # round 4: the reference module under ITS OWN autograd (it is an ordinary differentiable nn.Module, siren.py:413-477) -- gradients of
+    # sum(out * w) wrt the SIREN weights, the per-point mapping network, z (through the latent-grid generator) and, teacher-forced, the
+    # latent grid itself.  A separate pass after everything above: nothing recorded so far changes.
+    w = torch.from_numpy(np.random.default_rng(33).normal(size=tuple(res.shape)).astype(np.float32))
+    zz = z.clone().requires_grad_(True)
+    for p_ in ref.parameters():
+        p_.grad = None
+    res_g = ref(pts, zz, dirs)
+    assert torch.equal(res_g.detach(), res)
+    (res_g * w).sum().backward()
+    out["loss_w"], out["g_z"] = np_(w), np_(zz.grad)
+    for n_, p_ in ref.named_parameters():
+        if not n_.startswith("grid_latent_network"):
+            out["gw_" + n_] = np_(p_.grad)
+    gl = {n_: p_.grad for n_, p_ in ref.grid_latent_network.named_parameters() if p_.grad is not None}
+    out["g_generator_names"] = json.dumps(sorted(gl))
+    out["g_generator_norms"] = np.array([float(gl[k].double().norm()) for k in sorted(gl)])     # 4.1 M values: their norms pin them
+    lg = latent_grid.clone().requires_grad_(True)
+    sampled_g = ref.sample_local_latents(lg, ref.gridwarper(pts))
+    f_g, p_g = ref.mapping_network(sampled_g)
+    res_l = ref.forward_with_frequencies_phase_shifts(local, f_g, p_g, dirs, box_warp=False)
+    (res_l * w).sum().backward()
+    out["g_latent_grid"] = np_(lg.grad)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    print(f"{name}: out {tuple(res.shape)}, per-point freq {tuple(freq.shape)}")
+    print(f"{name}: out {tuple(res.shape)}, per-point freq {tuple(freq.shape)}, {sum(k.startswith('gw_') for k in out)} weight gradients + z + latent grid")
 
 
 def run_curriculums(refs, name="curriculums"):
