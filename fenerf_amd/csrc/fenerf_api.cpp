@@ -283,6 +283,8 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipGetDeviceProperties"); }
   m->num_cus = prop.multiProcessorCount;
+  // experiment switch (profiles/r04_gstep_overlap_why_not.md): size every persistent launch for fewer CUs than the device has
+  if (const char* e = getenv("FENERF_EXP_NUM_CUS")) { const int n = atoi(e); if (n > 0 && n < m->num_cus) m->num_cus = n; }
   rc = upload_model(m, d, nullptr, true);
   if (rc) { fenerf_model_destroy(m); return rc; }
   *out = m;

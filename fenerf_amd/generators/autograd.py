@@ -113,11 +113,16 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         C = nat.C
         need = ctx.needs_input_grad
         fine, coarse = out2[B:, :P].reshape(B * R, N, C), out2[:B, :P].reshape(B * R, N, C)
-        d_f, d_c = native.composite_backward(g_rgb.reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
-                                             noise=noise_f if noise_f.numel() else None)
-        d_out2 = torch.zeros((2 * B, Pp, C), dtype=torch.float32, device=out2.device) if Pp != P else torch.empty_like(out2)
-        d_out2[:B, :P] = d_c.reshape(B, P, C)
-        d_out2[B:, :P] = d_f.reshape(B, P, C)
+        if Pp == P:     # whole tiles per image: the composite backward writes the chain's input directly (coarse | fine halves, pass-major)
+            d_out2 = torch.empty_like(out2)
+            native.composite_backward(g_rgb.reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc, noise=noise_f if noise_f.numel() else None,
+                                      out_a=d_out2[B:].view(B * R, N, C), out_b=d_out2[:B].view(B * R, N, C))
+        else:
+            d_f, d_c = native.composite_backward(g_rgb.reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
+                                                 noise=noise_f if noise_f.numel() else None)
+            d_out2 = torch.zeros((2 * B, Pp, C), dtype=torch.float32, device=out2.device)
+            d_out2[:B, :P] = d_c.reshape(B, P, C)
+            d_out2[B:, :P] = d_f.reshape(B, P, C)
         film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         film_only = not any(need[14:])

@@ -744,17 +744,20 @@ def merge_composite(fine, coarse, z_fine, z_coarse, noise, opts, want_weights=Tr
     return rgb, depth, w, ws, zs
 
 
-def composite_backward(g_rgb, rows_a, z_a, opts, rows_b=None, z_b=None, noise=None):
+def composite_backward(g_rgb, rows_a, z_a, opts, rows_b=None, z_b=None, noise=None, out_a=None, out_b=None):
     """Gradient of the final composite wrt its input rows.  Non-merge: rows_a [BR,M,C], z_a [BR,M] -> d_rows_a.
-    Merge (rows_b given): fine rows_a / coarse rows_b [BR,N,C], z_a / z_b [BR,N] -> (d_fine, d_coarse)."""
+    Merge (rows_b given): fine rows_a / coarse rows_b [BR,N,C], z_a / z_b [BR,N] -> (d_fine, d_coarse).
+    out_a / out_b: contiguous fp32 device buffers of the rows' shapes to write into (views of a larger tensor: no copy afterwards)."""
     BR, N, Cc = rows_a.shape
     dev = rows_a.device
     merge = rows_b is not None
     ra, za, g = _f32(rows_a, dev), _f32(z_a, dev), _f32(g_rgb, dev).reshape(BR, Cc - 1)
     rb, zb = (_f32(rows_b, dev), _f32(z_b, dev)) if merge else (None, None)
     nz = _f32(noise, dev).reshape(BR, -1) if noise is not None else None
-    da = torch.empty_like(ra)
-    db = torch.empty_like(rb) if merge else None
+    for o, r in ((out_a, ra), (out_b, rb)):
+        assert o is None or (o.is_cuda and o.dtype == torch.float32 and o.is_contiguous() and o.numel() == r.numel())
+    da = out_a if out_a is not None else torch.empty_like(ra)
+    db = (out_b if out_b is not None else torch.empty_like(rb)) if merge else None
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().fenerf_composite_backward(BR, N, Cc, int(merge), _ptr(ra), _ptr(rb), _ptr(za), _ptr(zb), _ptr(nz),
                                                         C.byref(opts), _ptr(g), _ptr(da), _ptr(db), _stream()))

@@ -53,12 +53,15 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
-# dtheta of a backward chunk: at most this many points (x L*H*4 B = 2.2 GB at L*H = 2816).  With the round-2 kernels a generator step
-# at 1 x 128^2 x 24+24 takes 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for chunks of 98,304 / 131,072 /
-# 196,608 / 393,216 points (tools/chunk_sweep.py): half a pass per chunk keeps the peak under 12 GB.  The chain kernel writes dL/dtheta of
-# every FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist
-# for more points than one chain launch's worth: peak memory of a generator step = tape + one chunk instead of 2 x tape.
-BACKWARD_CHUNK_POINTS = 196608
+# dtheta of a backward chunk: at most this many points (x L*H*4 B = 8.9 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
+# FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist for more points than
+# one chain launch's worth: peak memory of a generator step = tape + one chunk.  Rounds 2-3 bounded the chunk at 196,608 points (half a
+# pass of a 128 x 128 x 24 image: 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for chunks of 98,304 / 131,072 /
+# 196,608 / 393,216 points with the round-2 kernels, tools/chunk_sweep.py) to keep the step under 12 GB.  An MI355X has 288 GB: since
+# round 4 a chunk is BOTH passes of such an image (786,432 points) -- one chain launch and one set of weight-gradient launches per image
+# instead of four (four launch ramps / drains, 3 x ~95 us of per-chunk reductions and gradient additions less), 18.4 GB peak per image step,
+# ~62 GB for the 6-image micro-batch of configs[2].
+BACKWARD_CHUNK_POINTS = 786432
 # inversion (FiLM gradients only, no dump): bytes of per-tile FiLM sums one chain launch may allocate
 FILM_SUMS_BUDGET_BYTES = 1 << 30
 

@@ -870,7 +870,7 @@ class _PerImageDraws(VR.TorchDraws):
 
 def test_generator_step_at_configs2_is_the_sum_of_its_six_images():
     """A size-independent property that pins VALUES at configs[2]'s full size: the micro-batch step (6 images in one forward_save /
-    chain / weight-gradient pass each, 24 backward chunks) must equal the six single-image steps -- pixels of image b bit for bit (the
+    chain / weight-gradient pass each, 6 backward chunks of 786,432 points) must equal the six single-image steps -- pixels of image b bit for bit (the
     arithmetic of a sample does not depend on which workgroup evaluates it), every parameter gradient the sum of the six (fp32 sums in a
     different grouping: <= 5e-6 of the tensor's largest entry)."""
     gen, cur, curriculums = _curriculum_generator()
@@ -1704,7 +1704,7 @@ def test_part_forward_gradient_on_a_ray_subset():
 
 # Sizes that give every workgroup of the 16-point kernels more than one oct of tiles (256 CUs x 128 points): the stream wraps for
 # the next tile, the ring slot counter and the tape-buffer parity carry over, the last oct is ragged -- and, last, the generator
-# step's own shape: H = 256, 393,216 points of one image = two backward chunks of the production size (196,608).  Checked against
+# step's own shape: H = 256, 393,216 points of one image (one pass of the 128 x 128 x 24 image; the production chunk is both passes: 786,432).  Checked against
 # torch autograd of the fp64 restatement (oracle/fenerf_oracle_grad.py, pinned to the reference's autograd), which walks the points
 # in slabs of 32,768 (every gradient is a sum over points) to bound the host memory.
 @pytest.mark.parametrize("precision,H,grid,B,P", [("f16x3", 32, 5, 1, 40000), ("f32", 32, 5, 1, 40000), ("f16x3", 64, 0, 2, 33024),
@@ -1765,9 +1765,11 @@ def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
 def test_grid_gradient_values_at_full_size_96cubed_grid():
     """The 96^3 grid-gradient scatter (113 MB of float atomics fused into the chain kernel, siren.py:314-330's grid_sample backward) VALUE-
     checked at the generator step's own size: bench model (H = 256 + 32 x 96^3 grid), the two passes of a 128 x 128 x 24 image = 786,432
-    points = four production backward chunks.  The upstream gradient is non-zero only on a 2,048-ray slab that straddles a chunk
-    boundary (98,304 points over both passes), so the full-size backward must reproduce, voxel for voxel, the fp64 autograd gradient of
-    that slab alone -- and leave every voxel the slab does not touch at exactly zero.  All other gradient tensors ride along."""
+    points.  The upstream gradient is non-zero only on a 2,048-ray slab (98,304 points over both passes), so the full-size backward must
+    reproduce, voxel for voxel, the fp64 autograd gradient of that slab alone -- and leave every voxel the slab does not touch at exactly
+    zero.  Run twice: as ONE production chunk (786,432 points in one chain launch and one set of weight-gradient launches: 8.9 GB of
+    d(theta), offsets beyond 2^32 bytes) and as four 196,608-point chunks whose first boundary the slab straddles.  All other gradient
+    tensors ride along."""
     from oracle import fenerf_oracle_grad as OG
     from fenerf_amd.siren import autograd as SA
     spec, sd = _full_weights()
@@ -1786,17 +1788,13 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
     dirs = d[:, :, None, :].expand(1, R, N, 3).reshape(1, R * N, 3).expand(2, -1, -1).contiguous()
     film = proc.film_params(spec, 1, seed=0)
     film2 = {k: np.repeat(v, 2, 0) for k, v in film.items()}                          # both passes of one image share its FiLM block
-    film_t = {k: T(v).requires_grad_(True) for k, v in film2.items()}
     r0, r1 = 7168, 9216                                                                # rays of the slab: points [172,032, 221,184) of each pass
-    assert r0 * N < SA.BACKWARD_CHUNK_POINTS < r1 * N
+    assert r0 * N < 196608 < r1 * N and SA.BACKWARD_CHUNK_POINTS >= 2 * R * N
     rng = np.random.default_rng(5)
     g_slab = rng.normal(size=(2, (r1 - r0) * N, 22)).astype(np.float32)
     g_slab[..., -1] *= 1e-3                                                            # sigma is ~2000 x the other outputs in this model
     g_out = torch.zeros((2, R * N, 22), device=DEV)
     g_out[:, r0 * N:r1 * N] = T(g_slab)
-    out = mod.forward_with_frequencies_phase_shifts(pts, film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], dirs)
-    (out * g_out).sum().backward()
-    g_nat = N_(mod.spatial_embeddings.grad)
     # fp64 autograd on the slab alone, in pieces of 8,192 points (gradients are sums over points)
     t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
     sd64 = {k: t64(v).requires_grad_(True) for k, v in sd.items()}
@@ -1807,17 +1805,29 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
         ref = OG.siren_forward(sd64, spec, t64(p_slab[:, sl]), t64(d_slab[:, sl]), film64["freq_geo"], film64["phase_geo"], film64["freq_app"], film64["phase_app"])
         (ref * t64(g_slab[:, sl])).sum().backward()
     g_ref = sd64["spatial_embeddings"].grad.numpy()
-    touched_ref, touched_nat = np.abs(g_ref).max(1) > 0, np.abs(g_nat).max(1) > 0
-    e_grid = _rel_err(g_nat, g_ref)
-    named = dict(mod.named_parameters())
-    errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film2}
-    errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
-    worst = max(errs, key=errs.get)
-    print(f"[parity] 96^3 grid gradient at full size (786,432 points, 4 backward chunks, upstream gradient on a 2,048-ray slab): "
-          f"{int(touched_nat.sum())} voxels touched (fp64 autograd of the slab alone: {int(touched_ref.sum())}), relative error (max-norm) "
-          f"{e_grid:.2e}; stray non-zero voxels {int((touched_nat & ~touched_ref).sum())}; worst of all {len(errs)} gradient tensors {errs[worst]:.2e} ({worst})")
-    assert not (touched_nat & ~touched_ref).any(), "a voxel the slab does not touch received gradient"
-    assert e_grid <= 6e-5 and errs[worst] <= 6e-5
+    touched_ref = np.abs(g_ref).max(1) > 0
+    for chunk in (SA.BACKWARD_CHUNK_POINTS, 196608):
+        old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
+        try:
+            for p_ in mod.parameters():
+                p_.grad = None
+            film_t = {k: T(v).requires_grad_(True) for k, v in film2.items()}
+            out = mod.forward_with_frequencies_phase_shifts(pts, film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], dirs)
+            (out * g_out).sum().backward()
+        finally:
+            SA.BACKWARD_CHUNK_POINTS = old
+        g_nat = N_(mod.spatial_embeddings.grad)
+        touched_nat = np.abs(g_nat).max(1) > 0
+        e_grid = _rel_err(g_nat, g_ref)
+        named = dict(mod.named_parameters())
+        errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film2}
+        errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
+        worst = max(errs, key=errs.get)
+        print(f"[parity] 96^3 grid gradient at full size (786,432 points in backward chunks of {chunk}, upstream gradient on a 2,048-ray slab): "
+              f"{int(touched_nat.sum())} voxels touched (fp64 autograd of the slab alone: {int(touched_ref.sum())}), relative error (max-norm) "
+              f"{e_grid:.2e}; stray non-zero voxels {int((touched_nat & ~touched_ref).sum())}; worst of all {len(errs)} gradient tensors {errs[worst]:.2e} ({worst})")
+        assert not (touched_nat & ~touched_ref).any(), "a voxel the slab does not touch received gradient"
+        assert e_grid <= 6e-5 and errs[worst] <= 6e-5
 
 
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 96), ("baseline", 64, 0, 1, 64), ("texture", 128, 4, 3, 160),

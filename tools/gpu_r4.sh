@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [ddp]'
+# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [ddp] [cuscale] [probe]'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -66,6 +66,16 @@ pmc)
   find gpurun_out/pmc -type f -size +4M -delete
   python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc/siren_pmc_summary.txt 2>&1
   cat gpurun_out/pmc/siren_pmc_summary.txt ;;
+cuscale)    # do the backward kernels scale with the CUs they get?  (profiles/r04_gstep_overlap_why_not.md: running the chain beside the weight
+            # gradients on disjoint CU sets only pays if they do NOT)  FENERF_EXP_NUM_CUS sizes every persistent launch for n CUs
+  for n in 256 192 128 64; do
+    echo "== FENERF_EXP_NUM_CUS=$n"
+    FENERF_EXP_NUM_CUS=$n timeout 200 python tools/time_bwd.py 196608 2>&1 | grep -E "forward_save|chain"
+    FENERF_EXP_NUM_CUS=$n timeout 200 python tools/time_wgrad.py 393216 2>&1 | tail -1
+  done > gpurun_out/cuscale.log 2>&1
+  cat gpurun_out/cuscale.log ;;
+probe)      # what v_sin_f32 / v_cos_f32 return for arguments of growing magnitude on this chip
+  ./tools/probe/sin_domain_probe > gpurun_out/vsin_domain_probe.txt 2>&1; cat gpurun_out/vsin_domain_probe.txt ;;
 gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
   rm -rf gpurun_out/gtl; mkdir -p gpurun_out/gtl
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtl -o gtl -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 1 --size 128 --skip-eager --iters 4 ${GTL_ARGS:-}) > gpurun_out/gtl/run.log 2>&1
