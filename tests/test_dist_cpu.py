@@ -93,3 +93,43 @@ def test_self_launch_command_is_the_drivers_launcher_line():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+
+
+def _mb_worker(rank, world, port, q):
+    """batch_split micro-batches through DDP: the reference's pattern (all-reduce every micro-batch) vs fdist.micro_batch_sync (local
+    accumulation, one all-reduce in the last micro-batch's backward)"""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fdist.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    ddp = DDP(net, find_unused_parameters=True)
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank))        # every rank its own data
+    n_splits, res = 4, {}
+    for mode in ("reference", "micro_batch_sync"):
+        ddp.zero_grad(set_to_none=True)
+        for split in range(n_splits):
+            ctx = fdist.micro_batch_sync(ddp, split, n_splits) if mode == "micro_batch_sync" else fdist.micro_batch_sync(net, split, n_splits)
+            with ctx:
+                ddp(x[2 * split:2 * split + 2]).square().sum().backward()
+        res[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    q.put((rank, res["reference"].tolist(), res["micro_batch_sync"].tolist()))      # plain lists: tensors would travel as shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_micro_batch_sync_equals_the_reference_pattern_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ref0, mb0), (_, ref1, mb1) = res
+    assert ref0 == ref1 and mb0 == mb1, "DDP leaves identical gradients on both ranks"
+    ref0, mb0 = torch.tensor(ref0), torch.tensor(mb0)
+    assert float(ref0.abs().max()) > 0 and torch.allclose(mb0, ref0, rtol=1e-5, atol=1e-6)
