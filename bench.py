@@ -308,7 +308,7 @@ def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_o
     zg, za = torch.randn(B, cur["latent_geo_dim"], device=dev), torch.randn(B, cur["latent_app_dim"], device=dev)
     w = torch.randn((B, cur["output_dim"] - 1, S, S), device=dev) / (B * S * S)
     params = [p for p in gen.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=cur[50000]["gen_lr"], betas=cur["betas"], weight_decay=cur["weight_decay"])
+    opt = torch.optim.Adam(params, lr=cur[50000]["gen_lr"], betas=tuple(float(v) for v in cur["betas"]), weight_decay=cur["weight_decay"])
 
     def loss_of(m):
         px, _ = m(zg, za, **md)

@@ -71,6 +71,7 @@ _i, _i64, _sz = C.c_int, C.c_int64, C.c_size_t
 _SIGS = {
     "fenerf_last_error": (C.c_char_p, []),
     "fenerf_abi_version": (_i, []),
+    "fenerf_set_cu_budget": (_i, [_i]),
     "fenerf_struct_size": (C.c_long, [C.c_char_p]),
     "fenerf_struct_field_offset": (C.c_long, [C.c_char_p, C.c_char_p]),
     "fenerf_struct_field_name": (C.c_char_p, [C.c_char_p, _i]),

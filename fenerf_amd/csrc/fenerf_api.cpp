@@ -82,6 +82,9 @@ PhaseScope::~PhaseScope() {
   g_phase_recs.push_back(r);
 }
 
+static thread_local int g_cu_budget = 0;
+int launch_cus(const FenerfModel* m) { return (g_cu_budget > 0 && g_cu_budget < m->num_cus) ? g_cu_budget : m->num_cus; }
+
 // the dump format of a backward chunk (fenerf_layout.h "bf16 dump"): opt-in per model (FenerfModelDesc.wgrad_bf16_min_points)
 bool use_bf16_dump(const FenerfModel* m, long long total_points) {
   return m && m->precision == FENERF_PREC_F16X3 && m->wgrad_bf16_min_points > 0 && total_points >= m->wgrad_bf16_min_points;
@@ -201,6 +204,11 @@ extern "C" int fenerf_phase_times(double* ms, int* calls, int n) {
   return rc;
 }
 extern "C" int fenerf_abi_version(void) { return FENERF_ABI_VERSION; }
+extern "C" int fenerf_set_cu_budget(int cus) {
+  const int prev = g_cu_budget;
+  g_cu_budget = cus > 0 ? cus : 0;
+  return prev;
+}
 
 // ---- struct layouts as compiled (include/fenerf.h fenerf_struct_*): bindings check themselves against the loaded library
 namespace {
@@ -264,6 +272,7 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   std::string err;
   int rc = validate_desc(d, err);
   if (rc) return fail(rc, err);
+  if ((rc = check_trig_domain())) return rc;        // fenerf_trig.h: the sine / cosine argument domain this build relies on
   FenerfModel* m = new (std::nothrow) FenerfModel();
   if (!m) return fail(FENERF_E_NOMEM, "out of host memory");
   // (value-initialised by `new FenerfModel()`: every scalar / pointer member is zero, the dump registry is an empty map)

@@ -28,6 +28,11 @@ struct PhaseScope {
   ~PhaseScope();
   void* rec;
 };
+// compute units the calling thread's launches are sized for: the device's, or fewer under fenerf_set_cu_budget
+int launch_cus(const FenerfModel* m);
+// once per device: v_sin_f32 / v_cos_f32 reduce arguments far beyond +-256 revolutions on this device (fenerf_trig.h); FENERF_OK, or
+// FENERF_E_UNSUPPORTED / FENERF_E_HIP with the error string set
+int check_trig_domain();
 int validate_desc(const FenerfModelDesc* d, std::string& err);
 int pack_weights(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);
 int pack_weights_f16(const FenerfModelDesc* d, std::vector<float>& blob, std::vector<float>& consts, std::string& err);

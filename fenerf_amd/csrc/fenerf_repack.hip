@@ -5,10 +5,56 @@
 // the same work issued as ~150 torch ops cost 1.5 ms of launch latency per step.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <mutex>
+
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
+#include "fenerf_trig.h"
 
 namespace fenerf {
+
+// ---- fenerf_trig.h: the kernels hand v_sin_f32 / v_cos_f32 unreduced revolutions; prove once per device that this device reduces them
+__global__ void trig_domain_kernel(const float* t, float* out, int n) {
+  const int i = threadIdx.x;
+  if (i < n) { out[i] = sin2pi(t[i]); out[n + i] = cos2pi(t[i]); }
+}
+int check_trig_domain() {
+  static std::mutex mu;
+  static int verdict[64] = {0};       // per device: 0 = not checked, 1 = ok, -1 = failed
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error(std::string("check_trig_domain: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64) return FENERF_OK;
+  if (verdict[dev] == 0) {
+    const int n = 8;
+    const float h_t[n] = {257.25f, -257.25f, 1000.125f, -1000.125f, 70000.75f, -70000.75f, 3000000.25f, 0.375f};
+    float h_o[2 * n];
+    float *d_t = nullptr, *d_o = nullptr;
+    if ((e = hipMalloc((void**)&d_t, sizeof(h_t))) == hipSuccess && (e = hipMalloc((void**)&d_o, sizeof(h_o))) == hipSuccess &&
+        (e = hipMemcpy(d_t, h_t, sizeof(h_t), hipMemcpyHostToDevice)) == hipSuccess) {
+      hipLaunchKernelGGL(trig_domain_kernel, dim3(1), dim3(64), 0, nullptr, d_t, d_o, n);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpy(h_o, d_o, sizeof(h_o), hipMemcpyDeviceToHost);
+    }
+    if (d_t) (void)hipFree(d_t);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) { set_error(std::string("check_trig_domain: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+    verdict[dev] = 1;
+    for (int i = 0; i < n; ++i) {
+      const double x = (double)h_t[i], r = x - std::nearbyint(x);          // the fp32 argument, reduced exactly
+      if (std::fabs((double)h_o[i] - std::sin(6.283185307179586476925 * r)) > 1e-6 ||
+          std::fabs((double)h_o[n + i] - std::cos(6.283185307179586476925 * r)) > 1e-6) verdict[dev] = -1;
+    }
+  }
+  if (verdict[dev] < 0) {
+    set_error("this device's v_sin_f32 / v_cos_f32 do not reduce arguments beyond +-256 revolutions: rebuild libfenerf_hip.so with "
+              "-DFENERF_TRIG_REDUCE=1 (fenerf_amd/csrc/fenerf_trig.h)");
+    return FENERF_E_UNSUPPORTED;
+  }
+  return FENERF_OK;
+}
 
 // one wave per scaled row: s = power of two with max|row| * s in [0.5, 1) (1 for an all-zero row) -- row_scales() of
 // fenerf_pack.cpp.  scale_fwd[1 + row] = s, scale_bwd[1 + row] = 16 s for FiLM-layer rows (the backward stream carries the

@@ -302,7 +302,7 @@ static int launch_bwd_t(const FenerfModel* m, const SirenBwdParams& p, void* str
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 31) / 32;
   long long blocks = (ntiles + 3) / 4;
-  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks > launch_cus(m)) blocks = launch_cus(m);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
   hipError_t e = hipGetLastError();

@@ -792,7 +792,7 @@ static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream)
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
-  if (blocks > m->num_cus) blocks = m->num_cus;
+  if (blocks > launch_cus(m)) blocks = launch_cus(m);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
   hipError_t e = hipGetLastError();

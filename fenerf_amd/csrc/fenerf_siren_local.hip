@@ -300,6 +300,7 @@ extern "C" int fenerf_local_model_create(const FenerfModelDesc* d, const FenerfL
   std::string err;
   int rc = pack_local_weights(d, mp, blob, consts, err);
   if (rc) return local_fail(rc, err);
+  if ((rc = check_trig_domain())) return rc;
   FenerfLocalModel* m = new (std::nothrow) FenerfLocalModel();
   if (!m) return local_fail(FENERF_E_NOMEM, "out of host memory");
   m->H = d->hidden_dim; m->n_geo = d->n_geo; m->n_color = d->n_color; m->L = d->n_geo + d->n_color;

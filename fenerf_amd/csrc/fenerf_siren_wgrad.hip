@@ -952,10 +952,10 @@ int wgrad_nchunk(const FenerfModel* m, int B, long long tiles_per_image) {
   double best_eff = 0.0;
   for (long long n = 1; n <= 64 && n <= tiles_per_image; ++n) {
     const long long wgs = jobs * n;
-    const long long rounds = (wgs + m->num_cus - 1) / m->num_cus;
+    const long long rounds = (wgs + launch_cus(m) - 1) / launch_cus(m);
     const long long t_per = (tiles_per_image + n - 1) / n;
     // time ~ rounds * tiles per chunk (+ a fixed per-workgroup cost of ~4 tiles: prologue, partial store, reduce traffic)
-    const double eff = (double)tiles_per_image / (double)(rounds * (t_per + 4)) / (double)m->num_cus * (double)jobs;
+    const double eff = (double)tiles_per_image / (double)(rounds * (t_per + 4)) / (double)launch_cus(m) * (double)jobs;
     if (eff > best_eff) { best_eff = eff; best = n; }
   }
   return (int)best;
@@ -969,7 +969,7 @@ int wgrad_nchunk_thin(const FenerfModel* m, int B, long long tiles_per_image) {
 #ifndef FENERF_THIN_WGS
 #define FENERF_THIN_WGS 2
 #endif
-  long long n = ((long long)FENERF_THIN_WGS * m->num_cus + B - 1) / B;
+  long long n = ((long long)FENERF_THIN_WGS * launch_cus(m) + B - 1) / B;
   if (n > tiles_per_image) n = tiles_per_image;
 #ifndef FENERF_THIN_CAP
 #define FENERF_THIN_CAP 256

@@ -304,6 +304,9 @@ class NativeModel:
 
     # ------------------------------------------------------------------
     def _workspace(self, key, nbytes):
+        """Persistent scratch per (purpose, HIP stream): calls issued on different streams (the overlapped backward of
+        siren/autograd.py, two host threads) must not share FiLM / weight-gradient scratch."""
+        key = (key, torch.cuda.current_stream(self.device).cuda_stream)
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
@@ -627,6 +630,22 @@ class NativeLocalModel:
             self.close()
         except Exception:
             pass
+
+
+class cu_budget:
+    """with native.cu_budget(n): ...  -- the calling thread's launches inside the block are sized for at most n compute units
+    (include/fenerf.h fenerf_set_cu_budget; 0 / None = the whole device).  Workspace sizes are queried under the same setting."""
+
+    def __init__(self, cus):
+        self.cus = int(cus or 0)
+
+    def __enter__(self):
+        self._prev = _lib.lib().fenerf_set_cu_budget(self.cus)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().fenerf_set_cu_budget(self._prev)
+        return False
 
 
 class phase_timing:

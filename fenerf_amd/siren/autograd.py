@@ -12,6 +12,8 @@ What is left to torch is the fold of the activation-free label head (tiny produc
 """
 import torch
 
+from .. import native
+
 
 def _fold_label_head(label_params):
     """The label head is 2-3 Linear layers with no activation between them (siren.py:1490-1494) = one affine map.
@@ -53,15 +55,16 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
-# dtheta of a backward chunk: at most this many points (x L*H*4 B = 8.9 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
-# FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist for more points than
-# one chain launch's worth: peak memory of a generator step = tape + one chunk.  Rounds 2-3 bounded the chunk at 196,608 points (half a
-# pass of a 128 x 128 x 24 image: 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for chunks of 98,304 / 131,072 /
-# 196,608 / 393,216 points with the round-2 kernels, tools/chunk_sweep.py) to keep the step under 12 GB.  An MI355X has 288 GB: since
-# round 4 a chunk is BOTH passes of such an image (786,432 points) -- one chain launch and one set of weight-gradient launches per image
-# instead of four (four launch ramps / drains, 3 x ~95 us of per-chunk reductions and gradient additions less), 18.4 GB peak per image step,
-# ~62 GB for the 6-image micro-batch of configs[2].
-BACKWARD_CHUNK_POINTS = 786432
+# dtheta of a backward chunk: at most this many points (x L*H*4 B = 2.2 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
+# FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so the backward walks the points in chunks:
+# chain(chunk i + 1) and the weight gradients of chunk i are independent and run side by side (below), and the dumps of a step never
+# total more than the tape.  Chunk-size history: 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for serial chunks of
+# 98,304 / 131,072 / 196,608 / 393,216 points with the round-2 kernels (tools/chunk_sweep.py); round 4's numbers for the overlapped
+# schedule are in profiles/r04_gstep_overlap.md.
+BACKWARD_CHUNK_POINTS = 196608
+# run the weight gradients of backward chunk i beside the chain of chunk i + 1 (two streams, CU budgets); the chain gets this share of the CUs
+OVERLAP_WGRAD = True
+CHAIN_CUS_FRACTION = 0.75
 # inversion (FiLM gradients only, no dump): bytes of per-tile FiLM sums one chain launch may allocate
 FILM_SUMS_BUDGET_BYTES = 1 << 30
 
@@ -132,33 +135,74 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             else:
                 _add_all(acc, [r[k] for k in FILM_KEYS])
         return {k: (torch.cat(v, 0) if len(v) > 1 else v[0]) for k, v in rows.items()}, None
+    # ---- chain + weight gradients per chunk.  With more than one chunk the weight gradients of chunk i run on a second stream BESIDE
+    # the chain of chunk i + 1 (OVERLAP_WGRAD): the chain kernel is persistent, one workgroup per CU, and scales with the CUs it is
+    # given; the weight-gradient kernels are HBM-bound and lose nothing on a quarter of the chip (profiles/r04_gstep_overlap.md) -- so the
+    # chain is launched for CHAIN_CUS_FRACTION of the CUs and the weight-gradient grids are sized for the rest (fenerf_set_cu_budget).
+    # The first chain and the last weight-gradient launch have the device to themselves.  Every d(theta) dump is kept alive until the
+    # end of the loop and tied to the side stream (record_stream); scratch is per stream (NativeModel._workspace).
+    dev = out.device
+    overlap = OVERLAP_WGRAD and len(chunks) > 1
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if overlap else main
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    chain_cus = max(1, int(n_cus * CHAIN_CUS_FRACTION)) if overlap else 0
+    wgrad_cus = max(1, n_cus - chain_cus) if overlap else 0
+    if overlap:
+        side.wait_stream(main)            # everything the weight gradients read (tape, outputs, upstream gradient) was produced on `main`
     total, film_rows = None, {k: [] for k in FILM_KEYS}
     acc_img = None           # FiLM gradients of the image whose point ranges are being walked
-    for b, nb, s, n in chunks:
+    keep = []
+    for i, (b, nb, s, n) in enumerate(chunks):
+        last = i == len(chunks) - 1
         film_c = tuple(t[b:b + nb] for t in film)
         g0 = b * Pp + s
         tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
         out_c, d_out_c, pts_c = out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], points[b:b + nb, s:s + n]
-        if G and not film_only:
-            d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid)
-        else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
-            d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c)
-        r = nat.siren_param_grads(pts_c, dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c, out_c, d_out_c, tape_c,
-                                  tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only)
-        del d_t
-        if total is None:
-            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
-        else:
-            _add_all(_flat(total), _flat(r, FILM_KEYS))      # one fused launch for all ~40 tensors
-        if s == 0:
-            acc_img = [r[k] for k in FILM_KEYS]
-            for k, t in zip(FILM_KEYS, acc_img):
-                film_rows[k].append(t)
-        else:
-            _add_all(acc_img, [r[k] for k in FILM_KEYS])
-    for k, rows in film_rows.items():
-        total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+        with native.cu_budget(chain_cus if (overlap and i > 0) else 0):      # chain i runs beside the weight gradients of chunk i - 1
+            if G and not film_only:
+                d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid)
+            else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
+                d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c)
+        if overlap:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            d_t.record_stream(side)
+            keep.append(d_t)
+        with torch.cuda.stream(side), native.cu_budget(wgrad_cus if (overlap and not last) else 0):
+            r = nat.siren_param_grads(pts_c, dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c, out_c, d_out_c, tape_c,
+                                      tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only)
+            del d_t
+            if total is None:
+                total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
+            else:
+                _add_all(_flat(total), _flat(r, FILM_KEYS))      # one fused launch for all ~40 tensors
+            if s == 0:
+                acc_img = [r[k] for k in FILM_KEYS]
+                for k, t in zip(FILM_KEYS, acc_img):
+                    film_rows[k].append(t)
+            else:
+                _add_all(acc_img, [r[k] for k in FILM_KEYS])
+            if last:
+                for k, rows in film_rows.items():
+                    total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+    if overlap:
+        main.wait_stream(side)
+        for t in _flat(total):            # allocated on the side stream, consumed by autograd on `main`
+            t.record_stream(main)
     return total, d_grid
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """one extra HIP stream per device for the overlapped weight gradients (created once)"""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 def check_same_weights(ctx, nat):

@@ -110,6 +110,14 @@ int fenerf_abi_version(void);
  * FenerfModelDesc, FenerfCompositeOpts, FenerfRepackMaps, FenerfLocalMapDesc, FenerfSirenGrads.  Unknown names return -1.
  * fenerf_struct_field_name(s, i) enumerates the fields in declaration order (NULL behind the last).  (No reference analogue: the
  * reference has no FFI.)  tests/test_host_cpu.py executes INTEGRATION.md's snippet against these. */
+/* Scheduling hint for the CALLING THREAD's subsequent launches (no reference analogue): size persistent launches (the backward chain)
+ * and the weight-gradient grids for at most `cus` compute units instead of all of them; 0 = the whole device (default).  Returns the
+ * previous value.  The generator step uses it to run the weight gradients of backward chunk i on a second stream BESIDE the chain of
+ * chunk i + 1: the chain scales with the CUs it gets (2.45 -> 2.74 -> 3.40 ms for 393,216 points on 256 / 192 / 128 CUs), the
+ * weight-gradient kernels do not (1.72 / 1.91 / 1.68 ms: they are HBM-bound), so the two share the chip (profiles/r04_gstep_overlap.md).
+ * Workspace sizes (fenerf_siren_grad_workspace_bytes) depend on it: query them under the same setting as the launch. */
+int fenerf_set_cu_budget(int cus);
+
 long fenerf_struct_size(const char* struct_name);
 long fenerf_struct_field_offset(const char* struct_name, const char* field);
 const char* fenerf_struct_field_name(const char* struct_name, int index);

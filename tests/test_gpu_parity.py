@@ -439,7 +439,7 @@ def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, s
     if np.dtype(dtype) != np.float32:
         oo, dd, zz = (a.astype(dtype) for a in (oo, dd, zz))
         uu = uu.astype(dtype) if uu is not None else None
-    px, dp, zs = [], [], []
+    px, dp, zs, ws = [], [], [], []
     for s0 in range(0, R, slab):
         sl = slice(s0, min(R, s0 + slab))
         o_, d_, z_ = oo[:, sl], dd[:, sl], zz[:, sl]
@@ -454,8 +454,9 @@ def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, s
             ao, az = O.merge_sorted(fine, coarse, zf, z_[..., None])
         else:
             ao, az = coarse, z_[..., None]
-        r_rgb, r_depth, _ = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color=fill_color)
-        px.append(r_rgb); dp.append(r_depth[..., 0]); zs.append(az[..., 0])
+        r_rgb, r_depth, r_w = O.fancy_integration(ao, az, clamp_mode="relu", fill_mode="seg_padding_background", fill_color=fill_color)
+        px.append(r_rgb); dp.append(r_depth[..., 0]); zs.append(az[..., 0]); ws.append(r_w[..., 0].sum(-1))
+    _oracle_render_rays.weights_sum = np.concatenate(ws, 1)     # [B,R]: how close every ray is to the 0.9 fill threshold (volumetric_rendering.py:84)
     return np.concatenate(px, 1), np.concatenate(dp, 1), np.concatenate(zs, 1)
 
 
@@ -475,6 +476,17 @@ def _check_render_vs_oracle(tag, nat, rays, tf, opts, rgb, depth, r_rgb, r_depth
         flip = np.abs(zs - r_z).max(-1) > 1e-5
     else:
         flip = np.zeros(err.shape, bool)
+    # FILL-THRESHOLD rays: seg_padding_background paints a ray whose weights_sum is below 0.9 (volumetric_rendering.py:84); a ray whose
+    # oracle weights_sum is within 2e-5 (fp32 rounding of a 48 .. 96-term sum) of 0.9 may be painted by one evaluation and not by the other
+    # -- a whole-pixel difference that is the reference's own discontinuity.  Such rays are excluded, counted and bounded: <= 2 per 16,384.
+    r_ws = getattr(_oracle_render_rays, "weights_sum", None)
+    thr = ((rgb[..., 0] == 1) != (r_rgb[..., 0] == 1))
+    if thr.any():
+        assert r_ws is not None and r_ws.shape == thr.shape and (np.abs(r_ws[thr] - 0.9) <= 2e-5).all(), "a fill decision differs away from the 0.9 threshold"
+        assert int(thr.sum()) <= max(2, err.size // 8192)
+        print(f"[parity] {tag}: {int(thr.sum())} ray(s) sit on the 0.9 fill threshold (oracle weights_sum {r_ws[thr].tolist()}) and are painted by one side only: excluded")
+        keep = ~thr
+        err, flip, rgb, r_rgb, depth, r_depth = err[keep][None], flip[keep][None], rgb[keep][None], r_rgb[keep][None], depth[keep][None], r_depth[keep][None]
     over = err > 1e-3
     derr = np.abs(depth - r_depth)
     print(f"[parity] {tag}: max|err| {err.max():.3e} over {err.size} rays; {int(over.sum())} rays > 1e-3 ({int((over & flip).sum())} of them "
@@ -521,7 +533,6 @@ def test_full_size_128_24p24_properties_and_oracle_all_rays(precision):
     # merge -> composite), in slabs of 2,048 rays to bound the numpy activations; ~10 s on the GPU box's host cores
     args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
     r_rgb, r_depth, r_z = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white")
-    assert ((rgb[..., 0] == 1) == (r_rgb[..., 0] == 1)).all(), "fill decisions"
     _check_render_vs_oracle(f"128x128 24+24 H=256 [{precision}] vs oracle on ALL {R} rays", nat, (o, d, z, u), tf, opts, rgb, depth, r_rgb, r_depth, r_z)
 
 
@@ -552,6 +563,7 @@ def test_resampling_flips_against_an_fp64_arbiter():
     opts = _lib.composite_opts("relu", fill_mode="seg_padding_background", fill_color="white")
     px32, dp32, z32 = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white")
     px64, dp64, z64 = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white", dtype=np.float64)
+    ws64 = _oracle_render_rays.weights_sum
     flip32 = np.abs(z32 - z64).max(-1) > 1e-5
     e32, d32 = np.abs(px32 - px64).max(-1), np.abs(dp32 - dp64)
     assert flip32.any() and e32[~flip32].max() <= 1e-3
@@ -566,6 +578,7 @@ def test_resampling_flips_against_an_fp64_arbiter():
         flip = np.abs(zs - z64).max(-1) > 1e-5
         both = flip & flip32
         err, derr = np.abs(rgb - px64).max(-1), np.abs(depth - dp64)
+        err = np.where((rgb[..., 0] == 1) != (px64[..., 0] == 1), 0.0, err)        # rays ON the fill threshold: asserted separately below
         over = err > 1e-3
         print(f"[parity] fp64 arbiter, native {precision}: {int(flip.sum())} rays resample differently from fp64 ({int(both.sum())} of them are the fp32 "
               f"oracle's flips too); pixel error on them max {err[flip].max():.2e} mean {err[flip].mean():.2e}, elsewhere {err[~flip].max():.2e} "
@@ -575,7 +588,8 @@ def test_resampling_flips_against_an_fp64_arbiter():
         assert err[~flip].max() <= 1e-3 and derr[~flip].max() <= 2e-3 and not (over & ~flip).any()
         assert err[flip].max() <= 1.5 * e32[flip32].max() and err[flip].mean() <= 1.5 * e32[flip32].mean()
         assert derr[flip].max() <= 1.5 * d32[flip32].max() and derr[flip].mean() <= 1.5 * d32[flip32].mean()
-        assert ((rgb[..., 0] == 1) == (px64[..., 0] == 1)).all(), "fill decisions agree with fp64 on every ray"
+        thr = (rgb[..., 0] == 1) != (px64[..., 0] == 1)
+        assert int(thr.sum()) <= 2 and (np.abs(ws64[thr] - 0.9) <= 2e-5).all(), "fill decisions agree with fp64 on every ray that is not ON the 0.9 threshold"
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1767,9 +1781,9 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
     checked at the generator step's own size: bench model (H = 256 + 32 x 96^3 grid), the two passes of a 128 x 128 x 24 image = 786,432
     points.  The upstream gradient is non-zero only on a 2,048-ray slab (98,304 points over both passes), so the full-size backward must
     reproduce, voxel for voxel, the fp64 autograd gradient of that slab alone -- and leave every voxel the slab does not touch at exactly
-    zero.  Run twice: as ONE production chunk (786,432 points in one chain launch and one set of weight-gradient launches: 8.9 GB of
-    d(theta), offsets beyond 2^32 bytes) and as four 196,608-point chunks whose first boundary the slab straddles.  All other gradient
-    tensors ride along."""
+    zero.  Run twice: as ONE chunk (786,432 points in one chain launch and one set of weight-gradient launches: 8.9 GB of d(theta),
+    offsets beyond 2^32 bytes) and as the production schedule -- four 196,608-point chunks whose first boundary the slab straddles, the
+    weight gradients of chunk i on a second stream beside the chain of chunk i + 1.  All other gradient tensors ride along."""
     from oracle import fenerf_oracle_grad as OG
     from fenerf_amd.siren import autograd as SA
     spec, sd = _full_weights()
@@ -1789,7 +1803,7 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
     film = proc.film_params(spec, 1, seed=0)
     film2 = {k: np.repeat(v, 2, 0) for k, v in film.items()}                          # both passes of one image share its FiLM block
     r0, r1 = 7168, 9216                                                                # rays of the slab: points [172,032, 221,184) of each pass
-    assert r0 * N < 196608 < r1 * N and SA.BACKWARD_CHUNK_POINTS >= 2 * R * N
+    assert r0 * N < 196608 < r1 * N
     rng = np.random.default_rng(5)
     g_slab = rng.normal(size=(2, (r1 - r0) * N, 22)).astype(np.float32)
     g_slab[..., -1] *= 1e-3                                                            # sigma is ~2000 x the other outputs in this model
@@ -1806,7 +1820,7 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
         (ref * t64(g_slab[:, sl])).sum().backward()
     g_ref = sd64["spatial_embeddings"].grad.numpy()
     touched_ref = np.abs(g_ref).max(1) > 0
-    for chunk in (SA.BACKWARD_CHUNK_POINTS, 196608):
+    for chunk in (2 * R * N, 196608):
         old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
         try:
             for p_ in mod.parameters():
@@ -2201,10 +2215,10 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
     else:
         px, _ = gen.forward_with_frequencies(tf[0], tf[2], tf[1], tf[3], **common)
     assert not gen.draws.arrays and px.requires_grad
-    # *_bigfilm (round 4): FiLM phase shifts of +-300 revolutions, first-layer frequency x 30 -- the reference's fp32 radians carry an
-    # argument rounding of 2.4e-4 rad there; its pixels / gradients sit 2e-3 / 4.9e-2 from the fp64 restatement (tests/test_oracle_golden.py)
+    # *_bigfilm (round 4): FiLM phase shifts of +-300 revolutions, first-layer frequency x 4 -- the reference's fp32 radians carry an
+    # argument rounding of 1.2e-4 .. 2.4e-4 rad there; its gradients sit 8e-4 from the fp64 restatement (tests/test_oracle_golden.py)
     big = name.endswith("_bigfilm")
-    assert np.abs(N_(px) - g["pixels"]).max() <= (5e-3 if big else 1e-3)
+    assert np.abs(N_(px) - g["pixels"]).max() <= (2e-3 if big else 1e-3)
     (px * T(g["loss_w"])).sum().backward()
     worst = 0.0
     for t, k in zip(tf, ("freq_geo", "phase_geo", "freq_app", "phase_app")):
@@ -2218,7 +2232,7 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
     print(f"[parity] generator gradients vs the reference's autograd {name}[{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
     # bound = the reference's own fp32 rounding: the fp64 restatement differs from these fixtures by 1.5e-4 (texture),
     # 4.8e-3 (baseline: softplus + last_back cancellation in final_layer.weight) and 1.8e-4 (single latent) on the CPU
-    assert n == {"texture": 33, "baseline": 30, "spatial": 22}[kind] and worst <= (1e-1 if big else 5e-3)
+    assert n == {"texture": 33, "baseline": 30, "spatial": 22}[kind] and worst <= (1e-2 if big else 5e-3)
 
 
 def test_amp_class_weight_gradients_against_the_references_own_autocast_step():
@@ -2435,21 +2449,21 @@ def test_siren_backward_with_sine_arguments_far_beyond_init(rev, precision):
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd_bigfilm", "h256_texture_8x8_n12_bigfilm"])
 def test_reference_fixtures_far_beyond_the_init_range(name, precision):
-    """The reference's own outputs with FiLM phase shifts of +-300 revolutions in every layer and the first layer's frequency x 30
-    (tools/make_golden.py, round 4; sine arguments 256 .. 450 revolutions: all beyond the hardware sine's documented domain): the
+    """The reference's own outputs with FiLM phase shifts of +-300 revolutions in every layer and the first layer's frequency x 4
+    (tools/make_golden.py, round 4; sine arguments 256 .. 320 revolutions: all beyond the hardware sine's documented domain): the
     SIREN kernels on the recorded coarse and fine points (teacher-forced), then generator.forward_with_frequencies on the recorded
-    draws.  Tolerances = the fixture's distance from fp64 (tests/test_oracle_golden.py): rgb 5e-5, sigma 4e-5 x sigma_gain; end to
-    end the bulk of the pixels (a 1e-7 change of a resampled depth moves a first-layer argument by 3e-4 rad at 30 x the frequency)."""
+    draws.  Tolerances = the fixture's distance from fp64 (tests/test_oracle_golden.py): rgb 5e-5, sigma 1e-4 x sigma_gain; end to
+    end the bulk of the pixels."""
     g = load_golden(name)
     nat, spec, sd = _native_for(name, precision)
     film, tf = _film(g, spec)
     B, R, N = g["st_z_coarse"].shape[:3]
     pts = g["st_points"].reshape(B, R * N, 3)
     dirs = np.broadcast_to(g["st_dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
-    sig_tol = 4e-5 * float(g["meta_sigma_gain"])
+    sig_tol = 1e-4 * float(g["meta_sigma_gain"])
     for tag, p_, ref in (("coarse", pts, g["st_siren_coarse"]), ("fine", g["st_fine_points"], g["st_siren_fine"])):
         out = N_(nat.siren_forward(T(p_), T(dirs), *tf))
-        _report(f"{name}[{precision}] {tag} vs reference (sine arguments 256 .. 450 rev)", out, ref)
+        _report(f"{name}[{precision}] {tag} vs reference (sine arguments 256 .. 320 rev)", out, ref)
         np.testing.assert_allclose(out[..., -4:-1], ref[..., -4:-1], atol=5e-5)
         np.testing.assert_allclose(out[..., :-4], ref[..., :-4], atol=2e-6, rtol=1e-4)
         np.testing.assert_allclose(out[..., -1], ref[..., -1], atol=sig_tol, rtol=2e-4)
@@ -2462,8 +2476,8 @@ def test_reference_fixtures_far_beyond_the_init_range(name, precision):
     assert not gen.draws.arrays
     e = np.abs(N_(px) - g["pixels"]).max(axis=1)
     print(f"[parity] {name}[{precision}] forward_with_frequencies vs reference: median|err| {np.median(e):.2e} max {e.max():.2e}, {int((e > 2e-3).sum())} of "
-          f"{e.size} pixels beyond 2e-3 (the fp32 numpy oracle: 0 of 128 / 4 of 64, the fp64 one up to 7e-3 on the H = 256 fixture)")
-    assert np.median(e) <= 2e-4 and (e > 2e-3).mean() <= 0.15
+          f"{e.size} pixels beyond 2e-3")
+    assert np.median(e) <= 2e-4 and (e > 2e-3).mean() <= 0.05
 
 
 def test_integration_md_binding_renders():

@@ -149,18 +149,18 @@ def test_forward_stagewise(name):
 @pytest.mark.parametrize("name", ["tiny_texture_fwd_bigfilm", "h256_texture_8x8_n12_bigfilm"])
 def test_forward_far_beyond_the_init_range_of_the_film_parameters(name):
     """Fixtures recorded from the reference with FiLM phase shifts of up to +-300 revolutions in every layer and the first layer's
-    frequency x 30 (sine arguments up to ~450 revolutions; tools/make_golden.py, round 4): torch.sin on fp32 radians of that size
+    frequency x 4 (sine arguments 256 .. 320 revolutions; tools/make_golden.py, round 4): torch.sin on fp32 radians of that size
     (siren.py:113-123) is what a hardware sine defined on +-256 revolutions must reproduce.  Pins the oracle there: teacher-forced
-    per stage, tolerances = the fp32 rounding of a ~2,800-rad argument (ulp 2.4e-4 rad) through the layers behind it."""
+    per stage, tolerances = the fp32 rounding of a ~2,000-rad argument (ulp 1.2e-4 .. 2.4e-4 rad) through the layers behind it."""
     g = load_golden(name)
-    assert float(g["meta_film_phase_rev"]) == 300.0 and float(g["meta_film_freq0_gain"]) == 30.0
+    assert float(g["meta_film_phase_rev"]) == 300.0 and float(g["meta_film_freq0_gain"]) == 4.0
     spec, sd, film = _model(g)
     B, R, N = g["st_z_coarse"].shape[:3]
     args = (film["freq_geo"], film["phase_geo"], film.get("freq_app"), film.get("phase_app"))
     dirs = np.broadcast_to(g["st_dirs"][:, :, None, :], (B, R, N, 3)).reshape(B, R * N, 3)
     tap = []
     out = O.siren_forward(sd, spec, g["st_points"].reshape(B, R * N, 3), dirs, *args, rev_tap=tap)
-    assert max(tap) > 380 and min(tap) > 256, tap                  # every layer beyond the hardware's documented domain
+    assert min(tap) > 256, tap                  # every layer beyond the hardware's documented domain
     sig_tol = 4e-5 * float(g["meta_sigma_gain"])
     for got, ref in ((out, g["st_siren_coarse"]), (O.siren_forward(sd, spec, g["st_fine_points"], dirs, *args), g["st_siren_fine"])):
         np.testing.assert_allclose(got[..., -4:-1], ref[..., -4:-1], atol=5e-5)
@@ -175,13 +175,11 @@ def test_forward_far_beyond_the_init_range_of_the_film_parameters(name):
     zf = O.fine_z_from_coarse(g["st_coarse_weights"], g["st_z_coarse"], g["rand_u_fine"])
     np.testing.assert_allclose(zf.reshape(B * R, N), g["st_z_fine"], atol=5e-6)      # (near-empty bins: conditioning, as in test_sample_pdf_cases)
     px, depth, third, st = _render(g)
-    # End to end the fixture is at the reference's own fp32 noise floor: with the first layer at 30 x the init frequency the field
-    # varies 30 x faster in space, and a 1e-7 difference in a resampled depth moves a sine argument by 3e-4 rad -- the fp64 oracle
-    # differs from the reference's pixels by up to 7e-3 on the H = 256 fixture, the fp32 oracle by up to 1.1e-2.  Asserted: the bulk.
+    # End to end: the bulk of the pixels (a resampling flip moves a pixel by more; none is expected on fixtures this small)
     e = np.abs(px - g["pixels"]).max(axis=1)
     print(f"[oracle] {name}: sine arguments up to {max(tap):.0f} revolutions; end-to-end pixels median|err| {np.median(e):.2e} max {e.max():.2e}, "
           f"{int((e > 2e-3).sum())} of {e.size} beyond 2e-3")
-    assert np.median(e) <= 2e-4 and (e > 2e-3).mean() <= 0.15
+    assert np.median(e) <= 2e-4 and e.max() <= 2e-3
 
 
 @pytest.mark.parametrize("name", ["tiny_texture_staged", "tiny_texture_staged_lock", "tiny_spatial_staged"])
@@ -302,8 +300,8 @@ def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
 
 @pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm"])
 def test_grad_oracle_matches_reference_autograd(name):
-    # *_bigfilm: FiLM phase shifts of +-300 revolutions, first-layer frequency x 30 (round 4): the reference's fp32 radians carry an
-    # argument rounding of 2.4e-4 rad there, so its own pixels / gradients sit that much further from fp64
+    # *_bigfilm: FiLM phase shifts of +-300 revolutions, first-layer frequency x 4 (round 4): the reference's fp32 radians carry an
+    # argument rounding of 1.2e-4 .. 2.4e-4 rad there, so its own pixels / gradients sit that much further from fp64 (measured 8e-4)
     big = name.endswith("_bigfilm")
     """tests/golden/tiny_*_grad.npz hold gradients computed by the REFERENCE's own autograd through
     generator.forward_with_frequencies (tools/make_golden.py::run_grad_case).  The torch fp64 restatement used to check the
@@ -344,7 +342,7 @@ def test_grad_oracle_matches_reference_autograd(name):
                                    noise_std=kw["nerf_noise"], clamp_mode=kw["clamp_mode"], white_back=kw.get("white_back", False),
                                    last_back=kw.get("last_back", False))
     px = rgb.reshape(B, S, S, C - 1).permute(0, 3, 1, 2) * 2 - 1
-    np.testing.assert_allclose(px.detach().numpy(), g["pixels"], atol=5e-3 if big else 2e-4)
+    np.testing.assert_allclose(px.detach().numpy(), g["pixels"], atol=1e-3 if big else 2e-4)
     (px * t(g["loss_w"])).sum().backward()
 
     def rel(a, b):
@@ -353,7 +351,7 @@ def test_grad_oracle_matches_reference_autograd(name):
     errs.update({k: rel(v.grad.numpy(), g["gparam_" + k]) for k, v in sd64.items()})
     worst = max(errs, key=errs.get)
     print(f"[oracle] {name}: worst relative gradient error {errs[worst]:.2e} ({worst})")
-    assert errs[worst] <= (1e-1 if big else 5e-3), (worst, errs[worst])      # the reference ran fp32 on the CPU through a frequency-30 SIREN
+    assert errs[worst] <= (1e-2 if big else 5e-3), (worst, errs[worst])      # the reference ran fp32 on the CPU through a frequency-30 SIREN
 
 
 def test_spatial_siren_grid_per_point_modulation():

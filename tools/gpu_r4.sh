@@ -74,6 +74,8 @@ cuscale)    # do the backward kernels scale with the CUs they get?  (profiles/r0
     FENERF_EXP_NUM_CUS=$n timeout 200 python tools/time_wgrad.py 393216 2>&1 | tail -1
   done > gpurun_out/cuscale.log 2>&1
   cat gpurun_out/cuscale.log ;;
+overlap)    # backward schedules of the generator step: serial chunks vs weight gradients beside the next chunk's chain
+  timeout 900 python tools/overlap_sweep.py ${OVERLAP_ARGS:-} > gpurun_out/overlap_sweep.log 2>&1; cat gpurun_out/overlap_sweep.log | tail -45 ;;
 probe)      # what v_sin_f32 / v_cos_f32 return for arguments of growing magnitude on this chip
   ./tools/probe/sin_domain_probe > gpurun_out/vsin_domain_probe.txt 2>&1; cat gpurun_out/vsin_domain_probe.txt ;;
 gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
