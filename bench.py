@@ -168,8 +168,10 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    out = {"ms": ms, "what": f"forward + backward + device re-pack of one generator step, batch {B} x {S}x{S} rays x {N}+{N} samples "
-                             f"({B * S * S * 2 * N} points), native differentiable path, precision {precision}, weight-gradient operands "
+    out = {"ms": ms, "what": f"generator.forward_with_frequencies + backward + device re-pack, batch {B} x {S}x{S} rays x {N}+{N} samples "
+                             f"({B * S * S * 2 * N} points): the render part of a generator step -- the two mapping networks, their backward "
+                             f"and the optimizer are NOT in it (the reference's own step, generator_ddp(z) + backward [+ Adam], is "
+                             f"gstep_ddp.ms_no_ddp / .ms / .ms_with_optimizer); native differentiable path, precision {precision}, weight-gradient operands "
                              + ("fp32 class (default)" if grad_precision == "f32" else "bf16, one MFMA per product: AMP class, opt-in (siren.grad_precision = 'amp')"),
            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
     if not breakdown:
@@ -535,6 +537,9 @@ def main(argv=None):
         if sweep:
             out["sweep64"] = sweep
         out.update(ddp_legs)
+        if "ms_no_ddp" in ddp_legs.get("gstep_ddp", {}):     # the reference's G step on one GPU without the wrapper: generator(z_geo, z_app) + backward
+            out["gstep_z"] = {"ms": ddp_legs["gstep_ddp"]["ms_no_ddp"], "what": "generator(z_geo, z_app, **metadata) + backward on the bare module "
+                              "(both mapping networks inside; = gstep_ddp.ms_no_ddp)"}
         if world == 1 and not args.no_f32 and args.precision != "f32":
             try:
                 nat32 = native.NativeModel(sd, spec, dev, "f32")

@@ -55,18 +55,23 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
     return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
 
 
-# dtheta of a backward chunk: at most this many points (x L*H*4 B = 2.2 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
-# FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so the backward walks the points in chunks:
-# chain(chunk i + 1) and the weight gradients of chunk i are independent and run side by side (below), and the dumps of a step never
-# total more than the tape.  Chunk-size history: 13.09 / 12.99 / 12.76 / 12.57 ms at 10.5 / 10.9 / 11.6 / 14.0 GB peak for serial chunks of
-# 98,304 / 131,072 / 196,608 / 393,216 points with the round-2 kernels (tools/chunk_sweep.py); round 4's numbers for the overlapped
-# schedule are in profiles/r04_gstep_overlap.md.
-BACKWARD_CHUNK_POINTS = 196608
-# run the weight gradients of backward chunk i beside the chain of chunk i + 1 (two streams, CU budgets); the chain gets this share of the CUs
-OVERLAP_WGRAD = True
-CHAIN_CUS_FRACTION = 0.75
+# dtheta of a backward chunk: at most this many points (x L*H*4 B = 4.4 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
+# FiLM layer (as large as the tape) only for the weight-gradient kernels to read it once, so it never needs to exist for more points than
+# one chain launch's worth: peak memory of a generator step = tape + one chunk.  Rounds 2-3 kept the chunk at 196,608 points to stay
+# under 12 GB; an MI355X has 288 GB, and the step at 1 x 128^2 x 24+24 measures 12.82 / 12.31 / 12.09 / 12.33 ms at 10.5 / 11.7 / 14.1 /
+# 18.9 GB peak for chunks of 98,304 / 196,608 / 393,216 / 786,432 points (round 4, tools/overlap_sweep.py, one box): one pass of a
+# 128 x 128 x 24 image per chunk.
+BACKWARD_CHUNK_POINTS = 393216
 # inversion (FiLM gradients only, no dump): bytes of per-tile FiLM sums one chain launch may allocate
 FILM_SUMS_BUDGET_BYTES = 1 << 30
+# Run the weight gradients of backward chunk i on a second stream BESIDE the chain of chunk i + 1 (CU budgets, fenerf_set_cu_budget).
+# Built and measured in round 4, OFF: the backward kernels are limited by what the memory system sustains for their access patterns
+# (4.0 - 5.8 TB/s), not by the CUs they occupy, so running two of them at once only makes both slower -- chain 1.12 -> 2.1 ms, square
+# weight gradients 0.77 -> 1.3 - 1.95 ms, thin jobs 0.2 -> 0.73 ms per 196,608-point chunk, step 12.3 -> 12.8 ms at best and 17 - 35 ms
+# with large chunks (profiles/r04_gstep_overlap.md: CU-scaling table, schedule sweep, kernel timeline).  tests/test_gpu_parity.py keeps
+# the schedule exact (it must equal the serial one); tools/overlap_sweep.py reproduces the measurement.
+OVERLAP_WGRAD = False
+CHAIN_CUS_FRACTION = 0.75
 
 
 FILM_KEYS = ("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")

@@ -1463,8 +1463,11 @@ def test_chunked_backward_equals_one_pass(precision):
     kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
               v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
     results = []
-    for chunk in (1 << 30, 128, 1700):
+    for chunk, overlap in ((1 << 30, False), (128, False), (1700, False), (128, True)):
+        # (128, True): the two-stream schedule of round 4 -- weight gradients of chunk i beside the chain of chunk i + 1 under CU budgets
+        # (OVERLAP_WGRAD; measured not to pay, profiles/r04_gstep_overlap.md, and off by default: kept exact here)
         SA_old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
+        ov_old, SA.OVERLAP_WGRAD = SA.OVERLAP_WGRAD, overlap
         try:
             film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
             for p_ in mod.parameters():
@@ -1477,14 +1480,15 @@ def test_chunked_backward_equals_one_pass(precision):
             grads.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
             results.append(grads)
         finally:
-            SA.BACKWARD_CHUNK_POINTS = SA_old
-    one, many, grouped = results
-    assert one.keys() == many.keys() == grouped.keys() and len(one) > 30
+            SA.BACKWARD_CHUNK_POINTS, SA.OVERLAP_WGRAD = SA_old, ov_old
+    one, many, grouped, overlapped = results
+    assert one.keys() == many.keys() == grouped.keys() == overlapped.keys() and len(one) > 30
     worst = max(_rel_err(many[k], one[k]) for k in one)
     worst_g = max(_rel_err(grouped[k], one[k]) for k in one)
+    worst_o = max(_rel_err(overlapped[k], one[k]) for k in one)
     print(f"[parity] chunked backward vs ONE launch over all images [{precision}]: worst relative difference over {len(one)} tensors "
-          f"{worst:.1e} (128-point chunks), {worst_g:.1e} (whole-image chunks)")
-    assert worst <= 2e-5 and worst_g <= 2e-5
+          f"{worst:.1e} (128-point chunks), {worst_g:.1e} (whole-image chunks), {worst_o:.1e} (128-point chunks, two-stream schedule)")
+    assert worst <= 2e-5 and worst_g <= 2e-5 and worst_o <= 2e-5
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -1781,9 +1785,9 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
     checked at the generator step's own size: bench model (H = 256 + 32 x 96^3 grid), the two passes of a 128 x 128 x 24 image = 786,432
     points.  The upstream gradient is non-zero only on a 2,048-ray slab (98,304 points over both passes), so the full-size backward must
     reproduce, voxel for voxel, the fp64 autograd gradient of that slab alone -- and leave every voxel the slab does not touch at exactly
-    zero.  Run twice: as ONE chunk (786,432 points in one chain launch and one set of weight-gradient launches: 8.9 GB of d(theta),
-    offsets beyond 2^32 bytes) and as the production schedule -- four 196,608-point chunks whose first boundary the slab straddles, the
-    weight gradients of chunk i on a second stream beside the chain of chunk i + 1.  All other gradient tensors ride along."""
+    zero.  Run three times: as ONE chunk (786,432 points in one chain launch and one set of weight-gradient launches: 8.9 GB of
+    d(theta), offsets beyond 2^32 bytes), as four serial 196,608-point chunks whose first boundary the slab straddles, and as those
+    four chunks on the two-stream schedule (OVERLAP_WGRAD).  All other gradient tensors ride along."""
     from oracle import fenerf_oracle_grad as OG
     from fenerf_amd.siren import autograd as SA
     spec, sd = _full_weights()
@@ -1820,8 +1824,9 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
         (ref * t64(g_slab[:, sl])).sum().backward()
     g_ref = sd64["spatial_embeddings"].grad.numpy()
     touched_ref = np.abs(g_ref).max(1) > 0
-    for chunk in (2 * R * N, 196608):
+    for chunk, overlap in ((2 * R * N, False), (196608, False), (196608, True)):
         old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, chunk
+        ov_old, SA.OVERLAP_WGRAD = SA.OVERLAP_WGRAD, overlap
         try:
             for p_ in mod.parameters():
                 p_.grad = None
@@ -1829,7 +1834,7 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
             out = mod.forward_with_frequencies_phase_shifts(pts, film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], dirs)
             (out * g_out).sum().backward()
         finally:
-            SA.BACKWARD_CHUNK_POINTS = old
+            SA.BACKWARD_CHUNK_POINTS, SA.OVERLAP_WGRAD = old, ov_old
         g_nat = N_(mod.spatial_embeddings.grad)
         touched_nat = np.abs(g_nat).max(1) > 0
         e_grid = _rel_err(g_nat, g_ref)
@@ -1837,7 +1842,7 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
         errs = {k: _rel_err(N_(film_t[k].grad), film64[k].grad.numpy()) for k in film2}
         errs.update({k: _rel_err(N_(named[k].grad), v.grad.numpy()) for k, v in sd64.items()})
         worst = max(errs, key=errs.get)
-        print(f"[parity] 96^3 grid gradient at full size (786,432 points in backward chunks of {chunk}, upstream gradient on a 2,048-ray slab): "
+        print(f"[parity] 96^3 grid gradient at full size (786,432 points in backward chunks of {chunk}{', two-stream schedule' if overlap else ''}, upstream gradient on a 2,048-ray slab): "
               f"{int(touched_nat.sum())} voxels touched (fp64 autograd of the slab alone: {int(touched_ref.sum())}), relative error (max-norm) "
               f"{e_grid:.2e}; stray non-zero voxels {int((touched_nat & ~touched_ref).sum())}; worst of all {len(errs)} gradient tensors {errs[worst]:.2e} ({worst})")
         assert not (touched_nat & ~touched_ref).any(), "a voxel the slab does not touch received gradient"
