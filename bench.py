@@ -235,8 +235,12 @@ def curriculum_generator(spec, sd, dev, precision, seed=11):
 
 
 GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_bytes", "allreduce_bytes_largest_tensor", "ddp_bucket_cap_mb",
-                  "allreduce_per_micro_batch", "ms_with_optimizer", "rays_per_s", "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend",
-                  "peak_GB")
+                  "allreduce_per_micro_batch", "ms_with_optimizer", "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "rays_per_s",
+                  "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend", "peak_GB")
+# what fenerf_amd recommends on xGMI instead of the reference's DDP defaults: gradients are views into the buckets (no copy in / out of a
+# 124-MB flat buffer per backward), every parameter takes part in every step (no autograd-graph traversal), and buckets large enough that
+# the 113-MB grid and the rest go out as two collectives instead of six (ring all-reduce over point-to-point links: per-link bound)
+TUNED_DDP = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=128)
 
 
 def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank):
@@ -276,18 +280,25 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         dist.init_process_group("nccl" if cuda else "gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, **kw)
         created = True
     try:
-        ddp = DDP(model, device_ids=[dev.index] if cuda else None, find_unused_parameters=True)
+        ddp = DDP(model, device_ids=[dev.index] if cuda else None, find_unused_parameters=True)      # the reference's wrapper, train...py:148
         ms = run(ddp, iters, False)
         ms_opt = run(ddp, max(2, iters // 2), True)
+        del ddp
+        opt.zero_grad(set_to_none=True)
+        ddp = DDP(model, device_ids=[dev.index] if cuda else None, **TUNED_DDP)
+        ms_tuned = run(ddp, iters, False)
         seen = torch.ones(1, device=dev)
         dist.all_reduce(seen)
         out = {"what": what, "ms": ms, "ms_no_ddp": ms_bare, "allreduce_ms_exposed": ms - ms_bare,
                "allreduce_bytes": sum(p.numel() * 4 for p in params), "allreduce_bytes_largest_tensor": max(p.numel() for p in params) * 4,
                "ddp_bucket_cap_mb": 25, "allreduce_per_micro_batch": True, "ms_with_optimizer": ms_opt,
+               "ms_tuned": ms_tuned, "allreduce_ms_exposed_tuned": ms_tuned - ms_bare,
+               "tuned_config": ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
                "rays_per_s": world * rays_per_rank / (ms * 1e-3), "n_ranks": world, "n_ranks_seen": int(seen.item()),
                "batch_per_rank": batch_per_rank, "dist_backend": dist.get_backend(),
                "peak_GB": torch.cuda.max_memory_allocated() / 2**30 if cuda else None}
         del ddp
+        opt.zero_grad(set_to_none=True)
     finally:
         if created:
             dist.destroy_process_group()
