@@ -1578,6 +1578,25 @@ def test_inversion_film_only_gradients_and_loop():
     assert all(p.grad is None for p in mod.parameters())
     for k in full:
         assert _rel_err(only[k], full[k]) <= 1e-5, k
+    # a FiLM-sum budget smaller than one image (round-3 advisory: launches were unbounded): the image is walked in point ranges of 128
+    # whose FiLM gradients add -- equal to the single launch up to fp32 summation order
+    from fenerf_amd.siren import autograd as SA
+    P_big = 640
+    pts_b, dirs_b = T(rng.uniform(-0.12, 0.12, (B, P_big, 3)).astype(np.float32)), T(rng.normal(size=(B, P_big, 3)).astype(np.float32))
+    g_b = T(rng.normal(size=(B, P_big, 22)).astype(np.float32))
+    res = []
+    for budget in (SA.FILM_SUMS_BUDGET_BYTES, 1):
+        old, SA.FILM_SUMS_BUDGET_BYTES = SA.FILM_SUMS_BUDGET_BYTES, budget
+        try:
+            ft = {k: T(v).requires_grad_(True) for k, v in film_np.items()}
+            out = mod.forward_with_frequencies_phase_shifts(pts_b, ft["freq_geo"], ft["freq_app"], ft["phase_geo"], ft["phase_app"], dirs_b)
+            (out * g_b).sum().backward()
+            res.append({k: N_(v.grad) for k, v in ft.items()})
+        finally:
+            SA.FILM_SUMS_BUDGET_BYTES = old
+    worst = max(_rel_err(res[1][k], res[0][k]) for k in res[0])
+    print(f"[parity] inversion with a FiLM-sum budget below one image (5 point ranges of 128 per image) vs one launch: {worst:.1e}")
+    assert worst <= 2e-5
 
     torch.manual_seed(3)
     gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
@@ -2046,6 +2065,17 @@ def test_backward_api_rejects_bad_arguments():
     assert l.fenerf_model_repack(diff._h, None, 0, C.byref(r), None, None) == _lib.E_INVALID
     rc = l.fenerf_model_export_packed(plain._h, None, 0, None, 0, p(scratch), 5, None)       # no backward stream to export
     assert rc == _lib.E_INVALID
+    # AMP-class model: the d(theta) dump's format (fp32 | bf16) follows from the chunk's point count; a weight-gradient call that
+    # describes the same buffer as a chunk of the other class is refused (round-3 advisory), the matching one runs
+    amp = native.NativeModel(sd, spec, DEV, "f16x3", differentiable=True, wgrad_bf16_min_points=64)
+    B2, P2 = 1, 96
+    pts2 = torch.zeros((B2, P2, 3), device=DEV)
+    out2, tape2, tape_e2 = amp.siren_forward_save(pts2, None, *args)
+    d_out2 = torch.ones_like(out2)
+    d_t2, _ = amp.siren_backward(B2, P2, *args, out2, d_out2, tape2)                           # 96 points >= 64: bf16 dump
+    with pytest.raises(_lib.FenerfError, match="other format"):
+        amp.siren_param_grads(pts2[:, :32].contiguous(), None, *args, out2[:, :32].contiguous(), d_out2[:, :32].contiguous(), tape2, tape_e2, d_t2)
+    amp.siren_param_grads(pts2, None, *args, out2, d_out2, tape2, tape_e2, d_t2)
     torch.cuda.synchronize()
 
 
