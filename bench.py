@@ -237,13 +237,12 @@ def curriculum_generator(spec, sd, dev, precision, seed=11):
 GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_bytes", "allreduce_bytes_largest_tensor", "ddp_bucket_cap_mb",
                   "allreduce_per_micro_batch", "ms_with_optimizer", "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "rays_per_s",
                   "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend", "peak_GB")
-# what fenerf_amd recommends on xGMI instead of the reference's DDP defaults: gradients are views into the buckets (no copy in / out of a
-# 124-MB flat buffer per backward), every parameter takes part in every step (no autograd-graph traversal), and buckets large enough that
-# the 113-MB grid and the rest go out as two collectives instead of six (ring all-reduce over point-to-point links: per-link bound)
-TUNED_DDP = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=128)
+# `ms_tuned`: what fenerf_amd recommends instead of the reference's wrapper -- fenerf_amd.dist.prepare_for_ddp(generator) (two-node backward:
+# the grid gradient reaches DDP before the weight-gradient kernels run, so its all-reduce overlaps them) + RECOMMENDED_DDP_KWARGS
+TUNED_DDP = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=128)       # == fenerf_amd.dist.RECOMMENDED_DDP_KWARGS
 
 
-def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank):
+def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank, tuned_prepare=None):
     """Times `loss_of(m).backward()` on the bare module and on DistributedDataParallel(module, find_unused_parameters=True) with the
     headline's bracket (barrier on both sides, max over ranks) -> the `gstep_ddp` object (GSTEP_DDP_KEYS).  Backend-agnostic: the GPU
     bench hands it the generator over RCCL; `--dist-check` (CPU, gloo, world 2) hands it a small stand-in so that the wrapper, the
@@ -285,15 +284,22 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         ms_opt = run(ddp, max(2, iters // 2), True)
         del ddp
         opt.zero_grad(set_to_none=True)
-        ddp = DDP(model, device_ids=[dev.index] if cuda else None, **TUNED_DDP)
-        ms_tuned = run(ddp, iters, False)
+        if tuned_prepare is not None:
+            tuned_prepare(True)
+        try:
+            ddp = DDP(model, device_ids=[dev.index] if cuda else None, **TUNED_DDP)
+            ms_tuned = run(ddp, iters, False)
+        finally:
+            if tuned_prepare is not None:
+                tuned_prepare(False)
         seen = torch.ones(1, device=dev)
         dist.all_reduce(seen)
         out = {"what": what, "ms": ms, "ms_no_ddp": ms_bare, "allreduce_ms_exposed": ms - ms_bare,
                "allreduce_bytes": sum(p.numel() * 4 for p in params), "allreduce_bytes_largest_tensor": max(p.numel() for p in params) * 4,
                "ddp_bucket_cap_mb": 25, "allreduce_per_micro_batch": True, "ms_with_optimizer": ms_opt,
                "ms_tuned": ms_tuned, "allreduce_ms_exposed_tuned": ms_tuned - ms_bare,
-               "tuned_config": ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
+               "tuned_config": ("fenerf_amd.dist.prepare_for_ddp(generator) [grid gradient delivered before the weight-gradient kernels], " if tuned_prepare else "")
+                               + ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
                "rays_per_s": world * rays_per_rank / (ms * 1e-3), "n_ranks": world, "n_ranks_seen": int(seen.item()),
                "batch_per_rank": batch_per_rank, "dist_backend": dist.get_backend(),
                "peak_GB": torch.cuda.max_memory_allocated() / 2**30 if cuda else None}
@@ -330,7 +336,10 @@ def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_o
     what = (f"generator_ddp(z_geo, z_app, **metadata) + backward per rank: batch {B} x {S}x{S} rays x {N}+{N} samples, both mapping networks, "
             "DDP(find_unused_parameters=True) bucketed all-reduce of all generator gradients inside backward (every micro-batch all-reduces: the "
             "reference has no no_sync()), device re-pack of the changed weights; precision " + precision)
-    return ddp_timed_leg(gen, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, B * S * S, what, B)
+    from fenerf_amd import dist as fdist
+    assert fdist.RECOMMENDED_DDP_KWARGS == TUNED_DDP
+    return ddp_timed_leg(gen, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, B * S * S, what, B,
+                         tuned_prepare=lambda on: fdist.prepare_for_ddp(gen, on))
 
 
 def dist_check(args):

@@ -51,6 +51,50 @@ class MergeCompositeFunction(torch.autograd.Function):
         return d_f, d_c, None, None, None, None
 
 
+def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params):
+    """Forward of the hierarchical render node (both variants below): coarse forward-save -> (no-grad) coarse weights -> resampled depths
+    -> fine forward-save -> merged composite; saves what the backward needs on ctx."""
+    dev = origins.device
+    nat = module.native_differentiable(dev)
+    B, R, N = z_c.shape
+    C, H = nat.C, nat.spec["hidden_dim"]
+    L = nat.spec["n_geo"] + nat.spec["n_color"]
+    P = R * N
+    Pp = (P + 31) // 32 * 32                      # whole 32-point tiles per image; pad rows get no gradient
+    G = nat.spec["grid_ch"]
+
+    def samples(z):                               # [B,R,N] depths -> padded [B,Pp,3] points
+        pts = (origins.unsqueeze(2) + dirs.unsqueeze(2) * z.unsqueeze(-1)).reshape(B, P, 3)   # generators.py:504
+        return torch.cat([pts, pts[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else pts
+
+    rd = None
+    if not lock_view:
+        rd = dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, P, 3)
+        rd = (torch.cat([rd, rd[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else rd).contiguous()
+    pts2 = torch.empty((2 * B, Pp, 3), dtype=torch.float32, device=dev)
+    out2 = torch.empty((2 * B, Pp, C), dtype=torch.float32, device=dev)
+    tape2 = torch.empty(L * H * B * Pp + nat.tape_floats(B * Pp), dtype=torch.float32, device=dev)   # pass 1 | pass 2 + slack
+    tape_e2 = torch.empty((2 * B * Pp, 32), dtype=torch.float32, device=dev) if G else None
+    half = L * H * B * Pp
+    pts2[:B] = samples(z_c)
+    nat.siren_forward_save(pts2[:B], rd, fg, pg, fa, pa, out=out2[:B], tape=tape2[:half], tape_e=tape_e2[:B * Pp] if G else None)
+    coarse = out2[:B, :P].reshape(B * R, N, C)
+    zc = z_c.reshape(B * R, N)
+    _, _, w_c, _ = native.composite(coarse, zc, noise_c, copts, want_wsum=False)
+    z_f = native.resample(zc, w_c, u)
+    pts2[B:] = samples(z_f.reshape(B, R, N))
+    nat.siren_forward_save(pts2[B:], rd, fg, pg, fa, pa, out=out2[B:], tape=tape2[half:], tape_e=tape_e2[B * Pp:] if G else None)
+    fine = out2[B:, :P].reshape(B * R, N, C)
+    rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
+    ctx.module, ctx.nat, ctx.opts, ctx.dims = module, nat, opts, (B, R, N, P, Pp)
+    ctx.pack_generation = nat.pack_generation
+    empty = origins.new_empty(0)
+    ctx.save_for_backward(pts2, rd if rd is not None else empty, fg, pg, fa, pa, out2, tape2, tape_e2 if G else empty, z_f, zc,
+                          noise_f if noise_f is not None else empty, *params)
+    ctx.mark_non_differentiable(depth)
+    return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
+
+
 class HierarchicalRenderFunction(torch.autograd.Function):
     """The whole differentiable hierarchical render of generators.py:479-519 as ONE autograd node: coarse SIREN pass ->
     (no-grad) coarse weights -> resampled depths -> fine SIREN pass -> merged composite.  Both passes write their tapes into
@@ -63,45 +107,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, *params):
-        dev = origins.device
-        nat = module.native_differentiable(dev)
-        B, R, N = z_c.shape
-        C, H = nat.C, nat.spec["hidden_dim"]
-        L = nat.spec["n_geo"] + nat.spec["n_color"]
-        P = R * N
-        Pp = (P + 31) // 32 * 32                      # whole 32-point tiles per image; pad rows get no gradient
-        G = nat.spec["grid_ch"]
-
-        def samples(z):                               # [B,R,N] depths -> padded [B,Pp,3] points
-            pts = (origins.unsqueeze(2) + dirs.unsqueeze(2) * z.unsqueeze(-1)).reshape(B, P, 3)   # generators.py:504
-            return torch.cat([pts, pts[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else pts
-
-        rd = None
-        if not lock_view:
-            rd = dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, P, 3)
-            rd = (torch.cat([rd, rd[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else rd).contiguous()
-        pts2 = torch.empty((2 * B, Pp, 3), dtype=torch.float32, device=dev)
-        out2 = torch.empty((2 * B, Pp, C), dtype=torch.float32, device=dev)
-        tape2 = torch.empty(L * H * B * Pp + nat.tape_floats(B * Pp), dtype=torch.float32, device=dev)   # pass 1 | pass 2 + slack
-        tape_e2 = torch.empty((2 * B * Pp, 32), dtype=torch.float32, device=dev) if G else None
-        half = L * H * B * Pp
-        pts2[:B] = samples(z_c)
-        nat.siren_forward_save(pts2[:B], rd, fg, pg, fa, pa, out=out2[:B], tape=tape2[:half], tape_e=tape_e2[:B * Pp] if G else None)
-        coarse = out2[:B, :P].reshape(B * R, N, C)
-        zc = z_c.reshape(B * R, N)
-        _, _, w_c, _ = native.composite(coarse, zc, noise_c, copts, want_wsum=False)
-        z_f = native.resample(zc, w_c, u)
-        pts2[B:] = samples(z_f.reshape(B, R, N))
-        nat.siren_forward_save(pts2[B:], rd, fg, pg, fa, pa, out=out2[B:], tape=tape2[half:], tape_e=tape_e2[B * Pp:] if G else None)
-        fine = out2[B:, :P].reshape(B * R, N, C)
-        rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
-        ctx.module, ctx.nat, ctx.opts, ctx.dims = module, nat, opts, (B, R, N, P, Pp)
-        ctx.pack_generation = nat.pack_generation
-        empty = origins.new_empty(0)
-        ctx.save_for_backward(pts2, rd if rd is not None else empty, fg, pg, fa, pa, out2, tape2, tape_e2 if G else empty, z_f, zc,
-                              noise_f if noise_f is not None else empty, *params)
-        ctx.mark_non_differentiable(depth)
-        return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
+        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -135,3 +141,103 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         if film_only:
             return head + film_grads + (None,) * len(params)
         return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, pts2, d_grid, need[14:])
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The same render as TWO autograd nodes (round 4): for DistributedDataParallel.  With one node every gradient of the step becomes
+# available at the same instant -- the end of the backward -- so DDP's bucketed all-reduce (124 MB, 113 MB of it the 96^3 feature
+# grid; train_double_latent_semantic.py:148-150) can only start when there is nothing left to hide it under.  But the grid gradient is
+# FINAL as soon as the last chain launch has scattered into it, with all the weight-gradient launches (a quarter of the step) still to
+# run.  Split: the render stage's backward runs the composite backward and every chunk's chain, and returns the grid gradient; the
+# engine hands it to the parameter (AccumulateGrad nodes run before any other ready node), DDP's hook starts the all-reduce of the
+# grid's bucket on its communication stream, and only then the weight stage's backward runs the weight-gradient kernels over the dumps
+# the chains left.  Price: the d(theta) dumps of all chunks are alive together (as large as the tape).  Opt-in per module
+# (`siren.split_backward = True`, fenerf_amd.dist.prepare_for_ddp) -- DDP must also be allowed to reduce buckets in the order the
+# gradients arrive (find_unused_parameters=False lets it rebuild its buckets after the first step; with the reference's
+# find_unused_parameters=True the grid's bucket stays last in line and nothing overlaps).
+# ----------------------------------------------------------------------------------------------------------------------------------
+class _SplitState:
+    """what the render stage's backward leaves for the weight stage's backward of the same render"""
+    def __init__(self):
+        self.work = None
+
+
+class HierarchicalWeightStage(torch.autograd.Function):
+    """Upstream node: owns the raw FiLM parameters and every render weight EXCEPT the grid.  forward: a token; backward: the
+    weight-gradient kernels over the dumps of the render stage."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, state, module, fg, pg, fa, pa, *params_no_grid):
+        ctx.state, ctx.module = state, module
+        return fg.new_zeros(1)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, _g_token):
+        w, ctx.state.work = ctx.state.work, None
+        if w is None:
+            raise RuntimeError("fenerf_amd: split backward: the render stage has not run (or ran twice) before the weight stage")
+        module, nat, B = ctx.module, w["nat"], w["B"]
+        need = ctx.needs_input_grad
+        r = _siren_autograd.run_weight_grads(nat, 2 * B, w["Pp"], w["film2"], w["pts2"], w["rd2"], w["out2"], w["d_out2"], w["tape2"], w["tape_e2"],
+                                             w["chunks"], w["dumps"])
+        fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
+        film_grads = (fold(r["d_freq_geo"], need[2]), fold(r["d_phase_geo"], need[3]), fold(r["d_freq_app"], need[4]), fold(r["d_phase_app"], need[5]))
+        params = w["params"]                                    # module._render_params() order, grid included
+        grid = module._roles(params)["grid"]
+        all_grads = _siren_autograd.assemble_param_grads(module, nat, params, r, w["pts2"], None, [True] * len(params))
+        no_grid = [g for p_, g in zip(params, all_grads) if p_ is not grid]
+        return (None, None) + film_grads + tuple(g if need[6 + i] else None for i, g in enumerate(no_grid))
+
+
+class HierarchicalRenderSplitFunction(torch.autograd.Function):
+    """Downstream node: the render itself.  Differentiable inputs: the weight stage's token and the grid.  backward: composite backward,
+    every chunk's chain (with the fused grid scatter), the grid gradient; the dumps go to the weight stage through `state`."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, state, token, grid, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa):
+        ctx.state = state
+        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, ())
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_rgb, _g_depth):
+        module, nat, opts = ctx.module, ctx.nat, ctx.opts
+        _siren_autograd.check_same_weights(ctx, nat)
+        B, R, N, P, Pp = ctx.dims
+        pts2, rd, fg, pg, fa, pa, out2, tape2, tape_e2, z_f, zc, noise_f = ctx.saved_tensors
+        C = nat.C
+        fine, coarse = out2[B:, :P].reshape(B * R, N, C), out2[:B, :P].reshape(B * R, N, C)
+        if Pp == P:
+            d_out2 = torch.empty_like(out2)
+            native.composite_backward(g_rgb.reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc, noise=noise_f if noise_f.numel() else None,
+                                      out_a=d_out2[B:].view(B * R, N, C), out_b=d_out2[:B].view(B * R, N, C))
+        else:
+            d_f, d_c = native.composite_backward(g_rgb.reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
+                                                 noise=noise_f if noise_f.numel() else None)
+            d_out2 = torch.zeros((2 * B, Pp, C), dtype=torch.float32, device=out2.device)
+            d_out2[:B, :P] = d_c.reshape(B, P, C)
+            d_out2[B:, :P] = d_f.reshape(B, P, C)
+        film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
+        rd2 = torch.cat([rd, rd]) if rd.numel() else None
+        chunks = _siren_autograd.plan_chunks(2 * B, Pp)
+        dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, chunks)
+        ctx.state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2,
+                              tape_e2=tape_e2 if tape_e2.numel() else None, chunks=chunks, dumps=dumps, params=module._render_params())
+        g_grid = nat.grid_gradient_ncdhw(d_grid).contiguous() if ctx.needs_input_grad[2] else None
+        g_token = torch.zeros(1, dtype=torch.float32, device=out2.device) if ctx.needs_input_grad[1] else None
+        if g_token is None:
+            ctx.state.work = None          # nothing upstream will consume the dumps
+        return (None, g_token, g_grid) + (None,) * 14
+
+
+def hierarchical_render_split(module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa):
+    """The two-node form of HierarchicalRenderFunction.apply(...) for a module with a feature grid (see the banner above)."""
+    params = module._render_params()
+    grid = module._roles(params)["grid"]
+    state = _SplitState()
+    token = HierarchicalWeightStage.apply(state, module, fg, pg, fa, pa, *[p_ for p_ in params if p_ is not grid])
+    return HierarchicalRenderSplitFunction.apply(state, token, grid, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f,
+                                                 fg.detach(), pg.detach(), fa.detach(), pa.detach())

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
-from .autograd import CompositeFunction, HierarchicalRenderFunction, MergeCompositeFunction
+from .autograd import CompositeFunction, HierarchicalRenderFunction, MergeCompositeFunction, hierarchical_render_split
 from . import volumetric_rendering as VR
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
 
@@ -204,10 +204,15 @@ class _Generator3dBase(nn.Module):
         # both SIREN passes + the merged composite as one autograd node (one chain launch and one set of weight-gradient
         # launches for the two passes)
         copts = _lib.composite_opts(kwargs["clamp_mode"], noise_std)
-        return HierarchicalRenderFunction.apply(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u,
-                                                noise_c.reshape(B * R, N) if use_noise else None,
-                                                noise_f.reshape(B * R, M) if use_noise else None, fg, pg, fa, pa,
-                                                *self.siren._render_params())
+        nc_, nf_ = (noise_c.reshape(B * R, N) if use_noise else None), (noise_f.reshape(B * R, M) if use_noise else None)
+        params = self.siren._render_params()
+        grid = self.siren._roles(params)["grid"]
+        if getattr(self.siren, "split_backward", False) and grid is not None and grid.requires_grad and \
+                any(p.requires_grad for p in params if p is not grid):
+            # two autograd nodes: the grid gradient reaches DistributedDataParallel before the weight-gradient kernels run (autograd.py)
+            return hierarchical_render_split(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u, nc_, nf_, fg, pg, fa, pa)
+        return HierarchicalRenderFunction.apply(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u, nc_, nf_, fg, pg, fa, pa,
+                                                *params)
 
     def _finish(self, pixels, batch_size, img_size):
         if self.softmax_label:

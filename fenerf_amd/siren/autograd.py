@@ -31,7 +31,8 @@ def _fold_label_head(label_params):
 
 def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params):
     """FenerfSirenGrads buffers (dict r) + the channels-last grid gradient chunked_backward accumulated -> gradients in the order of
-    `params` (module._render_params())."""
+    `params` (module._render_params()).  d_grid_cl None on a model with a grid: the grid's gradient is delivered elsewhere (split
+    backward) and its slot is None here."""
     roles = module._roles(params)
     n_lab = nat.spec["output_dim"] - 4
     grads = {}
@@ -50,9 +51,9 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
             grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
     rw, rb = roles["rgb"]
     grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
-    if roles["grid"] is not None:
+    if roles["grid"] is not None and d_grid_cl is not None:
         grads[id(roles["grid"])] = nat.grid_gradient_ncdhw(d_grid_cl).contiguous()
-    return tuple(grads[id(p)].reshape(p.shape) if need_params[i] else None for i, p in enumerate(params))
+    return tuple(grads[id(p)].reshape(p.shape) if (need_params[i] and id(p) in grads) else None for i, p in enumerate(params))
 
 
 # dtheta of a backward chunk: at most this many points (x L*H*4 B = 4.4 GB at L*H = 2816).  The chain kernel writes dL/dtheta of every
@@ -208,6 +209,67 @@ def _side_stream(dev):
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
+
+
+def plan_chunks(nB, Pp, max_points=None):
+    """(first image, images, first point, points) per backward launch -- the chunking of chunked_backward"""
+    max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
+    max_points = max(128, max_points // 128 * 128)
+    if Pp <= max_points:
+        per = max(1, max_points // Pp)
+        return [(b, min(per, nB - b), 0, Pp) for b in range(0, nB, per)]
+    return [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
+
+
+def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks):
+    """First half of a SPLIT backward (generators/autograd.py HierarchicalRenderSplitFunction): every chunk's chain launch, nothing else.
+    -> ([d(theta) dump per chunk], d_grid_cl or None).  All dumps are alive together afterwards (as large as the tape: the price of
+    handing the grid gradient -- final once the last chain has run -- to autograd / DistributedDataParallel BEFORE the weight-gradient
+    kernels, so that its all-reduce runs beside them)."""
+    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    G, C = nat.spec["grid_ch"], nat.C
+    out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
+    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G else None
+    dumps = []
+    for b, nb, s, n in chunks:
+        film_c = tuple(t[b:b + nb] for t in film)
+        g0 = b * Pp + s
+        tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
+        if G:
+            dumps.append(nat.siren_backward_grid(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, points[b:b + nb, s:s + n], d_grid))
+        else:
+            dumps.append(nat.siren_backward(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c)[0])
+    return dumps, d_grid
+
+
+def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, chunks, dumps):
+    """Second half of a split backward: the weight-gradient launches of every chunk over the dumps run_chains left, summed like
+    chunked_backward does.  Frees each dump after its chunk.  -> grads dict (FiLM gradients with [nB] leading)."""
+    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    G, C = nat.spec["grid_ch"], nat.C
+    out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
+    total, film_rows, acc_img = None, {k: [] for k in FILM_KEYS}, None
+    for i, (b, nb, s, n) in enumerate(chunks):
+        film_c = tuple(t[b:b + nb] for t in film)
+        g0 = b * Pp + s
+        tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
+        d_t, dumps[i] = dumps[i], None
+        r = nat.siren_param_grads(points[b:b + nb, s:s + n], dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c,
+                                  out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, tape_e[g0:g0 + nb * n] if G else None, d_t)
+        del d_t
+        if total is None:
+            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
+        else:
+            _add_all(_flat(total), _flat(r, FILM_KEYS))
+        if s == 0:
+            acc_img = [r[k] for k in FILM_KEYS]
+            for k, t in zip(FILM_KEYS, acc_img):
+                film_rows[k].append(t)
+        else:
+            _add_all(acc_img, [r[k] for k in FILM_KEYS])
+    for k, rows in film_rows.items():
+        total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+    return total
 
 
 def check_same_weights(ctx, nat):

