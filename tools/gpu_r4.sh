@@ -76,6 +76,14 @@ cuscale)    # do the backward kernels scale with the CUs they get?  (profiles/r0
   cat gpurun_out/cuscale.log ;;
 overlap)    # backward schedules of the generator step: serial chunks vs weight gradients beside the next chunk's chain
   timeout 900 python tools/overlap_sweep.py ${OVERLAP_ARGS:-} > gpurun_out/overlap_sweep.log 2>&1; cat gpurun_out/overlap_sweep.log | tail -45 ;;
+ddptl)      # kernel timeline of a DDP generator step (world 1): reference wrapper vs prepare_for_ddp + recommended arguments
+  for mode in reference tuned; do
+    rm -rf gpurun_out/ddptl_$mode; mkdir -p gpurun_out/ddptl_$mode
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ddptl_$mode -o tl -- python $GRAFT_REPO_ROOT/tools/ddp_timeline.py $mode) > gpurun_out/ddptl_$mode/run.log 2>&1
+    python tools/gstep_timeline.py gpurun_out/ddptl_$mode 4 > gpurun_out/ddp_timeline_$mode.txt 2>&1
+    find gpurun_out/ddptl_$mode -type f -size +2M -delete
+    echo "== $mode"; grep -E "one generator step|bwd16w|wgrad_sq|wgrad_thin|ccl|Ccl|grid_transpose|copyBuffer" gpurun_out/ddp_timeline_$mode.txt | head -40
+  done ;;
 probe)      # what v_sin_f32 / v_cos_f32 return for arguments of growing magnitude on this chip
   ./tools/probe/sin_domain_probe > gpurun_out/vsin_domain_probe.txt 2>&1; cat gpurun_out/vsin_domain_probe.txt ;;
 gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
