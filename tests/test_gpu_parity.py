@@ -2376,9 +2376,11 @@ def test_merge_composite_and_render_beyond_128_samples():
 
 # ---------------------------------------------------------------------------------------------------
 # FiLM arguments beyond the init range (round 4): torch.sin in the reference's FiLMLayer (siren.py:113-123) takes fp32 radians of any
-# magnitude; v_sin_f32 / v_cos_f32 are only defined on +-256 revolutions (beyond: sin = 0, cos = 1, silently).  Every kernel family
-# reduces its argument exactly first (fenerf_trig.h).  Bar: |native - fp64| <= ulp_fp32(largest sine argument) * 2 pi -- the error
-# one fp32 rounding of the argument makes, which the reference's own fp32 radians carry too (the fp32 numpy oracle is reported beside).
+# magnitude; the GCN3 / Vega manuals define v_sin_f32 / v_cos_f32 on +-256 revolutions only (beyond: sin = 0, cos = 1, silently).  gfx950's
+# instructions are full-range (fenerf_trig.h: compiler lowering, hardware sweep) and the kernels feed them unreduced revolutions; these
+# tests are what pins that per kernel family -- they fail on a device (or a build) where the assumption breaks.  Bar: |native - fp64| <=
+# ulp_fp32(largest sine argument) * 2 pi -- the error one fp32 rounding of the argument makes, which the reference's own fp32 radians
+# carry too (the fp32 numpy oracle is reported beside).
 # ---------------------------------------------------------------------------------------------------
 REVS = [45, 120, 250, 257, 400, 1000]
 
