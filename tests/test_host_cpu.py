@@ -479,3 +479,48 @@ def test_pickles_made_where_the_reference_cuda_ops_imported_still_load(tmp_path)
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_backward_chunk_plan_and_grid_digest():
+    """Host logic of the differentiable path that needs no GPU: the chunk plan of the backward (whole images while they fit, point
+    ranges of an image otherwise; every point exactly once) and the digest that lets a forced re-pack recognise an unchanged grid."""
+    from fenerf_amd import native
+    from fenerf_amd.siren import autograd as SA
+    for nB, Pp, cap in ((12, 393216, 393216), (2, 393216, 196608), (8, 24576, 196608), (3, 544, 128), (4, 1700, 1700), (1, 786432, 1 << 30)):
+        chunks = SA.plan_chunks(nB, Pp, cap)
+        seen = np.zeros((nB, Pp), np.int32)
+        for b, nb, s, n in chunks:
+            limit = max(128, cap // 128 * 128)
+            assert nb >= 1 and n >= 1 and (nb == 1 or (s == 0 and n == Pp)), "several images only as WHOLE images"
+            assert nb * n <= limit or (nb == 1 and n <= limit), (nb, n, limit)
+            seen[b:b + nb, s:s + n] += 1
+        assert (seen == 1).all(), (nB, Pp, cap)
+    assert SA.plan_chunks(12, 393216) == [(b, 1, 0, 393216) for b in range(12)] and SA.BACKWARD_CHUNK_POINTS == 393216 and SA.OVERLAP_WGRAD is False
+    # digest: wrap-around int32 sums of runs of 1,024 words -- a single changed word changes it, and so does a pair of compensating edits
+    # in DIFFERENT runs (which a single global sum would miss); equal content gives an equal digest
+    g = torch.randn(1, 32, 8, 8, 8)
+    d0 = native.NativeModel._grid_checksum(g)
+    assert d0.shape == (16,) and d0.dtype == torch.int32 and torch.equal(d0, native.NativeModel._grid_checksum(g.clone()))
+    h = g.clone().reshape(-1)
+    bits = h.view(torch.int32)
+    bits[5] += 7
+    bits[5000] -= 7                      # same global sum, different runs
+    assert int(bits.sum(dtype=torch.int32)) == int(g.reshape(-1).view(torch.int32).sum(dtype=torch.int32))
+    assert not torch.equal(native.NativeModel._grid_checksum(h.reshape(g.shape)), d0)
+    odd = torch.randn(1, 32, 3, 3, 5)    # 1,440 words: the run length falls back to a power of two that divides it (32)
+    assert native.NativeModel._grid_checksum(odd).shape == (45,)
+
+
+def test_film_params_beyond_the_init_range_are_what_the_fixtures_record():
+    """procedural.film_params(phase_rev, freq0_gain): defaults unchanged bit for bit (every earlier fixture depends on them); the
+    extensions add uniform phase shifts of +-phase_rev revolutions and scale the first layer's effective frequency 15 f + 30."""
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=4, z_dim=8)
+    base = proc.film_params(spec, 2, seed=3)
+    same = proc.film_params(spec, 2, seed=3, phase_rev=0.0, freq0_gain=1.0)
+    assert all(np.array_equal(base[k], same[k]) for k in base)
+    big = proc.film_params(spec, 2, seed=3, phase_rev=300.0, freq0_gain=4.0)
+    assert np.array_equal(big["freq_app"], base["freq_app"]) and np.array_equal(big["freq_geo"][:, 32:], base["freq_geo"][:, 32:])
+    np.testing.assert_allclose(15.0 * big["freq_geo"][:, :32] + 30.0, 4.0 * (15.0 * base["freq_geo"][:, :32] + 30.0), rtol=2e-6)
+    for k in ("phase_geo", "phase_app"):
+        shift = (big[k] - base[k]) / (2 * np.pi)
+        assert np.abs(shift).max() <= 300.0 and np.abs(shift).max() > 250.0 and abs(shift.mean()) < 30.0
