@@ -242,16 +242,20 @@ GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_
 TUNED_DDP = dict(find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=128)       # == fenerf_amd.dist.RECOMMENDED_DDP_KWARGS
 
 
-def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank, tuned_prepare=None):
+def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, rays_per_rank, what, batch_per_rank, tuned_prepare=None,
+                  agree=lambda ok: ok):
     """Times `loss_of(m).backward()` on the bare module and on DistributedDataParallel(module, find_unused_parameters=True) with the
     headline's bracket (barrier on both sides, max over ranks) -> the `gstep_ddp` object (GSTEP_DDP_KEYS).  Backend-agnostic: the GPU
     bench hands it the generator over RCCL; `--dist-check` (CPU, gloo, world 2) hands it a small stand-in so that the wrapper, the
-    rank census, the byte count and the schema of the N > 1 line are covered without a GPU (tests/test_dist_cpu.py)."""
+    rank census, the byte count and the schema of the N > 1 line are covered without a GPU (tests/test_dist_cpu.py).
+    `agree(ok)` = "every rank says ok" (an all-reduce at N > 1): the bare-module run -- which contains no collective of its own -- is made
+    symmetric with it, so that a rank that fails there (out of memory, say) takes every rank out of the leg together instead of leaving
+    the others waiting in DistributedDataParallel's all-reduce until the launcher's timeout."""
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
     bump = min(params, key=lambda t: t.numel())
 
-    def run(m, n, optimizer):
+    def run(m, n, optimizer, guarded=False):
         def step():
             opt.zero_grad(set_to_none=True)
             if not optimizer:
@@ -260,19 +264,30 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
             loss_of(m).backward()
             if optimizer:
                 opt.step()
-        for _ in range(2):
-            step()
+
+        def steps(k):                        # guarded (no collective inside the steps): an exception is held until every rank has passed the barriers
+            try:
+                for _ in range(k):
+                    step()
+            except Exception as e:
+                if not guarded:
+                    raise
+                return e
+            return None
+        err = steps(2)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
-            step()
+        err = err or steps(n)
         barrier()
-        return max_over_ranks(time.perf_counter() - t0) / n * 1e3
+        ms_ = max_over_ranks(time.perf_counter() - t0) / n * 1e3
+        if guarded and not agree(err is None):
+            raise RuntimeError(f"the generator step failed on a rank before any collective (this rank: {type(err).__name__ if err else 'ok'}: {err})")
+        return ms_
 
     cuda = dev.type == "cuda"
     if cuda:
         torch.cuda.reset_peak_memory_stats()
-    ms_bare = run(model, iters, False)
+    ms_bare = run(model, iters, False, guarded=True)
     created = False
     if not dist.is_initialized():            # N = 1 without a launcher: a one-rank group, so that the leg exists at every N
         kw = {"device_id": dev} if cuda else {}
@@ -312,7 +327,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
     return out
 
 
-def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_over_ranks, iters=6):
+def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_over_ranks, iters=6, agree=lambda ok: ok):
     """The reference's generator step as its training loop runs it (train_double_latent_semantic.py:148-150, 402-446):
     `generator_ddp = DDP(generator, find_unused_parameters=True)`; per micro-batch `gen_imgs, _ = generator_ddp(z_geo, z_app, **metadata)`
     (both mapping networks inside), `loss.backward()` -- DDP's bucketed all-reduce of EVERY generator gradient over RCCL/xGMI fires in
@@ -321,7 +336,13 @@ def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_o
     (same rank, same step on the bare module: no collective; at N = 1 this is the reference's G step `generator(z)` + backward),
     `allreduce_ms_exposed` = their difference, `allreduce_bytes` = fp32 bytes of all gradients DDP reduces (113 MB of them the 96^3
     grid), `ms_with_optimizer` (+ torch.optim.Adam.step() on all generator parameters)."""
-    gen, cur, curriculums = curriculum_generator(spec, sd, dev, precision)
+    err = None
+    try:
+        gen, cur, curriculums = curriculum_generator(spec, sd, dev, precision)
+    except Exception as e:
+        err = e
+    if not agree(err is None):               # every rank leaves together (no rank waits for one that could not build its model)
+        raise RuntimeError(f"building the generator failed on a rank (this rank: {type(err).__name__ if err else 'ok'}: {err})")
     md = {**curriculums.extract_metadata(cur, 60000), "img_size": S, "num_steps": N, "nerf_noise": 0.5}    # the 128 x 128 stage; noise as mid-fade (train...py:276)
     torch.manual_seed(4242 + rank)
     zg, za = torch.randn(B, cur["latent_geo_dim"], device=dev), torch.randn(B, cur["latent_app_dim"], device=dev)
@@ -339,7 +360,7 @@ def gstep_ddp_leg(spec, sd, dev, rank, world, B, S, N, precision, barrier, max_o
     from fenerf_amd import dist as fdist
     assert fdist.RECOMMENDED_DDP_KWARGS == TUNED_DDP
     return ddp_timed_leg(gen, params, loss_of, opt, dev, world, barrier, max_over_ranks, iters, B * S * S, what, B,
-                         tuned_prepare=lambda on: fdist.prepare_for_ddp(gen, on))
+                         tuned_prepare=lambda on: fdist.prepare_for_ddp(gen, on), agree=agree)
 
 
 def dist_check(args):
@@ -356,8 +377,14 @@ def dist_check(args):
     params = list(stand_in.parameters())
     x = torch.randn(8, 16, generator=torch.Generator().manual_seed(100 + rank))
     dev = torch.device("cpu")
+    def agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0])
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
     leg = ddp_timed_leg(stand_in, params, lambda m: m(x).square().sum(), torch.optim.Adam(params, lr=1e-3), dev, world,
-                        (dist.barrier if world > 1 else (lambda: None)), lambda v: fdist.max_over_ranks(v), 3, 8, "stand-in module (dist-check)", 8)
+                        (dist.barrier if world > 1 else (lambda: None)), lambda v: fdist.max_over_ranks(v), 3, 8, "stand-in module (dist-check)", 8,
+                        agree=agree)
     # after DDP steps every rank holds the same parameters (all-reduced gradients, same optimizer): checksum agreement
     csum = torch.tensor([float(sum(p.detach().double().sum() for p in params))], dtype=torch.float64)
     sums = [torch.zeros_like(csum) for _ in range(world)]
@@ -522,12 +549,19 @@ def main(argv=None):
     ddp_legs = {}
     if not args.no_gstep_ddp:
         mor = lambda v: fdist.max_over_ranks(v, device=dev)
+
+        def agree(ok):                           # "every rank says ok"
+            if not use_dist:
+                return bool(ok)
+            t = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
         for key, b_, it, skip in (("gstep_ddp", args.batch, 6, False), ("gstep_ddp_b6", 6, 3, args.no_gstep_b6 or (B, S, N) != (1, 128, 24))):
             if skip:
                 continue
             try:
                 torch.cuda.empty_cache()
-                ddp_legs[key] = gstep_ddp_leg(spec, sd, dev, rank, world, b_, S, N, args.precision, barrier, mor, iters=it)
+                ddp_legs[key] = gstep_ddp_leg(spec, sd, dev, rank, world, b_, S, N, args.precision, barrier, mor, iters=it, agree=agree)
             except Exception as e:               # an extra leg must never take the headline metric down with it
                 ddp_legs[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
