@@ -42,6 +42,14 @@ class FenerfLocalMapDesc(C.Structure):
                 ("w2", _fp), ("b2", _fp)]
 
 
+MAP_MAX_LAYERS = 8
+
+
+class FenerfMappingNet(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("z_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
+                ("W", _vp * MAP_MAX_LAYERS), ("b", _vp * MAP_MAX_LAYERS)]
+
+
 class FenerfSirenGrads(C.Structure):
     _fields_ = [("geo_w", _vp * MAX_GEO), ("geo_b", _vp * MAX_GEO), ("color_w", _vp * MAX_COLOR), ("color_b", _vp * MAX_COLOR),
                 ("head_w", _vp), ("head_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp),
@@ -72,6 +80,9 @@ _SIGS = {
     "fenerf_last_error": (C.c_char_p, []),
     "fenerf_abi_version": (_i, []),
     "fenerf_set_cu_budget": (_i, [_i]),
+    "fenerf_mapping_forward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, _vp]),
+    "fenerf_mapping_workspace_floats": (_sz, [C.POINTER(FenerfMappingNet), _i]),
+    "fenerf_mapping_backward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "fenerf_struct_size": (C.c_long, [C.c_char_p]),
     "fenerf_struct_field_offset": (C.c_long, [C.c_char_p, C.c_char_p]),
     "fenerf_struct_field_name": (C.c_char_p, [C.c_char_p, _i]),

@@ -240,10 +240,12 @@ const FieldInfo kGradFields[] = {
     FLD(FenerfSirenGrads, geo_w), FLD(FenerfSirenGrads, geo_b), FLD(FenerfSirenGrads, color_w), FLD(FenerfSirenGrads, color_b),
     FLD(FenerfSirenGrads, head_w), FLD(FenerfSirenGrads, head_b), FLD(FenerfSirenGrads, rgb_w), FLD(FenerfSirenGrads, rgb_b),
     FLD(FenerfSirenGrads, d_freq_geo), FLD(FenerfSirenGrads, d_phase_geo), FLD(FenerfSirenGrads, d_freq_app), FLD(FenerfSirenGrads, d_phase_app)};
+const FieldInfo kMapFields[] = {FLD(FenerfMappingNet, n_layers), FLD(FenerfMappingNet, z_dim), FLD(FenerfMappingNet, hidden),
+                                FLD(FenerfMappingNet, out_dim), FLD(FenerfMappingNet, W), FLD(FenerfMappingNet, b)};
 #undef FLD
 #define STRUCT(S, F) {#S, (long)sizeof(S), F, (int)(sizeof(F) / sizeof(F[0]))}
 const StructInfo kStructs[] = {STRUCT(FenerfModelDesc, kDescFields), STRUCT(FenerfCompositeOpts, kOptsFields), STRUCT(FenerfRepackMaps, kRepackFields),
-                               STRUCT(FenerfLocalMapDesc, kLocalFields), STRUCT(FenerfSirenGrads, kGradFields)};
+                               STRUCT(FenerfLocalMapDesc, kLocalFields), STRUCT(FenerfSirenGrads, kGradFields), STRUCT(FenerfMappingNet, kMapFields)};
 #undef STRUCT
 const StructInfo* find_struct(const char* name) {
   if (!name) return nullptr;

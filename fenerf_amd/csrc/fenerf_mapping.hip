@@ -1,0 +1,228 @@
+// CustomMappingNetwork (siren/siren.py:82-102): z -> Linear, LeakyReLU(0.2) x (n_blocks + 1) -> Linear; the two halves of the output are
+// the raw FiLM frequencies and phase shifts of one image.  Per image it is five matrix-vector products (z_dim -> 256 -> 256 -> 256 -> 256
+// -> 2 n H): as PyTorch ops that is ~18 launches forward and ~60 backward for the two networks of DoubleImplicitGenerator3d, each a 5-us
+// kernel at batch 1-6 -- 0.6 ms of a 13-ms generator step spent on 3 MFLOP (profiles/r04_ddp_step_timeline_*.txt).  Here: ONE launch
+// forward, THREE backward per network, exact fp32 FMAs (fenerf_mapping_forward / fenerf_mapping_backward).  Used for small batches only
+// (the 10,000-latent batch of generate_avg_frequencies, generators.py:530-543, stays a rocBLAS GEMM in PyTorch).
+//
+// forward   grid (B, S): every workgroup carries image b through the trunk (256-wide layers, activations in LDS; 4 waves, a wave per
+//           output row, lanes over the input: coalesced weight rows, shuffle reduction) and computes rows [s, s + 1) * out / S of the
+//           last layer; workgroup s = 0 also stores the post-activation vectors the backward needs.  The trunk is recomputed S times
+//           (3 x 65 k MACs) so that the 1 M MACs of the last layer spread over S workgroups.
+// backward  (1) head_dx: partial[s][b][i] = sum_{j in range s} W_last[j][i] d_out[b][j]      grid (B, S), thread = input feature i
+//           (2) deltas:  delta_last-1 = (sum_s partial) * lrelu'(act), then down the trunk: delta_{l-1}[i] = (sum_j W_l[j][i] delta_l[j])
+//                        * lrelu'(act_{l-1}[i]); all deltas stored                            grid (B), thread = feature
+//           (3) wgrad:   dW_l[j][i] = sum_b delta_l[b][j] x_{l-1}[b][i], db_l[j] = sum_b delta_l[b][j] for every layer in one launch
+//                        (fixed summation order over b: deterministic)                       grid (row tiles, layers)
+// LeakyReLU'(x) is taken from the sign of the stored POST-activation value (slope 0.2 > 0 keeps the sign; 0 -> slope, like torch).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "fenerf_internal.h"
+
+namespace fenerf {
+
+namespace {
+
+constexpr int MAP_MAX_LAYERS = FENERF_MAP_MAX_LAYERS;
+constexpr int MAP_THREADS = 256;
+constexpr float LRELU_SLOPE = 0.2f;
+
+struct MapParams {
+  int n_layers;                 // linear layers (n_blocks + 2)
+  int B, z_dim, hidden, out_dim, S;
+  const float* W[MAP_MAX_LAYERS];
+  const float* b[MAP_MAX_LAYERS];
+  float* dW[MAP_MAX_LAYERS];
+  float* db[MAP_MAX_LAYERS];
+  const float* z;               // [B][z_dim]
+  float* acts;                  // [n_layers - 1][B][hidden] post-activation outputs of the trunk layers
+  float* out;                   // [B][out_dim]
+  const float* d_out;           // [B][out_dim]
+  float* partial;               // [S][B][hidden]
+  float* delta;                 // [n_layers - 1][B][hidden] dL/d(pre-activation) of the trunk layers
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LRELU_SLOPE; }
+
+// y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1): a wave per row, lanes over i
+template <class F>
+__device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* x, int n_in, int r0, int r1, F store) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = r0 + wave; r < r1; r += MAP_THREADS / 64) {
+    const float* row = W + (size_t)r * n_in;
+    float acc = 0.f;
+    for (int i = lane; i < n_in; i += 64) acc = __builtin_fmaf(row[i], x[i], acc);
+    acc = wave_sum_f(acc);
+    if (lane == 0) store(r, acc + bias[r]);
+  }
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void mapping_forward_kernel(MapParams P) {
+  extern __shared__ float lds[];          // two activation buffers of max(z_dim, hidden) floats
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int wmax = P.z_dim > P.hidden ? P.z_dim : P.hidden;
+  float* x = lds;
+  float* y = lds + wmax;
+  for (int i = threadIdx.x; i < P.z_dim; i += MAP_THREADS) x[i] = P.z[(size_t)b * P.z_dim + i];
+  __syncthreads();
+  int n_in = P.z_dim;
+  for (int l = 0; l + 1 < P.n_layers; ++l) {
+    float* act = P.acts + ((size_t)l * P.B + b) * P.hidden;
+    matvec_rows(P.W[l], P.b[l], x, n_in, 0, P.hidden, [&](int r, float v) {
+      v = lrelu(v);
+      y[r] = v;
+      if (s == 0) act[r] = v;
+    });
+    __syncthreads();
+    float* t = x; x = y; y = t;
+    n_in = P.hidden;
+  }
+  const int L = P.n_layers - 1;
+  const int r0 = (int)((long long)P.out_dim * s / P.S), r1 = (int)((long long)P.out_dim * (s + 1) / P.S);
+  float* o = P.out + (size_t)b * P.out_dim;
+  matvec_rows(P.W[L], P.b[L], x, n_in, r0, r1, [&](int r, float v) { o[r] = v; });
+}
+
+// (1) partial[s][b][i] = sum_{j in range s} W_last[j][i] d_out[b][j]
+__global__ __launch_bounds__(MAP_THREADS) void mapping_head_dx_kernel(MapParams P) {
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int L = P.n_layers - 1;
+  const int j0 = (int)((long long)P.out_dim * s / P.S), j1 = (int)((long long)P.out_dim * (s + 1) / P.S);
+  const float* g = P.d_out + (size_t)b * P.out_dim;
+  for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) {
+    float acc = 0.f;
+    for (int j = j0; j < j1; ++j) acc = __builtin_fmaf(P.W[L][(size_t)j * P.hidden + i], g[j], acc);
+    P.partial[((size_t)s * P.B + b) * P.hidden + i] = acc;
+  }
+}
+
+// (2) deltas of the trunk layers, last to first
+__global__ __launch_bounds__(MAP_THREADS) void mapping_delta_kernel(MapParams P) {
+  extern __shared__ float lds[];          // delta of the layer above, hidden floats
+  const int b = blockIdx.x;
+  const int T = P.n_layers - 1;           // trunk layers 0 .. T - 1
+  for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) {
+    float acc = 0.f;
+    for (int s = 0; s < P.S; ++s) acc += P.partial[((size_t)s * P.B + b) * P.hidden + i];
+    const float a = P.acts[((size_t)(T - 1) * P.B + b) * P.hidden + i];
+    const float d = acc * (a > 0.f ? 1.f : LRELU_SLOPE);
+    P.delta[((size_t)(T - 1) * P.B + b) * P.hidden + i] = d;
+    lds[i] = d;
+  }
+  __syncthreads();
+  for (int l = T - 1; l >= 1; --l) {      // delta_{l-1} from delta_l through W_l [hidden][hidden]
+    float d_new[4];                       // hidden <= 4 * MAP_THREADS (checked by the launcher)
+    int n = 0;
+    for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS, ++n) {
+      float acc = 0.f;
+      for (int j = 0; j < P.hidden; ++j) acc = __builtin_fmaf(P.W[l][(size_t)j * P.hidden + i], lds[j], acc);
+      const float a = P.acts[((size_t)(l - 1) * P.B + b) * P.hidden + i];
+      d_new[n] = acc * (a > 0.f ? 1.f : LRELU_SLOPE);
+    }
+    __syncthreads();
+    n = 0;
+    for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS, ++n) {
+      lds[i] = d_new[n];
+      P.delta[((size_t)(l - 1) * P.B + b) * P.hidden + i] = d_new[n];
+    }
+    __syncthreads();
+  }
+}
+
+// (3) dW_l[j][i] = sum_b delta_l[b][j] x_{l-1}[b][i];  db_l[j] = sum_b delta_l[b][j];  blockIdx.y = layer, one thread per (j, i)
+__global__ __launch_bounds__(MAP_THREADS) void mapping_wgrad_kernel(MapParams P) {
+  const int l = blockIdx.y;
+  const int T = P.n_layers - 1;
+  const int n_out = l == T ? P.out_dim : P.hidden, n_in = l == 0 ? P.z_dim : P.hidden;
+  const float* dl = l == T ? P.d_out : P.delta + (size_t)l * P.B * P.hidden;          // [B][n_out]
+  const float* xin = l == 0 ? P.z : P.acts + (size_t)(l - 1) * P.B * P.hidden;        // [B][n_in]
+  const long long total = (long long)n_out * n_in;
+  for (long long k = (long long)blockIdx.x * MAP_THREADS + threadIdx.x; k < total; k += (long long)gridDim.x * MAP_THREADS) {
+    const int j = (int)(k / n_in), i = (int)(k % n_in);
+    float acc = 0.f;
+    for (int b = 0; b < P.B; ++b) acc = __builtin_fmaf(dl[(size_t)b * n_out + j], xin[(size_t)b * n_in + i], acc);
+    P.dW[l][k] = acc;
+    if (i == 0) {
+      float sb = 0.f;
+      for (int b = 0; b < P.B; ++b) sb += dl[(size_t)b * n_out + j];
+      P.db[l][j] = sb;
+    }
+  }
+}
+
+int map_fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+int fill(MapParams& P, const FenerfMappingNet* net, int B) {
+  if (!net) return map_fail(FENERF_E_INVALID, "mapping network description is NULL");
+  if (net->n_layers < 2 || net->n_layers > MAP_MAX_LAYERS) return map_fail(FENERF_E_INVALID, "mapping network: n_layers must be in [2, FENERF_MAP_MAX_LAYERS]");
+  if (B <= 0 || net->z_dim <= 0 || net->hidden <= 0 || net->out_dim <= 0) return map_fail(FENERF_E_INVALID, "mapping network: B, z_dim, hidden, out_dim must be > 0");
+  if (net->hidden > 4 * MAP_THREADS || net->z_dim > 4096) return map_fail(FENERF_E_UNSUPPORTED, "mapping network: hidden <= 1024 and z_dim <= 4096");
+  memset(&P, 0, sizeof(P));
+  P.n_layers = net->n_layers; P.B = B; P.z_dim = net->z_dim; P.hidden = net->hidden; P.out_dim = net->out_dim;
+  P.S = net->out_dim >= 2048 ? 16 : (net->out_dim >= 512 ? 8 : 1);
+  for (int l = 0; l < net->n_layers; ++l) {
+    if (!net->W[l] || !net->b[l]) return map_fail(FENERF_E_INVALID, "mapping network: weight / bias pointer is NULL");
+    P.W[l] = net->W[l]; P.b[l] = net->b[l];
+  }
+  return FENERF_OK;
+}
+
+}  // namespace
+}  // namespace fenerf
+
+using namespace fenerf;
+
+extern "C" size_t fenerf_mapping_workspace_floats(const FenerfMappingNet* net, int B) {
+  if (!net || B <= 0) return 0;
+  const size_t S = net->out_dim >= 2048 ? 16 : (net->out_dim >= 512 ? 8 : 1);
+  return (S + (size_t)(net->n_layers - 1)) * (size_t)B * (size_t)net->hidden;        // partial [S][B][hidden] | delta [n_layers - 1][B][hidden]
+}
+
+extern "C" int fenerf_mapping_forward(const FenerfMappingNet* net, int B, const float* z, float* acts, float* out, void* stream) {
+  MapParams P;
+  int rc = fill(P, net, B);
+  if (rc) return rc;
+  if (!z || !acts || !out) return map_fail(FENERF_E_INVALID, "fenerf_mapping_forward: NULL pointer");
+  P.z = z; P.acts = acts; P.out = out;
+  const int wmax = P.z_dim > P.hidden ? P.z_dim : P.hidden;
+  PhaseScope ph(PH_OTHER, stream);
+  hipLaunchKernelGGL(mapping_forward_kernel, dim3(B, P.S), dim3(MAP_THREADS), 2 * wmax * sizeof(float), (hipStream_t)stream, P);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : map_fail(FENERF_E_HIP, std::string("mapping forward launch: ") + hipGetErrorString(e));
+}
+
+extern "C" int fenerf_mapping_backward(const FenerfMappingNet* net, int B, const float* z, const float* acts, const float* d_out,
+                                       float* const* dW, float* const* db, float* workspace, void* stream) {
+  MapParams P;
+  int rc = fill(P, net, B);
+  if (rc) return rc;
+  if (!z || !acts || !d_out || !dW || !db || !workspace) return map_fail(FENERF_E_INVALID, "fenerf_mapping_backward: NULL pointer");
+  for (int l = 0; l < P.n_layers; ++l) {
+    if (!dW[l] || !db[l]) return map_fail(FENERF_E_INVALID, "fenerf_mapping_backward: gradient pointer is NULL");
+    P.dW[l] = dW[l]; P.db[l] = db[l];
+  }
+  P.z = z; P.acts = const_cast<float*>(acts); P.d_out = d_out;
+  P.partial = workspace;
+  P.delta = workspace + (size_t)P.S * B * P.hidden;
+  hipStream_t st = (hipStream_t)stream;
+  PhaseScope ph(PH_OTHER, stream);
+  hipLaunchKernelGGL(mapping_head_dx_kernel, dim3(B, P.S), dim3(MAP_THREADS), 0, st, P);
+  hipLaunchKernelGGL(mapping_delta_kernel, dim3(B), dim3(MAP_THREADS), P.hidden * sizeof(float), st, P);
+  const long long biggest = (long long)P.out_dim * P.hidden;
+  int gx = (int)((biggest + MAP_THREADS - 1) / MAP_THREADS);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(mapping_wgrad_kernel, dim3(gx, P.n_layers), dim3(MAP_THREADS), 0, st, P);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : map_fail(FENERF_E_HIP, std::string("mapping backward launch: ") + hipGetErrorString(e));
+}

@@ -682,6 +682,52 @@ def forward_kernel_name(nat):
 
 
 # ----------------------------------------------------------------------
+# CustomMappingNetwork as one launch forward / three backward (fenerf_mapping.hip; small batches)
+# ----------------------------------------------------------------------
+def _mapping_net(weights, biases):
+    """[W_0 .. W_{L-1}], [b_0 .. b_{L-1}] contiguous fp32 device tensors in nn.Linear layout -> (FenerfMappingNet, keep-alive)"""
+    L = len(weights)
+    if not 2 <= L <= _lib.MAP_MAX_LAYERS:
+        raise ValueError(f"mapping network with {L} linear layers (supported: 2 .. {_lib.MAP_MAX_LAYERS})")
+    net = _lib.FenerfMappingNet()
+    net.n_layers, net.z_dim, net.hidden, net.out_dim = L, weights[0].shape[1], weights[0].shape[0], weights[-1].shape[0]
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        want = (net.out_dim if l == L - 1 else net.hidden, net.z_dim if l == 0 else net.hidden)
+        if tuple(w.shape) != want or tuple(b.shape) != (want[0],):
+            raise ValueError(f"mapping network layer {l}: weight {tuple(w.shape)} / bias {tuple(b.shape)}, expected {want} / {(want[0],)}")
+        net.W[l], net.b[l] = w.data_ptr(), b.data_ptr()
+    return net
+
+
+def mapping_forward(weights, biases, z):
+    """z [B, z_dim] -> (out [B, out_dim], acts [L-1, B, hidden]) in ONE launch (fenerf_mapping_forward; siren.py:82-102)"""
+    dev = z.device
+    weights, biases, z = [_f32(w, dev) for w in weights], [_f32(b, dev) for b in biases], _f32(z, dev)
+    net = _mapping_net(weights, biases)
+    B = z.shape[0]
+    out = torch.empty((B, net.out_dim), dtype=torch.float32, device=dev)
+    acts = torch.empty((net.n_layers - 1, B, net.hidden), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_mapping_forward(C.byref(net), B, _ptr(z), _ptr(acts), _ptr(out), _stream()))
+    return out, acts
+
+
+def mapping_backward(weights, biases, z, acts, d_out):
+    """-> ([dW_l], [db_l]) of the parameters' shapes, three launches (fenerf_mapping_backward)"""
+    dev = z.device
+    weights, biases, z, d_out = [_f32(w, dev) for w in weights], [_f32(b, dev) for b in biases], _f32(z, dev), _f32(d_out, dev)
+    net = _mapping_net(weights, biases)
+    B = z.shape[0]
+    dW, db = [torch.empty_like(w) for w in weights], [torch.empty_like(b) for b in biases]
+    pw, pb = (C.c_void_p * len(dW))(*[t.data_ptr() for t in dW]), (C.c_void_p * len(db))(*[t.data_ptr() for t in db])
+    l = _lib.lib()
+    ws = torch.empty((max(1, int(l.fenerf_mapping_workspace_floats(C.byref(net), B))),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(l.fenerf_mapping_backward(C.byref(net), B, _ptr(z), _ptr(acts), _ptr(d_out), pw, pb, _ptr(ws), _stream()))
+    return dW, db
+
+
+# ----------------------------------------------------------------------
 # stand-alone ray-tail ops (no model needed)
 # ----------------------------------------------------------------------
 def ray_setup(B, img_size, N, z_cam, ray_start, ray_end, u_jitter, theta, phi):

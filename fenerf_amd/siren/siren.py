@@ -57,10 +57,45 @@ class CustomMappingNetwork(nn.Module):
         with torch.no_grad():
             self.network[-1].weight *= 0.25
 
+    # batches up to this size run as fenerf_mapping_forward / _backward (one launch forward, three backward, instead of ~9 and ~30 ATen
+    # launches of 5 us each); larger ones -- the 10,000 latents of generate_avg_frequencies -- are rocBLAS GEMMs in PyTorch
+    NATIVE_MAX_BATCH = 64
+
+    def _native_ok(self, z):
+        return (z.is_cuda and z.dim() == 2 and 0 < z.shape[0] <= self.NATIVE_MAX_BATCH and not z.requires_grad
+                and self.network[0].out_features <= 1024 and z.shape[1] <= 4096 and len(self.network) // 2 + 1 <= 8)
+
     def forward(self, z):
-        out = self.network(z)
+        if self._native_ok(z):
+            linears = [m for m in self.network if isinstance(m, nn.Linear)]
+            out = _MappingFunction.apply(z, len(linears), *[l.weight for l in linears], *[l.bias for l in linears])
+        else:
+            out = self.network(z)
         half = out.shape[-1] // 2
         return out[..., :half], out[..., half:]
+
+
+class _MappingFunction(torch.autograd.Function):
+    """CustomMappingNetwork on the native kernels (fenerf_mapping.hip): forward = one launch, backward = three; gradients wrt every
+    weight and bias (z takes none: the reference samples its latents)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, z, n, *params):
+        weights, biases = list(params[:n]), list(params[n:])
+        out, acts = native.mapping_forward(weights, biases, z)
+        ctx.n = n
+        ctx.save_for_backward(z, acts, *params)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, d_out):
+        z, acts, *params = ctx.saved_tensors
+        n = ctx.n
+        dW, db = native.mapping_backward(list(params[:n]), list(params[n:]), z, acts, d_out.contiguous().float())
+        need = ctx.needs_input_grad[2:]
+        return (None, None) + tuple(g if need[i] else None for i, g in enumerate(dW + db))
 
 
 class FiLMLayer(nn.Module):

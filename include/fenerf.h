@@ -91,6 +91,28 @@ typedef struct FenerfModelDesc {
 
 typedef struct FenerfModel FenerfModel;
 
+/* CustomMappingNetwork (siren/siren.py:82-102): z -> [Linear, LeakyReLU(0.2)] x (n_blocks + 1) -> Linear; the two halves of the output are
+ * the raw FiLM frequencies / phase shifts of an image.  All pointers [dev], fp32, nn.Linear layout (weight[out][in], bias[out]): the
+ * mapping networks are trained parameters that live on the device.  Layer 0 is [hidden][z_dim], layers 1 .. n_layers - 2 [hidden][hidden],
+ * the last [out_dim][hidden]. */
+#define FENERF_MAP_MAX_LAYERS 8
+typedef struct FenerfMappingNet {
+  int32_t n_layers;     /* Linear layers = n_blocks + 2 (5 for the generators' networks, 3 for SPATIALSIRENGRID's) */
+  int32_t z_dim, hidden, out_dim;
+  const float* W[FENERF_MAP_MAX_LAYERS];
+  const float* b[FENERF_MAP_MAX_LAYERS];
+} FenerfMappingNet;
+/* replaces: mapping_network(z) for small batches (generators.py:458-459 and every other `*.mapping_network(z)` call; ~18 ATen launches for
+ * the two networks of a DoubleImplicitGenerator3d) -- ONE launch.  z [B][z_dim] -> out [B][out_dim]; acts [n_layers - 1][B][hidden] receives
+ * the post-activation vectors fenerf_mapping_backward needs. */
+int fenerf_mapping_forward(const FenerfMappingNet* net, int B, const float* z, float* acts, float* out, void* stream);
+/* replaces: autograd through the same (AddmmBackward / LeakyReluBackward nodes, ~30 launches per network): gradients wrt every weight and
+ * bias (dW[l] / db[l]: [dev] buffers of the parameters' shapes, overwritten) from d_out [B][out_dim]; three launches.  z itself gets no
+ * gradient (the reference samples its latents; inversion optimises FiLM offsets).  workspace: fenerf_mapping_workspace_floats floats. */
+size_t fenerf_mapping_workspace_floats(const FenerfMappingNet* net, int B);
+int fenerf_mapping_backward(const FenerfMappingNet* net, int B, const float* z, const float* acts, const float* d_out,
+                            float* const* dW, float* const* db, float* workspace, void* stream);
+
 /* per-call compositing options = the kwargs fancy_integration reads (volumetric_rendering.py:18) */
 typedef struct FenerfCompositeOpts {
   int32_t clamp_mode;   /* FENERF_CLAMP_* ; 0 -> FENERF_E_CLAMP_MODE */
@@ -107,7 +129,7 @@ int fenerf_abi_version(void);
 /* Layout of the structs of this header AS THE LIBRARY WAS COMPILED, so that a binding written in another language (the ctypes mirrors of
  * INTEGRATION.md B and fenerf_amd/_lib.py) can be checked against the library it loads instead of against a copy of this file:
  * fenerf_struct_size("FenerfModelDesc") = sizeof, fenerf_struct_field_offset("FenerfModelDesc", "precision") = offsetof; structs:
- * FenerfModelDesc, FenerfCompositeOpts, FenerfRepackMaps, FenerfLocalMapDesc, FenerfSirenGrads.  Unknown names return -1.
+ * FenerfModelDesc, FenerfCompositeOpts, FenerfRepackMaps, FenerfLocalMapDesc, FenerfSirenGrads, FenerfMappingNet.  Unknown names return -1.
  * fenerf_struct_field_name(s, i) enumerates the fields in declaration order (NULL behind the last).  (No reference analogue: the
  * reference has no FFI.)  tests/test_host_cpu.py executes INTEGRATION.md's snippet against these. */
 /* Scheduling hint for the CALLING THREAD's subsequent launches (no reference analogue): size persistent launches (the backward chain)
