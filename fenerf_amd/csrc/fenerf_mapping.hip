@@ -5,8 +5,8 @@
 // forward, THREE backward per network, exact fp32 FMAs (fenerf_mapping_forward / fenerf_mapping_backward).  Used for small batches only
 // (the 10,000-latent batch of generate_avg_frequencies, generators.py:530-543, stays a rocBLAS GEMM in PyTorch).
 //
-// forward   grid (B, S): every workgroup carries image b through the trunk (256-wide layers, activations in LDS; 4 waves, a wave per
-//           output row, lanes over the input: coalesced weight rows, shuffle reduction) and computes rows [s, s + 1) * out / S of the
+// forward   grid (B, S): every workgroup carries image b through the trunk (256-wide layers, activations in LDS; 16 waves, each wave
+//           four output rows at a time, lanes over the input: coalesced weight rows, shuffle reduction) and computes rows [s, s + 1) * out / S of the
 //           last layer; workgroup s = 0 also stores the post-activation vectors the backward needs.  The trunk is recomputed S times
 //           (3 x 65 k MACs) so that the 1 M MACs of the last layer spread over S workgroups.
 // backward  (1) head_dx: partial[s][b][i] = sum_{j in range s} W_last[j][i] d_out[b][j]      grid (B, S), thread = input feature i
@@ -27,7 +27,9 @@ namespace fenerf {
 namespace {
 
 constexpr int MAP_MAX_LAYERS = FENERF_MAP_MAX_LAYERS;
-constexpr int MAP_THREADS = 256;
+constexpr int MAP_THREADS = 1024;          // 16 waves: a workgroup's layers are latency chains, the waves are what hides them
+constexpr int MAP_ROWS = 4;                // rows a wave has in flight at once (matvec_rows)
+constexpr int MAP_JSPLIT = MAP_THREADS / 256;
 constexpr float LRELU_SLOPE = 0.2f;
 
 struct MapParams {
@@ -52,16 +54,27 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LRELU_SLOPE; }
 
-// y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1): a wave per row, lanes over i
+// y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1): a wave takes MAP_ROWS rows at a time (their loads are all in flight together),
+// lanes over i (coalesced weight rows), shuffle reduction.  Summation order per row: lane-strided partial sums, then the butterfly.
 template <class F>
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* x, int n_in, int r0, int r1, F store) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = r0 + wave; r < r1; r += MAP_THREADS / 64) {
-    const float* row = W + (size_t)r * n_in;
-    float acc = 0.f;
-    for (int i = lane; i < n_in; i += 64) acc = __builtin_fmaf(row[i], x[i], acc);
-    acc = wave_sum_f(acc);
-    if (lane == 0) store(r, acc + bias[r]);
+  constexpr int NW = MAP_THREADS / 64;
+  for (int r = r0 + wave * MAP_ROWS; r < r1; r += NW * MAP_ROWS) {
+    float acc[MAP_ROWS];
+#pragma unroll
+    for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
+    for (int i = lane; i < n_in; i += 64) {
+      const float xi = x[i];
+#pragma unroll
+      for (int k = 0; k < MAP_ROWS; ++k)
+        if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < MAP_ROWS; ++k) {
+      const float v = wave_sum_f(acc[k]);
+      if (lane == 0 && r + k < r1) store(r + k, v + bias[r + k]);
+    }
   }
 }
 
@@ -91,22 +104,51 @@ __global__ __launch_bounds__(MAP_THREADS) void mapping_forward_kernel(MapParams 
   matvec_rows(P.W[L], P.b[L], x, n_in, r0, r1, [&](int r, float v) { o[r] = v; });
 }
 
+// dst[i] = sum_{j in [j0, j1)} W[j][i] g[j] for i < n (W row-major [.][n], g in memory or LDS): thread (i, q) sums the j of residue q
+// modulo MAP_JSPLIT, eight loads in flight, then the MAP_JSPLIT partial sums of an i meet in LDS (fixed order: deterministic).
+// red: MAP_THREADS floats of LDS.  Valid for n <= 256; larger n loops.  Ends with a __syncthreads().
+template <class F>
+__device__ __forceinline__ void matvec_cols(const float* __restrict__ W, const float* g, int n, int j0, int j1, float* red, F store) {
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + (threadIdx.x & 255), q = threadIdx.x >> 8;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (i < n) {
+      int j = j0 + q;
+      for (; j + 7 * MAP_JSPLIT < j1; j += 8 * MAP_JSPLIT) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_fmaf(W[(size_t)(j + k * MAP_JSPLIT) * n + i], g[j + k * MAP_JSPLIT], acc[k]);
+      }
+      for (; j < j1; j += MAP_JSPLIT) acc[0] = __builtin_fmaf(W[(size_t)j * n + i], g[j], acc[0]);
+    }
+    red[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (q == 0 && i < n) {
+      float v = red[threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < MAP_JSPLIT; ++k) v += red[threadIdx.x + 256 * k];
+      store(i, v);
+    }
+    __syncthreads();
+  }
+}
+
 // (1) partial[s][b][i] = sum_{j in range s} W_last[j][i] d_out[b][j]
 __global__ __launch_bounds__(MAP_THREADS) void mapping_head_dx_kernel(MapParams P) {
+  __shared__ float red[MAP_THREADS];
   const int b = blockIdx.x, s = blockIdx.y;
   const int L = P.n_layers - 1;
   const int j0 = (int)((long long)P.out_dim * s / P.S), j1 = (int)((long long)P.out_dim * (s + 1) / P.S);
-  const float* g = P.d_out + (size_t)b * P.out_dim;
-  for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) {
-    float acc = 0.f;
-    for (int j = j0; j < j1; ++j) acc = __builtin_fmaf(P.W[L][(size_t)j * P.hidden + i], g[j], acc);
-    P.partial[((size_t)s * P.B + b) * P.hidden + i] = acc;
-  }
+  float* dst = P.partial + ((size_t)s * P.B + b) * P.hidden;
+  matvec_cols(P.W[L], P.d_out + (size_t)b * P.out_dim, P.hidden, j0, j1, red, [&](int i, float v) { dst[i] = v; });
 }
 
 // (2) deltas of the trunk layers, last to first
 __global__ __launch_bounds__(MAP_THREADS) void mapping_delta_kernel(MapParams P) {
-  extern __shared__ float lds[];          // delta of the layer above, hidden floats
+  extern __shared__ float lds[];          // [hidden] delta of the layer above | [MAP_THREADS] reduction scratch
+  float* dcur = lds;
+  float* red = lds + P.hidden;
   const int b = blockIdx.x;
   const int T = P.n_layers - 1;           // trunk layers 0 .. T - 1
   for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) {
@@ -115,37 +157,29 @@ __global__ __launch_bounds__(MAP_THREADS) void mapping_delta_kernel(MapParams P)
     const float a = P.acts[((size_t)(T - 1) * P.B + b) * P.hidden + i];
     const float d = acc * (a > 0.f ? 1.f : LRELU_SLOPE);
     P.delta[((size_t)(T - 1) * P.B + b) * P.hidden + i] = d;
-    lds[i] = d;
+    dcur[i] = d;
   }
   __syncthreads();
-  for (int l = T - 1; l >= 1; --l) {      // delta_{l-1} from delta_l through W_l [hidden][hidden]
-    float d_new[4];                       // hidden <= 4 * MAP_THREADS (checked by the launcher)
-    int n = 0;
-    for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS, ++n) {
-      float acc = 0.f;
-      for (int j = 0; j < P.hidden; ++j) acc = __builtin_fmaf(P.W[l][(size_t)j * P.hidden + i], lds[j], acc);
-      const float a = P.acts[((size_t)(l - 1) * P.B + b) * P.hidden + i];
-      d_new[n] = acc * (a > 0.f ? 1.f : LRELU_SLOPE);
-    }
+  for (int l = T - 1; l >= 1; --l) {      // delta_{l-1} from delta_l through W_l [hidden][hidden]; results parked in the global delta
+    float* dst = P.delta + ((size_t)(l - 1) * P.B + b) * P.hidden;      // array first (dcur is still being read), copied to LDS after
+    const float* a = P.acts + ((size_t)(l - 1) * P.B + b) * P.hidden;
+    matvec_cols(P.W[l], dcur, P.hidden, 0, P.hidden, red, [&](int i, float v) { dst[i] = v * (a[i] > 0.f ? 1.f : LRELU_SLOPE); });
+    __threadfence_block();
     __syncthreads();
-    n = 0;
-    for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS, ++n) {
-      lds[i] = d_new[n];
-      P.delta[((size_t)(l - 1) * P.B + b) * P.hidden + i] = d_new[n];
-    }
+    for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) dcur[i] = dst[i];
     __syncthreads();
   }
 }
 
 // (3) dW_l[j][i] = sum_b delta_l[b][j] x_{l-1}[b][i];  db_l[j] = sum_b delta_l[b][j];  blockIdx.y = layer, one thread per (j, i)
-__global__ __launch_bounds__(MAP_THREADS) void mapping_wgrad_kernel(MapParams P) {
+__global__ __launch_bounds__(256) void mapping_wgrad_kernel(MapParams P) {
   const int l = blockIdx.y;
   const int T = P.n_layers - 1;
   const int n_out = l == T ? P.out_dim : P.hidden, n_in = l == 0 ? P.z_dim : P.hidden;
   const float* dl = l == T ? P.d_out : P.delta + (size_t)l * P.B * P.hidden;          // [B][n_out]
   const float* xin = l == 0 ? P.z : P.acts + (size_t)(l - 1) * P.B * P.hidden;        // [B][n_in]
   const long long total = (long long)n_out * n_in;
-  for (long long k = (long long)blockIdx.x * MAP_THREADS + threadIdx.x; k < total; k += (long long)gridDim.x * MAP_THREADS) {
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
     const int j = (int)(k / n_in), i = (int)(k % n_in);
     float acc = 0.f;
     for (int b = 0; b < P.B; ++b) acc = __builtin_fmaf(dl[(size_t)b * n_out + j], xin[(size_t)b * n_in + i], acc);
@@ -167,7 +201,7 @@ int fill(MapParams& P, const FenerfMappingNet* net, int B) {
   if (!net) return map_fail(FENERF_E_INVALID, "mapping network description is NULL");
   if (net->n_layers < 2 || net->n_layers > MAP_MAX_LAYERS) return map_fail(FENERF_E_INVALID, "mapping network: n_layers must be in [2, FENERF_MAP_MAX_LAYERS]");
   if (B <= 0 || net->z_dim <= 0 || net->hidden <= 0 || net->out_dim <= 0) return map_fail(FENERF_E_INVALID, "mapping network: B, z_dim, hidden, out_dim must be > 0");
-  if (net->hidden > 4 * MAP_THREADS || net->z_dim > 4096) return map_fail(FENERF_E_UNSUPPORTED, "mapping network: hidden <= 1024 and z_dim <= 4096");
+  if (net->hidden > 1024 || net->z_dim > 4096) return map_fail(FENERF_E_UNSUPPORTED, "mapping network: hidden <= 1024 and z_dim <= 4096");
   memset(&P, 0, sizeof(P));
   P.n_layers = net->n_layers; P.B = B; P.z_dim = net->z_dim; P.hidden = net->hidden; P.out_dim = net->out_dim;
   P.S = net->out_dim >= 2048 ? 16 : (net->out_dim >= 512 ? 8 : 1);
@@ -218,11 +252,11 @@ extern "C" int fenerf_mapping_backward(const FenerfMappingNet* net, int B, const
   hipStream_t st = (hipStream_t)stream;
   PhaseScope ph(PH_OTHER, stream);
   hipLaunchKernelGGL(mapping_head_dx_kernel, dim3(B, P.S), dim3(MAP_THREADS), 0, st, P);
-  hipLaunchKernelGGL(mapping_delta_kernel, dim3(B), dim3(MAP_THREADS), P.hidden * sizeof(float), st, P);
+  hipLaunchKernelGGL(mapping_delta_kernel, dim3(B), dim3(MAP_THREADS), (P.hidden + MAP_THREADS) * sizeof(float), st, P);
   const long long biggest = (long long)P.out_dim * P.hidden;
-  int gx = (int)((biggest + MAP_THREADS - 1) / MAP_THREADS);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(mapping_wgrad_kernel, dim3(gx, P.n_layers), dim3(MAP_THREADS), 0, st, P);
+  int gx = (int)((biggest + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(mapping_wgrad_kernel, dim3(gx, P.n_layers), dim3(256), 0, st, P);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : map_fail(FENERF_E_HIP, std::string("mapping backward launch: ") + hipGetErrorString(e));
 }
