@@ -6,7 +6,7 @@
 // (the 10,000-latent batch of generate_avg_frequencies, generators.py:530-543, stays a rocBLAS GEMM in PyTorch).
 //
 // forward   grid (B, S): every workgroup carries image b through the trunk (256-wide layers, activations in LDS; 16 waves, each wave
-//           four output rows at a time, lanes over the input: coalesced weight rows, shuffle reduction) and computes rows [s, s + 1) * out / S of the
+//           sixteen output rows at a time, lanes over the input: coalesced weight rows, shuffle reduction) and computes rows [s, s + 1) * out / S of the
 //           last layer; workgroup s = 0 also stores the post-activation vectors the backward needs.  The trunk is recomputed S times
 //           (3 x 65 k MACs) so that the 1 M MACs of the last layer spread over S workgroups.
 // backward  (1) head_dx: partial[s][b][i] = sum_{j in range s} W_last[j][i] d_out[b][j]      grid (B, S), thread = input feature i
@@ -28,7 +28,7 @@ namespace {
 
 constexpr int MAP_MAX_LAYERS = FENERF_MAP_MAX_LAYERS;
 constexpr int MAP_THREADS = 1024;          // 16 waves: a workgroup's layers are latency chains, the waves are what hides them
-constexpr int MAP_ROWS = 4;                // rows a wave has in flight at once (matvec_rows)
+constexpr int MAP_ROWS = 16;               // rows a wave has in flight at once (matvec_rows): 16 waves x 16 rows = a 256-row layer in ONE round of loads
 constexpr int MAP_JSPLIT = MAP_THREADS / 256;
 constexpr float LRELU_SLOPE = 0.2f;
 
@@ -64,11 +64,24 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
     float acc[MAP_ROWS];
 #pragma unroll
     for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
-    for (int i = lane; i < n_in; i += 64) {
-      const float xi = x[i];
+    const bool whole = r + MAP_ROWS <= r1;     // wave-uniform: the common case without per-row tests, so that all loads issue back to back
+    if (whole) {
+#pragma unroll 4
+      for (int i = lane; i < n_in; i += 64) {
+        const float xi = x[i];
+        float w[MAP_ROWS];
 #pragma unroll
-      for (int k = 0; k < MAP_ROWS; ++k)
-        if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
+        for (int k = 0; k < MAP_ROWS; ++k) w[k] = W[(size_t)(r + k) * n_in + i];
+#pragma unroll
+        for (int k = 0; k < MAP_ROWS; ++k) acc[k] = __builtin_fmaf(w[k], xi, acc[k]);
+      }
+    } else {
+      for (int i = lane; i < n_in; i += 64) {
+        const float xi = x[i];
+#pragma unroll
+        for (int k = 0; k < MAP_ROWS; ++k)
+          if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < MAP_ROWS; ++k) {
