@@ -54,37 +54,51 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LRELU_SLOPE; }
 
-// y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1): a wave takes MAP_ROWS rows at a time (their loads are all in flight together),
-// lanes over i (coalesced weight rows), shuffle reduction.  Summation order per row: lane-strided partial sums, then the butterfly.
+// y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1).  A wave takes MAP_ROWS rows at a time; a lane reads 16 bytes of each row (float4:
+// 64 lanes x 4 = a whole 256-wide row in ONE load per row), so a 256-row, 256-wide layer is one round of 16 loads per lane on 16 waves --
+// a layer costs one memory latency, not sixteen.  (n_in not a multiple of 4: scalar loads, four rows at a time.)  Summation order per
+// row: lane-strided partial sums, then the shuffle butterfly.
 template <class F>
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* x, int n_in, int r0, int r1, F store) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = MAP_THREADS / 64;
-  for (int r = r0 + wave * MAP_ROWS; r < r1; r += NW * MAP_ROWS) {
-    float acc[MAP_ROWS];
+  if ((n_in & 3) == 0) {
+    for (int r = r0 + wave * MAP_ROWS; r < r1; r += NW * MAP_ROWS) {
+      float acc[MAP_ROWS];
 #pragma unroll
-    for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
-    const bool whole = r + MAP_ROWS <= r1;     // wave-uniform: the common case without per-row tests, so that all loads issue back to back
-    if (whole) {
-#pragma unroll 4
-      for (int i = lane; i < n_in; i += 64) {
-        const float xi = x[i];
-        float w[MAP_ROWS];
-#pragma unroll
-        for (int k = 0; k < MAP_ROWS; ++k) w[k] = W[(size_t)(r + k) * n_in + i];
-#pragma unroll
-        for (int k = 0; k < MAP_ROWS; ++k) acc[k] = __builtin_fmaf(w[k], xi, acc[k]);
-      }
-    } else {
-      for (int i = lane; i < n_in; i += 64) {
-        const float xi = x[i];
+      for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
+      const int nr = r1 - r < MAP_ROWS ? r1 - r : MAP_ROWS;      // wave-uniform
+      for (int c = 4 * lane; c < n_in; c += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + c);
+        float4 wv[MAP_ROWS];
 #pragma unroll
         for (int k = 0; k < MAP_ROWS; ++k)
-          if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
+          wv[k] = k < nr ? *reinterpret_cast<const float4*>(W + (size_t)(r + k) * n_in + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < MAP_ROWS; ++k)
+          acc[k] = __builtin_fmaf(wv[k].w, xv.w, __builtin_fmaf(wv[k].z, xv.z, __builtin_fmaf(wv[k].y, xv.y, __builtin_fmaf(wv[k].x, xv.x, acc[k]))));
+      }
+#pragma unroll
+      for (int k = 0; k < MAP_ROWS; ++k) {
+        const float v = wave_sum_f(acc[k]);
+        if (lane == 0 && k < nr) store(r + k, v + bias[r + k]);
       }
     }
+    return;
+  }
+  constexpr int RS = 4;
+  for (int r = r0 + wave * RS; r < r1; r += NW * RS) {
+    float acc[RS];
 #pragma unroll
-    for (int k = 0; k < MAP_ROWS; ++k) {
+    for (int k = 0; k < RS; ++k) acc[k] = 0.f;
+    for (int i = lane; i < n_in; i += 64) {
+      const float xi = x[i];
+#pragma unroll
+      for (int k = 0; k < RS; ++k)
+        if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < RS; ++k) {
       const float v = wave_sum_f(acc[k]);
       if (lane == 0 && r + k < r1) store(r + k, v + bias[r + k]);
     }
