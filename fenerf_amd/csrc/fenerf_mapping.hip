@@ -68,6 +68,7 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
 #pragma unroll
       for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
       const int nr = r1 - r < MAP_ROWS ? r1 - r : MAP_ROWS;      // wave-uniform
+      const float bl = lane < nr ? bias[r + lane] : 0.f;         // row r + lane's bias, fetched with the weights (not behind the reduction)
       for (int c = 4 * lane; c < n_in; c += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(x + c);
         float4 wv[MAP_ROWS];
@@ -78,11 +79,13 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
         for (int k = 0; k < MAP_ROWS; ++k)
           acc[k] = __builtin_fmaf(wv[k].w, xv.w, __builtin_fmaf(wv[k].z, xv.z, __builtin_fmaf(wv[k].y, xv.y, __builtin_fmaf(wv[k].x, xv.x, acc[k]))));
       }
+      float res = 0.f;                                           // row r + k's sum ends in lane k: one coalesced store per pass
 #pragma unroll
       for (int k = 0; k < MAP_ROWS; ++k) {
         const float v = wave_sum_f(acc[k]);
-        if (lane == 0 && k < nr) store(r + k, v + bias[r + k]);
+        if (lane == k) res = v;
       }
+      if (lane < nr) store(r + lane, res + bl);
     }
     return;
   }
@@ -97,11 +100,14 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
       for (int k = 0; k < RS; ++k)
         if (r + k < r1) acc[k] = __builtin_fmaf(W[(size_t)(r + k) * n_in + i], xi, acc[k]);
     }
+    const float bl = (lane < RS && r + lane < r1) ? bias[r + lane] : 0.f;
+    float res = 0.f;
 #pragma unroll
     for (int k = 0; k < RS; ++k) {
       const float v = wave_sum_f(acc[k]);
-      if (lane == 0 && r + k < r1) store(r + k, v + bias[r + k]);
+      if (lane == k) res = v;
     }
+    if (lane < RS && r + lane < r1) store(r + lane, res + bl);
   }
 }
 
