@@ -57,7 +57,7 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LRELU
 // y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1).  A wave takes MAP_ROWS rows at a time; a lane reads 16 bytes of each row (float4:
 // 64 lanes x 4 = a whole 256-wide row in ONE load per row), so a 256-row, 256-wide layer is one round of 16 loads per lane on 16 waves --
 // a layer costs one memory latency, not sixteen.  (n_in not a multiple of 4: scalar loads, four rows at a time.)  Summation order per
-// row: lane-strided partial sums, then the shuffle butterfly.
+// row: lane-strided partial sums, then a fixed butterfly over the lanes (deterministic).
 template <class F>
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, const float* x, int n_in, int r0, int r1, F store) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,7 +68,8 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
 #pragma unroll
       for (int k = 0; k < MAP_ROWS; ++k) acc[k] = 0.f;
       const int nr = r1 - r < MAP_ROWS ? r1 - r : MAP_ROWS;      // wave-uniform
-      const float bl = lane < nr ? bias[r + lane] : 0.f;         // row r + lane's bias, fetched with the weights (not behind the reduction)
+      const int myrow = lane >> 2;                               // the row whose total the transposing butterfly below leaves in this lane
+      const float bl = myrow < nr ? bias[r + myrow] : 0.f;       // its bias, fetched with the weights (not behind the reduction)
       for (int c = 4 * lane; c < n_in; c += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(x + c);
         float4 wv[MAP_ROWS];
@@ -79,13 +80,21 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
         for (int k = 0; k < MAP_ROWS; ++k)
           acc[k] = __builtin_fmaf(wv[k].w, xv.w, __builtin_fmaf(wv[k].z, xv.z, __builtin_fmaf(wv[k].y, xv.y, __builtin_fmaf(wv[k].x, xv.x, acc[k]))));
       }
-      float res = 0.f;                                           // row r + k's sum ends in lane k: one coalesced store per pass
+      // 16 rows x 64 lane-partials -> 16 totals with 17 shuffles instead of 96: a transposing butterfly -- at each step a lane keeps the
+      // half of its rows that its lane bit selects and adds the partner's partials of those rows; row k's total ends in lanes 4 k .. 4 k + 3
+      static_assert(MAP_ROWS == 16, "the butterfly below is written for 16 rows");
+      float a8[8], a4[4], a2[2];
+      const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-      for (int k = 0; k < MAP_ROWS; ++k) {
-        const float v = wave_sum_f(acc[k]);
-        if (lane == k) res = v;
-      }
-      if (lane < nr) store(r + lane, res + bl);
+      for (int k = 0; k < 8; ++k) a8[k] = (b5 ? acc[k + 8] : acc[k]) + __shfl_xor(b5 ? acc[k] : acc[k + 8], 32, 64);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a4[k] = (b4 ? a8[k + 4] : a8[k]) + __shfl_xor(b4 ? a8[k] : a8[k + 4], 16, 64);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) a2[k] = (b3 ? a4[k + 2] : a4[k]) + __shfl_xor(b3 ? a4[k] : a4[k + 2], 8, 64);
+      float res = (b2 ? a2[1] : a2[0]) + __shfl_xor(b2 ? a2[0] : a2[1], 4, 64);
+      res += __shfl_xor(res, 2, 64);
+      res += __shfl_xor(res, 1, 64);
+      if ((lane & 3) == 0 && myrow < nr) store(r + myrow, res + bl);
     }
     return;
   }
