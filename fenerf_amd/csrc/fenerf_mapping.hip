@@ -27,7 +27,7 @@ namespace fenerf {
 namespace {
 
 constexpr int MAP_MAX_LAYERS = FENERF_MAP_MAX_LAYERS;
-constexpr int MAP_THREADS = 1024;          // 16 waves: a workgroup's layers are latency chains, the waves are what hides them
+constexpr int MAP_THREADS = 512;           // 8 waves (256 registers each: the 16 x float4 row tile of matvec_rows must not spill)
 constexpr int MAP_ROWS = 16;               // rows a wave has in flight at once (matvec_rows): 16 waves x 16 rows = a 256-row layer in ONE round of loads
 constexpr int MAP_JSPLIT = MAP_THREADS / 256;
 constexpr float LRELU_SLOPE = 0.2f;
