@@ -54,6 +54,17 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LRELU_SLOPE; }
 
+// The weights are cold every time (13 ms of other kernels' traffic since their last use), and a layer cannot start before the layer in
+// front of it has finished: reading them layer by layer pays one HBM miss latency per round of loads, ~10 rounds per kernel.  So each
+// kernel first touches every 128-byte line it is going to read -- all those misses overlap -- and the layers then run out of L2.
+__device__ __forceinline__ float warm_lines(const float* __restrict__ p, size_t n_floats, float sink) {
+  for (size_t off = (size_t)threadIdx.x * 32; off < n_floats; off += (size_t)MAP_THREADS * 32) sink += p[off];
+  return sink;
+}
+__device__ __forceinline__ void warm_done(float sink, float* somewhere) {
+  if (sink == 1.2345e30f) *somewhere = sink;      // never true: keeps the loads alive
+}
+
 // y[r] = sum_i W[r][i] x[i] + b[r] for rows [r0, r1).  A wave takes MAP_ROWS rows at a time; a lane reads 16 bytes of each row (float4:
 // 64 lanes x 4 = a whole 256-wide row in ONE load per row), so a 256-row, 256-wide layer is one round of 16 loads per lane on 16 waves --
 // a layer costs one memory latency, not sixteen.  (n_in not a multiple of 4: scalar loads, four rows at a time.)  Summation order per
@@ -127,6 +138,13 @@ __global__ __launch_bounds__(MAP_THREADS) void mapping_forward_kernel(MapParams 
   float* x = lds;
   float* y = lds + wmax;
   for (int i = threadIdx.x; i < P.z_dim; i += MAP_THREADS) x[i] = P.z[(size_t)b * P.z_dim + i];
+  {
+    float sink = 0.f;
+    for (int l = 0; l + 1 < P.n_layers; ++l) sink = warm_lines(P.W[l], (size_t)P.hidden * (l == 0 ? P.z_dim : P.hidden), sink);
+    const int w0 = (int)((long long)P.out_dim * s / P.S), w1 = (int)((long long)P.out_dim * (s + 1) / P.S);
+    sink = warm_lines(P.W[P.n_layers - 1] + (size_t)w0 * P.hidden, (size_t)(w1 - w0) * P.hidden, sink);
+    warm_done(sink, P.out);
+  }
   __syncthreads();
   int n_in = P.z_dim;
   for (int l = 0; l + 1 < P.n_layers; ++l) {
@@ -183,6 +201,7 @@ __global__ __launch_bounds__(MAP_THREADS) void mapping_head_dx_kernel(MapParams 
   const int L = P.n_layers - 1;
   const int j0 = (int)((long long)P.out_dim * s / P.S), j1 = (int)((long long)P.out_dim * (s + 1) / P.S);
   float* dst = P.partial + ((size_t)s * P.B + b) * P.hidden;
+  warm_done(warm_lines(P.W[L] + (size_t)j0 * P.hidden, (size_t)(j1 - j0) * P.hidden, 0.f), dst);
   matvec_cols(P.W[L], P.d_out + (size_t)b * P.out_dim, P.hidden, j0, j1, red, [&](int i, float v) { dst[i] = v; });
 }
 
@@ -193,6 +212,11 @@ __global__ __launch_bounds__(MAP_THREADS) void mapping_delta_kernel(MapParams P)
   float* red = lds + P.hidden;
   const int b = blockIdx.x;
   const int T = P.n_layers - 1;           // trunk layers 0 .. T - 1
+  {
+    float sink = 0.f;
+    for (int l = 1; l < T; ++l) sink = warm_lines(P.W[l], (size_t)P.hidden * P.hidden, sink);
+    warm_done(sink, P.delta);
+  }
   for (int i = threadIdx.x; i < P.hidden; i += MAP_THREADS) {
     float acc = 0.f;
     for (int s = 0; s < P.S; ++s) acc += P.partial[((size_t)s * P.B + b) * P.hidden + i];
