@@ -80,6 +80,7 @@ _SIGS = {
     "fenerf_last_error": (C.c_char_p, []),
     "fenerf_abi_version": (_i, []),
     "fenerf_set_cu_budget": (_i, [_i]),
+    "fenerf_set_render_fusion": (_i, [_i]),
     "fenerf_mapping_forward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, _vp]),
     "fenerf_mapping_workspace_floats": (_sz, [C.POINTER(FenerfMappingNet), _i]),
     "fenerf_mapping_backward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
@@ -137,7 +138,8 @@ _SIGS = {
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-N_PHASES = 16        # include/fenerf.h FENERF_N_PHASES
+N_PHASES = 17        # include/fenerf.h FENERF_N_PHASES
+FUSION_AUTO, FUSION_OFF, FUSION_FORCE = 0, 1, 2      # include/fenerf.h fenerf_set_render_fusion
 
 _lib = None
 

@@ -56,7 +56,7 @@ std::mutex g_phase_mu;
 std::vector<PhaseRec*> g_phase_recs;
 const char* const kPhaseNames[PH_COUNT] = {"film_prep", "siren_forward", "forward_save", "chain", "wgrad_film_sums", "wgrad_square",
                                            "wgrad_square_reduce", "wgrad_thin", "wgrad_thin_reduce", "composite", "resample",
-                                           "composite_backward", "repack", "grid", "ray_setup", "other"};
+                                           "composite_backward", "repack", "grid", "ray_setup", "other", "render_fused"};
 }  // namespace
 PhaseScope::PhaseScope(int phase, void* stream) : rec(nullptr) {
   if (!g_phase_on.load(std::memory_order_relaxed)) return;
@@ -204,6 +204,14 @@ extern "C" int fenerf_phase_times(double* ms, int* calls, int n) {
   return rc;
 }
 extern "C" int fenerf_abi_version(void) { return FENERF_ABI_VERSION; }
+static thread_local int g_render_fusion = FENERF_FUSION_AUTO;
+// AUTO takes the one-launch route only if it has been measured to be at least as fast as the four launches (profiles/r04_render_one_launch.md)
+static constexpr bool kFusionAutoEnabled = false;
+extern "C" int fenerf_set_render_fusion(int mode) {
+  const int prev = g_render_fusion;
+  g_render_fusion = (mode == FENERF_FUSION_OFF || mode == FENERF_FUSION_FORCE) ? mode : FENERF_FUSION_AUTO;
+  return prev;
+}
 extern "C" int fenerf_set_cu_budget(int cus) {
   const int prev = g_cu_budget;
   g_cu_budget = cus > 0 ? cus : 0;
@@ -975,12 +983,10 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   sp.film_bias = m->d_consts + CONST_FILM_BIAS;
   sp.film_inv_scale = m->precision == FENERF_PREC_F16X3 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr;
   sp.n_images = B;
-  rc = run_siren(m, sp, stream);                       // coarse pass   (generators.py:479)
-  if (rc) return rc;
-  sp.raw_fg = nullptr;                                    // the fine pass finds f' / p' in the workspace
-
   CompositeParams cp;
   if (!hierarchical) {
+    rc = run_siren(m, sp, stream);                     // the only pass     (generators.py:479)
+    if (rc) return rc;
     memset(&cp, 0, sizeof(cp));
     cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;
     cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_final; cp.o = *opts;
@@ -990,6 +996,29 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   }
   float* fine = (float*)(base + ws.fine);
   float* zf = (float*)(base + ws.zf);
+  FusedRenderPlan plan;
+  if ((g_render_fusion == FENERF_FUSION_FORCE || (g_render_fusion == FENERF_FUSION_AUTO && kFusionAutoEnabled)) &&
+      fused_render_plan(m, B, R, N, g_render_fusion == FENERF_FUSION_AUTO, &plan)) {
+    // ONE launch (fenerf_siren_f16w.hip, FUSED): per ray group coarse octs -> weights + resampling -> fine octs -> merge + composite
+    CompositeParams c1, c2;
+    memset(&c1, 0, sizeof(c1));
+    c1.BR = BR; c1.M = N; c1.C = m->C; c1.N = N;
+    c1.rows_a = coarse; c1.z_a = z_coarse; c1.noise = noise_coarse;
+    c1.o.clamp_mode = opts->clamp_mode; c1.o.noise_std = opts->noise_std;
+    c1.sigma_only = 1; c1.out_ch = m->C - 1;
+    c1.u = u; c1.z_fine = zf;
+    memset(&c2, 0, sizeof(c2));
+    c2.BR = BR; c2.M = 2 * N; c2.C = m->C; c2.N = N;
+    c2.rows_a = fine; c2.rows_b = coarse; c2.z_a = zf; c2.z_b = z_coarse; c2.noise = noise_final; c2.o = *opts;
+    c2.out_rgb = out_rgb; c2.out_depth = out_depth; c2.out_weights = out_weights; c2.out_wsum = out_wsum;
+    c2.out_ch = out_channels(m->C, opts);
+    sp.out = coarse;
+    PhaseScope ph(PH_RENDER_FUSED, stream);
+    return launch_render16w_fused(m, sp, plan, zf, fine, c1, c2, stream);
+  }
+  rc = run_siren(m, sp, stream);                       // coarse pass   (generators.py:479)
+  if (rc) return rc;
+  sp.raw_fg = nullptr;                                    // the fine pass finds f' / p' in the workspace
   memset(&cp, 0, sizeof(cp));                             // coarse weights (generators.py:487) and, in the same wave per ray, the
   cp.BR = BR; cp.M = N; cp.C = m->C; cp.N = N;            // inverse-CDF resampling from them (generators.py:489-499): one launch
   cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_coarse;

@@ -21,7 +21,7 @@ int ensure_dynamic_lds(const void* kfn, size_t bytes);
 // Per-phase device timing (fenerf_phase_timing / fenerf_phase_times): a PhaseScope around a launch group records a hipEvent pair on
 // the stream when timing is on, and is two loads of a flag when it is off.
 enum Phase { PH_FILM_PREP = 0, PH_SIREN, PH_SIREN_SAVE, PH_CHAIN, PH_WGRAD_FILM, PH_WGRAD_SQ, PH_WGRAD_SQ_REDUCE, PH_WGRAD_THIN,
-             PH_WGRAD_THIN_REDUCE, PH_COMPOSITE, PH_RESAMPLE, PH_COMPOSITE_BWD, PH_REPACK, PH_GRID, PH_RAY_SETUP, PH_OTHER, PH_COUNT };
+             PH_WGRAD_THIN_REDUCE, PH_COMPOSITE, PH_RESAMPLE, PH_COMPOSITE_BWD, PH_REPACK, PH_GRID, PH_RAY_SETUP, PH_OTHER, PH_RENDER_FUSED, PH_COUNT };
 static_assert(PH_COUNT == FENERF_N_PHASES, "include/fenerf.h FENERF_N_PHASES");
 struct PhaseScope {
   PhaseScope(int phase, void* stream);
@@ -168,6 +168,11 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles = nullptr);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
+// fenerf_render_forward as ONE launch (fenerf_siren_f16w.hip, FUSED): ray groups of whole octs, see there
+struct FusedRenderPlan { int rays_per_group, octs_per_group, blocks; long long groups; };
+bool fused_render_plan(const FenerfModel* m, long long B, long long R, int N, bool balanced_only, FusedRenderPlan* plan);
+int launch_render16w_fused(const FenerfModel* m, const SirenParams& p, const FusedRenderPlan& plan, float* z_fine, float* out_fine,
+                           const CompositeParams& coarse, const CompositeParams& final_, void* stream);
 int launch_composite(const CompositeParams& p, bool merge, void* stream);
 int launch_composite_backward(const CompositeParams& p, bool merge, void* stream);
 int launch_resample(long long BR, int N, const float* z, const float* w, const float* u, float* zf, void* stream);

@@ -28,6 +28,7 @@
 //   accumulators, FiLM'ed and split, ARE the next layer's B operand {acc[0][0..3], acc[1][0..3]}.
 #include <hip/hip_runtime.h>
 
+#include "fenerf_composite_ray.h"
 #include "fenerf_film.h"
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
@@ -272,8 +273,36 @@ __device__ __forceinline__ void piece_range(int qc, int& p0, int& p1) {
   p1 = 4 * (qc + 1) / QBE;
 }
 
-template <int H, bool GRID, bool SAVE>
-__global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C) {
+// FUSED = the whole hierarchical render of generators.py:479-519 in this one launch (fenerf_render_forward).  The unit of work is then not
+// an oct but a RAY GROUP: the fewest rays whose coarse samples fill whole octs (G = 128 / gcd(N, 128) rays = N / gcd(N, 128) octs; 16 rays =
+// 3 octs at N = 24).  A workgroup evaluates the coarse octs of a group exactly like the plain kernel (outputs to the workspace), then its
+// 8 waves take the group's rays one wave per ray through composite_ray -- coarse weights + inverse-CDF resampling, fine depths to the
+// workspace --, evaluates the fine octs from those depths, and the waves merge + composite the group's rays into the output pixels.  The
+// coarse / fine rows and the fine depths are written and read back by the SAME workgroup a few microseconds apart (L2), ordered by
+// workgroup-scope fences + barriers; the weight ring is untouched by the ray phases (chunks 0 .. D-1 of the next tile land and wait), which
+// use the per-wave LDS block that parks colour layer 0's extra operands during a tile.
+template <bool FUSED> struct FuseArgs {};
+template <> struct FuseArgs<true> {
+  int rays_per_group, octs_per_group;
+  long long groups, total_rays;
+  float* z_fine;            // [B*R][N]  written by the coarse ray phase, read by the fine tiles and the final ray phase
+  float* out_fine;          // [P][C]    fine rows (P.out takes the coarse rows)
+  CompositeParams coarse;   // sigma_only + u / z_fine: weights and resampling     (generators.py:486-499)
+  CompositeParams final_;   // merge of fine | coarse + fancy_integration          (generators.py:508-519)
+};
+// timing experiments only (tools/exp/fused_ray_phase.sh): 2 = the ray phases as shipped, 1 = their fences + barriers without the rays,
+// 0 = no ray phase at all (the tiles of a fused launch in fused order; wrong pixels)
+#ifndef FENERF_EXP_RAY_PHASE
+#define FENERF_EXP_RAY_PHASE 2
+#endif
+#ifndef FENERF_EXP_FUSED_MAXM
+#define FENERF_EXP_FUSED_MAXM 128
+#endif
+constexpr int FUSED_MAXM = FENERF_EXP_FUSED_MAXM;   // samples per ray (2 N) the ray phases handle: their LDS scratch is the 4-KiB colour-layer-0 block
+
+template <int H, bool GRID, bool SAVE, bool FUSED = false>
+__global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C, FuseArgs<FUSED> F) {
+  static_assert(!(FUSED && SAVE), "the fused render is the no-grad path");
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = (KS + 1) / 2;                              // chunks per square n-block body
   constexpr int C0_KS = KS + (GRID ? 1 : 0) + 1;                // colour layer 0: x | grid | dir
@@ -314,6 +343,15 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
     cst[64 + threadIdx.x - 32] = P.consts[CONST_FILM_BIAS + (size_t)2 * L * H + threadIdx.x];
     cst[68 + threadIdx.x - 32] = P.consts[CONST_RGB_BIAS + threadIdx.x - 32];
   }
+  // FUSED: the two CompositeParams of the ray phases live in LDS (behind the colour-layer-0 blocks), not in ~90 SGPRs across the tile body
+  CompositeParams* ray_par = reinterpret_cast<CompositeParams*>(reinterpret_cast<float4*>(cst + 80 + NWAVE * stage_f4 * 4) + NWAVE * 256);
+  if constexpr (FUSED) {
+    constexpr int NW = (int)(sizeof(CompositeParams) / 4);
+    static_assert(sizeof(CompositeParams) % 4 == 0 && NW <= 256, "copied one dword per thread");
+    const int t = threadIdx.x & 255;
+    const unsigned* src = reinterpret_cast<const unsigned*>(threadIdx.x < 256 ? &F.coarse : &F.final_);
+    if (t < NW) reinterpret_cast<unsigned*>(ray_par + (threadIdx.x >> 8))[t] = src[t];
+  }
   WAIT_VMCNT(0);
   __syncthreads();
 
@@ -332,20 +370,23 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   ws.ring_lane = ring + lane * 16;
   ws.early = wave < NWAVE / 2;
 
-  // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
+  // work split: octs of 16-point tiles (one tile per wave) -- FUSED: ray groups of octs_per_group octs --, XCD-contiguous ranges
   const long long ntiles = (P.P + 15) / 16;
   const long long nocts = (ntiles + NWAVE - 1) / NWAVE;
+  int opg = 1;
+  long long nunits = nocts;
+  if constexpr (FUSED) { opg = F.octs_per_group; nunits = F.groups; }
   const int nblk = gridDim.x;
   const int nx = nblk < 8 ? nblk : 8;
   const int xcd = blockIdx.x % nx, bi = blockIdx.x / nx;
   const int blocks_in_x = nblk / nx + (xcd < nblk % nx ? 1 : 0);
-  const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
+  const long long o_begin = nunits * xcd / nx, o_end = nunits * (xcd + 1) / nx;
 
   if (P.raw_fg && o_begin + bi < o_end) {
     // FiLM pre-pass in the launch (fenerf_film.h): the images of this workgroup's octs, before the first LDS-DMA of the stream is
     // issued (ordinary loads and stores: nothing of theirs is left in flight behind the fence + barrier that ends the prologue)
-    const long long p_first = (o_begin + bi) * (NWAVE * 16);
-    long long p_last = o_end * (NWAVE * 16) - 1;
+    const long long p_first = (o_begin + bi) * opg * (NWAVE * 16);
+    long long p_last = o_end * opg * (NWAVE * 16) - 1;
     if (p_last >= P.P) p_last = P.P - 1;
     film_prep_prologue(P, p_first / P.pts_per_image, p_last / P.pts_per_image, H, n_geo, n_color);
   }
@@ -366,7 +407,17 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   a_cur.n = ws_read(ws, 0, 1);
 
 
-  for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
+  for (long long unit = o_begin + bi; unit < o_end; unit += blocks_in_x) {
+  const int nsub = FUSED ? 2 * opg : 1;       // FUSED: the group's coarse octs, then its fine octs
+#pragma unroll 1
+  for (int sub = 0; sub < nsub; ++sub) {
+    const bool fine_pass = FUSED && sub >= opg;
+    const long long oct = FUSED ? unit * opg + (fine_pass ? sub - opg : sub) : unit;
+    const float* z_src = P.z;
+    float* out_dst = P.out;
+    if constexpr (FUSED) {
+      if (fine_pass) { z_src = F.z_fine; out_dst = F.out_fine; }
+    }
     // the previous tile ended by issuing the replicated head chunks nchunk..nchunk+D-1 (== this tile's chunks 0..D-1)
     ws.g_next = g_stream + (unsigned long long)DPF * (CH * 1024);
     const long long tile = oct * NWAVE + wave;
@@ -381,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       else { dx = 0.f; dy = 0.f; dz = -1.f; }
     } else {
       const long long ray = pt / P.n_per_ray;
-      const float zz = P.z[pt];
+      const float zz = z_src[pt];
       const float ox = P.origins[ray * 3 + 0], oy = P.origins[ray * 3 + 1], oz = P.origins[ray * 3 + 2];
       dx = P.dirs[ray * 3 + 0]; dy = P.dirs[ray * 3 + 1]; dz = P.dirs[ray * 3 + 2];
       px = __fadd_rn(ox, __fmul_rn(dx, zz)); py = __fadd_rn(oy, __fmul_rn(dy, zz)); pz = __fadd_rn(oz, __fmul_rn(dz, zz));
@@ -639,10 +690,44 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       const long long base = tile * 16 * C;
       const long long limit = P.P * C;
       for (int i = opaque(lane); i < 16 * C; i += 64)
-        if (base + i < limit) P.out[base + i] = stage[i];
+        if (base + i < limit) out_dst[base + i] = stage[i];
     }
     WAIT_VMCNT(0);   // stores may retire out of order with the DMA loads: keep them out of the counted waits
     __builtin_amdgcn_wave_barrier();
+    if constexpr (FUSED) {
+      if (FENERF_EXP_RAY_PHASE > 0 && (sub == opg - 1 || sub == nsub - 1)) {
+        // ---------------- ray phase: every wave has stored (and waited for) its rows of this pass; one wave per ray ----------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float* sc = reinterpret_cast<float*>(ext_wave);
+        float* s_z = sc;
+        float* s_zs = sc + FUSED_MAXM;
+        int* s_ord = reinterpret_cast<int*>(sc + 2 * FUSED_MAXM + 4);
+        float* s_w = sc + 3 * FUSED_MAXM + 4;
+        const int lane_r = opaque(lane);
+        const long long ray0 = unit * F.rays_per_group;
+        for (int r = wave; r < F.rays_per_group; r += NWAVE) {
+          const long long ray = ray0 + r;
+          if (FENERF_EXP_RAY_PHASE > 1 && ray < F.total_rays) {
+#pragma unroll 1
+            for (int rep = 0; rep < (FENERF_EXP_RAY_PHASE > 2 ? 2 : 1); ++rep) {   // > 2: every ray twice (marginal cost of a ray)
+              if (!fine_pass) composite_ray<false, FUSED_MAXM>(ray_par[0], ray, lane_r, s_z, s_zs, s_ord, s_w);
+              else composite_ray<true, FUSED_MAXM>(ray_par[1], ray, lane_r, s_z, s_zs, s_ord, s_w);
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (!fine_pass) {   // the fine depths of the group, for every wave's fine tiles
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        WAIT_VMCNT(0);      // nothing of the ray phase is in flight when the counted waits of the stream loop resume
+      }
+    }
+  }
   }
   WAIT_VMCNT(0);     // no LDS-DMA may land after the workgroup has released its LDS
   __builtin_amdgcn_s_barrier();
@@ -657,20 +742,35 @@ static int hip_fail16w(hipError_t e, const char* what) {
   return FENERF_E_HIP;
 }
 
-template <int H, bool GRID, bool SAVE>
-static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
+static size_t lds_bytes_16w(const FenerfModel* m, int H) {
   const int stage_f4 = (16 * m->C + 3) / 4;
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
-  const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)(H / 32) * 1024 + 80 * 4 +
-                     (size_t)NWAVE * stage_f4 * 16 + (size_t)NWAVE * 4096;   // ring + FiLM buffers + layer-0 weights + head consts +
-                                                                               // output staging + colour-layer-0 operands
-  auto kfn = siren16w_kernel<H, GRID, SAVE>;
+  return (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)(H / 32) * 1024 + 80 * 4 +
+         (size_t)NWAVE * stage_f4 * 16 + (size_t)NWAVE * 4096;   // ring + FiLM buffers + layer-0 weights + head consts +
+                                                                   // output staging + colour-layer-0 operands
+}
+
+// fenerf_render_forward in one launch (FUSED): `blocks` workgroups over F.groups ray groups
+template <int H, bool GRID>
+static int launch_fused_t(const FenerfModel* m, const SirenParams& p, const FuseArgs<true>& F, int blocks, void* stream) {
+  const size_t lds = lds_bytes_16w(m, H) + (2 * sizeof(CompositeParams) + 255) / 256 * 256;
+  auto kfn = siren16w_kernel<H, GRID, false, true>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C, F);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "fused render launch");
+}
+
+template <int H, bool GRID, bool SAVE>
+static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
+  const size_t lds = lds_bytes_16w(m, H);
+  auto kfn = siren16w_kernel<H, GRID, SAVE, false>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
   if (blocks > m->num_cus) blocks = m->num_cus;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C, FuseArgs<false>{});
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "siren16w launch");
 }
@@ -693,6 +793,39 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
     case 64: return g ? w16::launch_t<64, true, false>(m, q, stream) : w16::launch_t<64, false, false>(m, q, stream);
     case 128: return g ? w16::launch_t<128, true, false>(m, q, stream) : w16::launch_t<128, false, false>(m, q, stream);
     case 256: return g ? w16::launch_t<256, true, false>(m, q, stream) : w16::launch_t<256, false, false>(m, q, stream);
+  }
+  set_error("unsupported hidden_dim");
+  return FENERF_E_UNSUPPORTED;
+}
+
+// Geometry of the one-launch render: G rays per group, octs per group, groups, workgroups; false when this (B, R, N) cannot run fused.
+// `balanced_only`: refuse when the coarser unit of work would lengthen the critical path (whole groups per workgroup vs whole octs).
+bool fused_render_plan(const FenerfModel* m, long long B, long long R, int N, bool balanced_only, FusedRenderPlan* plan) {
+  if (m->precision != FENERF_PREC_F16X3 || N < 3 || 2 * N > w16::FUSED_MAXM) return false;
+  int g = N, b = 128;
+  while (b) { const int t = g % b; g = b; b = t; }          // gcd(N, 128)
+  const int G = 128 / g, opg = N / g;
+  if (R % G != 0) return false;                              // groups (hence tiles) do not straddle images
+  const long long groups = B * R / G, nocts = groups * opg;
+  const long long cus = launch_cus(m);
+  const long long blocks_f = groups < cus ? groups : cus, blocks_p = nocts < cus ? nocts : cus;
+  if (balanced_only && (groups + blocks_f - 1) / blocks_f * opg > (nocts + blocks_p - 1) / blocks_p) return false;
+  plan->rays_per_group = G; plan->octs_per_group = opg; plan->groups = groups; plan->blocks = (int)blocks_f;
+  return true;
+}
+
+int launch_render16w_fused(const FenerfModel* m, const SirenParams& p, const FusedRenderPlan& plan, float* z_fine, float* out_fine,
+                           const CompositeParams& coarse, const CompositeParams& final_, void* stream) {
+  w16::FuseArgs<true> F;
+  F.rays_per_group = plan.rays_per_group; F.octs_per_group = plan.octs_per_group; F.groups = plan.groups;
+  F.total_rays = coarse.BR;
+  F.z_fine = z_fine; F.out_fine = out_fine; F.coarse = coarse; F.final_ = final_;
+  const bool g = m->grid_ch != 0;
+  switch (m->H) {
+    case 32: return g ? w16::launch_fused_t<32, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<32, false>(m, p, F, plan.blocks, stream);
+    case 64: return g ? w16::launch_fused_t<64, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<64, false>(m, p, F, plan.blocks, stream);
+    case 128: return g ? w16::launch_fused_t<128, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<128, false>(m, p, F, plan.blocks, stream);
+    case 256: return g ? w16::launch_fused_t<256, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<256, false>(m, p, F, plan.blocks, stream);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

@@ -632,6 +632,24 @@ class NativeLocalModel:
             pass
 
 
+class render_fusion:
+    """with native.render_fusion("off" | "force" | "auto"): ...  -- how the calling thread's hierarchical renders are launched inside the
+    block (include/fenerf.h fenerf_set_render_fusion): one launch when the shape allows it and it is balanced ("auto", the default), always
+    four launches ("off"), one launch whenever the shape allows it ("force").  The results are the same bit for bit."""
+    MODES = {"auto": _lib.FUSION_AUTO, "off": _lib.FUSION_OFF, "force": _lib.FUSION_FORCE}
+
+    def __init__(self, mode):
+        self.mode = self.MODES[mode]
+
+    def __enter__(self):
+        self._prev = _lib.lib().fenerf_set_render_fusion(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().fenerf_set_render_fusion(self._prev)
+        return False
+
+
 class cu_budget:
     """with native.cu_budget(n): ...  -- the calling thread's launches inside the block are sized for at most n compute units
     (include/fenerf.h fenerf_set_cu_budget; 0 / None = the whole device).  Workspace sizes are queried under the same setting."""

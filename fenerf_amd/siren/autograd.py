@@ -29,6 +29,34 @@ def _fold_label_head(label_params):
     return A, c
 
 
+def _fold_label_head_backward(label_params, gA, gc):
+    """Gradients of every (W_i, b_i) of the label head from the gradient (gA [n_lab, H], gc [n_lab]) of its fold A = W_{n-1} ... W_0,
+    c = sum_i S_i b_i with S_i = W_{n-1} ... W_{i+1}.  Layer i sees y_i = R_i x + q_i (R_i = W_{i-1} ... W_0, q_i = W_{i-1} q_{i-1} + b_{i-1}),
+    so  dW_i = S_i^T (gA R_i^T + gc (x) q_i) = S_i^T U_i + db_i (x) q_i,  db_i = S_i^T gc,  U_i = U_{i-1} W_{i-1}^T, U_0 = gA.
+    Written out (11 launches for the three-layer head, every product with the n_lab rows as one dimension) instead of replaying the fold
+    through torch.autograd.grad (27 launches of ~6 us at the end of every generator step)."""
+    Ws = [W.detach() for W, _ in label_params]
+    bs = [b.detach() for _, b in label_params]
+    n = len(Ws)
+    U, q = [gA], [None]
+    for i in range(1, n):
+        U.append(U[-1] @ Ws[i - 1].t())
+        q.append(bs[i - 1] if q[-1] is None else torch.addmv(bs[i - 1], Ws[i - 1], q[-1]))
+    out = [None] * n
+    S = None                                      # S_{n-1} = identity
+    for i in range(n - 1, -1, -1):
+        if S is None:
+            db = gc
+            dW = U[i] if q[i] is None else torch.addr(U[i], gc, q[i])
+        else:
+            db = S.t() @ gc
+            dW = S.t() @ U[i] if q[i] is None else torch.addmm(torch.outer(db, q[i]), S.t(), U[i])
+        out[i] = (dW, db)
+        if i > 0:
+            S = Ws[i] if S is None else S @ Ws[i]
+    return out
+
+
 def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params):
     """FenerfSirenGrads buffers (dict r) + the channels-last grid gradient chunked_backward accumulated -> gradients in the order of
     `params` (module._render_params()).  d_grid_cl None on a model with a grid: the grid's gradient is delivered elsewhere (split
@@ -40,15 +68,9 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
         grads[id(W)], grads[id(b)] = gw, gb
     sw, sb = roles["sigma"]
     grads[id(sw)], grads[id(sb)] = r["head_w"][n_lab:n_lab + 1], r["head_b"][n_lab:n_lab + 1]
-    if n_lab > 0:      # back through the fold of the activation-free label head (tiny H x H products)
-        with torch.enable_grad():
-            leaves = [(Wi.detach().requires_grad_(True), bi.detach().requires_grad_(True)) for Wi, bi in roles["label"]]
-            A, c = _fold_label_head(leaves)
-            flat = [t for pair in leaves for t in pair]
-            g = torch.autograd.grad([A, c], flat, [r["head_w"][:n_lab], r["head_b"][:n_lab]], allow_unused=True)
-        for (Wi, bi), gw, gb in zip(roles["label"], g[0::2], g[1::2]):
-            grads[id(Wi)] = gw if gw is not None else torch.zeros_like(Wi)
-            grads[id(bi)] = gb if gb is not None else torch.zeros_like(bi)
+    if n_lab > 0:      # back through the fold of the activation-free label head (skinny products: n_lab rows on one side of each)
+        for (Wi, bi), (gw, gb) in zip(roles["label"], _fold_label_head_backward(roles["label"], r["head_w"][:n_lab], r["head_b"][:n_lab])):
+            grads[id(Wi)], grads[id(bi)] = gw, gb
     rw, rb = roles["rgb"]
     grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
     if roles["grid"] is not None and d_grid_cl is not None:

@@ -139,6 +139,19 @@ int fenerf_abi_version(void);
  * weight-gradient kernels do not (1.72 / 1.91 / 1.68 ms: they are HBM-bound), so the two share the chip (profiles/r04_gstep_overlap.md).
  * Workspace sizes (fenerf_siren_grad_workspace_bytes) depend on it: query them under the same setting as the launch. */
 int fenerf_set_cu_budget(int cus);
+/* How the CALLING THREAD's fenerf_render_forward calls run a hierarchical render of a FENERF_PREC_F16X3 model (no reference analogue; the
+ * results are the same bit for bit either way -- both run the same per-tile and per-ray code):
+ *   FENERF_FUSION_AUTO (default)  ONE launch -- per group of rays whose samples fill whole 128-point tile groups (16 rays at N = 24) a
+ *        workgroup evaluates the coarse samples, composites and resamples them, evaluates the fine samples and composites the pixel
+ *        (generators.py:479-519 without leaving the launch) -- when the shape allows it (2 N <= 128, rays per image a multiple of the
+ *        group) and the coarser unit of work does not lengthen the critical path; four launches otherwise;
+ *   FENERF_FUSION_OFF    always the four launches (coarse SIREN, weights + resampling, fine SIREN, merge + composite);
+ *   FENERF_FUSION_FORCE  one launch whenever the shape allows it, balanced or not (tests).
+ * Returns the previous mode. */
+#define FENERF_FUSION_AUTO 0
+#define FENERF_FUSION_OFF 1
+#define FENERF_FUSION_FORCE 2
+int fenerf_set_render_fusion(int mode);
 
 long fenerf_struct_size(const char* struct_name);
 long fenerf_struct_field_offset(const char* struct_name, const char* field);
@@ -290,7 +303,7 @@ double fenerf_siren_executed_flop_per_point(const FenerfModel* m);
  * makes every launch group record a hipEvent pair on its stream (off by default: no events, no cost); fenerf_phase_times
  * synchronises those events, ADDS the elapsed milliseconds / launch-group counts per phase into ms[] / calls[] (n >=
  * FENERF_N_PHASES entries, caller-zeroed) and forgets them.  fenerf_phase_name(i) names phase i ("forward_save", "chain", ...). */
-#define FENERF_N_PHASES 16
+#define FENERF_N_PHASES 17
 int fenerf_phase_timing(int enable);
 int fenerf_phase_times(double* ms, int* calls, int n);
 const char* fenerf_phase_name(int phase);

@@ -786,6 +786,57 @@ def test_one_model_handle_from_two_threads_and_streams():
             assert all(torch.equal(r, ref) for r in results[tid]), (precision, tid)
 
 
+@pytest.mark.parametrize("case", ["tiny_texture_fill_noise", "baseline_lock_view", "h256_bench_shape", "h256_48p48", "cannot_fuse"])
+def test_one_launch_render_equals_the_four_launch_render(case):
+    """fenerf_render_forward on an f16x3 model runs generators.py:479-519 as ONE launch when the shape allows it (ray groups of whole
+    128-point tile groups: coarse tiles -> weights + resampling -> fine tiles -> merge + composite inside the workgroup;
+    fenerf_siren_f16w.hip FUSED, include/fenerf.h fenerf_set_render_fusion).  Both routes run the same per-tile and per-ray code, so
+    every output -- pixels, depth, weights, weights_sum -- must be IDENTICAL bit for bit; the launch-group record says which route ran."""
+    cases = {
+        # kind, H, grid, B, S, N, composite kwargs, noise, lock_view
+        "tiny_texture_fill_noise": ("texture", 32, 8, 2, 8, 6, dict(fill_mode="seg_padding_background", fill_color="black", noise_std=0.3), True, False),
+        "baseline_lock_view": ("baseline", 64, 0, 1, 24, 10, dict(white_back=True), False, True),
+        "h256_bench_shape": ("texture", 256, 96, 1, 128, 24, dict(fill_mode="seg_padding_background", fill_color="black"), False, False),
+        "h256_48p48": ("texture", 256, 96, 1, 64, 48, dict(last_back=True), False, False),
+        "cannot_fuse": ("texture", 32, 8, 1, 10, 6, {}, False, False),          # 100 rays: not a multiple of the 64-ray group of N = 6
+    }
+    kind, H, grid, B, S_, N, okw, with_noise, lock = cases[case]
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8) if grid else proc.model_spec(kind, hidden_dim=H, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=6, sigma_gain=60.0, with_mapping=False)
+    film = proc.film_params(spec, B, seed=6)
+    tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
+    R = S_ * S_
+    torch.manual_seed(12)
+    o, d, z, _, _ = VR.sample_rays(B, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
+    u = torch.rand((B * R, N), device=DEV)
+    nc = torch.randn((B * R, N), device=DEV) if with_noise else None
+    nf = torch.randn((B * R, 2 * N), device=DEV) if with_noise else None
+    opts = _lib.composite_opts("relu", okw.pop("noise_std", 0.0), **okw)
+    nat = native.NativeModel(sd, spec, DEV, "f16x3")
+    outs, routes = {}, {}
+    for mode in ("off", "force", "auto"):
+        with native.render_fusion(mode), native.phase_timing() as t:
+            outs[mode] = nat.render(o, d, z, u, nc, nf, *tf, opts, hierarchical=True, lock_view=lock, want_weights=True, want_wsum=True)
+        routes[mode] = dict(t.calls)
+    assert routes["off"].get("render_fused", 0) == 0 and routes["off"]["siren_forward"] == 2 and routes["off"]["composite"] == 2, routes
+    if case == "cannot_fuse":
+        assert routes["force"] == routes["off"] == routes["auto"], routes
+    else:
+        assert routes["force"] == {"render_fused": 1}, routes
+        # auto: one launch when whole ray groups per workgroup do not lengthen the critical path (the bench shape and 48 + 48) AND the
+        # library was built with the one-launch route enabled for AUTO (it is only where it has been measured to be no slower)
+        assert routes["auto"] in ((({"render_fused": 1},) if case.startswith("h256") else ()) + (routes["off"],)), routes
+    for mode in ("force", "auto"):
+        for name, a, b_ in zip(("pixels", "depth", "weights", "weights_sum"), outs["off"], outs[mode]):
+            assert torch.equal(a, b_), (case, mode, name, float((a - b_).abs().max()))
+    # ... and an f32 model always takes the four launches
+    nat32 = native.NativeModel(sd, spec, DEV, "f32")
+    with native.render_fusion("force"), native.phase_timing() as t:
+        nat32.render(o, d, z, u, nc, nf, *tf, opts, hierarchical=True, lock_view=lock)
+    assert "render_fused" not in t.calls
+    print(f"[parity] one-launch render == four-launch render bit for bit [{case}]: B {B}, {S_}x{S_} rays, {N}+{N} samples; routes {routes}")
+
+
 def test_staged_forward_generator_call_at_configs4_256_48p48():
     """BASELINE.json configs[4] through the public method (generators.py:546-646), not only nat.render: 256x256 rays, 48+48
     samples, psi 0.7, the whole image as one fused render (max_batch_size ignored by design)."""

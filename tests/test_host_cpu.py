@@ -512,6 +512,28 @@ def test_backward_chunk_plan_and_grid_digest():
     assert native.NativeModel._grid_checksum(odd).shape == (45,)
 
 
+@pytest.mark.parametrize("n_layers", [1, 2, 3, 4])
+def test_label_head_fold_backward_is_the_gradient_of_the_fold(n_layers):
+    """The label head (activation-free Linear stack, siren.py label_layer_linear; reference siren.py:1000-1012) is folded into one
+    [n_lab, H] map before the kernels see it; its parameter gradients come back through written-out formulas, not through autograd.
+    They are the gradient of the fold: fp64 against torch.autograd.grad, every depth the reference configures (2 and 3) and the ends."""
+    from fenerf_amd.siren import autograd as SA
+    g = torch.Generator().manual_seed(10 + n_layers)
+    H, n = 24, 7
+    dims = [(H, H)] * (n_layers - 1) + [(n, H)]
+    params = [(torch.randn(o, i, dtype=torch.float64, generator=g).requires_grad_(True),
+               torch.randn(o, dtype=torch.float64, generator=g).requires_grad_(True)) for o, i in dims]
+    A, c = SA._fold_label_head(params)
+    gA, gc = torch.randn(n, H, dtype=torch.float64, generator=g), torch.randn(n, dtype=torch.float64, generator=g)
+    ref = torch.autograd.grad([A, c], [t for pair in params for t in pair], [gA, gc], allow_unused=True)
+    got = SA._fold_label_head_backward(params, gA, gc)
+    assert len(got) == n_layers
+    for k, (dW, db) in enumerate(got):
+        assert dW.shape == params[k][0].shape and db.shape == params[k][1].shape
+        np.testing.assert_allclose(dW.numpy(), ref[2 * k].numpy(), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(db.numpy(), ref[2 * k + 1].numpy(), rtol=1e-12, atol=1e-12)
+
+
 def test_film_params_beyond_the_init_range_are_what_the_fixtures_record():
     """procedural.film_params(phase_rev, freq0_gain): defaults unchanged bit for bit (every earlier fixture depends on them); the
     extensions add uniform phase shifts of +-phase_rev revolutions and scale the first layer's effective frequency 15 f + 30."""

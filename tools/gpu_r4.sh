@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [ddp] [cuscale] [probe]'
+# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [fusion] [fusionexp] [ddp] [cuscale] [probe]'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -86,6 +86,20 @@ ddptl)      # kernel timeline of a DDP generator step (world 1): reference wrapp
   done ;;
 probe)      # what v_sin_f32 / v_cos_f32 return for arguments of growing magnitude on this chip
   ./tools/probe/sin_domain_probe > gpurun_out/vsin_domain_probe.txt 2>&1; cat gpurun_out/vsin_domain_probe.txt ;;
+fusion)      # one-launch render: the bit-for-bit test against the four launches, then the A/B (bench shape, 256^2 x 48+48, 4 x 64^2 x 24+24)
+  timeout 900 python -m pytest tests -m gpu -q -s -k "one_launch_render or two_threads or e2e or staged_forward" --maxfail=5 > gpurun_out/fusion_tests.log 2>&1
+  grep -E "passed|failed|^E  |FAILED|one-launch" gpurun_out/fusion_tests.log | tail -30
+  timeout 300 python tools/render_fusion_ab.py > gpurun_out/fusion_ab.log 2>&1; tail -n 2 gpurun_out/fusion_ab.log
+  timeout 300 python tools/render_fusion_ab.py --size 256 --steps 48 --iters 10 >> gpurun_out/fusion_ab.log 2>&1; tail -n 1 gpurun_out/fusion_ab.log
+  timeout 300 python tools/render_fusion_ab.py --B 4 --size 64 --steps 24 --iters 40 >> gpurun_out/fusion_ab.log 2>&1; tail -n 1 gpurun_out/fusion_ab.log ;;
+fusionexp)   # where the one-launch render spends its extra time: tools/exp/fused_ray_phase.sh variants (barriers only / no ray phase)
+  for v in "" RAY1 RAY0 RAY3 M64; do
+    lib=$PWD/fenerf_amd/libfenerf_hip.so; [ -n "$v" ] && lib=$PWD/fenerf_amd/libexp_$v.so
+    [ -f $lib ] || continue
+    echo -n "variant ${v:-shipped}: "; FENERF_LIB=$lib timeout 200 python tools/render_fusion_ab.py --rounds 3 --modes off,force 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.readlines()[-1]); print(j['ms_per_render'], j['launch_groups_of_one_render']['force']['ms'])"
+  done 2>&1 | tee gpurun_out/fusionexp.log ;;
 gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
   rm -rf gpurun_out/gtl; mkdir -p gpurun_out/gtl
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtl -o gtl -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 1 --size 128 --skip-eager --iters 4 ${GTL_ARGS:-}) > gpurun_out/gtl/run.log 2>&1
