@@ -140,13 +140,15 @@ int fenerf_abi_version(void);
  * Workspace sizes (fenerf_siren_grad_workspace_bytes) depend on it: query them under the same setting as the launch. */
 int fenerf_set_cu_budget(int cus);
 /* How the CALLING THREAD's fenerf_render_forward calls run a hierarchical render of a FENERF_PREC_F16X3 model (no reference analogue; the
- * results are the same bit for bit either way -- both run the same per-tile and per-ray code):
- *   FENERF_FUSION_AUTO (default)  ONE launch -- per group of rays whose samples fill whole 128-point tile groups (16 rays at N = 24) a
- *        workgroup evaluates the coarse samples, composites and resamples them, evaluates the fine samples and composites the pixel
- *        (generators.py:479-519 without leaving the launch) -- when the shape allows it (2 N <= 128, rays per image a multiple of the
- *        group) and the coarser unit of work does not lengthen the critical path; four launches otherwise;
- *   FENERF_FUSION_OFF    always the four launches (coarse SIREN, weights + resampling, fine SIREN, merge + composite);
- *   FENERF_FUSION_FORCE  one launch whenever the shape allows it, balanced or not (tests).
+ * results are the same bit for bit either way -- both routes run the same per-tile and per-ray code):
+ *   FENERF_FUSION_OFF    four launches: coarse SIREN, weights + resampling, fine SIREN, merge + composite;
+ *   FENERF_FUSION_FORCE  ONE launch whenever the shape allows it (2 N <= 128, rays per image a multiple of the ray group): per group of
+ *        rays whose samples fill whole 128-point tile groups (16 rays at N = 24) a workgroup evaluates the coarse samples, composites and
+ *        resamples them, evaluates the fine samples and composites the pixels -- generators.py:479-519 without leaving the launch;
+ *   FENERF_FUSION_AUTO (default)  the faster of the two as measured on MI355X: the one launch where the shape allows it, whole ray groups
+ *        per workgroup do not lengthen the critical path AND the library was built with it enabled for AUTO -- which it is not: the
+ *        one launch is 6 % slower (profiles/r04_render_one_launch.md: its ray phases run at 8 waves per CU with the matrix pipe idle),
+ *        so AUTO currently means the four launches.
  * Returns the previous mode. */
 #define FENERF_FUSION_AUTO 0
 #define FENERF_FUSION_OFF 1
