@@ -604,6 +604,21 @@ def main(argv=None):
                 del nat32
             except Exception as e:
                 out["f32"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.precision == "f16x3":
+            # the same render as ONE launch (include/fenerf.h fenerf_set_render_fusion): reported beside the headline,
+            # which takes the faster four-launch route
+            try:
+                with native.render_fusion("force"):
+                    odt, _, _ = timed_render(nat, B, S, N, args.steps, args.warmup, 1000)
+                    with native.phase_timing() as one1:
+                        rgb1 = nat.render(o_, d_, z_, torch.ones((B * R, N), device=dev) * 0.5, None, None, *tf_, opts, hierarchical=True)[0]
+                rgb4 = nat.render(o_, d_, z_, torch.ones((B * R, N), device=dev) * 0.5, None, None, *tf_, opts, hierarchical=True)[0]
+                out["render_one_launch"] = {"value": B * R * args.steps / odt, "unit": "rays/s", "ms_per_step": odt / args.steps * 1e3,
+                                            "launches_per_step": sum(one1.calls.values()), "launch_groups": dict(one1.calls),
+                                            "bit_identical_to_the_four_launch_render": bool(torch.equal(rgb1, rgb4)),
+                                            "vs_headline": (B * R * args.steps / odt) / value * world}
+            except Exception as e:
+                out["render_one_launch"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_gstep:
             try:
                 out["gstep"] = gstep_leg(spec, sd, dev, B, S, N, args.precision)

@@ -214,12 +214,15 @@ int launch_composite_backward(const CompositeParams& p, bool merge, void* stream
   if (p.BR <= 0) return FENERF_OK;
   long long blocks = (p.BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  const bool big = p.M > 256;
+  // the smallest MAXM that holds the ray (a skipped slot contributes exact zeros: the result does not depend on it; fewer registers + LDS)
+  const bool big = p.M > 256, small = p.M <= 128;
   if (merge) {
     if (big) hipLaunchKernelGGL((composite_backward_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (small) hipLaunchKernelGGL((composite_backward_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((composite_backward_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   } else {
     if (big) hipLaunchKernelGGL((composite_backward_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (small) hipLaunchKernelGGL((composite_backward_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((composite_backward_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   }
   hipError_t e = hipGetLastError();
@@ -376,12 +379,14 @@ int launch_composite(const CompositeParams& p, bool merge, void* stream) {
   if (p.BR <= 0) return FENERF_OK;
   long long blocks = (p.BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  const bool big = p.M > 256;
+  const bool big = p.M > 256, small = p.M <= 128;   // smallest MAXM that holds the ray (same results: fenerf_composite_ray.h)
   if (merge) {
     if (big) hipLaunchKernelGGL((composite_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (small) hipLaunchKernelGGL((composite_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((composite_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   } else {
     if (big) hipLaunchKernelGGL((composite_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (small) hipLaunchKernelGGL((composite_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((composite_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   }
   hipError_t e = hipGetLastError();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [fusion] [fusionexp] [ddp] [cuscale] [probe]'
+# Round-4 GPU sessions.  usage: gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh [tests] [newtests] [sine] [trigab] [bench] [benchq] [prof] [pmc] [gtimeline] [fusion] [fusionexp] [fusionprof] [ddp] [cuscale] [probe]'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -100,6 +100,11 @@ fusionexp)   # where the one-launch render spends its extra time: tools/exp/fuse
 import sys, json
 j = json.loads(sys.stdin.readlines()[-1]); print(j['ms_per_render'], j['launch_groups_of_one_render']['force']['ms'])"
   done 2>&1 | tee gpurun_out/fusionexp.log ;;
+fusionprof)  # rocprofv3 kernel trace of the one-launch route: one kernel per render
+  rm -rf gpurun_out/fprof; mkdir -p gpurun_out/fprof
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/fprof -o fprof -- python $GRAFT_REPO_ROOT/tools/render_fusion_ab.py --rounds 2 --iters 20 --modes force) > gpurun_out/fprof/run.log 2>&1
+  find gpurun_out/fprof -name "*kernel_stats.csv" | head -1 | xargs -r head -8
+  find gpurun_out/fprof -type f -size +2M -delete ;;
 gtimeline)   # per-launch timeline of one generator step (kernel trace only, no counters)
   rm -rf gpurun_out/gtl; mkdir -p gpurun_out/gtl
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtl -o gtl -- python $GRAFT_REPO_ROOT/tools/bench_gstep.py --B 1 --size 128 --skip-eager --iters 4 ${GTL_ARGS:-}) > gpurun_out/gtl/run.log 2>&1
