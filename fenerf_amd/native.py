@@ -696,7 +696,7 @@ def forward_kernel_name(nat):
     H, g = nat.spec["hidden_dim"], "true" if nat.spec["grid_ch"] else "false"
     if nat.precision == "f32":
         return f"siren_kernel<{H},{g},false>"
-    return f"siren16w_kernel<{H},{g}>"
+    return f"siren16w_kernel<{H},{g},false,false>"      # <H, GRID, SAVE (tape), FUSED (one-launch render)>
 
 
 # ----------------------------------------------------------------------
