@@ -534,6 +534,30 @@ def test_label_head_fold_backward_is_the_gradient_of_the_fold(n_layers):
         np.testing.assert_allclose(db.numpy(), ref[2 * k + 1].numpy(), rtol=1e-12, atol=1e-12)
 
 
+def test_render_fusion_mode_is_per_thread_and_sanitised():
+    """include/fenerf.h fenerf_set_render_fusion: returns the previous mode of the CALLING THREAD, unknown values mean AUTO, another thread
+    keeps its own setting (no GPU needed: it only selects how later fenerf_render_forward calls are launched)."""
+    import threading
+    from fenerf_amd import native
+    l = _lib.lib()
+    prev = l.fenerf_set_render_fusion(_lib.FUSION_FORCE)
+    try:
+        assert prev == _lib.FUSION_AUTO
+        assert l.fenerf_set_render_fusion(_lib.FUSION_OFF) == _lib.FUSION_FORCE
+        assert l.fenerf_set_render_fusion(99) == _lib.FUSION_OFF            # 99 -> AUTO
+        assert l.fenerf_set_render_fusion(_lib.FUSION_FORCE) == _lib.FUSION_AUTO
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(l.fenerf_set_render_fusion(_lib.FUSION_OFF)))
+        t.start(); t.join()
+        assert seen == [_lib.FUSION_AUTO]                                    # the other thread started at the default ...
+        assert l.fenerf_set_render_fusion(_lib.FUSION_FORCE) == _lib.FUSION_FORCE   # ... and did not touch this one
+        with native.render_fusion("off"):
+            assert l.fenerf_set_render_fusion(_lib.FUSION_OFF) == _lib.FUSION_OFF
+        assert l.fenerf_set_render_fusion(_lib.FUSION_FORCE) == _lib.FUSION_FORCE   # restored by the context manager
+    finally:
+        l.fenerf_set_render_fusion(prev)
+
+
 def test_film_params_beyond_the_init_range_are_what_the_fixtures_record():
     """procedural.film_params(phase_rev, freq0_gain): defaults unchanged bit for bit (every earlier fixture depends on them); the
     extensions add uniform phase shifts of +-phase_rev revolutions and scale the first layer's effective frequency 15 f + 30."""
