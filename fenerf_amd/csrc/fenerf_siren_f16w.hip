@@ -26,6 +26,13 @@
 //   so lane group g ends n-block nb holding, in acc[rt][r], feature 32 nb + 16 (g >> 1) + 4 (g & 1) + 8 rt + r -- exactly the
 //   features feat16_of(2 nb + (g >> 1), g & 1, 4 rt + r) the packer put into lane group g's k slots of k32-step nb: the
 //   accumulators, FiLM'ed and split, ARE the next layer's B operand {acc[0][0..3], acc[1][0..3]}.
+//
+// Three uses of one kernel template, siren16w_kernel<H, GRID, SAVE, FUSED>:
+//   <.., false, false>  the no-grad forward of fenerf_siren_forward / the two SIREN launches of fenerf_render_forward;
+//   <.., true,  false>  forward-save (fenerf_siren_forward_save): the same tiles, every FiLM layer's accumulators also leave as the tape;
+//   <.., false, true >  the whole hierarchical render in ONE launch (round 4, fenerf_set_render_fusion): ray groups of whole octs, the
+//                       rays composited by the workgroup's own waves between its coarse and fine tiles -- see FuseArgs below and
+//                       profiles/r04_render_one_launch.md for why it is selectable and not the default (6 % slower).
 #include <hip/hip_runtime.h>
 
 #include "fenerf_composite_ray.h"
