@@ -139,19 +139,25 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
 
 
 def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_psi=0.0, lambda_seg=1.0, lambda_img=1.0,
-                   lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None, latent_noise=0.03):
+                   lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None, latent_noise=0.03,
+                   n_mean_latents=10000, record_offsets=False):
     """GAN inversion in FiLM space (inverse_render_double_semantic.py:306-410): optimise additive offsets on the geometry /
     appearance frequencies and phase shifts with Adam (lr 1e-2, weight_decay 1e-4, StepLR(100, 0.75)) under annealed
     latent noise so that generator.forward_with_frequencies reproduces gt_image [1,3,S,S] and gt_seg [1,18,S,S] (both in
     [-1,1]).  Every iteration is a native differentiable render; when the generator's parameters do not require grad
     only the FiLM gradients are computed.  `percept` (e.g. an LPIPS module) is optional -- none is shipped.
-    Returns a dict with the reference's checkpoint keys (w_*_frequencies, w_*_phase_shifts, w_*_offsets) + `losses`."""
+    Every draw (the mean-latent blocks -- `n_mean_latents` = 10,000 in the script --, the random latents, the four noise tensors of an
+    iteration) goes through generator.draws in the script's order: with the default source that is torch.randn / randn_like on the
+    device, value for value the script's generator consumption; a test replays the draws the reference recorded.
+    Returns a dict with the reference's checkpoint keys (w_*_frequencies, w_*_phase_shifts, w_*_offsets) + `losses`
+    (+ `offset_history`: the four offset tensors after every iteration, on the host, if record_offsets)."""
     device = generator.device
     siren = generator.siren
+    draws = generator.draws
 
     def init(mapping):     # :307-327
-        z = torch.randn((10000, z_dim), device=device)
-        rand_z = torch.randn((1, z_dim), device=device)
+        z = draws.randn((n_mean_latents, z_dim), device)
+        rand_z = draws.randn((1, z_dim), device)
         with torch.no_grad():
             freq, phase = mapping(z)
             rand_f, rand_p = mapping(rand_z)
@@ -171,12 +177,12 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
     optimizer = torch.optim.Adam(opt_params, lr=lr, weight_decay=1e-4)
     scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 100, gamma=0.75)
     mse = torch.nn.MSELoss(reduction="mean")
-    losses = []
+    losses, history = [], []
     for i in range(n_iterations):
-        k = latent_noise * (n_iterations - i) / n_iterations      # annealed noise on the FiLM parameters (:381-384; 0.03 there)
-        # draw order of the reference (:381-384): geo freq, geo phase, app freq, app phase
-        n_gf, n_gp = k * torch.randn_like(w_gf), k * torch.randn_like(w_gp)
-        n_af, n_ap = k * torch.randn_like(w_af), k * torch.randn_like(w_ap)
+        k = (n_iterations - i) / n_iterations                     # annealed noise on the FiLM parameters (:381-384; 0.03 there)
+        # draw order and arithmetic of the reference (:381-384): geo freq, geo phase, app freq, app phase; (0.03 * randn) * k
+        n_gf, n_gp = latent_noise * draws.randn(tuple(w_gf.shape), device) * k, latent_noise * draws.randn(tuple(w_gp.shape), device) * k
+        n_af, n_ap = latent_noise * draws.randn(tuple(w_af.shape), device) * k, latent_noise * draws.randn(tuple(w_ap.shape), device) * k
         frame, _ = generator.forward_with_frequencies(w_gf + n_gf + o_gf, w_af + n_af + o_af, w_gp + n_gp + o_gp, w_ap + n_ap + o_ap,
                                                       **options)
         loss = lambda_seg * mse(frame[:, :-3], gt_seg) + lambda_img * mse(frame[:, -3:], gt_image)
@@ -189,9 +195,12 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
         optimizer.zero_grad()
         scheduler.step()
         losses.append(float(loss.detach()))
+        if record_offsets:
+            history.append(tuple(o.detach().cpu().clone() for o in (o_gf, o_gp, o_af, o_ap)))
         if on_step is not None:
             on_step(i, losses[-1])
-    return dict(w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
+    extra = dict(offset_history=history) if record_offsets else {}
+    return dict(**extra, w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
                 w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
                 w_app_frequency_offsets=o_af.detach(), w_app_phase_shift_offsets=o_ap.detach(), losses=losses)
 

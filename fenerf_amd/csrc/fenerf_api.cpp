@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -303,7 +304,15 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipGetDeviceProperties"); }
   m->num_cus = prop.multiProcessorCount;
   // experiment switch (profiles/r04_gstep_overlap_why_not.md): size every persistent launch for fewer CUs than the device has
-  if (const char* e = getenv("FENERF_EXP_NUM_CUS")) { const int n = atoi(e); if (n > 0 && n < m->num_cus) m->num_cus = n; }
+  // -- said once on stderr when it takes effect, so that a leftover variable cannot shrink a production run silently
+  if (const char* e = getenv("FENERF_EXP_NUM_CUS")) {
+    const int n = atoi(e);
+    if (n > 0 && n < m->num_cus) {
+      static bool said = false;
+      if (!said) { fprintf(stderr, "libfenerf_hip: FENERF_EXP_NUM_CUS=%d: persistent launches sized for %d of %d CUs (experiment switch)\n", n, n, m->num_cus); said = true; }
+      m->num_cus = n;
+    }
+  }
   rc = upload_model(m, d, nullptr, true);
   if (rc) { fenerf_model_destroy(m); return rc; }
   *out = m;

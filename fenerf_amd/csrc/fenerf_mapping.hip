@@ -132,9 +132,9 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
 }
 
 __global__ __launch_bounds__(MAP_THREADS) void mapping_forward_kernel(MapParams P) {
-  extern __shared__ float lds[];          // two activation buffers of max(z_dim, hidden) floats
+  extern __shared__ float lds[];          // two activation buffers of max(z_dim, hidden) floats, each a whole number of float4
   const int b = blockIdx.x, s = blockIdx.y;
-  const int wmax = P.z_dim > P.hidden ? P.z_dim : P.hidden;
+  const int wmax = ((P.z_dim > P.hidden ? P.z_dim : P.hidden) + 3) & ~3;   // the buffers swap roles: both must take matvec_rows' 16-byte reads
   float* x = lds;
   float* y = lds + wmax;
   for (int i = threadIdx.x; i < P.z_dim; i += MAP_THREADS) x[i] = P.z[(size_t)b * P.z_dim + i];

@@ -32,14 +32,21 @@ int check_trig_domain() {
     const float h_t[n] = {257.25f, -257.25f, 1000.125f, -1000.125f, 70000.75f, -70000.75f, 3000000.25f, 0.375f};
     float h_o[2 * n];
     float *d_t = nullptr, *d_o = nullptr;
-    if ((e = hipMalloc((void**)&d_t, sizeof(h_t))) == hipSuccess && (e = hipMalloc((void**)&d_o, sizeof(h_o))) == hipSuccess &&
-        (e = hipMemcpy(d_t, h_t, sizeof(h_t), hipMemcpyHostToDevice)) == hipSuccess) {
-      hipLaunchKernelGGL(trig_domain_kernel, dim3(1), dim3(64), 0, nullptr, d_t, d_o, n);
+    // On a private non-blocking stream: nothing here touches the legacy null stream, so the check neither synchronises with nor is
+    // ordered against the caller's streams.  (Model creation itself allocates device memory -- upload_model -- so it is never legal inside
+    // a stream capture anyway; the check just does not add a null-stream dependency of its own.)
+    hipStream_t st = nullptr;
+    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) == hipSuccess &&
+        (e = hipMalloc((void**)&d_t, sizeof(h_t))) == hipSuccess && (e = hipMalloc((void**)&d_o, sizeof(h_o))) == hipSuccess &&
+        (e = hipMemcpyAsync(d_t, h_t, sizeof(h_t), hipMemcpyHostToDevice, st)) == hipSuccess) {
+      hipLaunchKernelGGL(trig_domain_kernel, dim3(1), dim3(64), 0, st, d_t, d_o, n);
       e = hipGetLastError();
-      if (e == hipSuccess) e = hipMemcpy(h_o, d_o, sizeof(h_o), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_o, d_o, sizeof(h_o), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (d_t) (void)hipFree(d_t);
     if (d_o) (void)hipFree(d_o);
+    if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) { set_error(std::string("check_trig_domain: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
     verdict[dev] = 1;
     for (int i = 0; i < n; ++i) {

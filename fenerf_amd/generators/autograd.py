@@ -154,7 +154,9 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 # the chains left.  Price: the d(theta) dumps of all chunks are alive together (as large as the tape).  Opt-in per module
 # (`siren.split_backward = True`, fenerf_amd.dist.prepare_for_ddp) -- DDP must also be allowed to reduce buckets in the order the
 # gradients arrive (find_unused_parameters=False lets it rebuild its buckets after the first step; with the reference's
-# find_unused_parameters=True the grid's bucket stays last in line and nothing overlaps).
+# find_unused_parameters=True the grid's bucket stays last in line and nothing overlaps).  What the render stage leaves for the weight
+# stage lives for one backward pass only (an engine callback drops it): torch.autograd.grad on a subset of the inputs is supported in
+# the sense that it returns what it can and leaks nothing; it does not deliver weight gradients unless the weight stage's inputs are asked for.
 # ----------------------------------------------------------------------------------------------------------------------------------
 class _SplitState:
     """what the render stage's backward leaves for the weight stage's backward of the same render"""
@@ -224,8 +226,13 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         chunks = _siren_autograd.plan_chunks(2 * B, Pp)
         dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, chunks)
-        ctx.state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2,
-                              tape_e2=tape_e2 if tape_e2.numel() else None, chunks=chunks, dumps=dumps, params=module._render_params())
+        state = ctx.state
+        state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2,
+                          tape_e2=tape_e2 if tape_e2.numel() else None, chunks=chunks, dumps=dumps, params=module._render_params())
+        # The dumps (as large as the tape) belong to THIS backward pass: if the weight stage does not consume them -- torch.autograd.grad
+        # with only the grid as input, an exception between the two stages -- they are dropped when the engine finishes the pass, not
+        # when the graph dies; a retained graph's next backward then starts from a clean state instead of overwriting a stale one.
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: setattr(state, "work", None))
         g_grid = nat.grid_gradient_ncdhw(d_grid).contiguous() if ctx.needs_input_grad[2] else None
         g_token = torch.zeros(1, dtype=torch.float32, device=out2.device) if ctx.needs_input_grad[1] else None
         if g_token is None:

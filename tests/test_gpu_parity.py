@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import film_from_golden, kwargs_from_golden, load_golden, spec_from_golden
+from conftest import film_from_golden, kwargs_from_golden, load_golden, spec_from_golden, state_from_golden, weights_from_golden
 from fenerf_amd import _lib, native, procedural as proc
 from fenerf_amd.generators import generators as G
 from fenerf_amd.generators import volumetric_rendering as VR
@@ -42,7 +42,7 @@ PRECISIONS = ["f32", "f16x3"]   # exact fp32 MFMA / error-compensated fp16 MFMA 
 def _weights_for(name):
     g = load_golden(name)
     spec = spec_from_golden(g)
-    return spec, proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]), with_mapping=False)
+    return spec, weights_from_golden(g, spec, with_mapping=False)
 
 
 @functools.lru_cache(maxsize=None)
@@ -77,7 +77,7 @@ def test_native_library_is_loaded():
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n12",
-                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained"])
 def test_siren_forward_vs_reference(name, precision):
     g = load_golden(name)
     nat, spec, sd = _native_for(name, precision)
@@ -89,18 +89,21 @@ def test_siren_forward_vs_reference(name, precision):
     out = N_(nat.siren_forward(T(pts), T(dirs), *tf))
     ref = g["st_siren_coarse"]
     _report(name + " coarse vs reference", out, ref)
-    gain = max(1.0, float(g["meta_sigma_gain"]))
-    np.testing.assert_allclose(out[..., -4:-1], ref[..., -4:-1], atol=1e-4)
-    np.testing.assert_allclose(out[..., :-4], ref[..., :-4], atol=1e-4, rtol=1e-4)
-    np.testing.assert_allclose(out[..., -1], ref[..., -1], atol=2e-4 * gain / 10 + 1e-4, rtol=2e-4)
-    # fine points (explicit) too, and the fp64 oracle as a tighter arbiter on rgb
+    # Bounds = what is measured x 1.5 (round 5; round 4 asserted 1e-4 on rgb / labels against a measured 5e-7 / 6e-8): rgb <= 5.4e-7,
+    # labels <= 6.0e-8, sigma <= 7.2e-6 x the fixture's largest |sigma| -- over all fixtures, both precisions, coarse and fine points.
+    def close(got, want, tag):
+        smax = float(np.abs(want[..., -1]).max())
+        e_rgb, e_lab, e_sig = (float(np.abs(got[..., sl] - want[..., sl]).max()) for sl in (slice(-4, -1), slice(None, -4), slice(-1, None)))
+        assert e_rgb <= 8.5e-7 and e_lab <= 9e-8 and e_sig <= 1.1e-5 * max(smax, 0.1), (tag, e_rgb, e_lab, e_sig, smax)
+    close(out, ref, "coarse")
+    # fine points (explicit) too, and the fp64 oracle as a tighter arbiter
     fo = N_(nat.siren_forward(T(g["st_fine_points"]), T(dirs), *tf))
     _report(name + " fine vs reference", fo, g["st_siren_fine"])
-    np.testing.assert_allclose(fo[..., -4:-1], g["st_siren_fine"][..., -4:-1], atol=1e-4)
+    close(fo, g["st_siren_fine"], "fine")
     o64 = O.siren_forward(sd, spec, pts[:, :512], dirs[:, :512], film["freq_geo"], film["phase_geo"], film["freq_app"],
                           film["phase_app"], dtype=np.float64)
     _report(name + " vs fp64 oracle", out[:, :512], o64)
-    np.testing.assert_allclose(out[:, :512, -4:-1], o64[..., -4:-1], atol=5e-5)
+    close(out[:, :512], o64, "fp64")      # measured: rgb <= 4.5e-7, labels <= 5.5e-8, sigma <= 5.1e-6 x |sigma|max
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -285,7 +288,7 @@ def test_more_than_128_samples_per_pass(N):
     assert err <= 1e-3 and np.abs(N_(depth) - r_depth[..., 0]).max() <= 1e-3
 
 
-@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n24_trained"])
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n24_trained", "tiny_texture_fwd_trained"])
 def test_merge_composite_vs_reference(name):
     g = load_golden(name)
     B, R, N = g["st_z_coarse"].shape[:3]
@@ -310,6 +313,9 @@ def _make_generator(g, spec, precision="f32"):
     gen = G.DoubleImplicitGenerator3d(functools.partial(cls, hidden_dim=H), spec.get("z_dim", 256), spec.get("z_dim", 256), 22)
     sd = proc.make_state_dict(dict(spec, z_dim=spec.get("z_dim", 256), map_hidden=256), seed=int(g["meta_seed"]) if "meta_seed" in g else 3,
                               sigma_gain=float(g["meta_sigma_gain"]) if "meta_sigma_gain" in g else 300.0)
+    st = state_from_golden(g)
+    if st is not None:      # a state the reference's own Adam run produced (round 5): its render weights replace the procedural ones
+        sd.update(st[0])
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     if "spatial_embeddings" in tsd:
         gen.siren.spatial_embeddings = torch.nn.Parameter(tsd["spatial_embeddings"].clone())
@@ -319,6 +325,14 @@ def _make_generator(g, spec, precision="f32"):
     gen.device = torch.device(DEV)
     gen.siren.device = gen.device
     return gen
+
+
+# max |pixel error| of the end-to-end fixtures as measured in round 4 (both precisions, every box: the library is deterministic) -- the
+# asserted bound is 1.5 x this, on top of north_star's 1e-3 (h256_texture_16x16_n24_trained is the closest to the bar: fp32 re-association at
+# a synthetic |sigma| ~ 200 density scale, identical in the exact-fp32 kernel).  A fixture not listed asserts the bar alone.
+E2E_MEASURED = {"tiny_texture_fwd": 1.7e-6, "tiny_texture_fwd_nohier": 3.1e-6, "tiny_baseline_fwd": 1e-6, "h256_texture_16x16_n12": 2.0e-5,
+                "h256_texture_16x16_n24_trained": 6.6e-4, "h256_baseline_8x8_n12": 1.2e-4, "tiny_texture_staged": 1.7e-6,
+                "tiny_texture_staged_lock": 9e-7, "forward(z)": 3.1e-5, "staged_forward(z, psi=0.7)": 1.4e-6}
 
 
 def _e2e_check(tag, px, ref_px, tol=1e-3, max_flips=0):
@@ -336,17 +350,20 @@ def _e2e_check(tag, px, ref_px, tol=1e-3, max_flips=0):
           f"more than {tol} (fill-threshold / resampling flips; allowed {max_flips}); label argmax mismatches on the other pixels: "
           f"{int(mism.sum())} (reference ties: {int(tie.sum())})")
     assert int(bad.sum()) <= max_flips, f"{int(bad.sum())} pixels off by more than {tol}, worst {err.max():.3e}"
+    measured = E2E_MEASURED.get(tag.split("[")[0])
+    if measured is not None and max_flips == 0:
+        assert err.max() <= min(tol, 1.5 * measured), f"{tag}: worst pixel {err.max():.3e}, measured {measured:.1e} in round 4"
     assert not (mism & ~tie).any(), "exact argmax semantics on every pixel the reference itself decides"
     return bad
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "h256_texture_16x16_n12",
-                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12"])
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained"])
 def test_forward_with_frequencies_vs_reference(name, precision):
     g = load_golden(name)
     spec = spec_from_golden(g)
-    gen = _make_generator(g, dict(spec, z_dim=16 if spec["hidden_dim"] == 32 else 256), precision)
+    gen = _make_generator(g, dict(spec, z_dim=spec.get("z_dim", 16) if spec["hidden_dim"] == 32 else 256), precision)
     name = f"{name}[{precision}]"
     film, tf = _film(g, spec)
     hier = bool(g["meta_hier"])
@@ -471,13 +488,16 @@ def _oracle_render_rays(sd, spec, args, oo, dd, zz, uu, fill_color, hier=True, s
     return px, dp, zs
 
 
-def _check_render_vs_oracle(tag, nat, rays, tf, opts, rgb, depth, r_rgb, r_depth, r_z, hier=True, max_over=2, over_bound=2e-3):
+def _check_render_vs_oracle(tag, nat, rays, tf, opts, rgb, depth, r_rgb, r_depth, r_z, hier=True, max_over=0, over_bound=1e-3, depth_bound=2e-3):
     """north_star's bar on a full render against the oracle, asserted as measured.  A ray is a RESAMPLING FLIP when the native
     pipeline and the oracle put a fine sample into different bins of the inverse-CDF (u within fp32 rounding of a knot; on background
     rays, whose coarse weights are ~1e-7 + the 1e-5 floor, the whole cdf moves with the rounding of those weights): both are valid
     evaluations of the same algorithm, the composited depths then differ by up to a bin while the pixel hardly moves.
-      * pixels: at most `max_over` rays beyond 1e-3, none beyond `over_bound` (measured: f32 0, f16x3 1 ray at 1.3e-3 of 16,384);
-      * depth: <= 5e-4 on every ray with identical resampling;
+      * pixels: at most `max_over` rays beyond 1e-3, none beyond `over_bound`;
+      * depth: <= `depth_bound` on every ray with identical resampling;
+        -- every call site passes its own (max_over, over_bound, depth_bound) = what was measured for that shape and precision x 1.5
+        (round 5; the library is deterministic, so the same build measures the same numbers on every box: round 4's common 2 rays /
+        2e-3 / 2e-3 would have let a 2 - 100 x regression through);
       * label argmax identical on every ray with identical resampling whose two best oracle logits are not tied."""
     import __graft_entry__ as ge
     o, d, z, u = rays
@@ -504,7 +524,7 @@ def _check_render_vs_oracle(tag, nat, rays, tf, opts, rgb, depth, r_rgb, r_depth
           f"resampling flips); {int(flip.sum())} rays resample differently (their max pixel error {err[flip].max() if flip.any() else 0:.3e}, "
           f"depth error {derr[flip].max() if flip.any() else 0:.3e}); depth max|err| elsewhere {derr[~flip].max():.3e}")
     assert int(over.sum()) <= max_over and err.max() <= over_bound, f"{int(over.sum())} rays off by more than 1e-3 (worst {err.max():.3e})"
-    assert derr[~flip].max() <= 2e-3          # (depth is not part of north_star's bar; measured 9e-4 at |sigma| ~ 2000)
+    assert derr[~flip].max() <= depth_bound, f"depth off by {derr[~flip].max():.3e} on a ray with identical resampling (bound {depth_bound:.1e})"   # (depth is not part of north_star's bar)
     lab, r_lab = rgb[..., 1:-3], r_rgb[..., 1:-3]
     top2 = np.sort(r_lab, axis=-1)
     decided = ((top2[..., -1] - top2[..., -2]) > 1e-6) & ~flip & (r_rgb[..., 0] != 1)
@@ -544,31 +564,40 @@ def test_full_size_128_24p24_properties_and_oracle_all_rays(precision):
     # merge -> composite), in slabs of 2,048 rays to bound the numpy activations; ~10 s on the GPU box's host cores
     args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
     r_rgb, r_depth, r_z = _oracle_render_rays(sd, spec, args, N_(o), N_(d), N_(z), N_(u), "white")
-    _check_render_vs_oracle(f"128x128 24+24 H=256 [{precision}] vs oracle on ALL {R} rays", nat, (o, d, z, u), tf, opts, rgb, depth, r_rgb, r_depth, r_z)
+    # measured (round 4, every box): f32 max 5.60e-4, 0 rays > 1e-3, depth 1.73e-3; f16x3 ONE ray at 1.309e-3 (a resampling flip: the fp64
+    # arbiter below), depth 9.04e-4
+    bounds = dict(f32=dict(max_over=0, over_bound=8.5e-4, depth_bound=2.6e-3), f16x3=dict(max_over=1, over_bound=2.0e-3, depth_bound=1.4e-3))[precision]
+    _check_render_vs_oracle(f"128x128 24+24 H=256 [{precision}] vs oracle on ALL {R} rays", nat, (o, d, z, u), tf, opts, rgb, depth, r_rgb, r_depth, r_z,
+                            **bounds)
 
 
-def test_resampling_flips_against_an_fp64_arbiter():
-    """DESIGN.md 2 says of a ray whose fine samples land in other bins than the fp32 oracle's: "both are valid evaluations of the same
+@pytest.mark.parametrize("S_,N", [(128, 24), (64, 48)])
+def test_resampling_flips_against_an_fp64_arbiter(S_, N):
+    """(64 x 64 x 48+48, round 5: configs[4]'s sampling density -- its 3,100 differently-resampled rays of 65,536 get the same backing as
+    configs[1]'s; asserted there with the generic factors of round 4 until a round has measured them.)
+    DESIGN.md 2 says of a ray whose fine samples land in other bins than the fp32 oracle's: "both are valid evaluations of the same
     algorithm".  That needs an arbiter: the oracle in fp64 on the same fp32 inputs (rays, draws, weights, FiLM parameters).  On the bench
     image (all 16,384 rays, 128x128, 24+24, H = 256 + 96^3 grid, |sigma| ~ 2000) a ray FLIPS against fp64 when its merged sample depths
     differ from the fp64 ones by more than 1e-5.  Measured (round 4): the fp32 oracle -- the reference's own arithmetic -- flips 278 rays
     against fp64, the native pipeline 266 (237 of them the same rays); a flipped ray is a silhouette ray (a sample moved across the
     |sigma| ~ 2000 surface), its pixel moves by up to 2.9e-3 (oracle) / 2.5e-3 (native) and its depth by up to 0.09 / 0.11.  Asserted, for
     both precisions:
-      * the native pipeline flips no more rays against fp64 than the fp32 oracle does (+ 10 %);
-      * on rays that agree with fp64 in their sample positions: pixels <= 1e-3 and depth <= 2e-3 on ALL of them -- so every ray beyond
-        north_star's 1e-3 is a flip;
-      * on rays that flip: pixel and depth errors are no larger than the fp32 oracle's own errors on ITS flipped rays (max within
-        1.5 x, mean within 1.5 x): the native result is as close to fp64 as the reference's arithmetic is;
+      * the native pipeline flips no more rays against fp64 than the fp32 oracle does (measured 261 / 257 against 278);
+      * on rays that agree with fp64 in their sample positions: pixels <= 6e-5 (measured 3.1e-5 / 2.8e-5; the fp32 oracle 2.6e-5) and
+        depth <= 1.7e-3 / 1.0e-3 (f32 / f16x3; measured 1.13e-3 / 6.2e-4) on ALL of them -- so every ray beyond north_star's 1e-3 is a flip;
+      * on rays that flip: pixel and depth errors are those of the fp32 oracle on ITS flipped rays: max and mean pixel error within 1.2 x
+        (measured 0.77 - 1.00 x), max depth error within 1.25 x (0.69 - 1.03 x), mean depth error within 1.5 x (0.97 - 1.28 x: different ray
+        sets) -- the native result is as close to fp64 as the reference's arithmetic is (round 5: the factors were a common 1.5);
       * fill decisions identical to fp64 on every ray."""
     import __graft_entry__ as ge
     spec, sd = _full_weights()
-    B, S_, N = 1, 128, 24
+    B = 1
     R = S_ * S_
+    bench = (S_, N) == (128, 24)
     film = proc.film_params(spec, B, seed=0)
     tf = tuple(T(film[k]) for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"))
     args = (film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
-    torch.manual_seed(0)
+    torch.manual_seed(0 if bench else 3)
     o, d, z, _, _ = VR.sample_rays(B, N, DEV, 12, (S_, S_), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
     u = torch.rand((B * R, N), device=DEV)
     opts = _lib.composite_opts("relu", fill_mode="seg_padding_background", fill_color="white")
@@ -578,7 +607,7 @@ def test_resampling_flips_against_an_fp64_arbiter():
     flip32 = np.abs(z32 - z64).max(-1) > 1e-5
     e32, d32 = np.abs(px32 - px64).max(-1), np.abs(dp32 - dp64)
     assert flip32.any() and e32[~flip32].max() <= 1e-3
-    print(f"[parity] fp64 arbiter, fp32 oracle (the reference's arithmetic): {int(flip32.sum())} of {R} rays resample differently from fp64; "
+    print(f"[parity] fp64 arbiter {S_}x{S_} {N}+{N}, fp32 oracle (the reference's arithmetic): {int(flip32.sum())} of {R} rays resample differently from fp64; "
           f"pixel error on them max {e32[flip32].max():.2e} mean {e32[flip32].mean():.2e}, elsewhere {e32[~flip32].max():.2e}; depth error on them "
           f"max {d32[flip32].max():.2e} mean {d32[flip32].mean():.2e}, elsewhere {d32[~flip32].max():.2e}")
     for precision in PRECISIONS:
@@ -591,14 +620,20 @@ def test_resampling_flips_against_an_fp64_arbiter():
         err, derr = np.abs(rgb - px64).max(-1), np.abs(depth - dp64)
         err = np.where((rgb[..., 0] == 1) != (px64[..., 0] == 1), 0.0, err)        # rays ON the fill threshold: asserted separately below
         over = err > 1e-3
-        print(f"[parity] fp64 arbiter, native {precision}: {int(flip.sum())} rays resample differently from fp64 ({int(both.sum())} of them are the fp32 "
+        print(f"[parity] fp64 arbiter {S_}x{S_} {N}+{N}, native {precision}: {int(flip.sum())} rays resample differently from fp64 ({int(both.sum())} of them are the fp32 "
               f"oracle's flips too); pixel error on them max {err[flip].max():.2e} mean {err[flip].mean():.2e}, elsewhere {err[~flip].max():.2e} "
               f"({int(over.sum())} rays > 1e-3, all of them flips: {bool((over & ~flip).sum() == 0)}); depth error on them max {derr[flip].max():.2e} "
               f"mean {derr[flip].mean():.2e}, elsewhere {derr[~flip].max():.2e}")
-        assert int(flip.sum()) <= int(1.1 * flip32.sum()) + 8, "the native pipeline resamples differently from fp64 more often than the reference's fp32 arithmetic does"
-        assert err[~flip].max() <= 1e-3 and derr[~flip].max() <= 2e-3 and not (over & ~flip).any()
-        assert err[flip].max() <= 1.5 * e32[flip32].max() and err[flip].mean() <= 1.5 * e32[flip32].mean()
-        assert derr[flip].max() <= 1.5 * d32[flip32].max() and derr[flip].mean() <= 1.5 * d32[flip32].mean()
+        if bench:
+            assert int(flip.sum()) <= int(flip32.sum()), "the native pipeline resamples differently from fp64 more often than the reference's fp32 arithmetic does"
+            assert err[~flip].max() <= 6e-5 and derr[~flip].max() <= dict(f32=1.7e-3, f16x3=1.0e-3)[precision] and not (over & ~flip).any()
+            assert err[flip].max() <= 1.2 * e32[flip32].max() and err[flip].mean() <= 1.2 * e32[flip32].mean()
+            assert derr[flip].max() <= 1.25 * d32[flip32].max() and derr[flip].mean() <= 1.5 * d32[flip32].mean()
+        else:
+            assert int(flip.sum()) <= int(1.1 * flip32.sum()) + 8
+            assert err[~flip].max() <= 1e-4 and derr[~flip].max() <= 2e-3 and not (over & ~flip).any()
+            assert err[flip].max() <= 1.5 * e32[flip32].max() and err[flip].mean() <= 1.5 * e32[flip32].mean()
+            assert derr[flip].max() <= 1.5 * d32[flip32].max() and derr[flip].mean() <= 1.5 * d32[flip32].mean()
         thr = (rgb[..., 0] == 1) != (px64[..., 0] == 1)
         assert int(thr.sum()) <= 2 and (np.abs(ws64[thr] - 0.9) <= 2e-5).all(), "fill decisions agree with fp64 on every ray that is not ON the 0.9 threshold"
 
@@ -656,8 +691,10 @@ def test_config5_256_48p48_and_config1_64_12():
         ti = torch.as_tensor(idx, device=DEV)
         o_i, d_i, z_i, u_i = o[:, ti].contiguous(), d[:, ti].contiguous(), z[:, ti].contiguous(), (u[ti].contiguous() if hier else None)
         r_rgb, r_depth, r_z = _oracle_render_rays(sd, spec, args, N_(o_i), N_(d_i), N_(z_i), N_(u_i) if hier else None, "black", hier=hier)
+        # measured (round 4): 256^2 x 48+48: max 7.37e-4, 0 rays > 1e-3, depth 5.2e-4; 64^2 x 12 coarse: max 1.67e-6, depth 2.1e-5
+        bounds = dict(max_over=0, over_bound=1e-3, depth_bound=8e-4) if hier else dict(max_over=0, over_bound=3e-6, depth_bound=3.2e-5)
         _check_render_vs_oracle(f"{S_}x{S_} {N}{'+' + str(N) if hier else ''} H=256 f16x3 vs oracle on {len(idx)} rays", nat, (o_i, d_i, z_i, u_i), tf,
-                                opts, rgb[:, idx], depth[:, idx], r_rgb, r_depth, r_z, hier=hier)
+                                opts, rgb[:, idx], depth[:, idx], r_rgb, r_depth, r_z, hier=hier, **bounds)
 
 
 def test_spatial_siren_grid_vs_reference():
@@ -1692,6 +1729,50 @@ def test_inversion_film_only_gradients_and_loop():
     assert res["w_geo_frequency_offsets"].abs().max() > 0
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_inversion_reproduces_the_references_own_trajectory(precision):
+    """tests/golden/tiny_texture_inversion.npz (round 5): the REFERENCE's inversion loop (inverse_render_double_semantic.py:306-410,
+    restated on the reference's generator by tools/make_golden.py::run_inversion_case: Adam lr 1e-2 / weight_decay 1e-4 on the four
+    offset tensors, StepLR(100, 0.75), annealed latent noise, the script's `options`, both MSE terms) on the frozen generator of
+    tiny_texture_trained_state.npz -- weights the reference's own forward + autograd + Adam produced --, with every draw, the loss of every
+    iteration and the four offset tensors after every iteration recorded.  callers.inverse_render on the same draws (30 native
+    differentiable renders, FiLM-only backward) must walk the same trajectory: replaces round 4's "the loss falls by 10 %".
+    Conditioning, measured with the reference itself in the build container: a 1e-5 relative change of the initial mean frequencies moves
+    its losses by <= 2e-4 relative and its offsets by <= 7e-5 over the 30 iterations (1e-6: 5e-5 / 1.3e-5)."""
+    from fenerf_amd import callers
+    g = load_golden("tiny_texture_inversion")
+    spec = spec_from_golden(g)
+    gen = _make_generator(g, spec, precision)
+    for p in gen.parameters():
+        p.requires_grad_(False)
+    n, S_, N = int(g["meta_iterations"]), int(g["meta_S"]), int(g["meta_N"])
+    gen.draws = VR.RecordedDraws([g[k] for k in sorted(k for k in g if k.startswith("draw"))])
+    # the script's options dict (:220-243) with its sizes scaled down, keys it never reads included
+    options = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0, v_stddev=0,
+                   h_mean=torch.tensor(np.pi / 2, device=DEV), v_mean=torch.tensor(np.pi / 2, device=DEV), hierarchical_sample=False,
+                   sample_dist=None, clamp_mode="relu", nerf_noise=0, fade_steps=10000, z_app_lambda=0, z_geo_lambda=0, pos_lambda=0,
+                   tok_interval=2000, tok_v=0.6, betas=(0, 0.9), fill_mode="eval_seg_padding_background")
+    res = callers.inverse_render(gen, T(g["gt_image"]), T(g["gt_seg"]), options, n_iterations=n, z_dim=spec["z_dim"],
+                                 n_mean_latents=int(g["meta_mean_latents"]), record_offsets=True)
+    assert not gen.draws.arrays, "all recorded draws consumed, in order"
+    for k in ("w_geo_frequencies", "w_geo_phase_shifts", "w_app_frequencies", "w_app_phase_shifts"):
+        np.testing.assert_allclose(N_(res[k]), g[k], atol=2e-6)       # mean FiLM parameters over the recorded latents (torch mapping networks)
+    losses = np.asarray(res["losses"])
+    rel = np.abs(losses - g["losses"]) / g["losses"]
+    off = np.zeros(n)
+    for j, nm in enumerate(("geo_frequency", "geo_phase_shift", "app_frequency", "app_phase_shift")):
+        ref = g[f"offsets_{nm}"]
+        got = np.stack([h[j].numpy() for h in res["offset_history"]])
+        assert got.shape == ref.shape
+        off = np.maximum(off, np.abs(got - ref).reshape(n, -1).max(1))
+    print(f"[parity] inversion trajectory {precision}: reference loss {g['losses'][0]:.5f} -> {g['losses'][-1]:.5f} over {n} iterations; native "
+          f"loss within {rel[:20].max():.1e} relative over the first 20 iterations ({rel.max():.1e} over all), offsets within {off[:20].max():.1e} "
+          f"/ {off.max():.1e} absolute (|offset| up to {max(np.abs(g['offsets_' + nm]).max() for nm in ('geo_frequency', 'geo_phase_shift', 'app_frequency', 'app_phase_shift')):.3f})")
+    assert rel[:20].max() <= 1e-3 and off[:20].max() <= 1e-3
+    assert rel.max() <= 3e-3 and off.max() <= 3e-3
+    assert losses[-1] < 0.5 * losses[0]
+
+
 def test_single_latent_generator_gradient_nonhierarchical_locked_view():
     """ImplicitGenerator3d.forward with grad: hierarchical_sample=False (CompositeFunction), lock_view_dependence=True (the kernels
     substitute the constant view direction (0,0,-1), siren.py:1515 / generators.py:474-476), white_back -- gradients of a pixel
@@ -2309,7 +2390,8 @@ def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm"])
+@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm",
+                                  "tiny_texture_grad_trained"])      # *_trained: at a state the reference's own Adam run produced (round 5)
 def test_generator_gradients_vs_reference_autograd(name, precision):
     """tests/golden/tiny_*_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies (texture:
     hierarchical 8+8, noise, white_back; baseline: softplus, noise, last_back; single-latent: locked view direction).  The
@@ -2318,7 +2400,7 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
     g = load_golden(name)
     spec = spec_from_golden(g)
     kind = spec["kind"]
-    gen = (_make_spatial_generator if kind == "spatial" else _make_generator)(g, dict(spec, z_dim=16), precision)
+    gen = (_make_spatial_generator if kind == "spatial" else _make_generator)(g, dict(spec, z_dim=spec.get("z_dim", 16)), precision)
     gen.train()
     film, tf = _film(g, spec)
     if kind == "spatial":      # the golden's film helper draws the colour slice like the generator test above
@@ -2599,7 +2681,9 @@ def test_reference_fixtures_far_beyond_the_init_range(name, precision):
     e = np.abs(N_(px) - g["pixels"]).max(axis=1)
     print(f"[parity] {name}[{precision}] forward_with_frequencies vs reference: median|err| {np.median(e):.2e} max {e.max():.2e}, {int((e > 2e-3).sum())} of "
           f"{e.size} pixels beyond 2e-3")
-    assert np.median(e) <= 2e-4 and (e > 2e-3).mean() <= 0.05
+    # measured (round 4): tiny median 6.6e-6 / 6.9e-6, max 2.6e-5 / 2.7e-5; h256 median 6.0e-6 / 6.2e-6, max 5.1e-4 / 3.8e-4 (f32 / f16x3);
+    # no pixel beyond 2e-3 in any of them (round 4 allowed 5 % of the pixels there and a 2e-4 median)
+    assert np.median(e) <= 1.1e-5 and e.max() <= (8e-4 if spec["hidden_dim"] == 256 else 4.5e-5)
 
 
 def test_integration_md_binding_renders():
@@ -2703,7 +2787,8 @@ def test_split_backward_equals_the_single_node_backward(precision):
                 p_.grad = None
             torch.manual_seed(11)
             px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
-            assert ("HierarchicalRenderSplit" in type(px.grad_fn).__name__ or "HierarchicalRenderSplit" in str(px.grad_fn.next_functions)) == split or True
+            route = [type(px.grad_fn).__name__] + [type(f).__name__ for f, _ in px.grad_fn.next_functions if f is not None]
+            assert any("HierarchicalRenderSplit" in r_ for r_ in route) == split, route      # the two-node route ran iff it was asked for
             w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
             (px * w).sum().backward()
             g = {k: N_(v.grad) for k, v in film_t.items()}
@@ -2720,7 +2805,8 @@ def test_split_backward_equals_the_single_node_backward(precision):
 
 
 @pytest.mark.parametrize("z_dim,hidden,out_dim,n_blocks,B", [(256, 256, 4096, 3, 1), (256, 256, 1536, 3, 6), (16, 256, 704, 3, 2), (32, 256, 64, 1, 5),
-                                                             (8, 32, 40, 3, 64), (100, 300, 1000, 2, 3)])
+                                                             (8, 32, 40, 3, 64), (100, 300, 1000, 2, 3),
+                                                             (514, 256, 96, 2, 2)])      # z_dim > hidden, z_dim % 4 != 0: LDS buffer alignment (round-4 advisory)
 def test_mapping_network_native_vs_torch(z_dim, hidden, out_dim, n_blocks, B):
     """CustomMappingNetwork (siren.py:82-102) at small batch runs as one native launch forward and three backward (fenerf_mapping.hip)
     instead of ~9 + ~30 ATen launches per network.  Same module, both routes: outputs and every weight / bias gradient against the

@@ -5,7 +5,7 @@ import ast
 import numpy as np
 import pytest
 
-from conftest import film_from_golden, kwargs_from_golden, load_golden, spec_from_golden
+from conftest import film_from_golden, kwargs_from_golden, load_golden, spec_from_golden, weights_from_golden
 from fenerf_amd import procedural as proc
 from oracle import fenerf_oracle as O
 
@@ -19,7 +19,7 @@ def _rand(g, prefix="rand_", mode="gaussian", h_std=0.3, v_std=0.155):
 
 def _model(g):
     spec = spec_from_golden(g)
-    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
+    sd = weights_from_golden(g, spec)
     assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-6 * max(1.0, abs(float(g["meta_weights_checksum"])))
     film = film_from_golden(g, spec)
     if spec["kind"] == "spatial":   # single latent: one [B, 9H] tensor, the colour layer uses its last H (siren.py:241)
@@ -109,7 +109,8 @@ def test_integration_variants():
         O.fancy_integration(rs, z, clamp_mode=None)
 
 
-@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "tiny_spatial_fwd"])
+@pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "tiny_spatial_fwd",
+                                  "tiny_texture_fwd_trained"])      # *_trained: weights + FiLM parameters the reference's own Adam run produced
 def test_forward_stagewise(name):
     g = load_golden(name)
     px, depth, third, st = _render(g)
@@ -298,7 +299,8 @@ def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
     np.testing.assert_allclose(got.numpy(), ref, atol=1e-11, rtol=1e-11)
 
 
-@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm"])
+@pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm",
+                                  "tiny_texture_grad_trained"])
 def test_grad_oracle_matches_reference_autograd(name):
     # *_bigfilm: FiLM phase shifts of +-300 revolutions, first-layer frequency x 4 (round 4): the reference's fp32 radians carry an
     # argument rounding of 1.2e-4 .. 2.4e-4 rad there, so its own pixels / gradients sit that much further from fp64 (measured 8e-4)
@@ -311,7 +313,7 @@ def test_grad_oracle_matches_reference_autograd(name):
     from oracle import fenerf_oracle_grad as OG
     g = load_golden(name)
     spec = spec_from_golden(g)
-    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
+    sd = weights_from_golden(g, spec)
     assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-9
     B, S, N = int(g["meta_B"]), int(g["meta_S"]), int(g["meta_N"])
     kw = kwargs_from_golden(g)

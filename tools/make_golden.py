@@ -32,7 +32,7 @@ class DrawRecorder:
 
     def __enter__(self):
         self.draws = []
-        self._orig = (torch.rand, torch.randn, torch.randperm)
+        self._orig = (torch.rand, torch.randn, torch.randperm, torch.randn_like)
 
         def wrap(fn, kind):
             def inner(*a, **k):
@@ -42,10 +42,11 @@ class DrawRecorder:
             return inner
 
         torch.rand, torch.randn, torch.randperm = wrap(torch.rand, "rand"), wrap(torch.randn, "randn"), wrap(torch.randperm, "randperm")
+        torch.randn_like = wrap(torch.randn_like, "randn")      # same generator consumption as randn(x.shape)
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.randn, torch.randperm = self._orig
+        torch.rand, torch.randn, torch.randperm, torch.randn_like = self._orig
 
 
 class CallRecorder:
@@ -84,7 +85,14 @@ def load_sd(module, sd):
     assert not missing and not unexpected
 
 
-def build_ref_generator(refs, spec, seed, sigma_gain):
+def load_state(name):
+    """a state fixture written by run_trained_state -> (render weights {name: array}, raw FiLM parameters {name: array})"""
+    st = np.load(os.path.join(OUT, name + ".npz"))
+    return ({k[3:]: st[k] for k in st.files if k.startswith("sd_")}, {k[5:]: st[k] for k in st.files if k.startswith("film_")})
+
+
+def build_ref_generator(refs, spec, seed, sigma_gain, state=None):
+    """state: name of a state fixture whose render weights replace the procedural ones (the mapping networks stay procedural)"""
     siren_mod, gens, vr, cur = refs
     H = spec["hidden_dim"]
     if spec["kind"] == "texture":
@@ -98,6 +106,8 @@ def build_ref_generator(refs, spec, seed, sigma_gain):
     else:
         g = gens.DoubleImplicitGenerator3d(cls, spec["z_dim"], spec["z_dim"], spec["output_dim"])
     sd = proc.make_state_dict(spec, seed=seed, sigma_gain=sigma_gain)
+    if state is not None:
+        sd.update(load_state(state)[0])
     load_sd(g.siren, sd)
     g.eval()
     g.device = torch.device("cpu")
@@ -117,12 +127,12 @@ def rand_dict_from_draws(draws, hierarchical):
     return rd
 
 
-def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, film_scale=1.0, stages=True, staged=False, film_kw=None):
+def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, film_scale=1.0, stages=True, staged=False, film_kw=None, state=None):
     """forward_with_frequencies / staged_forward_with_frequencies with explicit film params.  film_kw: procedural.film_params'
     phase_rev / freq0_gain -- FiLM parameters far beyond the init range (sine arguments of hundreds of revolutions)."""
     siren_mod, gens, vr, cur = refs
-    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
-    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {}))
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain, state)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {})) if state is None else load_state(state)[1]
     tf = {k: torch.from_numpy(v) for k, v in film.items()}
     if spec["kind"] == "spatial":   # single latent: one [B, 9H] frequency / phase tensor; the colour layer uses the last H
         tf["freq_geo"] = torch.cat([tf["freq_geo"], tf["freq_app"]], -1)
@@ -157,6 +167,8 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
                meta_film_scale=film_scale, meta_staged=int(staged), meta_weights_checksum=proc.checksum(sd))
     if film_kw:
         out.update(meta_film_phase_rev=float(film_kw["phase_rev"]), meta_film_freq0_gain=float(film_kw["freq0_gain"]))
+    if state is not None:
+        out["meta_state"] = state
     for k, v in spec.items():
         out["spec_" + k] = v
     for k, v in kwargs.items():
@@ -196,13 +208,13 @@ def run_film_case(refs, name, spec, seed, sigma_gain, B, S, N, hier, kwargs, fil
     return g, sd, out
 
 
-def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0, film_kw=None):
+def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0, film_kw=None, state=None):
     """The reference's OWN autograd through generator.forward_with_frequencies (what g_loss.backward() replays,
     train_double_latent_semantic.py:408-452): loss = sum(pixels * w) with a fixed w; gradients wrt the raw FiLM parameters
     and every render parameter, plus the draws and the pixels.  fp32 on the CPU (gradient noise ~1e-5 relative)."""
     siren_mod, gens, vr, cur = refs
-    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
-    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {}))
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain, state)
+    film = proc.film_params(spec, B, seed=seed, scale=film_scale, **(film_kw or {})) if state is None else load_state(state)[1]
     tf = {k: torch.from_numpy(v).requires_grad_(True) for k, v in film.items()}
     torch.manual_seed(4321 + seed)
     common = dict(img_size=S, num_steps=N, hierarchical_sample=True, fov=CURR["fov"], ray_start=CURR["ray_start"],
@@ -223,6 +235,8 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
                meta_weights_checksum=proc.checksum(sd))
     if film_kw:
         out.update(meta_film_phase_rev=float(film_kw["phase_rev"]), meta_film_freq0_gain=float(film_kw["freq0_gain"]))
+    if state is not None:
+        out["meta_state"] = state
     for k, v in spec.items():
         out["spec_" + k] = v
     for k, v in kwargs.items():
@@ -575,6 +589,146 @@ def run_multiview_case(refs, name="tiny_multiview"):
     print(f"{name}: images {out['images'].shape}, segmaps {out['segmaps'].shape}")
 
 
+def run_trained_state(refs, name, spec, seed, teacher_seed, steps, B, S, N, lr=1e-4, lr_film=2e-3):
+    """Weights and FiLM parameters an OPTIMISER produced (round 5): every other fixture sits on the init manifold (procedural weights in
+    the reference initialisers' ranges, FiLM parameters in the mapping networks' init range, or hand-scaled excursions of those).
+    Here the reference generator itself is trained in this container: `steps` Adam steps (betas (0, 0.9) like the curriculum's generator
+    optimiser, train_double_latent_semantic.py:166; lr 1e-4 on every render weight, 8^3 feature grid included -- the curriculum's 2e-5 ..
+    6e-5 over 100k+ steps is not affordable here, and a larger rate drives this tiny network into a regime where ANY two fp32 evaluations
+    differ by O(1): with lr 2e-3 a 1e-6 relative change of one input moved the reference's own loss by 7 % -- and 2e-3 on the raw FiLM
+    parameters), MSE between generator.forward_with_frequencies (hierarchical, fresh jitter / resampling draws per step, fixed pose) and
+    the pixels of a second, denser procedural generator ("teacher") -- the reference's own forward, the reference's own autograd, torch's
+    Adam.  The fixture holds the resulting state (sd_* / film_*), the loss curve and the target; run_film_case / run_grad_case(state=...)
+    then record the reference's stage-wise outputs and gradients AT that state."""
+    siren_mod, gens, vr, cur = refs
+    common = dict(img_size=S, num_steps=N, hierarchical_sample=True, fov=CURR["fov"], ray_start=CURR["ray_start"], ray_end=CURR["ray_end"],
+                  h_stddev=0.0, v_stddev=0.0, h_mean=CURR["h_mean"], v_mean=CURR["v_mean"], sample_dist=None, clamp_mode="relu", nerf_noise=0.0)
+    teacher, _ = build_ref_generator(refs, spec, teacher_seed, 300.0)
+    tfilm = {k: torch.from_numpy(v) for k, v in proc.film_params(spec, B, seed=teacher_seed).items()}
+    torch.manual_seed(9000 + seed)
+    with torch.no_grad():
+        target, _ = teacher.forward_with_frequencies(tfilm["freq_geo"], tfilm["freq_app"], tfilm["phase_geo"], tfilm["phase_app"], **common)
+    g, sd0 = build_ref_generator(refs, spec, seed, 60.0)
+    film = {k: torch.from_numpy(v).requires_grad_(True) for k, v in proc.film_params(spec, B, seed=seed).items()}
+    params = [p for n, p in g.siren.named_parameters() if "mapping_network" not in n]
+    opt = torch.optim.Adam([dict(params=params, lr=lr), dict(params=list(film.values()), lr=lr_film)], betas=(0.0, 0.9))
+    losses = []
+    for i in range(steps):
+        px, _ = g.forward_with_frequencies(film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], **common)
+        loss = torch.nn.functional.mse_loss(px, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:10]), (losses[0], losses[-1])
+    out = dict(meta_seed=seed, meta_teacher_seed=teacher_seed, meta_steps=steps, meta_lr=lr, meta_lr_film=lr_film, meta_B=B, meta_S=S, meta_N=N,
+               losses=np.asarray(losses, np.float32), target=np_(target))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    moved = []
+    for n, p in g.siren.named_parameters():
+        if "mapping_network" not in n:
+            out["sd_" + n] = np_(p)
+            moved.append(float(np.abs(out["sd_" + n] - sd0[n]).max() / np.abs(sd0[n]).max()))
+    f0 = proc.film_params(spec, B, seed=seed)
+    for k, t in film.items():
+        out["film_" + k] = np_(t)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {steps} Adam steps of the reference generator: loss {losses[0]:.4f} -> {losses[-1]:.4f}; weights moved by "
+          f"{min(moved):.2f} .. {max(moved):.2f} of their init range, FiLM parameters by up to "
+          f"{max(float(np.abs(out['film_' + k] - f0[k]).max()) for k in f0):.2f}")
+
+
+def run_inversion_case(refs, name, spec, state, seed, n_iterations, n_mean_latents, S, N):
+    """The reference's inversion loop (inverse_render_double_semantic.py:306-410) on the frozen trained generator of `state`, recorded:
+    every draw in call order, the loss of every iteration and the four offset tensors after every iteration.  The loop is a script body
+    there (not importable), so it is restated here statement by statement on the REFERENCE's generator, torch's Adam (lr 1e-2,
+    weight_decay 1e-4) and StepLR(100, 0.75): mean FiLM parameters over `n_mean_latents` latents (10,000 there), init_psi 0, annealed
+    latent noise 0.03 (n - i) / n, forward_with_frequencies with the script's `options` dict (its size entries scaled down),
+    lambda_seg = lambda_img = 1 on the two MSE terms, no LPIPS term (lambda_percept 0: the package is absent), no norm term.  The target is
+    a render of the same generator at truncated (psi 0.6) FiLM parameters of one random latent pair."""
+    siren_mod, gens, vr, cur = refs
+    g, sd = build_ref_generator(refs, spec, seed, 60.0, state)
+    for p in g.parameters():
+        p.requires_grad_(False)
+    zd = spec["z_dim"]
+    # the script's options (:220-243), sizes scaled to the tiny model; device tensors for h_mean / v_mean like there
+    options = dict(img_size=S, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0, v_stddev=0,
+                   h_mean=torch.tensor(np.pi / 2), v_mean=torch.tensor(np.pi / 2), hierarchical_sample=False, sample_dist=None,
+                   clamp_mode="relu", nerf_noise=0, fade_steps=10000, z_app_lambda=0, z_geo_lambda=0, pos_lambda=0, tok_interval=2000,
+                   tok_v=0.6, betas=(0, 0.9), fill_mode="eval_seg_padding_background")
+    torch.manual_seed(2500 + seed)
+    with torch.no_grad():      # target: psi-truncated sample of the same generator
+        zs_g, zs_a = torch.randn((2000, zd)), torch.randn((2000, zd))
+        mg, ma = g.siren.geo_mapping_network(zs_g), g.siren.app_mapping_network(zs_a)
+        rg, ra = g.siren.geo_mapping_network(torch.randn((1, zd))), g.siren.app_mapping_network(torch.randn((1, zd)))
+        mix = lambda m, r: m.mean(0, keepdim=True) + 0.6 * (r - m.mean(0, keepdim=True))
+        target, _ = g.forward_with_frequencies(mix(mg[0], rg[0]), mix(ma[0], ra[0]), mix(mg[1], rg[1]), mix(ma[1], ra[1]), **options)
+    gt_seg_18, gt_image = target[:, :-3].clone(), target[:, -3:].clone()
+    losses, offs = [], []
+    torch.manual_seed(2600 + seed)
+    with DrawRecorder() as dr:
+        z_geo = torch.randn((n_mean_latents, zd))
+        rand_z_geo = torch.randn((1, zd))
+        with torch.no_grad():
+            geo_frequencies, geo_phase_shifts = g.siren.geo_mapping_network(z_geo)
+            rand_geo_frequencies, rand_geo_phase_shifts = g.siren.geo_mapping_network(rand_z_geo)
+        init_psi = 0.0
+        w_geo_frequencies = geo_frequencies.mean(0, keepdim=True)
+        w_geo_phase_shifts = geo_phase_shifts.mean(0, keepdim=True)
+        w_geo_frequencies = w_geo_frequencies + init_psi * (rand_geo_frequencies - w_geo_frequencies)
+        w_geo_phase_shifts = w_geo_phase_shifts + init_psi * (rand_geo_phase_shifts - w_geo_phase_shifts)
+        w_geo_frequency_offsets = torch.zeros_like(w_geo_frequencies).requires_grad_()
+        w_geo_phase_shift_offsets = torch.zeros_like(w_geo_phase_shifts).requires_grad_()
+        z_app = torch.randn((n_mean_latents, zd))
+        rand_z_app = torch.randn((1, zd))
+        with torch.no_grad():
+            app_frequencies, app_phase_shifts = g.siren.app_mapping_network(z_app)
+            rand_app_frequencies, rand_app_phase_shifts = g.siren.app_mapping_network(rand_z_app)
+        w_app_frequencies = app_frequencies.mean(0, keepdim=True)
+        w_app_phase_shifts = app_phase_shifts.mean(0, keepdim=True)
+        w_app_frequencies = w_app_frequencies + init_psi * (rand_app_frequencies - w_app_frequencies)
+        w_app_phase_shifts = w_app_phase_shifts + init_psi * (rand_app_phase_shifts - w_app_phase_shifts)
+        w_app_frequency_offsets = torch.zeros_like(w_app_frequencies).requires_grad_()
+        w_app_phase_shift_offsets = torch.zeros_like(w_app_phase_shifts).requires_grad_()
+        optimizer = torch.optim.Adam([w_geo_frequency_offsets, w_geo_phase_shift_offsets, w_app_frequency_offsets, w_app_phase_shift_offsets],
+                                     lr=1e-2, weight_decay=1e-4)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 100, gamma=0.75)
+        for i in range(n_iterations):
+            k = (n_iterations - i) / n_iterations
+            noise_w_geo_frequencies = 0.03 * torch.randn_like(w_geo_frequencies) * k
+            noise_w_geo_phase_shifts = 0.03 * torch.randn_like(w_geo_phase_shifts) * k
+            noise_w_app_frequencies = 0.03 * torch.randn_like(w_app_frequencies) * k
+            noise_w_app_phase_shifts = 0.03 * torch.randn_like(w_app_phase_shifts) * k
+            frame, position = g.forward_with_frequencies(w_geo_frequencies + noise_w_geo_frequencies + w_geo_frequency_offsets,
+                                                         w_app_frequencies + noise_w_app_frequencies + w_app_frequency_offsets,
+                                                         w_geo_phase_shifts + noise_w_geo_phase_shifts + w_geo_phase_shift_offsets,
+                                                         w_app_phase_shifts + noise_w_app_phase_shifts + w_app_phase_shift_offsets, **options)
+            seg_loss = torch.nn.MSELoss(reduction="mean")(frame[:, :-3], gt_seg_18)
+            img_loss = torch.nn.MSELoss(reduction="mean")(frame[:, -3:], gt_image)
+            loss = 1.0 * seg_loss + 1.0 * img_loss
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            scheduler.step()
+            losses.append(float(loss.detach()))
+            offs.append([np_(t) for t in (w_geo_frequency_offsets, w_geo_phase_shift_offsets, w_app_frequency_offsets, w_app_phase_shift_offsets)])
+    out = dict(meta_state=state, meta_seed=seed, meta_sigma_gain=60.0, meta_iterations=n_iterations, meta_mean_latents=n_mean_latents,
+               meta_S=S, meta_N=N, meta_weights_checksum=proc.checksum(sd), gt_image=np_(gt_image), gt_seg=np_(gt_seg_18),
+               losses=np.asarray(losses, np.float64),
+               w_geo_frequencies=np_(w_geo_frequencies), w_geo_phase_shifts=np_(w_geo_phase_shifts),
+               w_app_frequencies=np_(w_app_frequencies), w_app_phase_shifts=np_(w_app_phase_shifts))
+    for j, nm in enumerate(("geo_frequency", "geo_phase_shift", "app_frequency", "app_phase_shift")):
+        out[f"offsets_{nm}"] = np.stack([o[j] for o in offs])          # [iteration, 1, n]
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    for i, (kind, v) in enumerate(dr.draws):
+        out[f"draw{i:04d}_{kind}"] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: the reference's inversion loop, {n_iterations} iterations, {len(dr.draws)} draws: loss {losses[0]:.5f} -> {losses[-1]:.5f}, "
+          f"|offsets| up to {max(float(np.abs(o).max()) for o in offs[-1]):.3f}")
+
+
 def json_dumps_curriculum(curriculum):
     import json
     return json.dumps({(f"int:{k}" if isinstance(k, int) else k): v for k, v in curriculum.items()}, sort_keys=True)
@@ -725,6 +879,17 @@ def main(out_dir=None):
     run_film_case(refs, "h256_texture_8x8_n12_bigfilm", full, seed=0, sigma_gain=30.0, B=1, S=8, N=12, hier=True, kwargs=relu, film_kw=big)
     run_grad_case(refs, "tiny_texture_grad_bigfilm", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True), film_kw=big)
+
+    # Off the init manifold (round 5): a state the reference's own forward + autograd + Adam produced in this container, then the usual
+    # stage-wise outputs and gradients AT that state, and the reference's inversion loop on the frozen trained generator.
+    tiny8 = proc.model_spec("texture", hidden_dim=32, grid_size=8, z_dim=8)
+    run_trained_state(refs, "tiny_texture_trained_state", tiny8, seed=1, teacher_seed=3, steps=400, B=2, S=8, N=6)
+    run_film_case(refs, "tiny_texture_fwd_trained", tiny8, seed=1, sigma_gain=60.0, B=2, S=8, N=6, hier=True, kwargs=relu,
+                  state="tiny_texture_trained_state")
+    run_grad_case(refs, "tiny_texture_grad_trained", tiny8, seed=1, sigma_gain=60.0, B=2, S=8, N=6,
+                  kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True), state="tiny_texture_trained_state")
+    run_inversion_case(refs, "tiny_texture_inversion", tiny8, "tiny_texture_trained_state", seed=1, n_iterations=30, n_mean_latents=500,
+                       S=8, N=12)
 
 
 if __name__ == "__main__":
