@@ -172,7 +172,10 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                              f"({B * S * S * 2 * N} points): the render part of a generator step -- the two mapping networks, their backward "
                              f"and the optimizer are NOT in it (the reference's own step, generator_ddp(z) + backward [+ Adam], is "
                              f"gstep_ddp.ms_no_ddp / .ms / .ms_with_optimizer); native differentiable path, precision {precision}, weight-gradient operands "
-                             + ("fp32 class (default)" if grad_precision == "f32" else "bf16, one MFMA per product: AMP class, opt-in (siren.grad_precision = 'amp')"),
+                             + {"f32": "fp32 class (default)", "amp": "bf16, one MFMA per product: AMP class, opt-in (siren.grad_precision = 'amp')",
+                                "tape16": "fp32 class, with the 16-bit tape between forward and backward (frac(theta) as fixed point, 2 instead of 4 bytes per "
+                                          "(point, layer-feature)): gradients within ~1.2e-4 of fp64 autograd instead of ~4e-5 -- a tier between the default "
+                                          "and AMP, opt-in (siren.grad_precision = 'tape16')"}[grad_precision],
            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
     if not breakdown:
         return out
@@ -180,8 +183,9 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
     nat = mod.native_differentiable(dev)
     L, C, G_ = spec["n_geo"] + spec["n_color"], spec["output_dim"], spec["grid_ch"]
     pts = B * ((S * S * N + 31) // 32 * 32) * 2                         # coarse + fine pass, whole 32-point tiles per image
-    tape_b = nat.tape_floats(pts) * 4.0 / pts                            # fp32 pre-FiLM accumulators of L layers
-    dump = nat.dump_bytes_per_point()                                    # what the chain writes / the weight gradients read, per layer-feature
+    fmt = mod.tape_format(nat, film_only=False)                          # include/fenerf.h FENERF_TAPE_*: fp32 accumulators, or 16-bit phases
+    tape_b = nat.tape_floats(pts, fmt) * 4.0 / pts                       # the tape of L layers, bytes per point
+    dump = nat.dump_bytes_per_point(tape_format=fmt)                     # what the chain writes / the weight gradients read, per layer-feature
     row, xyz = 4.0 * C, 12.0
     model = {
         "forward_save": tape_b + (128.0 if G_ else 0.0) + row + 2 * xyz,                        # tape + grid features + outputs written; points, dirs read
@@ -208,7 +212,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                        "per_kernel": per_kernel, "other_library_launches_ms": rest,
                        "ms_not_in_library_kernels": ms - accounted - sum(rest.values()),
                        "launch_groups_per_step": sum(t.calls.values()) // steps_b,
-                       "bytes_per_point": {"tape": tape_b, **dump},     # tape per point; the others per (point x layer-feature)
+                       "bytes_per_point": {"tape": tape_b, "tape_format": "u16" if fmt else "f32", **dump},     # tape per point; the others per (point x layer-feature)
                        "note": "algorithmic bytes = tape written once and read by the chain, the chain's dump written once and read once, the "
                                "tape layers the weight-gradient kernels re-read, per-point rows; `frac` = bytes / whole step time / 8 TB/s; "
                                "per_kernel times from hipEvent pairs in instrumented steps (their sum + torch glue = ms)"}
@@ -629,6 +633,10 @@ def main(argv=None):
                     out["gstep_amp"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision="amp")
                 except Exception as e:
                     out["gstep_amp"] = {"error": f"{type(e).__name__}: {e}"}
+                try:   # opt-in 16-bit tape (round 5): the tier between the default and AMP; reported beside, never instead
+                    out["gstep_tape16"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision="tape16")
+                except Exception as e:
+                    out["gstep_tape16"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_gstep_b6 and (B, S, N) == (1, 128, 24):
                 try:   # BASELINE.json configs[2]: the reference's generator micro-batch (batch 24 split 4 -> 6 images of 128x128 x 24+24 per GPU)
                     torch.cuda.empty_cache()

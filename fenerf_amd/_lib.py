@@ -133,6 +133,13 @@ _SIGS = {
     "fenerf_siren_backward_fuses_grid": (_i, [_vp]),
     "fenerf_siren_backward_grid": (_i, [_vp, _i, _i64] + [_vp] * 13),
     "fenerf_grid_gradient_ncdhw": (_i, [_vp, _vp, _vp, _vp]),
+    # round 5: the same four calls for a tape in `tape_format` (FENERF_TAPE_F32 | FENERF_TAPE_U16)
+    "fenerf_siren_tape_bytes": (_sz, [_vp, _i64, _i]),
+    "fenerf_siren_forward_save_fmt": (_i, [_vp, _i, _i64] + [_vp] * 10 + [_i, _vp]),
+    "fenerf_siren_backward_fmt": (_i, [_vp, _i, _i64] + [_vp] * 7 + [_i] + [_vp] * 4),
+    "fenerf_siren_backward_grid_fmt": (_i, [_vp, _i, _i64] + [_vp] * 7 + [_i] + [_vp] * 6),
+    "fenerf_siren_param_grads_fmt": (_i, [_vp, _i, _i64] + [_vp] * 9 + [_i, _vp, _vp, C.POINTER(FenerfSirenGrads), C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
+    "fenerf_siren_backward_stream_bytes_fmt": (_i, [_vp, _i64, _i, C.POINTER(C.c_double)]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),
@@ -140,6 +147,7 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 N_PHASES = 17        # include/fenerf.h FENERF_N_PHASES
 FUSION_AUTO, FUSION_OFF, FUSION_FORCE = 0, 1, 2      # include/fenerf.h fenerf_set_render_fusion
+TAPE_F32, TAPE_U16 = 0, 1                            # include/fenerf.h FENERF_TAPE_*
 
 _lib = None
 

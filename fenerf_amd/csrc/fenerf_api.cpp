@@ -705,6 +705,18 @@ extern "C" size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_p
   return (size_t)m->L * m->H * 32 * quads * 4;
 }
 
+extern "C" size_t fenerf_siren_tape_bytes(const FenerfModel* m, int64_t total_points, int tape_format) {
+  const size_t f = fenerf_siren_tape_floats(m, total_points);
+  return tape_format == FENERF_TAPE_U16 ? f * 2 : f * 4;      // same tiles, same slack, 2 instead of 4 bytes per (point, feature)
+}
+
+static int check_tape_format(const FenerfModel* m, int tape_format) {
+  if (tape_format != FENERF_TAPE_F32 && tape_format != FENERF_TAPE_U16) return fail(FENERF_E_INVALID, "unknown tape format");
+  if (tape_format == FENERF_TAPE_U16 && m->precision != FENERF_PREC_F16X3)
+    return fail(FENERF_E_UNSUPPORTED, "FENERF_TAPE_U16: FENERF_PREC_F16X3 models only (the exact-fp32 kernels keep the fp32 tape)");
+  return FENERF_OK;
+}
+
 extern "C" size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points) {
   if (!m || total_points <= 0) return 0;
   const long long tiles = (total_points + 31) / 32;
@@ -725,11 +737,29 @@ extern "C" int fenerf_siren_backward_stream_bytes(const FenerfModel* m, int64_t 
   return FENERF_OK;
 }
 
+extern "C" int fenerf_siren_backward_stream_bytes_fmt(const FenerfModel* m, int64_t chunk_points, int tape_format, double* out4) {
+  int rc = fenerf_siren_backward_stream_bytes(m, chunk_points, out4);
+  if (rc) return rc;
+  if (tape_format == FENERF_TAPE_U16) {     // every tape read shrinks from 4 to 2 bytes: the square job's, the thin jobs' two layers, the tape itself
+    out4[1] -= 2.0; out4[2] -= 2 * 2.0; out4[3] = 2.0;
+  }
+  return FENERF_OK;
+}
+
 extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                                          const float* freq_geo, const float* phase_geo, const float* freq_app,
                                          const float* phase_app, float* out, float* tape, float* tape_e, void* film_ws,
                                          void* stream) {
+  return fenerf_siren_forward_save_fmt(m, B, P, points, ray_dirs, freq_geo, phase_geo, freq_app, phase_app, out, tape, tape_e, film_ws,
+                                       FENERF_TAPE_F32, stream);
+}
+
+extern "C" int fenerf_siren_forward_save_fmt(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                             const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                             const float* phase_app, float* out, void* tape, float* tape_e, void* film_ws,
+                                             int tape_format, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (int rcf = check_tape_format(m, tape_format)) return rcf;
   if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
   if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
@@ -742,14 +772,21 @@ extern "C" int fenerf_siren_forward_save(const FenerfModel* m, int B, int64_t P,
   fill_common(m, sp, fp, pp);
   sp.points = points; sp.pdirs = ray_dirs;
   sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
-  sp.out = out; sp.tape = tape; sp.tape_e = tape_e;
+  sp.out = out; sp.tape = (float*)tape; sp.tape_e = tape_e; sp.tape_format = tape_format;
   return run_siren(m, sp, stream);
 }
 
 extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
                                      const float* freq_app, const float* phase_app, const float* out, const float* d_out,
                                      const float* tape, float* d_t, float* d_e, void* film_ws, void* stream) {
+  return fenerf_siren_backward_fmt(m, B, P, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, FENERF_TAPE_F32, d_t, d_e, film_ws, stream);
+}
+
+extern "C" int fenerf_siren_backward_fmt(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                         const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                         const void* tape, int tape_format, float* d_t, float* d_e, void* film_ws, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (int rcf = check_tape_format(m, tape_format)) return rcf;
   if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
   if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
@@ -764,7 +801,7 @@ extern "C" int fenerf_siren_backward(const FenerfModel* m, int B, int64_t P, con
   bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
   bp.fp = fp; bp.pp = pp;
   bp.P = (long long)B * P; bp.pts_per_image = P;
-  bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = d_e;
+  bp.out = out; bp.d_out = d_out; bp.tape = (const float*)tape; bp.tape_format = tape_format; bp.d_t = d_t; bp.d_e = d_e;
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;    // appended to the dtheta dump
   bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
   note_dump(m, d_t, (long long)B * P);
@@ -833,12 +870,21 @@ extern "C" int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P
                                           const float* freq_app, const float* phase_app, const float* out, const float* d_out,
                                           const float* tape, const float* points, float* d_t, float* d_grid_cl, float* scratch_d_e,
                                           void* film_ws, void* stream) {
+  return fenerf_siren_backward_grid_fmt(m, B, P, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, FENERF_TAPE_F32, points, d_t, d_grid_cl,
+                                        scratch_d_e, film_ws, stream);
+}
+
+extern "C" int fenerf_siren_backward_grid_fmt(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                              const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                              const void* tape, int tape_format, const float* points, float* d_t, float* d_grid_cl,
+                                              float* scratch_d_e, void* film_ws, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (!m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "model has no feature grid");
+  if (int rcf = check_tape_format(m, tape_format)) return rcf;
   if (!points || !d_grid_cl) return fail(FENERF_E_INVALID, "points / d_grid_cl is NULL");
   if (!fenerf_siren_backward_fuses_grid(m)) {
     if (!scratch_d_e) return fail(FENERF_E_INVALID, "this model's chain kernel does not scatter in place: scratch_d_e is required");
-    int rc = fenerf_siren_backward(m, B, P, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, d_t, scratch_d_e, film_ws, stream);
+    int rc = fenerf_siren_backward_fmt(m, B, P, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, tape_format, d_t, scratch_d_e, film_ws, stream);
     if (rc || P == 0) return rc;
     { PhaseScope ph(PH_GRID, stream); return launch_grid_backward(m, (long long)B * P, points, scratch_d_e, d_grid_cl, stream); }
   }
@@ -856,7 +902,7 @@ extern "C" int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P
   bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
   bp.fp = fp; bp.pp = pp;
   bp.P = (long long)B * P; bp.pts_per_image = P;
-  bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.d_t = d_t; bp.d_e = nullptr;
+  bp.out = out; bp.d_out = d_out; bp.tape = (const float*)tape; bp.tape_format = tape_format; bp.d_t = d_t; bp.d_e = nullptr;
   bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;
   bp.points = points; bp.d_grid_cl = d_grid_cl; bp.box_scale = m->box_scale; bp.gd = m->gd; bp.gh = m->gh; bp.gw = m->gw;
   bp.bf16_dump = use_bf16_dump(m, (long long)B * P);
@@ -874,7 +920,22 @@ extern "C" int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, 
                                         const float* phase_app, const float* out, const float* d_out, const float* tape,
                                         const float* tape_e, const float* d_t, const FenerfSirenGrads* g, void* workspace,
                                         void* film_ws, void* stream) {
+  return fenerf_siren_param_grads_fmt(m, B, P, points, ray_dirs, freq_geo, phase_geo, freq_app, phase_app, out, d_out, tape, FENERF_TAPE_F32, tape_e,
+                                      d_t, g, nullptr, workspace, film_ws, stream);
+}
+
+extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                            const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                            const float* phase_app, const float* out, const float* d_out, const void* tape,
+                                            int tape_format, const float* tape_e, const float* d_t, const FenerfSirenGrads* g,
+                                            const FenerfSirenGrads* weights, void* workspace, void* film_ws, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (int rcf = check_tape_format(m, tape_format)) return rcf;
+  if (tape_format == FENERF_TAPE_U16) {
+    if (!weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: the FiLM layers' weights are required (the frequency gradients are derived from the weight-gradient sums)");
+    for (int i = 0; i < m->n_geo; ++i) if (!weights->geo_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: weights->geo_w has a NULL entry");
+    for (int i = 0; i < m->n_color; ++i) if (!weights->color_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: weights->color_w has a NULL entry");
+  }
   if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
   if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
@@ -888,12 +949,15 @@ extern "C" int fenerf_siren_param_grads(const FenerfModel* m, int B, int64_t P, 
   want += 4; have += (g->head_w != nullptr) + (g->head_b != nullptr) + (g->rgb_w != nullptr) + (g->rgb_b != nullptr);
   if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
   const bool film_only = have == 0;
+  if (film_only && tape_format == FENERF_TAPE_U16)
+    return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 carries no accumulator: FiLM-only gradients need the fp32 tape");
   int rc = check_dump(m, d_t, (long long)B * P);
   if (rc) return rc;
   const float *fp, *pp;
   rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
   if (rc) return rc;
-  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, tape_e, d_t, *g, film_only, workspace, stream);
+  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, (const float*)tape, tape_e, d_t, *g, film_only, workspace, stream, nullptr,
+                            tape_format, weights);
 }
 
 extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e,

@@ -99,6 +99,7 @@ struct SirenParams {
   // register dumps of the 32-point tiles (fenerf_layout.h "Tape"), and the sampled grid features [P][32]
   float* tape;
   float* tape_e;
+  int tape_format;         // FENERF_TAPE_F32 | FENERF_TAPE_U16 (FENERF_PREC_F16X3 models; fenerf_layout.h "16-bit tape")
   // SPATIALSIRENGRID (siren.py:413-518): fp / pp hold one [L][H] block per POINT instead of per image (fp32 kernel only)
   int film_per_point;
   // fenerf_siren_clock_probe: [gridDim.x][4] = s_memtime / s_memrealtime at a workgroup's first and last instruction, or nullptr
@@ -120,6 +121,7 @@ struct SirenBwdParams {
   const float* out;        // [P][C] forward outputs (sigmoid' of the rgb head)
   const float* d_out;      // [P][C] gradient wrt the outputs
   const float* tape;       // from the forward (tape layout)
+  int tape_format;         // FENERF_TAPE_F32 | FENERF_TAPE_U16 (siren_bwd16w_kernel; the FiLM sums then carry no sum of d theta * tape)
   float* d_t;              // out, tape layout: dL/d(theta_l) = dx_l * cos(theta_l), theta = f (W x + b) + p
   int bf16_dump;           // siren_bwd16w_kernel: write the dump as bf16 [d theta | x = sin(2 pi theta)] halves instead (fenerf_layout.h "bf16 dump")
   float* d_e;              // [P][32] out: gradient wrt the sampled grid features (nullptr without a grid)
@@ -163,9 +165,12 @@ int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void
 bool use_bf16_dump(const FenerfModel* m, long long total_points);   // the dump format of a backward chunk (fenerf_layout.h "bf16 dump"); chain and weight-gradient launches ask the same question
 int bwd16w_film_unit(long long total_points, long long pts_per_image);   // points per FiLM-sum unit of that kernel: 128 (workgroup) or 16 (wave)
 size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
+// tape_format FENERF_TAPE_U16: `weights` = the FiLM layers' weights [dev], nn.Linear layout, in the geo_w / color_w fields (the FiLM
+// frequency gradients are then derived from the weight-gradient partial sums: fenerf_siren_wgrad.hip "frequency gradients without the tape")
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles = nullptr);
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles = nullptr,
+                       int tape_format = 0, const FenerfSirenGrads* weights = nullptr);
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
 // fenerf_render_forward as ONE launch (fenerf_siren_f16w.hip, FUSED): ray groups of whole octs, see there

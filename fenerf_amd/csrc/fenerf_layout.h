@@ -97,6 +97,18 @@ constexpr long long film_tile_floats(long long tiles, int L, int H) { return til
 // (max-norm relative) against fp64 autograd for point-wise random upstream gradients at 65,536 and at 393,216 points alike -- it does
 // not average down with the point count, which is why this is an opt-in training precision and not the default
 // (tests/test_gpu_parity.py::test_siren_backward_at_scale_vs_fp64_autograd).  FiLM sums and dz keep full precision (registers).
+// 16-bit tape (round 5; opt-in per call, FENERF_TAPE_U16, FENERF_PREC_F16X3 models): all the backward needs from a FiLM layer is
+// sin / cos of its phase theta = f'' t + p' (siren.py:113-123), i.e. frac(theta) in revolutions.  The forward-save kernel stores it as
+// 16-bit fixed point, round to nearest -- +-2^-17 rev = +-4.8e-5 rad on every recomputed activation and cosine -- in the bf16 dump's
+// piece layout: a (tile32, layer) block is H*64 bytes,
+//     [nb (H/32)][16-point tile (2)][lane (64)][8 x u16],  lane (n, g) slot t = 4 rt + r: feature dump16_feature(nb, g, t) of point
+//     32 tile32 + 16 (tile & 1) + n
+// -- ONE 16-byte store per lane and n-block in the forward-save kernel (two before), ONE 1-KiB LDS-DMA per body in the chain kernel,
+// 2 instead of 4 bytes per (point, feature) in the chain and in every weight-gradient job that recomputes activations.  What is lost:
+// the raw accumulator t, which only the FiLM FREQUENCY gradient needs (sum_p d theta (W x + b)); it is derived from the weight-gradient
+// partial sums instead (fenerf_siren_wgrad.hip), so inversion -- FiLM gradients only, no weight-gradient launch -- keeps the fp32 tape.
+// Gradient accuracy: 1.1e-4 (max-norm relative, simulated and measured) on top of the 3.5e-5 of the bf16x3 products: between the fp32
+// class (6e-5 asserted) and the AMP class (3e-3), hence a tier of its own (siren.grad_precision = "tape16"), never the default.
 constexpr int dump16_feature(int nb, int g, int t) { return 32 * nb + 16 * (g >> 1) + 4 * (g & 1) + 8 * (t >> 2) + (t & 3); }
 constexpr int tape_feature(int g, int half, int i) { return 32 * (g >> 2) + 8 * (g & 3) + 4 * half + i; }
 

@@ -12,6 +12,11 @@ __device__ __forceinline__ float4 nt_load(const float4* p) {
   const nfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const nfloat4*>(p));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef float nfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 nt_load(const float2* p) {
+  const nfloat2 v = __builtin_nontemporal_load(reinterpret_cast<const nfloat2*>(p));
+  return make_float2(v.x, v.y);
+}
 __device__ __forceinline__ void nt_store(float4* p, float a, float b, float c, float d) {
   const nfloat4 v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<nfloat4*>(p));

@@ -26,6 +26,12 @@
 // ONE 256-B store per n-block instead of eight: 23 MB instead of 184 MB per 131,072-point launch, written here and read by the
 // gather -- otherwise unit = the 16-point tile, each wave storing its own sums.
 //
+// T16 (round 5, fenerf_layout.h "16-bit tape"): the tape holds frac(theta) as 16-bit fixed point in the bf16 dump's piece layout -- ONE
+// 1-KiB tape DMA per body (both row tiles), theta is a convert and a multiply instead of the FiLM fma, and the second FiLM sum (sum of
+// d theta * tape, the frequency gradient's raw material) is not formed: the weight-gradient stage derives the frequency gradient from
+// its own partial sums.  The T16 instantiations live in a second translation unit (fenerf_siren_bwd16w_t16.hip includes this file with
+// FENERF_BW16_T16 = 1) so that the two halves compile side by side.
+//
 // With P.d_grid_cl set (fenerf_siren_backward_grid) the gradient wrt the sampled grid features is not written to d_e: the kernel
 // scatters it into the channels-last gradient grid itself (scatter_pairs below: float atomics, the arithmetic of
 // grid_backward_kernel), two points x 32 channels per atomic instruction, one point pair per body of the following stage.
@@ -38,6 +44,10 @@
 #include "fenerf_internal.h"
 #include "fenerf_layout.h"
 #include "fenerf_trig.h"
+
+#ifndef FENERF_BW16_T16
+#define FENERF_BW16_T16 0
+#endif
 
 namespace fenerf {
 namespace bw16 {
@@ -129,29 +139,32 @@ __device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, cons
 // stage's first count as zero, and the stores are not counted at all (they may retire out of order with the loads): a
 // smaller number, or outstanding stores on top of it, only wait for more.
 // ---------------------------------------------------------------------------------------------------------------------
+// 16-bit tape (`t16`): ONE DMA per body -- both row tiles' phases are one 16-byte piece per lane -- issued by item 2 = E(1), i.e. only
+// after BOTH row tiles of the block that sits in the target staging buffer (same parity, two n-blocks older) have been read: item 0's
+// slot would overwrite the second row tile's half one or two chunk steps before E(1) reads it.
 constexpr int item_chunk(int QB, int k) { return k * (QB < 4 ? QB : 4) / 4; }
-constexpr int step_loads(int QB, int qc) {
+constexpr int step_loads(int QB, int qc, bool t16 = false) {
   int n = 0;
-  for (int k = 0; k < 4; k += 2)
+  for (int k = (t16 ? 2 : 0); k < 4; k += 2)
     if (item_chunk(QB, k) == qc) n += 1;
   return n;
 }
-constexpr int ring_wait(int QB, int s) {
+constexpr int ring_wait(int QB, int s, bool t16 = false) {
   int n = DPF - 2;
   for (int j = 1; j <= DPF - 1; ++j) {
     const int t = s - j;
-    if (t >= 0) n += step_loads(QB, t % QB);
+    if (t >= 0) n += step_loads(QB, t % QB, t16);
   }
   return n;
 }
 
 // One barrier per TWO chunk steps (stages of an even number of steps): the barrier of even step i publishes chunks i + 1 and
 // i + 2 (read during steps i and i + 1), so every wave first waits for its own KiB of chunks <= i + 2.
-constexpr int ring_wait2(int QB, int s) {
+constexpr int ring_wait2(int QB, int s, bool t16 = false) {
   int n = DPF - 3;
   for (int j = 1; j <= DPF - 2; ++j) {
     const int t = s - j;
-    if (t >= 0) n += step_loads(QB, t % QB);
+    if (t >= 0) n += step_loads(QB, t % QB, t16);
   }
   return n;
 }
@@ -230,40 +243,54 @@ struct Sink {
   const char* dt_base;      // global (uniform): d theta dump of (tile32, layer)
   const char* film_base;    // global (uniform): FiLM sums of (tile16, layer)
   unsigned toff;            // lane offset inside a (tile32, layer) dump block: the register-dump position of this lane
+  unsigned ttoff;           // lane offset of the tape DMA: toff, or (16-bit tape) doff
   unsigned doff;            // bf16 dump: lane offset inside an n-block's 2 KiB = 1024 (tile & 1) + 16 lane
   unsigned foff;            // lane offset inside a FiLM-sum n-block
   bool b0, b1;              // lane & 1, lane & 2
 };
-struct EpiIn { float4 f, p, t; };
+struct EpiIn { float4 f, p, t; unsigned tu[2]; };   // t: fp32 tape values; tu (16-bit tape): the row tile's four phases, two per dword
 struct EpiOut { f32x4 dt, dtt; unsigned pd[2], px[2]; };   // pd / px (bf16 dump): d theta and x = sin(2 pi theta) as bf16 pairs
 
-template <int PF4>
+template <int PF4, bool T16>
 __device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tbuf) {
   EpiIn q;
   q.f = *reinterpret_cast<const float4*>(k.film + 32 * nbp + 8 * rt);
-  q.p = *reinterpret_cast<const float4*>(k.film + PF4 + 32 * nbp + 8 * rt);
-  q.t = *reinterpret_cast<const float4*>(k.tape_lane + (tbuf * 2 + rt) * 1024);
+  if (T16) {      // the lane's 16-byte piece of the n-block holds both row tiles: slots 4 rt .. 4 rt + 3 = 8 bytes
+    const uint2 w = *reinterpret_cast<const uint2*>(k.tape_lane + (tbuf * 2) * 1024 + rt * 8);
+    q.tu[0] = w.x; q.tu[1] = w.y;
+  } else {
+    q.p = *reinterpret_cast<const float4*>(k.film + PF4 + 32 * nbp + 8 * rt);
+    q.t = *reinterpret_cast<const float4*>(k.tape_lane + (tbuf * 2 + rt) * 1024);
+  }
   return q;
 }
 
 // E(rt) of n-block nbp: d theta = dx cos(2 pi theta), d z = d theta f'' 2 pi split into bf16 (hi = truncation, lo = the
 // remainder rounded to nearest) -> slots 4 rt .. 4 rt + 3 of k32-step nbp of the next stage's B operand; the d theta store.
 // BD (bf16 dump, header of this file): also x = sin(2 pi theta) -- bitwise the forward's activation -- and both rounded to bf16.
-template <bool BD>
+template <bool BD, bool T16>
 __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, u32x4& yh, u32x4& yl, int rt) {
   [[maybe_unused]] const float TWO_PI = 6.28318530717958647692f;
-  const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w}, p[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, t[4] = {q.t.x, q.t.y, q.t.z, q.t.w};
+  const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w};
   EpiOut o;
   unsigned hb[4];
   float rem[4];
   [[maybe_unused]] float xs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float th = rev_reduce(__builtin_fmaf(f[r], t[r], p[r]));      // fenerf_trig.h: the forward's reduction, bit for bit
+    float th, tr = 0.f;
+    if (T16) {    // frac(theta) as 16-bit fixed point: already reduced to [0, 1) revolutions
+      const unsigned w = q.tu[r >> 1];
+      th = (float)((r & 1) ? (w >> 16) : (w & 0xffffu)) * (1.f / 65536.f);
+    } else {
+      const float p[4] = {q.p.x, q.p.y, q.p.z, q.p.w}, t[4] = {q.t.x, q.t.y, q.t.z, q.t.w};
+      tr = t[r];
+      th = rev_reduce(__builtin_fmaf(f[r], tr, p[r]));      // fenerf_trig.h: the forward's reduction, bit for bit
+    }
     const float dt = acc[r] * cos_rev_reduced(th);
     if (BD) xs[r] = sin_rev_reduced(th);
     o.dt[r] = dt;
-    o.dtt[r] = dt * t[r];
+    o.dtt[r] = dt * tr;        // 16-bit tape: 0 -- no accumulator in the tape; the frequency gradient comes from the weight-gradient partial sums
     const float dz = dt * (f[r] * TWO_PI);
     hb[r] = __builtin_bit_cast(unsigned, dz);
     rem[r] = dz - __builtin_bit_cast(float, hb[r] & 0xffff0000u);
@@ -290,7 +317,7 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   return o;
 }
 
-template <int H, bool GRID, bool WGS, bool BD>
+template <int H, bool GRID, bool WGS, bool BD, bool T16>
 __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = pad_pf16(2 * (H / 16)) / CH;               // chunks per square body
@@ -298,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   constexpr int FILM_F = H * 4 < 1024 ? 1024 : H * 4;           // LDS-DMA moves whole KiBs
   constexpr int FILM_BYTES = 2 * FILM_F;
   constexpr int TL = H * 128;                                   // bytes of one (tile32, layer) dump block
+  constexpr int TLT = T16 ? H * 64 : H * 128;                   // ... of the tape
   // one barrier per two chunk steps where every stage has an even number of steps (H >= 128)
   constexpr bool B2 = (NB * QB) % 2 == 0 && (NB * C0_QB) % 2 == 0 && (!GRID || QB % 2 == 0);
   extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -364,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     const long long img = __builtin_amdgcn_readfirstlane((int)((tile * 16) / P.pts_per_image));
     const float* fp_img = P.fp + (size_t)img * L * H;
     const float* pp_img = P.pp + (size_t)img * L * H;
-    const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TL);
+    const char* tape_tile = uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)tile32 * L * TLT);
     const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
     const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)(WGS ? oct : tile) * L * (2 * H * 4));
     // ---- WGS: per-wave sums -> LDS buffer kb; one step of barriers later the wave whose turn it is combines and stores them
@@ -424,21 +452,31 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     };
     // tape block (nb, rt) of the (tile32, layer) dump at `base` -> staging buffer.  `base` is in SGPRs long before (make_sink): an
     // SGPR written by v_readfirstlane must not feed a vector-memory address within 5 wait states, and nothing checks an asm.
+    // 16-bit tape: the n-block's 2-KiB block holds both 16-point tiles' pieces; this wave's KiB (both row tiles) in one DMA, by E(1) only
+    // (step_loads above: the staging buffer it lands in is read by E(0) AND E(1) of this body first)
     auto tape_issue = [&](const char* base, int nb, int rt, int tbuf, unsigned toff) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(tape_stage) + (tbuf * 2 + rt) * 1024);
-      glds_1k_s_nt(base + (nb * 4 + rt) * 1024, toff, dst);
+      if constexpr (T16) {
+        if (rt == 1) {
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(tape_stage) + (tbuf * 2) * 1024);
+          glds_1k_s_nt(base + nb * 2048, toff, dst);
+        }
+      } else {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(tape_stage) + (tbuf * 2 + rt) * 1024);
+        glds_1k_s_nt(base + (nb * 4 + rt) * 1024, toff, dst);
+      }
     };
     auto make_sink = [&](int layer) -> Sink {
       Sink k;
       k.film = film_lane(layer);
       k.tape_lane = tape_stage + opaque(lane) * 16;
-      k.tape_base = uniform_ptr(tape_tile + (size_t)layer * TL);
-      k.tape_next = uniform_ptr(tape_tile + (size_t)(layer > 0 ? layer - 1 : 0) * TL);
+      k.tape_base = uniform_ptr(tape_tile + (size_t)layer * TLT);
+      k.tape_next = uniform_ptr(tape_tile + (size_t)(layer > 0 ? layer - 1 : 0) * TLT);
       k.dt_base = uniform_ptr(dt_tile + (size_t)layer * TL);
       k.film_base = uniform_ptr(film_tile + (size_t)layer * (2 * H * 4));
       k.toff = lane_toff();
       const int lo = opaque(lane);
       k.doff = (unsigned)(1024 * (int)(tile & 1) + 16 * lo);
+      k.ttoff = T16 ? k.doff : k.toff;
       k.foff = (unsigned)(((lo >> 4) * 4 + (lo & 3)) * 8);
       k.b0 = (lo & 1) != 0; k.b1 = (lo & 2) != 0;
       return k;
@@ -496,20 +534,27 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
       brgb = g == 0 ? dpre[0] : (g == 1 ? dpre[1] : (g == 2 ? dpre[2] : 0.f));
     }
     // the tape of layer L - 1 (all n-blocks) for the rgb stage's own epilogue: plain loads, once per tile
-    float4 t_rgb[NB][2];
+    float4 t_rgb[NB][T16 ? 1 : 2];      // 16-bit tape: one 16-byte piece per n-block (both row tiles)
     {
-      const float4* tp = reinterpret_cast<const float4*>(tape_tile + (size_t)(L - 1) * TL + lane_toff());
+      if constexpr (T16) {
+        const float4* tp = reinterpret_cast<const float4*>(tape_tile + (size_t)(L - 1) * TLT + 1024 * (int)(tile & 1) + 16 * opaque(lane));
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb) t_rgb[nb][0] = tp[nb * 128];
+      } else {
+        const float4* tp = reinterpret_cast<const float4*>(tape_tile + (size_t)(L - 1) * TLT + lane_toff());
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) t_rgb[nb][rt] = tp[(nb * 4 + rt) * 64];
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) t_rgb[nb][T16 ? 0 : rt] = tp[(nb * 4 + rt) * 64];
+      }
     }
     // tape blocks the first pipelined stage (FiLM layer L - 2) finds in flight: n-block 0 (n-block 1 is issued by its body 0)
     {
-      const char* tb = uniform_ptr(tape_tile + (size_t)(L - 2) * TL);
+      const char* tb = uniform_ptr(tape_tile + (size_t)(L - 2) * TLT);
+      const unsigned to0 = T16 ? (unsigned)(1024 * (int)(tile & 1) + 16 * opaque(lane)) : lane_toff();
       asm volatile("s_nop 4" ::: "memory");
-      tape_issue(tb, 0, 0, tpar & 1, lane_toff());
-      tape_issue(tb, 0, 1, tpar & 1, lane_toff());
+      tape_issue(tb, 0, 0, tpar & 1, to0);
+      tape_issue(tb, 0, 1, tpar & 1, to0);      // (16-bit tape: this one is the DMA)
     }
     wait_vmcnt<0>();      // once per tile: film L-1 / L-2, the prologue loads, and the ring prefetch have landed
     __builtin_amdgcn_s_barrier();   // ... in every wave: ring chunks 0 .. D-1 of this tile are visible
@@ -530,9 +575,14 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           const f32x4 acc = MFMA32W(wl[nb * 256 + 8 * rt * 4], brgb, z4);
           EpiIn q;
           q.f = *reinterpret_cast<const float4*>(k.film + 32 * nb + 8 * rt);
-          q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
-          q.t = t_rgb[nb][rt];
-          o2[rt] = epi_compute<BD>(acc, q, zh[nb], zl[nb], rt);
+          if constexpr (T16) {
+            const uint4 w = __builtin_bit_cast(uint4, t_rgb[nb][0]);
+            q.tu[0] = rt ? w.z : w.x; q.tu[1] = rt ? w.w : w.y;
+          } else {
+            q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
+            q.t = t_rgb[nb][T16 ? 0 : rt];
+          }
+          o2[rt] = epi_compute<BD, T16>(acc, q, zh[nb], zl[nb], rt);
           if (!BD && dump) st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o2[rt].dt);
           const f32x2 s = {row_sum4(o2[rt].dt, k.b0, k.b1), row_sum4(o2[rt].dtt, k.b0, k.b1)};
           if (WGS) fs_write(nb % 3, rt, s);
@@ -601,10 +651,10 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           // ---- top of the step: chunk s + 1 (B2: and s + 2) visible to every wave, then (waves 0-3) the DMA of chunk s + D.  The
           // DMA overwrites the slot of chunk s - 2, whose last reads every wave issued before the barrier (B2: of step s or s - 1)
           if constexpr (!B2) {
-            wait_vmcnt<EPI ? ring_wait(QBS, s) : DPF - 2>();
+            wait_vmcnt<EPI ? ring_wait(QBS, s, T16) : DPF - 2>();
             __builtin_amdgcn_s_barrier();
           } else if constexpr ((s & 1) == 0) {
-            wait_vmcnt<EPI ? ring_wait2(QBS, s) : DPF - 3>();
+            wait_vmcnt<EPI ? ring_wait2(QBS, s, T16) : DPF - 3>();
             __builtin_amdgcn_s_barrier();
           }
           LDS_FENCE();
@@ -615,8 +665,13 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
               if (item_chunk(QBS, 2 * rt) == qc) {
-                if constexpr (2 * QB < DPF) wait_vmcnt<2 * QB>();   // (2 QB >= DPF: implied by the ring waits of the 2 QB steps since)
-                q[rt] = epi_read<FILM_F / 4>(k, nb - 1, rt, ((nb - 1) + tpar) & 1);
+                // fp32 tape: the block was issued 2 QB steps ago at the same item position, with 2 QB loads behind it -- for 2 QB >= DPF that is
+                // implied by the ring waits since.  16-bit tape: issued by E(1) of the body two back, i.e. at least QB + (QB - chunk of item 2)
+                // steps ago (a longer colour-layer-0 body in between only adds), with at least the QB ring DMAs + 1 tape DMA of the body in
+                // between behind it.
+                if constexpr (!T16) { if constexpr (2 * QB < DPF) wait_vmcnt<2 * QB>(); }
+                else { if constexpr (2 * QB - item_chunk(QB, 2) < DPF) wait_vmcnt<QB + 1>(); }
+                q[rt] = epi_read<FILM_F / 4, T16>(k, nb - 1, rt, ((nb - 1) + tpar) & 1);
               }
           }
 #pragma unroll
@@ -641,14 +696,14 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   const int rt = it >> 1;
                   if ((it & 1) == 0) {
                     if constexpr (nb > 0) {
-                      eo[rt] = epi_compute<BD>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
+                      eo[rt] = epi_compute<BD, T16>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
                       if constexpr (!BD) { if (dump) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt); }
                       else if (rt == 1) dump_bf16(k, nb - 1, eo, true);
                     }
                     // the tape block two n-blocks ahead of its use: (lo, nb + 1), or the next stage's n-block 0; the last
                     // stage's last body re-fetches (0, 0) so that ring_wait's count holds
-                    if constexpr (nb + 1 < NBODY) tape_issue(k.tape_base, nb + 1, rt, ((nb + 1) + tpar) & 1, k.toff);
-                    else tape_issue(k.tape_next, 0, rt, (NBODY + tpar) & 1, k.toff);
+                    if constexpr (nb + 1 < NBODY) tape_issue(k.tape_base, nb + 1, rt, ((nb + 1) + tpar) & 1, k.ttoff);
+                    else tape_issue(k.tape_next, 0, rt, (NBODY + tpar) & 1, k.ttoff);
                   } else {
                     if constexpr (nb > 0) {
                       const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), row_sum4(eo[rt].dtt, k.b0, k.b1)};
@@ -686,10 +741,11 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           constexpr int c0 = item_chunk(QBS, 0), c1 = item_chunk(QBS, 2);
-          if (rt == 0) wait_vmcnt<2 * QBS - 1 - c0>(); else wait_vmcnt<2 * QBS - 1 - c1>();
+          // (16-bit tape: the block was issued by E(1) of the body before the last: the rt = 1 count holds for both reads)
+          if (rt == 0 && !T16) wait_vmcnt<2 * QBS - 1 - c0>(); else wait_vmcnt<2 * QBS - 1 - c1>();
           LDS_FENCE();
-          const EpiIn q = epi_read<FILM_F / 4>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
-          o2[rt] = epi_compute<BD>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
+          const EpiIn q = epi_read<FILM_F / 4, T16>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
+          o2[rt] = epi_compute<BD, T16>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
           const EpiOut& o = o2[rt];
           if (!BD) { if (dump) st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt); }
           else if (rt == 1) dump_bf16(k, NBODY - 1, o2, true);
@@ -785,10 +841,11 @@ static int hip_fail16w(hipError_t e, const char* what) {
 
 template <int H, bool GRID, bool WGS, bool BD>
 static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  constexpr bool T16 = FENERF_BW16_T16 != 0;
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
                      (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0) + (size_t)NWAVE * 48 * 4;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers + tile points
-  auto kfn = siren_bwd16w_kernel<H, GRID, WGS, BD>;
+  auto kfn = siren_bwd16w_kernel<H, GRID, WGS, BD, T16>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -809,10 +866,12 @@ static int launch_t(const FenerfModel* m, const SirenBwdParams& p, void* stream)
 
 }  // namespace fenerf
 
+#if !FENERF_BW16_T16
 // Test hook (not part of include/fenerf.h): the compile-time wait counts of the chain kernel's stream loop and the schedule they are
 // derived from, so that tests/test_bwd16w_wait_counts.py can replay the in-order load queue on the CPU and check that no wait ever
 // allows more loads in flight than were issued behind the chunk it waits for.  what: 0 = ring_wait(qb, step) (a barrier every step),
-// 1 = ring_wait2(qb, step) (a barrier every second step), 2 = tape DMAs issued in chunk `step` of a body of qb chunks, 3 = DPF.
+// 1 = ring_wait2(qb, step) (a barrier every second step), 2 = tape DMAs issued in chunk `step` of a body of qb chunks, 3 = DPF;
+// 4 / 5 / 6 = the same three for the 16-bit tape (one tape DMA per body).
 extern "C" int fenerf_internal_bwd16w_schedule(int what, int qb, int step) {
   using namespace fenerf::bw16;
   switch (what) {
@@ -820,17 +879,29 @@ extern "C" int fenerf_internal_bwd16w_schedule(int what, int qb, int step) {
     case 1: return ring_wait2(qb, step);
     case 2: return step_loads(qb, step);
     case 3: return DPF;
+    case 4: return ring_wait(qb, step, true);
+    case 5: return ring_wait2(qb, step, true);
+    case 6: return step_loads(qb, step, true);
   }
   return -1;
 }
+#endif
 
 namespace fenerf {
+#if !FENERF_BW16_T16
 // points per FiLM-sum unit of siren_bwd16w_kernel: the workgroup's 128 when an oct cannot straddle images, else the wave's 16
 int bwd16w_film_unit(long long total_points, long long pts_per_image) {
   return (total_points == pts_per_image || pts_per_image % 128 == 0) ? 128 : 16;
 }
+int launch_siren_backward16w_t16(const FenerfModel* m, const SirenBwdParams& p, void* stream);   // fenerf_siren_bwd16w_t16.hip
+#endif
 
+#if FENERF_BW16_T16
+int launch_siren_backward16w_t16(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+#else
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+  if (p.tape_format == FENERF_TAPE_U16) return launch_siren_backward16w_t16(m, p, stream);
+#endif
   if (p.P <= 0) return FENERF_OK;
   const bool g = m->grid_ch != 0;
   switch (m->H) {

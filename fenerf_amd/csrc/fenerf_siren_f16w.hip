@@ -29,7 +29,9 @@
 //
 // Three uses of one kernel template, siren16w_kernel<H, GRID, SAVE, FUSED>:
 //   <.., false, false>  the no-grad forward of fenerf_siren_forward / the two SIREN launches of fenerf_render_forward;
-//   <.., true,  false>  forward-save (fenerf_siren_forward_save): the same tiles, every FiLM layer's accumulators also leave as the tape;
+//   <.., 1 | 2, false>  forward-save (fenerf_siren_forward_save): the same tiles, every FiLM layer's phase also leaves as the tape --
+//                       SAVE = 1: the raw fp32 accumulators (fenerf_layout.h "Tape"); SAVE = 2 (round 5): frac(theta) as 16-bit fixed
+//                       point (fenerf_layout.h "16-bit tape"): half the bytes and half the store instructions;
 //   <.., false, true >  the whole hierarchical render in ONE launch (round 4, fenerf_set_render_fusion): ray groups of whole octs, the
 //                       rays composited by the workgroup's own waves between its coarse and fine tiles -- see FuseArgs below and
 //                       profiles/r04_render_one_launch.md for why it is selectable and not the default (6 % slower).
@@ -106,9 +108,21 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // store per (n-block, row tile): stores are not loads -- they only make the counted vmcnt waits stricter.  asm: uniform base
 // in SGPRs + one VGPR of lane offset; the s_nop is the hazard slot behind a > 8-byte store whose data registers are
 // overwritten next (the compiler does not look inside an asm).
-template <bool ON> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
+template <int MODE> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
+__device__ __forceinline__ void st_u4_nt(const void* g_uniform, unsigned voff, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+}
+// SAVE = 2: the four dwords (two 16-bit phases each) of an n-block that wait for the n-block's last epilogue piece: ONE 16-byte store
+// per lane and n-block, [nb][16-point tile][lane][slot 4 rt + r] (the bf16 dump's layout, dump16_feature)
+struct TapeQ { unsigned q[4]; };
+// frac(theta) in revolutions -> round-to-nearest 16-bit fixed point in the low half of the result (65536 wraps to 0 = the same phase):
+// fr * 2^16 + 2^23 rounds to an integer in the mantissa (RNE)
+__device__ __forceinline__ unsigned phase_u16(float theta) {
+  return __builtin_bit_cast(unsigned, __builtin_fmaf(__builtin_amdgcn_fractf(theta), 65536.f, 8388608.f));
 }
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
@@ -196,12 +210,12 @@ __device__ __forceinline__ FilmQ epi_load(int nbp, int piece, const float* film)
   q.p = *reinterpret_cast<const float2*>(film + PF4 + 32 * nbp + 8 * rt + 2 * pc);
   return q;
 }
-template <int KS, bool SAVE>
+template <int KS, int SAVE>
 __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int piece, const FilmQ& q, half8 (&yh)[KS],
-                                            half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd) {
+                                            half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd, TapeQ& tq) {
   const int rt = piece >> 1, pc = piece & 1;
   const float2 f = q.f, p = q.p;
-  if (SAVE && pc == 0) {
+  if (SAVE == 1 && pc == 0) {
     // register-dump position of this lane: float4 index (4 nb + 2 (g >> 1) + rt) * 64 + 32 (g & 1) + 16 (tile & 1) + n
     const int lo = opaque((int)(threadIdx.x & 63));
     const unsigned toff = (unsigned)(((2 * (lo >> 5)) * 64 + ((lo >> 4) & 1) * 32 + 16 * tile_odd + (lo & 15)) * 16);
@@ -210,8 +224,17 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
   // x = sin(2 pi theta); carried as hi = rn_f16(16 x), lo = rn_f16(16 x - hi).  Written as fmas on x so that each half is ONE
   // v_fma_mix{lo,hi}_f16 (fp32 fma, one rounding to f16; 16 x and 16 x - hi are exact in fp32, so the values are those of the
   // mul / convert / subtract / convert spelling): 8 VALU per two values instead of 14.
-  const float s0 = sin2pi(__builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x));
-  const float s1 = sin2pi(__builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y));
+  const float th0 = __builtin_fmaf(f.x, acc[rt][2 * pc + 0], p.x), th1 = __builtin_fmaf(f.y, acc[rt][2 * pc + 1], p.y);
+  if (SAVE == 2) {
+    tq.q[piece] = __builtin_amdgcn_perm(phase_u16(th1), phase_u16(th0), 0x05040100u);      // [u16 of value 2 pc + 1 | u16 of value 2 pc]
+    if (piece == 3) {
+      const int lo = opaque((int)(threadIdx.x & 63));
+      const u32x4 v = {tq.q[0], tq.q[1], tq.q[2], tq.q[3]};
+      st_u4_nt(tw.base + nbp * 2048, (unsigned)(1024 * tile_odd + 16 * lo), v);
+    }
+  }
+  const float s0 = sin2pi(th0);
+  const float s1 = sin2pi(th1);
   const _Float16 h0 = (_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, 0.f), h1 = (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, 0.f);
   half2 hp = {h0, h1}, lp = {(_Float16)__builtin_fmaf(s0, F16_ACT_SCALE, -(float)h0), (_Float16)__builtin_fmaf(s1, F16_ACT_SCALE, -(float)h1)};
   // pinned here: without a use in this block the compiler sinks the whole epilogue behind the stage (the outputs are only
@@ -221,16 +244,17 @@ __device__ __forceinline__ void epi_compute(const f32x4 (&acc)[2], int nbp, int 
   yh[nbp][s] = hp[0]; yh[nbp][s + 1] = hp[1];
   yl[nbp][s] = lp[0]; yl[nbp][s + 1] = lp[1];
 }
-template <int KS, int PF4, bool SAVE>
+template <int KS, int PF4, int SAVE>
 __device__ __forceinline__ void epi_piece(const f32x4 (&acc)[2], int nbp, int piece, const float* film, half8 (&yh)[KS],
-                                          half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd) {
-  epi_compute<KS, SAVE>(acc, nbp, piece, epi_load<PF4>(nbp, piece, film), yh, yl, tw, tile_odd);
+                                          half8 (&yl)[KS], TapeW<SAVE> tw, int tile_odd, TapeQ& tq) {
+  epi_compute<KS, SAVE>(acc, nbp, piece, epi_load<PF4>(nbp, piece, film), yh, yl, tw, tile_odd, tq);
 }
-template <int KS, int PF4, bool SAVE>
+template <int KS, int PF4, int SAVE>
 __device__ __forceinline__ void epi_all(const f32x4 (&acc)[2], int nbp, const float* film, half8 (&yh)[KS], half8 (&yl)[KS],
                                         TapeW<SAVE> tw, int tile_odd) {
+  TapeQ tq;
 #pragma unroll
-  for (int pc = 0; pc < 4; ++pc) epi_piece<KS, PF4, SAVE>(acc, nbp, pc, film, yh, yl, tw, tile_odd);
+  for (int pc = 0; pc < 4; ++pc) epi_piece<KS, PF4, SAVE>(acc, nbp, pc, film, yh, yl, tw, tile_odd, tq);
 }
 
 // Chunk step i of a stage: barrier (chunk i + 1 visible), then the chunk's two k32-steps.  bop(sp, bh, bl) supplies the B
@@ -307,9 +331,9 @@ template <> struct FuseArgs<true> {
 #endif
 constexpr int FUSED_MAXM = FENERF_EXP_FUSED_MAXM;   // samples per ray (2 N) the ray phases handle: their LDS scratch is the 4-KiB colour-layer-0 block
 
-template <int H, bool GRID, bool SAVE, bool FUSED = false>
+template <int H, bool GRID, int SAVE, bool FUSED = false>
 __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C, FuseArgs<FUSED> F) {
-  static_assert(!(FUSED && SAVE), "the fused render is the no-grad path");
+  static_assert(!(FUSED && SAVE != 0), "the fused render is the no-grad path");
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = (KS + 1) / 2;                              // chunks per square n-block body
   constexpr int C0_KS = KS + (GRID ? 1 : 0) + 1;                // colour layer 0: x | grid | dir
@@ -448,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
     const float qx = px * P.box_scale, qy = py * P.box_scale, qz = pz * P.box_scale;
     // forward-save: this tile's half of the (tile32) tape block of FiLM layer `layer`; phantom tiles of the last oct (clamped
     // points) dump into the slack fenerf_siren_tape_floats keeps behind the last tile
-    constexpr int TL = H * 128;
+    constexpr int TL = SAVE == 2 ? H * 64 : H * 128;       // bytes of a (tile32, layer) block of the tape
     const int tile_odd = (int)(tile & 1);
     const char* tape_tile = SAVE ? uniform_ptr(reinterpret_cast<const char*>(P.tape) + (size_t)(tile >> 1) * L * TL) : nullptr;
     auto tape_of = [&](int layer) {
@@ -577,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           return false;
         };
         f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        TapeQ tq;      // SAVE = 2: the packed phases of n-block nb - 1 between its first and last epilogue piece
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
                 piece_range<C0_QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
-                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd);
+                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd, tq);
               }
             });
           }
@@ -636,6 +661,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           return false;
         };
         f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        TapeQ tq;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -655,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
                 piece_range<QB>(qc, p0, p1);
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc)
-                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd);
+                  if (pc >= p0 && pc < p1) epi_compute<KS, SAVE>(acc_prev, nb - 1, pc, fq.q[pc], yh, yl, tw, tile_odd, tq);
               }
             });
           }
@@ -761,14 +787,14 @@ static size_t lds_bytes_16w(const FenerfModel* m, int H) {
 template <int H, bool GRID>
 static int launch_fused_t(const FenerfModel* m, const SirenParams& p, const FuseArgs<true>& F, int blocks, void* stream) {
   const size_t lds = lds_bytes_16w(m, H) + (2 * sizeof(CompositeParams) + 255) / 256 * 256;
-  auto kfn = siren16w_kernel<H, GRID, false, true>;
+  auto kfn = siren16w_kernel<H, GRID, 0, true>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p, m->n_geo, m->n_color, m->n_lab, m->C, F);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "fused render launch");
 }
 
-template <int H, bool GRID, bool SAVE>
+template <int H, bool GRID, int SAVE>
 static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const size_t lds = lds_bytes_16w(m, H);
   auto kfn = siren16w_kernel<H, GRID, SAVE, false>;
@@ -787,19 +813,27 @@ static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
 // One launch over points whose tiles do not straddle images.
 static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void* stream) {
   const bool g = m->grid_ch != 0;
+  if (q.tape && q.tape_format == FENERF_TAPE_U16) {   // forward-save with the 16-bit tape (round 5)
+    switch (m->H) {
+      case 32: return g ? w16::launch_t<32, true, 2>(m, q, stream) : w16::launch_t<32, false, 2>(m, q, stream);
+      case 64: return g ? w16::launch_t<64, true, 2>(m, q, stream) : w16::launch_t<64, false, 2>(m, q, stream);
+      case 128: return g ? w16::launch_t<128, true, 2>(m, q, stream) : w16::launch_t<128, false, 2>(m, q, stream);
+      case 256: return g ? w16::launch_t<256, true, 2>(m, q, stream) : w16::launch_t<256, false, 2>(m, q, stream);
+    }
+  }
   if (q.tape) {   // forward-save: the same kernel also dumps the tape (and the sampled grid features)
     switch (m->H) {
-      case 32: return g ? w16::launch_t<32, true, true>(m, q, stream) : w16::launch_t<32, false, true>(m, q, stream);
-      case 64: return g ? w16::launch_t<64, true, true>(m, q, stream) : w16::launch_t<64, false, true>(m, q, stream);
-      case 128: return g ? w16::launch_t<128, true, true>(m, q, stream) : w16::launch_t<128, false, true>(m, q, stream);
-      case 256: return g ? w16::launch_t<256, true, true>(m, q, stream) : w16::launch_t<256, false, true>(m, q, stream);
+      case 32: return g ? w16::launch_t<32, true, 1>(m, q, stream) : w16::launch_t<32, false, 1>(m, q, stream);
+      case 64: return g ? w16::launch_t<64, true, 1>(m, q, stream) : w16::launch_t<64, false, 1>(m, q, stream);
+      case 128: return g ? w16::launch_t<128, true, 1>(m, q, stream) : w16::launch_t<128, false, 1>(m, q, stream);
+      case 256: return g ? w16::launch_t<256, true, 1>(m, q, stream) : w16::launch_t<256, false, 1>(m, q, stream);
     }
   }
   switch (m->H) {
-    case 32: return g ? w16::launch_t<32, true, false>(m, q, stream) : w16::launch_t<32, false, false>(m, q, stream);
-    case 64: return g ? w16::launch_t<64, true, false>(m, q, stream) : w16::launch_t<64, false, false>(m, q, stream);
-    case 128: return g ? w16::launch_t<128, true, false>(m, q, stream) : w16::launch_t<128, false, false>(m, q, stream);
-    case 256: return g ? w16::launch_t<256, true, false>(m, q, stream) : w16::launch_t<256, false, false>(m, q, stream);
+    case 32: return g ? w16::launch_t<32, true, 0>(m, q, stream) : w16::launch_t<32, false, 0>(m, q, stream);
+    case 64: return g ? w16::launch_t<64, true, 0>(m, q, stream) : w16::launch_t<64, false, 0>(m, q, stream);
+    case 128: return g ? w16::launch_t<128, true, 0>(m, q, stream) : w16::launch_t<128, false, 0>(m, q, stream);
+    case 256: return g ? w16::launch_t<256, true, 0>(m, q, stream) : w16::launch_t<256, false, 0>(m, q, stream);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

@@ -48,6 +48,7 @@ struct WgradParams {
   int film16w;                 // the sums come from siren_bwd16w_kernel, register-dump order (fenerf_siren_bwd16w.hip): points per unit (16 / 128), 0 = no
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
   int bf16_dump;               // d_t holds the chain kernel's bf16 dump [d theta | x] (fenerf_layout.h "bf16 dump") instead of fp32 d theta
+  int tape_u16;                // `tape` is the 16-bit tape (fenerf_layout.h "16-bit tape"): frac(theta) pieces instead of fp32 accumulators
 };
 
 // Stage one register-dump tile into LDS rows [H][WG_LD]; optional FiLM transform to activations.  The f' / p' rows are
@@ -118,6 +119,23 @@ __device__ __forceinline__ void stage_dump16_f32(const uint4 (&v)[Dump16<H>::PER
   }
 }
 
+// 16-bit tape (fenerf_layout.h): the same pieces hold frac(theta) as u16 -> activation rows x = sin(2 pi frac) (the HEAD / RGB jobs' B side)
+template <int H>
+__device__ __forceinline__ void stage_tape16_sin(const uint4 (&v)[Dump16<H>::PER_THREAD], float* dst, int tid) {
+#pragma unroll
+  for (int q = 0; q < Dump16<H>::PER_THREAD; ++q) {
+    const int s_ = tid + 256 * q;
+    if (Dump16<H>::PIECES % 256 != 0 && s_ >= Dump16<H>::PIECES) continue;
+    const int nb = s_ >> 7, odd = (s_ >> 6) & 1, n = s_ & 15, g = (s_ >> 4) & 3;
+    const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float th = (float)((t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xffffu)) * (1.f / 65536.f);
+      dst[dump16_feature(nb, g, t) * WG_LD + 16 * odd + n] = sin_rev_reduced(th);
+    }
+  }
+}
+
 // JOB: which operands.  MT x KT = output tiles (32x32) of the workgroup; WM x WK = tiles per wave.
 template <int H, int JOB>
 struct WgShape {
@@ -183,7 +201,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   float acc3[3] = {0.f, 0.f, 0.f};   // V3 jobs: this thread's three dot products
 
   float4 va[NQ], vb[NQ];
-  uint4 va16[Dump16<H>::PER_THREAD];
+  uint4 va16[Dump16<H>::PER_THREAD], vb16[Dump16<H>::PER_THREAD];
   // The per-point side inputs of a tile (warped coordinates, grid features + view direction, output-gradient rows) are fetched into
   // registers ONE TILE AHEAD like the dumps (round 3: loaded inside the staging they put one HBM round trip per tile in front of the
   // barrier -- 24 tiles per workgroup, 20-40 % of its time).  Past the chunk's end the last tile is re-read (no branch around loads).
@@ -196,7 +214,10 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
       if (P.bf16_dump) load_dump16<H>(va16, reinterpret_cast<const char*>(dt4 + (tile * L + l) * tl), tid);
       else load_dump<H>(va, dt4 + (tile * L + l) * tl, wave, lane);
     }
-    if (S::B_DUMP) load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
+    if (S::B_DUMP) {
+      if (P.tape_u16) load_dump16<H>(vb16, reinterpret_cast<const char*>(P.tape) + (tile * L + lb) * (long long)(H * 64), tid);
+      else load_dump<H>(vb, tape4 + (tile * L + lb) * tl, wave, lane);
+    }
     if (JOB == WG_L0) {
       if (tid < 96) side_b = P.points[(pt0 + (tid & 31)) * 3 + (tid >> 5)];
     }
@@ -227,7 +248,10 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
       if (P.bf16_dump) stage_dump16_f32<H>(va16, A_s, tid);
       else stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
     }
-    if (S::B_DUMP) stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
+    if (S::B_DUMP) {
+      if (P.tape_u16) stage_tape16_sin<H>(vb16, B_s, tid);
+      else stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
+    }
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
       if (tid < 96) B_s[(tid >> 5) * WG_LD + (tid & 31)] = side_b * P.box_scale;
     }
@@ -427,7 +451,9 @@ template <int H> struct SqWaves { static constexpr int value = H >= 256 ? 8 : 4;
 // accumulator group, and every dump group's registers are refilled with tile t + 2 as soon as they have been staged: one
 // barrier per tile, loads in flight for a whole tile period.  (Staged in a phase of its own, the kernel spent 30 % of a
 // tile in staging and another 30 % waiting for loads that had only the MFMA phase to arrive.)
-template <int H, int NW>
+// T16 (round 5): the B side comes from the 16-bit tape -- 8-byte half-pieces (one point, the four features of a row tile), x =
+// sin(2 pi u / 65536): no FiLM rows, no fma, half the bytes of that stream.
+template <int H, int NW, bool T16>
 __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradParams P) {
   constexpr int NB = H / 32, NG = H / 8;                  // output tiles per side; dump groups per tile
   constexpr int GPW = NG >= NW ? NG / NW : 1;             // dump groups staged per wave
@@ -468,17 +494,24 @@ __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradPa
   static_assert(NW * GPW == NG, "every wave stages GPW dump groups");
 
   float4 va[GPW], vb[GPW];                                  // dump group q of the tile being staged next: dtheta_l, tape_{l-1}
+  uint2 vb16[GPW];                                          // T16: half-piece tid + NW * 64 * q of the tile's 16-bit tape block
   // No branches from here on: a branch inside the MFMA stream makes the compiler's vmcnt bookkeeping conservative (it
   // then waits for the refill loads it has just issued); past the chunk's end the last tile is re-read and never staged.
   auto fetch_q = [&](int t, int q) {
     const long long tile = tile_base + (t < t1 ? t : t1 - 1);
     const int g = wave * GPW + q;
     va[q] = nt_load(dt4 + (tile * L + l) * tl + g * 64 + lane);
-    vb[q] = nt_load(tape4 + (tile * L + lb) * tl + g * 64 + lane);
+    if constexpr (T16) {
+      const float2 w = nt_load(reinterpret_cast<const float2*>(reinterpret_cast<const char*>(P.tape) + (tile * L + lb) * (long long)(H * 64)) + tid + NW * 64 * q);
+      vb16[q] = __builtin_bit_cast(uint2, w);
+    } else {
+      vb[q] = nt_load(tape4 + (tile * L + lb) * tl + g * 64 + lane);
+    }
   };
   // half-piece hp = 2 q + part of the tile in (va, vb) -> buffer dst: part 0 = dtheta rows, part 1 = x = sin(2 pi (f' tape + p')) rows.
   // f4 / p4 = the FiLM rows of the group, fetched from LDS ahead of time (LDS reads do not move across LDS writes).
   auto film_rows = [&](int hp, float4& f4, float4& p4) {
+    if constexpr (T16) return;                              // the phase is in the tape: no FiLM rows
     const int row = tape_feature(wave * GPW + (hp >> 1), half, 0);
     f4 = *reinterpret_cast<const float4*>(f_s + row);
     p4 = *reinterpret_cast<const float4*>(p_s + row);
@@ -490,6 +523,15 @@ __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradPa
       const float4 a = va[q];
       const float d[4] = {a.x, a.y, a.z, a.w};
       stage_split4(reinterpret_cast<unsigned short*>(dst + row * WG_LD) + m, d);
+    } else if constexpr (T16) {
+      // half-piece hs = (16-byte piece s16 = (nb, 16-point tile, lane (n, g)), row tile rt): features dump16_feature(nb, g, 4 rt + r)
+      const int hs = tid + NW * 64 * q, s16 = hs >> 1, rt = hs & 1;
+      const int nb = s16 >> 7, odd = (s16 >> 6) & 1, n = s16 & 15, g = (s16 >> 4) & 3;
+      const unsigned w0 = vb16[q].x, w1 = vb16[q].y;
+      const float k = 1.f / 65536.f;
+      const float x[4] = {sin_rev_reduced((float)(w0 & 0xffffu) * k), sin_rev_reduced((float)(w0 >> 16) * k),
+                          sin_rev_reduced((float)(w1 & 0xffffu) * k), sin_rev_reduced((float)(w1 >> 16) * k)};
+      stage_split4(reinterpret_cast<unsigned short*>(dst + H * WG_LD + dump16_feature(nb, g, 4 * rt) * WG_LD) + 16 * odd + n, x);
     } else {
       const float4 b = vb[q];
       const float x[4] = {sin2pi(__builtin_fmaf(f4.x, b.x, p4.x)), sin2pi(__builtin_fmaf(f4.y, b.y, p4.y)),
@@ -814,23 +856,75 @@ __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int
 }
 
 // all square jobs in one launch: blockIdx.y = layer - 1; destination by layer (nn.Linear layout, FenerfSirenGrads)
-__global__ void wgrad_reduce_sq_kernel(FenerfSirenGrads g, const float* sq, int B, int nchunk, const float* fp, const float* inv, int L, int H,
-                                       int n_geo, int grid_ch) {
+//
+// Frequency gradients without the tape (FREQ; round 5, the 16-bit tape).  dL/dfreq_raw[b][l][n] = 15 sum_p d theta_l[n][p] Z_l[n][p] with
+// Z = W_l x_{l-1} + b_l the layer's pre-activation, which the chain kernel forms from the fp32 tape's accumulator (its second FiLM sum).
+// A tape of phases has no accumulator -- but the per-image partial sums of this very reduction are G_b[n][k] = sum_p d theta_l[n][p]
+// x_{l-1}[k][p], and  sum_p d theta Z = sum_k W_l[n][k] G_b[n][k] + b_l[n] sum_p d theta_l[n][p]  exactly (the second sum is the phase
+// gradient, already reduced by film_reduce_kernel).  So the thread of element (n, k) multiplies its image sum with W_l[n][k] and the
+// row's threads add up (LDS tree, fixed order: deterministic): one extra fma and a row reduction on data that is in registers anyway.
+// `w` = the FiLM layers' weights [dev], nn.Linear layout (geo_w / color_w fields).  Colour layer 0's view-direction and grid-feature
+// columns and layer 0 come from the thin jobs' partials (film_freq_thin_kernel, behind the thin reduction).
+template <bool FREQ>
+__global__ __launch_bounds__(256) void wgrad_reduce_sq_kernel(FenerfSirenGrads g, FenerfSirenGrads w, const float* sq, int B, int nchunk, const float* fp,
+                                                              const float* inv, const float* bias, int L, int H, int n_geo, int grid_ch) {
+  __shared__ float red[256];
   const float TWO_PI = 6.28318530717958647692f;
   const int l = blockIdx.y + 1;
   const float* src = sq + (size_t)(l - 1) * B * nchunk * H * H;
-  float* dst; int ld, col0 = 0;
-  if (l < n_geo) { dst = g.geo_w[l]; ld = H; }
-  else if (l == n_geo) { dst = g.color_w[0]; ld = 3 + grid_ch + H; col0 = 3 + grid_ch; }
-  else { dst = g.color_w[l - n_geo]; ld = H; }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * H; i += gridDim.x * blockDim.x) {
+  float* dst; const float* wl = nullptr; int ld, col0 = 0;
+  if (l < n_geo) { dst = g.geo_w[l]; ld = H; if (FREQ) wl = w.geo_w[l]; }
+  else if (l == n_geo) { dst = g.color_w[0]; ld = 3 + grid_ch + H; col0 = 3 + grid_ch; if (FREQ) wl = w.color_w[0]; }
+  else { dst = g.color_w[l - n_geo]; ld = H; if (FREQ) wl = w.color_w[l - n_geo]; }
+  const int n_color = L - n_geo;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * H; i += gridDim.x * blockDim.x) {      // H * H is a multiple of the block: no ragged trip
     const int r = i / H, c = i % H;
+    const float wv = FREQ ? wl[(size_t)r * ld + col0 + c] : 0.f;
     float sum = 0.f;
     for (int b = 0; b < B; ++b) {
       const float s = sum_chunks<4>(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk);
       sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
+      if (FREQ) {
+        red[threadIdx.x] = s * wv;
+        __syncthreads();
+        const int seg = H < 256 ? H : 256, cs = threadIdx.x % seg;       // H >= 256: the block is (a quarter of ...) one row -- H = 256: the row
+        for (int o = seg >> 1; o >= 1; o >>= 1) {
+          if (cs < o) red[threadIdx.x] += red[threadIdx.x + o];
+          __syncthreads();
+        }
+        if (cs == 0) {
+          float* df = l < n_geo ? g.d_freq_geo + ((size_t)b * n_geo + l) * H + r : g.d_freq_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
+          const float* dp = l < n_geo ? g.d_phase_geo + ((size_t)b * n_geo + l) * H + r : g.d_phase_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
+          *df = 15.f * __builtin_fmaf(bias[(size_t)l * H + r], *dp, red[threadIdx.x]);
+        }
+        __syncthreads();
+      }
     }
     dst[(size_t)r * ld + col0 + c] = sum;
+  }
+}
+
+// The thin jobs' share of the frequency gradients (16-bit tape; see wgrad_reduce_sq_kernel): layer 0 (three warped-coordinate columns,
+// the L0 job's partials [B][nt][H x 32]) and colour layer 0's view-direction + grid-feature columns (the C0X job's [B][nt][H x 64]: grid
+// features in columns 0 .. 31, view direction in 32 .. 34) -- added to what the square reduction left for that layer.  One wave per
+// (row, image): lane = column, 16 load chains per lane over the chunks, a fixed-order shuffle reduction.
+__global__ __launch_bounds__(64) void film_freq_thin_kernel(FenerfSirenGrads g, FenerfSirenGrads w, const float* p_l0, const float* p_c0, int nt,
+                                                            const float* bias, int H, int n_geo, int n_color, int grid_ch) {
+  const int r = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+  const int ldc = 3 + grid_ch + H;
+  float v0 = 0.f, v1 = 0.f;
+  if (c < 3) {
+    v0 = w.geo_w[0][r * 3 + c] * sum_chunks<16>(p_l0 + ((size_t)b * nt * H + r) * 32 + c, (size_t)H * 32, nt);
+  } else if (c < 6) {
+    v1 = w.color_w[0][(size_t)r * ldc + (c - 3)] * sum_chunks<16>(p_c0 + ((size_t)b * nt * H + r) * 64 + 32 + (c - 3), (size_t)H * 64, nt);
+  } else if (c < 6 + grid_ch) {
+    v1 = w.color_w[0][(size_t)r * ldc + 3 + (c - 6)] * sum_chunks<16>(p_c0 + ((size_t)b * nt * H + r) * 64 + (c - 6), (size_t)H * 64, nt);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+  if (c == 0) {
+    g.d_freq_geo[((size_t)b * n_geo) * H + r] = 15.f * __builtin_fmaf(bias[r], g.d_phase_geo[((size_t)b * n_geo) * H + r], v0);
+    g.d_freq_app[((size_t)b * n_color) * H + r] += 15.f * v1;
   }
 }
 
@@ -921,10 +1015,10 @@ int launch_job(const WgradParams& p, int nz, hipStream_t st) {
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad launch");
 }
 
-template <int H>
+template <int H, bool T16>
 int launch_sq_bf16(const WgradParams& p, int nz, hipStream_t st) {
   constexpr int NW = SqWaves<H>::value;
-  auto kfn = siren_wgrad_sq_bf16_kernel<H, NW>;
+  auto kfn = siren_wgrad_sq_bf16_kernel<H, NW, T16>;
   const size_t lds = (size_t)(4 * H * WG_LD + 2 * H) * sizeof(float);     // two [A | B] images + FiLM rows
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(NW * 64), lds, st, p);
@@ -995,7 +1089,8 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
 }
 
 template <int H>
-static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, bool film_only, hipStream_t st) {
+static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenGrads& g, float* ws, bool film_only, hipStream_t st,
+                         const FenerfSirenGrads* weights) {
   const int L = m->L, ng = m->n_geo, B = p.B;
   const int nc = p.nchunk, nt = wgrad_nchunk_thin(m, B, p.tiles_per_image), nf = film_nchunk(p.tiles_per_image), ncm = nf > nt ? nf : nt;
   const int G = m->grid_ch;
@@ -1023,11 +1118,13 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   {
     PhaseScope ph(PH_WGRAD_SQ, st);
     if ((rc = p.bf16_dump ? launch_sq_b16d<H>(p, L - 1, st)
-                          : ((m->precision == FENERF_PREC_F16X3) ? launch_sq_bf16<H>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st)))) return rc;
+                          : ((m->precision == FENERF_PREC_F16X3) ? (p.tape_u16 ? launch_sq_bf16<H, true>(p, L - 1, st) : launch_sq_bf16<H, false>(p, L - 1, st))
+                                                                 : launch_job<H, WG_SQ>(p, L - 1, st)))) return rc;
   }
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
-    hipLaunchKernelGGL(wgrad_reduce_sq_kernel, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, sq, B, nc, p.fp, p.inv, L, H, ng, G);
+    if (p.tape_u16) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
+    else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
   }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
   // side: [H x 32 | H x 64 | 32 x H | 32 x H] per (image, chunk) -- so that ONE launch reduces all of them
@@ -1069,13 +1166,16 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   J.rs_src[1] = rows_rgb; J.rs_dst[1] = g.rgb_b; J.rs_rows[1] = 3;
   PhaseScope ph(PH_WGRAD_THIN_REDUCE, st);
   hipLaunchKernelGGL(wgrad_reduce_thin_kernel, dim3((32 * H + 255) / 256, nm + 2), dim3(256), 0, st, J, B, nt, p.fp, p.inv, L, H);
+  if (p.tape_u16)      // the frequency gradients' thin-job share (reads the same partials; the square job reuses the buffer only in the next call)
+    hipLaunchKernelGGL(film_freq_thin_kernel, dim3(H, B), dim3(64), 0, st, g, *weights, p_l0, p_c0, nt, p.bias, H, ng, L - ng, G);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
 }
 
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
-                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles) {
+                       const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles, int tape_format,
+                       const FenerfSirenGrads* weights) {
   WgradParams p;
   memset(&p, 0, sizeof(p));
   p.tape = tape; p.d_t = d_t; p.film_tiles = film_tiles ? film_tiles : d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
@@ -1086,13 +1186,18 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.P = P; p.tiles_per_image = (int)(P / 32);
   p.film16w = m->precision == FENERF_PREC_F16X3 ? bwd16w_film_unit((long long)B * P, P) : 0;
   p.bf16_dump = use_bf16_dump(m, (long long)B * P);
+  p.tape_u16 = tape_format == FENERF_TAPE_U16;
+  if (p.tape_u16 && (film_only || !weights || m->precision != FENERF_PREC_F16X3 || p.bf16_dump)) {
+    set_error("16-bit tape: needs a FENERF_PREC_F16X3 model with fp32-class weight gradients, a full (not FiLM-only) backward and the FiLM layers' weights");
+    return FENERF_E_INVALID;
+  }
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);
   float* ws = (float*)workspace;
   switch (m->H) {
-    case 32: return param_grads_t<32>(m, p, g, ws, film_only, (hipStream_t)stream);
-    case 64: return param_grads_t<64>(m, p, g, ws, film_only, (hipStream_t)stream);
-    case 128: return param_grads_t<128>(m, p, g, ws, film_only, (hipStream_t)stream);
-    case 256: return param_grads_t<256>(m, p, g, ws, film_only, (hipStream_t)stream);
+    case 32: return param_grads_t<32>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
+    case 64: return param_grads_t<64>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
+    case 128: return param_grads_t<128>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
+    case 256: return param_grads_t<256>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
   }
   set_error("unsupported hidden_dim");
   return FENERF_E_UNSUPPORTED;

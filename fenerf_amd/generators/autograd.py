@@ -51,7 +51,7 @@ class MergeCompositeFunction(torch.autograd.Function):
         return d_f, d_c, None, None, None, None
 
 
-def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params):
+def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params, film_only):
     """Forward of the hierarchical render node (both variants below): coarse forward-save -> (no-grad) coarse weights -> resampled depths
     -> fine forward-save -> merged composite; saves what the backward needs on ctx."""
     dev = origins.device
@@ -73,17 +73,20 @@ def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_
         rd = (torch.cat([rd, rd[:, -1:].expand(-1, Pp - P, -1)], 1) if Pp != P else rd).contiguous()
     pts2 = torch.empty((2 * B, Pp, 3), dtype=torch.float32, device=dev)
     out2 = torch.empty((2 * B, Pp, C), dtype=torch.float32, device=dev)
-    tape2 = torch.empty(L * H * B * Pp + nat.tape_floats(B * Pp), dtype=torch.float32, device=dev)   # pass 1 | pass 2 + slack
+    # the tape's format is fixed here: the 16-bit tape (siren.grad_precision = "tape16") for backward passes that take weight gradients,
+    # the fp32 tape for FiLM-only ones (inversion); `film_only` as the backward will compute it
+    fmt = ctx.tape_format = module.tape_format(nat, film_only=film_only)
+    half = nat.tape_words_per_point(fmt) * B * Pp
+    tape2 = torch.empty(half + nat.tape_floats(B * Pp, fmt), dtype=torch.float32, device=dev)   # pass 1 | pass 2 + slack
     tape_e2 = torch.empty((2 * B * Pp, 32), dtype=torch.float32, device=dev) if G else None
-    half = L * H * B * Pp
     pts2[:B] = samples(z_c)
-    nat.siren_forward_save(pts2[:B], rd, fg, pg, fa, pa, out=out2[:B], tape=tape2[:half], tape_e=tape_e2[:B * Pp] if G else None)
+    nat.siren_forward_save(pts2[:B], rd, fg, pg, fa, pa, out=out2[:B], tape=tape2[:half], tape_e=tape_e2[:B * Pp] if G else None, tape_format=fmt)
     coarse = out2[:B, :P].reshape(B * R, N, C)
     zc = z_c.reshape(B * R, N)
     _, _, w_c, _ = native.composite(coarse, zc, noise_c, copts, want_wsum=False)
     z_f = native.resample(zc, w_c, u)
     pts2[B:] = samples(z_f.reshape(B, R, N))
-    nat.siren_forward_save(pts2[B:], rd, fg, pg, fa, pa, out=out2[B:], tape=tape2[half:], tape_e=tape_e2[B * Pp:] if G else None)
+    nat.siren_forward_save(pts2[B:], rd, fg, pg, fa, pa, out=out2[B:], tape=tape2[half:], tape_e=tape_e2[B * Pp:] if G else None, tape_format=fmt)
     fine = out2[B:, :P].reshape(B * R, N, C)
     rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
     ctx.module, ctx.nat, ctx.opts, ctx.dims = module, nat, opts, (B, R, N, P, Pp)
@@ -107,7 +110,8 @@ class HierarchicalRenderFunction(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, *params):
-        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params)
+        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params,
+                                     film_only=not any(ctx.needs_input_grad[14:]))
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -133,7 +137,8 @@ class HierarchicalRenderFunction(torch.autograd.Function):
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         film_only = not any(need[14:])
         r, d_grid = _siren_autograd.chunked_backward(nat, 2 * B, Pp, film2, pts2, rd2, out2, d_out2, tape2,
-                                                  tape_e2 if tape_e2.numel() else None, film_only)
+                                                  tape_e2 if tape_e2.numel() else None, film_only, tape_format=ctx.tape_format,
+                                                  weights=_siren_autograd.film_layer_weights(module, params) if ctx.tape_format else None)
         fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
         film_grads = (fold(r["d_freq_geo"], need[10]), fold(r["d_phase_geo"], need[11]), fold(r["d_freq_app"], need[12]),
                       fold(r["d_phase_app"], need[13]))
@@ -183,7 +188,8 @@ class HierarchicalWeightStage(torch.autograd.Function):
         module, nat, B = ctx.module, w["nat"], w["B"]
         need = ctx.needs_input_grad
         r = _siren_autograd.run_weight_grads(nat, 2 * B, w["Pp"], w["film2"], w["pts2"], w["rd2"], w["out2"], w["d_out2"], w["tape2"], w["tape_e2"],
-                                             w["chunks"], w["dumps"])
+                                             w["chunks"], w["dumps"], tape_format=w["tape_format"],
+                                             weights=_siren_autograd.film_layer_weights(module, w["params"]) if w["tape_format"] else None)
         fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
         film_grads = (fold(r["d_freq_geo"], need[2]), fold(r["d_phase_geo"], need[3]), fold(r["d_freq_app"], need[4]), fold(r["d_phase_app"], need[5]))
         params = w["params"]                                    # module._render_params() order, grid included
@@ -201,7 +207,8 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, state, token, grid, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa):
         ctx.state = state
-        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, ())
+        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, (),
+                                     film_only=False)        # the split form exists for training steps: weight gradients are taken
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -225,9 +232,9 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
         film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         chunks = _siren_autograd.plan_chunks(2 * B, Pp)
-        dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, chunks)
+        dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, chunks, tape_format=ctx.tape_format)
         state = ctx.state
-        state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2,
+        state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2, tape_format=ctx.tape_format,
                           tape_e2=tape_e2 if tape_e2.numel() else None, chunks=chunks, dumps=dumps, params=module._render_params())
         # The dumps (as large as the tape) belong to THIS backward pass: if the weight stage does not consume them -- torch.autograd.grad
         # with only the grid as input, an exception between the two stages -- they are dropped when the engine finishes the pass, not

@@ -361,21 +361,28 @@ class NativeModel:
                                                                          sl(pa), _ptr(out[b, s:s + n]), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
-    def tape_floats(self, total_points):
-        """floats of a tape for total_points points (L*H per point + the slack the kernel's last workgroup may write)"""
-        return int(_lib.lib().fenerf_siren_tape_floats(self._h, total_points))
+    def tape_floats(self, total_points, tape_format=0):
+        """fp32 words of a tape for total_points points (L*H values per point + the slack the kernel's last workgroup may write; the
+        16-bit tape, _lib.TAPE_U16, packs two values per word)"""
+        return int(_lib.lib().fenerf_siren_tape_bytes(self._h, total_points, int(tape_format))) // 4
 
-    def dump_bytes_per_point(self, chunk_points=None):
-        """HBM bytes per (point x layer-feature) of the backward streams of a chunk (fenerf_siren_backward_stream_bytes):
+    def tape_words_per_point(self, tape_format=0):
+        """fp32 words of tape per point (L*H, or half of it for the 16-bit tape): the stride of a point range inside a tape buffer"""
+        LH = (self.spec["n_geo"] + self.spec["n_color"]) * self.spec["hidden_dim"]
+        return LH // 2 if tape_format == _lib.TAPE_U16 else LH
+
+    def dump_bytes_per_point(self, chunk_points=None, tape_format=0):
+        """HBM bytes per (point x layer-feature) of the backward streams of a chunk (fenerf_siren_backward_stream_bytes_fmt):
         dict(chain_write, square_read, thin_read, tape)."""
         from .siren import autograd as _sa
         res = (C.c_double * 4)()
-        _lib.check(_lib.lib().fenerf_siren_backward_stream_bytes(self._h, int(chunk_points or _sa.BACKWARD_CHUNK_POINTS), res))
+        _lib.check(_lib.lib().fenerf_siren_backward_stream_bytes_fmt(self._h, int(chunk_points or _sa.BACKWARD_CHUNK_POINTS), int(tape_format), res))
         return dict(chain_write=res[0], square_read=res[1], thin_read=res[2], tape_layer=res[3])
 
-    def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa, out=None, tape=None, tape_e=None):
+    def siren_forward_save(self, points, ray_dirs, fg, pg, fa, pa, out=None, tape=None, tape_e=None, tape_format=0):
         """Differentiable evaluation: like siren_forward, also returns the tape (pre-FiLM accumulators, tape_floats(B*P) floats
-        of 32-point register dumps) and the sampled grid features [B*P,32] (None without a grid) that siren_backward consumes.
+        of 32-point register dumps -- or, tape_format = _lib.TAPE_U16, the 16-bit phases of fenerf_layout.h "16-bit tape") and the
+        sampled grid features [B*P,32] (None without a grid) that siren_backward consumes.
         out / tape / tape_e may be preallocated (contiguous views into larger buffers: several passes, one backward)."""
         B, P = points.shape[0], points.shape[1]
         H, L = self.spec["hidden_dim"], self.spec["n_geo"] + self.spec["n_color"]
@@ -385,18 +392,18 @@ class NativeModel:
         if out is None:
             out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
         if tape is None:
-            tape = torch.empty((self.tape_floats(B * P),), dtype=torch.float32, device=self.device)
+            tape = torch.empty((self.tape_floats(B * P, tape_format),), dtype=torch.float32, device=self.device)
         if tape_e is None and self.spec["grid_ch"]:
             tape_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device)
-        assert out.numel() == B * P * self.C and tape.numel() >= L * H * B * P    # + tape_floats' slack behind the last pass
+        assert out.numel() == B * P * self.C and tape.numel() >= self.tape_words_per_point(tape_format) * B * P    # + the slack behind the last pass
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
-            _lib.check(_lib.lib().fenerf_siren_forward_save(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa),
-                                                            _ptr(pa), _ptr(out), _ptr(tape), _ptr(tape_e), C.c_void_p(ws.data_ptr()),
-                                                            _stream()))
+            _lib.check(_lib.lib().fenerf_siren_forward_save_fmt(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa),
+                                                                _ptr(pa), _ptr(out), _ptr(tape), _ptr(tape_e), C.c_void_p(ws.data_ptr()),
+                                                                int(tape_format), _stream()))
         return out, tape, tape_e
 
-    def siren_backward(self, B, P, fg, pg, fa, pa, out, d_out, tape):
+    def siren_backward(self, B, P, fg, pg, fa, pa, out, d_out, tape, tape_format=0):
         """-> (d_t = dL/dtheta per FiLM layer in the tape's layout + the per-tile FiLM sums (opaque, fenerf_siren_dtheta_floats),
         d_e [B*P,32] or None)"""
         fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
@@ -405,8 +412,8 @@ class NativeModel:
         d_e = torch.empty((B * P, 32), dtype=torch.float32, device=self.device) if self.spec["grid_ch"] else None
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
-            _lib.check(_lib.lib().fenerf_siren_backward(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
-                                                        _ptr(tape), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
+            _lib.check(_lib.lib().fenerf_siren_backward_fmt(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
+                                                            _ptr(tape), int(tape_format), _ptr(d_t), _ptr(d_e), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t, d_e
 
     def film_sums_floats(self, B, P):
@@ -448,7 +455,7 @@ class NativeModel:
                                                  C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
         return res
 
-    def siren_backward_grid(self, B, P, fg, pg, fa, pa, out, d_out, tape, points, d_grid_cl):
+    def siren_backward_grid(self, B, P, fg, pg, fa, pa, out, d_out, tape, points, d_grid_cl, tape_format=0):
         """siren_backward whose gradient wrt the sampled grid features is scattered (accumulated) straight into d_grid_cl
         [D,H,W,32] (zero-initialised by the caller before the first chunk) -> d_t.  f16x3 models scatter inside the chain kernel;
         others run the chain and the scatter kernel over a scratch d_e."""
@@ -460,9 +467,9 @@ class NativeModel:
         scratch = None if fused else torch.empty((B * P, 32), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._workspace("film", _lib.lib().fenerf_film_workspace_bytes(self._h, B))
-            _lib.check(_lib.lib().fenerf_siren_backward_grid(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
-                                                             _ptr(tape), _ptr(points), _ptr(d_t), _ptr(d_grid_cl), _ptr(scratch),
-                                                             C.c_void_p(ws.data_ptr()), _stream()))
+            _lib.check(_lib.lib().fenerf_siren_backward_grid_fmt(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out),
+                                                                 _ptr(tape), int(tape_format), _ptr(points), _ptr(d_t), _ptr(d_grid_cl),
+                                                                 _ptr(scratch), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t
 
     def grid_gradient_ncdhw(self, d_grid_cl):
@@ -473,10 +480,11 @@ class NativeModel:
             _lib.check(_lib.lib().fenerf_grid_gradient_ncdhw(self._h, _ptr(d_grid_cl), _ptr(out), _stream()))
         return out
 
-    def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t, film_only=False):
+    def siren_param_grads(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape, tape_e, d_t, film_only=False, tape_format=0, weights=None):
         """(tape, d_t) -> dict of parameter gradients in nn.Linear layout: geo_w/geo_b/color_w/color_b lists, head_w [32,H]
         (folded label rows + sigma row), head_b [32], rgb_w [3,H], rgb_b [3], d_freq_geo / d_phase_geo [B,n_geo*H],
-        d_freq_app / d_phase_app [B,n_color*H]."""
+        d_freq_app / d_phase_app [B,n_color*H].  tape_format = _lib.TAPE_U16 needs `weights` = (geo weights, colour weights): the
+        FiLM layers' nn.Linear weight tensors on the device (the frequency gradients are formed from the weight-gradient sums)."""
         sp = self.spec
         H, ng, nc, G = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["grid_ch"]
         B, P = points.shape[0], points.shape[1]
@@ -500,9 +508,17 @@ class NativeModel:
         with torch.cuda.device(dev):
             fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
             ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
-            _lib.check(l.fenerf_siren_param_grads(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
-                                                  _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), _ptr(tape_e),
-                                                  _ptr(d_t), C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
+            wts, keep = None, []
+            if weights is not None:
+                wts = _lib.FenerfSirenGrads()
+                for i, w in enumerate(weights[0]):
+                    keep.append(_f32(w.detach(), dev)); wts.geo_w[i] = keep[-1].data_ptr()
+                for i, w in enumerate(weights[1]):
+                    keep.append(_f32(w.detach(), dev)); wts.color_w[i] = keep[-1].data_ptr()
+            _lib.check(l.fenerf_siren_param_grads_fmt(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
+                                                      _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), int(tape_format),
+                                                      _ptr(tape_e), _ptr(d_t), C.byref(g), C.byref(wts) if wts is not None else None,
+                                                      C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
         return res
 
     def grid_backward(self, points, d_e, grid_shape):

@@ -115,7 +115,13 @@ def _add_all(dst, src):
         torch._foreach_add_(dst, src)
 
 
-def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None):
+def film_layer_weights(module, params):
+    """(geometry FiLM-layer weights, colour FiLM-layer weights) of module._render_params(): what the 16-bit tape's frequency gradients need"""
+    roles = module._roles(params)
+    return [W for W, _ in roles["geo"]], [W for W, _ in roles["color"]]
+
+
+def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None, tape_format=0, weights=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
     `max_points` points: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per image, and every gradient
     is a sum over points, so chunk results simply add.  A chunk is a run of WHOLE images while those fit (the curriculum's early
@@ -123,10 +129,11 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     workgroups do not); an image larger than `max_points` is split into point ranges of its own.  The gradient wrt the sampled grid
     features never exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid;
     inside the chain kernel for f16x3 models).
+    tape_format / weights: the tape's format (_lib.TAPE_*) and, for the 16-bit tape, film_layer_weights(...).
     -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
-    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    LH = nat.tape_words_per_point(tape_format)          # fp32 words of tape per point
     G = nat.spec["grid_ch"]
     C = nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
@@ -189,9 +196,9 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
         out_c, d_out_c, pts_c = out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], points[b:b + nb, s:s + n]
         with native.cu_budget(chain_cus if (overlap and i > 0) else 0):      # chain i runs beside the weight gradients of chunk i - 1
             if G and not film_only:
-                d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid)
+                d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid, tape_format=tape_format)
             else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
-                d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c)
+                d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c, tape_format=tape_format)
         if overlap:
             ev = torch.cuda.Event()
             ev.record(main)
@@ -200,7 +207,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             keep.append(d_t)
         with torch.cuda.stream(side), native.cu_budget(wgrad_cus if (overlap and not last) else 0):
             r = nat.siren_param_grads(pts_c, dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c, out_c, d_out_c, tape_c,
-                                      tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only)
+                                      tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only, tape_format=tape_format, weights=weights)
             del d_t
             if total is None:
                 total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
@@ -243,12 +250,12 @@ def plan_chunks(nB, Pp, max_points=None):
     return [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
 
 
-def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks):
+def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks, tape_format=0):
     """First half of a SPLIT backward (generators/autograd.py HierarchicalRenderSplitFunction): every chunk's chain launch, nothing else.
     -> ([d(theta) dump per chunk], d_grid_cl or None).  All dumps are alive together afterwards (as large as the tape: the price of
     handing the grid gradient -- final once the last chain has run -- to autograd / DistributedDataParallel BEFORE the weight-gradient
     kernels, so that its all-reduce runs beside them)."""
-    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    LH = nat.tape_words_per_point(tape_format)
     G, C = nat.spec["grid_ch"], nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
     d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G else None
@@ -258,16 +265,17 @@ def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks):
         g0 = b * Pp + s
         tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
         if G:
-            dumps.append(nat.siren_backward_grid(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, points[b:b + nb, s:s + n], d_grid))
+            dumps.append(nat.siren_backward_grid(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, points[b:b + nb, s:s + n], d_grid,
+                                                 tape_format=tape_format))
         else:
-            dumps.append(nat.siren_backward(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c)[0])
+            dumps.append(nat.siren_backward(nb, n, *film_c, out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, tape_format=tape_format)[0])
     return dumps, d_grid
 
 
-def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, chunks, dumps):
+def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, chunks, dumps, tape_format=0, weights=None):
     """Second half of a split backward: the weight-gradient launches of every chunk over the dumps run_chains left, summed like
     chunked_backward does.  Frees each dump after its chunk.  -> grads dict (FiLM gradients with [nB] leading)."""
-    LH = (nat.spec["n_geo"] + nat.spec["n_color"]) * nat.spec["hidden_dim"]
+    LH = nat.tape_words_per_point(tape_format)
     G, C = nat.spec["grid_ch"], nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
     total, film_rows, acc_img = None, {k: [] for k in FILM_KEYS}, None
@@ -277,7 +285,8 @@ def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
         tape_c = tape[g0 * LH:(g0 + nb * n) * LH]
         d_t, dumps[i] = dumps[i], None
         r = nat.siren_param_grads(points[b:b + nb, s:s + n], dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c,
-                                  out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, tape_e[g0:g0 + nb * n] if G else None, d_t)
+                                  out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, tape_e[g0:g0 + nb * n] if G else None, d_t,
+                                  tape_format=tape_format, weights=weights)
         del d_t
         if total is None:
             total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
@@ -311,7 +320,10 @@ class SirenFunction(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast (the reference's training loop) inputs arrive as fp16
     def forward(ctx, module, points, dirs, fg, pg, fa, pa, *params):
         nat = module.native_differentiable(points.device)
-        out, tape, tape_e = nat.siren_forward_save(points, dirs, fg, pg, fa, pa)
+        # the tape's format is fixed at forward time: a backward that takes weight gradients may use the 16-bit tape (siren.grad_precision =
+        # "tape16"), a FiLM-only one (inversion) needs the accumulators of the fp32 tape
+        ctx.tape_format = module.tape_format(nat, film_only=not any(ctx.needs_input_grad[7:]))
+        out, tape, tape_e = nat.siren_forward_save(points, dirs, fg, pg, fa, pa, tape_format=ctx.tape_format)
         ctx.module, ctx.nat = module, nat
         ctx.pack_generation = nat.pack_generation
         ctx.has_dirs = dirs is not None
@@ -334,7 +346,8 @@ class SirenFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         film_only = not any(need[7:])        # inversion: only the FiLM parameters are optimised
         r, d_grid = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
-                                     tape_e if tape_e.numel() else None, film_only)
+                                     tape_e if tape_e.numel() else None, film_only, tape_format=ctx.tape_format,
+                                     weights=film_layer_weights(module, params) if ctx.tape_format else None)
         film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
                       r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
         if film_only:

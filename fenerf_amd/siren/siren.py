@@ -128,8 +128,17 @@ class _NativeSiren(nn.Module):
     # chunks of >= AMP_MIN_POINTS points the chain kernel hands d theta and the layer inputs to the weight-gradient kernel as bf16 (one
     # MFMA per product, fp32 accumulate) -- unbiased, ~1e-3 of a gradient entry's per-point noise floor: the class of the reference's
     # own autocast training loop (train_double_latent_semantic.py:402-446), 13 % less step time.  Never the default.
+    # "tape16" (round 5, f16x3 models) = fp32-class operands, but the tape between forward and backward holds frac(theta) as 16-bit fixed
+    # point instead of the fp32 accumulators (include/fenerf.h FENERF_TAPE_U16): half the tape bytes in three kernels, +-4.8e-5 rad on
+    # every recomputed activation, gradients within ~1.2e-4 of fp64 autograd instead of ~4e-5 -- a tier between the two.  Applies to
+    # backward passes that take weight gradients; inversion (FiLM gradients only) keeps the fp32 tape whatever this says.
     grad_precision = "f32"
     AMP_MIN_POINTS = 65536
+
+    def tape_format(self, nat, film_only):
+        """the tape format (_lib.TAPE_*) a differentiable evaluation on `nat` uses"""
+        from .. import _lib
+        return _lib.TAPE_U16 if (self.grad_precision == "tape16" and nat.precision == "f16x3" and not film_only) else _lib.TAPE_F32
 
     def _spec(self):
         H = self.hidden_dim

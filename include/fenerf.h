@@ -59,6 +59,13 @@ enum {
 #define FENERF_MAX_GEO 8
 #define FENERF_MAX_COLOR 4
 #define FENERF_MAX_LABEL_LAYERS 3
+/* Format of the tape fenerf_siren_forward_save_fmt writes and the backward entry points read (FENERF_PREC_F16X3 models; exact-fp32
+ * models keep FENERF_TAPE_F32):  F32 = the pre-FiLM accumulators, 4 bytes per (point, FiLM-layer feature) -- everything the backward
+ * may want; U16 = frac(theta) as 16-bit fixed point, 2 bytes -- all that sin / cos need (siren.py:113-123), +-4.8e-5 rad per recomputed
+ * activation, gradients within ~1.2e-4 (max-norm relative) of fp64 autograd instead of ~4e-5: a tier between the fp32 class and the
+ * AMP class.  Not for the FiLM-only backward (fenerf_siren_backward_film: the frequency gradient needs the accumulator). */
+#define FENERF_TAPE_F32 0
+#define FENERF_TAPE_U16 1
 
 typedef struct FenerfModelDesc {
   int32_t abi_version;      /* FENERF_ABI_VERSION */
@@ -371,6 +378,31 @@ typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in
 
 size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
 size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points);
+/* The *_fmt entry points (round 5) are the calls above for a tape in `tape_format` (FENERF_TAPE_F32 = what the calls above use;
+ * FENERF_TAPE_U16 = frac(theta) as 16-bit fixed point, see the definition of the constants): the same tape format must be given to the
+ * forward-save, the chain and the weight-gradient call of one evaluation.  replaces: the same reference lines as their plain
+ * counterparts -- FiLMLayer saves its input and theta for autograd (siren.py:113-123); sin / cos of theta are all its backward reads.
+ * fenerf_siren_tape_bytes: bytes of a tape (fenerf_siren_tape_floats * 4 or * 2).  fenerf_siren_param_grads_fmt with FENERF_TAPE_U16
+ * also takes `weights`: the FiLM layers' weights [dev], nn.Linear layout, in the geo_w / color_w fields of a FenerfSirenGrads (read
+ * only; every other field ignored) -- the FiLM frequency gradient sum_p d theta (W x + b) is then formed from the weight-gradient sums
+ * sum_p d theta x^T and W, because a tape of phases does not hold W x; all weight / bias outputs are required (no FiLM-only mode). */
+size_t fenerf_siren_tape_bytes(const FenerfModel* m, int64_t total_points, int tape_format);
+int fenerf_siren_forward_save_fmt(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                  const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                                  float* out, void* tape, float* tape_e, void* film_ws, int tape_format, void* stream);
+int fenerf_siren_backward_fmt(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                              const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                              const void* tape, int tape_format, float* d_t, float* d_e, void* film_ws, void* stream);
+int fenerf_siren_backward_grid_fmt(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                   const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                   const void* tape, int tape_format, const float* points, float* d_t, float* d_grid_cl,
+                                   float* scratch_d_e, void* film_ws, void* stream);
+int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                 const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                                 const float* out, const float* d_out, const void* tape, int tape_format, const float* tape_e,
+                                 const float* d_t, const FenerfSirenGrads* g, const FenerfSirenGrads* weights, void* workspace,
+                                 void* film_ws, void* stream);
+int fenerf_siren_backward_stream_bytes_fmt(const FenerfModel* m, int64_t chunk_points, int tape_format, double* out4);
 /* HBM bytes per (sample point x FiLM-layer feature) of the backward streams of a chunk of `chunk_points` points (bench.py's generator-step
  * roofline): out[0] = what the chain kernel writes into the dump, out[1] = what the square weight-gradient job reads for one of its L - 1
  * layers (the dump of layer l + the input activations of layer l), out[2] = the four thin jobs together (two dump layers + two

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-5 GPU session script (run through gpurun): targeted tests first, then timing.  Everything goes to gpurun_out/.
+mkdir -p gpurun_out
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+export TMPDIR=/tmp
+which="${1:-all}"
+if [ "$which" = "tape16" ] || [ "$which" = "all" ]; then
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -q -s -x -k "16bit_tape or tape16" > gpurun_out/r5_tape16_tests.log 2>&1
+  echo "tape16 tests rc=$?"; tail -3 gpurun_out/r5_tape16_tests.log
+fi
+if [ "$which" = "new" ] || [ "$which" = "all" ]; then
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -q -s -k "trained or inversion_reproduces or test_siren_forward_vs_reference or test_forward_with_frequencies_vs_reference or test_full_size or fp64_arbiter or test_config5 or far_beyond_the_init_range or mapping_network_native or split_backward or staged_forward_with_frequencies_vs_reference or forward_and_staged" > gpurun_out/r5_new_tests.log 2>&1
+  echo "new tests rc=$?"; tail -3 gpurun_out/r5_new_tests.log
+fi
+if [ "$which" = "bench" ] || [ "$which" = "all" ]; then
+  timeout 900 python bench.py --no-gstep-ddp --no-gstep-b6 --quick-cpu-baseline > gpurun_out/r5_bench_quick.log 2>&1
+  echo "bench rc=$?"; tail -c 3000 gpurun_out/r5_bench_quick.log
+fi
