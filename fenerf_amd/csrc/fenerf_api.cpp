@@ -1110,3 +1110,379 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   cp.out_ch = out_channels(m->C, opts);
   return run_composite(cp, true, stream);
 }
+
+// =====================================================================================================================================
+// The differentiable hierarchical render as TWO calls (round 5; SURVEY.md 8b "fenerf_render_backward"): what rounds 1-4 orchestrated in
+// Python (fenerf_amd/generators/autograd.py::_hierarchical_forward / HierarchicalRenderFunction.backward, siren/autograd.py::
+// chunked_backward: ~600 lines of chunk planning, workspace carving, launch order and gradient sums) lives here, so that a host that is
+// not Python can take a generator step (generators.py:479-527 + g_loss.backward(), train_double_latent_semantic.py:402-446) with two
+// entry points, and so that the Python host's step has no glue launches left between the library's kernels.
+// =====================================================================================================================================
+namespace {
+const long long kDefaultChunkPoints = 393216;          // one pass of a 128 x 128 x 24 image: profiles/r04_gstep_overlap.md (chunk-size sweep)
+const long long kDefaultFilmSumsBudget = 1LL << 30;    // bytes of per-unit FiLM sums one FiLM-only chain launch may write
+
+struct RenderSave {     // byte offsets into the caller's `save` buffer (everything the backward needs that the caller does not hold)
+  long long P, Pp;
+  size_t fp2, pp2, pts2, rd, out2, tape2, tape_half, tape_e2, zf, rows_c, rows_f, total;
+};
+RenderSave render_save(const FenerfModel* m, int B, int R, int N, int tape_format, int lock_view) {
+  RenderSave s;
+  s.P = (long long)R * N;
+  s.Pp = (s.P + 31) / 32 * 32;
+  const size_t Pp = (size_t)s.Pp, P = (size_t)s.P;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  s.fp2 = take((size_t)2 * B * m->L * m->H * sizeof(float));
+  s.pp2 = take((size_t)2 * B * m->L * m->H * sizeof(float));
+  s.pts2 = take((size_t)2 * B * Pp * 3 * sizeof(float));
+  s.rd = take(lock_view ? 0 : (size_t)2 * B * Pp * 3 * sizeof(float));     // per-point view directions, once per pass (a backward chunk may span both)
+  s.out2 = take((size_t)2 * B * Pp * m->C * sizeof(float));
+  s.tape_half = (size_t)(tape_format == FENERF_TAPE_U16 ? 2 : 4) * m->L * m->H * B * Pp;     // pass 1 | pass 2 + the slack behind the last tile
+  s.tape2 = take(s.tape_half + fenerf_siren_tape_bytes(m, (int64_t)B * s.Pp, tape_format));
+  s.tape_e2 = take(m->grid_ch ? (size_t)2 * B * Pp * 32 * sizeof(float) : 0);
+  s.zf = take((size_t)B * P * sizeof(float));
+  s.rows_c = take(Pp != P ? (size_t)B * P * m->C * sizeof(float) : 0);      // unpadded row copies for the composite kernels (ragged shapes only)
+  s.rows_f = take(Pp != P ? (size_t)B * P * m->C * sizeof(float) : 0);
+  s.total = off;
+  return s;
+}
+
+struct Chunk { int b, nb; long long s, n; };
+std::vector<Chunk> plan_chunks(int nB, long long Pp, long long max_points) {
+  max_points = max_points / 128 * 128;
+  if (max_points < 128) max_points = 128;
+  std::vector<Chunk> c;
+  if (Pp <= max_points) {
+    const int per = (int)(max_points / Pp) < 1 ? 1 : (int)(max_points / Pp);
+    for (int b = 0; b < nB; b += per) c.push_back(Chunk{b, nB - b < per ? nB - b : per, 0, Pp});
+  } else {
+    for (int b = 0; b < nB; ++b)
+      for (long long s = 0; s < Pp; s += max_points) c.push_back(Chunk{b, 1, s, Pp - s < max_points ? Pp - s : max_points});
+  }
+  return c;
+}
+
+// per-model sizes of the weight-gradient outputs, in FenerfSirenGrads order
+struct GradSizes { long long geo_w[FENERF_MAX_GEO], geo_b[FENERF_MAX_GEO], color_w[FENERF_MAX_COLOR], color_b[FENERF_MAX_COLOR], head_w, head_b, rgb_w, rgb_b, total; };
+GradSizes grad_sizes(const FenerfModel* m) {
+  GradSizes z;
+  memset(&z, 0, sizeof(z));
+  const long long H = m->H;
+  for (int i = 0; i < m->n_geo; ++i) { z.geo_w[i] = i == 0 ? H * 3 : H * H; z.geo_b[i] = H; }
+  for (int i = 0; i < m->n_color; ++i) { z.color_w[i] = i == 0 ? H * (3 + m->grid_ch + H) : H * H; z.color_b[i] = H; }
+  z.head_w = 32 * H; z.head_b = 32; z.rgb_w = 3 * H; z.rgb_b = 3;
+  for (int i = 0; i < m->n_geo; ++i) z.total += z.geo_w[i] + z.geo_b[i];
+  for (int i = 0; i < m->n_color; ++i) z.total += z.color_w[i] + z.color_b[i];
+  z.total += z.head_w + z.head_b + z.rgb_w + z.rgb_b;
+  return z;
+}
+// carve a FenerfSirenGrads' weight buffers out of `base` (floats), in grad_sizes order
+void carve_grads(const FenerfModel* m, const GradSizes& z, float* base, FenerfSirenGrads* g) {
+  for (int i = 0; i < m->n_geo; ++i) { g->geo_w[i] = base; base += z.geo_w[i]; g->geo_b[i] = base; base += z.geo_b[i]; }
+  for (int i = 0; i < m->n_color; ++i) { g->color_w[i] = base; base += z.color_w[i]; g->color_b[i] = base; base += z.color_b[i]; }
+  g->head_w = base; base += z.head_w; g->head_b = base; base += z.head_b; g->rgb_w = base; base += z.rgb_w; g->rgb_b = base; base += z.rgb_b;
+}
+
+// points one backward launch may take: the d(theta) dump's budget, or -- FiLM-only chain launches of f16x3 models write no dump -- what
+// their per-unit FiLM sums may occupy (and the kernel's 32-bit tile arithmetic: 2^24 points)
+long long backward_max_points(const FenerfModel* m, long long Pp, bool film16, long long chunk_points, long long film_budget) {
+  if (!film16) return chunk_points > 0 ? chunk_points : kDefaultChunkPoints;
+  const double bytes_pp = 4.0 * (double)fenerf_siren_film_sums_floats(m, 1, Pp) / (double)Pp;
+  double cap = (double)(film_budget > 0 ? film_budget : kDefaultFilmSumsBudget) / bytes_pp;
+  if (cap > (double)(1 << 24)) cap = (double)(1 << 24);
+  return (long long)cap;
+}
+
+struct BackwardWs {
+  size_t d_out2, d_fc, dump, d_grid_cl, d_e, wgrad, film2, scratch, total;
+  long long max_chunk_points, film_row;   // film_row = floats of one image's four FiLM gradient rows
+  int max_nb;
+};
+BackwardWs backward_ws(const FenerfModel* m, int B, int R, int N, int film_only, long long chunk_points, long long film_budget) {
+  BackwardWs w;
+  const long long P = (long long)R * N, Pp = (P + 31) / 32 * 32;
+  const bool film16 = film_only && m->precision == FENERF_PREC_F16X3;
+  const std::vector<Chunk> chunks = plan_chunks(2 * B, Pp, backward_max_points(m, Pp, film16, chunk_points, film_budget));
+  w.max_chunk_points = 0; w.max_nb = 0;
+  size_t wg = 0, sums = 0;
+  for (const Chunk& c : chunks) {
+    if ((long long)c.nb * c.n > w.max_chunk_points) w.max_chunk_points = (long long)c.nb * c.n;
+    if (c.nb > w.max_nb) w.max_nb = c.nb;
+    const size_t b = wgrad_workspace_bytes(m, c.nb, c.n);
+    if (b > wg) wg = b;
+    const size_t f = fenerf_siren_film_sums_floats(m, c.nb, c.n) * sizeof(float);
+    if (f > sums) sums = f;
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  w.d_out2 = take((size_t)2 * B * Pp * m->C * sizeof(float));
+  w.d_fc = take(Pp != P ? (size_t)2 * B * P * m->C * sizeof(float) : 0);
+  w.dump = take(film16 ? sums : fenerf_siren_dtheta_floats(m, w.max_chunk_points) * sizeof(float));
+  w.d_grid_cl = take(m->grid_ch && !film_only ? (size_t)m->gd * m->gh * m->gw * 32 * sizeof(float) : 0);
+  w.d_e = take(m->grid_ch && !fenerf_siren_backward_fuses_grid(m) ? (size_t)w.max_chunk_points * 32 * sizeof(float) : 0);
+  w.wgrad = take(align_up(wg, 256));
+  w.film_row = (long long)2 * (m->n_geo + m->n_color) * m->H;
+  w.film2 = take((size_t)2 * B * w.film_row * sizeof(float));
+  // a later chunk's gradients before they are added to the first one's: every weight tensor + the FiLM rows of the chunk's images
+  w.scratch = take(chunks.size() > 1 ? ((size_t)(film_only ? 0 : grad_sizes(m).total) + (size_t)w.max_nb * w.film_row) * sizeof(float) : 0);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t fenerf_render_save_bytes(const FenerfModel* m, int B, int R, int N, int tape_format, int lock_view) {
+  if (!m || B <= 0 || R <= 0 || N <= 0) return 0;
+  return render_save(m, B, R, N, tape_format, lock_view).total;
+}
+
+extern "C" int fenerf_render_forward_save(const FenerfModel* m, int B, int R, int N, int lock_view, const float* origins, const float* dirs,
+                                          const float* z_coarse, const float* u, const float* noise_coarse, const float* noise_final,
+                                          const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                                          const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, void* save, size_t save_bytes,
+                                          int tape_format, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  if ((rc = check_tape_format(m, tape_format))) return rc;
+  if (B <= 0 || R <= 0 || N < 3 || 2 * N > 512) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 256 (hierarchical render)");
+  if (opts->fill_mode != FENERF_FILL_NONE) return fail(FENERF_E_UNSUPPORTED, "fill modes are not differentiated (generator.forward does not use them)");
+  if (!origins || !dirs || !z_coarse || !u || !out_rgb || !out_depth) return fail(FENERF_E_INVALID, "origins / dirs / z_coarse / u / out_rgb / out_depth is NULL");
+  if (!freq_geo || !phase_geo || !freq_app || !phase_app) return fail(FENERF_E_INVALID, "film parameter pointer is NULL");
+  const RenderSave sv = render_save(m, B, R, N, tape_format, lock_view);
+  if (!save || save_bytes < sv.total) return fail(FENERF_E_INVALID, "save buffer too small (see fenerf_render_save_bytes)");
+  char* base = (char*)save;
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = sv.P, Pp = sv.Pp, BR = (long long)B * R;
+  const int C = m->C;
+  float* fp2 = (float*)(base + sv.fp2);
+  float* pp2 = (float*)(base + sv.pp2);
+  float* pts2 = (float*)(base + sv.pts2);
+  float* rd = lock_view ? nullptr : (float*)(base + sv.rd);
+  float* out2 = (float*)(base + sv.out2);
+  char* tape2 = base + sv.tape2;
+  float* tape_e2 = m->grid_ch ? (float*)(base + sv.tape_e2) : nullptr;
+  float* zf = (float*)(base + sv.zf);
+  // FiLM pre-pass once, for both passes and for the backward: f' / p' of image b at rows b and B + b (pass-major "images")
+  const size_t film_n = (size_t)B * m->L * m->H;
+  { PhaseScope ph(PH_FILM_PREP, stream); if ((rc = launch_film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, fp2, pp2, stream))) return rc; }
+  HIP_TRY(hipMemcpyAsync(fp2 + film_n, fp2, film_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(pp2 + film_n, pp2, film_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- coarse pass (generators.py:468-479)
+  { PhaseScope ph(PH_OTHER, stream); if ((rc = launch_render_points(B, R, N, Pp, origins, dirs, z_coarse, pts2, rd, stream))) return rc; }
+  SirenParams sp;
+  fill_common(m, sp, fp2, pp2);
+  sp.points = pts2; sp.pdirs = rd;
+  sp.P = (long long)B * Pp; sp.pts_per_image = Pp; sp.n_per_ray = 1;
+  sp.out = out2; sp.tape = (float*)tape2; sp.tape_e = tape_e2; sp.tape_format = tape_format;
+  if ((rc = run_siren(m, sp, stream))) return rc;
+  const float* coarse = out2;
+  const float* fine = out2 + (size_t)B * Pp * C;
+  if (Pp != P) {
+    PhaseScope ph(PH_OTHER, stream);
+    if ((rc = launch_pad_rows(out2, (float*)(base + sv.rows_c), B, P, Pp, C, false, stream))) return rc;
+    coarse = (const float*)(base + sv.rows_c);
+  }
+  // ---- coarse weights and, in the same wave per ray, the inverse-CDF resampling (generators.py:485-499; constants of the graph)
+  CompositeParams cp;
+  memset(&cp, 0, sizeof(cp));
+  cp.BR = BR; cp.M = N; cp.C = C; cp.N = N;
+  cp.rows_a = coarse; cp.z_a = z_coarse; cp.noise = noise_coarse;
+  cp.o.clamp_mode = opts->clamp_mode; cp.o.noise_std = opts->noise_std;
+  cp.sigma_only = 1; cp.out_ch = C - 1;
+  cp.u = u; cp.z_fine = zf;
+  if ((rc = run_composite(cp, false, stream))) return rc;
+  // ---- fine pass (generators.py:504-505)
+  { PhaseScope ph(PH_OTHER, stream); if ((rc = launch_render_points(B, R, N, Pp, origins, dirs, zf, pts2 + (size_t)B * Pp * 3, rd ? rd + (size_t)B * Pp * 3 : nullptr, stream))) return rc; }
+  sp.points = pts2 + (size_t)B * Pp * 3;
+  sp.out = out2 + (size_t)B * Pp * C;
+  sp.tape = (float*)(tape2 + sv.tape_half);
+  sp.tape_e = tape_e2 ? tape_e2 + (size_t)B * Pp * 32 : nullptr;
+  if ((rc = run_siren(m, sp, stream))) return rc;
+  if (Pp != P) {
+    PhaseScope ph(PH_OTHER, stream);
+    if ((rc = launch_pad_rows(out2 + (size_t)B * Pp * C, (float*)(base + sv.rows_f), B, P, Pp, C, false, stream))) return rc;
+    fine = (const float*)(base + sv.rows_f);
+  }
+  // ---- merge + final composite (generators.py:508-519)
+  memset(&cp, 0, sizeof(cp));
+  cp.BR = BR; cp.M = 2 * N; cp.C = C; cp.N = N;
+  cp.rows_a = fine; cp.rows_b = coarse; cp.z_a = zf; cp.z_b = z_coarse; cp.noise = noise_final; cp.o = *opts;
+  cp.out_rgb = out_rgb; cp.out_depth = out_depth;
+  cp.out_ch = out_channels(C, opts);
+  return run_composite(cp, true, stream);
+}
+
+extern "C" size_t fenerf_render_backward_workspace_bytes(const FenerfModel* m, int B, int R, int N, int film_only, int64_t chunk_points,
+                                                         int64_t film_sums_budget_bytes) {
+  if (!m || B <= 0 || R <= 0 || N <= 0) return 0;
+  return backward_ws(m, B, R, N, film_only, chunk_points, film_sums_budget_bytes).total;
+}
+
+extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N, int lock_view, const void* save, size_t save_bytes,
+                                      int tape_format, const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts,
+                                      const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights,
+                                      int64_t chunk_points, int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  if ((rc = check_tape_format(m, tape_format))) return rc;
+  if (B <= 0 || R <= 0 || N < 3 || 2 * N > 512) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 256 (hierarchical render)");
+  if (!save || !z_coarse || !g_rgb || !grads || !workspace) return fail(FENERF_E_INVALID, "NULL pointer");
+  if (!grads->d_freq_geo || !grads->d_phase_geo || !grads->d_freq_app || !grads->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
+  int have = 0, want = 0;
+  for (int i = 0; i < m->n_geo; ++i) { want += 2; have += (grads->geo_w[i] != nullptr) + (grads->geo_b[i] != nullptr); }
+  for (int i = 0; i < m->n_color; ++i) { want += 2; have += (grads->color_w[i] != nullptr) + (grads->color_b[i] != nullptr); }
+  want += 4; have += (grads->head_w != nullptr) + (grads->head_b != nullptr) + (grads->rgb_w != nullptr) + (grads->rgb_b != nullptr);
+  if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
+  const bool film_only = have == 0;
+  if (film_only && tape_format == FENERF_TAPE_U16) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 carries no accumulator: FiLM-only gradients need the fp32 tape");
+  if (tape_format == FENERF_TAPE_U16 && !weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: the FiLM layers' weights are required");
+  if (!film_only && m->grid_ch && !d_grid_ncdhw) return fail(FENERF_E_INVALID, "d_grid_ncdhw is NULL");
+  const RenderSave sv = render_save(m, B, R, N, tape_format, lock_view);
+  if (save_bytes < sv.total) return fail(FENERF_E_INVALID, "save buffer too small (see fenerf_render_save_bytes)");
+  const BackwardWs wsz = backward_ws(m, B, R, N, film_only, chunk_points, film_sums_budget_bytes);
+  if (workspace_bytes < wsz.total) return fail(FENERF_E_INVALID, "workspace too small (see fenerf_render_backward_workspace_bytes)");
+  const char* sb = (const char*)save;
+  char* wb = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = sv.P, Pp = sv.Pp, BR = (long long)B * R;
+  const int C = m->C, H = m->H, L = m->L, ng = m->n_geo, nc = m->n_color, nB = 2 * B;
+  const float* fp2 = (const float*)(sb + sv.fp2);
+  const float* pp2 = (const float*)(sb + sv.pp2);
+  const float* pts2 = (const float*)(sb + sv.pts2);
+  const float* rd = lock_view ? nullptr : (const float*)(sb + sv.rd);
+  const float* out2 = (const float*)(sb + sv.out2);
+  const char* tape2 = sb + sv.tape2;
+  const float* tape_e2 = m->grid_ch ? (const float*)(sb + sv.tape_e2) : nullptr;
+  const float* zf = (const float*)(sb + sv.zf);
+  float* d_out2 = (float*)(wb + wsz.d_out2);
+  // ---- composite backward: the gradient wrt the two passes' rows, written where the chain reads it (coarse | fine halves, pass-major)
+  {
+    CompositeParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.BR = BR; cp.M = 2 * N; cp.C = C; cp.N = N;
+    cp.rows_a = Pp == P ? out2 + (size_t)B * Pp * C : (const float*)(sb + sv.rows_f);
+    cp.rows_b = Pp == P ? out2 : (const float*)(sb + sv.rows_c);
+    cp.z_a = zf; cp.z_b = z_coarse; cp.noise = noise_final; cp.o = *opts;
+    cp.g_rgb = g_rgb;
+    float* d_f = Pp == P ? d_out2 + (size_t)B * Pp * C : (float*)(wb + wsz.d_fc);
+    float* d_c = Pp == P ? d_out2 : (float*)(wb + wsz.d_fc) + (size_t)B * P * C;
+    cp.d_rows_a = d_f; cp.d_rows_b = d_c;
+    { PhaseScope ph(PH_COMPOSITE_BWD, stream); if ((rc = launch_composite_backward(cp, true, stream))) return rc; }
+    if (Pp != P) {
+      PhaseScope ph(PH_OTHER, stream);
+      if ((rc = launch_pad_rows(d_c, d_out2, B, P, Pp, C, true, stream))) return rc;
+      if ((rc = launch_pad_rows(d_f, d_out2 + (size_t)B * Pp * C, B, P, Pp, C, true, stream))) return rc;
+    }
+  }
+  // ---- chunks of whole (pass, image) pairs -- or point ranges of one -- : chain, then the weight / FiLM gradients of the chunk
+  const bool film16 = film_only && m->precision == FENERF_PREC_F16X3;
+  const std::vector<Chunk> chunks = plan_chunks(nB, Pp, backward_max_points(m, Pp, film16, chunk_points, film_sums_budget_bytes));
+  float* dump = (float*)(wb + wsz.dump);
+  float* d_grid_cl = (m->grid_ch && !film_only) ? (float*)(wb + wsz.d_grid_cl) : nullptr;
+  float* d_e = (m->grid_ch && !fenerf_siren_backward_fuses_grid(m)) ? (float*)(wb + wsz.d_e) : nullptr;
+  if (d_grid_cl) HIP_TRY(hipMemsetAsync(d_grid_cl, 0, (size_t)m->gd * m->gh * m->gw * 32 * sizeof(float), st));
+  float* film2 = (float*)(wb + wsz.film2);      // [d_freq_geo | d_phase_geo: nB x ng H each][d_freq_app | d_phase_app: nB x nc H each]
+  float* f2[4] = {film2, film2 + (size_t)nB * ng * H, film2 + (size_t)2 * nB * ng * H, film2 + (size_t)2 * nB * ng * H + (size_t)nB * nc * H};
+  const long long frow[4] = {(long long)ng * H, (long long)ng * H, (long long)nc * H, (long long)nc * H};
+  const GradSizes gz = grad_sizes(m);
+  const size_t LHw = (size_t)(tape_format == FENERF_TAPE_U16 ? 2 : 4) * L * H;      // tape bytes per point
+  bool first = true;
+  for (const Chunk& c : chunks) {
+    const long long g0 = (long long)c.b * Pp + c.s, npts = (long long)c.nb * c.n;
+    const float* fp_c = fp2 + (size_t)c.b * L * H;
+    const float* pp_c = pp2 + (size_t)c.b * L * H;
+    const float* out_c = out2 + (size_t)g0 * C;
+    const float* dout_c = d_out2 + (size_t)g0 * C;
+    const float* pts_c = pts2 + (size_t)g0 * 3;
+    const char* tape_c = tape2 + (size_t)g0 * LHw;
+    SirenBwdParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.stream = m->d_bwd_stream;
+    bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
+    bp.fp = fp_c; bp.pp = pp_c;
+    bp.P = npts; bp.pts_per_image = c.n;
+    bp.out = out_c; bp.d_out = dout_c; bp.tape = (const float*)tape_c; bp.tape_format = tape_format;
+    const float* film_sums = nullptr;
+    if (film16) {
+      bp.d_t = nullptr; bp.d_e = nullptr; bp.film_tiles = dump; film_sums = dump;
+    } else {
+      bp.d_t = dump; bp.film_tiles = dump + (size_t)L * H * (size_t)npts;
+      bp.bf16_dump = use_bf16_dump(m, npts);
+      if (m->grid_ch && !film_only) {
+        if (fenerf_siren_backward_fuses_grid(m)) { bp.points = pts_c; bp.d_grid_cl = d_grid_cl; bp.box_scale = m->box_scale; bp.gd = m->gd; bp.gh = m->gh; bp.gw = m->gw; }
+        else bp.d_e = d_e;
+      } else if (m->grid_ch) {
+        bp.d_e = d_e;      // FiLM-only on an exact-fp32 model: the chain still writes d(grid features); nobody reads them
+      }
+    }
+    {
+      PhaseScope ph(PH_CHAIN, stream);
+      rc = m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16w(m, bp, stream) : launch_siren_backward(m, bp, stream);
+      if (rc) return rc;
+    }
+    if (m->grid_ch && !film_only && !fenerf_siren_backward_fuses_grid(m)) {
+      PhaseScope ph(PH_GRID, stream);
+      if ((rc = launch_grid_backward(m, npts, pts_c, d_e, d_grid_cl, stream))) return rc;
+    }
+    // where this chunk's gradients go: the first chunk writes the outputs, later ones a scratch set that is then added (chunk order:
+    // the sums of rounds 2-4, bit for bit); FiLM rows of an image's first point range are written in place, later ranges added
+    FenerfSirenGrads gc;
+    memset(&gc, 0, sizeof(gc));
+    float* scratch = (float*)(wb + wsz.scratch);
+    float* film_scratch = scratch + (film_only ? 0 : gz.total);
+    const bool film_direct = c.s == 0;
+    float* fdst[4];
+    {
+      size_t o = 0;
+      for (int k = 0; k < 4; ++k) {
+        fdst[k] = film_direct ? f2[k] + (size_t)c.b * frow[k] : film_scratch + o;
+        o += (size_t)c.nb * frow[k];
+      }
+    }
+    if (!film_only) {
+      if (first) gc = *grads;
+      else carve_grads(m, gz, scratch, &gc);
+    }
+    gc.d_freq_geo = fdst[0]; gc.d_phase_geo = fdst[1]; gc.d_freq_app = fdst[2]; gc.d_phase_app = fdst[3];
+    const float* dirs_c = rd ? rd + (size_t)g0 * 3 : nullptr;
+    rc = launch_param_grads(m, c.nb, c.n, pts_c, dirs_c, fp_c, pp_c, out_c, dout_c, (const float*)tape_c, tape_e2 ? tape_e2 + (size_t)g0 * 32 : nullptr,
+                            film16 ? nullptr : dump, gc, film_only, wb + wsz.wgrad, stream, film_sums, tape_format, weights);
+    if (rc) return rc;
+    if (!film_direct || (!first && !film_only)) {
+      MultiAdd J;
+      memset(&J, 0, sizeof(J));
+      int k = 0;
+      auto add = [&](float* dst, const float* src, long long n) { if (dst && src && n > 0) { J.dst[k] = dst; J.src[k] = src; J.n[k] = n; ++k; } };
+      if (!first && !film_only) {
+        for (int i = 0; i < ng; ++i) { add(grads->geo_w[i], gc.geo_w[i], gz.geo_w[i]); add(grads->geo_b[i], gc.geo_b[i], gz.geo_b[i]); }
+        for (int i = 0; i < nc; ++i) { add(grads->color_w[i], gc.color_w[i], gz.color_w[i]); add(grads->color_b[i], gc.color_b[i], gz.color_b[i]); }
+        add(grads->head_w, gc.head_w, gz.head_w); add(grads->head_b, gc.head_b, gz.head_b); add(grads->rgb_w, gc.rgb_w, gz.rgb_w); add(grads->rgb_b, gc.rgb_b, gz.rgb_b);
+      }
+      if (!film_direct)
+        for (int q = 0; q < 4; ++q) add(f2[q] + (size_t)c.b * frow[q], fdst[q], (long long)c.nb * frow[q]);
+      J.count = k;
+      PhaseScope ph(PH_OTHER, stream);
+      if ((rc = launch_multi_add(J, stream))) return rc;
+    }
+    first = false;
+  }
+  // ---- the two passes of an image share its FiLM parameters: row b + row B + b
+  {
+    FilmFold F;
+    F.B = B;
+    F.out[0] = grads->d_freq_geo; F.out[1] = grads->d_phase_geo; F.out[2] = grads->d_freq_app; F.out[3] = grads->d_phase_app;
+    for (int q = 0; q < 4; ++q) { F.in[q] = f2[q]; F.row[q] = (int)frow[q]; }
+    PhaseScope ph(PH_OTHER, stream);
+    if ((rc = launch_film_fold(F, stream))) return rc;
+  }
+  if (d_grid_cl) {
+    PhaseScope ph(PH_GRID, stream);
+    if ((rc = launch_grid_unlayout(d_grid_cl, d_grid_ncdhw, m->gd, m->gh, m->gw, stream))) return rc;
+  }
+  return FENERF_OK;
+}

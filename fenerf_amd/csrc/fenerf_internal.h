@@ -185,6 +185,14 @@ int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const floa
 int launch_ray_setup(int B, int S, int N, float z_cam, float ray_start, float ray_end, const float* u_jitter,
                      const float* theta, const float* phi, float* origins, float* dirs, float* z, float* pitch, float* yaw,
                      void* stream);
+// fenerf_render_grad.hip: the small kernels of fenerf_render_forward_save / fenerf_render_backward
+#define FENERF_MULTI_ADD_MAX 64
+struct MultiAdd { float* dst[FENERF_MULTI_ADD_MAX]; const float* src[FENERF_MULTI_ADD_MAX]; long long n[FENERF_MULTI_ADD_MAX]; int count; };
+struct FilmFold { float* out[4]; const float* in[4]; int row[4]; int B; };
+int launch_render_points(int B, int R, int N, long long Pp, const float* origins, const float* dirs, const float* z, float* pts, float* rd, void* stream);
+int launch_pad_rows(const float* src, float* dst, long long nb, long long P, long long Pp, int C, bool to_padded, void* stream);
+int launch_multi_add(const MultiAdd& J, void* stream);
+int launch_film_fold(const FilmFold& J, void* stream);
 int launch_repack(FenerfModel* m, const float* flat, const FenerfRepackMaps* r, float* scale_fwd, float* scale_bwd, void* stream);
 int launch_grid_relayout(const float* src_ncdhw, float* dst_cl, int C, int D, int Hh, int W, void* stream);
 int launch_grid_unlayout(const float* src_cl, float* dst_ncdhw, int D, int Hh, int W, void* stream);

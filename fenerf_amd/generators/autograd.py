@@ -98,6 +98,13 @@ def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_
     return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
 
 
+# The one-node render runs through fenerf_render_forward_save / fenerf_render_backward (round 5: chunk planning, workspaces, launch order and
+# gradient sums live behind the C-ABI; include/fenerf.h) -- the Python below it is the round-4 orchestration of the same kernels, kept for the
+# two-node (DistributedDataParallel) form, for the two-stream experiment (siren/autograd.py OVERLAP_WGRAD) and as the reference the tests
+# compare the one-call path with bit for bit.
+USE_RENDER_ABI = True
+
+
 class HierarchicalRenderFunction(torch.autograd.Function):
     """The whole differentiable hierarchical render of generators.py:479-519 as ONE autograd node: coarse SIREN pass ->
     (no-grad) coarse weights -> resampled depths -> fine SIREN pass -> merged composite.  Both passes write their tapes into
@@ -110,18 +117,43 @@ class HierarchicalRenderFunction(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, *params):
-        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params,
-                                     film_only=not any(ctx.needs_input_grad[14:]))
+        film_only = not any(ctx.needs_input_grad[14:])
+        ctx.abi = USE_RENDER_ABI and not (_siren_autograd.OVERLAP_WGRAD)
+        if not ctx.abi:
+            return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, params, film_only=film_only)
+        nat = module.native_differentiable(origins.device)
+        B, R, N = z_c.shape
+        ctx.tape_format = module.tape_format(nat, film_only=film_only)
+        rgb, depth, save = nat.render_forward_save(origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, opts, lock_view=lock_view,
+                                                   tape_format=ctx.tape_format)
+        ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
+        ctx.pack_generation = nat.pack_generation
+        ctx.save_for_backward(save, z_c, noise_f if noise_f is not None else origins.new_empty(0), *params)
+        ctx.mark_non_differentiable(depth)
+        return rgb, depth
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, _g_depth):
         module, nat, opts = ctx.module, ctx.nat, ctx.opts
         _siren_autograd.check_same_weights(ctx, nat)
+        need = ctx.needs_input_grad
+        if ctx.abi:
+            B, R, N = ctx.dims
+            save, z_c, noise_f, *params = ctx.saved_tensors
+            film_only = not any(need[14:])
+            r, g_grid = nat.render_backward(B, R, N, save, z_c, noise_f if noise_f.numel() else None, opts, g_rgb.contiguous().float(), film_only,
+                                            lock_view=ctx.lock_view, tape_format=ctx.tape_format,
+                                            weights=_siren_autograd.film_layer_weights(module, params) if ctx.tape_format else None,
+                                            chunk_points=_siren_autograd.BACKWARD_CHUNK_POINTS, film_sums_budget_bytes=_siren_autograd.FILM_SUMS_BUDGET_BYTES)
+            film_grads = tuple(r[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
+            head = (None,) * 10
+            if film_only:
+                return head + film_grads + (None,) * len(params)
+            return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, None, None, need[14:], d_grid_ncdhw=g_grid)
         B, R, N, P, Pp = ctx.dims
         pts2, rd, fg, pg, fa, pa, out2, tape2, tape_e2, z_f, zc, noise_f, *params = ctx.saved_tensors
         C = nat.C
-        need = ctx.needs_input_grad
         fine, coarse = out2[B:, :P].reshape(B * R, N, C), out2[:B, :P].reshape(B * R, N, C)
         if Pp == P:     # whole tiles per image: the composite backward writes the chain's input directly (coarse | fine halves, pass-major)
             d_out2 = torch.empty_like(out2)

@@ -578,6 +578,64 @@ class NativeModel:
         """FLOPs the SIREN kernel issues on the matrix pipe per point (static MFMA count), next to the algorithmic 1,603,584"""
         return float(_lib.lib().fenerf_siren_executed_flop_per_point(self._h))
 
+    def render_forward_save(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, lock_view=False, tape_format=0):
+        """fenerf_render_forward_save: the differentiable hierarchical render's forward in ONE call -> (rgb [B,R,C-1], depth [B,R], save);
+        `save` (opaque bytes on the device) is what render_backward needs besides z_coarse / noise_final / opts."""
+        B, R, N = z_coarse.shape
+        dev = self.device
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        origins, dirs, z_coarse, u = _f32(origins, dev), _f32(dirs, dev), _f32(z_coarse, dev), _f32(u, dev)
+        noise_coarse = _f32(noise_coarse, dev) if noise_coarse is not None else None
+        noise_final = _f32(noise_final, dev) if noise_final is not None else None
+        l = _lib.lib()
+        rgb = torch.empty((B, R, self.C - 1), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, R), dtype=torch.float32, device=dev)
+        save = torch.empty((int(l.fenerf_render_save_bytes(self._h, B, R, N, int(tape_format), int(lock_view))),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(l.fenerf_render_forward_save(self._h, B, R, N, int(lock_view), _ptr(origins), _ptr(dirs), _ptr(z_coarse), _ptr(u), _ptr(noise_coarse),
+                                                    _ptr(noise_final), _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), C.byref(opts), _ptr(rgb), _ptr(depth),
+                                                    C.c_void_p(save.data_ptr()), C.c_size_t(save.numel()), int(tape_format), _stream()))
+        return rgb, depth, save
+
+    def render_backward(self, B, R, N, save, z_coarse, noise_final, opts, g_rgb, film_only, lock_view=False, tape_format=0, weights=None,
+                        chunk_points=0, film_sums_budget_bytes=0):
+        """fenerf_render_backward: every gradient of the render in ONE call -> (dict like siren_param_grads -- FiLM gradients [B, n*H], both
+        passes summed; weight / bias gradients unless film_only --, d_grid [1,32,D,H,W] or None)."""
+        sp = self.spec
+        H, ng, nc, G = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["grid_ch"]
+        dev = self.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        res = dict(d_freq_geo=new(B, ng * H), d_phase_geo=new(B, ng * H), d_freq_app=new(B, nc * H), d_phase_app=new(B, nc * H))
+        g = _lib.FenerfSirenGrads()
+        if not film_only:
+            res.update(geo_w=[new(H, 3)] + [new(H, H) for _ in range(ng - 1)], geo_b=[new(H) for _ in range(ng)],
+                       color_w=[new(H, 3 + G + H)] + [new(H, H) for _ in range(nc - 1)], color_b=[new(H) for _ in range(nc)],
+                       head_w=new(32, H), head_b=new(32), rgb_w=new(3, H), rgb_b=new(3))
+            for i in range(ng):
+                g.geo_w[i], g.geo_b[i] = res["geo_w"][i].data_ptr(), res["geo_b"][i].data_ptr()
+            for i in range(nc):
+                g.color_w[i], g.color_b[i] = res["color_w"][i].data_ptr(), res["color_b"][i].data_ptr()
+        for k in res:
+            if not isinstance(res[k], list):
+                setattr(g, k, res[k].data_ptr())
+        d_grid = torch.empty((1, 32) + tuple(self.grid_shape), dtype=torch.float32, device=dev) if (G and not film_only) else None
+        wts, keep = None, []
+        if weights is not None:
+            wts = _lib.FenerfSirenGrads()
+            for i, w in enumerate(weights[0]):
+                keep.append(_f32(w.detach(), dev)); wts.geo_w[i] = keep[-1].data_ptr()
+            for i, w in enumerate(weights[1]):
+                keep.append(_f32(w.detach(), dev)); wts.color_w[i] = keep[-1].data_ptr()
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            ws = self._workspace("render_bwd", l.fenerf_render_backward_workspace_bytes(self._h, B, R, N, int(film_only), int(chunk_points),
+                                                                                        int(film_sums_budget_bytes)))
+            _lib.check(l.fenerf_render_backward(self._h, B, R, N, int(lock_view), C.c_void_p(save.data_ptr()), C.c_size_t(save.numel()), int(tape_format),
+                                                _ptr(_f32(z_coarse, dev)), _ptr(_f32(noise_final, dev)) if noise_final is not None else None,
+                                                C.byref(opts), _ptr(_f32(g_rgb, dev)), C.byref(g), _ptr(d_grid), C.byref(wts) if wts is not None else None,
+                                                int(chunk_points), int(film_sums_budget_bytes), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream()))
+        return res, d_grid
+
     def render(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, hierarchical=True,
                lock_view=False, want_weights=False, want_wsum=False):
         """The fused coarse->resample->fine->merge->composite pipeline (generators.py:479-519).

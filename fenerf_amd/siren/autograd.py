@@ -57,10 +57,10 @@ def _fold_label_head_backward(label_params, gA, gc):
     return out
 
 
-def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params):
+def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params, d_grid_ncdhw=None):
     """FenerfSirenGrads buffers (dict r) + the channels-last grid gradient chunked_backward accumulated -> gradients in the order of
     `params` (module._render_params()).  d_grid_cl None on a model with a grid: the grid's gradient is delivered elsewhere (split
-    backward) and its slot is None here."""
+    backward) and its slot is None here -- or it arrives in the parameter's own layout (d_grid_ncdhw: fenerf_render_backward)."""
     roles = module._roles(params)
     n_lab = nat.spec["output_dim"] - 4
     grads = {}
@@ -73,7 +73,9 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params)
             grads[id(Wi)], grads[id(bi)] = gw, gb
     rw, rb = roles["rgb"]
     grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]
-    if roles["grid"] is not None and d_grid_cl is not None:
+    if roles["grid"] is not None and d_grid_ncdhw is not None:
+        grads[id(roles["grid"])] = d_grid_ncdhw
+    elif roles["grid"] is not None and d_grid_cl is not None:
         grads[id(roles["grid"])] = nat.grid_gradient_ncdhw(d_grid_cl).contiguous()
     return tuple(grads[id(p)].reshape(p.shape) if (need_params[i] and id(p) in grads) else None for i, p in enumerate(params))
 

@@ -403,6 +403,37 @@ int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t P, const f
                                  const float* d_t, const FenerfSirenGrads* g, const FenerfSirenGrads* weights, void* workspace,
                                  void* film_ws, void* stream);
 int fenerf_siren_backward_stream_bytes_fmt(const FenerfModel* m, int64_t chunk_points, int tape_format, double* out4);
+
+/* The differentiable hierarchical render as TWO calls (round 5) -- replaces: DoubleImplicitGenerator3d.forward / forward_with_frequencies
+ * under autograd (generators.py:468-527, :735-797) and the part of g_loss.backward() (train_double_latent_semantic.py:402-446) /
+ * loss.backward() (inverse_render_double_semantic.py:397) that runs through them.
+ *
+ * fenerf_render_forward_save = fenerf_render_forward (hierarchical, no fill mode) that also keeps what the backward needs in `save`
+ *   (fenerf_render_save_bytes bytes of [dev] memory, opaque: prepared FiLM parameters, the two passes' sample points, outputs, tapes and
+ *   sampled grid features, the resampled depths): coarse SIREN pass -> coarse weights + inverse-CDF resampling (constants of the graph,
+ *   generators.py:485-503 is no_grad) -> fine pass -> merged composite.  Pixels and depth are those of fenerf_render_forward bit for bit.
+ * fenerf_render_backward: g_rgb [B,R,C-1] = dL/d(out_rgb) -> every gradient of the render:
+ *     grads->d_freq_* / d_phase_*  [B, n*H]   wrt the raw FiLM parameters (both passes summed),
+ *     grads->geo_w .. rgb_b                   the weight / bias gradients in nn.Linear layout (head_w: the folded label head, as in
+ *                                             fenerf_siren_param_grads) -- all NULL = FiLM gradients only (inversion),
+ *     d_grid_ncdhw [1,32,D,H,W]               wrt spatial_embeddings (models with a grid; not for FiLM-only),
+ *   from the same z_coarse / noise_final / opts the forward took.  It plans its own backward chunks (whole (pass, image) pairs or point
+ *   ranges of at most chunk_points points, 0 = 393,216; FiLM-only launches of FENERF_PREC_F16X3 models by film_sums_budget_bytes of
+ *   per-unit FiLM sums, 0 = 1 GiB), runs composite backward, the chain and the weight-gradient kernels per chunk and sums the chunks'
+ *   gradients in chunk order.  workspace: fenerf_render_backward_workspace_bytes bytes of [dev] scratch (film_only as the call will be).
+ *   `weights`: only for FENERF_TAPE_U16 (see fenerf_siren_param_grads_fmt). */
+size_t fenerf_render_save_bytes(const FenerfModel* m, int B, int R, int N, int tape_format, int lock_view);
+int fenerf_render_forward_save(const FenerfModel* m, int B, int R, int N, int lock_view, const float* origins, const float* dirs,
+                               const float* z_coarse, const float* u, const float* noise_coarse, const float* noise_final,
+                               const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                               const FenerfCompositeOpts* opts, float* out_rgb, float* out_depth, void* save, size_t save_bytes,
+                               int tape_format, void* stream);
+size_t fenerf_render_backward_workspace_bytes(const FenerfModel* m, int B, int R, int N, int film_only, int64_t chunk_points,
+                                              int64_t film_sums_budget_bytes);
+int fenerf_render_backward(const FenerfModel* m, int B, int R, int N, int lock_view, const void* save, size_t save_bytes, int tape_format,
+                           const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts, const float* g_rgb,
+                           const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights, int64_t chunk_points,
+                           int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* HBM bytes per (sample point x FiLM-layer feature) of the backward streams of a chunk of `chunk_points` points (bench.py's generator-step
  * roofline): out[0] = what the chain kernel writes into the dump, out[1] = what the square weight-gradient job reads for one of its L - 1
  * layers (the dump of layer l + the input activations of layer l), out[2] = the four thin jobs together (two dump layers + two

@@ -405,6 +405,7 @@ def test_integration_md_binding_structs_match_the_loaded_library():
     assert ns["FENERF_ABI_VERSION"] == _lib.lib().fenerf_abi_version() == _lib.ABI_VERSION
     _check_mirror(ns["Desc"], "FenerfModelDesc")
     _check_mirror(ns["Opts"], "FenerfCompositeOpts")
+    _check_mirror(ns["Grads"], "FenerfSirenGrads")
     # the package's own mirrors, all six structs of include/fenerf.h
     for cls, name in ((_lib.FenerfModelDesc, "FenerfModelDesc"), (_lib.FenerfCompositeOpts, "FenerfCompositeOpts"), (_lib.FenerfRepackMaps, "FenerfRepackMaps"),
                       (_lib.FenerfLocalMapDesc, "FenerfLocalMapDesc"), (_lib.FenerfSirenGrads, "FenerfSirenGrads"),
