@@ -608,6 +608,30 @@ def main(argv=None):
                 del nat32
             except Exception as e:
                 out["f32"] = {"error": f"{type(e).__name__}: {e}"}
+            # Round 5: the opt-in reduced-precision forwards (include/fenerf.h fenerf_model_set_forward_mode) beside the headline: the same
+            # timed render, the same roofline fields (cycles per launch, clock granted) and what they cost in accuracy against the
+            # headline's own pixels on the same rays.  Never the headline: they do not meet its asserted bounds (profiles/r05_*).
+            for key, what in (("f16x2", "two fp16 MFMAs per product everywhere (weights as ONE fp16 value: wl*xh dropped, the lo halves neither fetched nor read)"),
+                              ("f16x3c2", "three fp16 MFMAs per product through the geometry trunk and the label / sigma head (sigma and labels bit-identical to the headline's), two in the colour layers and the rgb head")):
+                try:
+                    natx = native.NativeModel(sd, spec, dev, key)
+                    xdt, _, xin = timed_render(natx, B, S, N, args.steps, args.warmup, 1000)
+                    xroof = roofline_of(natx, xin, B * R * N, "f16x3", max(5, args.steps // 2))
+                    xroof["mfma"] = what
+                    xroof.pop("frac_of_f16x3_ceiling", None)
+                    o2, d2, z2, tf2 = xin
+                    u2 = torch.rand((B * R, N), device=dev)
+                    ref_px, ref_dp, _, _ = nat.render(o2, d2, z2, u2, None, None, *tf2, opts, hierarchical=True)
+                    got_px, got_dp, _, _ = natx.render(o2, d2, z2, u2, None, None, *tf2, opts, hierarchical=True)
+                    err = (got_px - ref_px).abs().amax(-1)
+                    out[key] = {"value": B * R * args.steps / xdt, "unit": "rays/s", "ms_per_step": xdt / args.steps * 1e3, "dtype": what,
+                                "vs_headline": (B * R * args.steps / xdt) / value * world, "roofline": xroof,
+                                "pixels_vs_headline": {"max_abs": float(err.max()), "mean_abs": float(err.mean()),
+                                                       "rays_beyond_1e-3": int((err > 1e-3).sum()), "rays": int(err.numel()),
+                                                       "depth_max_abs": float((got_dp - ref_dp).abs().max())}}
+                    del natx
+                except Exception as e:
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.precision == "f16x3":
             # the same render as ONE launch (include/fenerf.h fenerf_set_render_fusion): reported beside the headline,
             # which takes the faster four-launch route

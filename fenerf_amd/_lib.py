@@ -141,6 +141,7 @@ _SIGS = {
     "fenerf_siren_param_grads_fmt": (_i, [_vp, _i, _i64] + [_vp] * 9 + [_i, _vp, _vp, C.POINTER(FenerfSirenGrads), C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_siren_backward_stream_bytes_fmt": (_i, [_vp, _i64, _i, C.POINTER(C.c_double)]),
     # round 5: the differentiable hierarchical render as two calls (SURVEY 8b fenerf_render_backward)
+    "fenerf_model_set_forward_mode": (_i, [_vp, _i]),
     "fenerf_render_save_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "fenerf_render_forward_save": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _sz, _i, _vp]),
     "fenerf_render_backward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i64, _i64]),

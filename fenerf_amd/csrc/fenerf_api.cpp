@@ -319,6 +319,15 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   return FENERF_OK;
 }
 
+extern "C" int fenerf_model_set_forward_mode(FenerfModel* m, int mode) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (mode != FENERF_FORWARD_F16X3 && mode != FENERF_FORWARD_F16X2 && mode != FENERF_FORWARD_F16X3_COLOR_X2) return fail(FENERF_E_INVALID, "unknown forward mode");
+  if (mode != FENERF_FORWARD_F16X3 && m->precision != FENERF_PREC_F16X3) return fail(FENERF_E_UNSUPPORTED, "reduced-precision forward modes: FENERF_PREC_F16X3 models only");
+  const int prev = m->forward_mode;
+  m->forward_mode = mode;
+  return prev;
+}
+
 extern "C" int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* d, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   std::string err;
@@ -623,7 +632,10 @@ extern "C" double fenerf_siren_executed_flop_per_point(const FenerfModel* m) {
     // [wl xh, wh xl, wh xh]); colour layer 0 has one k32-step of grid features and one of view direction more; the folded head and
     // the rgb head are one n-block each; layer 0 (K = 3) runs on v_mfma_f32_16x16x4_f32 (2,048 FLOP), 2 per n-block
     const int KS = H / 32;
-    const double mf16 = 6.0 * ((double)n_sq * NB * KS + (double)NB * (KS + G + 1) + 2.0 * KS);
+    // (fenerf_model_set_forward_mode: 4 instead of 6 where the weight lo halves are not multiplied -- everywhere, or in the colour layers and the rgb head)
+    const double geo = (double)(m->n_geo - 1) * NB * KS + KS /* label / sigma head */, col = (double)(m->n_color - 1) * NB * KS + (double)NB * (KS + G + 1) + KS /* rgb head */;
+    const double per_geo = m->forward_mode == FENERF_FORWARD_F16X2 ? 4.0 : 6.0, per_col = m->forward_mode == FENERF_FORWARD_F16X3 ? 6.0 : 4.0;
+    const double mf16 = per_geo * geo + per_col * col;
     return (mf16 * 16384.0 + 2.0 * NB * 2048.0) / 16.0;
   }
   // siren_kernel, per 32-point tile: v_mfma_f32_32x32x2_f32 (4,096 FLOP), ceil(K / 2) per 32-row n-block

@@ -55,6 +55,7 @@ struct FenerfModel {
   int num_cus;
   int precision;    // FENERF_PREC_*
   int differentiable;       // desc->differentiable: the backward-chain stream is resident too
+  int forward_mode;         // FENERF_FORWARD_*: the no-grad forward's arithmetic (fenerf_model_set_forward_mode; FENERF_PREC_F16X3 models)
   int wgrad_bf16_min_points; // desc->wgrad_bf16_min_points: 0 = fp32-class weight gradients; > 0 = bf16 dump for chunks of at least that many points
   fenerf::BwdShape bsh;
   float* d_bwd_stream;      // [rgb-head^T entries | backward ring] * 256 floats, or nullptr

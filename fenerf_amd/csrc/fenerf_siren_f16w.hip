@@ -32,10 +32,17 @@
 //   <.., 1 | 2, false>  forward-save (fenerf_siren_forward_save): the same tiles, every FiLM layer's phase also leaves as the tape --
 //                       SAVE = 1: the raw fp32 accumulators (fenerf_layout.h "Tape"); SAVE = 2 (round 5): frac(theta) as 16-bit fixed
 //                       point (fenerf_layout.h "16-bit tape"): half the bytes and half the store instructions;
+//   <.., 0, false, 1|2> the opt-in reduced-precision forwards (round 5, fenerf_model_set_forward_mode): TERMS2 = 1 ("f16x2") drops the
+//                       wl*xh term of every product -- weights as one fp16 (their lo halves are neither fetched by the LDS-DMA nor read from
+//                       the ring nor multiplied) --; TERMS2 = 2 keeps three terms through the geometry trunk and the label / sigma
+//                       head (sigma -- the output the inverse-CDF resampling and the 0.9 fill threshold are sensitive to -- and the labels
+//                       are then the default's bit for bit) and two in the colour layers and the rgb head;
 //   <.., false, true >  the whole hierarchical render in ONE launch (round 4, fenerf_set_render_fusion): ray groups of whole octs, the
 //                       rays composited by the workgroup's own waves between its coarse and fine tiles -- see FuseArgs below and
 //                       profiles/r04_render_one_launch.md for why it is selectable and not the default (6 % slower).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "fenerf_composite_ray.h"
 #include "fenerf_film.h"
@@ -127,6 +134,7 @@ __device__ __forceinline__ unsigned phase_u16(float theta) {
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
 struct WStream {
+  bool skip;                   // f16x2: this wave's operand is a weight lo half -- never fetched (g_next still advances)
   unsigned long long g_next;   // global address of the next chunk to issue (uniform)
   unsigned voff;               // this lane's byte offset inside a chunk (the re-tiling permutation)
   unsigned ring_lds;           // LDS byte address of ring slot 0 + wave * 1024 (for M0)
@@ -136,13 +144,14 @@ struct WStream {
 
 __device__ __forceinline__ void ws_issue(WStream& w, int slot) {
   const unsigned m0 = w.ring_lds + (unsigned)slot * (CH * 1024);
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1"
-      :
-      : "v"(w.voff), "s"(w.g_next), "s"(m0)
-      : "memory");
+  if (!w.skip)
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(w.voff), "s"(w.g_next), "s"(m0)
+        : "memory");
   w.g_next += CH * 1024;
 }
 
@@ -156,9 +165,11 @@ __device__ __forceinline__ void ws_read_hi(AK& a, const WStream& w, int slot, in
   const float4* p = reinterpret_cast<const float4*>(w.ring_lane + slot * (CH * 1024) + spl * 4096);
   a.hi[0] = p[0 * 64]; a.hi[1] = p[2 * 64];
 }
+template <bool LO = true>
 __device__ __forceinline__ AK ws_read(const WStream& w, int slot, int spl) {
   AK a;
-  ws_read_lo(a, w, slot, spl);
+  if (LO) ws_read_lo(a, w, slot, spl);
+  else { a.lo[0] = make_float4(0.f, 0.f, 0.f, 0.f); a.lo[1] = a.lo[0]; }
   ws_read_hi(a, w, slot, spl);
   return a;
 }
@@ -188,10 +199,13 @@ __device__ __forceinline__ void ws_issue_late(WStream& w, int i, bool early) {
   if (!early) ws_issue(w, (i + DPF) % NSLOT);
 }
 
-// 6 MFMAs of one k32-step, the two row tiles interleaved (dependent MFMAs are 2 apart): wl*xh + wh*xl + wh*xh
+// 6 MFMAs of one k32-step, the two row tiles interleaved (dependent MFMAs are 2 apart): wl*xh + wh*xl + wh*xh  (LO = false: 4, no wl*xh)
+template <bool LO = true>
 __device__ __forceinline__ void kstep_mfma(f32x4 (&acc)[2], const AK& a, const half8& bh, const half8& bl) {
-  acc[0] = MFMA16W(as_half8(a.lo[0]), bh, acc[0]);
-  acc[1] = MFMA16W(as_half8(a.lo[1]), bh, acc[1]);
+  if (LO) {
+    acc[0] = MFMA16W(as_half8(a.lo[0]), bh, acc[0]);
+    acc[1] = MFMA16W(as_half8(a.lo[1]), bh, acc[1]);
+  }
   acc[0] = MFMA16W(as_half8(a.hi[0]), bl, acc[0]);
   acc[1] = MFMA16W(as_half8(a.hi[1]), bl, acc[1]);
   acc[0] = MFMA16W(as_half8(a.hi[0]), bh, acc[0]);
@@ -264,7 +278,9 @@ __device__ __forceinline__ void epi_all(const f32x4 (&acc)[2], int nbp, const fl
 // leave the whole LDS latency in front of every k32-step -- in both waves of the SIMD at once, they run in phase.)
 struct APipe { AK c, n; };
 struct FilmQ2 { FilmQ q[4]; };
-template <class BOP, class LOADQ, class PIECE>
+// LOR: the ring reads include the weight lo halves (false only when no stage of the kernel multiplies them: the reads run one chunk step
+// ahead, across stage boundaries); LOM: this stage multiplies them.
+template <bool LOR = true, bool LOM = true, class BOP, class LOADQ, class PIECE>
 __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& ws, int i, int sp0, BOP bop, LOADQ loadq, PIECE piece) {
   ws_step(ws, i, ws.early);
   FilmQ2 fq;
@@ -276,10 +292,10 @@ __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& w
     // issued in the k32-step that consumes it put one LDS round trip (~190 cycles of s_waitcnt per chunk step and wave,
     // SQ_WAIT_ANY) into every chunk step.
     if (spl == 0) loadq(fq);
-    const AK nn = ws_read(ws, (i + 1) % NSLOT, spl);
+    const AK nn = ws_read<LOR>(ws, (i + 1) % NSLOT, spl);
     __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
     half8 bh, bl;
-    if (bop(sp0 + spl, bh, bl)) kstep_mfma(acc, a.c, bh, bl);
+    if (bop(sp0 + spl, bh, bl)) kstep_mfma<LOR && LOM>(acc, a.c, bh, bl);
     if (spl == 1) piece(fq);
     a.c = a.n;
     a.n = nn;
@@ -287,11 +303,12 @@ __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& w
   }
 }
 // Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's k32-steps.
+template <bool LO = true>
 __device__ __forceinline__ void chunk_skip(APipe& a, WStream& ws, int i) {
   ws_step(ws, i, ws.early);
   ws_issue_late(ws, i, ws.early);
-  a.c = ws_read(ws, (i + 1) % NSLOT, 0);
-  a.n = ws_read(ws, (i + 1) % NSLOT, 1);
+  a.c = ws_read<LO>(ws, (i + 1) % NSLOT, 0);
+  a.n = ws_read<LO>(ws, (i + 1) % NSLOT, 1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -331,9 +348,12 @@ template <> struct FuseArgs<true> {
 #endif
 constexpr int FUSED_MAXM = FENERF_EXP_FUSED_MAXM;   // samples per ray (2 N) the ray phases handle: their LDS scratch is the 4-KiB colour-layer-0 block
 
-template <int H, bool GRID, int SAVE, bool FUSED = false>
+template <int H, bool GRID, int SAVE, bool FUSED = false, int TERMS2 = 0>
 __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_geo, int n_color, int n_lab, int C, FuseArgs<FUSED> F) {
   static_assert(!(FUSED && SAVE != 0), "the fused render is the no-grad path");
+  static_assert(TERMS2 == 0 || (SAVE == 0 && !FUSED), "the reduced-precision forwards are plain no-grad evaluations");
+  constexpr bool LOR = TERMS2 != 1;      // weight lo halves are fetched and read from the ring at all
+  constexpr bool LOC = TERMS2 == 0;      // ... and multiplied in the colour layers and the rgb head (geometry trunk, label / sigma head: whenever they are read)
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = (KS + 1) / 2;                              // chunks per square n-block body
   constexpr int C0_KS = KS + (GRID ? 1 : 0) + 1;                // colour layer 0: x | grid | dir
@@ -400,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   ws.ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 1024);
   ws.ring_lane = ring + lane * 16;
   ws.early = wave < NWAVE / 2;
+  ws.skip = TERMS2 == 1 && (wave & 1);       // f16x2: the lo operands are never fetched
 
   // work split: octs of 16-point tiles (one tile per wave) -- FUSED: ray groups of octs_per_group octs --, XCD-contiguous ranges
   const long long ntiles = (P.P + 15) / 16;
@@ -434,8 +455,8 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
   // cycles per launch (- 3.8 %), of which the power manager gives back half (2.03 -> 1.99 GHz): 1.367 -> 1.342 ms on the same box.
   if (wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);
   APipe a_cur;
-  a_cur.c = ws_read(ws, 0, 0);
-  a_cur.n = ws_read(ws, 0, 1);
+  a_cur.c = ws_read<LOR>(ws, 0, 0);
+  a_cur.n = ws_read<LOR>(ws, 0, 1);
 
 
   for (long long unit = o_begin + bi; unit < o_end; unit += blocks_in_x) {
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < C0_QB; ++qc) {
-            chunk_step(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](FilmQ2& fq) {
+            chunk_step<LOR, LOC>(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
                 piece_range<C0_QB>(qc, p0, p1);
@@ -628,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
         }
 #pragma unroll
-        for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+        for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
         epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
         // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
         {
@@ -638,9 +659,10 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
             return false;
           };
 #pragma unroll
-          for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
+          // (the label / sigma head keeps every term the kernel reads: with TERMS2 = 2 sigma and the labels are those of the default, bit for bit)
+          for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, true>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
-          for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+          for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
           const int lane_o = opaque(lane);
           const int n_o = lane_o & 15, f_o = 16 * (lane_o >> 5) + 4 * ((lane_o >> 4) & 1);
 #pragma unroll
@@ -656,6 +678,8 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           }
         }
       } else {
+        auto square_stage = [&](auto lom_c) {
+        constexpr bool LOM = decltype(lom_c)::value;
         auto bop = [&](int sp, half8& bh, half8& bl) -> bool {
           if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
           return false;
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < QB; ++qc) {
-            chunk_step(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](FilmQ2& fq) {
+            chunk_step<LOR, LOM>(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
                 piece_range<QB>(qc, p0, p1);
@@ -688,8 +712,16 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
         }
 #pragma unroll
-        for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+        for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
         epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
+        };
+        // TERMS2 = 2: three terms per product through the geometry trunk, two in the colour layers (one instantiation of the stage each; the
+        // branch sits between stages, not inside an MFMA stream)
+        if constexpr (TERMS2 == 2) {
+          if (l < n_geo) square_stage(std::true_type{}); else square_stage(std::false_type{});
+        } else {
+          square_stage(std::integral_constant<bool, LOR>{});
+        }
       }
 #pragma unroll
       for (int k = 0; k < KS; ++k) { xh[k] = yh[k]; xl[k] = yl[k]; }
@@ -702,9 +734,9 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
         return false;
       };
 #pragma unroll
-      for (int qc = 0; qc < QB; ++qc) chunk_step(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
+      for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, LOC>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
-      for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip(a_cur, ws, i);
+      for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
       const int lane_o = opaque(lane);
       const int n_o = lane_o & 15;
       if ((lane_o >> 4) == 0) {
@@ -794,10 +826,10 @@ static int launch_fused_t(const FenerfModel* m, const SirenParams& p, const Fuse
   return e == hipSuccess ? FENERF_OK : hip_fail16w(e, "fused render launch");
 }
 
-template <int H, bool GRID, int SAVE>
+template <int H, bool GRID, int SAVE, int TERMS2 = 0>
 static int launch_t(const FenerfModel* m, const SirenParams& p, void* stream) {
   const size_t lds = lds_bytes_16w(m, H);
-  auto kfn = siren16w_kernel<H, GRID, SAVE, false>;
+  auto kfn = siren16w_kernel<H, GRID, SAVE, false, TERMS2>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -827,6 +859,22 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
       case 64: return g ? w16::launch_t<64, true, 1>(m, q, stream) : w16::launch_t<64, false, 1>(m, q, stream);
       case 128: return g ? w16::launch_t<128, true, 1>(m, q, stream) : w16::launch_t<128, false, 1>(m, q, stream);
       case 256: return g ? w16::launch_t<256, true, 1>(m, q, stream) : w16::launch_t<256, false, 1>(m, q, stream);
+    }
+  }
+  if (m->forward_mode == FENERF_FORWARD_F16X2) {
+    switch (m->H) {
+      case 32: return g ? w16::launch_t<32, true, 0, 1>(m, q, stream) : w16::launch_t<32, false, 0, 1>(m, q, stream);
+      case 64: return g ? w16::launch_t<64, true, 0, 1>(m, q, stream) : w16::launch_t<64, false, 0, 1>(m, q, stream);
+      case 128: return g ? w16::launch_t<128, true, 0, 1>(m, q, stream) : w16::launch_t<128, false, 0, 1>(m, q, stream);
+      case 256: return g ? w16::launch_t<256, true, 0, 1>(m, q, stream) : w16::launch_t<256, false, 0, 1>(m, q, stream);
+    }
+  }
+  if (m->forward_mode == FENERF_FORWARD_F16X3_COLOR_X2) {
+    switch (m->H) {
+      case 32: return g ? w16::launch_t<32, true, 0, 2>(m, q, stream) : w16::launch_t<32, false, 0, 2>(m, q, stream);
+      case 64: return g ? w16::launch_t<64, true, 0, 2>(m, q, stream) : w16::launch_t<64, false, 0, 2>(m, q, stream);
+      case 128: return g ? w16::launch_t<128, true, 0, 2>(m, q, stream) : w16::launch_t<128, false, 0, 2>(m, q, stream);
+      case 256: return g ? w16::launch_t<256, true, 0, 2>(m, q, stream) : w16::launch_t<256, false, 0, 2>(m, q, stream);
     }
   }
   switch (m->H) {

@@ -25,8 +25,15 @@ def _f32(t, device):
 class NativeModel:
     """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
 
+    # precision strings that are a FENERF_PREC_F16X3 model with a reduced-precision NO-GRAD forward (include/fenerf.h
+    # fenerf_model_set_forward_mode; round 5, opt-in): two fp16 MFMAs per product everywhere / in the colour layers and heads only
+    FORWARD_MODES = {"f16x2": 1, "f16x3c2": 2}
+
     def __init__(self, sd, spec, device, precision="f32", differentiable=False, wgrad_bf16_min_points=0):
         self.spec = dict(spec)
+        self.forward_mode = self.FORWARD_MODES.get(precision, 0)
+        self.requested_precision = precision
+        precision = "f16x3" if self.forward_mode else precision
         self.precision = precision
         self.differentiable = bool(differentiable)
         # > 0: AMP-class weight gradients (bf16 operands, include/fenerf.h FenerfModelDesc.wgrad_bf16_min_points); 0 = fp32 class
@@ -38,6 +45,9 @@ class NativeModel:
         with torch.cuda.device(self.device):
             d, keep = _lib.make_desc(sd, spec, precision, differentiable, self.wgrad_bf16_min_points)
             _lib.check(_lib.lib().fenerf_model_create(C.byref(d), C.byref(self._h)))
+            if self.forward_mode:
+                if _lib.lib().fenerf_model_set_forward_mode(self._h, self.forward_mode) < 0:
+                    raise _lib.FenerfError(-1, _lib.lib().fenerf_last_error().decode())
         self.C = spec["output_dim"]
         self.grid_shape = tuple(int(v) for v in sd["spatial_embeddings"].shape[2:]) if spec.get("grid_ch") else None   # (D, H, W)
         self.box_scale = 2 / 0.24       # UniformBoxWarp(0.24), siren.py:181-187 (what _lib.make_desc sets)

@@ -167,7 +167,7 @@ class _NativeSiren(nn.Module):
         device = torch.device(device if device is not None else params[0].device)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_model")
-        if nat is None or nat.device != device or nat.precision != self.precision:
+        if nat is None or nat.device != device or nat.requested_precision != self.precision:      # ("f16x2" / "f16x3c2": f16x3 handles with a reduced-precision forward)
             nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision)
             self.__dict__["_native_model"] = nat
         elif self.__dict__.get("_native_version") != ver:
@@ -186,9 +186,10 @@ class _NativeSiren(nn.Module):
         device = torch.device(device if device is not None else params[0].device)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_diff")
-        amp = self.AMP_MIN_POINTS if (self.grad_precision == "amp" and self.precision == "f16x3") else 0
-        if nat is None or nat.device != device or nat.precision != self.precision or nat.wgrad_bf16_min_points != amp:
-            nat = native.NativeModel(self._state_numpy(), self._spec(), device, self.precision, differentiable=True,
+        base = "f16x3" if self.precision in native.NativeModel.FORWARD_MODES else self.precision     # the differentiable path always runs three terms
+        amp = self.AMP_MIN_POINTS if (self.grad_precision == "amp" and base == "f16x3") else 0
+        if nat is None or nat.device != device or nat.precision != base or nat.wgrad_bf16_min_points != amp:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, base, differentiable=True,
                                      wgrad_bf16_min_points=amp)
             self.__dict__["_native_diff"] = nat
         elif self.__dict__.get("_native_diff_version") != ver:

@@ -178,6 +178,20 @@ int fenerf_model_create(const FenerfModelDesc* desc, FenerfModel** out);
 int fenerf_model_update(FenerfModel* m, const FenerfModelDesc* desc, void* stream);
 void fenerf_model_destroy(FenerfModel* m);
 
+/* Opt-in reduced-precision arithmetic for the NO-GRAD forward of a FENERF_PREC_F16X3 model (round 5; no reference analogue -- the
+ * reference's own low-precision mode is autocast fp16, train_double_latent_semantic.py:279).  The default evaluates every fp32 product as
+ * three fp16 MFMAs (wl xh + wh xl + wh xh: fp32-class results).  FENERF_FORWARD_F16X2 drops wl xh everywhere -- the weights enter as ONE
+ * fp16 value (2^-12 relative rounding each, a fixed perturbation of the network), a third of the MFMAs and half of the weight traffic
+ * through L2 -> LDS go away; FENERF_FORWARD_F16X3_COLOR_X2 keeps three terms through the geometry trunk and the label / sigma
+ * head (sigma -- which decides resampling bins and the 0.9 fill threshold -- and the labels stay the default's bit for bit) and two in the
+ * colour layers and the rgb head.  Both are measured beside the default in bench.py and
+ * against the same tests (profiles/r05_*): they do NOT meet the default's asserted bounds, hence opt-in.  fenerf_siren_forward*,
+ * fenerf_render_forward only; the differentiable path always runs the default.  Returns the previous mode or a negative error. */
+#define FENERF_FORWARD_F16X3 0
+#define FENERF_FORWARD_F16X2 1
+#define FENERF_FORWARD_F16X3_COLOR_X2 2
+int fenerf_model_set_forward_mode(FenerfModel* m, int mode);
+
 /* Training keeps the weights on the GPU, so re-packing them through the host every optimizer step (fenerf_model_update)
  * costs more than the step itself.  For FENERF_PREC_F32 models the packed streams are pure permutations (plus zero
  * padding) of the parameters (FENERF_PREC_F16X3: of their scaled fp16 hi / lo halves): the caller builds them on the device (a gather with an index map obtained ONCE by packing
