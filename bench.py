@@ -173,6 +173,8 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                              f"and the optimizer are NOT in it (the reference's own step, generator_ddp(z) + backward [+ Adam], is "
                              f"gstep_ddp.ms_no_ddp / .ms / .ms_with_optimizer); native differentiable path, precision {precision}, weight-gradient operands "
                              + {"f32": "fp32 class (default)", "amp": "bf16, one MFMA per product: AMP class, opt-in (siren.grad_precision = 'amp')",
+                                "amp16": "bf16 weight-gradient operands AND the 16-bit tape: AMP class throughout (FiLM frequency gradients included), "
+                                         "opt-in (siren.grad_precision = 'amp16')",
                                 "tape16": "fp32 class, with the 16-bit tape between forward and backward (frac(theta) as fixed point, 2 instead of 4 bytes per "
                                           "(point, layer-feature)): gradients within ~1.2e-4 of fp64 autograd instead of ~4e-5 -- a tier between the default "
                                           "and AMP, opt-in (siren.grad_precision = 'tape16')"}[grad_precision],
@@ -239,7 +241,8 @@ def curriculum_generator(spec, sd, dev, precision, seed=11):
 
 
 GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_bytes", "allreduce_bytes_largest_tensor", "ddp_bucket_cap_mb",
-                  "allreduce_per_micro_batch", "ms_with_optimizer", "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "rays_per_s",
+                  "allreduce_per_micro_batch", "ms_with_optimizer", "ms_optimizer_step_4_micro_batches", "ms_optimizer_step_4_micro_batches_one_allreduce",
+                  "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "rays_per_s",
                   "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend", "peak_GB")
 # `ms_tuned`: what fenerf_amd recommends instead of the reference's wrapper -- fenerf_amd.dist.prepare_for_ddp(generator) (two-node backward:
 # the grid gradient reaches DDP before the weight-gradient kernels run, so its all-reduce overlaps them) + RECOMMENDED_DDP_KWARGS
@@ -301,6 +304,28 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         ddp = DDP(model, device_ids=[dev.index] if cuda else None, find_unused_parameters=True)      # the reference's wrapper, train...py:148
         ms = run(ddp, iters, False)
         ms_opt = run(ddp, max(2, iters // 2), True)
+        # One OPTIMIZER step of the reference's loop = `batch_split` (4) micro-batches (train_double_latent_semantic.py:407-446).  The reference
+        # wraps no no_sync() around them: four all-reduces of the full gradient set per optimizer step.  fenerf_amd.dist.micro_batch_sync
+        # accumulates locally and reduces in the last micro-batch's backward: the same gradients (fp32 summation order), one all-reduce.
+        # Both patterns through the reference's wrapper, so that a multi-GPU run shows them side by side.
+        from fenerf_amd import dist as fdist
+        import contextlib
+
+        def opt_step_ms(sync_once, n=2, MB=4):
+            def one():
+                opt.zero_grad(set_to_none=True)
+                for s_ in range(MB):
+                    with (fdist.micro_batch_sync(ddp, s_, MB) if sync_once else contextlib.nullcontext()):
+                        loss_of(ddp).backward()
+                opt.step()
+            one()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                one()
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0) / n * 1e3
+        ms_mb4, ms_mb4_once = opt_step_ms(False), opt_step_ms(True)
         del ddp
         opt.zero_grad(set_to_none=True)
         if tuned_prepare is not None:
@@ -316,6 +341,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         out = {"what": what, "ms": ms, "ms_no_ddp": ms_bare, "allreduce_ms_exposed": ms - ms_bare,
                "allreduce_bytes": sum(p.numel() * 4 for p in params), "allreduce_bytes_largest_tensor": max(p.numel() for p in params) * 4,
                "ddp_bucket_cap_mb": 25, "allreduce_per_micro_batch": True, "ms_with_optimizer": ms_opt,
+               "ms_optimizer_step_4_micro_batches": ms_mb4, "ms_optimizer_step_4_micro_batches_one_allreduce": ms_mb4_once,
                "ms_tuned": ms_tuned, "allreduce_ms_exposed_tuned": ms_tuned - ms_bare,
                "tuned_config": ("fenerf_amd.dist.prepare_for_ddp(generator) [grid gradient delivered before the weight-gradient kernels], " if tuned_prepare else "")
                                + ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
@@ -657,10 +683,11 @@ def main(argv=None):
                     out["gstep_amp"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision="amp")
                 except Exception as e:
                     out["gstep_amp"] = {"error": f"{type(e).__name__}: {e}"}
-                try:   # opt-in 16-bit tape (round 5): the tier between the default and AMP; reported beside, never instead
-                    out["gstep_tape16"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision="tape16")
-                except Exception as e:
-                    out["gstep_tape16"] = {"error": f"{type(e).__name__}: {e}"}
+                for key in ("tape16", "amp16"):   # opt-in 16-bit tape (round 5): the tier between the default and AMP, and AMP on top of it; beside, never instead
+                    try:
+                        out["gstep_" + key] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision=key)
+                    except Exception as e:
+                        out["gstep_" + key] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_gstep_b6 and (B, S, N) == (1, 128, 24):
                 try:   # BASELINE.json configs[2]: the reference's generator micro-batch (batch 24 split 4 -> 6 images of 128x128 x 24+24 per GPU)
                     torch.cuda.empty_cache()

@@ -1187,8 +1187,8 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.film16w = m->precision == FENERF_PREC_F16X3 ? bwd16w_film_unit((long long)B * P, P) : 0;
   p.bf16_dump = use_bf16_dump(m, (long long)B * P);
   p.tape_u16 = tape_format == FENERF_TAPE_U16;
-  if (p.tape_u16 && (film_only || !weights || m->precision != FENERF_PREC_F16X3 || p.bf16_dump)) {
-    set_error("16-bit tape: needs a FENERF_PREC_F16X3 model with fp32-class weight gradients, a full (not FiLM-only) backward and the FiLM layers' weights");
+  if (p.tape_u16 && (film_only || !weights || m->precision != FENERF_PREC_F16X3)) {
+    set_error("16-bit tape: needs a FENERF_PREC_F16X3 model, a full (not FiLM-only) backward and the FiLM layers' weights");
     return FENERF_E_INVALID;
   }
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);

@@ -195,6 +195,12 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 # stage lives for one backward pass only (an engine callback drops it): torch.autograd.grad on a subset of the inputs is supported in
 # the sense that it returns what it can and leaks nothing; it does not deliver weight gradients unless the weight stage's inputs are asked for.
 # ----------------------------------------------------------------------------------------------------------------------------------
+# d(theta) dumps the render stage of a split backward leaves for the weight stage: the last SPLIT_KEEP_CHUNKS backward chunks' (a chunk = one
+# pass of a 128 x 128 x 24 image = 4.4 GB at H = 256).  Four chunks = 6 ms of weight-gradient kernels for the 113-MB grid all-reduce to run
+# beside, 17.6 GB instead of all 12 chunks' 52 GB at configs[2]'s 6-image micro-batch (round-4 review: peak 108 GB against 56.6 one-node).
+SPLIT_KEEP_CHUNKS = 4
+
+
 class _SplitState:
     """what the render stage's backward leaves for the weight stage's backward of the same render"""
     def __init__(self):
@@ -221,7 +227,8 @@ class HierarchicalWeightStage(torch.autograd.Function):
         need = ctx.needs_input_grad
         r = _siren_autograd.run_weight_grads(nat, 2 * B, w["Pp"], w["film2"], w["pts2"], w["rd2"], w["out2"], w["d_out2"], w["tape2"], w["tape_e2"],
                                              w["chunks"], w["dumps"], tape_format=w["tape_format"],
-                                             weights=_siren_autograd.film_layer_weights(module, w["params"]) if w["tape_format"] else None)
+                                             weights=_siren_autograd.film_layer_weights(module, w["params"]) if w["tape_format"] else None,
+                                             acc=w["acc"])
         fold = lambda t, ok: (t[:B] + t[B:]) if ok else None
         film_grads = (fold(r["d_freq_geo"], need[2]), fold(r["d_phase_geo"], need[3]), fold(r["d_freq_app"], need[4]), fold(r["d_phase_app"], need[5]))
         params = w["params"]                                    # module._render_params() order, grid included
@@ -264,10 +271,23 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
         film2 = [torch.cat([t, t]) for t in (fg, pg, fa, pa)]            # pass-major: image b' = pass * B + b
         rd2 = torch.cat([rd, rd]) if rd.numel() else None
         chunks = _siren_autograd.plan_chunks(2 * B, Pp)
-        dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, chunks, tape_format=ctx.tape_format)
+        # Bounded memory (round 5): only the LAST `split_keep_chunks` chunks' dumps are kept for the weight stage -- their weight-gradient
+        # kernels are what the grid gradient's all-reduce runs beside; every earlier chunk takes its chain AND its weight gradients right
+        # here, its dump freed before the next chain is launched (the one-node schedule), its gradients carried along as a running sum.
+        # Same kernels on the same chunks, sums in chunk order: the gradients are those of the one-node backward.
+        keep = max(1, int(getattr(module, "split_keep_chunks", SPLIT_KEEP_CHUNKS)))
+        early, late = chunks[:max(0, len(chunks) - keep)], chunks[max(0, len(chunks) - keep):]
+        tape_e = tape_e2 if tape_e2.numel() else None
+        weights = _siren_autograd.film_layer_weights(module, module._render_params()) if ctx.tape_format else None
+        acc, d_grid = _siren_autograd.GradSum(), None
+        for c in early:
+            d1, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, [c], tape_format=ctx.tape_format, d_grid=d_grid)
+            _siren_autograd.run_weight_grads(nat, 2 * B, Pp, film2, pts2, rd2, out2, d_out2, tape2, tape_e, [c], d1, tape_format=ctx.tape_format,
+                                             weights=weights, acc=acc, finish=False)
+        dumps, d_grid = _siren_autograd.run_chains(nat, 2 * B, Pp, film2, pts2, out2, d_out2, tape2, late, tape_format=ctx.tape_format, d_grid=d_grid)
         state = ctx.state
         state.work = dict(nat=nat, B=B, Pp=Pp, film2=film2, pts2=pts2, rd2=rd2, out2=out2, d_out2=d_out2, tape2=tape2, tape_format=ctx.tape_format,
-                          tape_e2=tape_e2 if tape_e2.numel() else None, chunks=chunks, dumps=dumps, params=module._render_params())
+                          tape_e2=tape_e, chunks=late, dumps=dumps, acc=acc if early else None, params=module._render_params())
         # The dumps (as large as the tape) belong to THIS backward pass: if the weight stage does not consume them -- torch.autograd.grad
         # with only the grid as input, an exception between the two stages -- they are dropped when the engine finishes the pass, not
         # when the graph dies; a retained graph's next backward then starts from a clean state instead of overwriting a stale one.

@@ -252,15 +252,44 @@ def plan_chunks(nB, Pp, max_points=None):
     return [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
 
 
-def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks, tape_format=0):
-    """First half of a SPLIT backward (generators/autograd.py HierarchicalRenderSplitFunction): every chunk's chain launch, nothing else.
-    -> ([d(theta) dump per chunk], d_grid_cl or None).  All dumps are alive together afterwards (as large as the tape: the price of
-    handing the grid gradient -- final once the last chain has run -- to autograd / DistributedDataParallel BEFORE the weight-gradient
-    kernels, so that its all-reduce runs beside them)."""
+class GradSum:
+    """The sum of per-chunk siren_param_grads results in chunk order, exactly as chunked_backward forms it: weight / bias gradients add,
+    FiLM gradients are one row per (pass, image) -- written by the image's first point range, added to by its later ones."""
+
+    def __init__(self):
+        self.total, self.film_rows, self.acc_img = None, {k: [] for k in FILM_KEYS}, None
+
+    def add(self, chunk, r):
+        b, nb, s, n = chunk
+        if self.total is None:
+            self.total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
+        else:
+            _add_all(_flat(self.total), _flat(r, FILM_KEYS))
+        if s == 0:
+            self.acc_img = [r[k] for k in FILM_KEYS]
+            for k, t in zip(FILM_KEYS, self.acc_img):
+                self.film_rows[k].append(t)
+        else:
+            _add_all(self.acc_img, [r[k] for k in FILM_KEYS])
+
+    def result(self):
+        total = dict(self.total)
+        for k, rows in self.film_rows.items():
+            total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+        return total
+
+
+def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks, tape_format=0, d_grid=None):
+    """First half of a SPLIT backward (generators/autograd.py HierarchicalRenderSplitFunction): the chain launches of `chunks`, nothing else.
+    -> ([d(theta) dump per chunk], d_grid_cl or None).  The dumps stay alive until run_weight_grads has consumed them (each as large as its
+    chunk's tape: the price of handing the grid gradient -- final once the last chain has run -- to autograd / DistributedDataParallel
+    BEFORE the weight-gradient kernels, so that its all-reduce runs beside them).  d_grid: the channels-last gradient grid to scatter into
+    (a caller that runs some chunks' chains elsewhere passes the same one to every call); None = a fresh zeroed one."""
     LH = nat.tape_words_per_point(tape_format)
     G, C = nat.spec["grid_ch"], nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
-    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G else None
+    if d_grid is None and G:
+        d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device)
     dumps = []
     for b, nb, s, n in chunks:
         film_c = tuple(t[b:b + nb] for t in film)
@@ -274,13 +303,14 @@ def run_chains(nat, nB, Pp, film, points, out, d_out, tape, chunks, tape_format=
     return dumps, d_grid
 
 
-def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, chunks, dumps, tape_format=0, weights=None):
-    """Second half of a split backward: the weight-gradient launches of every chunk over the dumps run_chains left, summed like
-    chunked_backward does.  Frees each dump after its chunk.  -> grads dict (FiLM gradients with [nB] leading)."""
+def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, chunks, dumps, tape_format=0, weights=None, acc=None, finish=True):
+    """Second half of a split backward: the weight-gradient launches of `chunks` over the dumps run_chains left, summed like
+    chunked_backward does (acc: a GradSum that already holds earlier chunks' gradients).  Frees each dump after its chunk.
+    -> grads dict (FiLM gradients with [nB] leading), or the GradSum itself when not `finish`."""
     LH = nat.tape_words_per_point(tape_format)
     G, C = nat.spec["grid_ch"], nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
-    total, film_rows, acc_img = None, {k: [] for k in FILM_KEYS}, None
+    acc = GradSum() if acc is None else acc
     for i, (b, nb, s, n) in enumerate(chunks):
         film_c = tuple(t[b:b + nb] for t in film)
         g0 = b * Pp + s
@@ -290,19 +320,8 @@ def run_weight_grads(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
                                   out[b:b + nb, s:s + n], d_out[b:b + nb, s:s + n], tape_c, tape_e[g0:g0 + nb * n] if G else None, d_t,
                                   tape_format=tape_format, weights=weights)
         del d_t
-        if total is None:
-            total = {k: ([x for x in v] if isinstance(v, list) else v) for k, v in r.items() if k not in FILM_KEYS}
-        else:
-            _add_all(_flat(total), _flat(r, FILM_KEYS))
-        if s == 0:
-            acc_img = [r[k] for k in FILM_KEYS]
-            for k, t in zip(FILM_KEYS, acc_img):
-                film_rows[k].append(t)
-        else:
-            _add_all(acc_img, [r[k] for k in FILM_KEYS])
-    for k, rows in film_rows.items():
-        total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
-    return total
+        acc.add((b, nb, s, n), r)
+    return acc.result() if finish else acc
 
 
 def check_same_weights(ctx, nat):

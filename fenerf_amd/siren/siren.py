@@ -132,13 +132,15 @@ class _NativeSiren(nn.Module):
     # point instead of the fp32 accumulators (include/fenerf.h FENERF_TAPE_U16): half the tape bytes in three kernels, +-4.8e-5 rad on
     # every recomputed activation, gradients within ~1.2e-4 of fp64 autograd instead of ~4e-5 -- a tier between the two.  Applies to
     # backward passes that take weight gradients; inversion (FiLM gradients only) keeps the fp32 tape whatever this says.
+    # "amp16" = both: bf16 weight-gradient operands AND the 16-bit tape (the FiLM frequency gradients, which "amp" takes from the fp32 tape,
+    # then come from the bf16 products too: everything AMP class) -- the fastest generator step this package has.
     grad_precision = "f32"
     AMP_MIN_POINTS = 65536
 
     def tape_format(self, nat, film_only):
         """the tape format (_lib.TAPE_*) a differentiable evaluation on `nat` uses"""
         from .. import _lib
-        return _lib.TAPE_U16 if (self.grad_precision == "tape16" and nat.precision == "f16x3" and not film_only) else _lib.TAPE_F32
+        return _lib.TAPE_U16 if (self.grad_precision in ("tape16", "amp16") and nat.precision == "f16x3" and not film_only) else _lib.TAPE_F32
 
     def _spec(self):
         H = self.hidden_dim
@@ -187,7 +189,7 @@ class _NativeSiren(nn.Module):
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         nat = self.__dict__.get("_native_diff")
         base = "f16x3" if self.precision in native.NativeModel.FORWARD_MODES else self.precision     # the differentiable path always runs three terms
-        amp = self.AMP_MIN_POINTS if (self.grad_precision == "amp" and base == "f16x3") else 0
+        amp = self.AMP_MIN_POINTS if (self.grad_precision in ("amp", "amp16") and base == "f16x3") else 0
         if nat is None or nat.device != device or nat.precision != base or nat.wgrad_bf16_min_points != amp:
             nat = native.NativeModel(self._state_numpy(), self._spec(), device, base, differentiable=True,
                                      wgrad_bf16_min_points=amp)

@@ -81,6 +81,8 @@ def test_bench_self_launch_rendezvous_world_size_2():
     assert leg["n_ranks"] == leg["n_ranks_seen"] == 2 and leg["dist_backend"] == "gloo" and leg["allreduce_per_micro_batch"] is True
     assert leg["allreduce_bytes"] == 4 * (16 * 32 + 32 + 32 * 4 + 4) and leg["allreduce_bytes_largest_tensor"] == 4 * 16 * 32
     assert leg["ms"] > 0 and leg["ms_no_ddp"] > 0 and abs(leg["allreduce_ms_exposed"] - (leg["ms"] - leg["ms_no_ddp"])) < 1e-9
+    # round 5: one optimizer step of four micro-batches, the reference's pattern (an all-reduce per micro-batch) beside micro_batch_sync (one)
+    assert leg["ms_optimizer_step_4_micro_batches"] > 0 and leg["ms_optimizer_step_4_micro_batches_one_allreduce"] > 0
     assert d["params_identical_across_ranks"] is True
 
 

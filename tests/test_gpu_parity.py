@@ -2085,18 +2085,20 @@ _FP64_BACKWARD_REFERENCE = {}
 @pytest.mark.parametrize("precision,H,grid,B,P", [("f16x3", 32, 5, 1, 40000), ("f32", 32, 5, 1, 40000), ("tape16", 32, 5, 1, 40000),
                                                   ("f16x3", 64, 0, 2, 33024), ("tape16", 64, 0, 2, 33024),
                                                   ("f16x3", 256, 6, 1, 65536), ("f32", 256, 6, 1, 65536), ("amp", 256, 6, 1, 65536),
-                                                  ("tape16", 256, 6, 1, 65536),
+                                                  ("tape16", 256, 6, 1, 65536), ("amp16", 256, 6, 1, 65536),
                                                   ("f16x3", 256, 6, 1, 393216), ("amp", 256, 6, 1, 393216), ("tape16", 256, 6, 1, 393216)])
 def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
     # "amp" = f16x3 with the opt-in AMP-class weight-gradient operands (bf16, one MFMA per product; siren.grad_precision)
     # "tape16" = f16x3 with the opt-in 16-bit tape (frac(theta) as fixed point between forward and backward): the tier between the two
-    amp, t16 = precision == "amp", precision == "tape16"
+    # "amp16" = both (everything that passes through the dump OR the tape is then AMP class: the FiLM frequency gradients too)
+    amp16 = precision == "amp16"
+    amp, t16 = precision in ("amp", "amp16"), precision == "tape16"
     precision = "f16x3" if (amp or t16) else precision
     from oracle import fenerf_oracle_grad as OG
     from fenerf_amd.siren import autograd as SA
     kind = "texture" if grid else "baseline"
     mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
-    mod.grad_precision = "amp" if amp else ("tape16" if t16 else "f32")
+    mod.grad_precision = "amp16" if amp16 else ("amp" if amp else ("tape16" if t16 else "f32"))
     rng = np.random.default_rng(17)
     pts = rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)
     dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
@@ -2133,7 +2135,7 @@ def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
     named = dict(mod.named_parameters())
     errs.update({k: _rel_err(N_(named[k].grad), v) for k, v in sd_ref.items()})
     worst = max(errs, key=errs.get)
-    print(f"[parity] SIREN backward at scale [{'amp (bf16 weight-gradient operands)' if amp else ('tape16 (16-bit tape)' if t16 else precision)}] H={H} B={B} P={P} ({nchunks} "
+    print(f"[parity] SIREN backward at scale [{('amp16 (bf16 operands + 16-bit tape)' if amp16 else 'amp (bf16 weight-gradient operands)') if amp else ('tape16 (16-bit tape)' if t16 else precision)}] H={H} B={B} P={P} ({nchunks} "
           f"backward launch(es)): worst relative error over {len(errs)} gradient tensors {errs[worst]:.2e} ({worst}); forward max|err| {fwd_err:.1e}")
     # measured: f32 1.6e-5 .. 2.2e-5; f16x3 3.3e-5 .. 4.0e-5
     if t16:
@@ -2148,10 +2150,10 @@ def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
         # AMP class, opt-in: the upstream gradient here is point-wise random, so every weight gradient is a pure noise sum and the
         # unbiased bf16 roundings (2^-9) show at full size whatever P is (measured 2.4e-3 .. 2.7e-3 at 65,536 and at 393,216 points);
         # what does not pass through the bf16 dump keeps the fp32 class
-        through_dump = [k for k in errs if k.endswith("layer.weight")]
+        through_dump = [k for k in errs if k.endswith("layer.weight") or (amp16 and k.startswith("freq_"))]
         rest = max(errs[k] for k in errs if k not in through_dump)
         print(f"[parity]   ... of which through the bf16 dump {max(errs[k] for k in through_dump):.2e}, everything else {rest:.2e}")
-        assert max(errs[k] for k in through_dump) <= 6e-3 and rest <= 6e-5
+        assert max(errs[k] for k in through_dump) <= 6e-3 and rest <= (2.5e-4 if amp16 else 6e-5)
 
 
 def test_grid_gradient_values_at_full_size_96cubed_grid():
