@@ -154,7 +154,7 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 N_PHASES = 17        # include/fenerf.h FENERF_N_PHASES
 FUSION_AUTO, FUSION_OFF, FUSION_FORCE = 0, 1, 2      # include/fenerf.h fenerf_set_render_fusion
-TAPE_F32, TAPE_U16 = 0, 1                            # include/fenerf.h FENERF_TAPE_*
+TAPE_F32, TAPE_U16, TAPE_F32_W = 0, 1, 2             # include/fenerf.h FENERF_TAPE_*
 
 _lib = None
 

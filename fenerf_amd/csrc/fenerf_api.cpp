@@ -723,9 +723,9 @@ extern "C" size_t fenerf_siren_tape_bytes(const FenerfModel* m, int64_t total_po
 }
 
 static int check_tape_format(const FenerfModel* m, int tape_format) {
-  if (tape_format != FENERF_TAPE_F32 && tape_format != FENERF_TAPE_U16) return fail(FENERF_E_INVALID, "unknown tape format");
-  if (tape_format == FENERF_TAPE_U16 && m->precision != FENERF_PREC_F16X3)
-    return fail(FENERF_E_UNSUPPORTED, "FENERF_TAPE_U16: FENERF_PREC_F16X3 models only (the exact-fp32 kernels keep the fp32 tape)");
+  if (tape_format != FENERF_TAPE_F32 && tape_format != FENERF_TAPE_U16 && tape_format != FENERF_TAPE_F32_W) return fail(FENERF_E_INVALID, "unknown tape format");
+  if (tape_format != FENERF_TAPE_F32 && m->precision != FENERF_PREC_F16X3)
+    return fail(FENERF_E_UNSUPPORTED, "FENERF_TAPE_U16 / FENERF_TAPE_F32_W: FENERF_PREC_F16X3 models only (the exact-fp32 kernels keep the fp32 tape)");
   return FENERF_OK;
 }
 
@@ -943,10 +943,10 @@ extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t
                                             const FenerfSirenGrads* weights, void* workspace, void* film_ws, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (int rcf = check_tape_format(m, tape_format)) return rcf;
-  if (tape_format == FENERF_TAPE_U16) {
-    if (!weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: the FiLM layers' weights are required (the frequency gradients are derived from the weight-gradient sums)");
-    for (int i = 0; i < m->n_geo; ++i) if (!weights->geo_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: weights->geo_w has a NULL entry");
-    for (int i = 0; i < m->n_color; ++i) if (!weights->color_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: weights->color_w has a NULL entry");
+  if (tape_format != FENERF_TAPE_F32) {
+    if (!weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 / _F32_W: the FiLM layers' weights are required (the frequency gradients are derived from the weight-gradient sums)");
+    for (int i = 0; i < m->n_geo; ++i) if (!weights->geo_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 / _F32_W: weights->geo_w has a NULL entry");
+    for (int i = 0; i < m->n_color; ++i) if (!weights->color_w[i]) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 / _F32_W: weights->color_w has a NULL entry");
   }
   if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
@@ -961,8 +961,8 @@ extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t
   want += 4; have += (g->head_w != nullptr) + (g->head_b != nullptr) + (g->rgb_w != nullptr) + (g->rgb_b != nullptr);
   if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
   const bool film_only = have == 0;
-  if (film_only && tape_format == FENERF_TAPE_U16)
-    return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 carries no accumulator: FiLM-only gradients need the fp32 tape");
+  if (film_only && tape_format != FENERF_TAPE_F32)
+    return fail(FENERF_E_INVALID, "FiLM-only gradients need FENERF_TAPE_F32 (the chain kernel's second FiLM sum)");
   int rc = check_dump(m, d_t, (long long)B * P);
   if (rc) return rc;
   const float *fp, *pp;
@@ -1351,8 +1351,8 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
   want += 4; have += (grads->head_w != nullptr) + (grads->head_b != nullptr) + (grads->rgb_w != nullptr) + (grads->rgb_b != nullptr);
   if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
   const bool film_only = have == 0;
-  if (film_only && tape_format == FENERF_TAPE_U16) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 carries no accumulator: FiLM-only gradients need the fp32 tape");
-  if (tape_format == FENERF_TAPE_U16 && !weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16: the FiLM layers' weights are required");
+  if (film_only && tape_format != FENERF_TAPE_F32) return fail(FENERF_E_INVALID, "FiLM-only gradients need FENERF_TAPE_F32 (the chain kernel's second FiLM sum)");
+  if (tape_format != FENERF_TAPE_F32 && !weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 / _F32_W: the FiLM layers' weights are required");
   if (!film_only && m->grid_ch && !d_grid_ncdhw) return fail(FENERF_E_INVALID, "d_grid_ncdhw is NULL");
   const RenderSave sv = render_save(m, B, R, N, tape_format, lock_view);
   if (save_bytes < sv.total) return fail(FENERF_E_INVALID, "save buffer too small (see fenerf_render_save_bytes)");

@@ -32,6 +32,10 @@
 // its own partial sums.  The T16 instantiations live in a second translation unit (fenerf_siren_bwd16w_t16.hip includes this file with
 // FENERF_BW16_T16 = 1) so that the two halves compile side by side.
 //
+// S1 = false (FENERF_TAPE_U16, FENERF_TAPE_F32_W): the second FiLM sum -- sum_p d theta * tape, the frequency gradient's raw material:
+// a multiply and a 16-lane butterfly per row tile -- is not formed (a fifth of the kernel's VALU instructions); the weight-gradient stage
+// derives the frequency gradient from its own partial sums (fenerf_siren_wgrad.hip).  FiLM-only launches (inversion) always run S1 = true.
+//
 // With P.d_grid_cl set (fenerf_siren_backward_grid) the gradient wrt the sampled grid features is not written to d_e: the kernel
 // scatters it into the channels-last gradient grid itself (scatter_pairs below: float atomics, the arithmetic of
 // grid_backward_kernel), two points x 32 channels per atomic instruction, one point pair per body of the following stage.
@@ -46,7 +50,7 @@
 #include "fenerf_trig.h"
 
 #ifndef FENERF_BW16_T16
-#define FENERF_BW16_T16 0
+#define FENERF_BW16_T16 0      // tape mode of this translation unit: 0 = FENERF_TAPE_F32, 1 = FENERF_TAPE_U16, 2 = FENERF_TAPE_F32_W
 #endif
 
 namespace fenerf {
@@ -268,11 +272,12 @@ __device__ __forceinline__ EpiIn epi_read(const Sink& k, int nbp, int rt, int tb
 // E(rt) of n-block nbp: d theta = dx cos(2 pi theta), d z = d theta f'' 2 pi split into bf16 (hi = truncation, lo = the
 // remainder rounded to nearest) -> slots 4 rt .. 4 rt + 3 of k32-step nbp of the next stage's B operand; the d theta store.
 // BD (bf16 dump, header of this file): also x = sin(2 pi theta) -- bitwise the forward's activation -- and both rounded to bf16.
-template <bool BD, bool T16>
+template <bool BD, bool T16, bool S1>
 __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, u32x4& yh, u32x4& yl, int rt) {
   [[maybe_unused]] const float TWO_PI = 6.28318530717958647692f;
   const float f[4] = {q.f.x, q.f.y, q.f.z, q.f.w};
   EpiOut o;
+  if (!S1) o.dtt = f32x4{0.f, 0.f, 0.f, 0.f};
   unsigned hb[4];
   float rem[4];
   [[maybe_unused]] float xs[4];
@@ -290,7 +295,7 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
     const float dt = acc[r] * cos_rev_reduced(th);
     if (BD) xs[r] = sin_rev_reduced(th);
     o.dt[r] = dt;
-    o.dtt[r] = dt * tr;        // 16-bit tape: 0 -- no accumulator in the tape; the frequency gradient comes from the weight-gradient partial sums
+    if (S1) o.dtt[r] = dt * tr;        // (!S1: not formed -- the frequency gradient comes from the weight-gradient partial sums)
     const float dz = dt * (f[r] * TWO_PI);
     hb[r] = __builtin_bit_cast(unsigned, dz);
     rem[r] = dz - __builtin_bit_cast(float, hb[r] & 0xffff0000u);
@@ -317,8 +322,10 @@ __device__ __forceinline__ EpiOut epi_compute(const f32x4& acc, const EpiIn& q, 
   return o;
 }
 
-template <int H, bool GRID, bool WGS, bool BD, bool T16>
+template <int H, bool GRID, bool WGS, bool BD, int TAPE>
 __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, int n_geo, int n_color, int n_lab, int C) {
+  constexpr bool T16 = TAPE == 1;       // FENERF_TAPE_U16: 16-bit phases
+  constexpr bool S1 = TAPE == 0;        // FENERF_TAPE_F32: the kernel forms sum_p d theta * tape (FiLM-only launches need it)
   constexpr int NB = H / 32, KS = H / 32;                       // 32-row n-blocks; k32-steps of an H-wide input
   constexpr int QB = pad_pf16(2 * (H / 16)) / CH;               // chunks per square body
   constexpr int C0_QB = pad_pf16(2 * (H / 16 + 2)) / CH;        // colour-layer-0 body: + one k32-step of head rows
@@ -582,9 +589,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
             q.p = *reinterpret_cast<const float4*>(k.film + FILM_F / 4 + 32 * nb + 8 * rt);
             q.t = t_rgb[nb][T16 ? 0 : rt];
           }
-          o2[rt] = epi_compute<BD, T16>(acc, q, zh[nb], zl[nb], rt);
+          o2[rt] = epi_compute<BD, T16, S1>(acc, q, zh[nb], zl[nb], rt);
           if (!BD && dump) st_f4_nt(k.dt_base + (nb * 4 + rt) * 1024, k.toff, o2[rt].dt);
-          const f32x2 s = {row_sum4(o2[rt].dt, k.b0, k.b1), row_sum4(o2[rt].dtt, k.b0, k.b1)};
+          const f32x2 s = {row_sum4(o2[rt].dt, k.b0, k.b1), S1 ? row_sum4(o2[rt].dtt, k.b0, k.b1) : 0.f};
           if (WGS) fs_write(nb % 3, rt, s);
           else st_f2(k.film_base + nb * 256 + rt * 128, k.foff, s);
         }
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   const int rt = it >> 1;
                   if ((it & 1) == 0) {
                     if constexpr (nb > 0) {
-                      eo[rt] = epi_compute<BD, T16>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
+                      eo[rt] = epi_compute<BD, T16, S1>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
                       if constexpr (!BD) { if (dump) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt); }
                       else if (rt == 1) dump_bf16(k, nb - 1, eo, true);
                     }
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                     else tape_issue(k.tape_next, 0, rt, (NBODY + tpar) & 1, k.ttoff);
                   } else {
                     if constexpr (nb > 0) {
-                      const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), row_sum4(eo[rt].dtt, k.b0, k.b1)};
+                      const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), S1 ? row_sum4(eo[rt].dtt, k.b0, k.b1) : 0.f};
                       if (WGS) {
                         fs_write(kb_next, rt, sm);
                         if (rt == 1) fs_push(k.film_base + (nb - 1) * 256);
@@ -745,11 +752,11 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           if (rt == 0 && !T16) wait_vmcnt<2 * QBS - 1 - c0>(); else wait_vmcnt<2 * QBS - 1 - c1>();
           LDS_FENCE();
           const EpiIn q = epi_read<FILM_F / 4, T16>(k, NBODY - 1, rt, ((NBODY - 1) + tpar) & 1);
-          o2[rt] = epi_compute<BD, T16>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
+          o2[rt] = epi_compute<BD, T16, S1>(acc_prev[rt], q, yh[NBODY - 1], yl[NBODY - 1], rt);
           const EpiOut& o = o2[rt];
           if (!BD) { if (dump) st_f4_nt(k.dt_base + ((NBODY - 1) * 4 + rt) * 1024, k.toff, o.dt); }
           else if (rt == 1) dump_bf16(k, NBODY - 1, o2, true);
-          const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), row_sum4(o.dtt, k.b0, k.b1)};
+          const f32x2 sm = {row_sum4(o.dt, k.b0, k.b1), S1 ? row_sum4(o.dtt, k.b0, k.b1) : 0.f};
           if (WGS) {
             fs_write(kb_next, rt, sm);
             if (rt == 1) {
@@ -841,11 +848,11 @@ static int hip_fail16w(hipError_t e, const char* what) {
 
 template <int H, bool GRID, bool WGS, bool BD>
 static int launch_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
-  constexpr bool T16 = FENERF_BW16_T16 != 0;
+  constexpr int TAPE = FENERF_BW16_T16;
   const size_t film_f = H * 4 < 1024 ? 1024 : H * 4;
   const size_t lds = (size_t)NSLOT * CH * 1024 + (size_t)NWAVE * 2 * (2 * film_f) + (size_t)NWAVE * 4096 + (size_t)(H / 32) * 1024 +
                      (size_t)NWAVE * 2048 + (WGS ? (size_t)3 * NWAVE * 32 * 8 : 0) + (size_t)NWAVE * 48 * 4;   // ring + FiLM buffers + tape staging + rgb head^T + head B operands + FiLM-sum buffers + tile points
-  auto kfn = siren_bwd16w_kernel<H, GRID, WGS, BD, T16>;
+  auto kfn = siren_bwd16w_kernel<H, GRID, WGS, BD, TAPE>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   const long long ntiles = (p.P + 15) / 16;
   long long blocks = (ntiles + NWAVE - 1) / NWAVE;
@@ -894,13 +901,17 @@ int bwd16w_film_unit(long long total_points, long long pts_per_image) {
   return (total_points == pts_per_image || pts_per_image % 128 == 0) ? 128 : 16;
 }
 int launch_siren_backward16w_t16(const FenerfModel* m, const SirenBwdParams& p, void* stream);   // fenerf_siren_bwd16w_t16.hip
+int launch_siren_backward16w_w(const FenerfModel* m, const SirenBwdParams& p, void* stream);     // fenerf_siren_bwd16w_w.hip
 #endif
 
-#if FENERF_BW16_T16
+#if FENERF_BW16_T16 == 1
 int launch_siren_backward16w_t16(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
+#elif FENERF_BW16_T16 == 2
+int launch_siren_backward16w_w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
 #else
 int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void* stream) {
   if (p.tape_format == FENERF_TAPE_U16) return launch_siren_backward16w_t16(m, p, stream);
+  if (p.tape_format == FENERF_TAPE_F32_W && p.d_t) return launch_siren_backward16w_w(m, p, stream);     // (FiLM-only launches need the second sum)
 #endif
   if (p.P <= 0) return FENERF_OK;
   const bool g = m->grid_ch != 0;

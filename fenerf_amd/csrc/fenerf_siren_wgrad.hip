@@ -49,6 +49,7 @@ struct WgradParams {
   float* rowsum_partial;       // HEAD / RGB: [b][chunk][32]
   int bf16_dump;               // d_t holds the chain kernel's bf16 dump [d theta | x] (fenerf_layout.h "bf16 dump") instead of fp32 d theta
   int tape_u16;                // `tape` is the 16-bit tape (fenerf_layout.h "16-bit tape"): frac(theta) pieces instead of fp32 accumulators
+  int freq_from_sums;          // the FiLM frequency gradients are derived from the weight-gradient partial sums (FENERF_TAPE_U16, FENERF_TAPE_F32_W)
 };
 
 // Stage one register-dump tile into LDS rows [H][WG_LD]; optional FiLM transform to activations.  The f' / p' rows are
@@ -1123,7 +1124,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   }
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
-    if (p.tape_u16) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
+    if (p.freq_from_sums) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
     else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
   }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
@@ -1166,7 +1167,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   J.rs_src[1] = rows_rgb; J.rs_dst[1] = g.rgb_b; J.rs_rows[1] = 3;
   PhaseScope ph(PH_WGRAD_THIN_REDUCE, st);
   hipLaunchKernelGGL(wgrad_reduce_thin_kernel, dim3((32 * H + 255) / 256, nm + 2), dim3(256), 0, st, J, B, nt, p.fp, p.inv, L, H);
-  if (p.tape_u16)      // the frequency gradients' thin-job share (reads the same partials; the square job reuses the buffer only in the next call)
+  if (p.freq_from_sums)      // the frequency gradients' thin-job share (reads the same partials; the square job reuses the buffer only in the next call)
     hipLaunchKernelGGL(film_freq_thin_kernel, dim3(H, B), dim3(64), 0, st, g, *weights, p_l0, p_c0, nt, p.bias, H, ng, L - ng, G);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
@@ -1187,8 +1188,9 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.film16w = m->precision == FENERF_PREC_F16X3 ? bwd16w_film_unit((long long)B * P, P) : 0;
   p.bf16_dump = use_bf16_dump(m, (long long)B * P);
   p.tape_u16 = tape_format == FENERF_TAPE_U16;
-  if (p.tape_u16 && (film_only || !weights || m->precision != FENERF_PREC_F16X3)) {
-    set_error("16-bit tape: needs a FENERF_PREC_F16X3 model, a full (not FiLM-only) backward and the FiLM layers' weights");
+  p.freq_from_sums = tape_format != FENERF_TAPE_F32;
+  if (p.freq_from_sums && (film_only || !weights || m->precision != FENERF_PREC_F16X3)) {
+    set_error("FENERF_TAPE_U16 / _F32_W: needs a FENERF_PREC_F16X3 model, a full (not FiLM-only) backward and the FiLM layers' weights");
     return FENERF_E_INVALID;
   }
   p.nchunk = wgrad_nchunk(m, B, p.tiles_per_image);

@@ -136,11 +136,19 @@ class _NativeSiren(nn.Module):
     # then come from the bf16 products too: everything AMP class) -- the fastest generator step this package has.
     grad_precision = "f32"
     AMP_MIN_POINTS = 65536
+    FREQ_FROM_WGRAD = True      # (round 5; False = rounds 2-4: the chain kernel forms sum_p d theta * tape itself -- kept for A/B runs and tests)
 
     def tape_format(self, nat, film_only):
         """the tape format (_lib.TAPE_*) a differentiable evaluation on `nat` uses"""
         from .. import _lib
-        return _lib.TAPE_U16 if (self.grad_precision in ("tape16", "amp16") and nat.precision == "f16x3" and not film_only) else _lib.TAPE_F32
+        if nat.precision != "f16x3" or film_only:
+            return _lib.TAPE_F32
+        if self.grad_precision in ("tape16", "amp16"):
+            return _lib.TAPE_U16
+        # default precision: the fp32 tape; the FiLM frequency gradients come from the weight-gradient sums (FENERF_TAPE_F32_W: the chain kernel
+        # then skips its second FiLM sum, a fifth of its VALU instructions) unless FREQ_FROM_WGRAD is off.  "amp" keeps the chain's own sums:
+        # its frequency gradients stay fp32 class while the weight gradients' operands are bf16.
+        return _lib.TAPE_F32_W if (self.FREQ_FROM_WGRAD and self.grad_precision == "f32") else _lib.TAPE_F32
 
     def _spec(self):
         H = self.hidden_dim

@@ -66,6 +66,12 @@ enum {
  * AMP class.  Not for the FiLM-only backward (fenerf_siren_backward_film: the frequency gradient needs the accumulator). */
 #define FENERF_TAPE_F32 0
 #define FENERF_TAPE_U16 1
+/* FENERF_TAPE_F32_W: the fp32 tape of FENERF_TAPE_F32, bit for bit -- what changes is who forms the FiLM FREQUENCY gradient sum_p d theta
+ * (W x + b): not the chain kernel from the tape's accumulators (a multiply and a 16-lane reduction per row tile: a fifth of its VALU
+ * instructions) but the weight-gradient stage from its partial sums and the weights, as for U16 (fenerf_siren_param_grads_fmt takes
+ * `weights`).  Same fp32 class (the sums are bf16x3 products like the weight gradients themselves).  Forward-save: identical to F32.
+ * Not for FiLM-only backward passes. */
+#define FENERF_TAPE_F32_W 2
 
 typedef struct FenerfModelDesc {
   int32_t abi_version;      /* FENERF_ABI_VERSION */
@@ -393,7 +399,8 @@ typedef struct FenerfSirenGrads {   /* [dev] outputs, nn.Linear layout ([out][in
 size_t fenerf_siren_tape_floats(const FenerfModel* m, int64_t total_points);
 size_t fenerf_siren_dtheta_floats(const FenerfModel* m, int64_t total_points);
 /* The *_fmt entry points (round 5) are the calls above for a tape in `tape_format` (FENERF_TAPE_F32 = what the calls above use;
- * FENERF_TAPE_U16 = frac(theta) as 16-bit fixed point, see the definition of the constants): the same tape format must be given to the
+ * FENERF_TAPE_U16 = frac(theta) as 16-bit fixed point, FENERF_TAPE_F32_W = the fp32 tape with the frequency gradients left to the
+ * weight-gradient stage; see the definition of the constants): the same tape format must be given to the
  * forward-save, the chain and the weight-gradient call of one evaluation.  replaces: the same reference lines as their plain
  * counterparts -- FiLMLayer saves its input and theta for autograd (siren.py:113-123); sin / cos of theta are all its backward reads.
  * fenerf_siren_tape_bytes: bytes of a tape (fenerf_siren_tape_floats * 4 or * 2).  fenerf_siren_param_grads_fmt with FENERF_TAPE_U16
