@@ -242,7 +242,8 @@ def curriculum_generator(spec, sd, dev, precision, seed=11):
 
 GSTEP_DDP_KEYS = ("what", "ms", "ms_no_ddp", "allreduce_ms_exposed", "allreduce_bytes", "allreduce_bytes_largest_tensor", "ddp_bucket_cap_mb",
                   "allreduce_per_micro_batch", "ms_with_optimizer", "ms_optimizer_step_4_micro_batches", "ms_optimizer_step_4_micro_batches_one_allreduce",
-                  "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "rays_per_s",
+                  "ms_tuned", "allreduce_ms_exposed_tuned", "tuned_config", "ms_generator_data_parallel",
+                  "allreduce_ms_exposed_generator_data_parallel", "collectives_per_step_generator_data_parallel", "rays_per_s",
                   "n_ranks", "n_ranks_seen", "batch_per_rank", "dist_backend", "peak_GB")
 # `ms_tuned`: what fenerf_amd recommends instead of the reference's wrapper -- fenerf_amd.dist.prepare_for_ddp(generator) (two-node backward:
 # the grid gradient reaches DDP before the weight-gradient kernels run, so its all-reduce overlaps them) + RECOMMENDED_DDP_KWARGS
@@ -281,7 +282,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
                     raise
                 return e
             return None
-        err = steps(2)
+        err = steps(3)           # as gstep_leg: the first steps after the allocator's first 10 GB run 3-10 % slow
         barrier()
         t0 = time.perf_counter()
         err = err or steps(n)
@@ -333,6 +334,14 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         try:
             ddp = DDP(model, device_ids=[dev.index] if cuda else None, **TUNED_DDP)
             ms_tuned = run(ddp, iters, False)
+            del ddp
+            opt.zero_grad(set_to_none=True)
+            # round 5: fenerf_amd.dist.GeneratorDataParallel -- the same averaged gradients without DDP's per-parameter launches and bucket
+            # bookkeeping: the grid's gradient reduced in place from its hook, the other 36 tensors as one flat buffer
+            ddp = fdist.GeneratorDataParallel(model)
+            ms_gdp = run(ddp, iters, False)
+            gdp_collectives = ddp.last_sync["collectives"]
+            ddp.detach_hooks()
         finally:
             if tuned_prepare is not None:
                 tuned_prepare(False)
@@ -345,6 +354,8 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
                "ms_tuned": ms_tuned, "allreduce_ms_exposed_tuned": ms_tuned - ms_bare,
                "tuned_config": ("fenerf_amd.dist.prepare_for_ddp(generator) [grid gradient delivered before the weight-gradient kernels], " if tuned_prepare else "")
                                + ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
+               "ms_generator_data_parallel": ms_gdp, "allreduce_ms_exposed_generator_data_parallel": ms_gdp - ms_bare,
+               "collectives_per_step_generator_data_parallel": gdp_collectives,
                "rays_per_s": world * rays_per_rank / (ms * 1e-3), "n_ranks": world, "n_ranks_seen": int(seen.item()),
                "batch_per_rank": batch_per_rank, "dist_backend": dist.get_backend(),
                "peak_GB": torch.cuda.max_memory_allocated() / 2**30 if cuda else None}

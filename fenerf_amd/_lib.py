@@ -84,6 +84,8 @@ _SIGS = {
     "fenerf_mapping_forward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, _vp]),
     "fenerf_mapping_workspace_floats": (_sz, [C.POINTER(FenerfMappingNet), _i]),
     "fenerf_mapping_backward": (_i, [C.POINTER(FenerfMappingNet), _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
+    "fenerf_label_head_workspace_floats": (_sz, [_i]),
+    "fenerf_label_head_backward": (_i, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "fenerf_struct_size": (C.c_long, [C.c_char_p]),
     "fenerf_struct_field_offset": (C.c_long, [C.c_char_p, C.c_char_p]),
     "fenerf_struct_field_name": (C.c_char_p, [C.c_char_p, _i]),

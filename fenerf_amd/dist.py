@@ -109,3 +109,106 @@ def prepare_for_ddp(generator, enable=True):
     its static bucket order, in which the grid comes last."""
     generator.siren.split_backward = bool(enable)
     return dict(RECOMMENDED_DDP_KWARGS)
+
+
+class GeneratorDataParallel(torch.nn.Module):
+    """Data-parallel gradient averaging for a generator WITHOUT DistributedDataParallel's per-parameter work (round 5).
+
+        generator_dp = fdist.GeneratorDataParallel(generator)          # where the reference writes DDP(generator, ...), train...py:148
+        imgs, _ = generator_dp(z_geo, z_app, **metadata); loss.backward()         # .grad of every parameter = the mean over ranks
+
+    Why: the render's gradients come out of ONE native call (fenerf_render_backward) a few microseconds apart, 37 tensors of which 36 are
+    smaller than 300 KB.  DistributedDataParallel handles each of them on its own -- a copy-and-divide launch into its bucket per parameter,
+    the bucket bookkeeping on the host before and after -- : measured at world 1 on an MI355X, 76 of the 159 launches of a generator step
+    and 1.8 of its 14.0 ms are the wrapper's (profiles/r05_ddp_step_timeline_*.txt), against 83 launches / 12.2 ms for the bare module.
+    Here the gradients are reduced when the backward pass has finished: tensors of at least `async_numel` elements (the 96^3 feature grid,
+    113 of the 124 MB) in place, started from the parameter's own post-accumulate hook so that with prepare_for_ddp's two-node backward
+    the collective runs beside the weight-gradient kernels; everything else concatenated into one flat buffer (one launch), reduced with
+    one collective, and handed back as views of it.  Averaging is the collective's own (RCCL `avg`; sum + one division on gloo).
+    The same arithmetic as DDP up to the summation order inside the collective; `no_sync()` as DDP's (local accumulation over micro-batches).
+    Every rank must produce gradients for the same parameters (DDP's find_unused_parameters=False contract); parameters and buffers are
+    broadcast from rank 0 at construction, as DDP does.  State dict keys carry DDP's `module.` prefix."""
+
+    def __init__(self, module, process_group=None, async_numel=1 << 20, broadcast=True):
+        super().__init__()
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GeneratorDataParallel needs an initialised process group (fenerf_amd.dist.init_from_env)")
+        self.module = module
+        self.process_group = process_group
+        self.async_numel = int(async_numel)
+        self.require_backward_grad_sync = True
+        self.world = dist.get_world_size(process_group)
+        self._avg = dist.get_backend(process_group) == "nccl"          # gloo has no ReduceOp.AVG
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._started, self._queued = [], False
+        self.last_sync = {"collectives": 0, "bytes": 0, "flat_tensors": 0}
+        if broadcast and self.world > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def detach_hooks(self):
+        """unregisters the gradient hooks from the wrapped module (which can then be used bare, or wrapped again)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def no_sync(self):
+        """as DistributedDataParallel.no_sync: backward passes inside accumulate locally; the next one outside reduces the sum"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self.require_backward_grad_sync = self.require_backward_grad_sync, False
+            try:
+                yield
+            finally:
+                self.require_backward_grad_sync = old
+        return ctx()
+
+    def _all_reduce(self, t, async_op):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self.last_sync["collectives"] += 1
+        self.last_sync["bytes"] += t.numel() * t.element_size()
+        return dist.all_reduce(t, op=op, group=self.process_group, async_op=async_op)
+
+    def _on_grad(self, p):
+        if not self.require_backward_grad_sync:
+            return
+        if not self._queued:          # once per backward pass: reduce the rest when the whole graph has run
+            self._queued = True
+            self.last_sync = {"collectives": 0, "bytes": 0, "flat_tensors": 0}
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        if p.numel() >= self.async_numel and p.grad is not None:
+            self._started.append((p, self._all_reduce(p.grad, True)))
+
+    def _finish(self):
+        self._queued = False
+        started, self._started = self._started, []
+        early = {id(p) for p, _ in started}
+        small = {}
+        for p in self._params:
+            if p.grad is not None and id(p) not in early:
+                small.setdefault(p.grad.dtype, []).append(p)
+        flats = []
+        for ps in small.values():                 # one flat buffer per dtype (the generator: fp32 only)
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            self._all_reduce(flat, False)
+            self.last_sync["flat_tensors"] += len(ps)
+            flats.append((ps, flat))
+        for p, work in started:
+            work.wait()
+            if not self._avg:
+                p.grad.div_(self.world)
+        for ps, flat in flats:
+            if not self._avg:
+                flat.div_(self.world)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
-from .autograd import CompositeFunction, HierarchicalRenderFunction, MergeCompositeFunction, hierarchical_render_split
+from .autograd import CompositeFunction, HierarchicalRenderFunction, ImageLayoutFunction, MergeCompositeFunction, hierarchical_render_split
 from . import volumetric_rendering as VR
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
 
@@ -222,6 +222,12 @@ class _Generator3dBase(nn.Module):
         pixels = pixels.reshape((batch_size, img_size, img_size, -1))
         return pixels.permute(0, 3, 1, 2).contiguous()
 
+    def _finish_scaled(self, pixels, batch_size, img_size):
+        """_finish(...) * 2 - 1 on the device, in one launch (and one in backward) when there is no softmax in between"""
+        if self.softmax_label or not pixels.is_cuda or pixels.dtype != torch.float32:
+            return self._finish_scaled(pixels, batch_size, img_size)
+        return ImageLayoutFunction.apply(pixels, batch_size, img_size)
+
 
 class DoubleImplicitGenerator3d(_Generator3dBase):
     """Two-latent generator (z_geo, z_app) -> 18 semantic logits + rgb (generators.py:434-910)."""
@@ -280,12 +286,12 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
             pixels, depth, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                           v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                           lock_view_dependence, kwargs)
-            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+            return self._finish_scaled(pixels, batch_size, img_size), torch.cat([pitch, yaw], -1)
         # forward() ignores fill_mode (generators.py:519) -> C-1 channels
         pixels, depth, _, pitch, yaw = self._render((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                     v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                     lock_view_dependence, kwargs, use_fill=False, third=None)
-        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, torch.cat([pitch, yaw], -1)
 
     def part_forward(self, z_geo, z_app, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
@@ -296,7 +302,7 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
         fa, pa = self.siren.app_mapping_network(z_app)
         pixels, _, pitch, yaw = self._render_grad((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                                   h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence, kwargs)
-        return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+        return self._finish_scaled(pixels, batch_size, img_size), torch.cat([pitch, yaw], -1)
 
     def point_forward(self, transformed_points, transformed_ray_directions_expanded, transformed_ray_origins,
                       transformed_ray_directions, z_vals, z_geo, z_app, num_steps, hierarchical_sample,
@@ -390,12 +396,12 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
             pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                                           h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
                                                           kwargs)
-            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+            return self._finish_scaled(pixels, batch_size, img_size), torch.cat([pitch, yaw], -1)
         pixels, depth, _, pitch, yaw = self._render((frequencies_geo, phase_shifts_geo, frequencies_app, phase_shifts_app),
                                                     img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean,
                                                     v_mean, hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
                                                     use_fill=False, third=None)
-        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, torch.cat([pitch, yaw], -1)
 
 
@@ -448,11 +454,11 @@ class ImplicitGenerator3d(_Generator3dBase):
             pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                                           h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
                                                           kwargs)
-            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+            return self._finish_scaled(pixels, batch_size, img_size), torch.cat([pitch, yaw], -1)
         pixels, depth, _, pitch, yaw = self._render(film, img_size, fov, ray_start, ray_end,
                                                     num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                                                     sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
-        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, torch.cat([pitch, yaw], -1)
 
     def staged_forward(self, z, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, psi=1,
@@ -471,7 +477,7 @@ class ImplicitGenerator3d(_Generator3dBase):
                                                             lock_view_dependence, kwargs, use_fill=True, third="auto")
             depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
             weights_sum = third.reshape((batch_size, img_size, img_size, -1)).permute(0, 3, 1, 2).contiguous().cpu() * 2 - 1
-            pixels = self._finish(pixels, batch_size, img_size) * 2 - 1   # stays on the device (generators.py:231)
+            pixels = self._finish_scaled(pixels, batch_size, img_size)   # stays on the device (generators.py:231)
         return pixels, depth_map, weights_sum
 
     def staged_forward_with_frequencies(self, truncated_frequencies, truncated_phase_shifts, img_size, fov, ray_start, ray_end,
@@ -486,7 +492,7 @@ class ImplicitGenerator3d(_Generator3dBase):
                                                         hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
                                                         use_fill=True, third=None)
             depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
-            pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+            pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, depth_map
 
     def forward_with_frequencies(self, frequencies, phase_shifts, img_size, fov, ray_start, ray_end, num_steps, h_stddev,
@@ -499,9 +505,9 @@ class ImplicitGenerator3d(_Generator3dBase):
             pixels, depth, pitch, yaw = self._render_grad(film, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev,
                                                           h_mean, v_mean, hierarchical_sample, sample_dist, lock_view_dependence,
                                                           kwargs)
-            return self._finish(pixels, batch_size, img_size) * 2 - 1, torch.cat([pitch, yaw], -1)
+            return self._finish_scaled(pixels, batch_size, img_size), torch.cat([pitch, yaw], -1)
         pixels, depth, _, pitch, yaw = self._render(film, img_size, fov, ray_start, ray_end,
                                                     num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                                                     sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
-        pixels = self._finish(pixels, batch_size, img_size) * 2 - 1
+        pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, torch.cat([pitch, yaw], -1)

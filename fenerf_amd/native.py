@@ -829,6 +829,28 @@ def mapping_backward(weights, biases, z, acts, d_out):
     return dW, db
 
 
+def label_head_backward(label_params, g_head_w, g_head_b):
+    """fenerf_label_head_backward: [(W_i, b_i)] of label_layer_linear in application order + the gradient of their fold (g_head_w [n_lab, H],
+    g_head_b [n_lab]) -> [(dW_i, db_i)] of the parameters' shapes; one launch (two layers) or two (three)."""
+    dev = g_head_w.device
+    Ws, bs = [_f32(W.detach(), dev) for W, _ in label_params], [_f32(b.detach(), dev) for _, b in label_params]
+    gA, gc = _f32(g_head_w, dev), _f32(g_head_b, dev)
+    n, (n_lab, H) = len(Ws), gA.shape
+    if tuple(Ws[-1].shape) != (n_lab, H) or any(tuple(W.shape) != (H, H) for W in Ws[:-1]):
+        raise ValueError("label head: layers must be [H, H] ... [n_lab, H] with the fold's gradient [n_lab, H]")
+    flat = torch.empty((sum(W.numel() + b.numel() for W, b in zip(Ws, bs)),), dtype=torch.float32, device=dev)     # one allocation: 2n views
+    dW, db, off = [], [], 0
+    for W, b in zip(Ws, bs):
+        dW.append(flat[off:off + W.numel()].view_as(W)); off += W.numel()
+        db.append(flat[off:off + b.numel()].view_as(b)); off += b.numel()
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    l = _lib.lib()
+    ws = torch.empty((max(1, int(l.fenerf_label_head_workspace_floats(H))),), dtype=torch.float32, device=dev) if n == 3 else None
+    with torch.cuda.device(dev):
+        _lib.check(l.fenerf_label_head_backward(n, H, n_lab, arr(Ws), arr(bs), _ptr(gA), _ptr(gc), arr(dW), arr(db), _ptr(ws), _stream()))
+    return list(zip(dW, db))
+
+
 # ----------------------------------------------------------------------
 # stand-alone ray-tail ops (no model needed)
 # ----------------------------------------------------------------------

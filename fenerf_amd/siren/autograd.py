@@ -57,6 +57,10 @@ def _fold_label_head_backward(label_params, gA, gc):
     return out
 
 
+# fenerf_label_head_backward (one or two launches) instead of the torch products above (11 launches); False: A/B runs and the parity test
+NATIVE_LABEL_HEAD_BACKWARD = True
+
+
 def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params, d_grid_ncdhw=None):
     """FenerfSirenGrads buffers (dict r) + the channels-last grid gradient chunked_backward accumulated -> gradients in the order of
     `params` (module._render_params()).  d_grid_cl None on a model with a grid: the grid's gradient is delivered elsewhere (split
@@ -69,7 +73,8 @@ def assemble_param_grads(module, nat, params, r, points, d_grid_cl, need_params,
     sw, sb = roles["sigma"]
     grads[id(sw)], grads[id(sb)] = r["head_w"][n_lab:n_lab + 1], r["head_b"][n_lab:n_lab + 1]
     if n_lab > 0:      # back through the fold of the activation-free label head (skinny products: n_lab rows on one side of each)
-        for (Wi, bi), (gw, gb) in zip(roles["label"], _fold_label_head_backward(roles["label"], r["head_w"][:n_lab], r["head_b"][:n_lab])):
+        unfold = native.label_head_backward if (NATIVE_LABEL_HEAD_BACKWARD and r["head_w"].is_cuda) else _fold_label_head_backward
+        for (Wi, bi), (gw, gb) in zip(roles["label"], unfold(roles["label"], r["head_w"][:n_lab], r["head_b"][:n_lab])):
             grads[id(Wi)], grads[id(bi)] = gw, gb
     rw, rb = roles["rgb"]
     grads[id(rw)], grads[id(rb)] = r["rgb_w"], r["rgb_b"]

@@ -126,6 +126,16 @@ size_t fenerf_mapping_workspace_floats(const FenerfMappingNet* net, int B);
 int fenerf_mapping_backward(const FenerfMappingNet* net, int B, const float* z, const float* acts, const float* d_out,
                             float* const* dW, float* const* db, float* workspace, void* stream);
 
+/* replaces: autograd through label_layer_linear (siren.py:1490-1494: 2-3 nn.Linear with NO activation between them, the layers the render
+ * kernels evaluate as one folded affine map) -- the gradient of every layer's weight and bias from the gradient of the fold, i.e. from rows
+ * [0, n_lab) of FenerfSirenGrads.head_w / head_b (g_head_w [n_lab][H], g_head_b [n_lab]).  W / b: the n_layers layers in application order,
+ * [dev] fp32 nn.Linear layout (layers 0 .. n-2 [H][H], the last [n_lab][H]); dW / db: buffers of the same shapes, overwritten.  n_lab <= 32.
+ * One launch for two layers, two for three (round 5; rounds 2-4: 11 rocBLAS / ATen launches at the end of every generator step).
+ * workspace: fenerf_label_head_workspace_floats(H) floats (three layers; may be NULL otherwise). */
+size_t fenerf_label_head_workspace_floats(int H);
+int fenerf_label_head_backward(int n_layers, int H, int n_lab, const float* const* W, const float* const* b, const float* g_head_w,
+                               const float* g_head_b, float* const* dW, float* const* db, float* workspace, void* stream);
+
 /* per-call compositing options = the kwargs fancy_integration reads (volumetric_rendering.py:18) */
 typedef struct FenerfCompositeOpts {
   int32_t clamp_mode;   /* FENERF_CLAMP_* ; 0 -> FENERF_E_CLAMP_MODE */

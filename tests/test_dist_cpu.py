@@ -1,7 +1,10 @@
 """world_size-2 gloo test (CPU) of the N>1 path: image sharding, max-over-ranks timing agreement, gather."""
+import copy
 import os
 import socket
 
+import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -83,6 +86,8 @@ def test_bench_self_launch_rendezvous_world_size_2():
     assert leg["ms"] > 0 and leg["ms_no_ddp"] > 0 and abs(leg["allreduce_ms_exposed"] - (leg["ms"] - leg["ms_no_ddp"])) < 1e-9
     # round 5: one optimizer step of four micro-batches, the reference's pattern (an all-reduce per micro-batch) beside micro_batch_sync (one)
     assert leg["ms_optimizer_step_4_micro_batches"] > 0 and leg["ms_optimizer_step_4_micro_batches_one_allreduce"] > 0
+    # round 5: fenerf_amd.dist.GeneratorDataParallel beside the two DDP configurations; the stand-in's 4 small tensors leave as ONE collective
+    assert leg["ms_generator_data_parallel"] > 0 and leg["collectives_per_step_generator_data_parallel"] == 1
     assert d["params_identical_across_ranks"] is True
 
 
@@ -135,3 +140,64 @@ def test_micro_batch_sync_equals_the_reference_pattern_world_size_2():
     assert ref0 == ref1 and mb0 == mb1, "DDP leaves identical gradients on both ranks"
     ref0, mb0 = torch.tensor(ref0), torch.tensor(mb0)
     assert float(ref0.abs().max()) > 0 and torch.allclose(mb0, ref0, rtol=1e-5, atol=1e-6)
+
+
+def _gdp_worker(rank, world, port, q):
+    """fdist.GeneratorDataParallel beside DistributedDataParallel on the same module and data: plain step, the large-tensor path
+    (collective started from the parameter's hook), and local accumulation under no_sync()"""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fdist.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)                     # DIFFERENT initial weights per rank: the wrapper must broadcast rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(6, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))
+    gdp = fdist.GeneratorDataParallel(net, async_numel=6 * 64)          # the first weight (384 elements) takes the early, in-place path
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    ddp = DDP(copy.deepcopy(net), find_unused_parameters=True)       # its own copy of the (broadcast) module: no hooks shared between the two
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank))
+    res = {}
+    for name, wrapper in (("ddp", ddp), ("gdp", gdp)):
+        flat = lambda: torch.cat([p.grad.reshape(-1) for p in wrapper.module.parameters()]).clone()
+        wrapper.zero_grad(set_to_none=True)
+        wrapper(x).square().sum().backward()
+        res[name] = flat()
+        wrapper.zero_grad(set_to_none=True)
+        for split in range(4):
+            with fdist.micro_batch_sync(wrapper, split, 4):
+                wrapper(x[2 * split:2 * split + 2]).square().sum().backward()
+        res[name + "_mb"] = flat()
+    stats = dict(gdp.last_sync)
+    # a second backward on gradients that are views of the previous flat buffer (zero_grad(set_to_none=False)): accumulate in place, reduce again
+    net.zero_grad(set_to_none=False)
+    gdp(x).square().sum().backward()
+    res["gdp_again"] = flat()
+    q.put((rank, w0.tolist(), {k: v.tolist() for k, v in res.items()}, stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generator_data_parallel_equals_ddp_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gdp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, r0, st0), (_, w1, r1, st1) = res
+    assert w0 == w1, "parameters broadcast from rank 0 at construction"
+    for k in r0:
+        assert r0[k] == r1[k], f"{k}: identical gradients on both ranks"
+    # two ranks: the mean of two fp32 numbers has one possible rounding, whatever the collective's order
+    np.testing.assert_allclose(r0["gdp"], r0["ddp"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r0["gdp_mb"], r0["ddp_mb"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r0["gdp_again"], r0["gdp"], rtol=0, atol=1e-7)
+    # 4 parameters: one reduced in place from its hook, three through the flat buffer = 2 collectives (DDP: per-parameter copies + buckets)
+    assert st0 == st1 == {"collectives": 2, "bytes": 4 * (6 * 64 + 64 + 64 * 3 + 3), "flat_tensors": 3}
+
+
+def test_generator_data_parallel_needs_a_process_group():
+    with pytest.raises(RuntimeError, match="process group"):
+        fdist.GeneratorDataParallel(torch.nn.Linear(2, 2))

@@ -3129,7 +3129,7 @@ def test_mapping_network_native_vs_torch(z_dim, hidden, out_dim, n_blocks, B):
     assert net._native_ok(z)
     f, p = net(z)
     out = torch.cat([f, p], -1)
-    assert out.requires_grad and "_MappingFunction" in str(f.grad_fn.next_functions), "the native route ran"
+    assert out.requires_grad and "_MappingFunction" in str(f.grad_fn) and f.grad_fn is p.grad_fn, "the native route ran (both halves are its outputs)"
     (out * w).sum().backward()
     got = {n: N_(q.grad) for n, q in net.named_parameters()}
     for q in net.parameters():
@@ -3146,3 +3146,53 @@ def test_mapping_network_native_vs_torch(z_dim, hidden, out_dim, n_blocks, B):
     assert torch.equal(torch.cat([f2, p2], -1), out.detach())
     big = torch.randn(net.NATIVE_MAX_BATCH + 1, z_dim, device=DEV)     # large batches stay rocBLAS GEMMs
     assert not net._native_ok(big) and torch.equal(torch.cat(net(big), -1), net.network(big))
+
+
+@pytest.mark.parametrize("n_layers,H,n_lab", [(3, 256, 18), (2, 256, 18), (3, 32, 18), (2, 100, 1), (3, 96, 32), (1, 64, 18)])
+def test_label_head_backward_native_vs_autograd(n_layers, H, n_lab):
+    """fenerf_label_head_backward (round 5: one / two launches) against what it replaces -- torch autograd through the label head's fold
+    (label_layer_linear, siren.py:1490-1494), in fp64 -- and against the torch products of rounds 2-4 (11 launches)."""
+    from fenerf_amd.siren import autograd as SA
+    g = torch.Generator(device="cpu").manual_seed(n_layers * 1000 + H + n_lab)
+    dims = [H] * n_layers + [n_lab]
+    params = [(torch.randn(dims[i + 1] if i == n_layers - 1 else H, H, generator=g).mul_(H ** -0.5).to(DEV), torch.randn(dims[i + 1] if i == n_layers - 1 else H, generator=g).mul_(0.3).to(DEV))
+              for i in range(n_layers)]
+    gA, gc = torch.randn(n_lab, H, generator=g).to(DEV), torch.randn(n_lab, generator=g).to(DEV)
+    got = native.label_head_backward(params, gA, gc)
+    p64 = [(W.double().requires_grad_(True), b.double().requires_grad_(True)) for W, b in params]
+    A, c = SA._fold_label_head(p64)
+    ((A * gA.double()).sum() + (c * gc.double()).sum()).backward()
+    old = SA._fold_label_head_backward(params, gA, gc)
+    worst, worst_old = 0.0, 0.0
+    for (dW, db), (W64, b64), (oW, ob) in zip(got, p64, old):
+        assert dW.shape == W64.shape and db.shape == b64.shape
+        worst = max(worst, _rel_err(N_(dW), N_(W64.grad)), _rel_err(N_(db), N_(b64.grad)))
+        worst_old = max(worst_old, _rel_err(N_(oW), N_(W64.grad)), _rel_err(N_(ob), N_(b64.grad)))
+    print(f"[parity] label head backward, {n_layers} layers H={H} n_lab={n_lab}: native vs fp64 autograd {worst:.1e} (the torch products it replaces: {worst_old:.1e})")
+    assert worst <= 2e-6
+
+
+def test_label_head_backward_refuses_what_it_cannot_do():
+    W, b = torch.zeros(40, 64, device=DEV), torch.zeros(40, device=DEV)
+    with pytest.raises(_lib.FenerfError, match="n_lab <= 32"):
+        native.label_head_backward([(torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)), (W, b)], torch.zeros(40, 64, device=DEV), torch.zeros(40, device=DEV))
+    with pytest.raises(ValueError, match="layers must be"):
+        native.label_head_backward([(torch.zeros(64, 32, device=DEV), torch.zeros(64, device=DEV)), (torch.zeros(18, 64, device=DEV), torch.zeros(18, device=DEV))],
+                                   torch.zeros(18, 64, device=DEV), torch.zeros(18, device=DEV))
+
+
+def test_image_layout_function_is_the_references_epilogue_bit_for_bit():
+    """generators.py:519-521 -- reshape, permute(0, 3, 1, 2).contiguous(), * 2 - 1 -- as one launch each way (ImageLayoutFunction)"""
+    from fenerf_amd.generators.autograd import ImageLayoutFunction
+    torch.manual_seed(2)
+    px = torch.rand(3, 16 * 16, 21, device=DEV, requires_grad=True)
+    w = torch.randn(3, 21, 16, 16, device=DEV)
+    out = ImageLayoutFunction.apply(px, 3, 16)
+    ref = px.reshape(3, 16, 16, -1).permute(0, 3, 1, 2).contiguous() * 2 - 1
+    assert out.is_contiguous() and torch.equal(out, ref)
+    g, = torch.autograd.grad((out * w).sum(), px)
+    g_ref, = torch.autograd.grad((ref * w).sum(), px)
+    assert torch.equal(g, g_ref)
+    g2, = torch.autograd.grad((out * w).permute(0, 1, 3, 2).sin().sum(), px)          # a non-contiguous incoming gradient
+    g2_ref, = torch.autograd.grad((ref * w).permute(0, 1, 3, 2).sin().sum(), px)
+    assert torch.equal(g2, g2_ref)

@@ -572,3 +572,33 @@ def test_film_params_beyond_the_init_range_are_what_the_fixtures_record():
     for k in ("phase_geo", "phase_app"):
         shift = (big[k] - base[k]) / (2 * np.pi)
         assert np.abs(shift).max() <= 300.0 and np.abs(shift).max() > 250.0 and abs(shift.mean()) < 30.0
+
+
+def test_image_layout_function_cpu_bits():
+    """ImageLayoutFunction (the generators' NCHW * 2 - 1 epilogue as one op each way) against the reference's three ops, bit for bit"""
+    import torch
+    from fenerf_amd.generators.autograd import ImageLayoutFunction
+    torch.manual_seed(0)
+    px = torch.rand(2, 8 * 8, 21, requires_grad=True)
+    w = torch.randn(2, 21, 8, 8)
+    out = ImageLayoutFunction.apply(px, 2, 8)
+    ref = px.reshape(2, 8, 8, -1).permute(0, 3, 1, 2).contiguous() * 2 - 1
+    assert out.is_contiguous() and torch.equal(out, ref)
+    g, = torch.autograd.grad((out * w).sum(), px)
+    g_ref, = torch.autograd.grad((ref * w).sum(), px)
+    assert torch.equal(g, g_ref)
+
+
+def test_label_head_backward_validates_before_any_launch():
+    """fenerf_label_head_backward: argument errors are reported without touching a device"""
+    import ctypes as C
+    from fenerf_amd import _lib
+    l = _lib.lib()
+    assert l.fenerf_label_head_workspace_floats(256) == (2 * 32 + 1) * 256 and l.fenerf_label_head_workspace_floats(0) == 0
+    null = (C.c_void_p * 3)()
+    assert l.fenerf_label_head_backward(4, 256, 18, null, null, None, None, null, null, None, None) == _lib.E_INVALID
+    assert b"n_layers" in l.fenerf_last_error()
+    assert l.fenerf_label_head_backward(2, 256, 33, null, null, None, None, null, null, None, None) == _lib.E_INVALID
+    assert b"n_lab <= 32" in l.fenerf_last_error()
+    assert l.fenerf_label_head_backward(2, 256, 18, null, null, None, None, null, null, None, None) == _lib.E_INVALID
+    assert b"NULL" in l.fenerf_last_error()

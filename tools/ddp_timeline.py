@@ -1,6 +1,7 @@
 """A few generator steps through DistributedDataParallel at world 1 (one-rank RCCL group) for a kernel-trace timeline: where does the
 all-reduce of the 124 MB of gradients sit relative to the weight-gradient kernels?
-    rocprofv3 --kernel-trace ... -- python tools/ddp_timeline.py [reference|tuned]      then tools/gstep_timeline.py <dir>"""
+    rocprofv3 --kernel-trace ... -- python tools/ddp_timeline.py [reference|tuned|bare|gdp]      then tools/gstep_timeline.py <dir>
+(bare: the same steps on the module itself, no wrapper: bench.py's gstep_z; gdp: fenerf_amd.dist.GeneratorDataParallel)"""
 import os
 import sys
 
@@ -21,8 +22,8 @@ sd = proc.make_state_dict(spec, seed=0, sigma_gain=2000.0, with_mapping=False)
 gen, cur, curriculums = bench.curriculum_generator(spec, sd, dev, "f16x3")
 md = {**curriculums.extract_metadata(cur, 60000), "img_size": 128, "num_steps": 24, "nerf_noise": 0.5}
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{bench._free_port()}", rank=0, world_size=1, device_id=dev)
-kw = fdist.prepare_for_ddp(gen) if mode == "tuned" else dict(find_unused_parameters=True)
-ddp = DDP(gen, device_ids=[0], **kw)
+kw = fdist.prepare_for_ddp(gen) if mode in ("tuned", "gdp") else dict(find_unused_parameters=True)
+ddp = gen if mode == "bare" else fdist.GeneratorDataParallel(gen) if mode == "gdp" else DDP(gen, device_ids=[0], **kw)
 zg, za = torch.randn(1, 256, device=dev), torch.randn(1, 256, device=dev)
 w = torch.randn((1, 21, 128, 128), device=dev) / (128 * 128)
 for _ in range(int(os.environ.get("STEPS", "6"))):
