@@ -1265,7 +1265,6 @@ extern "C" int fenerf_render_forward_save(const FenerfModel* m, int B, int R, in
   const RenderSave sv = render_save(m, B, R, N, tape_format, lock_view);
   if (!save || save_bytes < sv.total) return fail(FENERF_E_INVALID, "save buffer too small (see fenerf_render_save_bytes)");
   char* base = (char*)save;
-  hipStream_t st = (hipStream_t)stream;
   const long long P = sv.P, Pp = sv.Pp, BR = (long long)B * R;
   const int C = m->C;
   float* fp2 = (float*)(base + sv.fp2);
@@ -1277,10 +1276,7 @@ extern "C" int fenerf_render_forward_save(const FenerfModel* m, int B, int R, in
   float* tape_e2 = m->grid_ch ? (float*)(base + sv.tape_e2) : nullptr;
   float* zf = (float*)(base + sv.zf);
   // FiLM pre-pass once, for both passes and for the backward: f' / p' of image b at rows b and B + b (pass-major "images")
-  const size_t film_n = (size_t)B * m->L * m->H;
-  { PhaseScope ph(PH_FILM_PREP, stream); if ((rc = launch_film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, fp2, pp2, stream))) return rc; }
-  HIP_TRY(hipMemcpyAsync(fp2 + film_n, fp2, film_n * sizeof(float), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(pp2 + film_n, pp2, film_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  { PhaseScope ph(PH_FILM_PREP, stream); if ((rc = launch_film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, fp2, pp2, stream, false, true))) return rc; }
   // ---- coarse pass (generators.py:468-479)
   { PhaseScope ph(PH_OTHER, stream); if ((rc = launch_render_points(B, R, N, Pp, origins, dirs, z_coarse, pts2, rd, stream))) return rc; }
   SirenParams sp;

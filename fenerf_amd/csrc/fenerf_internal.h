@@ -158,7 +158,8 @@ struct CompositeParams {
 };
 
 int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
-                     float* fp, float* pp, void* stream, bool for_f32_kernel = false);   // for_f32_kernel: biases of d_consts32, no GEMM result scale
+                     float* fp, float* pp, void* stream, bool for_f32_kernel = false,    // for_f32_kernel: biases of d_consts32, no GEMM result scale
+                     bool twice = false);                                                // twice: rows [B, 2B) of fp / pp receive a copy of rows [0, B)
 int launch_siren(const FenerfModel* m, const SirenParams& p, void* stream);     // dispatches on m->precision
 int launch_siren_f32(const FenerfModel* m, const SirenParams& p, void* stream); // the exact-fp32 kernel on whatever stream `p` points at
 int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* stream);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void siren_kernel(SirenParams P, int n_geo,
 // ------------------------------------------------------------------------------------------------
 __global__ void film_prep_kernel(long long B, int H, int n_geo, int n_color, const float* fg, const float* pg, const float* fa,
                                  const float* pa, const float* bias /* [L][H] */, const float* inv_scale /* [L][H] or null */,
-                                 float* fp, float* pp) {
+                                 float* fp, float* pp, long long dup /* > 0: every value also at index i + dup */) {
   const int L = n_geo + n_color;
   const long long total = (long long)B * L * H;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -294,8 +294,11 @@ __global__ void film_prep_kernel(long long B, int H, int n_geo, int n_color, con
     const double inv2pi = 0.15915494309189533576888;
     // f16x3 mode: fold the (power-of-two, exact) result scale of the layer's GEMM into the frequency
     const double sc = inv_scale ? (double)inv_scale[l * H + n] : 1.0;
-    fp[i] = (float)((double)f * inv2pi * sc);
-    pp[i] = (float)(((double)f * (double)bias[l * H + n] + (double)ph) * inv2pi);
+    const float fv = (float)((double)f * inv2pi * sc);
+    const float pv = (float)(((double)f * (double)bias[l * H + n] + (double)ph) * inv2pi);
+    fp[i] = fv;
+    pp[i] = pv;
+    if (dup > 0) { fp[i + dup] = fv; pp[i + dup] = pv; }
   }
 }
 
@@ -329,13 +332,14 @@ static int hip_fail(hipError_t e, const char* what) {
 }
 
 int launch_film_prep(const FenerfModel* m, long long B, const float* fg, const float* pg, const float* fa, const float* pa,
-                     float* fp, float* pp, void* stream, bool for_f32_kernel) {
+                     float* fp, float* pp, void* stream, bool for_f32_kernel, bool twice) {
   const long long total = (long long)B * m->L * m->H;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   const bool f16 = m->precision == FENERF_PREC_F16X3 && !for_f32_kernel;
   const float* cst = (for_f32_kernel && m->precision == FENERF_PREC_F16X3) ? m->d_consts32 : m->d_consts;
   hipLaunchKernelGGL(film_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, m->H, m->n_geo, m->n_color, fg,
-                     pg, fa, pa, cst + CONST_FILM_BIAS, f16 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr, fp, pp);
+                     pg, fa, pa, cst + CONST_FILM_BIAS, f16 ? m->d_consts + CONST_FILM_BIAS + (size_t)m->L * m->H : nullptr, fp, pp,
+                     twice ? total : 0LL);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail(e, "film_prep launch");
 }

@@ -2576,7 +2576,17 @@ def test_generator_step_through_ddp(tmp_path):
         ddp2 = DDP(gen, device_ids=[0], **kw_ddp)
         grads(ddp2)                                        # first step: DDP rebuilds its buckets in arrival order afterwards
         tuned = grads(ddp2)
+        del ddp2
+        # round 5: fenerf_amd.dist.GeneratorDataParallel -- the same gradients, the 8^3 grid reduced in place from its hook (async_numel lowered
+        # so that this small model takes that path too), everything else as one flat buffer; with and without the two-node backward
+        gdp = fdist.GeneratorDataParallel(gen, async_numel=32 * 8 ** 3)
+        flat_split = grads(gdp)
+        stats = dict(gdp.last_sync)
         fdist.prepare_for_ddp(gen, False)
+        flat_single = grads(gdp)
+        n_grads = len(flat_single)
+        views = len({p.grad.untyped_storage().data_ptr() for p in gen.parameters() if p.grad is not None})
+        gdp.detach_hooks()
     finally:
         if created:
             dist.destroy_process_group()
@@ -2584,8 +2594,13 @@ def test_generator_step_through_ddp(tmp_path):
     assert max(_rel_err(wrapped[k], plain[k]) for k in plain) <= 1e-5
     assert any(np.abs(again[k] - wrapped[k]).max() > 0 for k in plain)
     assert set(plain) == set(tuned) and max(_rel_err(tuned[k], plain2[k]) for k in plain2) <= 1e-5
+    for got in (flat_split, flat_single):
+        assert set(got) == set(plain2) and max(_rel_err(got[k], plain2[k]) for k in plain2) <= 1e-5
+    assert stats["collectives"] == 2 and stats["flat_tensors"] == n_grads - 1 and stats["bytes"] == 4 * sum(v.size for v in plain2.values())
+    assert views == 2, "after the step every small gradient is a view of the one flat buffer; the grid's is its own"
     print("[parity] generator step through DistributedDataParallel over RCCL (backend nccl, world 1): gradients identical to the bare "
-          "module; optimizer step picked up")
+          f"module; optimizer step picked up; fenerf_amd.dist.GeneratorDataParallel: the same gradients from {stats['collectives']} collectives "
+          f"({stats['flat_tensors']} tensors in the flat one)")
 
 
 def test_bench_under_torch_distributed_run_initialises_rccl():

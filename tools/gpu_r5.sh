@@ -16,3 +16,16 @@ if [ "$which" = "bench" ] || [ "$which" = "all" ]; then
   timeout 900 python bench.py --no-gstep-ddp --no-gstep-b6 --quick-cpu-baseline > gpurun_out/r5_bench_quick.log 2>&1
   echo "bench rc=$?"; tail -c 3000 gpurun_out/r5_bench_quick.log
 fi
+if [ "$which" = "glue" ]; then
+  timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -x -k "label_head or image_layout or mapping_network_native or integration_md or render_backward_abi or split_backward or gstep_e2e or generator_step" > gpurun_out/r5_glue_tests.log 2>&1
+  echo "glue tests rc=$?"; tail -3 gpurun_out/r5_glue_tests.log
+  for mode in bare gdp; do
+    mkdir -p gpurun_out/ddptl_$mode
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ddptl_$mode -o tl -- python $GRAFT_REPO_ROOT/tools/ddp_timeline.py $mode) > gpurun_out/ddptl_$mode/run.log 2>&1
+    python tools/gstep_timeline.py gpurun_out/ddptl_$mode 4 > gpurun_out/r5_ddp_timeline_${mode}_v2.txt 2>&1
+    head -1 gpurun_out/r5_ddp_timeline_${mode}_v2.txt
+    rm -rf gpurun_out/ddptl_$mode
+  done
+  timeout 900 python bench.py --no-cpu-baseline --no-f32 --no-sweep64 > gpurun_out/r5_bench_glue.log 2>&1
+  echo "bench rc=$?"; tail -c 2500 gpurun_out/r5_bench_glue.log
+fi
