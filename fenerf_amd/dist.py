@@ -121,15 +121,15 @@ class GeneratorDataParallel(torch.nn.Module):
     smaller than 300 KB.  DistributedDataParallel handles each of them on its own -- a copy-and-divide launch into its bucket per parameter,
     the bucket bookkeeping on the host before and after -- : measured at world 1 on an MI355X, 76 of the 159 launches of a generator step
     and 1.8 of its 14.0 ms are the wrapper's (profiles/r05_ddp_step_timeline_*.txt), against 83 launches / 12.2 ms for the bare module.
-    Here the gradients are reduced when the backward pass has finished: tensors of at least `async_numel` elements (the 96^3 feature grid,
-    113 of the 124 MB) in place, started from the parameter's own post-accumulate hook so that with prepare_for_ddp's two-node backward
+    Here the gradients are reduced when the backward pass has finished: tensors of at least `async_numel` elements (16 MB: the 96^3 feature
+    grid, 113 of the 124 MB) in place, started from the parameter's own post-accumulate hook so that with prepare_for_ddp's two-node backward
     the collective runs beside the weight-gradient kernels; everything else concatenated into one flat buffer (one launch), reduced with
     one collective, and handed back as views of it.  Averaging is the collective's own (RCCL `avg`; sum + one division on gloo).
     The same arithmetic as DDP up to the summation order inside the collective; `no_sync()` as DDP's (local accumulation over micro-batches).
     Every rank must produce gradients for the same parameters (DDP's find_unused_parameters=False contract); parameters and buffers are
     broadcast from rank 0 at construction, as DDP does.  State dict keys carry DDP's `module.` prefix."""
 
-    def __init__(self, module, process_group=None, async_numel=1 << 20, broadcast=True):
+    def __init__(self, module, process_group=None, async_numel=1 << 22, broadcast=True):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GeneratorDataParallel needs an initialised process group (fenerf_amd.dist.init_from_env)")

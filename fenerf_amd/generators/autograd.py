@@ -217,9 +217,10 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 # the sense that it returns what it can and leaks nothing; it does not deliver weight gradients unless the weight stage's inputs are asked for.
 # ----------------------------------------------------------------------------------------------------------------------------------
 # d(theta) dumps the render stage of a split backward leaves for the weight stage: the last SPLIT_KEEP_CHUNKS backward chunks' (a chunk = one
-# pass of a 128 x 128 x 24 image = 4.4 GB at H = 256).  Four chunks = 6 ms of weight-gradient kernels for the 113-MB grid all-reduce to run
-# beside, 17.6 GB instead of all 12 chunks' 52 GB at configs[2]'s 6-image micro-batch (round-4 review: peak 108 GB against 56.6 one-node).
-SPLIT_KEEP_CHUNKS = 4
+# pass of a 128 x 128 x 24 image = 4.4 GB at H = 256).  Two chunks = 3.6 ms of weight-gradient kernels for the 113-MB grid all-reduce to run
+# beside (a ring all-reduce of that size over 8 GPUs' xGMI links is 1 - 2 ms), 8.8 GB instead of all 12 chunks' 52 GB at configs[2]'s
+# 6-image micro-batch (round-4 review: peak 108 GB against 56.6 one-node; measured round 5: 76.1 GB with four chunks kept).
+SPLIT_KEEP_CHUNKS = 2
 
 
 class _SplitState:
