@@ -602,7 +602,7 @@ def main(argv=None):
             t = torch.tensor([1.0 if ok else 0.0], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item() > 0.5)
-        for key, b_, it, skip in (("gstep_ddp", args.batch, 6, False), ("gstep_ddp_b6", 6, 3, args.no_gstep_b6 or (B, S, N) != (1, 128, 24))):
+        for key, b_, it, skip in (("gstep_ddp", args.batch, 12, False), ("gstep_ddp_b6", 6, 3, args.no_gstep_b6 or (B, S, N) != (1, 128, 24))):
             if skip:
                 continue
             try:

@@ -29,3 +29,9 @@ if [ "$which" = "glue" ]; then
   timeout 900 python bench.py --no-cpu-baseline --no-f32 --no-sweep64 > gpurun_out/r5_bench_glue.log 2>&1
   echo "bench rc=$?"; tail -c 2500 gpurun_out/r5_bench_glue.log
 fi
+if [ "$which" = "glue2" ]; then
+  timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -x -k "generator_step_through_ddp or reduced_precision_forward_modes or split_backward or configs2" > gpurun_out/r5_glue2_tests.log 2>&1
+  echo "glue2 tests rc=$?"; tail -3 gpurun_out/r5_glue2_tests.log
+  timeout 900 python bench.py --no-cpu-baseline --no-f32 --no-sweep64 > gpurun_out/r5_bench_glue2.log 2>&1
+  echo "bench rc=$?"; tail -c 600 gpurun_out/r5_bench_glue2.log
+fi
