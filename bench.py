@@ -214,7 +214,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                        "per_kernel": per_kernel, "other_library_launches_ms": rest,
                        "ms_not_in_library_kernels": ms - accounted - sum(rest.values()),
                        "launch_groups_per_step": sum(t.calls.values()) // steps_b,
-                       "bytes_per_point": {"tape": tape_b, "tape_format": "u16" if fmt else "f32", **dump},     # tape per point; the others per (point x layer-feature)
+                       "bytes_per_point": {"tape": tape_b, "tape_format": {0: "f32", 1: "u16", 2: "f32_w (fp32 tape; FiLM frequency gradients from the weight-gradient sums)"}[int(fmt)], **dump},     # tape per point; the others per (point x layer-feature)
                        "note": "algorithmic bytes = tape written once and read by the chain, the chain's dump written once and read once, the "
                                "tape layers the weight-gradient kernels re-read, per-point rows; `frac` = bytes / whole step time / 8 TB/s; "
                                "per_kernel times from hipEvent pairs in instrumented steps (their sum + torch glue = ms)"}
