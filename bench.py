@@ -543,7 +543,7 @@ def main(argv=None):
         k_ms = nat.time_siren_rays(o, d, z, *tf, iters=iters)       # dominant kernel alone, hipEvents on the launch stream
         achieved = pts * FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
         if precision == "f32":
-            peak, kname, mfma, extra = PEAK_FP32_MATRIX_TFLOPS, "siren_kernel<256,true,false>", "v_mfma_f32_32x32x2_f32 (exact fp32)", {}
+            peak, kname, mfma, extra = PEAK_FP32_MATRIX_TFLOPS, "siren_kernel<256, true, false>", "v_mfma_f32_32x32x2_f32 (exact fp32)", {}
         else:
             # every algorithmic product is evaluated as 3 fp16 MFMAs (wh*xh + wh*xl + wl*xh, fp32 accumulate): the attainable
             # ceiling of this algorithm on the fp16 pipe is peak/3; `frac` is quoted against the full dense fp16 peak.

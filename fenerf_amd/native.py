@@ -779,8 +779,9 @@ def forward_kernel_name(nat):
     """Name of the no-grad forward SIREN kernel a NativeModel launches (bench / profile labels; fenerf_siren*.hip)."""
     H, g = nat.spec["hidden_dim"], "true" if nat.spec["grid_ch"] else "false"
     if nat.precision == "f32":
-        return f"siren_kernel<{H},{g},false>"
-    return f"siren16w_kernel<{H},{g},false,false>"      # <H, GRID, SAVE (tape), FUSED (one-launch render)>
+        return f"siren_kernel<{H}, {g}, false>"
+    # <H, GRID, SAVE (0 no tape / 1 fp32 / 2 16-bit), FUSED (one-launch render), TERMS2 (0 f16x3 / 1 f16x2 / 2 f16x3c2)>: as rocprofv3 prints it
+    return f"siren16w_kernel<{H}, {g}, 0, false, {getattr(nat, 'forward_mode', 0)}>"
 
 
 # ----------------------------------------------------------------------

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Summarises rocprofv3 --pmc passes (counter_collection csv) for the siren kernel: per-dispatch averages."""
+"""Summarises rocprofv3 --pmc passes (counter_collection csv) for the headline's forward kernel: per-dispatch averages.
+usage: pmc_summary.py <dir with p1 .. pN> [kernel name substring; default = the no-grad f16x3 forward of the bench model]"""
 import csv
 import glob
 import os
@@ -7,17 +8,19 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "siren16w_kernel<256, true, 0, false, 0>"      # <H, GRID, SAVE, FUSED, TERMS2>
 agg = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
     per_dispatch = defaultdict(dict)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "siren" not in row.get("Kernel_Name", "") or "_kernel" not in row.get("Kernel_Name", ""):
+            if KERNEL not in row.get("Kernel_Name", ""):
                 continue
             per_dispatch[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
     for d, cs in per_dispatch.items():
         for k, v in cs.items():
             agg[k].append(v)
+print(f"# kernel: {KERNEL}")
 print("counter,avg_per_siren_dispatch,n_dispatches")
 for k in sorted(agg):
     v = agg[k]
