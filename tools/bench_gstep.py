@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--grid", type=int, default=96)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-eager", action="store_true")
-    ap.add_argument("--grad-precision", choices=["f32", "amp"], default="f32", help="weight-gradient operands (siren.grad_precision)")
+    ap.add_argument("--grad-precision", choices=["f32", "tape16", "amp", "amp16"], default="f32", help="weight-gradient operands (siren.grad_precision)")
     a = ap.parse_args()
     B, S_, N, H = a.B, a.size, a.steps, a.H
     spec = proc.model_spec("texture", hidden_dim=H, grid_size=a.grid, z_dim=8)

@@ -35,3 +35,14 @@ if [ "$which" = "glue2" ]; then
   timeout 900 python bench.py --no-cpu-baseline --no-f32 --no-sweep64 > gpurun_out/r5_bench_glue2.log 2>&1
   echo "bench rc=$?"; tail -c 600 gpurun_out/r5_bench_glue2.log
 fi
+if [ "$which" = "gpmc" ]; then      # HBM traffic (two tape formats) and matrix-pipe occupancy of the generator-step kernels at 1 x 128^2 x 24+24
+  for gp in f32 tape16; do
+    GSTEP_ARGS="--B 1 --size 128 --grad-precision $gp" bash tools/pmc_gstep.sh > /dev/null 2>&1
+    cp gpurun_out/pmc_gstep/gstep_pmc_summary.txt gpurun_out/r5_pmc_gstep_traffic_$gp.txt
+  done
+  GSTEP_ARGS="--B 1 --size 128 --grad-precision f32" bash tools/pmc_gstep_mfma.sh > /dev/null 2>&1
+  cp gpurun_out/pmc_gstep_mfma/summary.txt gpurun_out/r5_pmc_gstep_mfma_f32.txt
+  rm -rf gpurun_out/pmc_gstep gpurun_out/pmc_gstep_mfma
+  grep -v "^#" gpurun_out/r5_pmc_gstep_traffic_f32.txt | grep "siren\|kernel," | head -30
+  grep "^#" gpurun_out/r5_pmc_gstep_mfma_f32.txt
+fi
