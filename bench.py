@@ -15,9 +15,13 @@ the timing barrier, the max-over-ranks reduce and an all-reduce of ones (`n_rank
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the SIREN kernel, MFMA-bound): algorithmic
 FLOPs per launch (1,603,584 FLOP/point x points) / its hipEvent-timed average duration.  Extra objects on the
-same line: `f32` (the same step at exact-fp32 precision, N=1), `sweep64` (north_star's 64x64, 24+24 scaling batch),
-`gstep` (one generator step, N=1), `cpu_baseline` (numpy oracle = port of the reference CPU path, 1 warm-up + 3 timed runs
-per shape, N=1).
+same line (DESIGN.md §5 has the table): `cpu_baseline` (numpy oracle = port of the reference CPU path, 1 warm-up + 3 timed runs per
+shape, N=1); `f32` (the same step at exact-fp32 precision), `f16x3c2` / `f16x2` (the opt-in reduced-precision forward modes, each with
+its pixel difference from the headline's image), `sweep64` (north_star's 64x64, 24+24 scaling batch), `render_one_launch`; `gstep`
+(one generator step, default precision tier, with its HBM byte model per kernel), `gstep_tape16` / `gstep_amp` / `gstep_amp16` (the
+other tiers), `gstep_b6` (configs[2]'s 6-image micro-batch), `gstep_z` (generator(z) + backward on the bare module), `gstep_ddp` /
+`gstep_ddp_b6` (the same step through DistributedDataParallel as the reference wraps it, with the recommended arguments, and through
+fenerf_amd.dist.GeneratorDataParallel; at every N).
 """
 import argparse
 import json
