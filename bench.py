@@ -316,12 +316,14 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
         from fenerf_amd import dist as fdist
         import contextlib
 
-        def opt_step_ms(sync_once, n=2, MB=4):
+        def opt_step_ms(sync_once, n=3, MB=4):
             def one():
                 opt.zero_grad(set_to_none=True)
                 for s_ in range(MB):
                     with (fdist.micro_batch_sync(ddp, s_, MB) if sync_once else contextlib.nullcontext()):
-                        loss_of(ddp).backward()
+                        loss = loss_of(ddp)
+                        loss.item()              # the reference reads every micro-batch's loss on the host (generator_losses.append(g_loss.item()), :444)
+                        loss.backward()
                 opt.step()
             one()
             barrier()
