@@ -69,6 +69,17 @@ def pmc_traffic():
     }
 
 
+def quiesce_gc():
+    """Before a timed region: collect, then move every live object to the permanent generation.  This process holds ~10^6 Python objects
+    (state dicts, modules, ctypes mirrors); a full collection of them takes 70 ms and is triggered by allocation counts, i.e. at a fixed
+    but arbitrary step -- measured in round 5 as one 85-ms generator step in ~100 (tools/exp/ddp_stall_probe.py: the stall IS a generation-2
+    collection; none with the collector frozen).  A 56-ms headline region cannot absorb that.  Training loops over these classes want the
+    same two lines after building their models."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -164,6 +175,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
         (px * w).sum().backward()
 
     torch.cuda.reset_peak_memory_stats()
+    quiesce_gc()
     for _ in range(3):           # the first steps after the allocator's first 10 GB run 3-10 % slow (kernel trace: 16.6, 15.4, 15.0, 14.9 ...)
         step()
     torch.cuda.synchronize()
@@ -299,6 +311,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
     cuda = dev.type == "cuda"
     if cuda:
         torch.cuda.reset_peak_memory_stats()
+    quiesce_gc()
     ms_bare = run(model, iters, False, guarded=True)
     created = False
     if not dist.is_initialized():            # N = 1 without a launcher: a one-rank group, so that the leg exists at every N
@@ -528,6 +541,7 @@ def main(argv=None):
         torch.manual_seed(seed + 234 + rank)
         o, d, z, _, _ = VR.sample_rays(B, N, dev, 12, (S, S), 0.88, 1.12, 0.3, 0.155, np.pi / 2, np.pi / 2, "gaussian")
         u = torch.rand((B * R, N), device=dev)
+        quiesce_gc()
         for _ in range(warmup):
             nat.render(o, d, z, u, None, None, *tf, opts, hierarchical=True)
         barrier()
