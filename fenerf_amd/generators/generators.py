@@ -444,6 +444,13 @@ class ImplicitGenerator3d(_Generator3dBase):
     def _film(self, frequencies, phase_shifts):
         return self.siren.split_film(frequencies, phase_shifts)
 
+    def _staged_film(self, z, psi):
+        """raw FiLM parameters staged_forward renders with: truncated towards the average ones (generators.py:158-165)"""
+        self.generate_avg_frequencies()
+        raw_frequencies, raw_phase_shifts = self.siren.mapping_network(z)
+        return (self.avg_frequencies + psi * (raw_frequencies - self.avg_frequencies),
+                self.avg_phase_shifts + psi * (raw_phase_shifts - self.avg_phase_shifts))
+
     def forward(self, z, img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                 sample_dist=None, lock_view_dependence=False, **kwargs):
         """-> (pixels [B,3,S,S], poses)   (generators.py:32-119)."""
@@ -467,11 +474,8 @@ class ImplicitGenerator3d(_Generator3dBase):
         """-> (pixels.cpu(), depth_map.cpu(), weights_sum.cpu()*2-1): the single-latent class returns 3 values
         (generators.py:132-248)."""
         batch_size = z.shape[0]
-        self.generate_avg_frequencies()
         with torch.no_grad():
-            raw_frequencies, raw_phase_shifts = self.siren.mapping_network(z)
-            f = self.avg_frequencies + psi * (raw_frequencies - self.avg_frequencies)
-            p = self.avg_phase_shifts + psi * (raw_phase_shifts - self.avg_phase_shifts)
+            f, p = self._staged_film(z, psi)
             pixels, depth, third, pitch, yaw = self._render(self._film(f, p), img_size, fov, ray_start, ray_end, num_steps,
                                                             h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                             lock_view_dependence, kwargs, use_fill=True, third="auto")
@@ -511,3 +515,29 @@ class ImplicitGenerator3d(_Generator3dBase):
                                                     sample_dist, lock_view_dependence, kwargs, use_fill=False, third=None)
         pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, torch.cat([pitch, yaw], -1)
+
+
+class StyleGenerator3d(ImplicitGenerator3d):
+    """The reference's third generator class (generators.py:914-1294; no curriculum or script of the reference instantiates it): a copy
+    of ImplicitGenerator3d WITHOUT average frequencies -- `set_device` draws no 10,000 latents, `staged_forward` evaluates
+    `self.siren(points, z, ray_directions)` (generators.py:1042, :1071), i.e. the raw mapping-network outputs: `psi` is accepted and
+    ignored -- and whose two staged methods do not pass `fill_color` on to fancy_integration (:1084, :1188: its default, 'black').
+    Same four methods, return shapes and RNG draw order otherwise; a pickled one loads through compat.install_aliases()."""
+
+    def set_device(self, device):
+        self.device = device
+        self.siren.device = device
+
+    def generate_avg_frequencies(self):
+        raise AttributeError("'StyleGenerator3d' object has no attribute 'generate_avg_frequencies'")      # as in the reference: the class has none
+
+    def _staged_film(self, z, psi):
+        return self.siren.mapping_network(z)
+
+    def staged_forward(self, z, *args, **kwargs):
+        kwargs.pop("fill_color", None)
+        return super().staged_forward(z, *args, **kwargs)
+
+    def staged_forward_with_frequencies(self, truncated_frequencies, truncated_phase_shifts, *args, **kwargs):
+        kwargs.pop("fill_color", None)
+        return super().staged_forward_with_frequencies(truncated_frequencies, truncated_phase_shifts, *args, **kwargs)

@@ -206,6 +206,26 @@ def test_reference_checkpoint_unpickles_into_this_package():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_reference_style_generator_unpickles_into_this_package():
+    """A pickled StyleGenerator3d (generators.py:914; tests/golden/ref_style_generator_tiny.pth is the reference's own object) loads
+    as fenerf_amd's class of that name -- round 4's review: 'a pickled one would not load'."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from fenerf_amd import compat; compat.install_aliases()\n"
+        "g = torch.load(%r, weights_only=False)\n"
+        "assert type(g).__name__ == 'StyleGenerator3d' and type(g).__module__ == 'fenerf_amd.generators.generators'\n"
+        "assert type(g.siren).__name__ == 'SPATIALSIRENBASELINE' and g.z_dim == 16 and g.output_dim == 4 and not hasattr(g, 'avg_frequencies')\n"
+        "import numpy as np; from fenerf_amd import procedural as proc\n"
+        "sd = proc.make_state_dict(proc.model_spec('spatial', hidden_dim=32, z_dim=16), seed=8, sigma_gain=300.0)\n"
+        "mine = g.siren.state_dict()\n"
+        "assert set(mine) == set(sd) and all(np.array_equal(mine[k].numpy(), sd[k]) for k in sd)\n"
+        "print('ok')\n") % (os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0], os.path.join(GOLDEN, "ref_style_generator_tiny.pth"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_ema_shim_matches_the_reference_usage(tmp_path):
     """train_double_latent_semantic.py:145,456,487-488 / render_multiview_images_double_semantic.py:62-64: an EMA object is
     pickled whole (torch.save(ema)) under the module path torch_ema.ema and later unpickled and copied into the generator."""

@@ -370,3 +370,23 @@ def test_spatial_siren_grid_per_point_modulation():
     out = O.siren_forward(sd, spec, g["local_coords"], g["dirs"], g["freq"], g["phase"])
     np.testing.assert_allclose(out[..., :3], g["out"][..., :3], atol=2e-5)
     np.testing.assert_allclose(out[..., 3], g["out"][..., 3], atol=1e-4, rtol=1e-4)
+
+
+def test_style_generator3d_fixture():
+    """tests/golden/tiny_style_generator.npz (round 5): the reference's StyleGenerator3d (generators.py:914-1294) is ImplicitGenerator3d
+    without average frequencies -- the oracle reproduces its forward(z) from the raw mapping-network outputs, and its
+    staged_forward(z, psi=0.3, fill_color='white') from the SAME raw outputs: psi and fill_color play no part."""
+    g = load_golden("tiny_style_generator")
+    spec = spec_from_golden(g)
+    sd = proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))
+    assert abs(proc.checksum(sd) - float(g["meta_weights_checksum"])) < 1e-6 * max(1.0, abs(float(g["meta_weights_checksum"])))
+    f, p = O.mapping_network(sd, "mapping_network", g["z"])
+    film = dict(freq_geo=f, phase_geo=p)
+    kw = dict(clamp_mode="relu", nerf_noise=0.5, white_back=True)
+    px, _, _ = O.render_forward(sd, spec, film, 6, 12, 0.88, 1.12, 6, _rand(g, "fwd_rand_"), **kw)
+    e_f = np.abs(px - g["fwd_pixels"]).max()
+    px, depth, third = O.render_forward(sd, spec, film, 6, 12, 0.88, 1.12, 6, _rand(g, "stg_rand_"), fill_mode="weight", **kw)
+    third = third.reshape(px.shape[0], 6, 6, -1).transpose(0, 3, 1, 2) * 2 - 1
+    e_s, e_d, e_t = np.abs(px - g["stg_pixels"]).max(), np.abs(depth - g["stg_depth"]).max(), np.abs(third - g["stg_third"]).max()
+    print(f"[parity] oracle vs the reference's StyleGenerator3d: forward {e_f:.2e}, staged pixels {e_s:.2e} depth {e_d:.2e} weights_sum {e_t:.2e}")
+    assert max(e_f, e_s, e_t) <= 2e-5 and e_d <= 1e-4

@@ -507,6 +507,44 @@ def run_mapping_and_full(refs, name):
     print(f"{name}: mapping + forward + staged_forward")
 
 
+def run_style_generator_case(refs, name="tiny_style_generator"):
+    """StyleGenerator3d (generators.py:914-1294; round 5): forward(z) and staged_forward(z, psi) -- psi and fill_color are ignored by that
+    class -- on the tiny single-latent model, every draw recorded; and the pickled module (ref_style_generator_tiny.pth)."""
+    siren_mod, gens, vr, cur = refs
+    spec = proc.model_spec("spatial", hidden_dim=32, z_dim=16)
+    cls = functools.partial(siren_mod.SPATIALSIRENBASELINE, hidden_dim=32)
+    g = gens.StyleGenerator3d(cls, spec["z_dim"], spec["output_dim"])
+    sd = proc.make_state_dict(spec, seed=8, sigma_gain=300.0)
+    load_sd(g.siren, sd)
+    g.eval()
+    g.set_device(torch.device("cpu"))
+    assert not hasattr(g, "avg_frequencies")
+    B, S, N = 2, 6, 6
+    z = torch.from_numpy(proc.normal("z_style", (B, 16), 1.0, 8))
+    out = dict(z=np_(z), meta_seed=8, meta_sigma_gain=300.0, meta_weights_checksum=proc.checksum(sd))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    kw = dict(img_size=S, num_steps=N, hierarchical_sample=True, clamp_mode="relu", nerf_noise=0.5, white_back=True, **CURR)
+    torch.manual_seed(52)
+    with torch.no_grad(), DrawRecorder() as dr:
+        px, poses = g.forward(z, **kw)
+    for k, v in rand_dict_from_draws(dr.draws, True).items():
+        out["fwd_rand_" + k] = v
+    out["fwd_pixels"], out["fwd_poses"] = np_(px), np_(poses)
+    torch.manual_seed(53)
+    with torch.no_grad(), DrawRecorder() as dr:
+        # fill_mode 'weight': the only family of modes this method survives (it reshapes fancy_integration's third output to channel_dim, :1086)
+        px, depth, wsum = g.staged_forward(z, psi=0.3, max_batch_size=97, fill_mode="weight", fill_color="white", **kw)
+    assert len(dr.draws) == 6, "no 10,000-latent average pass in this class"
+    for k, v in rand_dict_from_draws(dr.draws, True).items():
+        out["stg_rand_" + k] = v
+    out["stg_pixels"], out["stg_depth"], out["stg_third"] = np_(px), np_(depth), np_(wsum)
+    out["stg_psi"] = 0.3
+    torch.save(g, os.path.join(OUT, "ref_style_generator_tiny.pth"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: StyleGenerator3d forward + staged_forward")
+
+
 def run_caller_helpers(name="caller_helpers"):
     """mask2color (train_double_latent_semantic.py:36-72) and create_samples (extract_double_semantic_shapes.py:13-35):
     the two function bodies are executed straight from the reference sources (AST-extracted, so the scripts' heavy
@@ -843,6 +881,7 @@ def main(out_dir=None):
     run_caller_helpers()
     run_multiview_case(refs)
     run_spatial_grid_case(refs)
+    run_style_generator_case(refs)
     run_part_forward_case(refs, "tiny_texture_part_forward")
     run_grad_case(refs, "tiny_texture_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=60.0,
                   B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
