@@ -85,7 +85,7 @@ int validate_desc(const FenerfModelDesc* d, std::string& err) {
   if (!d) { err = "desc is NULL"; return FENERF_E_INVALID; }
   if (d->abi_version != FENERF_ABI_VERSION) { err = "abi_version mismatch"; return FENERF_E_INVALID; }
   const int H = d->hidden_dim;
-  if (!(H == 32 || H == 64 || H == 128 || H == 256)) { err = "hidden_dim must be 32, 64, 128 or 256"; return FENERF_E_UNSUPPORTED; }
+  if (!(H == 32 || H == 64 || H == 96 || H == 128 || H == 192 || H == 256)) { err = "hidden_dim must be 32, 64, 96, 128, 192 or 256"; return FENERF_E_UNSUPPORTED; }
   if (d->n_geo < 2 || d->n_geo > FENERF_MAX_GEO) { err = "n_geo out of range"; return FENERF_E_INVALID; }
   if (d->n_color < 1 || d->n_color > FENERF_MAX_COLOR) { err = "n_color out of range"; return FENERF_E_INVALID; }
   if (d->n_label_layers < 0 || d->n_label_layers > FENERF_MAX_LABEL_LAYERS) { err = "n_label_layers out of range"; return FENERF_E_INVALID; }

@@ -392,7 +392,9 @@ int launch_siren_f32(const FenerfModel* m, const SirenParams& p, void* stream) {
   switch (m->H) {
     case 32: return launch_siren_h<32>(m, p, stream);
     case 64: return launch_siren_h<64>(m, p, stream);
+    case 96: return launch_siren_h<96>(m, p, stream);
     case 128: return launch_siren_h<128>(m, p, stream);
+    case 192: return launch_siren_h<192>(m, p, stream);
     case 256: return launch_siren_h<256>(m, p, stream);
   }
   set_error("unsupported hidden_dim");

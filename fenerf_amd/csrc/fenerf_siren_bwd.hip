@@ -315,7 +315,9 @@ int launch_siren_backward(const FenerfModel* m, const SirenBwdParams& p, void* s
   switch (m->H) {
     case 32: return g ? launch_bwd_t<32, true>(m, p, stream) : launch_bwd_t<32, false>(m, p, stream);
     case 64: return g ? launch_bwd_t<64, true>(m, p, stream) : launch_bwd_t<64, false>(m, p, stream);
+    case 96: return g ? launch_bwd_t<96, true>(m, p, stream) : launch_bwd_t<96, false>(m, p, stream);
     case 128: return g ? launch_bwd_t<128, true>(m, p, stream) : launch_bwd_t<128, false>(m, p, stream);
+    case 192: return g ? launch_bwd_t<192, true>(m, p, stream) : launch_bwd_t<192, false>(m, p, stream);
     case 256: return g ? launch_bwd_t<256, true>(m, p, stream) : launch_bwd_t<256, false>(m, p, stream);
   }
   set_error("unsupported hidden_dim");

@@ -918,7 +918,9 @@ int launch_siren_backward16w(const FenerfModel* m, const SirenBwdParams& p, void
   switch (m->H) {
     case 32: return g ? bw16::launch_t<32, true>(m, p, stream) : bw16::launch_t<32, false>(m, p, stream);
     case 64: return g ? bw16::launch_t<64, true>(m, p, stream) : bw16::launch_t<64, false>(m, p, stream);
+    case 96: return g ? bw16::launch_t<96, true>(m, p, stream) : bw16::launch_t<96, false>(m, p, stream);
     case 128: return g ? bw16::launch_t<128, true>(m, p, stream) : bw16::launch_t<128, false>(m, p, stream);
+    case 192: return g ? bw16::launch_t<192, true>(m, p, stream) : bw16::launch_t<192, false>(m, p, stream);
     case 256: return g ? bw16::launch_t<256, true>(m, p, stream) : bw16::launch_t<256, false>(m, p, stream);
   }
   set_error("unsupported hidden_dim");

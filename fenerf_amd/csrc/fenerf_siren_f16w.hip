@@ -849,7 +849,9 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
     switch (m->H) {
       case 32: return g ? w16::launch_t<32, true, 2>(m, q, stream) : w16::launch_t<32, false, 2>(m, q, stream);
       case 64: return g ? w16::launch_t<64, true, 2>(m, q, stream) : w16::launch_t<64, false, 2>(m, q, stream);
+      case 96: return g ? w16::launch_t<96, true, 2>(m, q, stream) : w16::launch_t<96, false, 2>(m, q, stream);
       case 128: return g ? w16::launch_t<128, true, 2>(m, q, stream) : w16::launch_t<128, false, 2>(m, q, stream);
+      case 192: return g ? w16::launch_t<192, true, 2>(m, q, stream) : w16::launch_t<192, false, 2>(m, q, stream);
       case 256: return g ? w16::launch_t<256, true, 2>(m, q, stream) : w16::launch_t<256, false, 2>(m, q, stream);
     }
   }
@@ -857,7 +859,9 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
     switch (m->H) {
       case 32: return g ? w16::launch_t<32, true, 1>(m, q, stream) : w16::launch_t<32, false, 1>(m, q, stream);
       case 64: return g ? w16::launch_t<64, true, 1>(m, q, stream) : w16::launch_t<64, false, 1>(m, q, stream);
+      case 96: return g ? w16::launch_t<96, true, 1>(m, q, stream) : w16::launch_t<96, false, 1>(m, q, stream);
       case 128: return g ? w16::launch_t<128, true, 1>(m, q, stream) : w16::launch_t<128, false, 1>(m, q, stream);
+      case 192: return g ? w16::launch_t<192, true, 1>(m, q, stream) : w16::launch_t<192, false, 1>(m, q, stream);
       case 256: return g ? w16::launch_t<256, true, 1>(m, q, stream) : w16::launch_t<256, false, 1>(m, q, stream);
     }
   }
@@ -865,7 +869,9 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
     switch (m->H) {
       case 32: return g ? w16::launch_t<32, true, 0, 1>(m, q, stream) : w16::launch_t<32, false, 0, 1>(m, q, stream);
       case 64: return g ? w16::launch_t<64, true, 0, 1>(m, q, stream) : w16::launch_t<64, false, 0, 1>(m, q, stream);
+      case 96: return g ? w16::launch_t<96, true, 0, 1>(m, q, stream) : w16::launch_t<96, false, 0, 1>(m, q, stream);
       case 128: return g ? w16::launch_t<128, true, 0, 1>(m, q, stream) : w16::launch_t<128, false, 0, 1>(m, q, stream);
+      case 192: return g ? w16::launch_t<192, true, 0, 1>(m, q, stream) : w16::launch_t<192, false, 0, 1>(m, q, stream);
       case 256: return g ? w16::launch_t<256, true, 0, 1>(m, q, stream) : w16::launch_t<256, false, 0, 1>(m, q, stream);
     }
   }
@@ -873,14 +879,18 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
     switch (m->H) {
       case 32: return g ? w16::launch_t<32, true, 0, 2>(m, q, stream) : w16::launch_t<32, false, 0, 2>(m, q, stream);
       case 64: return g ? w16::launch_t<64, true, 0, 2>(m, q, stream) : w16::launch_t<64, false, 0, 2>(m, q, stream);
+      case 96: return g ? w16::launch_t<96, true, 0, 2>(m, q, stream) : w16::launch_t<96, false, 0, 2>(m, q, stream);
       case 128: return g ? w16::launch_t<128, true, 0, 2>(m, q, stream) : w16::launch_t<128, false, 0, 2>(m, q, stream);
+      case 192: return g ? w16::launch_t<192, true, 0, 2>(m, q, stream) : w16::launch_t<192, false, 0, 2>(m, q, stream);
       case 256: return g ? w16::launch_t<256, true, 0, 2>(m, q, stream) : w16::launch_t<256, false, 0, 2>(m, q, stream);
     }
   }
   switch (m->H) {
     case 32: return g ? w16::launch_t<32, true, 0>(m, q, stream) : w16::launch_t<32, false, 0>(m, q, stream);
     case 64: return g ? w16::launch_t<64, true, 0>(m, q, stream) : w16::launch_t<64, false, 0>(m, q, stream);
+    case 96: return g ? w16::launch_t<96, true, 0>(m, q, stream) : w16::launch_t<96, false, 0>(m, q, stream);
     case 128: return g ? w16::launch_t<128, true, 0>(m, q, stream) : w16::launch_t<128, false, 0>(m, q, stream);
+    case 192: return g ? w16::launch_t<192, true, 0>(m, q, stream) : w16::launch_t<192, false, 0>(m, q, stream);
     case 256: return g ? w16::launch_t<256, true, 0>(m, q, stream) : w16::launch_t<256, false, 0>(m, q, stream);
   }
   set_error("unsupported hidden_dim");
@@ -913,7 +923,9 @@ int launch_render16w_fused(const FenerfModel* m, const SirenParams& p, const Fus
   switch (m->H) {
     case 32: return g ? w16::launch_fused_t<32, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<32, false>(m, p, F, plan.blocks, stream);
     case 64: return g ? w16::launch_fused_t<64, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<64, false>(m, p, F, plan.blocks, stream);
+    case 96: return g ? w16::launch_fused_t<96, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<96, false>(m, p, F, plan.blocks, stream);
     case 128: return g ? w16::launch_fused_t<128, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<128, false>(m, p, F, plan.blocks, stream);
+    case 192: return g ? w16::launch_fused_t<192, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<192, false>(m, p, F, plan.blocks, stream);
     case 256: return g ? w16::launch_fused_t<256, true>(m, p, F, plan.blocks, stream) : w16::launch_fused_t<256, false>(m, p, F, plan.blocks, stream);
   }
   set_error("unsupported hidden_dim");

@@ -342,7 +342,9 @@ extern "C" int fenerf_siren_forward_local(const FenerfLocalModel* m, int64_t tot
   switch (m->H) {
     case 32: return launch_local_t<32>(m, p, stream);
     case 64: return launch_local_t<64>(m, p, stream);
+    case 96: return launch_local_t<96>(m, p, stream);
     case 128: return launch_local_t<128>(m, p, stream);
+    case 192: return launch_local_t<192>(m, p, stream);
     case 256: return launch_local_t<256>(m, p, stream);
   }
   return local_fail(FENERF_E_UNSUPPORTED, "unsupported hidden_dim");

@@ -878,31 +878,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sq_kernel(FenerfSirenGrads g
   else if (l == n_geo) { dst = g.color_w[0]; ld = 3 + grid_ch + H; col0 = 3 + grid_ch; if (FREQ) wl = w.color_w[0]; }
   else { dst = g.color_w[l - n_geo]; ld = H; if (FREQ) wl = w.color_w[l - n_geo]; }
   const int n_color = L - n_geo;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * H; i += gridDim.x * blockDim.x) {      // H * H is a multiple of the block: no ragged trip
-    const int r = i / H, c = i % H;
-    const float wv = FREQ ? wl[(size_t)r * ld + col0 + c] : 0.f;
-    float sum = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float s = sum_chunks<4>(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk);
-      sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
-      if (FREQ) {
-        red[threadIdx.x] = s * wv;
-        __syncthreads();
-        const int seg = H < 256 ? H : 256, cs = threadIdx.x % seg;       // H >= 256: the block is (a quarter of ...) one row -- H = 256: the row
-        for (int o = seg >> 1; o >= 1; o >>= 1) {
-          if (cs < o) red[threadIdx.x] += red[threadIdx.x + o];
-          __syncthreads();
-        }
-        if (cs == 0) {
-          float* df = l < n_geo ? g.d_freq_geo + ((size_t)b * n_geo + l) * H + r : g.d_freq_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
-          const float* dp = l < n_geo ? g.d_phase_geo + ((size_t)b * n_geo + l) * H + r : g.d_phase_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
-          *df = 15.f * __builtin_fmaf(bias[(size_t)l * H + r], *dp, red[threadIdx.x]);
-        }
+  // one workgroup per output row r (H <= 256 columns: thread = column, the rest idle), so that the row sum of the frequency gradient is a
+  // reduction over the whole workgroup whatever H is (round 5 first cut: 256 consecutive elements per workgroup and a tree over H
+  // threads -- right only for H a power of two; H = 96 / 192 put rows across workgroups)
+  const int r = blockIdx.x, c = threadIdx.x;
+  const bool active = c < H;
+  const float wv = (FREQ && active) ? wl[(size_t)r * ld + col0 + c] : 0.f;
+  float sum = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float s = active ? sum_chunks<4>(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk) : 0.f;
+    sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
+    if (FREQ) {
+      red[c] = s * wv;
+      __syncthreads();
+      for (int o = 128; o >= 1; o >>= 1) {
+        if (c < o) red[c] += red[c + o];
         __syncthreads();
       }
+      if (c == 0) {
+        float* df = l < n_geo ? g.d_freq_geo + ((size_t)b * n_geo + l) * H + r : g.d_freq_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
+        const float* dp = l < n_geo ? g.d_phase_geo + ((size_t)b * n_geo + l) * H + r : g.d_phase_app + ((size_t)b * n_color + (l - n_geo)) * H + r;
+        *df = 15.f * __builtin_fmaf(bias[(size_t)l * H + r], *dp, red[0]);
+      }
+      __syncthreads();
     }
-    dst[(size_t)r * ld + col0 + c] = sum;
   }
+  if (active) dst[(size_t)r * ld + col0 + c] = sum;
 }
 
 // The thin jobs' share of the frequency gradients (16-bit tape; see wgrad_reduce_sq_kernel): layer 0 (three warped-coordinate columns,
@@ -1124,8 +1125,8 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   }
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
-    if (p.freq_from_sums) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
-    else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3((H * H + 255) / 256, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
+    if (p.freq_from_sums) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3(H, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
+    else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3(H, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
   }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
   // side: [H x 32 | H x 64 | 32 x H | 32 x H] per (image, chunk) -- so that ONE launch reduces all of them
@@ -1198,7 +1199,9 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   switch (m->H) {
     case 32: return param_grads_t<32>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
     case 64: return param_grads_t<64>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
+    case 96: return param_grads_t<96>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
     case 128: return param_grads_t<128>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
+    case 192: return param_grads_t<192>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
     case 256: return param_grads_t<256>(m, p, g, ws, film_only, (hipStream_t)stream, weights);
   }
   set_error("unsupported hidden_dim");

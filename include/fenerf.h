@@ -31,7 +31,7 @@ enum {
   FENERF_E_INVALID = -1,     /* bad argument / unsupported shape */
   FENERF_E_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
   FENERF_E_NOMEM = -3,
-  FENERF_E_UNSUPPORTED = -4, /* model variant not built (hidden_dim not in {32,64,128,256}, ...) */
+  FENERF_E_UNSUPPORTED = -4, /* model variant not built (hidden_dim not in {32,64,96,128,192,256}, ...) */
   FENERF_E_CLAMP_MODE = -5   /* reference raises TypeError("Need to choose clamp mode"), volumetric_rendering.py:34 */
 };
 
@@ -75,7 +75,7 @@ enum {
 
 typedef struct FenerfModelDesc {
   int32_t abi_version;      /* FENERF_ABI_VERSION */
-  int32_t hidden_dim;       /* H in {32,64,128,256} */
+  int32_t hidden_dim;       /* H in {32,64,96,128,192,256}: multiples of 32 the kernel templates are instantiated for (96 / 192: round 5) */
   int32_t n_geo;            /* FiLM layers of the density trunk (8) */
   int32_t n_color;          /* FiLM layers of the colour branch (3, or 1) */
   int32_t n_label_layers;   /* plain Linear layers of the semantic head (3, 2 or 0); NO activation between them */

@@ -51,7 +51,7 @@ def stage_queue(qb, nbody, two_step, prefix_loads, t16=False):
 
 @pytest.mark.parametrize("t16", [False, True])
 @pytest.mark.parametrize("two_step", [False, True])
-@pytest.mark.parametrize("qb,nbody", [(4, 8), (5, 8), (2, 4), (3, 4), (1, 2), (2, 2), (1, 1), (4, 1), (2, 1)])
+@pytest.mark.parametrize("qb,nbody", [(4, 8), (5, 8), (2, 4), (3, 4), (1, 2), (2, 2), (1, 1), (4, 1), (2, 1), (2, 3), (3, 6), (4, 6)])
 def test_ring_waits_never_run_ahead_of_the_dma(qb, nbody, two_step, t16):
     o = 4 if t16 else 0
     if two_step and (qb * nbody) % 2:

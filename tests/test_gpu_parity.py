@@ -77,7 +77,8 @@ def test_native_library_is_loaded():
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_baseline_fwd", "h256_texture_16x16_n12",
-                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained"])
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained",
+                                  "h96_texture_8x8_n12", "h192_baseline_8x8_n12"])       # H = 96 / 192 (round 5): widths that are not powers of two
 def test_siren_forward_vs_reference(name, precision):
     g = load_golden(name)
     nat, spec, sd = _native_for(name, precision)
@@ -362,7 +363,8 @@ def _e2e_check(tag, px, ref_px, tol=1e-3, max_flips=0):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "h256_texture_16x16_n12",
-                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained"])
+                                  "h256_texture_16x16_n24_trained", "h256_baseline_8x8_n12", "tiny_texture_fwd_trained",
+                                  "h96_texture_8x8_n12", "h192_baseline_8x8_n12"])
 def test_forward_with_frequencies_vs_reference(name, precision):
     g = load_golden(name)
     spec = spec_from_golden(g)
@@ -1403,7 +1405,8 @@ def _rel_err(got, ref):
 
 @pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 75), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 33),
-                                             ("texture", 128, 4, 3, 130), ("texture", 256, 6, 2, 200)])
+                                             ("texture", 128, 4, 3, 130), ("texture", 256, 6, 2, 200),
+                                             ("texture", 96, 5, 2, 75), ("baseline", 192, 0, 1, 64), ("spatial", 96, 0, 2, 33)])      # round 5: H = 96 / 192
 def test_siren_backward_vs_autograd(kind, H, grid, B, P, precision):
     from oracle import fenerf_oracle_grad as OG
     mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
@@ -1636,7 +1639,7 @@ def test_device_side_repack_matches_host_pack(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("kind,H,grid", [("texture", 64, 5), ("baseline", 32, 0), ("spatial", 32, 0), ("texture", 256, 6)])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 64, 5), ("baseline", 32, 0), ("spatial", 32, 0), ("texture", 256, 6), ("texture", 96, 5), ("baseline", 192, 0)])
 def test_native_repack_is_the_torch_repack_bit_for_bit(kind, H, grid, precision):
     """fenerf_model_repack (row scales, gathers, fp16 / bf16 hi-lo splits in four kernels, written in place) against the same
     re-pack spelled out in torch ops (NativeModel._pack_on_device, itself pinned to the host packer on the CPU): forward
@@ -1784,7 +1787,8 @@ def test_inversion_reproduces_the_references_own_trajectory(precision):
 
 
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 96), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 160), ("texture", 128, 4, 3, 160),
-                                             ("texture", 256, 6, 2, 224), ("texture", 256, 6, 1, 4224), ("texture", 256, 6, 2, 2080)])
+                                             ("texture", 256, 6, 2, 224), ("texture", 256, 6, 1, 4224), ("texture", 256, 6, 2, 2080),
+                                             ("texture", 96, 5, 2, 224), ("texture", 192, 4, 2, 224)])
 def test_16bit_tape_against_the_fp32_tape(kind, H, grid, B, P):
     """Round 5 (include/fenerf.h FENERF_TAPE_U16, siren.grad_precision = "tape16"): the tape between forward and backward holds frac(theta) as
     16-bit fixed point instead of the fp32 accumulators.  Same model, same inputs, both tapes:
@@ -1838,7 +1842,8 @@ def test_16bit_tape_against_the_fp32_tape(kind, H, grid, B, P):
 
 
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 96), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 160), ("texture", 256, 6, 2, 224),
-                                             ("texture", 256, 6, 1, 4224)])
+                                             ("texture", 256, 6, 1, 4224), ("texture", 96, 5, 2, 224), ("baseline", 192, 0, 2, 224)])     # H = 96 / 192: rows that
+                                             # do not tile the reduction's workgroups (the round-5 first cut of that kernel was wrong there)
 def test_frequency_gradients_from_the_weight_gradient_sums(kind, H, grid, B, P):
     """include/fenerf.h FENERF_TAPE_F32_W (round 5, the default of f16x3 models): the chain kernel no longer forms sum_p d theta * tape -- a
     multiply and a 16-lane butterfly per row tile, a fifth of its VALU instructions --; the FiLM frequency gradient sum_p d theta (W x + b) is
@@ -2149,7 +2154,9 @@ _FP64_BACKWARD_REFERENCE = {}
                                                   ("f16x3", 64, 0, 2, 33024), ("tape16", 64, 0, 2, 33024),
                                                   ("f16x3", 256, 6, 1, 65536), ("f32", 256, 6, 1, 65536), ("amp", 256, 6, 1, 65536),
                                                   ("tape16", 256, 6, 1, 65536), ("amp16", 256, 6, 1, 65536),
-                                                  ("f16x3", 256, 6, 1, 393216), ("amp", 256, 6, 1, 393216), ("tape16", 256, 6, 1, 393216)])
+                                                  ("f16x3", 256, 6, 1, 393216), ("amp", 256, 6, 1, 393216), ("tape16", 256, 6, 1, 393216),
+                                                  ("f16x3", 96, 5, 1, 40000), ("f32", 96, 5, 1, 40000), ("tape16", 96, 5, 1, 40000),      # round 5: H = 96 / 192
+                                                  ("f16x3", 192, 4, 1, 66000), ("amp", 192, 4, 1, 66000), ("amp16", 192, 4, 1, 66000)])
 def test_siren_backward_at_scale_vs_fp64_autograd(precision, H, grid, B, P):
     # "amp" = f16x3 with the opt-in AMP-class weight-gradient operands (bf16, one MFMA per product; siren.grad_precision)
     # "tape16" = f16x3 with the opt-in 16-bit tape (frac(theta) as fixed point between forward and backward): the tier between the two
@@ -2289,7 +2296,7 @@ def test_grid_gradient_values_at_full_size_96cubed_grid():
 
 
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 96), ("baseline", 64, 0, 1, 64), ("texture", 128, 4, 3, 160),
-                                             ("texture", 256, 6, 2, 224), ("texture", 256, 6, 1, 4224)])
+                                             ("texture", 256, 6, 2, 224), ("texture", 256, 6, 1, 4224), ("texture", 96, 5, 2, 224), ("texture", 192, 4, 2, 224)])
 def test_bf16_dump_layout_at_small_point_counts(kind, H, grid, B, P):
     """The opt-in AMP-class weight gradients (module.grad_precision = "amp": in backward chunks of >= AMP_MIN_POINTS points the chain
     kernel writes d theta and x = sin(2 pi theta) as bf16 and the square weight-gradient job multiplies them with one MFMA per product,
@@ -2675,7 +2682,8 @@ def test_weight_swaps_through_param_data_are_picked_up_at_mode_switch():
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm",
-                                  "tiny_texture_grad_trained"])      # *_trained: at a state the reference's own Adam run produced (round 5)
+                                  "tiny_texture_grad_trained",       # *_trained: at a state the reference's own Adam run produced (round 5)
+                                  "h96_texture_grad"])               # hidden width 96 (round 5)
 def test_generator_gradients_vs_reference_autograd(name, precision):
     """tests/golden/tiny_*_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies (texture:
     hierarchical 8+8, noise, white_back; baseline: softplus, noise, last_back; single-latent: locked view direction).  The

@@ -110,7 +110,8 @@ def test_integration_variants():
 
 
 @pytest.mark.parametrize("name", ["tiny_texture_fwd", "tiny_texture_fwd_nohier", "tiny_baseline_fwd", "tiny_spatial_fwd",
-                                  "tiny_texture_fwd_trained"])      # *_trained: weights + FiLM parameters the reference's own Adam run produced
+                                  "tiny_texture_fwd_trained",       # *_trained: weights + FiLM parameters the reference's own Adam run produced
+                                  "h96_texture_8x8_n12", "h192_baseline_8x8_n12"])      # hidden widths that are not powers of two (round 5)
 def test_forward_stagewise(name):
     g = load_golden(name)
     px, depth, third, st = _render(g)
@@ -300,7 +301,7 @@ def test_grad_oracle_siren_matches_numpy_oracle(kind, grid):
 
 
 @pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm",
-                                  "tiny_texture_grad_trained"])
+                                  "tiny_texture_grad_trained", "h96_texture_grad"])
 def test_grad_oracle_matches_reference_autograd(name):
     # *_bigfilm: FiLM phase shifts of +-300 revolutions, first-layer frequency x 4 (round 4): the reference's fp32 radians carry an
     # argument rounding of 1.2e-4 .. 2.4e-4 rad there, so its own pixels / gradients sit that much further from fp64 (measured 8e-4)

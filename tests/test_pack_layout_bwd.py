@@ -250,7 +250,7 @@ def check_chain(case, got, d_e, precision, grid):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0)])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0), ("texture", 96, 5), ("baseline", 192, 0)])
 def test_backward_stream_and_chain_dataflow(kind, H, grid, precision):
     case = chain_case(kind, H, grid, precision)
     emu = emulate_chain16 if precision == "f16x3" else emulate_chain

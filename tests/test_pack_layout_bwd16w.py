@@ -109,7 +109,7 @@ def emulate_chain16w(blob, spec, theta, f_true, row_scale, d_out, out):
     return dtheta, d_e, sums
 
 
-@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0), ("texture", 128, 4)])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("baseline", 64, 0), ("spatial", 32, 0), ("texture", 128, 4), ("texture", 96, 5), ("baseline", 192, 0)])
 def test_backward16w_stream_walk_and_dataflow(kind, H, grid):
     case = chain_case(kind, H, grid, "f16x3")
     got, d_e, sums = emulate_chain16w(case["blob"], case["spec"], case["theta"], case["f_true"], case["row_scale"], case["d_out"], case["out"])

@@ -180,7 +180,7 @@ def emulate_tile_f16w(blob, consts, spec, pts, dirs, film, grid_cl):
 
 
 @pytest.mark.parametrize("kind,H,grid", [("texture", 32, 5), ("texture", 64, 4), ("baseline", 32, 0), ("spatial", 32, 0),
-                                         ("texture", 128, 4), ("texture", 256, 6)])
+                                         ("texture", 128, 4), ("texture", 256, 6), ("texture", 96, 5), ("baseline", 192, 0)])
 def test_f16w_dataflow_on_the_packed_stream(kind, H, grid):
     spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
     sd = proc.make_state_dict(spec, seed=12, sigma_gain=500.0, with_mapping=False)

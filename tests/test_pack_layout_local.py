@@ -163,7 +163,7 @@ def emulate_tile(blob, consts, spec, pts, dirs, lat):
     return out
 
 
-@pytest.mark.parametrize("H,n_geo", [(32, 3), (64, 8), (256, 2)])
+@pytest.mark.parametrize("H,n_geo", [(32, 3), (64, 8), (256, 2), (96, 3)])
 def test_local_stream_walk_matches_the_plain_statement(H, n_geo):
     spec = dict(proc.model_spec("spatial", hidden_dim=H, grid_size=0, output_dim=4), n_geo=n_geo)
     sd = proc.make_state_dict(spec, seed=5, sigma_gain=20.0, with_mapping=False)

@@ -927,6 +927,14 @@ def main(out_dir=None):
                   state="tiny_texture_trained_state")
     run_grad_case(refs, "tiny_texture_grad_trained", tiny8, seed=1, sigma_gain=60.0, B=2, S=8, N=6,
                   kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True), state="tiny_texture_trained_state")
+    # hidden widths beyond the powers of two (round 5; round-4 review, next-round #8): the reference's constructors take any width
+    # (siren.py:1455); H = 96 with a 24^3 grid forward + the reference's autograd, H = 192 baseline forward
+    h96 = proc.model_spec("texture", hidden_dim=96, grid_size=24, z_dim=16)
+    run_film_case(refs, "h96_texture_8x8_n12", h96, seed=9, sigma_gain=300.0, B=2, S=8, N=12, hier=True, kwargs=relu)
+    run_grad_case(refs, "h96_texture_grad", proc.model_spec("texture", hidden_dim=96, grid_size=6, z_dim=16), seed=17, sigma_gain=60.0,
+                  B=2, S=6, N=8, kwargs=dict(clamp_mode="relu", nerf_noise=0.2, white_back=True))
+    run_film_case(refs, "h192_baseline_8x8_n12", proc.model_spec("baseline", hidden_dim=192, z_dim=16), seed=10, sigma_gain=300.0, B=1, S=8, N=12,
+                  hier=True, kwargs=relu)
     run_inversion_case(refs, "tiny_texture_inversion", tiny8, "tiny_texture_trained_state", seed=1, n_iterations=30, n_mean_latents=500,
                        S=8, N=12)
 
