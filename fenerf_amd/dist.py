@@ -149,6 +149,7 @@ class GeneratorDataParallel(torch.nn.Module):
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
 
     def forward(self, *args, **kwargs):
+        self._queued, self._started = False, []        # a backward pass that raised half way must not leave the next one unsynchronised
         return self.module(*args, **kwargs)
 
     def detach_hooks(self):
