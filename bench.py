@@ -359,10 +359,18 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
             opt.zero_grad(set_to_none=True)
             # round 5: fenerf_amd.dist.GeneratorDataParallel -- the same averaged gradients without DDP's per-parameter launches and bucket
             # bookkeeping: the grid's gradient reduced in place from its hook, the other 36 tensors as one flat buffer
-            ddp = fdist.GeneratorDataParallel(model)
-            ms_gdp = run(ddp, iters, False)
-            gdp_collectives = ddp.last_sync["collectives"]
-            ddp.detach_hooks()
+            ms_gdp = gdp_collectives = None
+            try:                              # its own guard: a failure here must not take the DistributedDataParallel figures above with it
+                ddp = fdist.GeneratorDataParallel(model)
+                ms_gdp = run(ddp, iters, False)
+                gdp_collectives = ddp.last_sync["collectives"]
+            except Exception as e:
+                gdp_collectives = f"{type(e).__name__}: {e}"
+            finally:
+                try:
+                    ddp.detach_hooks()
+                except Exception:
+                    pass
             del ddp
             opt.zero_grad(set_to_none=True)
         finally:
@@ -381,7 +389,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
                "ms_tuned": ms_tuned, "allreduce_ms_exposed_tuned": ms_tuned - ms_bare,
                "tuned_config": ("fenerf_amd.dist.prepare_for_ddp(generator) [grid gradient delivered before the weight-gradient kernels], " if tuned_prepare else "")
                                + ", ".join(f"{k}={v}" for k, v in TUNED_DDP.items()),
-               "ms_generator_data_parallel": ms_gdp, "allreduce_ms_exposed_generator_data_parallel": ms_gdp - ms_bare,
+               "ms_generator_data_parallel": ms_gdp, "allreduce_ms_exposed_generator_data_parallel": (ms_gdp - ms_bare) if ms_gdp is not None else None,
                "collectives_per_step_generator_data_parallel": gdp_collectives,
                "rays_per_s": world * rays_per_rank / (ms * 1e-3), "n_ranks": world, "n_ranks_seen": int(seen.item()),
                "batch_per_rank": batch_per_rank, "dist_backend": dist.get_backend(),
