@@ -359,7 +359,7 @@ def ddp_timed_leg(model, params, loss_of, opt, dev, world, barrier, max_over_ran
             opt.zero_grad(set_to_none=True)
             # round 5: fenerf_amd.dist.GeneratorDataParallel -- the same averaged gradients without DDP's per-parameter launches and bucket
             # bookkeeping: the grid's gradient reduced in place from its hook, the other 36 tensors as one flat buffer
-            ms_gdp = gdp_collectives = None
+            ms_gdp = gdp_collectives = ddp = None
             try:                              # its own guard: a failure here must not take the DistributedDataParallel figures above with it
                 ddp = fdist.GeneratorDataParallel(model)
                 ms_gdp = run(ddp, iters, False)
