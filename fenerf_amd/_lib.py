@@ -149,6 +149,9 @@ _SIGS = {
     "fenerf_render_backward_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i64, _i64]),
     "fenerf_render_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, C.POINTER(FenerfSirenGrads), _vp,
                                     C.POINTER(FenerfSirenGrads), _i64, _i64, _vp, _sz, _vp]),
+    "fenerf_render_backward_split_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i64, _i]),
+    "fenerf_render_backward_stage": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, C.POINTER(FenerfSirenGrads), _vp,
+                                          C.POINTER(FenerfSirenGrads), _i64, _vp, _sz, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),

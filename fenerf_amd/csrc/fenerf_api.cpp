@@ -1207,11 +1207,11 @@ long long backward_max_points(const FenerfModel* m, long long Pp, bool film16, l
 }
 
 struct BackwardWs {
-  size_t d_out2, d_fc, dump, d_grid_cl, d_e, wgrad, film2, scratch, total;
+  size_t d_out2, d_fc, dump, dump_stride, d_grid_cl, d_e, wgrad, film2, scratch, total;      // dump_stride: bytes of one chunk's dump (split backward: several slots)
   long long max_chunk_points, film_row;   // film_row = floats of one image's four FiLM gradient rows
   int max_nb;
 };
-BackwardWs backward_ws(const FenerfModel* m, int B, int R, int N, int film_only, long long chunk_points, long long film_budget) {
+BackwardWs backward_ws(const FenerfModel* m, int B, int R, int N, int film_only, long long chunk_points, long long film_budget, int dump_slots = 1) {
   BackwardWs w;
   const long long P = (long long)R * N, Pp = (P + 31) / 32 * 32;
   const bool film16 = film_only && m->precision == FENERF_PREC_F16X3;
@@ -1230,7 +1230,11 @@ BackwardWs backward_ws(const FenerfModel* m, int B, int R, int N, int film_only,
   auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
   w.d_out2 = take((size_t)2 * B * Pp * m->C * sizeof(float));
   w.d_fc = take(Pp != P ? (size_t)2 * B * P * m->C * sizeof(float) : 0);
-  w.dump = take(film16 ? sums : fenerf_siren_dtheta_floats(m, w.max_chunk_points) * sizeof(float));
+  w.dump_stride = align_up(film16 ? sums : fenerf_siren_dtheta_floats(m, w.max_chunk_points) * sizeof(float), 256);
+  {
+    const size_t slots = (size_t)(dump_slots < 1 ? 1 : (dump_slots > (int)chunks.size() ? (int)chunks.size() : dump_slots));
+    w.dump = take(w.dump_stride * (slots < 1 ? 1 : slots));
+  }
   w.d_grid_cl = take(m->grid_ch && !film_only ? (size_t)m->gd * m->gh * m->gw * 32 * sizeof(float) : 0);
   w.d_e = take(m->grid_ch && !fenerf_siren_backward_fuses_grid(m) ? (size_t)w.max_chunk_points * 32 * sizeof(float) : 0);
   w.wgrad = take(align_up(wg, 256));
@@ -1328,18 +1332,22 @@ extern "C" size_t fenerf_render_backward_workspace_bytes(const FenerfModel* m, i
   return backward_ws(m, B, R, N, film_only, chunk_points, film_sums_budget_bytes).total;
 }
 
-extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N, int lock_view, const void* save, size_t save_bytes,
-                                      int tape_format, const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts,
-                                      const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights,
-                                      int64_t chunk_points, int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+// stage 0: the whole backward in one call (fenerf_render_backward).  stage 1 / 2: the same launches cut in two (fenerf_render_backward_stage):
+// 1 = composite backward, chain AND weight gradients of every chunk but the last `keep_chunks`, the chains of those last chunks -- each
+// into its own dump slot -- and the finished grid gradient; 2 = the weight gradients of the last chunks, the sums, the FiLM fold.  Same
+// kernels on the same chunks in the same order per gradient tensor: stage 1 + stage 2 = stage 0 bit for bit (atomics of the grid aside).
+static int render_backward_impl(const FenerfModel* m, int B, int R, int N, int lock_view, const void* save, size_t save_bytes,
+                                int tape_format, const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts,
+                                const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights,
+                                int64_t chunk_points, int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes,
+                                void* stream, int keep_chunks, int stage) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   int rc = check_opts(opts);
   if (rc) return rc;
   if ((rc = check_tape_format(m, tape_format))) return rc;
   if (B <= 0 || R <= 0 || N < 3 || 2 * N > 512) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 256 (hierarchical render)");
-  if (!save || !z_coarse || !g_rgb || !grads || !workspace) return fail(FENERF_E_INVALID, "NULL pointer");
+  if (!save || !grads || !workspace || (stage != 2 && (!z_coarse || !g_rgb))) return fail(FENERF_E_INVALID, "NULL pointer");
   if (!grads->d_freq_geo || !grads->d_phase_geo || !grads->d_freq_app || !grads->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
   int have = 0, want = 0;
   for (int i = 0; i < m->n_geo; ++i) { want += 2; have += (grads->geo_w[i] != nullptr) + (grads->geo_b[i] != nullptr); }
@@ -1347,13 +1355,14 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
   want += 4; have += (grads->head_w != nullptr) + (grads->head_b != nullptr) + (grads->rgb_w != nullptr) + (grads->rgb_b != nullptr);
   if (have != 0 && have != want) return fail(FENERF_E_INVALID, "grads: give every weight / bias buffer or none (FiLM gradients only)");
   const bool film_only = have == 0;
+  if (stage != 0 && (film_only || keep_chunks < 1)) return fail(FENERF_E_INVALID, "the two-stage backward takes weight gradients and keeps at least one chunk");
   if (film_only && tape_format != FENERF_TAPE_F32) return fail(FENERF_E_INVALID, "FiLM-only gradients need FENERF_TAPE_F32 (the chain kernel's second FiLM sum)");
   if (tape_format != FENERF_TAPE_F32 && !weights) return fail(FENERF_E_INVALID, "FENERF_TAPE_U16 / _F32_W: the FiLM layers' weights are required");
-  if (!film_only && m->grid_ch && !d_grid_ncdhw) return fail(FENERF_E_INVALID, "d_grid_ncdhw is NULL");
+  if (!film_only && m->grid_ch && !d_grid_ncdhw && stage != 2) return fail(FENERF_E_INVALID, "d_grid_ncdhw is NULL");
   const RenderSave sv = render_save(m, B, R, N, tape_format, lock_view);
   if (save_bytes < sv.total) return fail(FENERF_E_INVALID, "save buffer too small (see fenerf_render_save_bytes)");
-  const BackwardWs wsz = backward_ws(m, B, R, N, film_only, chunk_points, film_sums_budget_bytes);
-  if (workspace_bytes < wsz.total) return fail(FENERF_E_INVALID, "workspace too small (see fenerf_render_backward_workspace_bytes)");
+  const BackwardWs wsz = backward_ws(m, B, R, N, film_only, chunk_points, film_sums_budget_bytes, stage == 0 ? 1 : keep_chunks);
+  if (workspace_bytes < wsz.total) return fail(FENERF_E_INVALID, "workspace too small (see fenerf_render_backward_workspace_bytes / _split_workspace_bytes)");
   const char* sb = (const char*)save;
   char* wb = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
@@ -1369,7 +1378,7 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
   const float* zf = (const float*)(sb + sv.zf);
   float* d_out2 = (float*)(wb + wsz.d_out2);
   // ---- composite backward: the gradient wrt the two passes' rows, written where the chain reads it (coarse | fine halves, pass-major)
-  {
+  if (stage != 2) {
     CompositeParams cp;
     memset(&cp, 0, sizeof(cp));
     cp.BR = BR; cp.M = 2 * N; cp.C = C; cp.N = N;
@@ -1390,17 +1399,24 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
   // ---- chunks of whole (pass, image) pairs -- or point ranges of one -- : chain, then the weight / FiLM gradients of the chunk
   const bool film16 = film_only && m->precision == FENERF_PREC_F16X3;
   const std::vector<Chunk> chunks = plan_chunks(nB, Pp, backward_max_points(m, Pp, film16, chunk_points, film_sums_budget_bytes));
-  float* dump = (float*)(wb + wsz.dump);
+  float* const dump0 = (float*)(wb + wsz.dump);
   float* d_grid_cl = (m->grid_ch && !film_only) ? (float*)(wb + wsz.d_grid_cl) : nullptr;
   float* d_e = (m->grid_ch && !fenerf_siren_backward_fuses_grid(m)) ? (float*)(wb + wsz.d_e) : nullptr;
-  if (d_grid_cl) HIP_TRY(hipMemsetAsync(d_grid_cl, 0, (size_t)m->gd * m->gh * m->gw * 32 * sizeof(float), st));
+  if (d_grid_cl && stage != 2) HIP_TRY(hipMemsetAsync(d_grid_cl, 0, (size_t)m->gd * m->gh * m->gw * 32 * sizeof(float), st));
   float* film2 = (float*)(wb + wsz.film2);      // [d_freq_geo | d_phase_geo: nB x ng H each][d_freq_app | d_phase_app: nB x nc H each]
   float* f2[4] = {film2, film2 + (size_t)nB * ng * H, film2 + (size_t)2 * nB * ng * H, film2 + (size_t)2 * nB * ng * H + (size_t)nB * nc * H};
   const long long frow[4] = {(long long)ng * H, (long long)ng * H, (long long)nc * H, (long long)nc * H};
   const GradSizes gz = grad_sizes(m);
   const size_t LHw = (size_t)(tape_format == FENERF_TAPE_U16 ? 2 : 4) * L * H;      // tape bytes per point
-  bool first = true;
-  for (const Chunk& c : chunks) {
+  const int n_chunks = (int)chunks.size();
+  const int n_late = stage == 0 ? 0 : (keep_chunks < n_chunks ? keep_chunks : n_chunks), n_early = n_chunks - n_late;
+  bool first = stage != 2 || n_early == 0;      // does the next weight-gradient call write the output buffers (or a scratch set that is then added)?
+  for (int ci = 0; ci < n_chunks; ++ci) {
+    const Chunk& c = chunks[ci];
+    const bool late = ci >= n_early;
+    if (stage == 2 && !late) continue;
+    const bool do_chain = stage != 2, do_wgrad = stage == 0 || (stage == 1 && !late) || (stage == 2 && late);
+    float* const dump = dump0 + (late ? (size_t)(ci - n_early) * (wsz.dump_stride / sizeof(float)) : 0);
     const long long g0 = (long long)c.b * Pp + c.s, npts = (long long)c.nb * c.n;
     const float* fp_c = fp2 + (size_t)c.b * L * H;
     const float* pp_c = pp2 + (size_t)c.b * L * H;
@@ -1428,15 +1444,16 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
         bp.d_e = d_e;      // FiLM-only on an exact-fp32 model: the chain still writes d(grid features); nobody reads them
       }
     }
-    {
+    if (do_chain) {
       PhaseScope ph(PH_CHAIN, stream);
       rc = m->precision == FENERF_PREC_F16X3 ? launch_siren_backward16w(m, bp, stream) : launch_siren_backward(m, bp, stream);
       if (rc) return rc;
     }
-    if (m->grid_ch && !film_only && !fenerf_siren_backward_fuses_grid(m)) {
+    if (do_chain && m->grid_ch && !film_only && !fenerf_siren_backward_fuses_grid(m)) {
       PhaseScope ph(PH_GRID, stream);
       if ((rc = launch_grid_backward(m, npts, pts_c, d_e, d_grid_cl, stream))) return rc;
     }
+    if (!do_wgrad) continue;
     // where this chunk's gradients go: the first chunk writes the outputs, later ones a scratch set that is then added (chunk order:
     // the sums of rounds 2-4, bit for bit); FiLM rows of an image's first point range are written in place, later ranges added
     FenerfSirenGrads gc;
@@ -1480,7 +1497,7 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
     first = false;
   }
   // ---- the two passes of an image share its FiLM parameters: row b + row B + b
-  {
+  if (stage != 1) {
     FilmFold F;
     F.B = B;
     F.out[0] = grads->d_freq_geo; F.out[1] = grads->d_phase_geo; F.out[2] = grads->d_freq_app; F.out[3] = grads->d_phase_app;
@@ -1488,9 +1505,33 @@ extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N,
     PhaseScope ph(PH_OTHER, stream);
     if ((rc = launch_film_fold(F, stream))) return rc;
   }
-  if (d_grid_cl) {
+  if (d_grid_cl && stage != 2) {
     PhaseScope ph(PH_GRID, stream);
     if ((rc = launch_grid_unlayout(d_grid_cl, d_grid_ncdhw, m->gd, m->gh, m->gw, stream))) return rc;
   }
   return FENERF_OK;
+}
+
+extern "C" int fenerf_render_backward(const FenerfModel* m, int B, int R, int N, int lock_view, const void* save, size_t save_bytes,
+                                      int tape_format, const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts,
+                                      const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights,
+                                      int64_t chunk_points, int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  return render_backward_impl(m, B, R, N, lock_view, save, save_bytes, tape_format, z_coarse, noise_final, opts, g_rgb, grads, d_grid_ncdhw, weights,
+                              chunk_points, film_sums_budget_bytes, workspace, workspace_bytes, stream, 1, 0);
+}
+
+extern "C" size_t fenerf_render_backward_split_workspace_bytes(const FenerfModel* m, int B, int R, int N, int64_t chunk_points, int keep_chunks) {
+  if (!m || B <= 0 || R <= 0 || N <= 0 || keep_chunks < 1) return 0;
+  return backward_ws(m, B, R, N, 0, chunk_points, 0, keep_chunks).total;
+}
+
+extern "C" int fenerf_render_backward_stage(const FenerfModel* m, int stage, int keep_chunks, int B, int R, int N, int lock_view, const void* save,
+                                            size_t save_bytes, int tape_format, const float* z_coarse, const float* noise_final,
+                                            const FenerfCompositeOpts* opts, const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw,
+                                            const FenerfSirenGrads* weights, int64_t chunk_points, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  if (stage != 1 && stage != 2) return fail(FENERF_E_INVALID, "stage must be 1 (render stage) or 2 (weight stage)");
+  return render_backward_impl(m, B, R, N, lock_view, save, save_bytes, tape_format, z_coarse, noise_final, opts, g_rgb, grads, d_grid_ncdhw, weights,
+                              chunk_points, 0, workspace, workspace_bytes, stream, keep_chunks, stage);
 }

@@ -119,10 +119,10 @@ def _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_
     return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
 
 
-# The one-node render runs through fenerf_render_forward_save / fenerf_render_backward (round 5: chunk planning, workspaces, launch order and
-# gradient sums live behind the C-ABI; include/fenerf.h) -- the Python below it is the round-4 orchestration of the same kernels, kept for the
-# two-node (DistributedDataParallel) form, for the two-stream experiment (siren/autograd.py OVERLAP_WGRAD) and as the reference the tests
-# compare the one-call path with bit for bit.
+# The render runs through fenerf_render_forward_save / fenerf_render_backward (round 5: chunk planning, workspaces, launch order and gradient
+# sums live behind the C-ABI; include/fenerf.h) -- and, in its two-node (DistributedDataParallel) form, fenerf_render_backward_stage 1 / 2.  The
+# Python below it is the round-4 orchestration of the same kernels, kept for the two-stream experiment (siren/autograd.py OVERLAP_WGRAD) and
+# as the reference the tests compare the library's paths with bit for bit.
 USE_RENDER_ABI = True
 
 
@@ -247,6 +247,15 @@ class HierarchicalWeightStage(torch.autograd.Function):
             raise RuntimeError("fenerf_amd: split backward: the render stage has not run (or ran twice) before the weight stage")
         module, nat, B = ctx.module, w["nat"], w["B"]
         need = ctx.needs_input_grad
+        if w.get("abi"):        # fenerf_render_backward_stage(2): the kept chunks' weight gradients, the sums, the FiLM fold -- all in the library
+            r = nat.render_backward_stage(2, w["keep"], B, w["R"], w["N"], w["save"], None, None, w["opts"], None, lock_view=w["lock_view"],
+                                          tape_format=w["tape_format"], weights=w["weights"], chunk_points=w["chunk_points"], carry=w["carry"])
+            film_grads = tuple(r[k] if need[2 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
+            params = w["params"]
+            grid = module._roles(params)["grid"]
+            all_grads = _siren_autograd.assemble_param_grads(module, nat, params, r, None, None, [True] * len(params))
+            no_grid = [g for p_, g in zip(params, all_grads) if p_ is not grid]
+            return (None, None) + film_grads + tuple(g if need[6 + i] else None for i, g in enumerate(no_grid))
         r = _siren_autograd.run_weight_grads(nat, 2 * B, w["Pp"], w["film2"], w["pts2"], w["rd2"], w["out2"], w["d_out2"], w["tape2"], w["tape_e2"],
                                              w["chunks"], w["dumps"], tape_format=w["tape_format"],
                                              weights=_siren_autograd.film_layer_weights(module, w["params"]) if w["tape_format"] else None,
@@ -268,14 +277,43 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, state, token, grid, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa):
         ctx.state = state
-        return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, (),
-                                     film_only=False)        # the split form exists for training steps: weight gradients are taken
+        ctx.abi = USE_RENDER_ABI and not _siren_autograd.OVERLAP_WGRAD
+        if not ctx.abi:
+            return _hierarchical_forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, (),
+                                         film_only=False)        # the split form exists for training steps: weight gradients are taken
+        nat = module.native_differentiable(origins.device)
+        B, R, N = z_c.shape
+        ctx.tape_format = module.tape_format(nat, film_only=False)
+        rgb, depth, save = nat.render_forward_save(origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, opts, lock_view=lock_view,
+                                                   tape_format=ctx.tape_format)
+        ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
+        ctx.pack_generation = nat.pack_generation
+        ctx.save_for_backward(save, z_c, noise_f if noise_f is not None else origins.new_empty(0))
+        ctx.mark_non_differentiable(depth)
+        return rgb, depth
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_rgb, _g_depth):
         module, nat, opts = ctx.module, ctx.nat, ctx.opts
         _siren_autograd.check_same_weights(ctx, nat)
+        if ctx.abi:      # fenerf_render_backward_stage(1): composite backward, the early chunks whole, the kept chunks' chains, the grid gradient
+            B, R, N = ctx.dims
+            save, z_c, noise_f = ctx.saved_tensors
+            keep = max(1, int(getattr(module, "split_keep_chunks", SPLIT_KEEP_CHUNKS)))
+            params = module._render_params()
+            weights = _siren_autograd.film_layer_weights(module, params) if ctx.tape_format else None
+            g_grid, carry = nat.render_backward_stage(1, keep, B, R, N, save, z_c, noise_f if noise_f.numel() else None, opts, g_rgb.contiguous().float(),
+                                                      lock_view=ctx.lock_view, tape_format=ctx.tape_format, weights=weights,
+                                                      chunk_points=_siren_autograd.BACKWARD_CHUNK_POINTS)
+            state = ctx.state
+            state.work = dict(abi=True, nat=nat, B=B, R=R, N=N, save=save, opts=opts, lock_view=ctx.lock_view, tape_format=ctx.tape_format,
+                              weights=weights, keep=keep, chunk_points=_siren_autograd.BACKWARD_CHUNK_POINTS, carry=carry, params=params)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: setattr(state, "work", None))      # see below
+            g_token = torch.zeros(1, dtype=torch.float32, device=save.device) if ctx.needs_input_grad[1] else None
+            if g_token is None:
+                state.work = None
+            return (None, g_token, g_grid if ctx.needs_input_grad[2] else None) + (None,) * 14
         B, R, N, P, Pp = ctx.dims
         pts2, rd, fg, pg, fa, pa, out2, tape2, tape_e2, z_f, zc, noise_f = ctx.saved_tensors
         C = nat.C

@@ -607,10 +607,8 @@ class NativeModel:
                                                     C.c_void_p(save.data_ptr()), C.c_size_t(save.numel()), int(tape_format), _stream()))
         return rgb, depth, save
 
-    def render_backward(self, B, R, N, save, z_coarse, noise_final, opts, g_rgb, film_only, lock_view=False, tape_format=0, weights=None,
-                        chunk_points=0, film_sums_budget_bytes=0):
-        """fenerf_render_backward: every gradient of the render in ONE call -> (dict like siren_param_grads -- FiLM gradients [B, n*H], both
-        passes summed; weight / bias gradients unless film_only --, d_grid [1,32,D,H,W] or None)."""
+    def _render_grad_buffers(self, B, film_only):
+        """-> (dict like siren_param_grads of freshly allocated gradient buffers, the FenerfSirenGrads pointing at them, d_grid or None)"""
         sp = self.spec
         H, ng, nc, G = sp["hidden_dim"], sp["n_geo"], sp["n_color"], sp["grid_ch"]
         dev = self.device
@@ -629,13 +627,26 @@ class NativeModel:
             if not isinstance(res[k], list):
                 setattr(g, k, res[k].data_ptr())
         d_grid = torch.empty((1, 32) + tuple(self.grid_shape), dtype=torch.float32, device=dev) if (G and not film_only) else None
-        wts, keep = None, []
-        if weights is not None:
-            wts = _lib.FenerfSirenGrads()
-            for i, w in enumerate(weights[0]):
-                keep.append(_f32(w.detach(), dev)); wts.geo_w[i] = keep[-1].data_ptr()
-            for i, w in enumerate(weights[1]):
-                keep.append(_f32(w.detach(), dev)); wts.color_w[i] = keep[-1].data_ptr()
+        return res, g, d_grid
+
+    def _film_weight_struct(self, weights):
+        """film_layer_weights(...) -> (FenerfSirenGrads of their pointers or None, keep-alive list)"""
+        if weights is None:
+            return None, []
+        wts, keep = _lib.FenerfSirenGrads(), []
+        for i, w in enumerate(weights[0]):
+            keep.append(_f32(w.detach(), self.device)); wts.geo_w[i] = keep[-1].data_ptr()
+        for i, w in enumerate(weights[1]):
+            keep.append(_f32(w.detach(), self.device)); wts.color_w[i] = keep[-1].data_ptr()
+        return wts, keep
+
+    def render_backward(self, B, R, N, save, z_coarse, noise_final, opts, g_rgb, film_only, lock_view=False, tape_format=0, weights=None,
+                        chunk_points=0, film_sums_budget_bytes=0):
+        """fenerf_render_backward: every gradient of the render in ONE call -> (dict like siren_param_grads -- FiLM gradients [B, n*H], both
+        passes summed; weight / bias gradients unless film_only --, d_grid [1,32,D,H,W] or None)."""
+        dev = self.device
+        res, g, d_grid = self._render_grad_buffers(B, film_only)
+        wts, keep = self._film_weight_struct(weights)
         l = _lib.lib()
         with torch.cuda.device(dev):
             ws = self._workspace("render_bwd", l.fenerf_render_backward_workspace_bytes(self._h, B, R, N, int(film_only), int(chunk_points),
@@ -645,6 +656,33 @@ class NativeModel:
                                                 C.byref(opts), _ptr(_f32(g_rgb, dev)), C.byref(g), _ptr(d_grid), C.byref(wts) if wts is not None else None,
                                                 int(chunk_points), int(film_sums_budget_bytes), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream()))
         return res, d_grid
+
+    def render_backward_stage(self, stage, keep_chunks, B, R, N, save, z_coarse, noise_final, opts, g_rgb, lock_view=False, tape_format=0,
+                              weights=None, chunk_points=0, carry=None):
+        """fenerf_render_backward_stage.  stage 1 (carry None): -> (d_grid [1,32,D,H,W] finished, carry) -- carry holds the gradient buffers
+        and the workspace (own allocation: it must survive until stage 2, whatever else renders in between); stage 2 (carry from stage 1):
+        -> the finished dict like siren_param_grads."""
+        dev = self.device
+        l = _lib.lib()
+        wts, keep = self._film_weight_struct(weights)
+        with torch.cuda.device(dev):
+            if stage == 1:
+                res, g, d_grid = self._render_grad_buffers(B, False)
+                nbytes = int(l.fenerf_render_backward_split_workspace_bytes(self._h, B, R, N, int(chunk_points), int(keep_chunks)))
+                ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+                carry = dict(res=res, g=g, d_grid=d_grid, ws=ws)
+            res, g, d_grid, ws = carry["res"], carry["g"], carry["d_grid"], carry["ws"]
+            _lib.check(l.fenerf_render_backward_stage(self._h, int(stage), int(keep_chunks), B, R, N, int(lock_view), C.c_void_p(save.data_ptr()),
+                                                      C.c_size_t(save.numel()), int(tape_format),
+                                                      _ptr(_f32(z_coarse, dev)) if z_coarse is not None else None,
+                                                      _ptr(_f32(noise_final, dev)) if noise_final is not None else None, C.byref(opts),
+                                                      _ptr(_f32(g_rgb, dev)) if g_rgb is not None else None, C.byref(g), _ptr(d_grid),
+                                                      C.byref(wts) if wts is not None else None, int(chunk_points), C.c_void_p(ws.data_ptr()),
+                                                      C.c_size_t(ws.numel()), _stream()))
+        if stage == 1:
+            carry["d_grid"] = None          # finished: the caller's (autograd may take the tensor as the parameter's .grad without a copy)
+            return d_grid, carry
+        return res
 
     def render(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, hierarchical=True,
                lock_view=False, want_weights=False, want_wsum=False):

@@ -465,6 +465,22 @@ int fenerf_render_backward(const FenerfModel* m, int B, int R, int N, int lock_v
                            const float* z_coarse, const float* noise_final, const FenerfCompositeOpts* opts, const float* g_rgb,
                            const FenerfSirenGrads* grads, float* d_grid_ncdhw, const FenerfSirenGrads* weights, int64_t chunk_points,
                            int64_t film_sums_budget_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
+/* fenerf_render_backward cut in two, for data-parallel training (train_double_latent_semantic.py:148-150: DistributedDataParallel all-reduces
+ * every generator gradient; 113 of the 124 MB are spatial_embeddings.grad).  That gradient is final as soon as the last chain launch has
+ * scattered into it, with the last chunks' weight-gradient kernels still to run:
+ *   stage 1 -- composite backward; chain AND weight gradients of every backward chunk but the last `keep_chunks`; the chains of those last
+ *              chunks, each dump in its own slot of the workspace; d_grid_ncdhw finished.  The caller hands it to its all-reduce.
+ *   stage 2 -- the weight gradients of the last chunks, the sums over chunks, the FiLM fold: everything else in `grads` finished.
+ * Same arguments in both calls (g_rgb / z_coarse / noise_final / opts are read by stage 1 only and may be NULL in stage 2); `grads`' buffers
+ * and the workspace (fenerf_render_backward_split_workspace_bytes: + one dump per kept chunk) must stay untouched between the two calls.
+ * Weight gradients are required (no FiLM-only form).  Same kernels on the same chunks, every gradient summed in the same order:
+ * stage 1 + stage 2 == fenerf_render_backward bit for bit (the atomically scattered grid gradient aside). */
+size_t fenerf_render_backward_split_workspace_bytes(const FenerfModel* m, int B, int R, int N, int64_t chunk_points, int keep_chunks);
+int fenerf_render_backward_stage(const FenerfModel* m, int stage, int keep_chunks, int B, int R, int N, int lock_view, const void* save,
+                                 size_t save_bytes, int tape_format, const float* z_coarse, const float* noise_final,
+                                 const FenerfCompositeOpts* opts, const float* g_rgb, const FenerfSirenGrads* grads, float* d_grid_ncdhw,
+                                 const FenerfSirenGrads* weights, int64_t chunk_points, void* workspace, size_t workspace_bytes, void* stream);
 /* HBM bytes per (sample point x FiLM-layer feature) of the backward streams of a chunk of `chunk_points` points (bench.py's generator-step
  * roofline): out[0] = what the chain kernel writes into the dump, out[1] = what the square weight-gradient job reads for one of its L - 1
  * layers (the dump of layer l + the input activations of layer l), out[2] = the four thin jobs together (two dump layers + two
