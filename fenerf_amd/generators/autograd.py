@@ -248,8 +248,11 @@ class HierarchicalWeightStage(torch.autograd.Function):
         module, nat, B = ctx.module, w["nat"], w["B"]
         need = ctx.needs_input_grad
         if w.get("abi"):        # fenerf_render_backward_stage(2): the kept chunks' weight gradients, the sums, the FiLM fold -- all in the library
-            r = nat.render_backward_stage(2, w["keep"], B, w["R"], w["N"], w["save"], None, None, w["opts"], None, lock_view=w["lock_view"],
-                                          tape_format=w["tape_format"], weights=w["weights"], chunk_points=w["chunk_points"], carry=w["carry"])
+            try:
+                r = nat.render_backward_stage(2, w["keep"], B, w["R"], w["N"], w["save"], None, None, w["opts"], None, lock_view=w["lock_view"],
+                                              tape_format=w["tape_format"], weights=w["weights"], chunk_points=w["chunk_points"], carry=w["carry"])
+            finally:
+                nat.release_split_workspace(w["carry"])
             film_grads = tuple(r[k] if need[2 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
             params = w["params"]
             grid = module._roles(params)["grid"]
@@ -309,10 +312,14 @@ class HierarchicalRenderSplitFunction(torch.autograd.Function):
             state = ctx.state
             state.work = dict(abi=True, nat=nat, B=B, R=R, N=N, save=save, opts=opts, lock_view=ctx.lock_view, tape_format=ctx.tape_format,
                               weights=weights, keep=keep, chunk_points=_siren_autograd.BACKWARD_CHUNK_POINTS, carry=carry, params=params)
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: setattr(state, "work", None))      # see below
+            def drop():         # the engine has finished the pass: whatever the weight stage did not consume is dropped (see below)
+                w_, state.work = state.work, None
+                if w_ is not None:
+                    nat.release_split_workspace(w_["carry"])
+            torch.autograd.Variable._execution_engine.queue_callback(drop)
             g_token = torch.zeros(1, dtype=torch.float32, device=save.device) if ctx.needs_input_grad[1] else None
             if g_token is None:
-                state.work = None
+                drop()
             return (None, g_token, g_grid if ctx.needs_input_grad[2] else None) + (None,) * 14
         B, R, N, P, Pp = ctx.dims
         pts2, rd, fg, pg, fa, pa, out2, tape2, tape_e2, z_f, zc, noise_f = ctx.saved_tensors

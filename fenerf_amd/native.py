@@ -669,8 +669,16 @@ class NativeModel:
             if stage == 1:
                 res, g, d_grid = self._render_grad_buffers(B, False)
                 nbytes = int(l.fenerf_render_backward_split_workspace_bytes(self._h, B, R, N, int(chunk_points), int(keep_chunks)))
-                ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-                carry = dict(res=res, g=g, d_grid=d_grid, ws=ws)
+                # The workspace must survive until stage 2.  The model's persistent scratch when no other two-stage backward holds it (a
+                # fresh 10-GB tensor per backward pass fragments the caching allocator between the forward's 54-GB save block and this:
+                # + 1 ms per 6-image step); a second render of the same graph whose stage 1 runs before this one's stage 2 gets its own.
+                cached = not getattr(self, "_split_ws_busy", False)
+                if cached:
+                    self._split_ws_busy = True
+                    ws = self._workspace("render_bwd_split", nbytes)
+                else:
+                    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+                carry = dict(res=res, g=g, d_grid=d_grid, ws=ws, cached=cached)
             res, g, d_grid, ws = carry["res"], carry["g"], carry["d_grid"], carry["ws"]
             _lib.check(l.fenerf_render_backward_stage(self._h, int(stage), int(keep_chunks), B, R, N, int(lock_view), C.c_void_p(save.data_ptr()),
                                                       C.c_size_t(save.numel()), int(tape_format),
@@ -682,7 +690,14 @@ class NativeModel:
         if stage == 1:
             carry["d_grid"] = None          # finished: the caller's (autograd may take the tensor as the parameter's .grad without a copy)
             return d_grid, carry
+        self.release_split_workspace(carry)
         return res
+
+    def release_split_workspace(self, carry):
+        """stage 2 has run -- or never will (the backward pass ended without it): the persistent two-stage scratch is free again"""
+        if carry is not None and carry.get("cached"):
+            carry["cached"] = False
+            self._split_ws_busy = False
 
     def render(self, origins, dirs, z_coarse, u, noise_coarse, noise_final, fg, pg, fa, pa, opts, hierarchical=True,
                lock_view=False, want_weights=False, want_wsum=False):

@@ -3284,3 +3284,47 @@ def test_style_generator3d_vs_reference(precision):
     print(f"[parity] StyleGenerator3d[{precision}] vs the reference class: forward(z) {e_f:.2e}, staged_forward(z) pixels {e_s:.2e} depth {e_d:.2e} "
           f"weights_sum {e_t:.2e}; psi / fill_color ignored, no average frequencies")
     assert e_f <= 2.6e-6 and e_s <= 2.6e-6 and e_d <= 3e-6 and e_t <= 6e-7          # measured x 1.5 (1.7e-6 / 1.7e-6 / 2.0e-6 / 3.6e-7, both precisions)
+
+
+def test_two_renders_in_one_graph_through_the_two_stage_backward():
+    """generator called twice before ONE backward with siren.split_backward on: the render stage of the second render runs before the weight
+    stage of the first (autograd orders by topology), so the two passes' two-stage workspaces are alive together -- the second gets its
+    own (native.render_backward_stage) -- and the gradients are the sum of the two single-render backward passes'."""
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision="f16x3")
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    B, S_, N = 1, 6, 8
+    kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.0, last_back=False)
+    films = [proc.film_params(spec, B, seed=s_) for s_ in (4, 9)]
+    w = torch.randn((B, 21, S_, S_), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+
+    def render(film, seed):
+        torch.manual_seed(seed)
+        px, _ = gen.forward_with_frequencies(T(film["freq_geo"]), T(film["freq_app"]), T(film["phase_geo"]), T(film["phase_app"]), **kw)
+        return (px * w).sum()
+
+    def grads():
+        return {k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None}
+
+    try:
+        mod.split_backward = True
+        singles = []
+        for film, seed in zip(films, (11, 12)):
+            for p_ in mod.parameters():
+                p_.grad = None
+            render(film, seed).backward()
+            singles.append(grads())
+        for p_ in mod.parameters():
+            p_.grad = None
+        (render(films[0], 11) + render(films[1], 12)).backward()
+        both = grads()
+    finally:
+        mod.split_backward = False
+    nat = mod.native_differentiable(torch.device(DEV))
+    assert not getattr(nat, "_split_ws_busy", False), "the persistent two-stage workspace was released"
+    worst = max(_rel_err(both[k], singles[0][k] + singles[1][k]) for k in both)
+    print(f"[parity] two renders in one graph through the two-stage backward: gradients = the sum of the two single backward passes', {worst:.1e} over {len(both)} tensors")
+    assert len(both) > 30 and worst <= 2e-6
