@@ -3053,10 +3053,20 @@ def test_integration_md_binding_generator_step():
         else:
             assert torch.equal(param_g[k].reshape(p_.shape), p_.grad), k
     assert worst <= 1e-5, worst
+    # the same backward as two calls (fenerf_render_backward_stage 1 / 2, keep_chunks 1 and 2): the grid gradient handed to on_grid_ready
+    # is already the final one -- bit for bit what the call returns afterwards --, every other gradient equals the one-call backward's
+    for keep in (1, 2):
+        at_stage1 = []
+        film_g2, param_g2 = ns["render_backward"](h, mod, save, z, nf, opts, g_px, on_grid_ready=lambda t_: at_stage1.append(t_.clone()), keep_chunks=keep)
+        assert len(at_stage1) == 1 and torch.equal(at_stage1[0], param_g2["spatial_embeddings"]), "finished at stage 1"
+        assert _rel_err(N_(param_g2["spatial_embeddings"]), N_(param_g["spatial_embeddings"])) <= 1e-6       # float atomics
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(film_g, film_g2))
+        assert all(torch.equal(param_g[k], param_g2[k]) for k in param_g if k != "spatial_embeddings"), keep
     ns["_l"].fenerf_model_destroy.argtypes = [ctypes_void_p()]
     ns["_l"].fenerf_model_destroy(h)
     print(f"[parity] INTEGRATION.md B binding, generator step: render_forward_save + render_backward through the documented ctypes calls == the package's "
-          f"autograd path (pixels, 4 FiLM gradients, {len(named) - 6} kernel-written parameter gradients bit for bit; the label head's un-fold {worst:.1e})")
+          f"autograd path (pixels, 4 FiLM gradients, {len(named) - 6} kernel-written parameter gradients bit for bit; the label head's un-fold {worst:.1e}); "
+          f"the two-stage form (fenerf_render_backward_stage) hands over the finished grid gradient at stage 1 and returns the same gradients")
 
 
 def ctypes_void_p():
