@@ -22,7 +22,7 @@ def test_committed_fixtures_regenerate_from_the_reference(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_golden.py"), out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     committed = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
-    assert len(committed) >= 19
+    assert len(committed) >= 33
     for f in committed:
         g = os.path.join(out, os.path.basename(f))
         assert os.path.exists(g), f"make_golden.py no longer writes {os.path.basename(f)}"
@@ -36,7 +36,7 @@ def test_committed_fixtures_regenerate_from_the_reference(tmp_path):
                 continue
             assert np.array_equal(a[k], b[k]), f"{os.path.basename(f)}:{k} differs from what the reference produces today"
     assert json.load(open(os.path.join(GOLDEN, "curriculums.json"))) == json.load(open(os.path.join(out, "curriculums.json")))
-    assert os.path.exists(os.path.join(out, "ref_generator_tiny.pth"))
+    assert os.path.exists(os.path.join(out, "ref_generator_tiny.pth")) and os.path.exists(os.path.join(out, "ref_style_generator_tiny.pth"))
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference only exists in the build container")
