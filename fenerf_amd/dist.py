@@ -119,8 +119,9 @@ class GeneratorDataParallel(torch.nn.Module):
 
     Why: the render's gradients come out of ONE native call (fenerf_render_backward) a few microseconds apart, 37 tensors of which 36 are
     smaller than 300 KB.  DistributedDataParallel handles each of them on its own -- a copy-and-divide launch into its bucket per parameter,
-    the bucket bookkeeping on the host before and after -- : measured at world 1 on an MI355X, 76 of the 159 launches of a generator step
-    and 1.8 of its 14.0 ms are the wrapper's (profiles/r05_ddp_step_timeline_*.txt), against 83 launches / 12.2 ms for the bare module.
+    the bucket bookkeeping on the host before and after -- : measured at world 1 on an MI355X, 109 of the 169 launches of a generator step
+    and 1.5 of its 13.5 - 13.9 ms are the wrapper's (55 of 115 with RECOMMENDED_DDP_KWARGS; profiles/r05_ddp_step_timeline_*.txt), against
+    60 launches / 12.0 ms for the bare module and 65 / 12.1 ms through this class.
     Here the gradients are reduced when the backward pass has finished: tensors of at least `async_numel` elements (16 MB: the 96^3 feature
     grid, 113 of the 124 MB) in place, started from the parameter's own post-accumulate hook so that with prepare_for_ddp's two-node backward
     the collective runs beside the weight-gradient kernels; everything else concatenated into one flat buffer (one launch), reduced with
