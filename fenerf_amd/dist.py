@@ -101,12 +101,14 @@ RECOMMENDED_DDP_KWARGS = dict(find_unused_parameters=False, gradient_as_bucket_v
 def prepare_for_ddp(generator, enable=True):
     """Call before wrapping a generator in DistributedDataParallel(generator, device_ids=[rank], **RECOMMENDED_DDP_KWARGS).
 
-    Switches the generator's hierarchical render to its two-node backward (generators/autograd.py): the gradient of the 96^3 feature grid
-    -- 113 of the 124 MB DDP all-reduces per backward -- is handed to autograd as soon as the last chain launch has finished, so DDP
-    starts its all-reduce while the weight-gradient kernels (a quarter of the step) are still running, instead of after everything.
-    Costs memory (the d(theta) dumps of all backward chunks are alive together: + 4.4 GB per 128 x 128 x 24 pass) -- hence opt-in.
-    Returns RECOMMENDED_DDP_KWARGS.  With the reference's own wrapper arguments the switch is harmless but buys nothing: DDP then keeps
-    its static bucket order, in which the grid comes last."""
+    Switches the generator's hierarchical render to its two-node backward (generators/autograd.py over fenerf_render_backward_stage 1 / 2): the
+    gradient of the 96^3 feature grid -- 113 of the 124 MB a rank all-reduces per backward -- is handed to autograd when the last chain launch
+    has been issued, with the weight-gradient kernels of the last two backward chunks (3.6 ms at 128 x 128 x 24) still to come, so the wrapper's
+    all-reduce of it runs beside them instead of after everything.  Costs the dumps of those two chunks (+ 4.4 GB each at H = 256: 66.9 instead
+    of 56.4 GB peak at the reference's 6-image micro-batch) -- hence opt-in.  Gradients: bit-identical to the one-call backward but for the
+    atomically scattered grid's (1e-8).  Returns RECOMMENDED_DDP_KWARGS.  With the reference's own wrapper arguments the switch is harmless
+    but buys nothing: DDP then keeps its static bucket order, in which the grid comes last.  fenerf_amd.dist.GeneratorDataParallel uses the
+    same switch (and needs no bucket order)."""
     generator.siren.split_backward = bool(enable)
     return dict(RECOMMENDED_DDP_KWARGS)
 
