@@ -42,6 +42,76 @@ PEAK_HBM_TBPS = 8.0                 # MI355X_MICROARCH.md: HBM3E
 SPEC_CLOCK_GHZ = 2.4                # the clock the matrix peaks above are quoted at
 
 
+COMPACT_LINE_LIMIT = 4096           # bytes; the driver reads the LAST stdout line (round 5's 20.6 KB line came back `parsed: null`)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _sig(v, n=6):
+    """floats to n significant digits (the compact line is read by people and by a parser with a tail limit)"""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float(f"{v:.{n}g}")
+
+
+def compact_line(out):
+    """The ONE line the driver parses, from the full result object `out` (which goes to bench_detail.json unchanged): the contract's
+    keys, `roofline` and `cpu_baseline` as flat objects of scalars, and one scalar (or a small flat object) per extra leg.  No `what`
+    strings, no per-kernel tables, no tier legs.  Always < COMPACT_LINE_LIMIT bytes (asserted here and in tests/test_host_cpu.py)."""
+    def pick(d, keys):
+        return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+    def leg_ms(name, keys=("ms",)):
+        d = out.get(name)
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": str(d["error"])[:120]}
+        return pick(d, keys)
+
+    line = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = {k: v for k, v in out.get("config", {}).items() if not isinstance(v, (dict, list))}
+    line["roofline"] = pick(out.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "points_per_launch",
+                                                      "frac_of_f16x3_ceiling", "frac_executed", "clock_ghz_effective", "frac_at_spec_clock"))
+    line["roofline"].setdefault("traffic", None)
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "threads", "kind", "sample"))
+    line["n_ranks_seen"] = out.get("n_ranks_seen")
+    line["launches_per_step"] = out.get("launches_per_step")
+    for name, keys in (("f32", ("value", "ms_per_step")), ("sweep64", ("value", "ms_per_step", "roofline_frac")),
+                       ("gstep", ("ms", "rays_per_s", "peak_GB")), ("gstep_b6", ("ms", "ms_per_image", "peak_GB")),
+                       ("gstep_ddp", ("ms", "ms_no_ddp", "ms_tuned", "ms_generator_data_parallel", "allreduce_ms_exposed", "allreduce_bytes",
+                                      "n_ranks_seen", "dist_backend")),
+                       ("gstep_ddp_b6", ("ms", "ms_no_ddp", "ms_generator_data_parallel", "allreduce_ms_exposed"))):
+        v = leg_ms(name, keys)
+        if v is not None:
+            line[name] = v
+    if isinstance(out.get("f32"), dict) and isinstance(out["f32"].get("roofline"), dict):
+        line["f32"]["roofline_frac"] = _sig(out["f32"]["roofline"].get("frac"))
+    g = out.get("gstep")
+    if isinstance(g, dict) and isinstance(g.get("roofline"), dict):          # the step's roofs both ways (bytes / 8 TB/s and FLOP / 2,500 TFLOP/s)
+        line["gstep"].update(pick(g["roofline"], ("frac", "frac_flop")))
+        line["gstep"]["kernels_ms"] = {k["name"]: _sig(k["ms"], 4) for k in g["roofline"].get("per_kernel", [])}
+    line["detail"] = DETAIL_FILE
+    text = json.dumps(line, separators=(", ", ": "))
+    assert len(text.encode()) < COMPACT_LINE_LIMIT and "\n" not in text, len(text)
+    return text
+
+
+def write_detail(out):
+    """the full result object (every leg, `what` strings, per-kernel tables) next to the script and, on a gpurun box, under gpurun_out/"""
+    text = json.dumps(out, indent=1)
+    paths = [os.path.join(ROOT, DETAIL_FILE)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_FILE))
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {pth}: {e}", file=sys.stderr)
+
+
 def pmc_traffic():
     """HBM-side bytes per SIREN launch at the default workload (393,216 points) from the newest committed rocprofv3 PMC summary
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes over this file's default command, tools/gpu_r3.sh pmc -> tools/pmc_summary.py):
@@ -96,37 +166,88 @@ def self_launch_command(n, argv, script=None, port=None):
             "--master-port", str(port or _free_port()), script or os.path.abspath(__file__)] + list(argv)
 
 
-def _oracle_run(spec, sd, film, S, N, hier, seed):
-    from oracle import fenerf_oracle as O
+def _oracle_inputs(S, N, seed):
     B, R = 1, S * S
     rng = np.random.default_rng(seed)
-    rand = dict(u_jitter=rng.random((B, R, N, 1), dtype=np.float32), theta=np.full((B, 1), np.pi / 2 + 0.1, np.float32),
+    return dict(u_jitter=rng.random((B, R, N, 1), dtype=np.float32), theta=np.full((B, 1), np.pi / 2 + 0.1, np.float32),
                 phi=np.full((B, 1), np.pi / 2 - 0.05, np.float32), noise_coarse=None,
                 u_fine=rng.random((B * R, N), dtype=np.float32), noise_fine=None)
+
+
+def _oracle_run(spec, sd, film, S, N, hier, seed):
+    """one image through the numpy oracle (BLAS GEMMs threaded, every elementwise pass on one core): detail file only since round 6"""
+    from oracle import fenerf_oracle as O
+    rand = _oracle_inputs(S, N, seed)
     t0 = time.perf_counter()
     O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rand, hierarchical_sample=hier, clamp_mode="relu")
     return time.perf_counter() - t0
 
 
-def cpu_baseline(spec, sd, film, seed, full=True):
-    """Oracle (numpy port of the reference CPU path, validated against the reference's own outputs in tests/) on the GPU box's
-    host cores: BASELINE.md §5 = 1 warm-up + 3 timed runs per shape; shapes = configs[0] (64x64, 12 coarse), configs[1] (128x128,
-    24+24: the headline workload, `value`) and the 64x64, 24+24 scaling batch.  `full=False`: headline shape only, 1+1 runs."""
+def _oracle_torch_run(spec, tsd, film, S, N, hier, seed, max_batch_size):
+    """one image through the torch-CPU oracle: the reference's ATen statements (F.grid_sample, F.linear, torch.sin, cumprod, searchsorted,
+    sort / gather), all of them on torch's intra-op thread pool"""
+    from oracle import fenerf_oracle_torch as OT
+    rand = _oracle_inputs(S, N, seed)
+    t0 = time.perf_counter()
+    OT.render_forward(tsd, spec, film, S, 12, 0.88, 1.12, N, rand, hierarchical_sample=hier, clamp_mode="relu", max_batch_size=max_batch_size)
+    return time.perf_counter() - t0
+
+
+CPU_BASELINE_BUDGET_S = 40.0        # bound on the whole leg (the contract: ~10-30 s of CPU work, the default bench run within minutes)
+
+
+def cpu_baseline(spec, sd, film, seed, full=True, budget_s=CPU_BASELINE_BUDGET_S):
+    """the reference's CPU path on the GPU box's host cores = oracle/fenerf_oracle_torch.py (bit-identical to the imported
+    reference on the committed fixtures, tests/test_oracle_golden.py) under torch.set_num_threads(all host cores): 1 warm-up + 3 timed runs
+    per shape, median; shapes = configs[1] (128x128, 24+24: the headline workload, `value`), configs[0] (64x64, 12 coarse) and the 64x64,
+    24+24 scaling batch; point chunks of 2,400,000 as the reference's render scripts pass (render_multiview_images_double_semantic.py:36).
+    The leg is bounded: when a slow host would take it past `budget_s`, later shapes run 1 timed run or are skipped (recorded in `runs`).
+    `full=False` (N > 1 lines): headline shape only, 1 + 1 runs.  The numpy oracle (the parity checker; single-threaded outside BLAS) is
+    timed once on the headline shape for the detail file."""
+    from oracle import fenerf_oracle_torch as OT
     cores = os.cpu_count()
-    shapes = [("configs[1]: 128x128 rays, 24+24 samples", 128, 24, True)]
-    if full:
-        shapes += [("configs[0]: 64x64 rays, 12 coarse samples, no resampling", 64, 12, False),
-                   ("scaling batch: 64x64 rays, 24+24 samples", 64, 24, True)]
-    res = []
-    for name, S, N, hier in shapes:
-        _oracle_run(spec, sd, film, S, N, hier, seed)                          # warm-up
-        ts = [_oracle_run(spec, sd, film, S, N, hier, seed + 1 + i) for i in range(3 if full else 1)]
-        res.append({"shape": name, "rays": S * S, "seconds": [round(t, 3) for t in ts], "rays_per_s": S * S / float(np.median(ts))})
-    out = dict(value=res[0]["rays_per_s"], unit="rays/s", cores=cores, kind="port",
-               sample=f"numpy oracle render_forward on one image per shape, H=256 + 96^3 grid, 1 warm-up + {len(res[0]['seconds'])} timed "
-                      f"run(s), median (BLAS GEMMs use all {cores} host cores, elementwise ops 1); value = {res[0]['shape']}",
-               runs=res)
-    return out
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    threads = torch.get_num_threads()
+    t_leg = time.perf_counter()
+    try:
+        tsd = OT.state_to_torch(sd)
+        shapes = [("configs[1]: 128x128 rays, 24+24 samples", 128, 24, True)]
+        if full:
+            shapes += [("configs[0]: 64x64 rays, 12 coarse samples, no resampling", 64, 12, False),
+                       ("scaling batch: 64x64 rays, 24+24 samples", 64, 24, True)]
+        res = []
+        for name, S, N, hier in shapes:
+            left = budget_s - (time.perf_counter() - t_leg)
+            if res and left <= 0:
+                res.append({"shape": name, "skipped": "leg budget spent"})
+                continue
+            warm = _oracle_torch_run(spec, tsd, film, S, N, hier, seed, 2400000)
+            left = budget_s - (time.perf_counter() - t_leg)
+            n = 3 if (full and 3 * warm <= max(left, 0.0)) else 1
+            ts = [_oracle_torch_run(spec, tsd, film, S, N, hier, seed + 1 + i, 2400000) for i in range(n)]
+            res.append({"shape": name, "rays": S * S, "warmup_s": round(warm, 3), "seconds": [round(t, 3) for t in ts],
+                        "rays_per_s": S * S / float(np.median(ts))})
+        head = res[0]
+        out = dict(value=head["rays_per_s"], unit="rays/s", cores=cores, threads=threads, kind="port",
+                   sample=f"torch-CPU oracle (the reference's ATen statements, all passes on {threads} threads of {cores} host cores), one "
+                          f"128x128 x 24+24 image (configs[1]), 1 warm-up + {len(head['seconds'])} timed run(s), median",
+                   runs=res)
+        t_head = float(np.median(head["seconds"]))
+        if full:
+            try:        # detail only, while the budget lasts: the reference's default chunk (staged_forward's max_batch_size=50000) ...
+                if budget_s - (time.perf_counter() - t_leg) > 1.5 * t_head:
+                    out["chunk_50000"] = {"rays_per_s": 128 * 128 / _oracle_torch_run(spec, tsd, film, 128, 24, True, seed + 9, 50000)}
+                if budget_s - (time.perf_counter() - t_leg) > 5 * t_head:      # ... and the numpy oracle (3-5 x the torch edition's time)
+                    t_np = _oracle_run(spec, sd, film, 128, 24, True, seed + 9)
+                    out["numpy_oracle"] = {"rays_per_s": 128 * 128 / t_np, "seconds": round(t_np, 3),
+                                           "note": "the parity checker; BLAS GEMMs threaded, elementwise passes on one core (round 5's cpu_baseline)"}
+            except Exception as e:
+                out["detail_error"] = f"{type(e).__name__}: {e}"
+        out["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+        return out
+    finally:
+        torch.set_num_threads(prev)
 
 
 def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_precision="f32"):
@@ -211,6 +332,14 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
         "wgrad_square": dump["square_read"] * (L - 1) * H,                                       # d(theta)_l and x_{l-1} (or tape_{l-1}) of the L-1 square layers
         "wgrad_thin": dump["thin_read"] * H + (128.0 if G_ else 0.0) + 2 * xyz + 3 * row,        # four thin jobs: two dumps, two tape layers, points / dirs / features, rows
     }
+    # the same launch groups by FLOP (round 6: the counters say these kernels are issue-bound, not byte-bound -- both roofs are reported):
+    # algorithmic dense-layer FLOP per point, 2 per MAC.  forward_save = the forward; the chain multiplies d(theta) by the same
+    # matrices transposed (same MACs); the weight gradients are the outer products of the same shapes: L-1 square H x H layers, and the thin
+    # ones (first layer 3 x H, colour layer 0's dirs + grid columns, sigma / rgb / folded label rows)
+    thin_cols = 3 + (3 + G_ if spec["kind"] != "spatial" else 3) + (C - 1) + 1
+    flop_model = {"forward_save": float(FLOP_PER_POINT) if (H, L, C, G_) == (256, 11, 22, 32) else None,
+                  "chain": float(FLOP_PER_POINT) if (H, L, C, G_) == (256, 11, 22, 32) else None,
+                  "wgrad_square": 2.0 * (L - 1) * H * H, "wgrad_thin": 2.0 * thin_cols * H}
     steps_b = 3
     with native.phase_timing() as t:
         for _ in range(steps_b):
@@ -220,13 +349,19 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
         k_ms = t.ms.get(name, 0.0) / steps_b
         nbytes = b_pt * pts
         accounted += k_ms
+        flop = flop_model[name] * pts if flop_model.get(name) else None
         per_kernel.append({"name": name, "ms": k_ms, "launches": t.calls.get(name, 0) // steps_b, "algorithmic_bytes": nbytes,
                            "achieved_TBps": nbytes / (k_ms * 1e-3) / 1e12 if k_ms else None,
-                           "frac": nbytes / (k_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS if k_ms else None})
+                           "frac": nbytes / (k_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS if k_ms else None,
+                           "algorithmic_flop": flop, "achieved_TFLOPs": flop / (k_ms * 1e-3) / 1e12 if (k_ms and flop) else None,
+                           "frac_flop": flop / (k_ms * 1e-3) / 1e12 / PEAK_F16_MATRIX_TFLOPS if (k_ms and flop) else None})
     rest = {k: v / steps_b for k, v in t.ms.items() if k not in model}
     total_bytes = sum(k["algorithmic_bytes"] for k in per_kernel)
+    total_flop = sum(k["algorithmic_flop"] or 0.0 for k in per_kernel)
     out["roofline"] = {"bound": "hbm", "algorithmic_bytes": total_bytes, "achieved": total_bytes / (ms * 1e-3) / 1e12, "achieved_TBps": total_bytes / (ms * 1e-3) / 1e12,
                        "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": total_bytes / (ms * 1e-3) / 1e12 / PEAK_HBM_TBPS,
+                       "algorithmic_flop": total_flop, "achieved_TFLOPs": total_flop / (ms * 1e-3) / 1e12, "peak_flop": PEAK_F16_MATRIX_TFLOPS,
+                       "frac_flop": total_flop / (ms * 1e-3) / 1e12 / PEAK_F16_MATRIX_TFLOPS,
                        "per_kernel": per_kernel, "other_library_launches_ms": rest,
                        "ms_not_in_library_kernels": ms - accounted - sum(rest.values()),
                        "launch_groups_per_step": sum(t.calls.values()) // steps_b,
@@ -492,10 +627,13 @@ def main(argv=None):
     ap.add_argument("--no-gstep-ddp", action="store_true", help="skip the DistributedDataParallel generator-step legs (run at every N)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-sweep64", action="store_true", help="skip the 64x64, 24+24 scaling-batch leg")
+    ap.add_argument("--dead-ends", action="store_true", help="also run the documented dead ends (f16x2 forward, the one-launch render): detail file only")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="arithmetic of the dense layers: exact fp32 MFMA, or error-compensated fp16 MFMA (fp32-class accuracy)")
     ap.add_argument("--dist-check", action="store_true", help="rendezvous + all-reduce of ones only (no GPU needed)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo for the CPU dry run of --dist-check")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo for the CPU dry run of --dist-check and for --one-device")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank on cuda:0 (with --dist-backend gloo: RCCL refuses two ranks on one device): the N > 1 code path on a one-GPU box")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -510,8 +648,9 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     from fenerf_amd import dist as fdist
     n_ranks_seen = 1
@@ -519,7 +658,9 @@ def main(argv=None):
     # so that a one-GPU box exercises the code the driver's 2/4/8-GPU runs depend on (tests/test_gpu_parity.py)
     use_dist = world > 1 or bool(os.environ.get("FENERF_BENCH_FORCE_DIST"))
     if use_dist:
-        fdist.init_from_env(backend="nccl", device=dev, force=True)   # RCCL over xGMI; timing barrier / max-reduce / rank census only
+        if args.one_device and world > 1 and args.dist_backend == "nccl":
+            sys.exit("bench.py: --one-device with N > 1 needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+        fdist.init_from_env(backend=args.dist_backend, device=dev, force=True)   # RCCL over xGMI; timing barrier / max-reduce / rank census only
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         n_ranks_seen = int(ones.item())
@@ -563,7 +704,7 @@ def main(argv=None):
     def gather_floats(v):
         if not use_dist:
             return [float(v)]
-        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")     # gloo gathers host memory
         outs = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         return [float(x.item()) for x in outs]
@@ -660,7 +801,9 @@ def main(argv=None):
                             f"{render_launches} kernel launches per step); the mapping networks, ray setup and the NCHW epilogue of a full "
                             "generator call (0.05-0.18 ms, tools/time_call_overhead.py) are outside it",
             "launches_per_step": render_launches,
-            "launcher": ("torch.distributed.run, one rank per GPU, backend nccl (RCCL)" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1
+            "launcher": ((f"torch.distributed.run, one rank per GPU, backend {'nccl (RCCL)' if args.dist_backend == 'nccl' else args.dist_backend}"
+                          if not args.one_device else f"torch.distributed.run, {world} ranks on ONE device (cuda:0), backend {args.dist_backend}")
+                         if "TORCHELASTIC_RUN_ID" in os.environ or world > 1
                          else "single process") + (" [process group forced at world 1]" if use_dist and world == 1 else ""),
             "dist_backend": dist.get_backend() if use_dist else None,
         }
@@ -683,8 +826,8 @@ def main(argv=None):
             # Round 5: the opt-in reduced-precision forwards (include/fenerf.h fenerf_model_set_forward_mode) beside the headline: the same
             # timed render, the same roofline fields (cycles per launch, clock granted) and what they cost in accuracy against the
             # headline's own pixels on the same rays.  Never the headline: they do not meet its asserted bounds (profiles/r05_*).
-            for key, what in (("f16x2", "two fp16 MFMAs per product everywhere (weights as ONE fp16 value: wl*xh dropped, the lo halves neither fetched nor read)"),
-                              ("f16x3c2", "three fp16 MFMAs per product through the geometry trunk and the label / sigma head (sigma and labels bit-identical to the headline's), two in the colour layers and the rgb head")):
+            for key, what in ((("f16x2", "two fp16 MFMAs per product everywhere (weights as ONE fp16 value: wl*xh dropped, the lo halves neither fetched nor read)"),) if args.dead_ends else ()) + (
+                              ("f16x3c2", "three fp16 MFMAs per product through the geometry trunk and the label / sigma head (sigma and labels bit-identical to the headline's), two in the colour layers and the rgb head"),):
                 try:
                     natx = native.NativeModel(sd, spec, dev, key)
                     xdt, _, xin = timed_render(natx, B, S, N, args.steps, args.warmup, 1000)
@@ -704,7 +847,7 @@ def main(argv=None):
                     del natx
                 except Exception as e:
                     out[key] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and args.precision == "f16x3":
+        if world == 1 and args.precision == "f16x3" and args.dead_ends:
             # the same render as ONE launch (include/fenerf.h fenerf_set_render_fusion): reported beside the headline,
             # which takes the faster four-launch route
             try:
@@ -747,7 +890,8 @@ def main(argv=None):
             # the driver's scaling sweep is self-contained while the other ranks wait at the final barrier for ~20 s, not a minute
             film1 = proc.film_params(spec, 1, seed=1000)
             out["cpu_baseline"] = cpu_baseline(spec, sd, film1, 7, full=(world == 1 and not args.quick_cpu_baseline))
-        print(json.dumps(out), flush=True)
+        write_detail(out)
+        print(compact_line(out), flush=True)        # the LAST stdout line, < 4 KB
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -303,8 +303,9 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
   if (e != hipSuccess) { delete m; return hip_fail(e, "hipGetDeviceProperties"); }
   m->num_cus = prop.multiProcessorCount;
-  // experiment switch (profiles/r04_gstep_overlap_why_not.md): size every persistent launch for fewer CUs than the device has
-  // -- said once on stderr when it takes effect, so that a leftover variable cannot shrink a production run silently
+#ifdef FENERF_EXPERIMENT_SWITCHES
+  // experiment switch (profiles/r04_gstep_overlap_why_not.md): size every persistent launch for fewer CUs than the device has.
+  // Compiled in only by `make EXPERIMENTS=1` (round 6): the shipped library reads no tuning variable from the environment.
   if (const char* e = getenv("FENERF_EXP_NUM_CUS")) {
     const int n = atoi(e);
     if (n > 0 && n < m->num_cus) {
@@ -313,6 +314,7 @@ extern "C" int fenerf_model_create(const FenerfModelDesc* d, FenerfModel** out) 
       m->num_cus = n;
     }
   }
+#endif
   rc = upload_model(m, d, nullptr, true);
   if (rc) { fenerf_model_destroy(m); return rc; }
   *out = m;

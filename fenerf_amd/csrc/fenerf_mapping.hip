@@ -295,7 +295,7 @@ extern "C" int fenerf_mapping_forward(const FenerfMappingNet* net, int B, const 
   if (rc) return rc;
   if (!z || !acts || !out) return map_fail(FENERF_E_INVALID, "fenerf_mapping_forward: NULL pointer");
   P.z = z; P.acts = acts; P.out = out;
-  const int wmax = P.z_dim > P.hidden ? P.z_dim : P.hidden;
+  const int wmax = ((P.z_dim > P.hidden ? P.z_dim : P.hidden) + 3) & ~3;     // as the kernel rounds it: two buffers of whole float4s
   PhaseScope ph(PH_OTHER, stream);
   hipLaunchKernelGGL(mapping_forward_kernel, dim3(B, P.S), dim3(MAP_THREADS), 2 * wmax * sizeof(float), (hipStream_t)stream, P);
   hipError_t e = hipGetLastError();

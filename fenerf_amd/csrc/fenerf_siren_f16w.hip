@@ -901,6 +901,8 @@ static int launch_siren16w_one(const FenerfModel* m, const SirenParams& q, void*
 // `balanced_only`: refuse when the coarser unit of work would lengthen the critical path (whole groups per workgroup vs whole octs).
 bool fused_render_plan(const FenerfModel* m, long long B, long long R, int N, bool balanced_only, FusedRenderPlan* plan) {
   if (m->precision != FENERF_PREC_F16X3 || N < 3 || 2 * N > w16::FUSED_MAXM) return false;
+  if (m->forward_mode != FENERF_FORWARD_F16X3) return false;   // the fused kernel is instantiated for the full f16x3 arithmetic only: an opt-in
+                                                               // reduced-precision model takes the four-launch route, which honours its mode
   int g = N, b = 128;
   while (b) { const int t = g % b; g = b; b = t; }          // gcd(N, 128)
   const int G = 128 / g, opg = N / g;

@@ -129,10 +129,15 @@ class GeneratorDataParallel(torch.nn.Module):
     the collective runs beside the weight-gradient kernels; everything else concatenated into one flat buffer (one launch), reduced with
     one collective, and handed back as views of it.  Averaging is the collective's own (RCCL `avg`; sum + one division on gloo).
     The same arithmetic as DDP up to the summation order inside the collective; `no_sync()` as DDP's (local accumulation over micro-batches).
-    Every rank must produce gradients for the same parameters (DDP's find_unused_parameters=False contract); parameters and buffers are
-    broadcast from rank 0 at construction, as DDP does.  State dict keys carry DDP's `module.` prefix."""
+    Every rank must produce gradients for the same parameters (DDP's find_unused_parameters=False contract): what is reduced is the set of
+    parameters whose gradient hook fired since the last synchronisation (so a stale .grad kept by zero_grad(set_to_none=False) is not averaged
+    again, and gradients accumulated under no_sync() are); `check_ranks=True` verifies with one extra 16-byte collective per step that all
+    ranks reduce the same number of tensors and elements and raises instead of hanging in a mismatched all-reduce.  Parameters and buffers
+    are broadcast from rank 0 at construction only (DDP re-broadcasts buffers every forward; the generators have none that change).  After a
+    step the small parameters' .grad are views of one flat buffer, as with DDP's gradient_as_bucket_view=True.  State dict keys carry DDP's
+    `module.` prefix."""
 
-    def __init__(self, module, process_group=None, async_numel=1 << 22, broadcast=True):
+    def __init__(self, module, process_group=None, async_numel=1 << 22, broadcast=True, check_ranks=False):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GeneratorDataParallel needs an initialised process group (fenerf_amd.dist.init_from_env)")
@@ -143,7 +148,8 @@ class GeneratorDataParallel(torch.nn.Module):
         self.world = dist.get_world_size(process_group)
         self._avg = dist.get_backend(process_group) == "nccl"          # gloo has no ReduceOp.AVG
         self._params = [p for p in module.parameters() if p.requires_grad]
-        self._started, self._queued = [], False
+        self._started, self._queued, self._fired = [], False, set()
+        self.check_ranks = bool(check_ranks)
         self.last_sync = {"collectives": 0, "bytes": 0, "flat_tensors": 0}
         if broadcast and self.world > 1:
             with torch.no_grad():
@@ -181,6 +187,7 @@ class GeneratorDataParallel(torch.nn.Module):
         return dist.all_reduce(t, op=op, group=self.process_group, async_op=async_op)
 
     def _on_grad(self, p):
+        self._fired.add(id(p))        # (also under no_sync(): the locally accumulated gradient is reduced by the next synchronised pass)
         if not self.require_backward_grad_sync:
             return
         if not self._queued:          # once per backward pass: reduce the rest when the whole graph has run
@@ -194,10 +201,23 @@ class GeneratorDataParallel(torch.nn.Module):
         self._queued = False
         started, self._started = self._started, []
         early = {id(p) for p, _ in started}
+        fired, self._fired = self._fired, set()
         small = {}
-        for p in self._params:
-            if p.grad is not None and id(p) not in early:
+        for p in self._params:        # module order: the same on every rank
+            if id(p) in fired and p.grad is not None and id(p) not in early:
                 small.setdefault(p.grad.dtype, []).append(p)
+        if self.check_ranks and self.world > 1:
+            n_t = len(started) + sum(len(ps) for ps in small.values())
+            n_e = sum(p.numel() for p, _ in started) + sum(p.numel() for ps in small.values() for p in ps)
+            dev = next((p.grad.device for p in self._params if p.grad is not None), torch.device("cpu"))
+            sig = torch.tensor([n_t, -n_t, n_e, -n_e], dtype=torch.float64, device=dev)
+            dist.all_reduce(sig, op=dist.ReduceOp.MAX, group=self.process_group)
+            if sig[0].item() != -sig[1].item() or sig[2].item() != -sig[3].item():
+                for _, work in started:
+                    work.wait()
+                raise RuntimeError(f"GeneratorDataParallel: ranks disagree on the gradients of this step (this rank: {n_t} tensors, {n_e} elements; "
+                                   f"max over ranks {int(sig[0].item())} / {int(sig[2].item())}, min {int(-sig[1].item())} / {int(-sig[3].item())}): "
+                                   "every rank must produce gradients for the same parameters")
         flats = []
         for ps in small.values():                 # one flat buffer per dtype (the generator: fp32 only)
             flat = torch.cat([p.grad.reshape(-1) for p in ps])

@@ -225,7 +225,7 @@ class _Generator3dBase(nn.Module):
     def _finish_scaled(self, pixels, batch_size, img_size):
         """_finish(...) * 2 - 1 on the device, in one launch (and one in backward) when there is no softmax in between"""
         if self.softmax_label or not pixels.is_cuda or pixels.dtype != torch.float32:
-            return self._finish_scaled(pixels, batch_size, img_size)
+            return self._finish(pixels, batch_size, img_size) * 2 - 1
         return ImageLayoutFunction.apply(pixels, batch_size, img_size)
 
 

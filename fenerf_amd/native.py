@@ -680,13 +680,17 @@ class NativeModel:
                     ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
                 carry = dict(res=res, g=g, d_grid=d_grid, ws=ws, cached=cached)
             res, g, d_grid, ws = carry["res"], carry["g"], carry["d_grid"], carry["ws"]
-            _lib.check(l.fenerf_render_backward_stage(self._h, int(stage), int(keep_chunks), B, R, N, int(lock_view), C.c_void_p(save.data_ptr()),
-                                                      C.c_size_t(save.numel()), int(tape_format),
-                                                      _ptr(_f32(z_coarse, dev)) if z_coarse is not None else None,
-                                                      _ptr(_f32(noise_final, dev)) if noise_final is not None else None, C.byref(opts),
-                                                      _ptr(_f32(g_rgb, dev)) if g_rgb is not None else None, C.byref(g), _ptr(d_grid),
-                                                      C.byref(wts) if wts is not None else None, int(chunk_points), C.c_void_p(ws.data_ptr()),
-                                                      C.c_size_t(ws.numel()), _stream()))
+            try:
+                _lib.check(l.fenerf_render_backward_stage(self._h, int(stage), int(keep_chunks), B, R, N, int(lock_view), C.c_void_p(save.data_ptr()),
+                                                          C.c_size_t(save.numel()), int(tape_format),
+                                                          _ptr(_f32(z_coarse, dev)) if z_coarse is not None else None,
+                                                          _ptr(_f32(noise_final, dev)) if noise_final is not None else None, C.byref(opts),
+                                                          _ptr(_f32(g_rgb, dev)) if g_rgb is not None else None, C.byref(g), _ptr(d_grid),
+                                                          C.byref(wts) if wts is not None else None, int(chunk_points), C.c_void_p(ws.data_ptr()),
+                                                          C.c_size_t(ws.numel()), _stream()))
+            except Exception:
+                self.release_split_workspace(carry)      # a failed stage hands no carry back: the persistent scratch must not stay claimed
+                raise
         if stage == 1:
             carry["d_grid"] = None          # finished: the caller's (autograd may take the tensor as the parameter's .grad without a copy)
             return d_grid, carry

@@ -87,8 +87,10 @@ class _MappingFunction(torch.autograd.Function):
         ctx.save_for_backward(z, acts, *params)
         # the two halves as the Function's OWN outputs: left to autograd, the backward of the two slices of `out` is two zero fills, two
         # strided copies and an add (5 launches per network per step) before this backward even starts; here it is one concatenation
+        # (fresh tensors, not two views of `out`: autograd refuses in-place edits -- frequencies.mul_(...) -- of a Function's view outputs,
+        # which the reference's plain slices allow)
         half = out.shape[-1] // 2
-        return out[..., :half], out[..., half:]
+        return out[..., :half].clone(), out[..., half:].clone()
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")

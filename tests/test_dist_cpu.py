@@ -150,7 +150,7 @@ def _gdp_worker(rank, world, port, q):
     fdist.init_from_env(backend="gloo")
     torch.manual_seed(100 + rank)                     # DIFFERENT initial weights per rank: the wrapper must broadcast rank 0's
     net = torch.nn.Sequential(torch.nn.Linear(6, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))
-    gdp = fdist.GeneratorDataParallel(net, async_numel=6 * 64)          # the first weight (384 elements) takes the early, in-place path
+    gdp = fdist.GeneratorDataParallel(net, async_numel=6 * 64, check_ranks=True)          # the first weight (384 elements) takes the early, in-place path
     w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
     ddp = DDP(copy.deepcopy(net), find_unused_parameters=True)       # its own copy of the (broadcast) module: no hooks shared between the two
     x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank))
@@ -170,6 +170,26 @@ def _gdp_worker(rank, world, port, q):
     net.zero_grad(set_to_none=False)
     gdp(x).square().sum().backward()
     res["gdp_again"] = flat()
+    # round 6: only gradients produced since the last synchronisation are reduced.  A parameter skipped in this pass keeps its
+    # stale .grad (zero_grad(set_to_none=False) semantics) untouched -- rank-dependent values are NOT averaged a second time
+    net.zero_grad(set_to_none=False)
+    net[2].bias.grad.fill_(float(rank + 1))
+    net[2].bias.requires_grad_(False)
+    gdp(x).square().sum().backward()
+    net[2].bias.requires_grad_(True)
+    res["stale_bias"] = net[2].bias.grad.clone()
+    skipped_stats = dict(gdp.last_sync)
+    # ranks that disagree on which parameters took part: check_ranks raises on every rank instead of hanging in a mismatched collective
+    net.zero_grad(set_to_none=True)
+    if rank == 1:
+        net[2].bias.requires_grad_(False)
+    try:
+        gdp(x).square().sum().backward()
+        res["mismatch"] = torch.zeros(1)
+    except RuntimeError as e:
+        res["mismatch"] = torch.ones(1) if "ranks disagree" in str(e) else torch.full((1,), 2.0)
+    net[2].bias.requires_grad_(True)
+    stats["skipped_flat_tensors"] = skipped_stats["flat_tensors"]
     q.put((rank, w0.tolist(), {k: v.tolist() for k, v in res.items()}, stats))
     dist.barrier()
     dist.destroy_process_group()
@@ -188,6 +208,9 @@ def test_generator_data_parallel_equals_ddp_world_size_2():
         assert p.exitcode == 0
     (_, w0, r0, st0), (_, w1, r1, st1) = res
     assert w0 == w1, "parameters broadcast from rank 0 at construction"
+    assert r0.pop("stale_bias") == [1.0] * 3 and r1.pop("stale_bias") == [2.0] * 3, "a gradient no backward produced is not reduced again"
+    assert r0.pop("mismatch") == [1.0] and r1.pop("mismatch") == [1.0], "check_ranks: both ranks raise on a parameter-set mismatch"
+    assert st0.pop("skipped_flat_tensors") == st1.pop("skipped_flat_tensors") == 2
     for k in r0:
         assert r0[k] == r1[k], f"{k}: identical gradients on both ranks"
     # two ranks: the mean of two fp32 numbers has one possible rounding, whatever the collective's order

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, ROOT, load_golden
 from fenerf_amd import curriculums, _lib
 from fenerf_amd.generators import generators as G
 from fenerf_amd.generators import volumetric_rendering as VR
@@ -622,3 +622,96 @@ def test_label_head_backward_validates_before_any_launch():
     assert b"n_lab <= 32" in l.fenerf_last_error()
     assert l.fenerf_label_head_backward(2, 256, 18, null, null, None, None, null, null, None, None) == _lib.E_INVALID
     assert b"NULL" in l.fenerf_last_error()
+
+
+@pytest.mark.parametrize("softmax_label,dtype", [(True, "float32"), (False, "float32"), (False, "float16"), (True, "float64")])
+def test_finish_scaled_fallback_is_the_references_epilogue(softmax_label, dtype):
+    """_Generator3dBase._finish_scaled away from the one-launch device path (softmax_label=True, host tensors, non-fp32 pixels) is the
+    reference's epilogue statement for statement (generators/generators.py:520-525, :97-102): softmax over the label channels, NHWC ->
+    NCHW, * 2 - 1.  Round 5 shipped this branch calling itself (RecursionError)."""
+    import torch
+    from fenerf_amd.generators import generators as G
+    from fenerf_amd.siren import siren as S_
+    gen = G.DoubleImplicitGenerator3d(lambda **kw: S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE(hidden_dim=32, **kw), 16, 16, 22, softmax_label=softmax_label)
+    torch.manual_seed(1)
+    px = torch.rand(2, 8 * 8, 21).to(getattr(torch, dtype)).requires_grad_(True)
+    out = gen._finish_scaled(px, 2, 8)
+    ref = px
+    if softmax_label:
+        ref = torch.cat([torch.nn.Softmax(dim=-1)(px[..., :-3]), px[..., -3:]], dim=-1)
+    ref = ref.reshape((2, 8, 8, -1)).permute(0, 3, 1, 2).contiguous() * 2 - 1
+    assert out.shape == (2, 21, 8, 8) and out.dtype == px.dtype and out.is_contiguous() and torch.equal(out, ref)
+    g, = torch.autograd.grad(out.float().square().sum(), px)
+    assert torch.isfinite(g).all()
+    single = G.ImplicitGenerator3d(lambda **kw: S_.SPATIALSIRENBASELINE(hidden_dim=32, **kw), 16, 4, softmax_label=softmax_label)
+    assert torch.equal(single._finish_scaled(px, 2, 8), ref)
+
+
+def test_bench_last_stdout_line_is_compact_and_parses_from_a_tail():
+    """bench.py's contract line (round 5's grew to 20.6 KB and the driver recorded `parsed: null`): compact_line() of a full result
+    object -- round 5's own, every leg present -- is one line below 4 KB that carries the contract's keys with flat `roofline` /
+    `cpu_baseline` objects, survives an 8 KB tail cut of the process's stdout, and stays small whatever the legs contain."""
+    import json
+    import bench
+    log = os.path.join(ROOT, "profiles", "r05_bench_default_command.json.log")
+    full = [json.loads(l) for l in open(log).read().splitlines() if l.startswith("{")][-1]
+    assert len(json.dumps(full)) > 20000                                   # the object that broke the driver's parse
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line.encode()) < 4096 == bench.COMPACT_LINE_LIMIT
+    stdout = "RCCL version : 2.26.6\n" + json.dumps({"noise": "x" * 30000}) + "\n" + line + "\n"
+    tail = stdout.encode()[-8192:].decode()
+    got = json.loads(tail.rstrip("\n").splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == pytest.approx(full["value"], rel=1e-5) and got["config"]["workload"].startswith("configs[1]")
+    roof = got["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"} <= set(roof) and len(roof) <= 14
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(got["cpu_baseline"])
+    assert got["gstep"]["ms"] == pytest.approx(full["gstep"]["ms"], rel=1e-5) and got["gstep_b6"]["ms"] > 0 and got["gstep_ddp"]["ms"] > 0
+    assert "render_one_launch" not in got and "f16x2" not in got and got["detail"] == bench.DETAIL_FILE
+    # legs that failed, with long messages; legs that are missing; a result with no legs at all
+    broken = dict(full, gstep={"error": "RuntimeError: " + "y" * 5000}, f32={"error": "z" * 5000})
+    del broken["gstep_b6"], broken["sweep64"]
+    l2 = json.loads(bench.compact_line(broken))
+    assert len(l2["gstep"]["error"]) <= 120 and "gstep_b6" not in l2
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data", "config", "roofline")}
+    l3 = json.loads(bench.compact_line(bare))
+    assert "cpu_baseline" not in l3 and l3["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+
+
+def test_bench_cpu_baseline_is_the_torch_oracle_on_all_cores(monkeypatch):
+    """bench.cpu_baseline times oracle/fenerf_oracle_torch.py (every pass on torch's thread pool) under set_num_threads(all cores),
+    restores the caller's thread count and honours its time budget; tiny model, 8x8 .. 128x128 replaced by a stub clock-free check of the
+    bookkeeping on a small spec."""
+    import torch
+    import bench
+    from fenerf_amd import procedural as proc
+    spec = proc.model_spec("texture", hidden_dim=32, grid_size=8)
+    sd = proc.make_state_dict(spec, seed=0, sigma_gain=20.0, with_mapping=False)
+    film = proc.film_params(spec, 1, seed=3)
+    torch.set_num_threads(2)
+    seen = []
+    real = bench._oracle_torch_run
+
+    def spy(spec_, tsd, film_, S, N, hier, seed, mbs):
+        seen.append((S, N, hier, mbs, torch.get_num_threads()))
+        return real(spec_, tsd, film_, 16 if S == 128 else 8, 6, hier, seed, mbs)      # the shapes' bookkeeping at a size that runs in milliseconds
+    monkeypatch.setattr(bench, "_oracle_torch_run", spy)
+    monkeypatch.setattr(bench, "_oracle_run", lambda *a: 0.25)
+    out = bench.cpu_baseline(spec, sd, film, 7, full=True)
+    assert torch.get_num_threads() == 2
+    assert out["kind"] == "port" and out["cores"] == os.cpu_count() and out["threads"] == os.cpu_count() and out["unit"] == "rays/s"
+    assert "elementwise ops 1" not in out["sample"] and "torch-CPU oracle" in out["sample"]
+    assert [r["shape"].split(":")[0] for r in out["runs"]] == ["configs[1]", "configs[0]", "scaling batch"]
+    assert all(len(r["seconds"]) == 3 for r in out["runs"]) and out["value"] == out["runs"][0]["rays_per_s"]
+    assert all(t == os.cpu_count() for *_, t in seen) and {m for _, _, _, m, _ in seen} == {2400000, 50000}
+    assert out["numpy_oracle"]["seconds"] == 0.25
+    seen.clear()
+    quick = bench.cpu_baseline(spec, sd, film, 7, full=False)
+    assert len(quick["runs"]) == 1 and len(quick["runs"][0]["seconds"]) == 1 and len(seen) == 2
+    spent = bench.cpu_baseline(spec, sd, film, 7, full=True, budget_s=0.0)
+    assert len(spent["runs"][0]["seconds"]) == 1 and all("skipped" in r for r in spent["runs"][1:]) and "numpy_oracle" not in spent

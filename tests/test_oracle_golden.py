@@ -391,3 +391,92 @@ def test_style_generator3d_fixture():
     e_s, e_d, e_t = np.abs(px - g["stg_pixels"]).max(), np.abs(depth - g["stg_depth"]).max(), np.abs(third - g["stg_third"]).max()
     print(f"[parity] oracle vs the reference's StyleGenerator3d: forward {e_f:.2e}, staged pixels {e_s:.2e} depth {e_d:.2e} weights_sum {e_t:.2e}")
     assert max(e_f, e_s, e_t) <= 2e-5 and e_d <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The torch-CPU edition of the oracle (oracle/fenerf_oracle_torch.py): the thing bench.py times as `cpu_baseline` (BASELINE.md §5 --
+# the reference's ATen statements, every pass on all host cores).  Pinned against the same reference fixtures and against the numpy oracle.
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,tol", [("tiny_texture_fwd", 2e-3), ("tiny_texture_fwd_nohier", 2e-3), ("tiny_baseline_fwd", 2e-3), ("tiny_spatial_fwd", 2e-3),
+                                      ("tiny_texture_fwd_trained", 2e-3), ("h96_texture_8x8_n12", 2e-3), ("h192_baseline_8x8_n12", 2e-3),
+                                      ("h256_texture_16x16_n12", 2e-4), ("h256_texture_16x16_n24_trained", 1e-3), ("h256_baseline_8x8_n12", 1e-3),
+                                      ("tiny_texture_staged", None), ("tiny_texture_staged_lock", None), ("tiny_spatial_staged", None)])
+def test_torch_oracle_vs_reference_fixtures_and_numpy_oracle(name, tol):
+    import torch
+    from oracle import fenerf_oracle_torch as OT
+    g = load_golden(name)
+    spec, sd, film = _model(g)
+    kw = {k: v for k, v in kwargs_from_golden(g).items() if k in RENDER_KW}
+    S, N, hier = int(g["meta_S"]), int(g["meta_N"]), bool(g["meta_hier"])
+    rd = _rand(g)
+    tsd = OT.state_to_torch(sd)
+    # chunked like the reference's staged_forward (points, not rays): a chunk size that does not divide R*N
+    px, depth, third, st = OT.render_forward(tsd, spec, film, S, 12, 0.88, 1.12, N, rd, hierarchical_sample=hier, return_stages=True,
+                                             max_batch_size=max(7, (S * S * N) // 3 + 1), **kw)
+    npx, ndepth, nthird, nst = O.render_forward(sd, spec, film, S, 12, 0.88, 1.12, N, rd, hierarchical_sample=hier, return_stages=True, **kw)
+    B, R = st["z_coarse"].shape[:2]
+    # stage by stage against the reference's recorded tensors (same bounds as the numpy oracle's test)
+    np.testing.assert_allclose(st["points"].numpy(), g["st_points"], atol=5e-7)
+    np.testing.assert_allclose(st["z_coarse"].numpy(), g["st_z_coarse"], atol=2e-7)
+    np.testing.assert_allclose(st["dirs"].numpy(), g["st_dirs"], atol=3e-7)
+    np.testing.assert_allclose(st["origins"].numpy(), g["st_origins"], atol=3e-7)
+    sig_tol = 1e-5 * max(float(g["meta_sigma_gain"]), 10.0 if spec["hidden_dim"] >= 192 else 1.0)
+    co = st["coarse"].reshape(B, R * N, -1).numpy()
+    if "st_siren_coarse" in g:
+        np.testing.assert_allclose(co[..., :-1], g["st_siren_coarse"][..., :-1], atol=2e-5, rtol=1e-4)
+        np.testing.assert_allclose(co[..., -1], g["st_siren_coarse"][..., -1], atol=sig_tol, rtol=2e-4)
+    np.testing.assert_allclose(co, nst["coarse"].reshape(B, R * N, -1), atol=max(2e-5, sig_tol), rtol=2e-4)      # the numpy oracle on the same points
+    # teacher-forced resampling + merge on the reference's own intermediate tensors
+    if hier and "st_siren_coarse" in g:
+        cref = torch.from_numpy(g["st_siren_coarse"].reshape(B, R, N, -1))
+        zc = torch.from_numpy(g["st_z_coarse"])
+        _, _, w = OT.fancy_integration(cref, zc, noise=torch.from_numpy(g["rand_noise_coarse"]) if "rand_noise_coarse" in g else None,
+                                       noise_std=float(g["kw_nerf_noise"]), clamp_mode=str(g["kw_clamp_mode"]))
+        np.testing.assert_allclose(w.numpy(), g["st_coarse_weights"], atol=2e-6)
+        wr = torch.from_numpy(g["st_coarse_weights"]).reshape(B * R, N) + 1e-5
+        z = zc.reshape(B * R, N)
+        zf = OT.sample_pdf(0.5 * (z[:, :-1] + z[:, 1:]), wr[:, 1:-1], torch.from_numpy(g["rand_u_fine"]))
+        np.testing.assert_allclose(zf.numpy(), g["st_z_fine"], atol=2e-6)
+    # end to end: the reference's pixels, and the numpy oracle's (both oracles see the same inputs; a resampling flip may differ)
+    e_ref = np.abs(px.numpy() - g["pixels"]).max(axis=1)
+    e_np = np.abs(px.numpy() - npx).max(axis=1)
+    print(f"[torch oracle] {name}: vs reference max {e_ref.max():.2e}, vs numpy oracle max {e_np.max():.2e}")
+    if tol is None:                    # staged fixtures: threshold-flip pixels allowed, must be rare (as test_staged_with_frequencies)
+        assert (e_ref > 2e-3).mean() <= 0.05 and (e_np > 2e-3).mean() <= 0.05
+        ok = e_ref <= 2e-3
+        np.testing.assert_allclose(depth.numpy()[ok], g["depth"][ok], atol=1e-4)
+    else:
+        assert e_ref.max() <= tol and e_np.max() <= tol
+        if spec["kind"] != "spatial":
+            am, am_ref = O.label_argmax(px.numpy()), O.label_argmax(g["pixels"])
+            top2 = np.sort(g["pixels"][:, :-3], axis=1)
+            tie = (top2[:, -1] - top2[:, -2]) <= 1e-6
+            assert not ((am != am_ref) & ~tie).any()
+
+
+def test_torch_oracle_integration_variants_and_sample_pdf_cases():
+    """fancy_integration / sample_pdf of the torch edition on the reference's flag-variant and edge-case fixtures"""
+    import torch
+    from oracle import fenerf_oracle_torch as OT
+    g = load_golden("integration_variants")
+    rs, z = torch.from_numpy(g["rgb_sigma"]), torch.from_numpy(g["z_vals"])
+    done = 0
+    for i in range(int(g["n_variants"])):
+        kw = ast.literal_eval(str(g[f"v{i}_kw"]))
+        if kw.get("fill_mode") in ("debug", "weight_debug"):
+            continue
+        rgb, dep, third = OT.fancy_integration(rs.clone(), z, noise=torch.from_numpy(g[f"v{i}_noise"]), **kw)
+        np.testing.assert_allclose(rgb.numpy(), g[f"v{i}_rgb"], atol=3e-6, err_msg=str(kw))
+        np.testing.assert_allclose(dep.numpy(), g[f"v{i}_depth"], atol=3e-6, err_msg=str(kw))
+        np.testing.assert_allclose(third.numpy(), g[f"v{i}_third"], atol=3e-6, err_msg=str(kw))
+        done += 1
+    assert done >= 15, done
+    rgb, dep, third = OT.fancy_integration(torch.from_numpy(g["ewb_rgb_sigma"]), z, clamp_mode="relu", noise_std=0.0, fill_mode="eval_white_back")
+    np.testing.assert_allclose(rgb.numpy(), g["ewb_rgb"], atol=3e-6)
+    np.testing.assert_allclose(third.numpy(), g["ewb_third"], atol=3e-6)
+    g = load_golden("sample_pdf_cases")
+    for i in range(int(g["n_cases"])):
+        s = OT.sample_pdf(torch.from_numpy(g[f"c{i}_bins"]), torch.from_numpy(g[f"c{i}_weights"]), torch.from_numpy(g[f"c{i}_u"]))
+        np.testing.assert_allclose(s.numpy(), g[f"c{i}_samples"], atol=2e-6)
+    s = OT.sample_pdf(torch.from_numpy(g["edge_bins"]), torch.from_numpy(g["edge_weights"]), torch.from_numpy(g["edge_u"]))
+    np.testing.assert_allclose(s.numpy(), g["edge_samples"], atol=2e-6)
