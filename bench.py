@@ -193,6 +193,34 @@ def _oracle_torch_run(spec, tsd, film, S, N, hier, seed, max_batch_size):
     return time.perf_counter() - t0
 
 
+def effective_host_cores():
+    """The host cores this process may actually use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU quota
+    (v2 cpu.max / v1 cpu.cfs_quota_us).  The GPU boxes of this pool show 256 logical CPUs with a quota of 16 (`cpu.max 1600000 100000`):
+    256 OpenMP threads on 16 cores' worth of time ran the torch-CPU oracle 16 x SLOWER than 16 threads (tools/exp/cpu_threads_probe.py,
+    round 6: 118 vs 1,765 rays/s at 64x64x24+24)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return n
+
+
 CPU_BASELINE_BUDGET_S = 40.0        # bound on the whole leg (the contract: ~10-30 s of CPU work, the default bench run within minutes)
 
 
@@ -205,7 +233,7 @@ def cpu_baseline(spec, sd, film, seed, full=True, budget_s=CPU_BASELINE_BUDGET_S
     `full=False` (N > 1 lines): headline shape only, 1 + 1 runs.  The numpy oracle (the parity checker; single-threaded outside BLAS) is
     timed once on the headline shape for the detail file."""
     from oracle import fenerf_oracle_torch as OT
-    cores = os.cpu_count()
+    cores = effective_host_cores()          # all the host cores this process is allowed (cgroup quota honoured), one thread on each
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     threads = torch.get_num_threads()
@@ -230,9 +258,10 @@ def cpu_baseline(spec, sd, film, seed, full=True, budget_s=CPU_BASELINE_BUDGET_S
                         "rays_per_s": S * S / float(np.median(ts))})
         head = res[0]
         out = dict(value=head["rays_per_s"], unit="rays/s", cores=cores, threads=threads, kind="port",
-                   sample=f"torch-CPU oracle (the reference's ATen statements, all passes on {threads} threads of {cores} host cores), one "
-                          f"128x128 x 24+24 image (configs[1]), 1 warm-up + {len(head['seconds'])} timed run(s), median",
-                   runs=res)
+                   sample=f"torch-CPU oracle (the reference's ATen statements, every pass threaded) on {threads} threads = the {cores} host cores this "
+                          f"process may use ({os.cpu_count()} logical CPUs, cgroup quota / affinity honoured), one 128x128 x 24+24 image (configs[1]), "
+                          f"1 warm-up + {len(head['seconds'])} timed run(s), median",
+                   logical_cpus=os.cpu_count(), runs=res)
         t_head = float(np.median(head["seconds"]))
         if full:
             try:        # detail only, while the budget lasts: the reference's default chunk (staged_forward's max_batch_size=50000) ...

@@ -387,7 +387,9 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   const long long o_begin = nocts * xcd / nx, o_end = nocts * (xcd + 1) / nx;
 
   // fenerf_siren_backward_film (inversion: only the FiLM sums are wanted): no d(theta) dump, no d(grid features)
-  const bool dump = P.d_t != nullptr;
+  // (TAPE = 2 is only ever launched with a dump -- launch_siren_backward16w below sends FiLM-only launches to the TAPE = 0 kernel -- so the
+  // default generator step carries no branch around its d(theta) stores: round 6)
+  const bool dump = TAPE == 2 ? true : P.d_t != nullptr;
   int tpar = 0;   // parity of the tape staging buffers (advances per stage when NB is odd)
   for (long long oct = o_begin + bi; oct < o_end; oct += blocks_in_x) {
     // a wave past the last tile repeats the last tile: same loads, same values, same stores (no guard in the stream loop)
@@ -403,10 +405,16 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     const char* dt_tile = uniform_ptr(reinterpret_cast<const char*>(P.d_t) + (size_t)tile32 * L * TL);
     const char* film_tile = uniform_ptr(reinterpret_cast<const char*>(P.film_tiles) + (size_t)(WGS ? oct : tile) * L * (2 * H * 4));
     // ---- WGS: per-wave sums -> LDS buffer kb; one step of barriers later the wave whose turn it is combines and stores them
-    auto fs_write = [&](int kb, int rt, const f32x2& sm) {
+    // this lane's slot of its wave's block in buffer 0, once per tile (round 6: the five address instructions per row tile it replaces were
+    // 10 of a body's ~180 VALU instructions); buffer and row tile are uniform / immediate offsets
+    int fs_idx;      // (an index, not a pointer: an opaque pointer would lose its address space and turn the ds_write into a flat store)
+    {
       const int lo = opaque(lane);
+      fs_idx = opaque(wave * 32 + (lo >> 4) * 4 + (lo & 3));
+    }
+    auto fs_write = [&](int kb, int rt, const f32x2& sm) {
       const f32x2 v = {sm[0] * vf, sm[1] * vf};
-      fsum[(kb * NWAVE + wave) * 32 + rt * 16 + (lo >> 4) * 4 + (lo & 3)] = v;
+      fsum[fs_idx + kb * (NWAVE * 32) + rt * 16] = v;
     };
     auto fs_combine = [&](int kb, int who, const char* dst) {
       if (wave == who) {

@@ -102,9 +102,9 @@ def test_siren_forward_vs_reference(name, precision):
     # larger labels): measured rgb 1.64e-6, labels 6.9e-7, sigma 3.1e-6 x |sigma|max.
     b_rgb, b_lab = (7e-6, 2e-6) if "trained" in name and name.startswith("tiny") else (8.5e-7, 9e-8)     # (fine points: 4.4e-6 / 1.2e-6)
     if precision == "f16x3c2":
-        # two MFMAs per product in the colour branch: rgb measured 1.6e-5 .. 2.4e-5 (tiny trained 3.4e-5) on the coarse points
-        # (profiles/r05_forward_modes.md) x 1.5; labels and sigma are the default's, bit for bit -- asserted against the default's own output
-        b_rgb = 5.1e-5 if "trained" in name and name.startswith("tiny") else 3.6e-5
+        # two MFMAs per product in the colour branch: rgb measured (round 6, all fixtures, coarse / fine / fp64) <= 2.91e-5, tiny trained
+        # 3.40e-5 coarse / 5.74e-5 fine; x 1.5.  Labels and sigma are the default's, bit for bit -- asserted against the default's own output
+        b_rgb = 8.7e-5 if "trained" in name and name.startswith("tiny") else 4.4e-5
         ref3 = N_(_native_for(name.split("[")[0], "f16x3")[0].siren_forward(T(pts), T(dirs), *tf))
         assert np.array_equal(out[..., :-4], ref3[..., :-4]) and np.array_equal(out[..., -1], ref3[..., -1]), "f16x3c2: labels and sigma bit-identical to f16x3"
     def close(got, want, tag):
@@ -353,7 +353,8 @@ E2E_MEASURED = {"tiny_texture_fwd_trained": 1.5e-5, "tiny_texture_fwd": 1.7e-6, 
 
 # the same for the opt-in "f16x3c2" forward (profiles/r05_forward_modes.md, second table)
 E2E_MEASURED_C2 = {"tiny_texture_fwd": 2.9e-5, "tiny_texture_fwd_nohier": 3.1e-5, "tiny_baseline_fwd": 1e-6, "h256_texture_16x16_n12": 2.8e-5,
-                   "h256_texture_16x16_n24_trained": 6.6e-4, "h256_baseline_8x8_n12": 1.2e-4, "tiny_texture_fwd_trained": 5.5e-5}
+                   "h256_texture_16x16_n24_trained": 6.6e-4, "h256_baseline_8x8_n12": 1.2e-4, "tiny_texture_fwd_trained": 5.5e-5,
+                   "h96_texture_8x8_n12": 2.7e-5, "h192_baseline_8x8_n12": 2.1e-5}
 
 
 def _e2e_check(tag, px, ref_px, tol=1e-3, max_flips=0):
@@ -557,8 +558,9 @@ def _check_render_vs_oracle(tag, nat, rays, tf, opts, rgb, depth, r_rgb, r_depth
 
 
 # the rays of the bench image (seed 0) whose pixel differs from the fp32 oracle's by more than 1e-3, by index (measured on an MI355X; the
-# library is deterministic).  f16x3: one ray, 1.309e-3, a resampling flip (asserted against the fp64 arbiter inside the test)
-EXPECTED_RAYS_BEYOND_1E3 = {"f32": (), "f16x3": tuple(range(128 * 128)), "f16x3c2": tuple(range(128 * 128))}      # f16x3*: pinned after the round-6 GPU run
+# library is deterministic).  f16x3: ray 9880, 1.309e-3 from the fp32 oracle -- a resampling flip (asserted against the fp64 arbiter inside the
+# test: its merged sample depths are 2.7e-4 from fp64's, the fp32 oracle's own 1.15e-3; its pixel is 8.9e-4 from fp64's, the oracle's 2.2e-3)
+EXPECTED_RAYS_BEYOND_1E3 = {"f32": (), "f16x3": (9880,), "f16x3c2": (9880,)}      # f16x3c2: sigma is f16x3's, bit for bit -> the same ray
 
 
 @pytest.mark.parametrize("precision", FORWARD_PRECISIONS)
@@ -2730,8 +2732,9 @@ def test_world_2_on_one_gpu_native_two_stage_backward_through_both_wrappers():
     for k in legs:
         print(f"[dist] world 2 on one GPU (gloo), {k}: worst relative error vs the mean of the bare-module gradients {d[k]['worst_rel_err']:.1e} "
               f"({d[k]['worst']}; {d[k]['tensors']} tensors), identical on both ranks: {d[k]['identical_on_both_ranks']}")
-        assert d[k]["tensors"] == 55 or d[k]["tensors"] > 30
-        assert d[k]["worst_rel_err"] <= 2e-6 and d[k]["identical_on_both_ranks"], (k, d[k])
+        # measured 1.2e-6 .. 1.5e-6 (the mapping networks' first-layer gradients: the FiLM-parameter gradients feeding them carry the
+        # atomically accumulated sums of the render backward -- run-to-run rounding, not the collective); every other tensor <= 1e-7
+        assert d[k]["tensors"] == 53 and d[k]["worst_rel_err"] <= 4e-6 and d[k]["identical_on_both_ranks"], (k, d[k])
     assert d["gdp_split"]["collectives"] >= 2
     print(f"[dist] world 2 on one GPU: peak {d['peak_GB']:.1f} GB per rank")
 
@@ -3084,7 +3087,9 @@ def test_reference_fixtures_far_beyond_the_init_range(name, precision):
           f"{e.size} pixels beyond 2e-3")
     # measured (round 4): tiny median 6.6e-6 / 6.9e-6, max 2.6e-5 / 2.7e-5; h256 median 6.0e-6 / 6.2e-6, max 5.1e-4 / 3.8e-4 (f32 / f16x3);
     # no pixel beyond 2e-3 in any of them (round 4 allowed 5 % of the pixels there and a 2e-4 median)
-    assert np.median(e) <= 1.1e-5 and e.max() <= (8e-4 if spec["hidden_dim"] == 256 else 4.5e-5)
+    # f16x3c2 (round 6): tiny median 1.46e-5 max 4.18e-5; h256 median 5.8e-6 max 3.82e-4
+    b_med, b_max = (2.2e-5, 6.3e-5) if precision == "f16x3c2" else (1.1e-5, 4.5e-5)
+    assert np.median(e) <= b_med and e.max() <= (8e-4 if spec["hidden_dim"] == 256 else b_max)
 
 
 def test_integration_md_binding_renders():
@@ -3403,7 +3408,7 @@ def test_style_generator3d_vs_reference(precision):
     e_s, e_d, e_t = (np.abs(N_(a) - g[k]).max() for a, k in ((px_s, "stg_pixels"), (depth, "stg_depth"), (third, "stg_third")))
     print(f"[parity] StyleGenerator3d[{precision}] vs the reference class: forward(z) {e_f:.2e}, staged_forward(z) pixels {e_s:.2e} depth {e_d:.2e} "
           f"weights_sum {e_t:.2e}; psi / fill_color ignored, no average frequencies")
-    b_px = 9e-5 if precision == "f16x3c2" else 2.6e-6         # f16x3c2: the colour branch's two-term products (rgb 2e-5 .. 3e-5, x 2 in [-1, 1] pixels)
+    b_px = 1.7e-5 if precision == "f16x3c2" else 2.6e-6         # f16x3c2: the colour branch's two-term products (measured 1.12e-5 / 1.13e-5)
     assert e_f <= b_px and e_s <= b_px and e_d <= 3e-6 and e_t <= 6e-7          # measured x 1.5 (1.7e-6 / 1.7e-6 / 2.0e-6 / 3.6e-7, both precisions)
 
 

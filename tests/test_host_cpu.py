@@ -704,11 +704,13 @@ def test_bench_cpu_baseline_is_the_torch_oracle_on_all_cores(monkeypatch):
     monkeypatch.setattr(bench, "_oracle_run", lambda *a: 0.25)
     out = bench.cpu_baseline(spec, sd, film, 7, full=True)
     assert torch.get_num_threads() == 2
-    assert out["kind"] == "port" and out["cores"] == os.cpu_count() and out["threads"] == os.cpu_count() and out["unit"] == "rays/s"
+    cores = bench.effective_host_cores()
+    assert 1 <= cores <= os.cpu_count()
+    assert out["kind"] == "port" and out["cores"] == cores and out["threads"] == cores and out["unit"] == "rays/s"
     assert "elementwise ops 1" not in out["sample"] and "torch-CPU oracle" in out["sample"]
     assert [r["shape"].split(":")[0] for r in out["runs"]] == ["configs[1]", "configs[0]", "scaling batch"]
     assert all(len(r["seconds"]) == 3 for r in out["runs"]) and out["value"] == out["runs"][0]["rays_per_s"]
-    assert all(t == os.cpu_count() for *_, t in seen) and {m for _, _, _, m, _ in seen} == {2400000, 50000}
+    assert all(t == cores for *_, t in seen) and {m for _, _, _, m, _ in seen} == {2400000, 50000}
     assert out["numpy_oracle"]["seconds"] == 0.25
     seen.clear()
     quick = bench.cpu_baseline(spec, sd, film, 7, full=False)
