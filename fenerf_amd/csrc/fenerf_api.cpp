@@ -974,6 +974,90 @@ extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t
                             tape_format, weights);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-point modulation under autograd (round 6): SPATIALSIRENGRID.forward_with_frequencies_phase_shifts with one FiLM
+// block per sample point (siren.py:464-477; FiLMLayer takes them unbroadcast, :119-122), differentiable.  Three calls in the shape of
+// fenerf_siren_forward_save / _backward / _param_grads, on the exact-fp32 kernels (FENERF_PREC_F32 models): the forward keeps the tape,
+// the chain reads every lane's own FiLM block, the weight-gradient jobs scale d(theta) by the point's own frequency while they stage it
+// (the factorisation sum_images diag(f_image) sum_points d(theta) x^T of the per-image path does not exist here) and the gradients
+// wrt the per-point frequencies / phase shifts leave as [B, P, n*H] tensors for the mapping network's own backward.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static int pointwise_prep(const FenerfModel* m, int B, int64_t P, const float* fg, const float* pg, const float* fa, const float* pa, void* film_ws,
+                          const float** fp, const float** pp, void* stream) {
+  if (m->precision != FENERF_PREC_F32) return fail(FENERF_E_UNSUPPORTED, "differentiable per-point FiLM parameters: FENERF_PREC_F32 models only");
+  if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (!fg || !pg || !fa || !pa || !film_ws) return fail(FENERF_E_INVALID, "film parameter / workspace pointer is NULL");
+  float* f = (float*)film_ws;
+  float* q = f + (size_t)B * (size_t)P * m->L * m->H;
+  *fp = f; *pp = q;
+  if (P == 0) return FENERF_OK;
+  PhaseScope ph(PH_FILM_PREP, stream);
+  return launch_film_prep(m, (long long)B * P, fg, pg, fa, pa, f, q, stream, true);
+}
+
+extern "C" int fenerf_siren_forward_save_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                                   const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                                   const float* phase_app, float* out, float* tape, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters: models without a feature grid (the reference's SPATIALSIRENGRID has none)");
+  const float *fp, *pp;
+  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc || P == 0) return rc;
+  if (!points || !out || !tape) return fail(FENERF_E_INVALID, "points / out / tape is NULL");
+  SirenParams sp;
+  fill_common(m, sp, fp, pp);
+  sp.points = points; sp.pdirs = ray_dirs;
+  sp.P = (long long)B * P; sp.pts_per_image = P; sp.n_per_ray = 1;
+  sp.out = out; sp.tape = tape; sp.tape_format = FENERF_TAPE_F32;
+  sp.film_per_point = 1;
+  PhaseScope ph(PH_SIREN, stream);
+  return launch_siren_f32(m, sp, stream);
+}
+
+extern "C" int fenerf_siren_backward_pointwise(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                               const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                               const float* tape, float* d_t, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters: models without a feature grid");
+  const float *fp, *pp;
+  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc || P == 0) return rc;
+  if (!out || !d_out || !tape || !d_t) return fail(FENERF_E_INVALID, "NULL pointer");
+  SirenBwdParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.stream = m->d_bwd_stream;
+  bp.ring_offset_floats = (long long)m->bsh.ht_entries * 256;
+  bp.fp = fp; bp.pp = pp;
+  bp.P = (long long)B * P; bp.pts_per_image = P;
+  bp.out = out; bp.d_out = d_out; bp.tape = tape; bp.tape_format = FENERF_TAPE_F32; bp.d_t = d_t; bp.d_e = nullptr;
+  bp.film_tiles = d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P;    // (written, not used: the sums mix points of different frequencies)
+  bp.film_per_point = 1;
+  note_dump(m, d_t, (long long)B * P);
+  PhaseScope ph(PH_CHAIN, stream);
+  return launch_siren_backward(m, bp, stream);
+}
+
+extern "C" int fenerf_siren_param_grads_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                                  const float* freq_geo, const float* phase_geo, const float* freq_app,
+                                                  const float* phase_app, const float* out, const float* d_out, const float* tape,
+                                                  const float* d_t, const FenerfSirenGrads* g, void* workspace, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters: models without a feature grid");
+  const float *fp, *pp;
+  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc || P == 0) return rc;
+  if (!points || !out || !d_out || !tape || !d_t || !g || !workspace) return fail(FENERF_E_INVALID, "NULL pointer");
+  if (!g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
+  for (int i = 0; i < m->n_geo; ++i) if (!g->geo_w[i] || !g->geo_b[i]) return fail(FENERF_E_INVALID, "grads: every weight / bias buffer is required");
+  for (int i = 0; i < m->n_color; ++i) if (!g->color_w[i] || !g->color_b[i]) return fail(FENERF_E_INVALID, "grads: every weight / bias buffer is required");
+  if (!g->head_w || !g->head_b || !g->rgb_w || !g->rgb_b) return fail(FENERF_E_INVALID, "grads: every weight / bias buffer is required");
+  rc = check_dump(m, d_t, (long long)B * P);
+  if (rc) return rc;
+  return launch_param_grads(m, B, P, points, ray_dirs, fp, pp, out, d_out, tape, nullptr, d_t, *g, false, workspace, stream, nullptr, FENERF_TAPE_F32, nullptr, 1);
+}
+
 extern "C" int fenerf_grid_backward(const FenerfModel* m, int64_t total_points, const float* points, const float* d_e,
                                     float* d_grid_cl, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");

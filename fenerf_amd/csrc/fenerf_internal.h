@@ -133,6 +133,8 @@ struct SirenBwdParams {
   float* d_grid_cl;        // [gd][gh][gw][32], accumulated into
   float box_scale;
   int gd, gh, gw;
+  // SPATIALSIRENGRID (siren.py:413-518) under autograd: fp / pp hold one [L][H] block per POINT (siren_bwd_kernel only; round 6)
+  int film_per_point;
 };
 
 struct CompositeParams {
@@ -172,7 +174,8 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P);
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles = nullptr,
-                       int tape_format = 0, const FenerfSirenGrads* weights = nullptr);
+                       int tape_format = 0, const FenerfSirenGrads* weights = nullptr,
+                       int film_per_point = 0);    // film_per_point: fp / pp are [B*P][L][H]; g.d_freq_* / d_phase_* are [B*P][n*H] (FENERF_PREC_F32 models)
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
 int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
 // fenerf_render_forward as ONE launch (fenerf_siren_f16w.hip, FUSED): ray groups of whole octs, see there

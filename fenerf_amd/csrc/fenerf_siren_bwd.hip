@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(SirenBwdParams P, int
     long long pt = tile * 32 + m;
     const bool valid = pt < P.P;
     if (!valid) pt = P.P - 1;
-    const long long img = pt / P.pts_per_image;
+    // FiLM block of this lane: its image's, or -- per-point modulation (SPATIALSIRENGRID under autograd, round 6) -- its own point's.
+    // The per-tile FiLM sums below then mix points with different frequencies and are ignored: the per-point FiLM gradients are the
+    // d(theta) dump itself (pointwise_film_grads_kernel, fenerf_siren_wgrad.hip)
+    const long long img = P.film_per_point ? pt : pt / P.pts_per_image;
     const float* fpl = P.fp + (size_t)img * L * H + 4 * h;
     const float* ppl = P.pp + (size_t)img * L * H + 4 * h;
     const float4* tp = reinterpret_cast<const float4*>(P.tape) + tile * L * (long long)tl + lane;   // + layer * tl

@@ -50,22 +50,33 @@ struct WgradParams {
   int bf16_dump;               // d_t holds the chain kernel's bf16 dump [d theta | x] (fenerf_layout.h "bf16 dump") instead of fp32 d theta
   int tape_u16;                // `tape` is the 16-bit tape (fenerf_layout.h "16-bit tape"): frac(theta) pieces instead of fp32 accumulators
   int freq_from_sums;          // the FiLM frequency gradients are derived from the weight-gradient partial sums (FENERF_TAPE_U16, FENERF_TAPE_F32_W)
+  // Per-point modulation (round 6; SPATIALSIRENGRID under autograd, siren.py:440-477): fp / pp are [B*P][L][H].  The weight gradient of a
+  // FiLM layer is then sum_p (f_l[p] (.) d theta_l[p]) x_{l-1}[p]^T -- the frequency cannot be pulled out of the sum over points -- so the
+  // A side is scaled by the point's own 2 pi f' while it is staged, the B side's activations are recomputed with the point's own
+  // (f', p'), the reductions apply no diag(f), and the FiLM-layer bias gradients are the row sums of the scaled A side.
+  int film_per_point;
+  float* bias_partial;         // film_per_point: [L][B][bias_stride][H] row sums of the scaled d theta (SQ: layers 1 .. L-1; L0: layer 0)
+  int bias_stride;
 };
 
 // Stage one register-dump tile into LDS rows [H][WG_LD]; optional FiLM transform to activations.  The f' / p' rows are
 // fetched (128-bit LDS reads) for the whole tile BEFORE the first write: LDS reads cannot be moved across LDS writes by the
 // compiler, and one read-wait-write per element serialised the staging on LDS latency (measured: 35 % of the kernel).
+// f_g / p_g (per-point modulation): this LANE's point's [H] rows of f' / p' in global memory instead of the image's rows in LDS;
+// with !SIN (the d theta side) f_g scales the row by 2 pi f' = the point's own frequency (WgradParams::film_per_point).
 template <int H, bool SIN>
-__device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst, int wave, int lane, const float* f_s, const float* p_s) {
+__device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst, int wave, int lane, const float* f_s, const float* p_s,
+                                           const float* f_g = nullptr, const float* p_g = nullptr) {
   constexpr int NQ = H / 32;
+  const float TWO_PI = 6.28318530717958647692f;
   const int m = lane & 31, half = lane >> 5;
   float4 f4[NQ], p4[NQ];
-  if (SIN) {
+  if (SIN || f_g) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int row = tape_feature(wave * NQ + q, half, 0);
-      f4[q] = *reinterpret_cast<const float4*>(f_s + row);
-      p4[q] = *reinterpret_cast<const float4*>(p_s + row);
+      f4[q] = *reinterpret_cast<const float4*>((f_g ? f_g : f_s) + row);
+      if (SIN) p4[q] = *reinterpret_cast<const float4*>((p_g ? p_g : p_s) + row);
     }
   }
 #pragma unroll
@@ -75,6 +86,8 @@ __device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst
     if (SIN) {
       e[0] = sin2pi(__builtin_fmaf(f4[q].x, e[0], p4[q].x)); e[1] = sin2pi(__builtin_fmaf(f4[q].y, e[1], p4[q].y));
       e[2] = sin2pi(__builtin_fmaf(f4[q].z, e[2], p4[q].z)); e[3] = sin2pi(__builtin_fmaf(f4[q].w, e[3], p4[q].w));
+    } else if (f_g) {
+      e[0] *= f4[q].x * TWO_PI; e[1] *= f4[q].y * TWO_PI; e[2] *= f4[q].z * TWO_PI; e[3] *= f4[q].w * TWO_PI;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[(row + i) * WG_LD + m] = e[i];
@@ -178,7 +191,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   const int lb = (JOB == WG_SQ) ? l - 1 : ((JOB == WG_HEAD) ? P.n_geo - 1 : P.L - 1);   // B-side activation layer
   const int L = P.L, C = P.C;
 
-  if (S::B_DUMP) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
+  if (S::B_DUMP && !P.film_per_point) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
   if (!S::A_DUMP) for (int i = tid; i < S::A_ROWS * WG_LD; i += 256) A_s[i] = 0.f;     // padded rows stay zero
   if (!S::B_DUMP) for (int i = tid; i < S::B_ROWS * WG_LD; i += 256) B_s[i] = 0.f;
   __syncthreads();
@@ -199,6 +212,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int wm0 = (wave / S::WGK) * S::WM, wk0 = (wave % S::WGK) * S::WK;
   float s0 = 0.f;              // head row sums (thread = row)
+  float sb = 0.f;              // film_per_point: row sum of the scaled d theta (thread = row): the FiLM layer's bias gradient
   float acc3[3] = {0.f, 0.f, 0.f};   // V3 jobs: this thread's three dot products
 
   float4 va[NQ], vb[NQ];
@@ -245,13 +259,16 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   fetch(t0);
   for (int t = t0; t < t1; ++t) {
     // ---- stage the tile
+    // per-point modulation: this lane's point of the tile being staged and its FiLM rows (layer l for the A side, lb for the B side)
+    const size_t pw_pt = (size_t)((tile_base + t) * 32 + (lane & 31)) * L;
     if (S::A_DUMP) {
       if (P.bf16_dump) stage_dump16_f32<H>(va16, A_s, tid);
-      else stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr);
+      else stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr, P.film_per_point ? P.fp + (pw_pt + l) * H : nullptr);
     }
     if (S::B_DUMP) {
       if (P.tape_u16) stage_tape16_sin<H>(vb16, B_s, tid);
-      else stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s);
+      else stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s, P.film_per_point ? P.fp + (pw_pt + lb) * H : nullptr,
+                               P.film_per_point ? P.pp + (pw_pt + lb) * H : nullptr);
     }
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
       if (tid < 96) B_s[(tid >> 5) * WG_LD + (tid & 31)] = side_b * P.box_scale;
@@ -280,6 +297,13 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
     fetch(t + 1);                          // next tile's global loads (dump and side inputs) fly behind this tile's MFMAs
 
     // ---- row sums (thread = row)
+    if ((JOB == WG_SQ || JOB == WG_L0) && P.film_per_point) {
+      if (tid < H) {
+        const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 a = ar[q]; sb += (a.x + a.y) + (a.z + a.w); }
+      }
+    }
     if (JOB == WG_HEAD || JOB == WG_RGB) {
       if (tid < 32) {
         const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
@@ -370,6 +394,8 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
             }
     }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
+    if ((JOB == WG_SQ || JOB == WG_L0) && P.film_per_point && tid < H)
+      P.bias_partial[(((size_t)l * P.B + img) * P.bias_stride + chunk) * H + tid] = sb;
   }
 }
 
@@ -868,7 +894,8 @@ __device__ __forceinline__ float sum_chunks(const float* src, size_t stride, int
 // columns and layer 0 come from the thin jobs' partials (film_freq_thin_kernel, behind the thin reduction).
 template <bool FREQ>
 __global__ __launch_bounds__(256) void wgrad_reduce_sq_kernel(FenerfSirenGrads g, FenerfSirenGrads w, const float* sq, int B, int nchunk, const float* fp,
-                                                              const float* inv, const float* bias, int L, int H, int n_geo, int grid_ch) {
+                                                              const float* inv, const float* bias, int L, int H, int n_geo, int grid_ch,
+                                                              int film_per_point = 0 /* the partials already carry the points' frequencies */) {
   __shared__ float red[256];
   const float TWO_PI = 6.28318530717958647692f;
   const int l = blockIdx.y + 1;
@@ -887,7 +914,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sq_kernel(FenerfSirenGrads g
   float sum = 0.f;
   for (int b = 0; b < B; ++b) {
     const float s = active ? sum_chunks<4>(src + ((size_t)b * nchunk * H + r) * H + c, (size_t)H * H, nchunk) : 0.f;
-    sum += s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
+    sum += film_per_point ? s : s * (fp[((size_t)b * L + l) * H + r] * TWO_PI / (inv ? inv[(size_t)l * H + r] : 1.f));
     if (FREQ) {
       red[c] = s * wv;
       __syncthreads();
@@ -995,6 +1022,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_thin_kernel(ReduceSet J, int
   }
 }
 
+// Per-point modulation (WgradParams::film_per_point): the gradients wrt the RAW per-point FiLM parameters are the d(theta) dump itself,
+//     dL/dphase[p][l][n] = d theta_l[n][p],      dL/dfreq[p][l][n] = 15 d theta_l[n][p] (W x + b)_l[n][p] = 15 d theta (tape + bias),
+// moved from the register-dump layout (lane = point, four consecutive features per float4) to the caller's [point][n*H] rows (geometry |
+// colour split, 16-byte pieces).  One workgroup per 32-point tile and layer range; what torch autograd leaves in `frequencies.grad` /
+// `phase_shifts.grad` of SPATIALSIRENGRID.forward_with_frequencies_phase_shifts (siren.py:464-477, FiLMLayer :119-122 unbroadcast).
+__global__ __launch_bounds__(256) void pointwise_film_grads_kernel(WgradParams P, float* d_freq_geo, float* d_phase_geo, float* d_freq_app, float* d_phase_app) {
+  const int H = P.H, L = P.L, ng = P.n_geo, nc = L - ng;
+  const long long tile = blockIdx.x;
+  const int l = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, half = lane >> 5;
+  const long long tl = (long long)(H / 8) * 64;
+  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t) + (tile * L + l) * tl;
+  const float4* tp4 = reinterpret_cast<const float4*>(P.tape) + (tile * L + l) * tl;
+  const long long pt = tile * 32 + m;
+  float* df = l < ng ? d_freq_geo + (pt * ng + l) * H : d_freq_app + (pt * nc + (l - ng)) * H;
+  float* dp = l < ng ? d_phase_geo + (pt * ng + l) * H : d_phase_app + (pt * nc + (l - ng)) * H;
+  const float* bias = P.bias + (size_t)l * H;
+  for (int grp = wave; grp < H / 8; grp += 4) {
+    const int row = tape_feature(grp, half, 0);
+    const float4 d = nt_load(dt4 + grp * 64 + lane), t = nt_load(tp4 + grp * 64 + lane);
+    const float4 b = *reinterpret_cast<const float4*>(bias + row);
+    *reinterpret_cast<float4*>(dp + row) = d;
+    *reinterpret_cast<float4*>(df + row) = make_float4(15.f * (d.x * (t.x + b.x)), 15.f * (d.y * (t.y + b.y)), 15.f * (d.z * (t.z + b.z)), 15.f * (d.w * (t.w + b.w)));
+  }
+}
+
+// film_per_point: FiLM-layer bias gradients = the chunk partials of the scaled d(theta) row sums, summed in a fixed order
+__global__ __launch_bounds__(256) void pointwise_bias_reduce_kernel(FenerfSirenGrads g, const float* part, int B, int L, int H, int n_geo, int nchunk0, int nchunk, int stride) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * H; i += gridDim.x * blockDim.x) {
+    const int l = i / H, n = i % H;
+    const int nk = l == 0 ? nchunk0 : nchunk;
+    float db = 0.f;
+    for (int b = 0; b < B; ++b) db += sum_chunks<4>(part + (((size_t)l * B + b) * stride) * H + n, (size_t)H, nk);
+    float* dst = l < n_geo ? g.geo_b[l] : g.color_b[l - n_geo];
+    if (dst) dst[n] = db;
+  }
+}
+
 namespace {
 int hipfail(hipError_t e, const char* what) {
   set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -1087,6 +1153,8 @@ size_t wgrad_workspace_bytes(const FenerfModel* m, int B, long long P) {
   size_t f = sq;
   f += (size_t)m->L * B * ncm * H * 2;                      // FiLM sums
   f += (size_t)2 * B * ncm * 32;                            // head / rgb row sums
+  const int ncb = nc > nt ? nc : nt;
+  f += (size_t)m->L * B * ncb * H;                          // per-point modulation: bias-gradient partials (fenerf_siren_param_grads_pointwise)
   return f * sizeof(float) + 1024;
 }
 
@@ -1103,7 +1171,15 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   float* film = sq + sq_floats;
   float* rows = film + (size_t)L * B * ncm * H * 2;
   p.film_partial = film; p.rowsum_partial = rows; p.film_stride = nf;
+  p.bias_partial = rows + (size_t)2 * B * ncm * 32; p.bias_stride = nc > nt ? nc : nt;
   int rc;
+  if (p.film_per_point) {   // the per-point FiLM gradients are the dump itself, re-laid; the bias gradients come from the jobs below
+    PhaseScope ph(PH_WGRAD_FILM, st);
+    hipLaunchKernelGGL(pointwise_film_grads_kernel, dim3((unsigned)((long long)B * p.tiles_per_image), L), dim3(256), 0, st, p, g.d_freq_geo, g.d_phase_geo,
+                       g.d_freq_app, g.d_phase_app);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "per-point film gradients launch");
+  } else
   {  // FiLM frequency / phase gradients and the FiLM-layer biases: gather the chain kernel's per-tile sums, reduce
     PhaseScope ph(PH_WGRAD_FILM, st);
     WgradParams pf = p;
@@ -1126,7 +1202,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
     if (p.freq_from_sums) hipLaunchKernelGGL(wgrad_reduce_sq_kernel<true>, dim3(H, L - 1), dim3(256), 0, st, g, *weights, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
-    else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3(H, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G);
+    else hipLaunchKernelGGL(wgrad_reduce_sq_kernel<false>, dim3(H, L - 1), dim3(256), 0, st, g, g, sq, B, nc, p.fp, p.inv, p.bias, L, H, ng, G, p.film_per_point);
   }
   // the thin jobs reuse the square partial buffer (stream-ordered after the reduction above), with their own chunking and side by
   // side: [H x 32 | H x 64 | 32 x H | 32 x H] per (image, chunk) -- so that ONE launch reduces all of them
@@ -1158,9 +1234,10 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   auto mat = [&](float* dst, int dst_ld, int dst_col0, const float* src, int src_rows, int src_ld, int src_col0, int rws, int cols, int layer, int film) {
     J.m[nm++] = ReduceMat{dst, src, dst_ld, dst_col0, src_rows, src_ld, src_col0, rws, cols, layer, film};
   };
-  mat(g.geo_w[0], 3, 0, p_l0, H, 32, 0, H, 3, 0, 1);
-  mat(g.color_w[0], 3 + G + H, 0, p_c0, H, 64, 32, H, 3, ng, 1);          // view direction columns
-  if (G) mat(g.color_w[0], 3 + G + H, 3, p_c0, H, 64, 0, H, G, ng, 1);    // grid feature columns
+  const int fsc = p.film_per_point ? 0 : 1;    // diag(f) of the image in the reduction -- not with per-point frequencies (already in the partials)
+  mat(g.geo_w[0], 3, 0, p_l0, H, 32, 0, H, 3, 0, fsc);
+  mat(g.color_w[0], 3 + G + H, 0, p_c0, H, 64, 32, H, 3, ng, fsc);          // view direction columns
+  if (G) mat(g.color_w[0], 3 + G + H, 3, p_c0, H, 64, 0, H, G, ng, fsc);    // grid feature columns
   mat(g.head_w, H, 0, p_hd, 32, H, 0, 32, H, 0, 0);
   mat(g.rgb_w, H, 0, p_rgb, 32, H, 0, 3, H, 0, 0);
   J.n_mat = nm;
@@ -1170,6 +1247,8 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
   hipLaunchKernelGGL(wgrad_reduce_thin_kernel, dim3((32 * H + 255) / 256, nm + 2), dim3(256), 0, st, J, B, nt, p.fp, p.inv, L, H);
   if (p.freq_from_sums)      // the frequency gradients' thin-job share (reads the same partials; the square job reuses the buffer only in the next call)
     hipLaunchKernelGGL(film_freq_thin_kernel, dim3(H, B), dim3(64), 0, st, g, *weights, p_l0, p_c0, nt, p.bias, H, ng, L - ng, G);
+  if (p.film_per_point)
+    hipLaunchKernelGGL(pointwise_bias_reduce_kernel, dim3((L * H + 255) / 256), dim3(256), 0, st, g, p.bias_partial, B, L, H, ng, nt, nc, p.bias_stride);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hipfail(e, "wgrad reduce launch");
 }
@@ -1177,7 +1256,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
 int launch_param_grads(const FenerfModel* m, int B, long long P, const float* points, const float* dirs, const float* fp, const float* pp,
                        const float* out, const float* d_out, const float* tape, const float* tape_e, const float* d_t,
                        const FenerfSirenGrads& g, bool film_only, void* workspace, void* stream, const float* film_tiles, int tape_format,
-                       const FenerfSirenGrads* weights) {
+                       const FenerfSirenGrads* weights, int film_per_point) {
   WgradParams p;
   memset(&p, 0, sizeof(p));
   p.tape = tape; p.d_t = d_t; p.film_tiles = film_tiles ? film_tiles : d_t + (size_t)m->L * m->H * (size_t)B * (size_t)P; p.tape_e = tape_e; p.points = points; p.dirs = dirs; p.out = out; p.d_out = d_out;
@@ -1190,6 +1269,11 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
   p.bf16_dump = use_bf16_dump(m, (long long)B * P);
   p.tape_u16 = tape_format == FENERF_TAPE_U16;
   p.freq_from_sums = tape_format != FENERF_TAPE_F32;
+  p.film_per_point = film_per_point;
+  if (film_per_point && (m->precision != FENERF_PREC_F32 || film_only)) {
+    set_error("per-point FiLM parameters: FENERF_PREC_F32 models, full backward only");
+    return FENERF_E_UNSUPPORTED;
+  }
   if (p.freq_from_sums && (film_only || !weights || m->precision != FENERF_PREC_F16X3)) {
     set_error("FENERF_TAPE_U16 / _F32_W: needs a FENERF_PREC_F16X3 model, a full (not FiLM-only) backward and the FiLM layers' weights");
     return FENERF_E_INVALID;

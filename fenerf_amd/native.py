@@ -371,6 +371,65 @@ class NativeModel:
                                                                          sl(pa), _ptr(out[b, s:s + n]), C.c_void_p(ws.data_ptr()), _stream()))
         return out
 
+    # ---- per-point modulation under autograd (include/fenerf.h fenerf_siren_*_pointwise; SPATIALSIRENGRID, siren.py:464-477)
+    def _film_pointwise(self, B, P, fg, pg, fa, pa):
+        H, ng, nc = self.spec["hidden_dim"], self.spec["n_geo"], self.spec["n_color"]
+        fg, pg, fa, pa = (_f32(t, self.device) for t in (fg, pg, fa, pa))
+        for t, n in ((fg, ng), (pg, ng), (fa, nc), (pa, nc)):
+            if tuple(t.shape) != (B, P, n * H):
+                raise ValueError(f"per-point film parameter of shape {tuple(t.shape)}, expected {(B, P, n * H)}")
+        return fg, pg, fa, pa
+
+    def siren_forward_save_pointwise(self, points, ray_dirs, fg, pg, fa, pa):
+        """Differentiable evaluation with one FiLM block per point: fg / pg [B,P,n_geo*H], fa / pa [B,P,n_color*H] -> (out [B,P,C], tape).
+        The model must be precision 'f32', differentiable, without a feature grid; P a multiple of 32."""
+        B, P = points.shape[0], points.shape[1]
+        fg, pg, fa, pa = self._film_pointwise(B, P, fg, pg, fa, pa)
+        points = _f32(points, self.device)
+        ray_dirs = _f32(ray_dirs, self.device) if ray_dirs is not None else None
+        out = torch.empty((B, P, self.C), dtype=torch.float32, device=self.device)
+        tape = torch.empty((self.tape_floats(B * P),), dtype=torch.float32, device=self.device)
+        l = _lib.lib()
+        with torch.cuda.device(self.device):
+            ws = self._workspace("film_pw", l.fenerf_film_workspace_bytes_pointwise(self._h, B, P))
+            _lib.check(l.fenerf_siren_forward_save_pointwise(self._h, B, P, _ptr(points), _ptr(ray_dirs), _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa),
+                                                             _ptr(out), _ptr(tape), C.c_void_p(ws.data_ptr()), _stream()))
+        return out, tape
+
+    def siren_backward_pointwise(self, points, ray_dirs, fg, pg, fa, pa, out, d_out, tape):
+        """chain + weight gradients of the per-point-modulated SIREN -> dict like siren_param_grads, with d_freq_geo / d_phase_geo
+        [B,P,n_geo*H] and d_freq_app / d_phase_app [B,P,n_color*H] (gradients wrt the RAW per-point parameters)."""
+        sp = self.spec
+        H, ng, nc = sp["hidden_dim"], sp["n_geo"], sp["n_color"]
+        B, P = points.shape[0], points.shape[1]
+        dev = self.device
+        fg, pg, fa, pa = self._film_pointwise(B, P, fg, pg, fa, pa)
+        out, d_out = _f32(out, dev), _f32(d_out, dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        res = dict(d_freq_geo=new(B, P, ng * H), d_phase_geo=new(B, P, ng * H), d_freq_app=new(B, P, nc * H), d_phase_app=new(B, P, nc * H),
+                   geo_w=[new(H, 3)] + [new(H, H) for _ in range(ng - 1)], geo_b=[new(H) for _ in range(ng)],
+                   color_w=[new(H, 3 + H)] + [new(H, H) for _ in range(nc - 1)], color_b=[new(H) for _ in range(nc)],
+                   head_w=new(32, H), head_b=new(32), rgb_w=new(3, H), rgb_b=new(3))
+        g = _lib.FenerfSirenGrads()
+        for i in range(ng):
+            g.geo_w[i], g.geo_b[i] = res["geo_w"][i].data_ptr(), res["geo_b"][i].data_ptr()
+        for i in range(nc):
+            g.color_w[i], g.color_b[i] = res["color_w"][i].data_ptr(), res["color_b"][i].data_ptr()
+        for k in res:
+            if not isinstance(res[k], list):
+                setattr(g, k, res[k].data_ptr())
+        l = _lib.lib()
+        d_t = torch.empty((int(l.fenerf_siren_dtheta_floats(self._h, B * P)),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            fws = self._workspace("film_pw", l.fenerf_film_workspace_bytes_pointwise(self._h, B, P))
+            ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
+            _lib.check(l.fenerf_siren_backward_pointwise(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape),
+                                                         _ptr(d_t), C.c_void_p(fws.data_ptr()), _stream()))
+            _lib.check(l.fenerf_siren_param_grads_pointwise(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
+                                                            _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), _ptr(d_t),
+                                                            C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
+        return res
+
     def tape_floats(self, total_points, tape_format=0):
         """fp32 words of a tape for total_points points (L*H values per point + the slack the kernel's last workgroup may write; the
         16-bit tape, _lib.TAPE_U16, packs two values per word)"""

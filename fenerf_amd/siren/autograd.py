@@ -381,6 +381,52 @@ class SirenFunction(torch.autograd.Function):
         return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, d_grid, need[7:])
 
 
+class PointwiseSirenFunction(torch.autograd.Function):
+    """out = siren(points, dirs; per-point film params [B,P,n*H], weights): SPATIALSIRENGRID.forward_with_frequencies_phase_shifts
+    (siren.py:464-477) under autograd on the native kernels (round 6; include/fenerf.h fenerf_siren_*_pointwise).  Gradients wrt the
+    per-point frequencies / phase shifts (for the per-point mapping network's own backward) and every SIREN weight and bias."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, module, points, dirs, fg, pg, fa, pa, *params):
+        nat = module.native_pointwise_differentiable(points.device)
+        out, tape = nat.siren_forward_save_pointwise(points, dirs, fg, pg, fa, pa)
+        ctx.module, ctx.nat = module, nat
+        ctx.pack_generation = nat.pack_generation
+        ctx.has_dirs = dirs is not None
+        ctx.save_for_backward(points, dirs if dirs is not None else points.new_empty(0), fg, pg, fa, pa, out, tape, *params)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, d_out):
+        module, nat = ctx.module, ctx.nat
+        check_same_weights(ctx, nat)
+        points, dirs, fg, pg, fa, pa, out, tape, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        r = nat.siren_backward_pointwise(points, dirs if ctx.has_dirs else None, fg, pg, fa, pa, out, d_out.contiguous().float(), tape)
+        film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
+                      r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
+        return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, None, need[7:])
+
+
+def siren_apply_pointwise(module, points, dirs, fg, pg, fa, pa):
+    """Differentiable SIREN evaluation with per-point FiLM tensors [B,P,n*H]; pads to whole 32-point tiles like siren_apply."""
+    if points.requires_grad or (dirs is not None and dirs.requires_grad):
+        raise NotImplementedError("fenerf_amd: gradients wrt sample positions / view directions are not provided "
+                                  "(the reference's training and inversion loops do not use them)")
+    params = module._render_params()
+    P = points.shape[1]
+    pad = (-P) % 32
+    if pad:
+        rep = lambda t: torch.cat([t, t[:, -1:].expand(-1, pad, -1)], 1)
+        points, fg, pg, fa, pa = rep(points), rep(fg), rep(pg), rep(fa), rep(pa)
+        dirs = rep(dirs) if dirs is not None else None
+    out = PointwiseSirenFunction.apply(module, points.contiguous(), dirs.contiguous() if dirs is not None else None, fg.contiguous(), pg.contiguous(),
+                                       fa.contiguous(), pa.contiguous(), *params)
+    return out[:, :P] if pad else out
+
+
 def siren_apply(module, points, dirs, fg, pg, fa, pa):
     """Differentiable SIREN evaluation.  The native path works on whole 32-point tiles per image: other point counts are
     padded here (with the last point; the pads get no gradient because their outputs are sliced away)."""

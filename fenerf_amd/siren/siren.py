@@ -378,11 +378,17 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
     fenerf_siren_forward_pointwise on the caller's tensors.  Both are exact-fp32 kernels whatever `precision` says -- fp32-class
     results is what "f16x3" promises too.
     Under autograd (an input, latent or parameter requires grad in grad mode) the module is what the reference's is: an ordinary
-    differentiable nn.Module.  The per-point-modulated SIREN then runs as PyTorch-ROCm ops on the device (`_film_siren_torch`) so that
-    torch autograd reaches the SIREN weights, the per-point mapping network, the latent grid and, through StyleGenerator2D, z.  It is
-    NOT routed through the native chain / weight-gradient kernels: those factor a layer's weight gradient as
-    sum_images diag(f_image) sum_points d(theta) x^T, which holds only when the frequencies are per image.  The variant is in no
-    curriculum and the reference never trains it; pinned to the reference module's own autograd (tiny_spatial_grid.npz)."""
+    differentiable nn.Module.  Since round 6 the per-point-modulated SIREN itself is native there too (`siren.autograd.
+    PointwiseSirenFunction` over fenerf_siren_forward_save_pointwise / _backward_pointwise / _param_grads_pointwise: exact-fp32 forward
+    with tape, chain kernel reading every lane's own FiLM block, weight-gradient jobs that scale d(theta) by the POINT's frequency while
+    staging it -- the per-image path's sum_images diag(f_image) sum_points d(theta) x^T does not exist with per-point frequencies -- and
+    the gradients wrt the per-point frequencies / phase shifts as [B, P, 9H] tensors).  The per-point mapping network (two nn.Linear on
+    [B*P, 32] / [B*P, 256]: plain rocBLAS GEMMs), the bilinear latent sampling and StyleGenerator2D stay PyTorch-ROCm autograd, through which
+    the gradient reaches the latent grid and z.  `NATIVE_POINTWISE_BACKWARD = False` (or sample positions / view directions that require
+    grad) takes the rounds-3-5 route: the SIREN as PyTorch-ROCm ops (`_film_siren_torch`), kept as the A/B reference of the tests.  The
+    variant is in no curriculum and the reference never trains it; pinned to the reference module's own autograd
+    (tiny_spatial_grid.npz)."""
+    NATIVE_POINTWISE_BACKWARD = True
 
     def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
         super().__init__(input_dim=input_dim, z_dim=z_dim, hidden_dim=hidden_dim, output_dim=output_dim, device=device)
@@ -402,8 +408,31 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
             input = self.get_local_coordinates(global_coords=input, local_grid_length=32, preserve_y=False)
         if self._wants_grad(input, ray_directions, sampled_latent, *self.mapping_network.parameters()):
             frequencies, phase_shifts = self.mapping_network(sampled_latent)
-            return self._film_siren_torch(input, frequencies, phase_shifts, ray_directions)
+            return self._film_siren_grad(input, frequencies, phase_shifts, ray_directions)
         return self.native_local(input.device).forward(input, ray_directions, sampled_latent)
+
+    def _film_siren_grad(self, input, frequencies, phase_shifts, ray_directions):
+        """the per-point-modulated SIREN under autograd: native (PointwiseSirenFunction) unless switched off or a gradient wrt the sample
+        positions / view directions is wanted (not provided natively, as everywhere in this package)"""
+        wants_xyz = input.requires_grad or (ray_directions is not None and ray_directions.requires_grad)
+        if not self.NATIVE_POINTWISE_BACKWARD or wants_xyz or frequencies.dim() != 3 or input.device.type != "cuda":
+            return self._film_siren_torch(input, frequencies, phase_shifts, ray_directions)
+        fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
+        return _autograd.siren_apply_pointwise(self, input, ray_directions, fg, pg, fa, pa)
+
+    def native_pointwise_differentiable(self, device=None):
+        """The exact-fp32 FenerfModel with the backward stream resident (fenerf_siren_*_pointwise), re-packed lazily on the device."""
+        params = self._render_params()
+        device = torch.device(device if device is not None else params[0].device)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        nat = self.__dict__.get("_native_pw_diff")
+        if nat is None or nat.device != device:
+            nat = native.NativeModel(self._state_numpy(), self._spec(), device, "f32", differentiable=True)
+            self.__dict__["_native_pw_diff"] = nat
+        elif self.__dict__.get("_native_pw_diff_version") != ver:
+            nat.load_from_device(dict(self._named_render_params()), maybe_unchanged=self.__dict__.get("_native_pw_diff_packed") == ver)
+        self.__dict__["_native_pw_diff_version"] = self.__dict__["_native_pw_diff_packed"] = ver
+        return nat
 
     def _film_siren_torch(self, input, frequencies, phase_shifts, ray_directions):
         """siren.py:464-477 as differentiable PyTorch-ROCm ops (per-point [B, P, 9H] or per-image [B, 9H] FiLM blocks): the autograd
@@ -455,10 +484,12 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
         super().invalidate_native()
         self.__dict__.pop("_native_local_version", None)
         self.__dict__.pop("_native_pw_version", None)
+        self.__dict__.pop("_native_pw_diff_version", None)
 
     def __getstate__(self):
         st = super().__getstate__()
-        for k in ("_native_local", "_native_local_version", "_native_pw", "_native_pw_version"):
+        for k in ("_native_local", "_native_local_version", "_native_pw", "_native_pw_version", "_native_pw_diff", "_native_pw_diff_version",
+                  "_native_pw_diff_packed"):
             st.pop(k, None)
         return st
 
@@ -467,7 +498,7 @@ class SPATIALSIRENGRID(SPATIALSIRENBASELINE):
         if frequencies.dim() == 2:
             return super().forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions, **kwargs)
         if self._wants_grad(input, ray_directions, frequencies, phase_shifts):
-            return self._film_siren_torch(input, frequencies, phase_shifts, ray_directions)
+            return self._film_siren_grad(input, frequencies, phase_shifts, ray_directions)
         fg, pg, fa, pa = self.split_film(frequencies, phase_shifts)
         return self.native(input.device).siren_forward_pointwise(input, ray_directions, fg, pg, fa, pa)
 

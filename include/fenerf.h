@@ -435,6 +435,27 @@ int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t P, const f
                                  void* film_ws, void* stream);
 int fenerf_siren_backward_stream_bytes_fmt(const FenerfModel* m, int64_t chunk_points, int tape_format, double* out4);
 
+/* Per-point modulation under autograd (round 6) -- replaces: what torch autograd derives for
+ * SPATIALSIRENGRID.forward_with_frequencies_phase_shifts (siren.py:464-477) when frequencies / phase_shifts hold one FiLM block PER SAMPLE
+ * POINT (per-point mapping network, :440-462; FiLMLayer takes them unbroadcast, :119-122): d(out) -> gradients of every SIREN weight and bias
+ * and of the per-point frequencies / phase shifts themselves (which the caller's mapping network backpropagates).
+ * Like fenerf_siren_forward_save / fenerf_siren_backward / fenerf_siren_param_grads with freq_geo / phase_geo [B, P, n_geo*H] and freq_app /
+ * phase_app [B, P, n_color*H] (raw mapping outputs, '*15+30' inside) and g->d_freq_geo / d_phase_geo [B, P, n_geo*H], g->d_freq_app /
+ * d_phase_app [B, P, n_color*H] as outputs; every weight / bias buffer of `g` is required.  FENERF_PREC_F32 models created with
+ * differentiable != 0, without a feature grid; P a multiple of 32.  tape: fenerf_siren_tape_floats(m, B*P) floats, d_t:
+ * fenerf_siren_dtheta_floats(m, B*P) floats, film_ws: fenerf_film_workspace_bytes_pointwise(m, B, P) bytes, workspace:
+ * fenerf_siren_grad_workspace_bytes(m, B, P) bytes, all [dev].  Gradients wrt sample positions / view directions are not provided. */
+int fenerf_siren_forward_save_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                        const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                                        float* out, float* tape, void* film_ws, void* stream);
+int fenerf_siren_backward_pointwise(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
+                                    const float* freq_app, const float* phase_app, const float* out, const float* d_out,
+                                    const float* tape, float* d_t, void* film_ws, void* stream);
+int fenerf_siren_param_grads_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
+                                       const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
+                                       const float* out, const float* d_out, const float* tape, const float* d_t,
+                                       const FenerfSirenGrads* g, void* workspace, void* film_ws, void* stream);
+
 /* The differentiable hierarchical render as TWO calls (round 5) -- replaces: DoubleImplicitGenerator3d.forward / forward_with_frequencies
  * under autograd (generators.py:468-527, :735-797) and the part of g_loss.backward() (train_double_latent_semantic.py:402-446) /
  * loss.backward() (inverse_render_double_semantic.py:397) that runs through them.

@@ -38,3 +38,7 @@ for k in ("gstep_tape16", "gstep_amp", "gstep_amp16"):
 PY
   done
 fi
+if [ "$which" = "pw" ]; then
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -q -s -x -k "pointwise_siren_backward or spatial_siren_grid" > gpurun_out/r6_pw_tests.log 2>&1
+  echo "pointwise tests rc=$?"; grep "parity\]" gpurun_out/r6_pw_tests.log | cut -c1-400; tail -30 gpurun_out/r6_pw_tests.log | cut -c1-300
+fi
