@@ -141,8 +141,8 @@ _SIGS = {
     "fenerf_siren_backward_fmt": (_i, [_vp, _i, _i64] + [_vp] * 7 + [_i] + [_vp] * 4),
     "fenerf_siren_backward_grid_fmt": (_i, [_vp, _i, _i64] + [_vp] * 7 + [_i] + [_vp] * 6),
     "fenerf_siren_forward_save_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 10),
-    "fenerf_siren_backward_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 10),
-    "fenerf_siren_param_grads_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 10 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
+    "fenerf_siren_backward_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 9 + [_i, _vp]),
+    "fenerf_siren_param_grads_pointwise": (_i, [_vp, _i, _i64] + [_vp] * 10 + [C.POINTER(FenerfSirenGrads)] + [_vp] * 2 + [_i, _vp]),
     "fenerf_siren_param_grads_fmt": (_i, [_vp, _i, _i64] + [_vp] * 9 + [_i, _vp, _vp, C.POINTER(FenerfSirenGrads), C.POINTER(FenerfSirenGrads)] + [_vp] * 3),
     "fenerf_siren_backward_stream_bytes_fmt": (_i, [_vp, _i64, _i, C.POINTER(C.c_double)]),
     # round 5: the differentiable hierarchical render as two calls (SURVEY 8b fenerf_render_backward)

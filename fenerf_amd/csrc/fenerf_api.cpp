@@ -983,7 +983,7 @@ extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t
 // wrt the per-point frequencies / phase shifts leave as [B, P, n*H] tensors for the mapping network's own backward.
 // ---------------------------------------------------------------------------------------------------------------------------------
 static int pointwise_prep(const FenerfModel* m, int B, int64_t P, const float* fg, const float* pg, const float* fa, const float* pa, void* film_ws,
-                          const float** fp, const float** pp, void* stream) {
+                          const float** fp, const float** pp, void* stream, int prepared = 0) {
   if (m->precision != FENERF_PREC_F32) return fail(FENERF_E_UNSUPPORTED, "differentiable per-point FiLM parameters: FENERF_PREC_F32 models only");
   if (!m->differentiable || !m->d_bwd_stream) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
   if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
@@ -992,7 +992,7 @@ static int pointwise_prep(const FenerfModel* m, int B, int64_t P, const float* f
   float* f = (float*)film_ws;
   float* q = f + (size_t)B * (size_t)P * m->L * m->H;
   *fp = f; *pp = q;
-  if (P == 0) return FENERF_OK;
+  if (P == 0 || prepared) return FENERF_OK;     // prepared: film_ws still holds the blocks an earlier call of this family wrote for the same arguments
   PhaseScope ph(PH_FILM_PREP, stream);
   return launch_film_prep(m, (long long)B * P, fg, pg, fa, pa, f, q, stream, true);
 }
@@ -1018,11 +1018,11 @@ extern "C" int fenerf_siren_forward_save_pointwise(const FenerfModel* m, int B, 
 
 extern "C" int fenerf_siren_backward_pointwise(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
                                                const float* freq_app, const float* phase_app, const float* out, const float* d_out,
-                                               const float* tape, float* d_t, void* film_ws, void* stream) {
+                                               const float* tape, float* d_t, void* film_ws, int film_ws_prepared, void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters: models without a feature grid");
   const float *fp, *pp;
-  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream, film_ws_prepared);
   if (rc || P == 0) return rc;
   if (!out || !d_out || !tape || !d_t) return fail(FENERF_E_INVALID, "NULL pointer");
   SirenBwdParams bp;
@@ -1042,11 +1042,12 @@ extern "C" int fenerf_siren_backward_pointwise(const FenerfModel* m, int B, int6
 extern "C" int fenerf_siren_param_grads_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                                                   const float* freq_geo, const float* phase_geo, const float* freq_app,
                                                   const float* phase_app, const float* out, const float* d_out, const float* tape,
-                                                  const float* d_t, const FenerfSirenGrads* g, void* workspace, void* film_ws, void* stream) {
+                                                  const float* d_t, const FenerfSirenGrads* g, void* workspace, void* film_ws, int film_ws_prepared,
+                                                  void* stream) {
   if (!m) return fail(FENERF_E_INVALID, "model is NULL");
   if (m->grid_ch) return fail(FENERF_E_UNSUPPORTED, "per-point FiLM parameters: models without a feature grid");
   const float *fp, *pp;
-  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  int rc = pointwise_prep(m, B, P, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream, film_ws_prepared);
   if (rc || P == 0) return rc;
   if (!points || !out || !d_out || !tape || !d_t || !g || !workspace) return fail(FENERF_E_INVALID, "NULL pointer");
   if (!g->d_freq_geo || !g->d_phase_geo || !g->d_freq_app || !g->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");

@@ -49,6 +49,9 @@
 #include "fenerf_layout.h"
 #include "fenerf_trig.h"
 
+#ifndef FENERF_WAVE_HALF_COPIES
+#define FENERF_WAVE_HALF_COPIES 1     // 0: the wave half as a run-time flag inside the stream loop (rounds 3-5); A/B builds only
+#endif
 #ifndef FENERF_BW16_T16
 #define FENERF_BW16_T16 0      // tape mode of this translation unit: 0 = FENERF_TAPE_F32, 1 = FENERF_TAPE_U16, 2 = FENERF_TAPE_F32_W
 #endif
@@ -651,9 +654,14 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
 
     // One stage: NBODY bodies of QBS chunks; bop(sp, bh, bl) supplies the B operand of k32-step sp (false = padding).  With
     // EPI the bodies carry the epilogue of FiLM layer `lo` (tape layer lo, d theta / FiLM sums of layer lo) into y.
-    auto run_stage = [&](auto nbody_c, auto qbs_c, auto epi_c, int lo, auto bop, u32x4 (&yh)[KS], u32x4 (&yl)[KS], f32x4 (&acc_last)[2]) {
+    // ph_c (round 6): one compile-time copy of a stage per wave half -- PH = 0: waves 0-3 (ring DMA at the top of a chunk step), 1: waves
+    // 4-7 (half a step later) -- instead of testing the run-time flag ws.early twice per k32-step (two scalar branches, one taken, in front
+    // of every MFMA burst); the branch now sits between stages.  (fenerf_siren_f16w.hip: the same change, - 6 % shader cycles there.)
+    auto run_stage = [&](auto ph_c, auto nbody_c, auto qbs_c, auto epi_c, int lo, auto bop, u32x4 (&yh)[KS], u32x4 (&yl)[KS], f32x4 (&acc_last)[2]) {
       constexpr int NBODY = decltype(nbody_c)::value, QBS = decltype(qbs_c)::value;
       constexpr bool EPI = decltype(epi_c)::value;
+      constexpr int PH = decltype(ph_c)::value;             // -1 (FENERF_WAVE_HALF_COPIES = 0, A/B builds): the run-time flag, as in rounds 3-5
+      const bool early = PH < 0 ? ws.early : PH == 0;
       const Sink k = make_sink(lo);
       f32x4 acc_prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       EpiOut eo[2];
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
             __builtin_amdgcn_s_barrier();
           }
           LDS_FENCE();
-          if (ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+          if (early) ws_issue(ws, (ws.cs + DPF) & 7);
           // operands of the items of this chunk: FiLM parameters and tape from LDS, read before the A operands (LDS returns in order)
           EpiIn q[2];
           if constexpr (EPI && nb > 0) {
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           }
 #pragma unroll
           for (int spl = 0; spl < 2; ++spl) {
-            if (spl == 1 && !ws.early) ws_issue(ws, (ws.cs + DPF) & 7);
+            if (spl == 1 && !early) ws_issue(ws, (ws.cs + DPF) & 7);
             const AK nn = spl == 0 ? ws_read(ws, ws.cs, 1) : ws_read(ws, (ws.cs + 1) & 7, 0);
             __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
             bf16x8 bh, bl;
@@ -781,8 +789,7 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
     };
 
     // ---------------- FiLM layers L-2 .. 0: colour layers, colour layer 0 (+ heads, + grid-feature gradient), trunk ----------------
-#pragma unroll 1
-    for (int lo = L - 2; lo >= 0; --lo) {
+    auto film_layer = [&](auto ph_c, int lo) {
       u32x4 yh[KS], yl[KS];
       f32x4 unused[2];
       if (lo >= 1) film_issue(lo - 1);
@@ -798,11 +805,11 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           if (sp == KS) { bh = as_bf16x8(ext[0]); bl = as_bf16x8(ext[64]); return true; }
           return false;
         };
-        run_stage(std::integral_constant<int, NB>{}, std::integral_constant<int, C0_QB>{}, std::true_type{}, lo, bop0, yh, yl, unused);
+        run_stage(ph_c, std::integral_constant<int, NB>{}, std::integral_constant<int, C0_QB>{}, std::true_type{}, lo, bop0, yh, yl, unused);
         if (GRID) {
           // d(grid features) = W_c0[:, grid]^T dz_{n_geo}: one body on the stage's input, no epilogue
           f32x4 ge[2];
-          run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, QB>{}, std::false_type{}, lo, bop, yh, yl, ge);
+          run_stage(ph_c, std::integral_constant<int, 1>{}, std::integral_constant<int, QB>{}, std::false_type{}, lo, bop, yh, yl, ge);
           const int lq = opaque(lane);
           if (P.d_grid_cl) {
             // Fused scatter (grid_backward_kernel's arithmetic): the tile's [16 points][32 channels] block goes through the head-operand
@@ -828,11 +835,19 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
           }
         }
       } else {
-        run_stage(std::integral_constant<int, NB>{}, std::integral_constant<int, QB>{}, std::true_type{}, lo, bop, yh, yl, unused);
+        run_stage(ph_c, std::integral_constant<int, NB>{}, std::integral_constant<int, QB>{}, std::true_type{}, lo, bop, yh, yl, unused);
       }
 #pragma unroll
       for (int s = 0; s < KS; ++s) { zh[s] = yh[s]; zl[s] = yl[s]; }
       if (NB & 1) tpar ^= 1;
+    };
+#pragma unroll 1
+    for (int lo = L - 2; lo >= 0; --lo) {
+#if FENERF_WAVE_HALF_COPIES
+      if (ws.early) film_layer(std::integral_constant<int, 0>{}, lo); else film_layer(std::integral_constant<int, 1>{}, lo);
+#else
+      film_layer(std::integral_constant<int, -1>{}, lo);
+#endif
     }
     if (GRID) scatter_pairs(8);   // whatever no later stage picked up (a model without trunk layers behind colour layer 0)
     if (WGS) {   // the last two n-blocks' sums

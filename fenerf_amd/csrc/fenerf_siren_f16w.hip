@@ -132,6 +132,12 @@ __device__ __forceinline__ unsigned phase_u16(float theta) {
   return __builtin_bit_cast(unsigned, __builtin_fmaf(__builtin_amdgcn_fractf(theta), 65536.f, 8388608.f));
 }
 #define LDS_FENCE() asm volatile("" ::: "memory")
+#ifndef FENERF_WAVE_HALF_COPIES
+#define FENERF_WAVE_HALF_COPIES 1     // 0: rounds 2-5 (the wave half is a run-time flag inside the stream loop); A/B builds only
+#endif
+#ifndef FENERF_EXP_DEPHASE
+#define FENERF_EXP_DEPHASE 0          // 1: experiment, measured and dropped in round 6 (+ 8 % cycles): see chunk_step
+#endif
 
 struct WStream {
   bool skip;                   // f16x2: this wave's operand is a weight lo half -- never fetched (g_next still advances)
@@ -280,13 +286,21 @@ struct APipe { AK c, n; };
 struct FilmQ2 { FilmQ q[4]; };
 // LOR: the ring reads include the weight lo halves (false only when no stage of the kernel multiplies them: the reads run one chunk step
 // ahead, across stage boundaries); LOM: this stage multiplies them.
-template <bool LOR = true, bool LOM = true, class BOP, class LOADQ, class PIECE>
+// PH (round 6): -1 = the wave's DMA half is a run-time flag (ws.early) and the epilogue pieces sit behind k32-step 1 in every wave;
+// 0 / 1 = compile-time copy of the step for waves 0-3 / 4-7 (no branch per k32-step; the shipped build).  FENERF_EXP_DEPHASE == 1
+// (experiment, round 6): waves 4-7 take their epilogue pieces behind k32-step 0 -- the two waves of a SIMD (w, w + 4) run the same program
+// in phase, both with their VALU-heavy epilogue in the same half of a chunk step and bare MFMAs in the other, and the idea was that one
+// wave's epilogue VALU would issue under its partner's bare MFMA burst.  Measured: 2,640,000 instead of 2,444,000 cycles per launch
+// (+ 8 %): the pieces then consume FiLM values read from LDS in the same k32-step, and the partner's burst does not hide that round trip.
+template <bool LOR = true, bool LOM = true, int PH = -1, class BOP, class LOADQ, class PIECE>
 __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& ws, int i, int sp0, BOP bop, LOADQ loadq, PIECE piece) {
-  ws_step(ws, i, ws.early);
+  const bool early = PH < 0 ? ws.early : PH == 0;
+  constexpr int PSPL = (PH == 1 && FENERF_EXP_DEPHASE == 1) ? 0 : 1;     // the k32-step behind whose MFMAs the epilogue pieces are issued
+  ws_step(ws, i, early);
   FilmQ2 fq;
 #pragma unroll
   for (int spl = 0; spl < 2; ++spl) {
-    if (spl == 1) ws_issue_late(ws, i, ws.early);
+    if (spl == 1) ws_issue_late(ws, i, early);
     // FiLM parameters of the chunk's epilogue pieces: read at the top of k32-step 0 (BEFORE the A operands: LDS returns in
     // order, a read behind them could only be waited for together with them), used behind k32-step 1's MFMAs -- a read
     // issued in the k32-step that consumes it put one LDS round trip (~190 cycles of s_waitcnt per chunk step and wave,
@@ -296,17 +310,18 @@ __device__ __forceinline__ void chunk_step(f32x4 (&acc)[2], APipe& a, WStream& w
     __builtin_amdgcn_sched_barrier(0);   // the reads stay at the top of the k32-step
     half8 bh, bl;
     if (bop(sp0 + spl, bh, bl)) kstep_mfma<LOR && LOM>(acc, a.c, bh, bl);
-    if (spl == 1) piece(fq);
+    if (spl == PSPL) piece(fq);
     a.c = a.n;
     a.n = nn;
     __builtin_amdgcn_sched_barrier(0);   // keep every k32-step's MFMAs / epilogue pieces where they are written
   }
 }
 // Stage-padding chunk (no weights in it): keep the DMA / barrier cadence, fetch the next chunk's k32-steps.
-template <bool LO = true>
+template <bool LO = true, int PH = -1>
 __device__ __forceinline__ void chunk_skip(APipe& a, WStream& ws, int i) {
-  ws_step(ws, i, ws.early);
-  ws_issue_late(ws, i, ws.early);
+  const bool early = PH < 0 ? ws.early : PH == 0;
+  ws_step(ws, i, early);
+  ws_issue_late(ws, i, early);
   a.c = ws_read<LO>(ws, (i + 1) % NSLOT, 0);
   a.n = ws_read<LO>(ws, (i + 1) % NSLOT, 1);
   __builtin_amdgcn_sched_barrier(0);
@@ -605,8 +620,8 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       }
     }
     // ---------------- FiLM layers 1 .. L-1 ----------------
-#pragma unroll 1
-    for (int l = 1; l < L; ++l) {
+    auto film_layer = [&](auto ph_c, int l) {
+      constexpr int PH = decltype(ph_c)::value;
       const float* ff = film_lane(l);
       const TapeW<SAVE> tw = tape_of(l);
       half8 yh[KS], yl[KS];
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < C0_QB; ++qc) {
-            chunk_step<LOR, LOC>(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](FilmQ2& fq) {
+            chunk_step<LOR, LOC, PH>(acc, a_cur, ws, nb * C0_QB + qc, 2 * qc, bop0, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
                 piece_range<C0_QB>(qc, p0, p1);
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
         }
 #pragma unroll
-        for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
+        for (int i = NB * C0_QB; i < C0_CHUNKS; ++i) chunk_skip<LOR, PH>(a_cur, ws, i);
         epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
         // head on x (the trunk output), before x is overwritten with the colour-layer-0 activations
         {
@@ -660,9 +675,9 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           };
 #pragma unroll
           // (the label / sigma head keeps every term the kernel reads: with TERMS2 = 2 sigma and the labels are those of the default, bit for bit)
-          for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, true>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
+          for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, true, PH>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
-          for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
+          for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR, PH>(a_cur, ws, i);
           const int lane_o = opaque(lane);
           const int n_o = lane_o & 15, f_o = 16 * (lane_o >> 5) + 4 * ((lane_o >> 4) & 1);
 #pragma unroll
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int qc = 0; qc < QB; ++qc) {
-            chunk_step<LOR, LOM>(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](FilmQ2& fq) {
+            chunk_step<LOR, LOM, PH>(acc, a_cur, ws, nb * QB + qc, 2 * qc, bop, [&](FilmQ2& fq) {
               if (nb > 0) {
                 int p0, p1;
                 piece_range<QB>(qc, p0, p1);
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
           acc_prev[0] = acc[0]; acc_prev[1] = acc[1];
         }
 #pragma unroll
-        for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
+        for (int i = NB * QB; i < SQ_CHUNKS; ++i) chunk_skip<LOR, PH>(a_cur, ws, i);
         epi_all<KS, FILM_F / 4, SAVE>(acc_prev, NB - 1, ff, yh, yl, tw, tile_odd);
         };
         // TERMS2 = 2: three terms per product through the geometry trunk, two in the colour layers (one instantiation of the stage each; the
@@ -725,18 +740,31 @@ __global__ __launch_bounds__(512, 2) void siren16w_kernel(SirenParams P, int n_g
       }
 #pragma unroll
       for (int k = 0; k < KS; ++k) { xh[k] = yh[k]; xl[k] = yl[k]; }
+    };
+#pragma unroll 1
+    for (int l = 1; l < L; ++l) {
+      // One compile-time copy of the layer per wave half (round 6): the DMA position of a wave (top of a chunk step / half a step later)
+      // was a run-time flag tested in every k32-step -- two scalar branches per k32-step, one of them taken.  With the branch between
+      // layers instead: 2,599,000 -> 2,444,000 shader cycles per launch (- 6.0 %), of which the power manager keeps two thirds
+      // (1.95 -> 1.87 GHz): 5.75 -> 5.86 M rays/s on the same box (profiles/r06_forward_wave_half_copies.md).
+#if FENERF_WAVE_HALF_COPIES
+      if (ws.early) film_layer(std::integral_constant<int, 0>{}, l); else film_layer(std::integral_constant<int, 1>{}, l);
+#else
+      film_layer(std::integral_constant<int, -1>{}, l);
+#endif
     }
     // ---------------- rgb head + sigmoid (rows 0..2 = row tile 0, lane group 0) ----------------
     {
+      constexpr int PH = -1;
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       auto bop = [&](int sp, half8& bh, half8& bl) -> bool {
         if (sp < KS) { bh = xh[sp]; bl = xl[sp]; return true; }
         return false;
       };
 #pragma unroll
-      for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, LOC>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
+      for (int qc = 0; qc < QB; ++qc) chunk_step<LOR, LOC, PH>(acc, a_cur, ws, qc, 2 * qc, bop, [](FilmQ2&) {}, [](const FilmQ2&) {});
 #pragma unroll
-      for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR>(a_cur, ws, i);
+      for (int i = QB; i < HEAD_CHUNKS; ++i) chunk_skip<LOR, PH>(a_cur, ws, i);
       const int lane_o = opaque(lane);
       const int n_o = lane_o & 15;
       if ((lane_o >> 4) == 0) {

@@ -424,10 +424,10 @@ class NativeModel:
             fws = self._workspace("film_pw", l.fenerf_film_workspace_bytes_pointwise(self._h, B, P))
             ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
             _lib.check(l.fenerf_siren_backward_pointwise(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape),
-                                                         _ptr(d_t), C.c_void_p(fws.data_ptr()), _stream()))
+                                                         _ptr(d_t), C.c_void_p(fws.data_ptr()), 0, _stream()))
             _lib.check(l.fenerf_siren_param_grads_pointwise(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
                                                             _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), _ptr(d_t),
-                                                            C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
+                                                            C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), 1, _stream()))   # (prepared by the chain call above)
         return res
 
     def tape_floats(self, total_points, tape_format=0):

@@ -444,17 +444,19 @@ int fenerf_siren_backward_stream_bytes_fmt(const FenerfModel* m, int64_t chunk_p
  * d_phase_app [B, P, n_color*H] as outputs; every weight / bias buffer of `g` is required.  FENERF_PREC_F32 models created with
  * differentiable != 0, without a feature grid; P a multiple of 32.  tape: fenerf_siren_tape_floats(m, B*P) floats, d_t:
  * fenerf_siren_dtheta_floats(m, B*P) floats, film_ws: fenerf_film_workspace_bytes_pointwise(m, B, P) bytes, workspace:
- * fenerf_siren_grad_workspace_bytes(m, B, P) bytes, all [dev].  Gradients wrt sample positions / view directions are not provided. */
+ * fenerf_siren_grad_workspace_bytes(m, B, P) bytes, all [dev].  film_ws_prepared != 0: film_ws still holds what an earlier call of this
+ * family wrote for the same FiLM tensors (the 2 L H floats per point are not prepared again).  Gradients wrt sample positions / view
+ * directions are not provided. */
 int fenerf_siren_forward_save_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                                         const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
                                         float* out, float* tape, void* film_ws, void* stream);
 int fenerf_siren_backward_pointwise(const FenerfModel* m, int B, int64_t P, const float* freq_geo, const float* phase_geo,
                                     const float* freq_app, const float* phase_app, const float* out, const float* d_out,
-                                    const float* tape, float* d_t, void* film_ws, void* stream);
+                                    const float* tape, float* d_t, void* film_ws, int film_ws_prepared, void* stream);
 int fenerf_siren_param_grads_pointwise(const FenerfModel* m, int B, int64_t P, const float* points, const float* ray_dirs,
                                        const float* freq_geo, const float* phase_geo, const float* freq_app, const float* phase_app,
                                        const float* out, const float* d_out, const float* tape, const float* d_t,
-                                       const FenerfSirenGrads* g, void* workspace, void* film_ws, void* stream);
+                                       const FenerfSirenGrads* g, void* workspace, void* film_ws, int film_ws_prepared, void* stream);
 
 /* The differentiable hierarchical render as TWO calls (round 5) -- replaces: DoubleImplicitGenerator3d.forward / forward_with_frequencies
  * under autograd (generators.py:468-527, :735-797) and the part of g_loss.backward() (train_double_latent_semantic.py:402-446) /

@@ -42,3 +42,65 @@ if [ "$which" = "pw" ]; then
   timeout 1200 python -m pytest tests/test_gpu_parity.py -q -s -x -k "pointwise_siren_backward or spatial_siren_grid" > gpurun_out/r6_pw_tests.log 2>&1
   echo "pointwise tests rc=$?"; grep "parity\]" gpurun_out/r6_pw_tests.log | cut -c1-400; tail -30 gpurun_out/r6_pw_tests.log | cut -c1-300
 fi
+if [ "$which" = "evidence" ]; then   # the round's profiles: kernel stats of the default bench command, PMC passes, per-point backward timing
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 3) > gpurun_out/r6_bench_under_rocprofv3.log 2>&1
+  echo "prof exit: $?"
+  find gpurun_out/prof -name "*kernel_stats*" | head -1 | xargs -I{} cp {} gpurun_out/r6_bench_kernel_stats_default_command.csv
+  cp bench_detail.json gpurun_out/r6_bench_detail_under_rocprofv3.json
+  find gpurun_out/prof -type f -size +1M -delete
+  head -8 gpurun_out/r6_bench_kernel_stats_default_command.csv | cut -c1-220
+  bash tools/gpu_r3.sh pmc > gpurun_out/r6_pmc_forward.log 2>&1
+  cp gpurun_out/pmc/siren_pmc_summary.txt gpurun_out/r6_pmc_siren16w_f16x3.txt; rm -rf gpurun_out/pmc
+  GSTEP_ARGS="--B 1 --size 128 --grad-precision f32" bash tools/pmc_gstep_mfma.sh > /dev/null 2>&1
+  cp gpurun_out/pmc_gstep_mfma/summary.txt gpurun_out/r6_pmc_gstep_mfma_f32.txt; rm -rf gpurun_out/pmc_gstep_mfma
+  bash tools/pmc_gstep_waits.sh > /dev/null 2>&1
+  cp gpurun_out/pmc_gstep_waits/summary.txt gpurun_out/r6_pmc_gstep_waits.txt; rm -rf gpurun_out/pmc_gstep_waits
+  grep "bwd16w\|^kernel" gpurun_out/r6_pmc_gstep_waits.txt | head; grep "^#" gpurun_out/r6_pmc_gstep_mfma_f32.txt
+  for n in 65536 196608; do timeout 300 python tools/time_pointwise_backward.py $n 256 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r6_pointwise_backward_timing.txt
+  cat gpurun_out/r6_pointwise_backward_timing.txt
+fi
+if [ "$which" = "pmcfwd" ]; then   # HBM traffic + pipe counters of the headline forward kernel: separate --pmc passes over the (shortened) default command
+  rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
+  QQ="--no-cpu-baseline --no-gstep --no-f32 --no-sweep64 --no-gstep-ddp --no-gstep-b6"
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 3 --warmup 1 $QQ) > gpurun_out/pmc/p$i.log 2>&1
+    echo "pass $i ($set) exit $?"
+  done
+  find gpurun_out/pmc -type f -size +4M -delete
+  python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/r6_pmc_siren16w_f16x3.txt 2>&1
+  cat gpurun_out/r6_pmc_siren16w_f16x3.txt; tail -3 gpurun_out/pmc/p1.log
+  rm -rf gpurun_out/pmc
+fi
+if [ "$which" = "dephase" ]; then   # A/B of the forward kernel's wave de-phasing (libexp_dephase{1,2}.so) against the shipped library, interleaved
+  for rep in 1 2; do
+  for v in "" dephase2 dephase1; do
+    if [ -z "$v" ]; then lib=$PWD/fenerf_amd/libfenerf_hip.so; else lib=$PWD/fenerf_amd/libexp_$v.so; fi
+    [ -f $lib ] || continue
+    echo -n "${v:-shipped}: "
+    FENERF_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gstep --no-f32 --no-sweep64 --no-gstep-ddp --no-gstep-b6 > /dev/null 2>&1
+    python - <<PY
+import json
+d = json.load(open("bench_detail.json")); r = d["roofline"]
+print("rays/s %.0f ms/step %.4f kernel_ms %.4f cycles %.0f clock %.3f" % (d["value"], d["ms_per_step"], r["kernel_ms"], r.get("cycles_per_launch", 0), r.get("clock_ghz_effective", 0)))
+PY
+  done; done
+  FENERF_LIB=$PWD/fenerf_amd/libexp_dephase1.so timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "test_siren_forward_vs_reference or test_forward_with_frequencies_vs_reference or one_launch_render or test_full_size" 2>&1 | tail -3
+fi
+if [ "$which" = "halfab" ]; then   # same-box A/B of the wave-half copies: shipped vs chain with the run-time flag vs forward(-save) with the run-time flag
+  for rep in 1 2; do
+  for v in "" chain_runtime_flag forward_runtime_flag; do
+    if [ -z "$v" ]; then lib=$PWD/fenerf_amd/libfenerf_hip.so; else lib=$PWD/fenerf_amd/libexp_$v.so; fi
+    [ -f $lib ] || continue
+    echo -n "${v:-shipped}: "
+    FENERF_LIB=$lib timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32 --no-sweep64 --no-gstep-ddp --no-gstep-b6 > /dev/null 2>&1
+    python - <<PY
+import json
+d = json.load(open("bench_detail.json")); r = d["roofline"]; g = d["gstep"]
+print("rays/s %.0f kernel_ms %.4f cycles %.0f clock %.3f | gstep %.3f" % (d["value"], r["kernel_ms"], r.get("cycles_per_launch", 0), r.get("clock_ghz_effective", 0), g["ms"]),
+      {k["name"]: round(k["ms"], 3) for k in g["roofline"]["per_kernel"]}, "| tape16 %.3f amp16 %.3f" % (d["gstep_tape16"]["ms"], d["gstep_amp16"]["ms"]))
+PY
+  done; done
+fi
