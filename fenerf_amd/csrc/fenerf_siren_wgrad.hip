@@ -64,19 +64,19 @@ struct WgradParams {
 // compiler, and one read-wait-write per element serialised the staging on LDS latency (measured: 35 % of the kernel).
 // f_g / p_g (per-point modulation): this LANE's point's [H] rows of f' / p' in global memory instead of the image's rows in LDS;
 // with !SIN (the d theta side) f_g scales the row by 2 pi f' = the point's own frequency (WgradParams::film_per_point).
-template <int H, bool SIN>
+template <int H, bool SIN, bool PW = false>
 __device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst, int wave, int lane, const float* f_s, const float* p_s,
                                            const float* f_g = nullptr, const float* p_g = nullptr) {
   constexpr int NQ = H / 32;
   const float TWO_PI = 6.28318530717958647692f;
   const int m = lane & 31, half = lane >> 5;
   float4 f4[NQ], p4[NQ];
-  if (SIN || f_g) {
+  if (SIN || PW) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int row = tape_feature(wave * NQ + q, half, 0);
-      f4[q] = *reinterpret_cast<const float4*>((f_g ? f_g : f_s) + row);
-      if (SIN) p4[q] = *reinterpret_cast<const float4*>((p_g ? p_g : p_s) + row);
+      f4[q] = *reinterpret_cast<const float4*>((PW ? f_g : f_s) + row);
+      if (SIN) p4[q] = *reinterpret_cast<const float4*>((PW ? p_g : p_s) + row);
     }
   }
 #pragma unroll
@@ -86,7 +86,7 @@ __device__ __forceinline__ void stage_dump(const float4 (&v)[H / 32], float* dst
     if (SIN) {
       e[0] = sin2pi(__builtin_fmaf(f4[q].x, e[0], p4[q].x)); e[1] = sin2pi(__builtin_fmaf(f4[q].y, e[1], p4[q].y));
       e[2] = sin2pi(__builtin_fmaf(f4[q].z, e[2], p4[q].z)); e[3] = sin2pi(__builtin_fmaf(f4[q].w, e[3], p4[q].w));
-    } else if (f_g) {
+    } else if (PW) {
       e[0] *= f4[q].x * TWO_PI; e[1] *= f4[q].y * TWO_PI; e[2] *= f4[q].z * TWO_PI; e[3] *= f4[q].w * TWO_PI;
     }
 #pragma unroll
@@ -175,7 +175,7 @@ struct WgShape {
   static constexpr int A_ROWS = MT * 32, B_ROWS = KT * 32;
 };
 
-template <int H, int JOB>
+template <int H, int JOB, bool PW = false>     // PW: per-point FiLM parameters (WgradParams::film_per_point) -- its own instantiation: the per-image jobs keep their code
 __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int bz) {
   using S = WgShape<H, JOB>;
   constexpr int NQ = H / 32;                   // dump groups per wave
@@ -191,7 +191,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   const int lb = (JOB == WG_SQ) ? l - 1 : ((JOB == WG_HEAD) ? P.n_geo - 1 : P.L - 1);   // B-side activation layer
   const int L = P.L, C = P.C;
 
-  if (S::B_DUMP && !P.film_per_point) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
+  if (S::B_DUMP && !PW) for (int i = tid; i < H; i += 256) { f_s[i] = P.fp[((size_t)img * L + lb) * H + i]; p_s[i] = P.pp[((size_t)img * L + lb) * H + i]; }
   if (!S::A_DUMP) for (int i = tid; i < S::A_ROWS * WG_LD; i += 256) A_s[i] = 0.f;     // padded rows stay zero
   if (!S::B_DUMP) for (int i = tid; i < S::B_ROWS * WG_LD; i += 256) B_s[i] = 0.f;
   __syncthreads();
@@ -260,15 +260,14 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
   for (int t = t0; t < t1; ++t) {
     // ---- stage the tile
     // per-point modulation: this lane's point of the tile being staged and its FiLM rows (layer l for the A side, lb for the B side)
-    const size_t pw_pt = (size_t)((tile_base + t) * 32 + (lane & 31)) * L;
+    const size_t pw_pt = PW ? (size_t)((tile_base + t) * 32 + (lane & 31)) * L : 0;
     if (S::A_DUMP) {
       if (P.bf16_dump) stage_dump16_f32<H>(va16, A_s, tid);
-      else stage_dump<H, false>(va, A_s, wave, lane, nullptr, nullptr, P.film_per_point ? P.fp + (pw_pt + l) * H : nullptr);
+      else stage_dump<H, false, PW>(va, A_s, wave, lane, nullptr, nullptr, PW ? P.fp + (pw_pt + l) * H : nullptr);
     }
     if (S::B_DUMP) {
       if (P.tape_u16) stage_tape16_sin<H>(vb16, B_s, tid);
-      else stage_dump<H, true>(vb, B_s, wave, lane, f_s, p_s, P.film_per_point ? P.fp + (pw_pt + lb) * H : nullptr,
-                               P.film_per_point ? P.pp + (pw_pt + lb) * H : nullptr);
+      else stage_dump<H, true, PW>(vb, B_s, wave, lane, f_s, p_s, PW ? P.fp + (pw_pt + lb) * H : nullptr, PW ? P.pp + (pw_pt + lb) * H : nullptr);
     }
     if (JOB == WG_L0) {            // B rows 0..2 = warped coordinates
       if (tid < 96) B_s[(tid >> 5) * WG_LD + (tid & 31)] = side_b * P.box_scale;
@@ -297,7 +296,7 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
     fetch(t + 1);                          // next tile's global loads (dump and side inputs) fly behind this tile's MFMAs
 
     // ---- row sums (thread = row)
-    if ((JOB == WG_SQ || JOB == WG_L0) && P.film_per_point) {
+    if ((JOB == WG_SQ || JOB == WG_L0) && PW) {
       if (tid < H) {
         const float4* ar = reinterpret_cast<const float4*>(A_s + tid * WG_LD);
 #pragma unroll
@@ -394,29 +393,29 @@ __device__ __forceinline__ void wgrad_job(const WgradParams& P, float* lds, int 
             }
     }
     if ((JOB == WG_HEAD || JOB == WG_RGB) && tid < 32) P.rowsum_partial[((size_t)img * P.nchunk + chunk) * 32 + tid] = s0;
-    if ((JOB == WG_SQ || JOB == WG_L0) && P.film_per_point && tid < H)
+    if ((JOB == WG_SQ || JOB == WG_L0) && PW && tid < H)
       P.bias_partial[(((size_t)l * P.B + img) * P.bias_stride + chunk) * H + tid] = sb;
   }
 }
 
-template <int H, int JOB>
+template <int H, int JOB, bool PW = false>
 __global__ __launch_bounds__(256, 1) void siren_wgrad_kernel(WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  wgrad_job<H, JOB>(P, lds, blockIdx.z);
+  wgrad_job<H, JOB, PW>(P, lds, blockIdx.z);
 }
 
 // The four thin jobs of one backward chunk in ONE launch (blockIdx.z = which): each is a chain of load -> stage -> barrier -> exact-fp32
 // MFMAs per 32-point tile with one workgroup per CU and chunk, i.e. latency-bound (30-40 us each with the MFMAs removed); side by
 // side their workgroups fill each other's waits.
 struct ThinJobs { WgradParams j[4]; };
-template <int H>
+template <int H, bool PW = false>
 __global__ __launch_bounds__(256, 1) void siren_wgrad_thin_kernel(ThinJobs T) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   switch (blockIdx.z) {
-    case 0: wgrad_job<H, WG_C0X>(T.j[0], lds, 0); break;     // longest first
-    case 1: wgrad_job<H, WG_HEAD>(T.j[1], lds, 0); break;
-    case 2: wgrad_job<H, WG_RGB>(T.j[2], lds, 0); break;
-    default: wgrad_job<H, WG_L0>(T.j[3], lds, 0); break;
+    case 0: wgrad_job<H, WG_C0X, PW>(T.j[0], lds, 0); break;     // longest first
+    case 1: wgrad_job<H, WG_HEAD, PW>(T.j[1], lds, 0); break;
+    case 2: wgrad_job<H, WG_RGB, PW>(T.j[2], lds, 0); break;
+    default: wgrad_job<H, WG_L0, PW>(T.j[3], lds, 0); break;
   }
 }
 
@@ -1073,9 +1072,9 @@ size_t wg_lds_bytes() {
   return (size_t)((S::A_ROWS + S::B_ROWS) * WG_LD + 2 * H) * sizeof(float);
 }
 
-template <int H, int JOB>
+template <int H, int JOB, bool PW = false>
 int launch_job(const WgradParams& p, int nz, hipStream_t st) {
-  auto kfn = siren_wgrad_kernel<H, JOB>;
+  auto kfn = siren_wgrad_kernel<H, JOB, PW>;
   const size_t lds = wg_lds_bytes<H, JOB>();
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   hipLaunchKernelGGL(kfn, dim3(p.nchunk, p.B, nz), dim3(256), lds, st, p);
@@ -1197,7 +1196,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
     PhaseScope ph(PH_WGRAD_SQ, st);
     if ((rc = p.bf16_dump ? launch_sq_b16d<H>(p, L - 1, st)
                           : ((m->precision == FENERF_PREC_F16X3) ? (p.tape_u16 ? launch_sq_bf16<H, true>(p, L - 1, st) : launch_sq_bf16<H, false>(p, L - 1, st))
-                                                                 : launch_job<H, WG_SQ>(p, L - 1, st)))) return rc;
+                                                                 : (p.film_per_point ? launch_job<H, WG_SQ, true>(p, L - 1, st) : launch_job<H, WG_SQ>(p, L - 1, st))))) return rc;
   }
   {
     PhaseScope ph(PH_WGRAD_SQ_REDUCE, st);
@@ -1219,7 +1218,7 @@ static int param_grads_t(const FenerfModel* m, WgradParams p, const FenerfSirenG
     T.j[1] = p; T.j[1].layer0 = ng - 1; T.j[1].partial = p_hd; T.j[1].rowsum_partial = rows;
     T.j[2] = p; T.j[2].layer0 = L - 1; T.j[2].partial = p_rgb; T.j[2].rowsum_partial = rows_rgb;
     T.j[3] = p; T.j[3].layer0 = 0; T.j[3].partial = p_l0;
-    auto kfn = siren_wgrad_thin_kernel<H>;
+    auto kfn = p.film_per_point ? siren_wgrad_thin_kernel<H, true> : siren_wgrad_thin_kernel<H, false>;
     size_t lds = wg_lds_bytes<H, WG_C0X>();
     if (wg_lds_bytes<H, WG_HEAD>() > lds) lds = wg_lds_bytes<H, WG_HEAD>();
     if (wg_lds_bytes<H, WG_L0>() > lds) lds = wg_lds_bytes<H, WG_L0>();
