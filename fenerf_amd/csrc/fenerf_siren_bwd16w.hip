@@ -52,6 +52,11 @@
 #ifndef FENERF_WAVE_HALF_COPIES
 #define FENERF_WAVE_HALF_COPIES 1     // 0: the wave half as a run-time flag inside the stream loop (rounds 3-5); A/B builds only
 #endif
+// Timing ablations of the stage bodies (tools/exp/chain_ablations.sh; WRONG results): 1 = no FiLM sums (the B items: row butterfly, LDS
+// hand-over, combine), 2 = no d(theta) stores, 4 = tape DMA from one L2-resident block instead of the tile's (same instruction, same queue)
+#ifndef FENERF_EXP_CHAIN_ABLATE
+#define FENERF_EXP_CHAIN_ABLATE 0
+#endif
 #ifndef FENERF_BW16_T16
 #define FENERF_BW16_T16 0      // tape mode of this translation unit: 0 = FENERF_TAPE_F32, 1 = FENERF_TAPE_U16, 2 = FENERF_TAPE_F32_W
 #endif
@@ -720,14 +725,15 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
                   if ((it & 1) == 0) {
                     if constexpr (nb > 0) {
                       eo[rt] = epi_compute<BD, T16, S1>(acc_prev[rt], q[rt], yh[nb - 1], yl[nb - 1], rt);
-                      if constexpr (!BD) { if (dump) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt); }
+                      if constexpr (!BD) { if (dump && !(FENERF_EXP_CHAIN_ABLATE & 2)) st_f4_nt(k.dt_base + ((nb - 1) * 4 + rt) * 1024, k.toff, eo[rt].dt); }
                       else if (rt == 1) dump_bf16(k, nb - 1, eo, true);
                     }
                     // the tape block two n-blocks ahead of its use: (lo, nb + 1), or the next stage's n-block 0; the last
                     // stage's last body re-fetches (0, 0) so that ring_wait's count holds
-                    if constexpr (nb + 1 < NBODY) tape_issue(k.tape_base, nb + 1, rt, ((nb + 1) + tpar) & 1, k.ttoff);
+                    if constexpr (FENERF_EXP_CHAIN_ABLATE & 4) tape_issue(reinterpret_cast<const char*>(P.tape), 0, rt, ((nb + 1) + tpar) & 1, k.ttoff);
+                    else if constexpr (nb + 1 < NBODY) tape_issue(k.tape_base, nb + 1, rt, ((nb + 1) + tpar) & 1, k.ttoff);
                     else tape_issue(k.tape_next, 0, rt, (NBODY + tpar) & 1, k.ttoff);
-                  } else {
+                  } else if constexpr (!(FENERF_EXP_CHAIN_ABLATE & 1)) {
                     if constexpr (nb > 0) {
                       const f32x2 sm = {row_sum4(eo[rt].dt, k.b0, k.b1), S1 ? row_sum4(eo[rt].dtt, k.b0, k.b1) : 0.f};
                       if (WGS) {
