@@ -435,6 +435,9 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_thin_kernel(ThinJobs T) {
 // With the MFMA time cut 5x the kernel is bound by its two dump reads (dtheta_l, tape_{l-1}); the FiLM sums come from the
 // chain kernel (film_gather_kernel).
 // ------------------------------------------------------------------------------------------------
+#ifndef FENERF_WGRAD_PAIR_STORES
+#define FENERF_WGRAD_PAIR_STORES 1    // 0: rounds 2-5 (one 16-bit LDS store per value and half); A/B builds only
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
@@ -458,6 +461,32 @@ __device__ __forceinline__ void stage_split4(unsigned short* row0_m, const float
     row0_m[(2 * j + 1) * (2 * WG_LD)] = (unsigned short)(vb[2 * j + 1] >> 16);
     row0_m[(2 * j) * (2 * WG_LD) + 32] = (unsigned short)lo2;
     row0_m[(2 * j + 1) * (2 * WG_LD) + 32] = (unsigned short)(lo2 >> 16);
+  }
+}
+
+// The same split for a PAIR of adjacent points (round 6): lanes m and m ^ 1 hold the same four rows of points m and m + 1.  They trade two
+// values each (one DPP quad_perm), so that the even lane owns rows 0, 1 and the odd lane rows 2, 3 of BOTH points and writes them as
+// whole dwords [even point | odd point]: 4 ds_write_b32 per lane instead of 8 ds_write_b16.  A 16-bit LDS store costs what a 32-bit one
+// costs (address + data transfer, 64 B/clk at best), and with 512 of them per tile and workgroup the LDS -- 1,536 cycles of fragment
+// reads + 2,048 of staging writes per tile against 3,072 cycles of MFMA work per SIMD -- was what bounded this kernel
+// (SQ_WAIT_INST_LDS 21 %, matrix pipe 59 % busy, profiles/r06_pmc_gstep_waits.txt).  Same bits in the same places as stage_split4.
+__device__ __forceinline__ float wg_lane_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ void stage_split4_pair(unsigned* row0 /* dword 0 of row `row` of the image */, int m, const float (&v)[4]) {
+  const bool odd = (m & 1) != 0;
+  const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];        // what the partner lane's rows need from this point
+  const float r0 = wg_lane_xor1(s0), r1 = wg_lane_xor1(s1);           // the partner point's values of THIS lane's rows
+  const float o0 = odd ? v[2] : v[0], o1 = odd ? v[3] : v[1];        // this point's values of this lane's rows
+  const float ev[2] = {odd ? r0 : o0, odd ? r1 : o1};                // even point (low half of the dword)
+  const float od[2] = {odd ? o0 : r0, odd ? o1 : r1};                // odd point (high half)
+  unsigned* dst = row0 + (odd ? 2 : 0) * WG_LD + (m >> 1);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned eb = __builtin_bit_cast(unsigned, ev[j]), ob = __builtin_bit_cast(unsigned, od[j]);
+    const f32x2w rr = {ev[j] - __builtin_bit_cast(float, eb & 0xffff0000u), od[j] - __builtin_bit_cast(float, ob & 0xffff0000u)};
+    dst[j * WG_LD] = __builtin_amdgcn_perm(ob, eb, 0x07060302u);                                          // hi: [od.hi16 | ev.hi16]
+    dst[j * WG_LD + 16] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf16x2w));             // lo, 64 B behind
   }
 }
 
@@ -548,7 +577,11 @@ __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradPa
     if ((hp & 1) == 0) {
       const float4 a = va[q];
       const float d[4] = {a.x, a.y, a.z, a.w};
+#if FENERF_WGRAD_PAIR_STORES
+      stage_split4_pair(dst + row * WG_LD, m, d);
+#else
       stage_split4(reinterpret_cast<unsigned short*>(dst + row * WG_LD) + m, d);
+#endif
     } else if constexpr (T16) {
       // half-piece hs = (16-byte piece s16 = (nb, 16-point tile, lane (n, g)), row tile rt): features dump16_feature(nb, g, 4 rt + r)
       const int hs = tid + NW * 64 * q, s16 = hs >> 1, rt = hs & 1;
@@ -562,7 +595,11 @@ __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradPa
       const float4 b = vb[q];
       const float x[4] = {sin2pi(__builtin_fmaf(f4.x, b.x, p4.x)), sin2pi(__builtin_fmaf(f4.y, b.y, p4.y)),
                           sin2pi(__builtin_fmaf(f4.z, b.z, p4.z)), sin2pi(__builtin_fmaf(f4.w, b.w, p4.w))};
+#if FENERF_WGRAD_PAIR_STORES
+      stage_split4_pair(dst + H * WG_LD + row * WG_LD, m, x);
+#else
       stage_split4(reinterpret_cast<unsigned short*>(dst + H * WG_LD + row * WG_LD) + m, x);
+#endif
     }
   };
 
