@@ -104,3 +104,13 @@ print("rays/s %.0f kernel_ms %.4f cycles %.0f clock %.3f | gstep %.3f" % (d["val
 PY
   done; done
 fi
+if [ "$which" = "b6" ]; then
+  for i in 1 2 3; do
+    timeout 600 python bench.py --no-cpu-baseline --no-f32 --no-sweep64 --no-gstep-ddp > /dev/null 2>&1
+    python - <<PY
+import json
+d = json.load(open("bench_detail.json"))
+print("gstep %.3f b6 %.3f ms (%.3f per image) peak %.1f GB" % (d["gstep"]["ms"], d["gstep_b6"]["ms"], d["gstep_b6"]["ms"] / 6, d["gstep_b6"]["peak_GB"]))
+PY
+  done
+fi
