@@ -3237,7 +3237,7 @@ def test_spatial_siren_grid_gradients_vs_reference_autograd(native_route):
     assert e_fwd <= 2e-5 and errs[worst] <= (4.4e-4 if native_route else 3e-4), errs
 
 
-@pytest.mark.parametrize("H,B,P", [(32, 2, 96), (64, 1, 100), (256, 2, 2048)])
+@pytest.mark.parametrize("H,B,P", [(32, 2, 96), (64, 1, 100), (96, 3, 160), (192, 1, 512), (256, 2, 2048)])
 def test_pointwise_siren_backward_native_vs_fp64_autograd(H, B, P):
     """fenerf_siren_forward_save_pointwise / _backward_pointwise / _param_grads_pointwise (round 6): the per-point-modulated
     SIREN (siren.py:464-477 with [B, P, 9H] frequencies / phase shifts) through SPATIALSIRENGRID.forward_with_frequencies_phase_shifts under
@@ -3285,6 +3285,49 @@ def test_pointwise_siren_backward_native_vs_fp64_autograd(H, B, P):
           f"{errs['native'][wn]:.2e} ({wn}), PyTorch-ROCm route {errs['torch'][wt]:.2e} ({wt}); outputs {errs['native']['out']:.1e} / {errs['torch']['out']:.1e}")
     # measured (round 6): native 5.6e-5 / 5.2e-5 / 5.5e-5, the PyTorch-ROCm route 7.4e-5 / 7.3e-5 / 5.7e-5 (H = 32 / 64 / 256); x 1.5
     assert errs["native"][wn] <= 8.5e-5 and errs["native"]["out"] <= 4.5e-5, errs["native"]
+
+
+def test_pointwise_siren_backward_at_scale_native_vs_pytorch_route():
+    """The whole differentiable SPATIALSIRENGRID call at the size of a render pass (H = 256, 1 x 65,536 points: latent grid from z, per-point
+    latents, per-point mapping network, per-point-modulated SIREN): the native route (PointwiseSirenFunction) against the PyTorch-ROCm route
+    on the same inputs -- outputs and every gradient (SIREN weights, mapping network, z through StyleGenerator2D) --, its step time and
+    peak memory beside the other's, and a second step after an optimizer update (the native model re-packs on the device)."""
+    import time
+    torch.manual_seed(3)
+    mod = S.SPATIALSIRENGRID(input_dim=3, z_dim=64, hidden_dim=256, output_dim=4).to(DEV).train()
+    mod.device = torch.device(DEV)
+    P = 65536
+    pts = torch.rand((1, P, 3), device=DEV) * 2 - 1
+    dirs = torch.nn.functional.normalize(torch.randn((1, P, 3), device=DEV), dim=-1)
+    z0 = torch.randn((1, 64), device=DEV)
+    w = torch.randn((1, P, 4), device=DEV) / P
+    res, ms = {}, {}
+    for route in ("native", "torch"):
+        mod.NATIVE_POINTWISE_BACKWARD = route == "native"
+        for it in range(3):
+            mod.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = mod(pts, z, dirs)
+            (out * w).sum().backward()
+            torch.cuda.synchronize()
+            ms[route] = (time.perf_counter() - t0) * 1e3
+        res[route] = dict(out=N_(out), z=N_(z.grad), **{n: N_(q.grad) for n, q in mod.named_parameters() if q.grad is not None})
+    assert set(res["native"]) == set(res["torch"]) and len(res["native"]) > 40
+    errs = {k: _rel_err(res["native"][k], res["torch"][k]) for k in res["torch"]}
+    worst = max(errs, key=errs.get)
+    print(f"[parity] SPATIALSIRENGRID step at 65,536 points, H = 256: native vs PyTorch-ROCm route worst relative difference over {len(errs)} tensors {errs[worst]:.2e} "
+          f"({worst}); outputs {errs['out']:.1e}; step {ms['native']:.1f} ms native / {ms['torch']:.1f} ms PyTorch-ROCm")
+    assert errs[worst] <= 7.5e-5 and errs["out"] <= 9e-6, errs         # measured 4.8e-5 / 5.5e-6 (two fp32 evaluations, each ~5e-5 from fp64: tests above); x 1.5
+    # an optimizer step, then the native route again: the device-side re-pack is picked up (pack_generation)
+    mod.NATIVE_POINTWISE_BACKWARD = True
+    opt = torch.optim.SGD([q for n, q in mod.named_parameters() if mod._is_render_param(n)], lr=1e-2)
+    opt.step()
+    mod.zero_grad(set_to_none=True)
+    out2 = mod(pts, z0, dirs)
+    (out2 * w).sum().backward()
+    assert np.abs(N_(out2) - res["native"]["out"]).max() > 1e-6 and all(q.grad is not None for n, q in mod.named_parameters() if mod._is_render_param(n))
 
 
 @pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
