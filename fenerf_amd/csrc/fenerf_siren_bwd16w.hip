@@ -54,6 +54,9 @@
 #endif
 // Timing ablations of the stage bodies (tools/exp/chain_ablations.sh; WRONG results): 1 = no FiLM sums (the B items: row butterfly, LDS
 // hand-over, combine), 2 = no d(theta) stores, 4 = tape DMA from one L2-resident block instead of the tile's (same instruction, same queue)
+#ifndef FENERF_CHAIN_SETPRIO
+#define FENERF_CHAIN_SETPRIO 1        // round 6: chain 4.16-4.19 -> 4.08-4.11 ms per step in same-box A/B (tools/gpu_r6.sh prioab)
+#endif
 #ifndef FENERF_EXP_CHAIN_ABLATE
 #define FENERF_EXP_CHAIN_ABLATE 0
 #endif
@@ -384,6 +387,11 @@ __global__ __launch_bounds__(512, 2) void siren_bwd16w_kernel(SirenBwdParams P, 
   // ---- prime the shared stream: chunks 0..D-1 in flight
 #pragma unroll
   for (int i = 0; i < DPF; ++i) ws_issue(ws, i);
+#if FENERF_CHAIN_SETPRIO
+  // static issue priority for the second-dispatched half, as in the forward kernel (fenerf_siren_f16w.hip): between the two waves of a
+  // SIMD the arbiter prefers the older one, so waves 4-7 arrive last at every barrier
+  if (wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // work split: octs of 16-point tiles (one tile per wave), XCD-contiguous ranges
   const long long ntiles = (P.P + 15) / 16;

@@ -435,6 +435,9 @@ __global__ __launch_bounds__(256, 1) void siren_wgrad_thin_kernel(ThinJobs T) {
 // With the MFMA time cut 5x the kernel is bound by its two dump reads (dtheta_l, tape_{l-1}); the FiLM sums come from the
 // chain kernel (film_gather_kernel).
 // ------------------------------------------------------------------------------------------------
+#ifndef FENERF_WGRAD_SETPRIO
+#define FENERF_WGRAD_SETPRIO 0        // measured in round 6: no effect on this kernel (2.74 against 2.72-2.76 ms per step)
+#endif
 #ifndef FENERF_WGRAD_PAIR_STORES
 #define FENERF_WGRAD_PAIR_STORES 1    // 0: rounds 2-5 (one 16-bit LDS store per value and half); A/B builds only
 #endif
@@ -547,6 +550,9 @@ __global__ __launch_bounds__(NW * 64, 1) void siren_wgrad_sq_bf16_kernel(WgradPa
   const int wm0 = (wave / WGK) * WM, wk0 = (wave % WGK) * WK;
   const int m = lane & 31, half = lane >> 5;
   static_assert(NW * GPW == NG, "every wave stages GPW dump groups");
+#if FENERF_WGRAD_SETPRIO
+  if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   float4 va[GPW], vb[GPW];                                  // dump group q of the tile being staged next: dtheta_l, tape_{l-1}
   uint2 vb16[GPW];                                          // T16: half-piece tid + NW * 64 * q of the tile's 16-bit tape block

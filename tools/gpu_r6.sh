@@ -114,3 +114,17 @@ print("gstep %.3f b6 %.3f ms (%.3f per image) peak %.1f GB" % (d["gstep"]["ms"],
 PY
   done
 fi
+if [ "$which" = "prioab" ]; then   # same-box A/B: static issue priority for waves 4-7 in the chain / in the square weight-gradient kernel
+  for rep in 1 2; do
+  for v in "" chain_setprio wgrad_setprio; do
+    if [ -z "$v" ]; then lib=$PWD/fenerf_amd/libfenerf_hip.so; else lib=$PWD/fenerf_amd/libexp_$v.so; fi
+    [ -f $lib ] || continue
+    echo -n "${v:-shipped}: "
+    FENERF_LIB=$lib timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32 --no-sweep64 --no-gstep-ddp --no-gstep-b6 > /dev/null 2>&1
+    python - <<PY
+import json
+d = json.load(open("bench_detail.json")); g = d["gstep"]
+print("gstep %.3f" % g["ms"], {k["name"]: round(k["ms"], 3) for k in g["roofline"]["per_kernel"]}, "| tape16 %.3f amp16 %.3f" % (d["gstep_tape16"]["ms"], d["gstep_amp16"]["ms"]))
+PY
+  done; done
+fi
