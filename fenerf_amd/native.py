@@ -22,6 +22,57 @@ def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+
+# Hidden widths the kernels are instantiated for (include/fenerf.h).  Any other width up to the largest is run at the next instantiated one
+# with zero padding (round 6): padded rows / columns of every weight matrix, padded biases and padded FiLM phase shifts are zero, so a padded
+# feature's activation is sin(f' * 0 + 0) = 0 and nothing it touches changes a sum (adding exact zeros) -- outputs and the gradients of the
+# real entries are those of the unpadded network; gradients of padded entries are dropped.  The reference constructs any width
+# (siren/siren.py:1451).
+SUPPORTED_HIDDEN = (32, 64, 96, 128, 192, 256)
+
+
+def padded_hidden_dim(H):
+    for w in SUPPORTED_HIDDEN:
+        if H <= w:
+            return w
+    raise ValueError(f"hidden_dim {H}: the kernels are instantiated up to {SUPPORTED_HIDDEN[-1]} (include/fenerf.h)")
+
+
+def _pad_axes(name, spec_kind):
+    """which axes of render parameter `name` are hidden-width axes: (pad rows?, pad the LAST H columns?) -- the colour layer 0's input is
+    [dirs | grid features | x]: its hidden part is the trailing H columns"""
+    if name == "spatial_embeddings":
+        return False, False
+    if name.endswith(".bias"):
+        last_label = name.startswith("label_layer_linear.") and name == _pad_axes.last_label_bias
+        return (not (name.startswith("final_layer") or name.startswith("color_layer_linear") or last_label)), False
+    if name == "network.0.layer.weight":
+        return True, False
+    if name.startswith("final_layer") or name.startswith("color_layer_linear") or name == _pad_axes.last_label_weight:
+        return False, True
+    return True, True
+
+
+_pad_axes.last_label_weight = _pad_axes.last_label_bias = None
+
+
+def _pad_param(name, t, H, Hp, n_label_layers, is_numpy):
+    """zero-pad one reference-named render parameter from hidden width H to Hp (numpy array or torch tensor)"""
+    _pad_axes.last_label_weight = f"label_layer_linear.{n_label_layers - 1}.weight" if n_label_layers else None
+    _pad_axes.last_label_bias = f"label_layer_linear.{n_label_layers - 1}.bias" if n_label_layers else None
+    rows, cols = _pad_axes(name, None)
+    d = Hp - H
+    if t.ndim == 1:
+        if not rows:
+            return t
+        return np.concatenate([t, np.zeros(d, t.dtype)]) if is_numpy else torch.nn.functional.pad(t, (0, d))
+    if cols:
+        t = np.concatenate([t, np.zeros((t.shape[0], d), t.dtype)], 1) if is_numpy else torch.nn.functional.pad(t, (0, d))
+    if rows:
+        t = np.concatenate([t, np.zeros((d, t.shape[1]), t.dtype)], 0) if is_numpy else torch.nn.functional.pad(t, (0, 0, 0, d))
+    return t
+
+
 class NativeModel:
     """Owns a FenerfModel* built from a reference-named state dict (numpy fp32 arrays)."""
 
@@ -30,7 +81,10 @@ class NativeModel:
     FORWARD_MODES = {"f16x2": 1, "f16x3c2": 2}
 
     def __init__(self, sd, spec, device, precision="f32", differentiable=False, wgrad_bf16_min_points=0):
+        self.logical_H = int(spec["hidden_dim"])                       # the module's width; self.spec carries the (padded) width the kernels run at
+        spec = dict(spec, hidden_dim=padded_hidden_dim(self.logical_H))
         self.spec = dict(spec)
+        sd = self._pad_state(sd)
         self.forward_mode = self.FORWARD_MODES.get(precision, 0)
         self.requested_precision = precision
         precision = "f16x3" if self.forward_mode else precision
@@ -54,7 +108,56 @@ class NativeModel:
         self._ws = {}
         self.pack_generation = 0      # bumped by every re-pack: autograd nodes check that forward and backward saw the same weights
 
+    # ---- hidden widths between the instantiated ones: zero padding on the way in, slicing on the way out (padded_hidden_dim above)
+    @property
+    def padded(self):
+        return self.logical_H != self.spec["hidden_dim"]
+
+    def _pad_state(self, sd):
+        if not self.padded:
+            return sd
+        H, Hp, nl = self.logical_H, self.spec["hidden_dim"], self.spec.get("n_label_layers", 0)
+        return {k: _pad_param(k, np.asarray(v), H, Hp, nl, True) for k, v in sd.items()}
+
+    def _pad_film(self, t, n):
+        """[..., n * H] -> [..., n * Hp], zeros behind every layer's block"""
+        H, Hp = self.logical_H, self.spec["hidden_dim"]
+        if t.shape[-1] == n * Hp:
+            return t
+        return torch.nn.functional.pad(t.reshape(*t.shape[:-1], n, H), (0, Hp - H)).reshape(*t.shape[:-1], n * Hp)
+
+    def _unpad_grads(self, res):
+        """a gradient dict of siren_param_grads' layout at the padded width -> the module's width (views; the label head's rows stay)"""
+        if not self.padded:
+            return res
+        H, Hp = self.logical_H, self.spec["hidden_dim"]
+        ng, nc, G = self.spec["n_geo"], self.spec["n_color"], self.spec["grid_ch"]
+        out = dict(res)
+        for k, n in (("d_freq_geo", ng), ("d_phase_geo", ng), ("d_freq_app", nc), ("d_phase_app", nc)):
+            if k in res:
+                t = res[k]
+                out[k] = t.reshape(*t.shape[:-1], n, Hp)[..., :H].reshape(*t.shape[:-1], n * H).contiguous()
+        if "geo_w" in res:
+            out["geo_w"] = [res["geo_w"][0][:H].contiguous()] + [w[:H, :H].contiguous() for w in res["geo_w"][1:]]
+            out["color_w"] = [res["color_w"][0][:H, :3 + G + H].contiguous()] + [w[:H, :H].contiguous() for w in res["color_w"][1:]]
+            out["geo_b"] = [b[:H].contiguous() for b in res["geo_b"]]
+            out["color_b"] = [b[:H].contiguous() for b in res["color_b"]]
+            out["head_w"] = res["head_w"][:, :H].contiguous()
+            out["rgb_w"] = res["rgb_w"][:, :H].contiguous()
+        return out
+
+    def _pad_weights(self, weights):
+        """film_layer_weights(...) at the module's width -> at the kernels' width (device copies)"""
+        if weights is None or not self.padded:
+            return weights
+        H, Hp, G = self.logical_H, self.spec["hidden_dim"], self.spec["grid_ch"]
+        pad2 = lambda w, cols: torch.nn.functional.pad(w.detach().float(), (0, cols - w.shape[1], 0, Hp - H))
+        geo = [pad2(weights[0][0], 3)] + [pad2(w, Hp) for w in weights[0][1:]]
+        col = [pad2(weights[1][0], 3 + G + Hp)] + [pad2(w, Hp) for w in weights[1][1:]]
+        return geo, col
+
     def update(self, sd):
+        sd = self._pad_state(sd)
         self.pack_generation += 1
         self._resident = None         # what a later load_from_device(maybe_unchanged=True) compares against is no longer what is resident
         with torch.cuda.device(self.device):
@@ -203,6 +306,11 @@ class NativeModel:
                 for i in range(nl - 2, -1, -1):
                     A = A @ p[f"label_layer_linear.{i}.weight"]
                 p["label_layer_linear.0.weight"], p["label_layer_linear.0.bias"] = A, c
+            if self.padded:       # folded label head first (at the module's width), then every canonical item to the kernels' width
+                H, Hp = self.logical_H, sp["hidden_dim"]
+                for name, shape in self._canonical():
+                    if tuple(p[name].shape) != tuple(shape):
+                        p[name] = _pad_param(name, p[name], H, Hp, 1 if n_lab > 0 else 0, False)
             flat = torch.cat([torch.zeros(1, device=dev)] + [p[name].reshape(-1) for name, _ in self._canonical()])
         return p, flat
 
@@ -327,9 +435,11 @@ class NativeModel:
         H, ng, nc = self.spec["hidden_dim"], self.spec["n_geo"], self.spec["n_color"]
         dev = self.device
         fg, pg, fa, pa = (_f32(t, dev) for t in (fg, pg, fa, pa))
+        if self.padded:
+            fg, pg, fa, pa = self._pad_film(fg, ng), self._pad_film(pg, ng), self._pad_film(fa, nc), self._pad_film(pa, nc)
         for t, n in ((fg, ng), (pg, ng), (fa, nc), (pa, nc)):
             if tuple(t.shape) != (B, n * H):
-                raise ValueError(f"film parameter of shape {tuple(t.shape)}, expected {(B, n * H)}")
+                raise ValueError(f"film parameter of shape {tuple(t.shape)}, expected {(B, n * self.logical_H)}")
         return fg, pg, fa, pa
 
     def siren_forward(self, points, ray_dirs, fg, pg, fa, pa):
@@ -375,6 +485,8 @@ class NativeModel:
     def _film_pointwise(self, B, P, fg, pg, fa, pa):
         H, ng, nc = self.spec["hidden_dim"], self.spec["n_geo"], self.spec["n_color"]
         fg, pg, fa, pa = (_f32(t, self.device) for t in (fg, pg, fa, pa))
+        if self.padded:
+            fg, pg, fa, pa = self._pad_film(fg, ng), self._pad_film(pg, ng), self._pad_film(fa, nc), self._pad_film(pa, nc)
         for t, n in ((fg, ng), (pg, ng), (fa, nc), (pa, nc)):
             if tuple(t.shape) != (B, P, n * H):
                 raise ValueError(f"per-point film parameter of shape {tuple(t.shape)}, expected {(B, P, n * H)}")
@@ -428,7 +540,7 @@ class NativeModel:
             _lib.check(l.fenerf_siren_param_grads_pointwise(self._h, B, P, _ptr(_f32(points, dev)), _ptr(_f32(ray_dirs, dev)) if ray_dirs is not None else None,
                                                             _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), _ptr(d_t),
                                                             C.byref(g), C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), 1, _stream()))   # (prepared by the chain call above)
-        return res
+        return self._unpad_grads(res)
 
     def tape_floats(self, total_points, tape_format=0):
         """fp32 words of a tape for total_points points (L*H values per point + the slack the kernel's last workgroup may write; the
@@ -522,7 +634,7 @@ class NativeModel:
             ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
             _lib.check(l.fenerf_siren_film_grads(self._h, B, P, _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(film_sums), C.byref(g),
                                                  C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
-        return res
+        return self._unpad_grads(res)
 
     def siren_backward_grid(self, B, P, fg, pg, fa, pa, out, d_out, tape, points, d_grid_cl, tape_format=0):
         """siren_backward whose gradient wrt the sampled grid features is scattered (accumulated) straight into d_grid_cl
@@ -578,6 +690,7 @@ class NativeModel:
             fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
             ws = self._workspace("wgrad", l.fenerf_siren_grad_workspace_bytes(self._h, B, P))
             wts, keep = None, []
+            weights = self._pad_weights(weights)
             if weights is not None:
                 wts = _lib.FenerfSirenGrads()
                 for i, w in enumerate(weights[0]):
@@ -588,7 +701,7 @@ class NativeModel:
                                                       _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(out), _ptr(d_out), _ptr(tape), int(tape_format),
                                                       _ptr(tape_e), _ptr(d_t), C.byref(g), C.byref(wts) if wts is not None else None,
                                                       C.c_void_p(ws.data_ptr()), C.c_void_p(fws.data_ptr()), _stream()))
-        return res
+        return self._unpad_grads(res)
 
     def grid_backward(self, points, d_e, grid_shape):
         """Scatter d_e [Ptot,32] into the gradient of spatial_embeddings; returns it in the parameter's [1,32,D,H,W] shape."""
@@ -692,6 +805,7 @@ class NativeModel:
         """film_layer_weights(...) -> (FenerfSirenGrads of their pointers or None, keep-alive list)"""
         if weights is None:
             return None, []
+        weights = self._pad_weights(weights)
         wts, keep = _lib.FenerfSirenGrads(), []
         for i, w in enumerate(weights[0]):
             keep.append(_f32(w.detach(), self.device)); wts.geo_w[i] = keep[-1].data_ptr()
@@ -714,7 +828,7 @@ class NativeModel:
                                                 _ptr(_f32(z_coarse, dev)), _ptr(_f32(noise_final, dev)) if noise_final is not None else None,
                                                 C.byref(opts), _ptr(_f32(g_rgb, dev)), C.byref(g), _ptr(d_grid), C.byref(wts) if wts is not None else None,
                                                 int(chunk_points), int(film_sums_budget_bytes), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream()))
-        return res, d_grid
+        return self._unpad_grads(res), d_grid
 
     def render_backward_stage(self, stage, keep_chunks, B, R, N, save, z_coarse, noise_final, opts, g_rgb, lock_view=False, tape_format=0,
                               weights=None, chunk_points=0, carry=None):
@@ -754,7 +868,7 @@ class NativeModel:
             carry["d_grid"] = None          # finished: the caller's (autograd may take the tensor as the parameter's .grad without a copy)
             return d_grid, carry
         self.release_split_workspace(carry)
-        return res
+        return self._unpad_grads(res)
 
     def release_split_workspace(self, carry):
         """stage 2 has run -- or never will (the backward pass ended without it): the persistent two-stage scratch is free again"""

@@ -31,7 +31,11 @@ enum {
   FENERF_E_INVALID = -1,     /* bad argument / unsupported shape */
   FENERF_E_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
   FENERF_E_NOMEM = -3,
-  FENERF_E_UNSUPPORTED = -4, /* model variant not built (hidden_dim not in {32,64,96,128,192,256}, ...) */
+  FENERF_E_UNSUPPORTED = -4, /* model variant not built (hidden_dim not in {32,64,96,128,192,256}, ...).  Any other width up to 256 (the
+                              * reference constructs any, siren/siren.py:1451) runs EXACTLY at the next instantiated one with zero padding:
+                              * zero rows / trailing hidden columns of every weight matrix, zero biases and zero FiLM phase shifts make a
+                              * padded feature sin(f' 0 + 0) = 0; the host packs that way (fenerf_amd/native.py padded_hidden_dim pads on
+                              * the way in and slices gradients on the way out: pixels bit-identical to the padded network's) */
   FENERF_E_CLAMP_MODE = -5   /* reference raises TypeError("Need to choose clamp mode"), volumetric_rendering.py:34 */
 };
 

@@ -1446,7 +1446,9 @@ def _rel_err(got, ref):
 @pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
 @pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 75), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 33),
                                              ("texture", 128, 4, 3, 130), ("texture", 256, 6, 2, 200),
-                                             ("texture", 96, 5, 2, 75), ("baseline", 192, 0, 1, 64), ("spatial", 96, 0, 2, 33)])      # round 5: H = 96 / 192
+                                             ("texture", 96, 5, 2, 75), ("baseline", 192, 0, 1, 64), ("spatial", 96, 0, 2, 33),      # round 5: H = 96 / 192
+                                             # round 6: widths BETWEEN the instantiated ones run zero-padded at the next one (native.padded_hidden_dim)
+                                             ("texture", 100, 5, 2, 75), ("baseline", 40, 0, 1, 64), ("spatial", 72, 0, 2, 33), ("texture", 250, 4, 1, 96)])
 def test_siren_backward_vs_autograd(kind, H, grid, B, P, precision):
     from oracle import fenerf_oracle_grad as OG
     mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
@@ -1493,6 +1495,94 @@ def test_siren_backward_vs_autograd(kind, H, grid, B, P, precision):
         worst = max(worst, e)
         assert e <= 2e-4, (k, e)
     print(f"[parity] SIREN backward {precision} {kind} H={H} B={B} P={P}: worst relative error over {len(sd64) + len(film)} gradient tensors {worst:.2e}")
+
+
+def test_hidden_width_between_the_instantiated_ones_is_the_padded_network_bit_for_bit():
+    """The reference constructs any hidden width (siren.py:1451); the kernels are instantiated for 32 / 64 / 96 / 128 / 192 / 256.  Round 6:
+    another width up to 256 runs at the next instantiated one with zero padding (native.padded_hidden_dim): padded features are
+    sin(f' 0 + 0) = 0 and add exact zeros to every sum.  A 100-wide generator against the SAME network written out as a 128-wide module
+    with zero rows / columns: hierarchical render under autograd -- pixels bit-identical, every gradient equal on the real entries (the
+    padded module's gradients of padded entries are whatever they are) --, then an optimizer step on the 100-wide module (device-side re-pack
+    through the padding) and a no-grad render against the oracle at the updated weights."""
+    H, Hp = 100, 128
+    mod, spec, sd = _siren_module("texture", H, 5, sigma_gain=150.0)
+    big, spec_b, _ = _siren_module("texture", Hp, 5, sigma_gain=150.0)
+    assert native.padded_hidden_dim(H) == Hp and native.padded_hidden_dim(33) == 64 and native.padded_hidden_dim(256) == 256
+    with pytest.raises(ValueError):
+        native.padded_hidden_dim(257)
+    with torch.no_grad():
+        for (n, p), (nb, pb) in zip(mod.named_parameters(), big.named_parameters()):
+            assert n == nb
+            if "mapping_network" in n or n == "spatial_embeddings":
+                if n == "spatial_embeddings":
+                    pb.copy_(p)
+                continue
+            pb.zero_()
+            if p.dim() == 1:
+                pb[:p.shape[0]] = p
+            elif n.startswith("color_layer_sine.0."):          # [dirs | grid | x]: the hidden part is the trailing columns
+                pb[:H, :35] = p[:, :35]
+                pb[:H, 35:35 + H] = p[:, 35:]
+            else:
+                pb[:p.shape[0], :p.shape[1]] = p
+    gens = []
+    for m_, w in ((mod, H), (big, Hp)):
+        gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=w), 8, 8, 22)
+        gen.siren = m_
+        gen = gen.to(DEV).train()
+        gen.device = torch.device(DEV); gen.siren.device = gen.device
+        gens.append(gen)
+    B = 2
+    film = proc.film_params(spec, B, seed=9)
+    pad = lambda a, n: np.pad(a.reshape(B, n, H), ((0, 0), (0, 0), (0, Hp - H))).reshape(B, n * Hp)
+    film_b = dict(freq_geo=pad(film["freq_geo"], 8), phase_geo=pad(film["phase_geo"], 8), freq_app=pad(film["freq_app"], 3), phase_app=pad(film["phase_app"], 3))
+    kw = dict(img_size=8, fov=12, ray_start=0.88, ray_end=1.12, num_steps=12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2, v_mean=np.pi / 2,
+              hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.3)
+    w = T(np.random.default_rng(2).normal(size=(B, 21, 8, 8)).astype(np.float32))
+    res = []
+    for gen, f in ((gens[0], film), (gens[1], film_b)):
+        ft = {k: T(v).requires_grad_(True) for k, v in f.items()}
+        torch.manual_seed(77)
+        px, _ = gen.forward_with_frequencies(ft["freq_geo"], ft["freq_app"], ft["phase_geo"], ft["phase_app"], **kw)
+        (px * w).sum().backward()
+        res.append((N_(px), {k: N_(v.grad) for k, v in ft.items()}, {n: N_(p.grad) for n, p in gen.siren.named_parameters() if p.grad is not None}))
+    (px_a, fg_a, pg_a), (px_b, fg_b, pg_b) = res
+    assert np.array_equal(px_a, px_b), "pixels of the padded evaluation are those of the 128-wide network with zero rows, bit for bit"
+    worst = 0.0
+    for k, n in (("freq_geo", 8), ("phase_geo", 8), ("freq_app", 3), ("phase_app", 3)):
+        assert fg_a[k].shape == (B, n * H)
+        worst = max(worst, _rel_err(fg_a[k], fg_b[k].reshape(B, n, Hp)[..., :H].reshape(B, n * H)))
+    for n, g in pg_a.items():
+        gb = pg_b[n]
+        assert g.shape == tuple(dict(mod.named_parameters())[n].shape)
+        if n == "spatial_embeddings":
+            ref = gb
+        elif g.ndim == 1:
+            ref = gb[:g.shape[0]]
+        elif n.startswith("color_layer_sine.0."):
+            ref = np.concatenate([gb[:H, :35], gb[:H, 35:35 + H]], 1)
+        else:
+            ref = gb[:g.shape[0], :g.shape[1]]
+        worst = max(worst, _rel_err(g, ref))
+    print(f"[parity] hidden_dim 100 (run at 128, zero-padded) vs the same network as a 128-wide module: pixels bit-identical; worst relative gradient "
+          f"difference over {len(pg_a) + 4} tensors {worst:.1e}")
+    assert worst <= 2e-6          # the same kernels on the same values; only the atomically scattered grid gradient may differ in the last bits
+    # optimizer step -> device-side re-pack through the padding -> no-grad render vs the oracle at the new weights
+    with torch.no_grad():       # an in-place update of every render parameter, 1e-3 of its gradient's scale (version counters bump like an optimizer's)
+        for n, p in mod.named_parameters():
+            if mod._is_render_param(n) and p.grad is not None:
+                p.add_(p.grad / p.grad.abs().max().clamp_min(1e-30), alpha=-1e-3)
+    sd2 = {n: N_(p) for n, p in mod.named_parameters() if mod._is_render_param(n)}
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-0.11, 0.11, (B, 64, 3)).astype(np.float32)
+    dirs = rng.normal(size=(B, 64, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    for grad_mode in (False, True):
+        with torch.set_grad_enabled(grad_mode):
+            out = N_(mod.forward_with_frequencies_phase_shifts(T(pts), T(film["freq_geo"]), T(film["freq_app"]), T(film["phase_geo"]), T(film["phase_app"]), T(dirs)))
+        ref = O.siren_forward(sd2, spec, pts, dirs, film["freq_geo"], film["phase_geo"], film["freq_app"], film["phase_app"])
+        e = np.abs(out - ref)
+        assert e[..., :-1].max() <= 2e-5 and e[..., -1].max() <= 1e-5 * max(float(np.abs(ref[..., -1]).max()), 1.0), (grad_mode, e[..., :-1].max(), e[..., -1].max())
 
 
 @pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
