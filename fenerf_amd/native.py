@@ -111,7 +111,7 @@ class NativeModel:
     # ---- hidden widths between the instantiated ones: zero padding on the way in, slicing on the way out (padded_hidden_dim above)
     @property
     def padded(self):
-        return self.logical_H != self.spec["hidden_dim"]
+        return getattr(self, "logical_H", self.spec["hidden_dim"]) != self.spec["hidden_dim"]
 
     def _pad_state(self, sd):
         if not self.padded:

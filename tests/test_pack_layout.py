@@ -244,6 +244,68 @@ def test_device_packing_reproduces_the_host_streams(precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,H,grid", [("texture", 40, 4), ("baseline", 100, 0), ("spatial", 72, 0)])
+def test_padded_hidden_width_packs_like_the_padded_state(kind, H, grid, precision):
+    """Round 6: a hidden width between the instantiated ones runs zero-padded at the next one (native.padded_hidden_dim).  Host side
+    (`_pad_state`: what fenerf_model_create / _update receive) and device side (`_flat_params` inside load_from_device) must produce the
+    SAME streams: the device packing of the module's H-wide tensors == the host packer on the padded state dict, with the bounds of
+    test_device_packing_reproduces_the_host_streams; and the padded entries of the host state are exact zeros in the right places."""
+    import torch
+    from fenerf_amd import native
+    Hp = native.padded_hidden_dim(H)
+    assert Hp > H
+    spec = proc.model_spec(kind, hidden_dim=H, grid_size=grid, z_dim=8)
+    sd = proc.make_state_dict(spec, seed=2, sigma_gain=10.0, with_mapping=False)
+    nm = object.__new__(native.NativeModel)
+    nm.logical_H = H
+    nm.spec, nm.differentiable, nm.device, nm.precision, nm._maps, nm._h = dict(spec, hidden_dim=Hp), True, torch.device("cpu"), precision, None, None
+    assert nm.padded
+    psd = nm._pad_state(sd)
+    G = spec["grid_ch"]
+    for k, v in sd.items():
+        if k == "spatial_embeddings":
+            assert psd[k] is v or np.array_equal(psd[k], v)
+            continue
+        q = psd[k]
+        if v.ndim == 1:
+            assert np.array_equal(q[:v.shape[0]], v) and not q[v.shape[0]:].any()
+        elif k.startswith("color_layer_sine.0.") or k == "color_layer_sine.layer.weight":      # [dirs | grid | x]: hidden columns are the trailing ones
+            assert q.shape == (Hp, 3 + G + Hp) and np.array_equal(q[:H, :3 + G + H], v) and not q[H:].any() and not q[:, 3 + G + H:].any()
+        else:
+            assert np.array_equal(q[:v.shape[0], :v.shape[1]], v) and not q[v.shape[0]:].any() and not q[:, v.shape[1]:].any()
+    pspec = dict(spec, hidden_dim=Hp)
+    stream, consts, bwd, _ = nm._pack_on_device({k: torch.from_numpy(v) for k, v in sd.items()})
+    blob, hconsts = _lib.pack_weights_host(psd, pspec, precision)
+    hbwd = _lib.pack_backward_host(psd, pspec, precision)
+    assert stream.numel() == blob.size and consts.numel() == hconsts.size and bwd.numel() == hbwd.size
+    fold = spec["n_label_layers"] > 1
+    if precision == "f32":
+        d = np.abs(stream.numpy() - blob)
+        assert d.max() <= (1e-7 if fold else 0) and (d != 0).mean() <= 0.05
+        np.testing.assert_allclose(bwd.numpy(), hbwd, rtol=1e-6, atol=1e-9)
+    else:
+        diff = stream.numpy().view(np.uint16) != blob.view(np.uint16)
+        assert diff.mean() <= (0.05 if fold else 0.0)
+    np.testing.assert_allclose(consts.numpy(), hconsts, rtol=0, atol=1e-7)
+    # FiLM tensors: zeros behind every layer's block, and gradients sliced back
+    t = torch.arange(2 * 3 * H, dtype=torch.float32).reshape(2, 3 * H)
+    q = nm._pad_film(t, 3)
+    assert q.shape == (2, 3 * Hp) and torch.equal(q.reshape(2, 3, Hp)[..., :H].reshape(2, 3 * H), t) and not q.reshape(2, 3, Hp)[..., H:].any()
+    ng, nc = spec["n_geo"], spec["n_color"]
+    res = dict(d_freq_geo=torch.randn(2, ng * Hp), d_phase_geo=torch.randn(2, ng * Hp), d_freq_app=torch.randn(2, nc * Hp), d_phase_app=torch.randn(2, nc * Hp),
+               geo_w=[torch.randn(Hp, 3)] + [torch.randn(Hp, Hp) for _ in range(ng - 1)], geo_b=[torch.randn(Hp) for _ in range(ng)],
+               color_w=[torch.randn(Hp, 3 + G + Hp)] + [torch.randn(Hp, Hp) for _ in range(nc - 1)], color_b=[torch.randn(Hp) for _ in range(nc)],
+               head_w=torch.randn(32, Hp), head_b=torch.randn(32), rgb_w=torch.randn(3, Hp), rgb_b=torch.randn(3))
+    u = nm._unpad_grads(res)
+    assert u["d_freq_geo"].shape == (2, ng * H) and torch.equal(u["d_freq_geo"].reshape(2, ng, H), res["d_freq_geo"].reshape(2, ng, Hp)[..., :H])
+    assert u["geo_w"][0].shape == (H, 3) and u["geo_w"][1].shape == (H, H) and u["color_w"][0].shape == (H, 3 + G + H)
+    assert torch.equal(u["color_w"][0], res["color_w"][0][:H, :3 + G + H]) and u["head_w"].shape == (32, H) and u["rgb_w"].shape == (3, H)
+    assert u["head_b"] is res["head_b"] and u["geo_b"][0].shape == (H,)
+    wts = nm._pad_weights(([torch.randn(H, 3)] + [torch.randn(H, H)] * (ng - 1), [torch.randn(H, 3 + G + H)] + [torch.randn(H, H)] * (nc - 1)))
+    assert wts[0][0].shape == (Hp, 3) and wts[0][1].shape == (Hp, Hp) and wts[1][0].shape == (Hp, 3 + G + Hp) and not wts[1][0][H:].any()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_repack_maps_cover_the_packed_buffers(precision):
     """FenerfRepackMaps (what fenerf_model_repack consumes; the kernels themselves are compared bit for bit on the GPU): sizes must add
     up to the host packer's buffers, every index must address the canonical flat parameter vector, every scaled row must be
