@@ -660,7 +660,7 @@ extern "C" int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma
                                 float* out_wsum, void* stream) {
   int rc = check_opts(opts);
   if (rc) return rc;
-  if (BR < 0 || M < 1 || M > 512 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= M <= 512, C >= 2");
+  if (BR < 0 || M < 1 || M > FENERF_MAX_RAY_SAMPLES || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= M <= 1024 (FENERF_MAX_RAY_SAMPLES), C >= 2");
   if (BR == 0) return FENERF_OK;
   if (!rgb_sigma || !z) return fail(FENERF_E_INVALID, "rgb_sigma / z is NULL");
   if (opts->fill_mode == FENERF_FILL_EVAL_WHITE_BACK && C != 4) return fail(FENERF_E_INVALID, "eval_white_back needs a 3-channel model");
@@ -676,7 +676,7 @@ extern "C" int fenerf_composite(int64_t BR, int M, int C, const float* rgb_sigma
 
 extern "C" int fenerf_resample(int64_t BR, int N, const float* z_coarse, const float* coarse_weights, const float* u,
                                float* z_fine, void* stream) {
-  if (BR < 0 || N < 3 || N > 256) return fail(FENERF_E_INVALID, "need BR >= 0 and 3 <= N <= 256");
+  if (BR < 0 || N < 3 || 2 * N > FENERF_MAX_RAY_SAMPLES) return fail(FENERF_E_INVALID, "need BR >= 0 and 3 <= N <= 512 (FENERF_MAX_RAY_SAMPLES / 2)");
   if (BR == 0) return FENERF_OK;
   if (!z_coarse || !coarse_weights || !u || !z_fine) return fail(FENERF_E_INVALID, "NULL pointer");
   { PhaseScope ph(PH_RESAMPLE, stream); return launch_resample(BR, N, z_coarse, coarse_weights, u, z_fine, stream); }
@@ -684,8 +684,8 @@ extern "C" int fenerf_resample(int64_t BR, int N, const float* z_coarse, const f
 
 extern "C" int fenerf_sample_pdf(int64_t BR, int K, int n_importance, const float* bins, const float* weights,
                                  const float* u, float* samples, void* stream) {
-  if (BR < 0 || K < 1 || K > 255 || n_importance < 1 || n_importance > 256)
-    return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= K <= 255, 1 <= n_importance <= 256");
+  if (BR < 0 || K < 1 || 2 * (K + 1) > FENERF_MAX_RAY_SAMPLES || n_importance < 1 || 2 * n_importance > FENERF_MAX_RAY_SAMPLES)
+    return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= K <= 511, 1 <= n_importance <= 512 (FENERF_MAX_RAY_SAMPLES / 2)");
   if (BR == 0) return FENERF_OK;
   if (!bins || !weights || !u || !samples) return fail(FENERF_E_INVALID, "NULL pointer");
   { PhaseScope ph(PH_RESAMPLE, stream); return launch_sample_pdf(BR, K, n_importance, bins, weights, u, samples, stream); }
@@ -697,7 +697,7 @@ extern "C" int fenerf_merge_composite(int64_t BR, int N, int C, const float* fin
                                       float* out_weights, float* out_wsum, float* out_z_sorted, void* stream) {
   int rc = check_opts(opts);
   if (rc) return rc;
-  if (BR < 0 || N < 1 || 2 * N > 512 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= N <= 256, C >= 2");
+  if (BR < 0 || N < 1 || 2 * N > FENERF_MAX_RAY_SAMPLES || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= N <= 512 (FENERF_MAX_RAY_SAMPLES / 2), C >= 2");
   if (BR == 0) return FENERF_OK;
   if (!fine || !coarse || !z_fine || !z_coarse) return fail(FENERF_E_INVALID, "NULL pointer");
   if (opts->fill_mode == FENERF_FILL_EVAL_WHITE_BACK && C != 4) return fail(FENERF_E_INVALID, "eval_white_back needs a 3-channel model");
@@ -1082,7 +1082,7 @@ extern "C" int fenerf_composite_backward(int64_t BR, int N, int C, int merge, co
   int rc = check_opts(opts);
   if (rc) return rc;
   const int M = merge ? 2 * N : N;
-  if (BR < 0 || N < 1 || M > 512 || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= samples <= 512, C >= 2");
+  if (BR < 0 || N < 1 || M > FENERF_MAX_RAY_SAMPLES || C < 2) return fail(FENERF_E_INVALID, "need BR >= 0, 1 <= samples <= 1024 (FENERF_MAX_RAY_SAMPLES), C >= 2");
   if (opts->fill_mode != FENERF_FILL_NONE) return fail(FENERF_E_UNSUPPORTED, "fill modes are not differentiated (generator.forward does not use them)");
   if (BR == 0) return FENERF_OK;
   if (!rows_a || !z_a || !g_rgb || !d_rows_a || (merge && (!rows_b || !z_b || !d_rows_b))) return fail(FENERF_E_INVALID, "NULL pointer");
@@ -1130,7 +1130,7 @@ extern "C" int fenerf_render_forward(const FenerfModel* m, int B, int R, int N, 
   if (rc) return rc;
   if (B <= 0 || R <= 0 || N <= 0) return fail(FENERF_E_INVALID, "B, R, N must be > 0");
   const int M = hierarchical ? 2 * N : N;
-  if (M > 512) return fail(FENERF_E_INVALID, "at most 512 samples per ray (256+256 hierarchical)");
+  if (M > FENERF_MAX_RAY_SAMPLES) return fail(FENERF_E_INVALID, "at most 1024 samples per ray (512 + 512 hierarchical; FENERF_MAX_RAY_SAMPLES)");
   if (hierarchical && N < 3) return fail(FENERF_E_INVALID, "hierarchical sampling needs num_steps >= 3");
   if (!origins || !dirs || !z_coarse || !out_rgb) return fail(FENERF_E_INVALID, "origins / dirs / z_coarse / out_rgb is NULL");
   if (hierarchical && !u) return fail(FENERF_E_INVALID, "hierarchical sampling needs u");
@@ -1349,7 +1349,7 @@ extern "C" int fenerf_render_forward_save(const FenerfModel* m, int B, int R, in
   int rc = check_opts(opts);
   if (rc) return rc;
   if ((rc = check_tape_format(m, tape_format))) return rc;
-  if (B <= 0 || R <= 0 || N < 3 || 2 * N > 512) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 256 (hierarchical render)");
+  if (B <= 0 || R <= 0 || N < 3 || 2 * N > FENERF_MAX_RAY_SAMPLES) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 512 (hierarchical render; FENERF_MAX_RAY_SAMPLES / 2)");
   if (opts->fill_mode != FENERF_FILL_NONE) return fail(FENERF_E_UNSUPPORTED, "fill modes are not differentiated (generator.forward does not use them)");
   if (!origins || !dirs || !z_coarse || !u || !out_rgb || !out_depth) return fail(FENERF_E_INVALID, "origins / dirs / z_coarse / u / out_rgb / out_depth is NULL");
   if (!freq_geo || !phase_geo || !freq_app || !phase_app) return fail(FENERF_E_INVALID, "film parameter pointer is NULL");
@@ -1433,7 +1433,7 @@ static int render_backward_impl(const FenerfModel* m, int B, int R, int N, int l
   int rc = check_opts(opts);
   if (rc) return rc;
   if ((rc = check_tape_format(m, tape_format))) return rc;
-  if (B <= 0 || R <= 0 || N < 3 || 2 * N > 512) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 256 (hierarchical render)");
+  if (B <= 0 || R <= 0 || N < 3 || 2 * N > FENERF_MAX_RAY_SAMPLES) return fail(FENERF_E_INVALID, "need B, R > 0 and 3 <= num_steps <= 512 (hierarchical render; FENERF_MAX_RAY_SAMPLES / 2)");
   if (!save || !grads || !workspace || (stage != 2 && (!z_coarse || !g_rgb))) return fail(FENERF_E_INVALID, "NULL pointer");
   if (!grads->d_freq_geo || !grads->d_phase_geo || !grads->d_freq_app || !grads->d_phase_app) return fail(FENERF_E_INVALID, "grads: film pointer is NULL");
   int have = 0, want = 0;

@@ -16,16 +16,20 @@ namespace fenerf {
 // ------------------------------------------------------------------------------------------------
 // composite (+ optional merge of fine/coarse): one wave per ray
 // ------------------------------------------------------------------------------------------------
+// waves (= rays in flight) per workgroup: four, two for rays of more than 512 samples (their four LDS arrays are 16 KiB per wave)
+template <int MAXM> struct RayWaves { static constexpr int n = MAXM > 512 ? 2 : 4; };
+
 template <bool MERGE, int MAXM>
-__global__ __launch_bounds__(256) void composite_kernel(CompositeParams P) {
-  __shared__ float s_z[4][MAXM];      // z by source index (merge) / sorted z
-  __shared__ float s_zs[4][MAXM + 1]; // sorted z
-  __shared__ int s_ord[4][MAXM];      // sorted position -> source index
-  __shared__ float s_w[4][MAXM];      // weights by sorted position
+__global__ __launch_bounds__(64 * RayWaves<MAXM>::n) void composite_kernel(CompositeParams P) {
+  constexpr int WPB = RayWaves<MAXM>::n;
+  __shared__ float s_z[WPB][MAXM];      // z by source index (merge) / sorted z
+  __shared__ float s_zs[WPB][MAXM + 1]; // sorted z
+  __shared__ int s_ord[WPB][MAXM];      // sorted position -> source index
+  __shared__ float s_w[WPB][MAXM];      // weights by sorted position
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long nwaves = (long long)gridDim.x * 4;
-  for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
+  const long long nwaves = (long long)gridDim.x * WPB;
+  for (long long ray = (long long)blockIdx.x * WPB + wv; ray < P.BR; ray += nwaves) {
     composite_ray<MERGE, MAXM>(P, ray, lane, s_z[wv], s_zs[wv], s_ord[wv], s_w[wv]);
     __builtin_amdgcn_wave_barrier();
   }
@@ -49,20 +53,20 @@ __device__ __forceinline__ float wave_suffix_incl(float v, int lane) {   // incl
 }
 
 template <bool MERGE, int MAXM>
-__global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams P) {
-  constexpr int SLOTS = MAXM / 64;
-  __shared__ float s_z[4][MAXM];
-  __shared__ float s_zs[4][MAXM + 1];
-  __shared__ int s_ord[4][MAXM];
+__global__ __launch_bounds__(64 * RayWaves<MAXM>::n) void composite_backward_kernel(CompositeParams P) {
+  constexpr int SLOTS = MAXM / 64, WPB = RayWaves<MAXM>::n;
+  __shared__ float s_z[WPB][MAXM];
+  __shared__ float s_zs[WPB][MAXM + 1];
+  __shared__ int s_ord[WPB][MAXM];
   // gradient rows of one ray, by SOURCE index, for a coalesced write-out (round 3: every lane writing its own 88-byte row channel by
   // channel cost 5x the bytes at the memory side -- PMC WRITE_SIZE 369 MB for 69 MB of gradients); rays of up to CB_STAGE_M samples
   constexpr int CB_STAGE_M = 64, CB_STAGE_C = 24;
-  __shared__ float s_out[4][MAXM <= 256 ? CB_STAGE_M * CB_STAGE_C : 1];
+  __shared__ float s_out[WPB][MAXM <= 256 ? CB_STAGE_M * CB_STAGE_C : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int M = P.M, C = P.C, N = P.N, nch = C - 1;
   const bool staged = MAXM <= 256 && M <= CB_STAGE_M && C <= CB_STAGE_C;
-  const long long nwaves = (long long)gridDim.x * 4;
-  for (long long ray = (long long)blockIdx.x * 4 + wv; ray < P.BR; ray += nwaves) {
+  const long long nwaves = (long long)gridDim.x * WPB;
+  for (long long ray = (long long)blockIdx.x * WPB + wv; ray < P.BR; ray += nwaves) {
     // ---- sorted order (identical to the forward kernel)
     if (MERGE) {
 #pragma unroll
@@ -210,21 +214,28 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(CompositeParams
   }
 }
 
+// one launch of a wave-per-ray kernel instantiated for MAXM samples per ray
+template <int MAXM, typename K, typename... A>
+static void launch_rays(K kernel, long long rays, void* stream, A... args) {
+  constexpr int WPB = RayWaves<MAXM>::n;
+  long long blocks = (rays + WPB - 1) / WPB;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPB), 0, (hipStream_t)stream, args...);
+}
+
+// the smallest MAXM that holds the ray (a skipped slot contributes exact zeros: the result does not depend on it; fewer registers + LDS)
+#define FENERF_BY_RAY_SAMPLES(M, KERNEL, FLAG, rays, stream, ...)                                    \
+  do {                                                                                               \
+    if ((M) <= 128) launch_rays<128>(KERNEL<FLAG, 128>, rays, stream, __VA_ARGS__);                  \
+    else if ((M) <= 256) launch_rays<256>(KERNEL<FLAG, 256>, rays, stream, __VA_ARGS__);             \
+    else if ((M) <= 512) launch_rays<512>(KERNEL<FLAG, 512>, rays, stream, __VA_ARGS__);             \
+    else launch_rays<1024>(KERNEL<FLAG, 1024>, rays, stream, __VA_ARGS__);                           \
+  } while (0)
+
 int launch_composite_backward(const CompositeParams& p, bool merge, void* stream) {
   if (p.BR <= 0) return FENERF_OK;
-  long long blocks = (p.BR + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
-  // the smallest MAXM that holds the ray (a skipped slot contributes exact zeros: the result does not depend on it; fewer registers + LDS)
-  const bool big = p.M > 256, small = p.M <= 128;
-  if (merge) {
-    if (big) hipLaunchKernelGGL((composite_backward_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else if (small) hipLaunchKernelGGL((composite_backward_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((composite_backward_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  } else {
-    if (big) hipLaunchKernelGGL((composite_backward_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else if (small) hipLaunchKernelGGL((composite_backward_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((composite_backward_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  }
+  if (merge) FENERF_BY_RAY_SAMPLES(p.M, composite_backward_kernel, true, p.BR, stream, p);
+  else FENERF_BY_RAY_SAMPLES(p.M, composite_backward_kernel, false, p.BR, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error(std::string("composite_backward launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
   return FENERF_OK;
@@ -235,7 +246,7 @@ int launch_composite_backward(const CompositeParams& p, bool merge, void* stream
 // ------------------------------------------------------------------------------------------------
 // RAW = false: zc [BR,N], wc [BR,N] (coarse z / weights), K = N-2, draws N samples      (generators.py:486-499)
 // RAW = true : zc = bins [BR,K+1], wc = weights [BR,K] as the caller passes them to sample_pdf, draws NS samples
-// RS = 64-sample slots per lane: K + 1 <= 64 RS knots, NS <= 64 RS draws (2: the reference's curricula; 4: up to 256 samples)
+// RS = 64-sample slots per lane: K + 1 <= 64 RS knots, NS <= 64 RS draws (2: the reference's curricula; 4: up to 256 samples; 8: up to 512)
 template <bool RAW, int RS>
 __global__ __launch_bounds__(256) void resample_kernel(long long BR, int K, int NS, const float* __restrict__ zc,
                                                        const float* __restrict__ wc, const float* __restrict__ u,
@@ -377,18 +388,8 @@ static int hip_fail2(hipError_t e, const char* what) {
 
 int launch_composite(const CompositeParams& p, bool merge, void* stream) {
   if (p.BR <= 0) return FENERF_OK;
-  long long blocks = (p.BR + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
-  const bool big = p.M > 256, small = p.M <= 128;   // smallest MAXM that holds the ray (same results: fenerf_composite_ray.h)
-  if (merge) {
-    if (big) hipLaunchKernelGGL((composite_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else if (small) hipLaunchKernelGGL((composite_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((composite_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  } else {
-    if (big) hipLaunchKernelGGL((composite_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else if (small) hipLaunchKernelGGL((composite_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((composite_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  }
+  if (merge) FENERF_BY_RAY_SAMPLES(p.M, composite_kernel, true, p.BR, stream, p);   // same results for any MAXM: fenerf_composite_ray.h
+  else FENERF_BY_RAY_SAMPLES(p.M, composite_kernel, false, p.BR, stream, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "composite launch");
 }
@@ -397,7 +398,8 @@ int launch_resample(long long BR, int N, const float* z, const float* w, const f
   if (BR <= 0) return FENERF_OK;
   long long blocks = (BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  if (N > 128) hipLaunchKernelGGL((resample_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
+  if (N > 256) hipLaunchKernelGGL((resample_kernel<false, 8>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
+  else if (N > 128) hipLaunchKernelGGL((resample_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
   else hipLaunchKernelGGL((resample_kernel<false, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, N - 2, N, z, w, u, zf);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "resample launch");
@@ -407,7 +409,8 @@ int launch_sample_pdf(long long BR, int K, int NS, const float* bins, const floa
   if (BR <= 0) return FENERF_OK;
   long long blocks = (BR + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  if (K > 127 || NS > 128) hipLaunchKernelGGL((resample_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
+  if (K > 255 || NS > 256) hipLaunchKernelGGL((resample_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
+  else if (K > 127 || NS > 128) hipLaunchKernelGGL((resample_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
   else hipLaunchKernelGGL((resample_kernel<true, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, BR, K, NS, bins, w, u, out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FENERF_OK : hip_fail2(e, "sample_pdf launch");

@@ -12,7 +12,7 @@
 
 namespace fenerf {
 
-// MAXM (template parameter: 128 in the fused render launch, 256 or 512 in the stand-alone kernels): samples per ray handled by one wave;
+// MAXM (template parameter: 128 in the fused render launch, 128 ... 1024 in the stand-alone kernels): samples per ray handled by one wave;
 // SLOTS = MAXM / 64 samples per lane: slot s of lane l is sample 64 s + l (slots past M are skipped, and a skipped slot contributes exact
 // zeros: the result does not depend on MAXM).  The launchers pick the smallest that fits (LDS and registers).
 

@@ -63,6 +63,10 @@ enum {
 #define FENERF_MAX_GEO 8
 #define FENERF_MAX_COLOR 4
 #define FENERF_MAX_LABEL_LAYERS 3
+/* Samples per ray one wavefront composites (lane = sample, up to 16 samples per lane): 512 coarse + 512 fine of a hierarchical render, or
+ * 1024 samples of a single pass.  The reference has no limit (its tensors are [B, R, M, C]); its curricula use 12 ... 48 + 48
+ * (curriculums.py), the inversion / video scripts up to 48 + 48.  More than this returns FENERF_E_INVALID. */
+#define FENERF_MAX_RAY_SAMPLES 1024
 /* Format of the tape fenerf_siren_forward_save_fmt writes and the backward entry points read (FENERF_PREC_F16X3 models; exact-fp32
  * models keep FENERF_TAPE_F32):  F32 = the pre-FiLM accumulators, 4 bytes per (point, FiLM-layer feature) -- everything the backward
  * may want; U16 = frac(theta) as 16-bit fixed point, 2 bytes -- all that sin / cos need (siren.py:113-123), +-4.8e-5 rad per recomputed
@@ -371,7 +375,7 @@ int fenerf_sample_pdf(int64_t BR, int K, int n_importance, const float* bins, co
                       float* samples, void* stream);
 
 /* replaces: cat([fine, coarse]) -> torch.sort(z) -> gather -> fancy_integration (generators.py:508-519):
- * merges without materialising the sorted [BR,2N,C] tensor.  fine/coarse [BR,N,C] (N <= 256), z_* [BR,N], noise [BR,2N] or NULL
+ * merges without materialising the sorted [BR,2N,C] tensor.  fine/coarse [BR,N,C] (2 N <= FENERF_MAX_RAY_SAMPLES), z_* [BR,N], noise [BR,2N] or NULL
  * (indexed by SORTED position, like the reference's noise tensor).  out_weights [BR,2N] in sorted order or NULL;
  * out_z_sorted [BR,2N] or NULL. */
 int fenerf_merge_composite(int64_t BR, int N, int C, const float* fine, const float* coarse, const float* z_fine,

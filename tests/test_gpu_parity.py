@@ -206,9 +206,10 @@ def test_composite_variants_vs_reference():
 
 
 def test_composite_max_samples_and_empty():
-    """M = 512 (eight samples per lane, the documented maximum; up to 256 the four-slot kernel runs), slot boundaries, M = 1, zero rays."""
+    """M = 1024 (sixteen samples per lane, FENERF_MAX_RAY_SAMPLES; the smallest of the 2- / 4- / 8- / 16-slot kernels that holds the ray
+    runs), slot boundaries, M = 1, zero rays."""
     rng = np.random.default_rng(5)
-    for M in (512, 449, 257, 256, 193, 129, 128, 65, 64, 1):
+    for M in (1024, 961, 770, 513, 512, 449, 257, 256, 193, 129, 128, 65, 64, 1):
         rs = rng.normal(size=(3, 7, M, 22)).astype(np.float32)
         rs[..., -1] *= 30
         z = np.sort(rng.uniform(0.88, 1.12, (3, 7, M, 1)).astype(np.float32), axis=2)
@@ -224,7 +225,7 @@ def test_composite_max_samples_and_empty():
     e = native.composite(torch.empty((0, 4, 22), device=DEV), torch.empty((0, 4), device=DEV), None, _lib.composite_opts("relu"))
     assert e[0].shape == (0, 21)
     with pytest.raises(_lib.FenerfError):
-        native.composite(torch.zeros((1, 513, 22), device=DEV), torch.zeros((1, 513), device=DEV), None, _lib.composite_opts("relu"))
+        native.composite(torch.zeros((1, 1025, 22), device=DEV), torch.zeros((1, 1025), device=DEV), None, _lib.composite_opts("relu"))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -253,10 +254,11 @@ def test_sample_pdf_and_resample_vs_reference():
         native.resample(torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV), torch.zeros((4, 2), device=DEV))
 
 
-@pytest.mark.parametrize("N", [129, 200, 256])
+@pytest.mark.parametrize("N", [129, 200, 256, 257, 400, 512])
 def test_more_than_128_samples_per_pass(N):
-    """The reference has no limit on num_steps; one wave per ray handles up to 256 + 256: resample (four 64-sample slots), the
-    rank-merge composite on 2 N <= 512 samples and its backward, against the oracle / torch autograd."""
+    """The reference has no limit on num_steps; one wave per ray handles up to 512 + 512 (FENERF_MAX_RAY_SAMPLES): resample (four / eight
+    64-sample slots), the rank-merge composite on 2 N <= 1024 samples, and the whole render, against the oracle (the backward at these
+    sizes: test_composite_backward_vs_autograd, test_merge_composite_backward_vs_autograd)."""
     rng = np.random.default_rng(N)
     BR, C = 9, 22
     z_c = np.sort(rng.uniform(0.88, 1.12, (BR, N)).astype(np.float32), axis=1)
@@ -269,6 +271,13 @@ def test_more_than_128_samples_per_pass(N):
     print(f"[parity] resample N={N}: max|err| {np.abs(N_(zf) - ref).max():.3e}")
     np.testing.assert_allclose(N_(zf), ref, atol=6e-5)
     assert np.abs(N_(zf) - ref).mean() < 1e-6
+    # sample_pdf in its reference shape (bins [BR, K + 1], weights [BR, K]) with as many knots and draws
+    bins = np.sort(rng.uniform(0.88, 1.12, (BR, N)).astype(np.float32), axis=1)
+    wk = (rng.random((BR, N - 1)).astype(np.float32) ** 4)
+    s = native.sample_pdf(T(bins), T(wk), T(u))
+    rs_ = O.sample_pdf(bins, wk, u)
+    np.testing.assert_allclose(N_(s), rs_, atol=6e-5)
+    assert np.abs(N_(s) - rs_).mean() < 1e-6
     fine = rng.normal(size=(BR, N, C)).astype(np.float32); coarse = rng.normal(size=(BR, N, C)).astype(np.float32)
     fine[..., -1] *= 30; coarse[..., -1] *= 30
     z_f = N_(zf)
@@ -1383,7 +1392,7 @@ def _grad_case(BR, N, C, seed, merge):
 @pytest.mark.parametrize("clamp,last_back,white,black,noise_std", [("relu", False, False, False, 0.0), ("softplus", False, False, False, 0.5),
                                                                     ("relu", True, False, False, 0.3), ("relu", False, True, False, 0.0),
                                                                     ("softplus", True, False, True, 0.2)])
-@pytest.mark.parametrize("N", [1, 7, 24, 64, 100, 150, 256, 300, 512])
+@pytest.mark.parametrize("N", [1, 7, 24, 64, 100, 150, 256, 300, 512, 700, 1024])
 def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise_std):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(37, N, 22, 5 + N, False)
@@ -1400,7 +1409,7 @@ def test_composite_backward_vs_autograd(N, clamp, last_back, white, black, noise
     assert err <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("N", [12, 24, 64, 72, 128, 200])
+@pytest.mark.parametrize("N", [12, 24, 64, 72, 128, 200, 300, 512])
 def test_merge_composite_backward_vs_autograd(N):
     from oracle import fenerf_oracle_grad as OG
     rows, z, noise, g = _grad_case(29, N, 22, 40 + N, True)
