@@ -138,6 +138,162 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
     return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()
 
 
+def film_from_inversion(meta, device=None):
+    """(freq_geo, freq_app, phase_geo, phase_app) = mean + offset of an inversion checkpoint (the dict inverse_render returns / the
+    reference's `freq_phase_offset_<name>.pth`), in forward_with_frequencies' argument order (extract_double_semantic_shapes.py:127-133,
+    inverse_render_double_semantic.py:465-467)."""
+    t = (lambda v: v.detach().to(device)) if device is not None else (lambda v: v.detach())
+    return (t(meta["w_geo_frequencies"]) + t(meta["w_geo_frequency_offsets"]), t(meta["w_app_frequencies"]) + t(meta["w_app_frequency_offsets"]),
+            t(meta["w_geo_phase_shifts"]) + t(meta["w_geo_phase_shift_offsets"]), t(meta["w_app_phase_shifts"]) + t(meta["w_app_phase_shift_offsets"]))
+
+
+def sample_generator_wth_frequencies_phase_shifts(generator, meta, max_batch=None, voxel_resolution=256, voxel_origin=(0, 0, 0),
+                                                  cube_length=2.0, psi=0.5):
+    """Density volume [N,N,N] of an INVERTED identity (extract_double_semantic_shapes.py:65-87, the reference's spelling of the name):
+    meta carries 'truncated_frequencies_geo' / '_app' and 'truncated_phase_shifts_geo' / '_app' (the script fills them with mean +
+    offset of an inversion checkpoint, :127-133 -- film_from_inversion above); view direction locked to (0, 0, -1); `max_batch` and `psi`
+    are accepted and ignored (the reference ignores psi here too)."""
+    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length)
+    samples = samples.to(generator.device)
+    with torch.no_grad():
+        out = generator.siren.native(samples.device).siren_forward(samples, None, meta["truncated_frequencies_geo"], meta["truncated_phase_shifts_geo"],
+                                                                   meta["truncated_frequencies_app"], meta["truncated_phase_shifts_app"])
+    return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()
+
+
+# ---- the inversion script's host pieces (inverse_render_double_semantic.py) ------------------------------------------------------------
+COLOR_MAP_COMPLETE_KEYS = 19      # labels 0 (background) .. 18 of the script's COLOR_MAP_COMPLETE (:50-69); COLOR_MAP has 1 .. 18
+
+
+def mask2labels(mask_np, n_labels=18):
+    """One-hot [n_labels, H, W] float64 of a label image (:82-92): 19 labels -> channel i is label i; 18 -> channel i is label i + 1
+    (background dropped)."""
+    labels = np.zeros((n_labels, mask_np.shape[0], mask_np.shape[1]))
+    for i in range(n_labels):
+        labels[i][mask_np == (i if n_labels == 19 else i + 1)] = 1.0
+    return labels
+
+
+def mIOU(source, target):
+    """(:122-126) mean over classes of |s * t| / (|s + t > 0| + 1e-6), per image"""
+    return torch.mean(torch.div(torch.sum(source * target, dim=[2, 3]).float(), torch.sum((source + target) > 0, dim=[2, 3]).float() + 1e-6), dim=1)
+
+
+def _pil_resize_shorter(img, size, resample):
+    """torchvision.transforms.Resize(int) on a PIL image: the shorter side becomes `size`, the other int(size * long / short)"""
+    w, h = img.size
+    if (w <= h and w == size) or (h <= w and h == size):
+        return img
+    if w < h:
+        return img.resize((size, int(size * h / w)), resample)
+    return img.resize((int(size * w / h), size), resample)
+
+
+def _pil_center_crop(img, size):
+    """torchvision.transforms.CenterCrop(size) for an image at least that large: left/top = round((dim - size) / 2)"""
+    w, h = img.size
+    left, top = int(round((w - size) / 2.0)), int(round((h - size) / 2.0))
+    return img.crop((left, top, left + size, top + size))
+
+
+def _pil_to_tensor(img):
+    """transforms.ToTensor(): [C, H, W] float in [0, 1] ('L' -> one channel)"""
+    a = np.asarray(img, dtype=np.uint8)
+    a = a[:, :, None] if a.ndim == 2 else a
+    return torch.from_numpy(np.array(a.transpose(2, 0, 1))).float().div(255)
+
+
+def inversion_targets(gt_image, gt_seg, image_size=256, no_center_crop=False, background_mask=False, white_background_mask=False):
+    """The targets of one inversion from two PIL images -- an RGB photo and its 'L' label map (values 0 .. 18) -- as
+    inverse_render_double_semantic.py:178-222, :290-327 builds them with torchvision transforms (restated on PIL directly: Resize(320,
+    bilinear) -> CenterCrop(256) -> Resize((S, S), NEAREST) -> ToTensor [-> Normalize(0.5, 0.5)]; `no_center_crop`: the last resize only):
+    -> gt_image [1,3,S,S] in [-1,1], gt_seg_18 [1,18,S,S] in {-1,1}, gt_seg_19 [1,19,256,256] in {0,1} (the mIoU target, always 256^2).
+    background_mask / white_background_mask paint the photo 0 / 1 where the label map is 0 (:295-310)."""
+    from PIL import Image
+    gt_image, gt_seg = gt_image.convert("RGB"), gt_seg.convert("L")
+    if background_mask or white_background_mask:
+        i = _pil_to_tensor(gt_image)
+        lab = _pil_to_tensor(gt_seg.resize(gt_image.size, resample=Image.NEAREST)) * 255.0
+        i[lab.expand_as(i) == 0] = 0.0 if background_mask else 1.0
+        gt_image = Image.fromarray(i.mul(255).byte().permute(1, 2, 0).numpy())     # transforms.ToPILImage() of a float tensor: mul(255).byte()
+
+    def pipeline(img, size):
+        if not no_center_crop:
+            img = _pil_center_crop(_pil_resize_shorter(img, 320, Image.BILINEAR), 256)
+        return _pil_to_tensor(img.resize((size, size), Image.NEAREST))
+
+    image = (pipeline(gt_image, image_size) - 0.5) / 0.5
+    seg18 = (torch.tensor(mask2labels((pipeline(gt_seg, image_size) * 255.0)[0].numpy(), 18), dtype=torch.float) - 0.5) / 0.5
+    seg19 = torch.tensor(mask2labels((pipeline(gt_seg, 256) * 255.0)[0].numpy(), 19), dtype=torch.float)
+    return image[None], seg18[None], seg19[None]
+
+
+def inversion_options(image_size=256, fov=12, device=None):
+    """The kwargs bag of the optimisation renders (:225-247): 24 coarse samples only, frontal camera, eval fill mode"""
+    import math
+    hv = torch.tensor(math.pi / 2)
+    hv = hv.to(device) if device is not None else hv
+    return {'img_size': image_size, 'fov': fov, 'ray_start': 0.88, 'ray_end': 1.12, 'num_steps': 24, 'h_stddev': 0, 'v_stddev': 0,
+            'h_mean': hv, 'v_mean': hv.clone(), 'hierarchical_sample': False, 'sample_dist': None, 'clamp_mode': 'relu', 'nerf_noise': 0,
+            'fade_steps': 10000, 'z_app_lambda': 0, 'z_geo_lambda': 0, 'pos_lambda': 0, 'tok_interval': 2000, 'tok_v': 0.6, 'betas': (0, 0.9),
+            'fill_mode': 'eval_seg_padding_background'}
+
+
+def inversion_render_options(fov=12, fill_color='black', img_size=256, num_steps=48):
+    """The kwargs bag of the preview / reconstruction renders (:249-265): 256^2, 48 + 48 samples"""
+    import math
+    return {'img_size': img_size, 'fov': fov, 'ray_start': 0.88, 'ray_end': 1.12, 'num_steps': num_steps, 'h_stddev': 0, 'v_stddev': 0,
+            'v_mean': math.pi / 2, 'hierarchical_sample': True, 'sample_dist': None, 'clamp_mode': 'relu', 'nerf_noise': 0, 'last_back': False,
+            'fill_mode': 'eval_seg_padding_background', 'fill_color': fill_color}
+
+
+def inversion_trajectory(name, num_frames, fov):
+    """[(t, pitch, yaw, fov)] of the inversion script's set_trajectory (:504-570): the video script's trajectories plus 'inverse_sphere'
+    and 'rotation_linear'; its 'zoom' runs t over linspace(-1, 1) (50 frames whatever num_frames says) with fov + 5 + 5 sin(2 pi t)."""
+    pi = np.pi
+    if name in ("front", "orbit", "non_rotation", "sphere", "rotation_horizontal"):
+        return camera_trajectory(name, num_frames, fov)
+    if name == "inverse_sphere":
+        return [(t, 0.2 * (1 - np.cos(t * 2 * pi)) + pi / 2, 0.4 * np.sin(t * 2 * pi) + pi / 2, fov) for t in np.linspace(0, 1, num_frames)]
+    if name == "zoom":
+        return [(t, pi / 2, pi / 2, fov + 5 + np.sin(t * 2 * pi) * 5) for t in np.linspace(-1, 1)]
+    if name == "rotation_linear":
+        return [(t, pi / 2, pi / 2 + t, fov) for t in np.linspace(-0.4, 0.4, num_frames)]
+    raise ValueError(f"unknown trajectory {name!r} (front | orbit | non_rotation | sphere | inverse_sphere | rotation_horizontal | zoom | rotation_linear)")
+
+
+def render_inversion_views(generator, meta, render_options, angles=(0.0,), max_batch_size=2400000, lock_view_dependence=False):
+    """staged_forward_with_frequencies of an inversion state at yaws pi/2 + angle (:419-431, :441-446) -> [(angle, frame [1,22,S,S])]"""
+    import math
+    film = film_from_inversion(meta)
+    out = []
+    with torch.no_grad():
+        for angle in angles:
+            img, _, _ = generator.staged_forward_with_frequencies(*film, h_mean=math.pi / 2 + angle, max_batch_size=max_batch_size,
+                                                                  lock_view_dependence=lock_view_dependence, **render_options)
+            out.append((angle, img))
+    return out
+
+
+def render_inversion_recon(generator, meta, render_options, trajectory, max_batch_size=2400000, lock_view_dependence=False):
+    """The frames of run_render_recon_video (:462-501): per trajectory entry one staged render of the inverted identity at (pitch, yaw) --
+    the trajectory's fov is NOT applied (the reference sets only h_mean / v_mean) -- as uint8 [S, 3 S, 3] RGB panels
+    [image | label colours | 0.5 / 0.5 blend] (the reference hands them to cv2 as BGR)."""
+    from . import imageio_lite
+    film = film_from_inversion(meta)
+    kw = dict(render_options)
+    frames = []
+    to_u8 = lambda t: imageio_lite.to_uint8_hwc(imageio_lite.make_grid(t, normalize=True))     # tensor_to_PIL (:114-119)
+    with torch.no_grad():
+        for _, pitch, yaw, _ in trajectory:
+            kw.update(h_mean=float(yaw), v_mean=float(pitch))
+            frame, _, _ = generator.staged_forward_with_frequencies(*film, max_batch_size=max_batch_size, lock_view_dependence=lock_view_dependence, **kw)
+            image, sem = to_u8(frame[:, -3:].cpu()), to_u8(mask2color(frame[:, :-3]).cpu())
+            blend = image * 0.5 + sem * 0.5
+            frames.append(np.concatenate([image, sem, blend], axis=1).astype("uint8"))
+    return frames
+
+
 def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_psi=0.0, lambda_seg=1.0, lambda_img=1.0,
                    lambda_percept=0.0, lambda_norm=0.0, percept=None, z_dim=256, lr=1e-2, on_step=None, latent_noise=0.03,
                    n_mean_latents=10000, record_offsets=False):
@@ -197,8 +353,10 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
         losses.append(float(loss.detach()))
         if record_offsets:
             history.append(tuple(o.detach().cpu().clone() for o in (o_gf, o_gp, o_af, o_ap)))
-        if on_step is not None:
-            on_step(i, losses[-1])
+        if on_step is not None:      # (i, loss, the reference's checkpoint dict at this iteration: what its in-loop preview renders use, :419-452)
+            on_step(i, losses[-1], dict(w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
+                                        w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
+                                        w_app_frequency_offsets=o_af.detach(), w_app_phase_shift_offsets=o_ap.detach()))
     extra = dict(offset_history=history) if record_offsets else {}
     return dict(**extra, w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
                 w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),

@@ -107,3 +107,53 @@ class AviWriter:
         with open(self.path, "wb") as fh:
             fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
         self.frames = []
+
+
+def write_mrc(path, volume):
+    """A float32 volume [nz, ny, nx] as an MRC2014 map (mode 2) -- what the reference's shape scripts write through
+    `mrcfile.new_mmap(path, shape=volume.shape, mrc_mode=2); mrc.data[:] = volume` (extract_double_semantic_shapes.py:120-121; mrcfile is
+    not a dependency here).  1024-byte little-endian header in mrcfile's defaults for a new volume: nx / ny / nz = mx / my / mz = the
+    array's axes reversed, cell = one unit per voxel, 90-degree angles, axis order (1, 2, 3), ISPG 1, density statistics of the
+    data, 'MAP ' + machine stamp 0x44 0x44, NVERSION 20140.  Readable by mrcfile, ChimeraX and read_mrc below."""
+    vol = np.ascontiguousarray(volume, dtype="<f4")
+    if vol.ndim != 3:
+        raise ValueError(f"write_mrc: a 3-d volume, got shape {vol.shape}")
+    nz, ny, nx = vol.shape
+    h = bytearray(1024)
+    struct.pack_into("<3i", h, 0, nx, ny, nz)
+    struct.pack_into("<i", h, 12, 2)                                   # MODE 2: 32-bit float
+    struct.pack_into("<3i", h, 16, 0, 0, 0)                            # nxstart ..
+    struct.pack_into("<3i", h, 28, nx, ny, nz)                         # mx, my, mz
+    struct.pack_into("<3f", h, 40, float(nx), float(ny), float(nz))    # cella: voxel size 1
+    struct.pack_into("<3f", h, 52, 90.0, 90.0, 90.0)                   # cellb
+    struct.pack_into("<3i", h, 64, 1, 2, 3)                            # mapc, mapr, maps
+    dmin, dmax, dmean = (float(vol.min()), float(vol.max()), float(vol.mean(dtype=np.float64))) if vol.size else (0.0, 0.0, 0.0)
+    rms = float(np.sqrt(((vol.astype(np.float64) - dmean) ** 2).mean())) if vol.size else 0.0
+    struct.pack_into("<3f", h, 76, dmin, dmax, dmean)
+    struct.pack_into("<i", h, 88, 1)                                   # ISPG 1: a volume (0 would be an image stack)
+    struct.pack_into("<i", h, 92, 0)                                   # NSYMBT
+    h[104:108] = b"MRCO"                                               # EXTTYP (mrcfile's default)
+    struct.pack_into("<i", h, 108, 20140)                              # NVERSION
+    h[208:212] = b"MAP "
+    h[212:216] = bytes([0x44, 0x44, 0x00, 0x00])                       # machine stamp: little-endian
+    struct.pack_into("<f", h, 216, rms)
+    label = b"fenerf_amd.imageio_lite.write_mrc"
+    struct.pack_into("<i", h, 220, 1)                                  # NLABL
+    h[224:224 + len(label)] = label
+    with open(path, "wb") as f:
+        f.write(bytes(h))
+        f.write(vol.tobytes())
+
+
+def read_mrc(path):
+    """(volume [nz, ny, nx] float32, header dict) of a mode-2 MRC file (the inverse of write_mrc; tests and the marching-cubes step of a
+    downstream tool)."""
+    raw = open(path, "rb").read()
+    nx, ny, nz, mode = struct.unpack_from("<4i", raw, 0)
+    if raw[208:212] != b"MAP " or mode != 2:
+        raise ValueError(f"{path}: not a mode-2 MRC map")
+    nsymbt = struct.unpack_from("<i", raw, 92)[0]
+    data = np.frombuffer(raw, "<f4", nx * ny * nz, 1024 + nsymbt).reshape(nz, ny, nx)
+    dmin, dmax, dmean = struct.unpack_from("<3f", raw, 76)
+    return data, dict(nx=nx, ny=ny, nz=nz, mode=mode, cella=struct.unpack_from("<3f", raw, 40), ispg=struct.unpack_from("<i", raw, 88)[0],
+                      dmin=dmin, dmax=dmax, dmean=dmean, rms=struct.unpack_from("<f", raw, 216)[0], nversion=struct.unpack_from("<i", raw, 108)[0])

@@ -148,3 +148,106 @@ print("ok")
 ''' % (ROOT, str(tmp_path / "ema.pth"), str(tmp_path / "lin.pth"))
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
+
+
+def test_inversion_and_shape_front_ends_mirror_the_reference_scripts():
+    """tools/inverse_render.py / tools/extract_shapes.py: the argparse surfaces of inverse_render_double_semantic.py:132-169 and
+    extract_double_semantic_shapes.py:90-97, option for option and default for default."""
+    import extract_shapes
+    import inverse_render
+    d = inverse_render.build_parser().parse_args(["debug", "ckpt/7000_generator.pth"])
+    assert (d.name, d.generator_path, d.image_path, d.seg_path, d.save_dir, d.load_checkpoint, d.seeds, d.init_seed, d.image_size, d.fov,
+            d.num_frames, d.max_batch_size, d.lock_view_dependence, d.iteration, d.background_mask, d.white_background_mask, d.inverse_type,
+            d.img_loss, d.seg_loss, d.lambda_img, d.lambda_seg, d.lambda_percept, d.lambda_norm, d.latent_normalize, d.latent_type, d.psi,
+            d.init_psi, d.trajectory, d.depth_map, d.save_with_video, d.recon, d.fill_color, d.no_center_crop, d.checkpoint_path) == \
+        ("debug", "ckpt/7000_generator.pth", None, None, None, False, [0], 0, 256, 12, 100, 2400000, False, 1000, False, False, "semantic",
+         "mse", "mse", 0.0, 0.0, 0.0, 1.0, False, "app", 0, 0, "front", False, False, False, "black", False, "")
+    o = inverse_render.build_parser().parse_args(["n", "g.pth", "--image_path", "a.jpg", "--seg_path", "a.png", "--save_dir", "o", "--iteration", "7",
+                                                  "--lambda_seg", "1", "--lambda_img", "0.5", "--latent_normalize", "--recon", "--trajectory",
+                                                  "rotation_linear", "--fill_color", "white", "--no_center_crop", "--white_background_mask"])
+    assert (o.iteration, o.lambda_seg, o.lambda_img, o.latent_normalize, o.recon, o.trajectory, o.fill_color, o.no_center_crop,
+            o.white_background_mask) == (7, 1.0, 0.5, True, True, "rotation_linear", "white", True, True)
+    assert inverse_render.PREVIEW_ANGLES == (-0.5, -0.4, -0.3, -0.2, -0.1, 0, 0.1, 0.2, 0.3, 0.4, 0.5)
+    s = extract_shapes.build_parser().parse_args(["g.pth"])
+    assert (s.path, s.seeds, s.cube_size, s.voxel_resolution, s.output_dir, s.latent_path) == ("g.pth", [3, 4, 5], 0.3, 256, "shapes", None)
+    s = extract_shapes.build_parser().parse_args(["g.pth", "--seeds", "9", "--cube_size", "0.5", "--voxel_resolution", "64", "--output_dir", "x",
+                                                  "--latent_path", "m.pth"])
+    assert (s.seeds, s.cube_size, s.voxel_resolution, s.output_dir, s.latent_path) == (["9"], 0.5, 64, "x", "m.pth")
+
+
+def test_mrc_writer_round_trip_and_header(tmp_path):
+    """imageio_lite.write_mrc: the mode-2 MRC2014 map the reference's shape scripts write through mrcfile (extract_double_semantic_shapes.py:
+    120-121): header words at their MRC2014 byte offsets, data in [nz][ny][nx] order."""
+    rng = np.random.default_rng(3)
+    vol = rng.normal(size=(3, 4, 5)).astype(np.float32)
+    p = str(tmp_path / "v.mrc")
+    imageio_lite.write_mrc(p, vol)
+    raw = open(p, "rb").read()
+    assert len(raw) == 1024 + vol.size * 4
+    assert struct.unpack_from("<4i", raw, 0) == (5, 4, 3, 2)                              # nx, ny, nz, mode
+    assert struct.unpack_from("<3i", raw, 28) == (5, 4, 3) and struct.unpack_from("<3i", raw, 64) == (1, 2, 3)
+    assert struct.unpack_from("<3f", raw, 52) == (90.0, 90.0, 90.0) and struct.unpack_from("<i", raw, 88)[0] == 1
+    assert raw[208:212] == b"MAP " and raw[212:214] == b"\x44\x44" and struct.unpack_from("<i", raw, 108)[0] == 20140
+    back, h = imageio_lite.read_mrc(p)
+    assert np.array_equal(back, vol) and back.dtype == np.float32
+    np.testing.assert_allclose([h["dmin"], h["dmax"], h["dmean"], h["rms"]], [vol.min(), vol.max(), vol.mean(), vol.std()], rtol=1e-6)
+    np.testing.assert_array_equal(np.frombuffer(raw, "<f4", 5, 1024), vol[0, 0])           # x runs fastest
+    with pytest.raises(ValueError):
+        imageio_lite.write_mrc(p, np.zeros((4, 4), np.float32))
+
+
+def test_inversion_targets_options_and_trajectories():
+    """callers.inversion_targets restates the script's torchvision pipelines on PIL (inverse_render_double_semantic.py:178-222, :290-327);
+    inversion_options / inversion_render_options are its two kwargs bags (:225-265); inversion_trajectory its set_trajectory (:504-570)."""
+    from PIL import Image
+    # a 400 x 300 photo of a constant colour and a label map of four constant quadrants: Resize(320) -> 426 x 320 (int(320 * 400 / 300)),
+    # CenterCrop(256) at left = round(170 / 2) = 85, top = 32, then NEAREST to S x S
+    photo = Image.fromarray(np.full((300, 400, 3), (255, 128, 0), np.uint8))
+    lab = np.zeros((300, 400), np.uint8)
+    lab[:150, :200], lab[:150, 200:], lab[150:, :200], lab[150:, 200:] = 0, 1, 5, 18
+    seg = Image.fromarray(lab, "L")
+    img, s18, s19 = callers.inversion_targets(photo, seg, image_size=16)
+    assert tuple(img.shape) == (1, 3, 16, 16) and tuple(s18.shape) == (1, 18, 16, 16) and tuple(s19.shape) == (1, 19, 256, 256)
+    np.testing.assert_allclose(img[0, :, 3, 3].numpy(), [1.0, 128 / 255 * 2 - 1, -1.0], atol=1e-6)      # Normalize(0.5, 0.5)
+    assert set(np.unique(s18.numpy())) == {-1.0, 1.0} and set(np.unique(s19.numpy())) == {0.0, 1.0}
+    # quadrant interiors (the bilinear Resize(320) only blends at the quadrant borders): label 1 -> channel 0 of 18 / channel 1 of 19
+    assert s18[0, 0, 2, 12] == 1 and s18[0, 4, 12, 2] == 1 and s18[0, 17, 12, 12] == 1 and (s18[0, :, 2, 2] == -1).all()      # background: no channel
+    assert s19[0, 0, 20, 20] == 1 and s19[0, 1, 20, 200] == 1 and s19[0, 5, 200, 20] == 1 and s19[0, 18, 200, 200] == 1
+    assert (s19.sum(1)[0, 20:100, 20:100] == 1).all()
+    # --no_center_crop: the last resize only; --white_background_mask paints the photo 1 where the label map is 0
+    img2, s18b, _ = callers.inversion_targets(photo, seg, image_size=8, no_center_crop=True, white_background_mask=True)
+    assert tuple(img2.shape) == (1, 3, 8, 8) and (img2[0, :, 1, 1] == 1.0).all() and img2[0, 2, 6, 6] == -1.0
+    assert s18b[0, 4, 6, 1] == 1
+    img3, _, _ = callers.inversion_targets(photo, seg, image_size=8, no_center_crop=True, background_mask=True)
+    assert (img3[0, :, 1, 1] == -1.0).all()
+    # helpers
+    m = np.array([[0, 1], [18, 5]])
+    l18, l19 = callers.mask2labels(m, 18), callers.mask2labels(m, 19)
+    assert l18.shape == (18, 2, 2) and l18[0, 0, 1] == 1 and l18[17, 1, 0] == 1 and l18[:, 0, 0].sum() == 0
+    assert l19[0, 0, 0] == 1 and l19[18, 1, 0] == 1 and l19.sum() == 4
+    a = torch.tensor(l19[None], dtype=torch.float)
+    np.testing.assert_allclose(callers.mIOU(a, a).item(), 4 / 19, atol=1e-6)               # four classes present with IoU 1, fifteen empty with 0
+    # options bags
+    o = callers.inversion_options(64, 12)
+    assert (o["img_size"], o["num_steps"], o["hierarchical_sample"], o["fill_mode"], o["nerf_noise"], o["h_stddev"]) == \
+        (64, 24, False, "eval_seg_padding_background", 0, 0) and abs(float(o["h_mean"]) - np.pi / 2) < 1e-6
+    r = callers.inversion_render_options(12, "white")
+    assert (r["img_size"], r["num_steps"], r["hierarchical_sample"], r["last_back"], r["fill_color"], r["fill_mode"]) == \
+        (256, 48, True, False, "white", "eval_seg_padding_background") and "h_mean" not in r
+    # trajectories
+    t = callers.inversion_trajectory("inverse_sphere", 5, 12)
+    np.testing.assert_allclose(t[0][1:], (np.pi / 2, np.pi / 2, 12), atol=1e-12)
+    np.testing.assert_allclose(t[2][1], 0.4 + np.pi / 2, atol=1e-12)                       # t = 0.5: 0.2 * (1 - cos(pi))
+    z = callers.inversion_trajectory("zoom", 7, 12)
+    assert len(z) == 50 and abs(z[0][3] - 17) < 1e-9                                        # linspace(-1, 1) has 50 points whatever num_frames says
+    rl = callers.inversion_trajectory("rotation_linear", 3, 12)
+    np.testing.assert_allclose([y for _, _, y, _ in rl], [np.pi / 2 - 0.4, np.pi / 2, np.pi / 2 + 0.4], atol=1e-12)
+    assert callers.inversion_trajectory("front", 4, 12) == callers.camera_trajectory("front", 4, 12)
+    with pytest.raises(ValueError):
+        callers.inversion_trajectory("nope", 3, 12)
+    # film_from_inversion: mean + offset in forward_with_frequencies' argument order
+    meta = {k: torch.full((1, 4), float(i)) for i, k in enumerate(
+        ("w_geo_frequencies", "w_geo_phase_shifts", "w_app_frequencies", "w_app_phase_shifts", "w_geo_frequency_offsets",
+         "w_geo_phase_shift_offsets", "w_app_frequency_offsets", "w_app_phase_shift_offsets"))}
+    fg, fa, pg, pa = callers.film_from_inversion(meta)
+    assert (float(fg[0, 0]), float(fa[0, 0]), float(pg[0, 0]), float(pa[0, 0])) == (0 + 4, 2 + 6, 1 + 5, 3 + 7)

@@ -1281,6 +1281,69 @@ def test_cli_front_ends_write_what_the_reference_scripts_write(tmp_path):
     assert raw[:4] == b"RIFF" and raw.count(b"00db") == 6                               # 3 frames [image | labels | blend | depth]
 
 
+def test_inversion_and_shape_front_ends_as_commands(tmp_path):
+    """tools/inverse_render.py and tools/extract_shapes.py as commands (the reference's argparse surfaces,
+    inverse_render_double_semantic.py:132-169 / extract_double_semantic_shapes.py:90-97) on a checkpoint directory laid out like the
+    reference's: previews, the eight-tensor checkpoint under the reference's keys, mious.npy, the reconstruction video; then the density
+    volume of the inverted identity and of seeded identities as MRC maps, equal to the library-level callers' volumes."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import ROOT
+    from fenerf_amd import imageio_lite
+    ckpt = _tiny_checkpoint_dir(tmp_path)
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (40, 32, 3), dtype=np.uint8)).save(str(tmp_path / "face.jpg"))
+    lab = np.zeros((40, 32), np.uint8); lab[8:30, 6:26] = 1; lab[12:16, 10:14] = 4; lab[24:28, 12:20] = 12
+    Image.fromarray(lab, "L").save(str(tmp_path / "face.png"))
+    out = str(tmp_path / "inv")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "inverse_render.py"), "t", ckpt, "--image_path", str(tmp_path / "face.jpg"), "--seg_path",
+           str(tmp_path / "face.png"), "--save_dir", out, "--image_size", "8", "--iteration", "21", "--lambda_seg", "1", "--lambda_img", "1",
+           "--latent_normalize", "--no_center_crop", "--preview_size", "8", "--preview_steps", "6"]
+    recon = ["--recon", "--trajectory", "rotation_linear", "--num_frames", "3", "--fill_color", "white"]
+    r = subprocess.run(cmd + recon, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    for angle in (-0.5, 0, 0.5):
+        for kind in ("img", "seg"):
+            assert np.asarray(Image.open(os.path.join(out, f"0_{angle}_{kind}.jpg"))).shape == (8, 8, 3)
+    assert not os.path.exists(os.path.join(out, "20_0_img.jpg"))                       # previews every 200 iterations, mIoU every 20
+    mious = np.load(os.path.join(out, "mious.npy"))
+    assert mious.shape == (2,) and ((0 <= mious) & (mious <= 1)).all()
+    meta = torch.load(os.path.join(out, "freq_phase_offset_t.pth"), weights_only=False)
+    assert sorted(meta) == sorted(["w_geo_frequencies", "w_geo_phase_shifts", "w_geo_frequency_offsets", "w_geo_phase_shift_offsets",
+                                   "w_app_frequencies", "w_app_phase_shifts", "w_app_frequency_offsets", "w_app_phase_shift_offsets"])
+    assert all(float(meta[k].abs().max()) > 0 for k in meta if "offset" in k)           # 21 Adam steps moved every offset tensor
+    assert all(not meta[k].requires_grad for k in meta if "offset" in k)
+    raw = open(os.path.join(out, "reconstructed_debug_rotation_linear_white.avi"), "rb").read()
+    assert raw[:4] == b"RIFF" and raw.count(b"00db") == 2 * 3                          # three frames [image | labels | blend]
+    line = [l for l in r.stdout.splitlines() if "loss" in l][0]
+    print("[parity] tools/inverse_render.py on the tiny pickled generator:", line.strip())
+    # an existing --checkpoint_path is reused (no optimisation) unless --load_checkpoint
+    r2 = subprocess.run(cmd + ["--checkpoint_path", os.path.join(out, "freq_phase_offset_t.pth")], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "loss" not in r2.stdout, (r2.stdout[-500:], r2.stderr[-2000:])
+    # shapes: the inverted identity, then two seeded ones
+    shapes = str(tmp_path / "shapes")
+    base = [sys.executable, os.path.join(ROOT, "tools", "extract_shapes.py"), ckpt, "--cube_size", "0.3", "--voxel_resolution", "12", "--output_dir", shapes]
+    r = subprocess.run(base + ["--latent_path", os.path.join(out, "freq_phase_offset_t.pth"), "--seeds", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vol, h = imageio_lite.read_mrc(os.path.join(shapes, "7.mrc"))
+    assert vol.shape == (12, 12, 12) and h["mode"] == 2 and np.isfinite(vol).all() and vol.std() > 0
+    cm = callers_mod()
+    gen = cm.load_generator(ckpt, DEV, reset_render_options=False)
+    fg, fa, pg, pa = cm.film_from_inversion(meta, DEV)
+    ref = cm.sample_generator_wth_frequencies_phase_shifts(gen, dict(truncated_frequencies_geo=fg, truncated_frequencies_app=fa,
+                                                                     truncated_phase_shifts_geo=pg, truncated_phase_shifts_app=pa),
+                                                           cube_length=0.3, voxel_resolution=12)
+    np.testing.assert_array_equal(vol, ref)
+    r = subprocess.run(base + ["--seeds", "3", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    v3, v4 = (imageio_lite.read_mrc(os.path.join(shapes, f"{s}.mrc"))[0] for s in (3, 4))
+    assert not np.array_equal(v3, v4)
+    torch.manual_seed(3)
+    z = torch.randn(1, gen.z_geo_dim, device=DEV)
+    np.testing.assert_array_equal(v3, cm.sample_generator(gen, z, cube_length=0.3, voxel_resolution=12))
+
+
 def test_single_latent_video_interpolation_loop_and_cli(tmp_path):
     """callers.render_latent_video / --interpolation_type video_latent_interpolation (render_video_interpolation_semantic.py:187-312,
     the ImplicitGenerator3d variant): frame j is staged_forward_with_frequencies on the truncated FiLM parameters interpolated at the
