@@ -38,29 +38,26 @@ def padded_hidden_dim(H):
     raise ValueError(f"hidden_dim {H}: the kernels are instantiated up to {SUPPORTED_HIDDEN[-1]} (include/fenerf.h)")
 
 
-def _pad_axes(name, spec_kind):
+def _pad_axes(name, n_label_layers):
     """which axes of render parameter `name` are hidden-width axes: (pad rows?, pad the LAST H columns?) -- the colour layer 0's input is
-    [dirs | grid features | x]: its hidden part is the trailing H columns"""
+    [dirs | grid features | x]: its hidden part is the trailing H columns; the LAST label layer, final_layer and color_layer_linear map
+    hidden features to outputs (columns only, biases untouched)"""
+    last_label_weight = f"label_layer_linear.{n_label_layers - 1}.weight" if n_label_layers else None
+    last_label_bias = f"label_layer_linear.{n_label_layers - 1}.bias" if n_label_layers else None
     if name == "spatial_embeddings":
         return False, False
     if name.endswith(".bias"):
-        last_label = name.startswith("label_layer_linear.") and name == _pad_axes.last_label_bias
-        return (not (name.startswith("final_layer") or name.startswith("color_layer_linear") or last_label)), False
+        return (not (name.startswith("final_layer") or name.startswith("color_layer_linear") or name == last_label_bias)), False
     if name == "network.0.layer.weight":
         return True, False
-    if name.startswith("final_layer") or name.startswith("color_layer_linear") or name == _pad_axes.last_label_weight:
+    if name.startswith("final_layer") or name.startswith("color_layer_linear") or name == last_label_weight:
         return False, True
     return True, True
 
 
-_pad_axes.last_label_weight = _pad_axes.last_label_bias = None
-
-
 def _pad_param(name, t, H, Hp, n_label_layers, is_numpy):
     """zero-pad one reference-named render parameter from hidden width H to Hp (numpy array or torch tensor)"""
-    _pad_axes.last_label_weight = f"label_layer_linear.{n_label_layers - 1}.weight" if n_label_layers else None
-    _pad_axes.last_label_bias = f"label_layer_linear.{n_label_layers - 1}.bias" if n_label_layers else None
-    rows, cols = _pad_axes(name, None)
+    rows, cols = _pad_axes(name, n_label_layers)
     d = Hp - H
     if t.ndim == 1:
         if not rows:
