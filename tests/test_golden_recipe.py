@@ -22,7 +22,7 @@ def test_committed_fixtures_regenerate_from_the_reference(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_golden.py"), out], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     committed = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
-    assert len(committed) >= 33
+    assert len(committed) >= 34
     for f in committed:
         g = os.path.join(out, os.path.basename(f))
         assert os.path.exists(g), f"make_golden.py no longer writes {os.path.basename(f)}"

@@ -185,6 +185,21 @@ def test_mask2color_and_voxel_samples_match_reference():
     assert all(isinstance(k, str) for k in kw) and kw["fill_mode"] == "seg_padding_background"
 
 
+def test_inversion_host_pieces_match_the_reference_script():
+    """callers.mask2labels / mIOU / inversion_trajectory against the functions of inverse_render_double_semantic.py itself (:82-92,
+    :122-126, :504-570; tests/golden/inversion_helpers.npz: AST-extracted from the reference source and executed by tools/make_golden.py)."""
+    from fenerf_amd import callers
+    g = load_golden("inversion_helpers")
+    np.testing.assert_array_equal(callers.mask2labels(g["mask"], 18), g["labels_18"])
+    np.testing.assert_array_equal(callers.mask2labels(g["mask"], 19), g["labels_19"])
+    np.testing.assert_array_equal(callers.mIOU(torch.from_numpy(g["miou_source"]), torch.from_numpy(g["miou_target"])).numpy(), g["miou"])
+    n = int(g["trajectory_num_frames"])
+    for name in g["trajectory_names"]:
+        mine = np.array(callers.inversion_trajectory(str(name), n, 12), dtype=np.float64)
+        np.testing.assert_array_equal(mine, g["trajectory_" + str(name)], err_msg=str(name))
+    assert g["trajectory_zoom"].shape == (50, 4)          # the script's zoom ignores --num_frames
+
+
 def test_reference_checkpoint_unpickles_into_this_package():
     """generator.pth of the reference is a pickled nn.Module (train_double_latent_semantic.py:526) whose class paths are
     generators.generators.* / siren.siren.*; with the import aliases it loads as this package's drop-in classes."""

@@ -571,6 +571,38 @@ def run_caller_helpers(name="caller_helpers"):
     print(f"{name}: mask2color + create_samples")
 
 
+def run_inversion_helpers(name="inversion_helpers"):
+    """The host pieces of inverse_render_double_semantic.py that fenerf_amd.callers restates -- mask2labels (:82-92), mIOU (:122-126),
+    set_trajectory (:504-570) -- executed straight from the reference source (AST-extracted: the script's imports -- lpips, skvideo,
+    torchvision, tensorboard -- and its module-level argparse / torch.load never run)."""
+    import ast
+    import math
+    import types
+    fn = "inverse_render_double_semantic.py"
+    wanted = {"COLOR_MAP", "COLOR_MAP_COMPLETE", "mask2labels", "mIOU", "set_trajectory"}
+    tree = ast.parse(open(os.path.join(ref_import.REFERENCE_ROOT, fn)).read())
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in wanted) or
+            (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in wanted for t in n.targets))]
+    ns = {"torch": torch, "np": np, "math": math, "render_options": {"fov": 12}}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), fn, "exec"), ns)
+    out = {}
+    rng = np.random.default_rng(21)
+    mask = rng.integers(0, 19, (6, 5)).astype(np.float32)
+    out["mask"] = mask
+    out["labels_18"] = ns["mask2labels"](mask)
+    out["labels_19"] = ns["mask2labels"](mask, ns["COLOR_MAP_COMPLETE"])
+    src = torch.tensor(rng.integers(0, 2, (2, 19, 6, 5)).astype(np.float32))
+    tgt = torch.tensor(rng.integers(0, 2, (2, 19, 6, 5)).astype(np.float32))
+    out["miou_source"], out["miou_target"], out["miou"] = np_(src), np_(tgt), np_(ns["mIOU"](src, tgt))
+    names = ["front", "orbit", "non_rotation", "sphere", "inverse_sphere", "rotation_horizontal", "zoom", "rotation_linear"]
+    out["trajectory_names"] = np.array(names)
+    out["trajectory_num_frames"] = 7
+    for n in names:
+        out["trajectory_" + n] = np.array(ns["set_trajectory"](types.SimpleNamespace(trajectory=n, num_frames=7)), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: mask2labels + mIOU + set_trajectory of the inversion script")
+
+
 def run_multiview_case(refs, name="tiny_multiview"):
     """generate_img of render_multiview_images_double_semantic.py:24-29 (AST-extracted, executed as is) over the script's
     five yaw angles (:68-83) on the tiny reference generator, with the options bag the script builds (:43-54) from a small
@@ -879,6 +911,7 @@ def main(out_dir=None):
     run_camera_cases(refs, "camera_rays")
     run_mapping_and_full(refs, "tiny_texture_z_full")
     run_caller_helpers()
+    run_inversion_helpers()
     run_multiview_case(refs)
     run_spatial_grid_case(refs)
     run_style_generator_case(refs)
