@@ -50,8 +50,7 @@ if [ "$which" = "evidence" ]; then   # the round's profiles: kernel stats of the
   cp bench_detail.json gpurun_out/r6_bench_detail_under_rocprofv3.json
   find gpurun_out/prof -type f -size +1M -delete
   head -8 gpurun_out/r6_bench_kernel_stats_default_command.csv | cut -c1-220
-  bash tools/gpu_r3.sh pmc > gpurun_out/r6_pmc_forward.log 2>&1
-  cp gpurun_out/pmc/siren_pmc_summary.txt gpurun_out/r6_pmc_siren16w_f16x3.txt; rm -rf gpurun_out/pmc
+  bash tools/gpu_r6.sh pmcfwd > gpurun_out/r6_pmc_forward.log 2>&1      # (the round-3 script's pmc step no longer matches bench.py's flags)
   GSTEP_ARGS="--B 1 --size 128 --grad-precision f32" bash tools/pmc_gstep_mfma.sh > /dev/null 2>&1
   cp gpurun_out/pmc_gstep_mfma/summary.txt gpurun_out/r6_pmc_gstep_mfma_f32.txt; rm -rf gpurun_out/pmc_gstep_mfma
   bash tools/pmc_gstep_waits.sh > /dev/null 2>&1
