@@ -134,11 +134,14 @@ __device__ __forceinline__ void glds_1k_s_nt(const void* g_uniform, unsigned vof
 }
 // fire-and-forget stores, uniform base + 32-bit lane offset.  The s_nop is the hazard slot the compiler would insert behind a
 // store of more than 8 bytes whose data registers the next VALU instruction overwrites -- it does not look inside an asm.
+#ifndef FENERF_ST_POLICY
+#define FENERF_ST_POLICY "nt"      // cache policy of the fire-and-forget tape / d(theta) stores (A/B builds: profiles/r06_store_policy_ab.txt)
+#endif
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 " FENERF_ST_POLICY "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 __device__ __forceinline__ void st_u4_nt(const void* g_uniform, unsigned voff, const u32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 " FENERF_ST_POLICY "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 __device__ __forceinline__ void st_f2(const void* g_uniform, unsigned voff, const f32x2& v) {
   asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");

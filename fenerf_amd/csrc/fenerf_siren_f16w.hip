@@ -117,11 +117,14 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // overwritten next (the compiler does not look inside an asm).
 template <int MODE> struct TapeW { const char* base; };   // (tile32, layer) block of the tape (uniform), or unused
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FENERF_ST_POLICY
+#define FENERF_ST_POLICY "nt"      // cache policy of the fire-and-forget tape / d(theta) stores (A/B builds: profiles/r06_store_policy_ab.txt)
+#endif
 __device__ __forceinline__ void st_f4_nt(const void* g_uniform, unsigned voff, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 " FENERF_ST_POLICY "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 __device__ __forceinline__ void st_u4_nt(const void* g_uniform, unsigned voff, const u32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 " FENERF_ST_POLICY "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(g_uniform) : "memory");
 }
 // SAVE = 2: the four dwords (two 16-bit phases each) of an n-block that wait for the n-block's last epilogue piece: ONE 16-byte store
 // per lane and n-block, [nb][16-point tile][lane][slot 4 rt + r] (the bf16 dump's layout, dump16_feature)
