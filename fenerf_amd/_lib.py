@@ -135,6 +135,7 @@ _SIGS = {
     "fenerf_siren_backward_fuses_grid": (_i, [_vp]),
     "fenerf_siren_backward_grid": (_i, [_vp, _i, _i64] + [_vp] * 13),
     "fenerf_grid_gradient_ncdhw": (_i, [_vp, _vp, _vp, _vp]),
+    "fenerf_siren_input_grads": (_i, [_vp, _i, _i64] + [_vp] * 8 + [_i] + [_vp] * 4),
     # round 5: the same four calls for a tape in `tape_format` (FENERF_TAPE_F32 | FENERF_TAPE_U16)
     "fenerf_siren_tape_bytes": (_sz, [_vp, _i64, _i]),
     "fenerf_siren_forward_save_fmt": (_i, [_vp, _i, _i64] + [_vp] * 10 + [_i, _vp]),

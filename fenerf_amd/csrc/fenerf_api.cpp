@@ -974,6 +974,32 @@ extern "C" int fenerf_siren_param_grads_fmt(const FenerfModel* m, int B, int64_t
                             tape_format, weights);
 }
 
+// Gradients wrt the SIREN's inputs (sample positions, view directions) from the fp32 d(theta) dump a fenerf_siren_backward* call left:
+// one extra pass over two layers of the dump (fenerf_siren_inputgrad.hip).  include/fenerf.h says what it replaces.
+extern "C" int fenerf_siren_input_grads(const FenerfModel* m, int B, int64_t P, const float* points, const float* freq_geo, const float* phase_geo,
+                                        const float* freq_app, const float* phase_app, const float* d_t, const float* w_geo0,
+                                        const float* w_color0, int w_color0_ld, float* d_points, float* d_dirs, void* film_ws, void* stream) {
+  if (!m) return fail(FENERF_E_INVALID, "model is NULL");
+  if (!m->differentiable) return fail(FENERF_E_UNSUPPORTED, "model was not created with differentiable != 0");
+  if (B <= 0 || P < 0) return fail(FENERF_E_INVALID, "B must be > 0 and P >= 0");
+  if (P % 32) return fail(FENERF_E_INVALID, "differentiable path: points per image must be a multiple of 32");
+  if (P == 0) return FENERF_OK;
+  if (!d_t || !w_geo0 || !w_color0) return fail(FENERF_E_INVALID, "d_t / w_geo0 / w_color0 is NULL");
+  if (!d_points && !d_dirs) return fail(FENERF_E_INVALID, "d_points and d_dirs are both NULL");
+  if (m->grid_ch != 0 && m->grid_ch != 32) return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_input_grads: feature grids of 32 channels only");
+  if (m->grid_ch && d_points && !points) return fail(FENERF_E_INVALID, "points is NULL (the grid's coordinate gradient needs the sample positions)");
+  if (w_color0_ld < 3 + m->grid_ch) return fail(FENERF_E_INVALID, "w_color0_ld < 3 + grid channels");
+  if (use_bf16_dump(m, (long long)B * P))
+    return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_input_grads reads the fp32 d(theta) dump; this chunk's dump is bf16 (wgrad_bf16_min_points)");
+  int rc = check_dump(m, d_t, (long long)B * P);
+  if (rc) return rc;
+  const float *fp, *pp;
+  rc = film_prep(m, B, freq_geo, phase_geo, freq_app, phase_app, film_ws, &fp, &pp, stream);
+  if (rc) return rc;
+  PhaseScope ph(PH_OTHER, stream);
+  return launch_siren_input_grads(m, B, P, points, fp, d_t, w_geo0, w_color0, w_color0_ld, d_points, d_dirs, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Per-point modulation under autograd (round 6): SPATIALSIRENGRID.forward_with_frequencies_phase_shifts with one FiLM
 // block per sample point (siren.py:464-477; FiLMLayer takes them unbroadcast, :119-122), differentiable.  Three calls in the shape of

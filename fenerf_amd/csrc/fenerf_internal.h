@@ -177,6 +177,9 @@ int launch_param_grads(const FenerfModel* m, int B, long long P, const float* po
                        int tape_format = 0, const FenerfSirenGrads* weights = nullptr,
                        int film_per_point = 0);    // film_per_point: fp / pp are [B*P][L][H]; g.d_freq_* / d_phase_* are [B*P][n*H] (FENERF_PREC_F32 models)
 int launch_grid_backward(const FenerfModel* m, long long P, const float* points, const float* d_e, float* d_grid_cl, void* stream);
+// fenerf_siren_inputgrad.hip: d points / d dirs from the fp32 d(theta) dump (layer 0 and colour layer 0) + grid_sample's coordinate gradient
+int launch_siren_input_grads(const FenerfModel* m, int B, long long P, const float* points, const float* fp, const float* d_t, const float* w_geo0,
+                             const float* w_color0, int w_color0_ld, float* d_points, float* d_dirs, void* stream);
 int launch_siren16w(const FenerfModel* m, const SirenParams& p, void* stream);   // f16x3 forward / forward-save, 16-point waves (fenerf_siren_f16w.hip)
 // fenerf_render_forward as ONE launch (fenerf_siren_f16w.hip, FUSED): ray groups of whole octs, see there
 struct FusedRenderPlan { int rays_per_group, octs_per_group, blocks; long long groups; };

@@ -650,6 +650,25 @@ class NativeModel:
                                                                  _ptr(scratch), C.c_void_p(ws.data_ptr()), _stream()))
         return d_t
 
+    def siren_input_grads(self, points, fg, pg, fa, pa, d_t, w_geo0, w_color0, d_points=None, d_dirs=None):
+        """Gradients wrt the SIREN's inputs from the fp32 d(theta) dump `d_t` of siren_backward / siren_backward_grid over the same
+        (points, FiLM parameters): fills d_points / d_dirs [B,P,3] (contiguous fp32 device tensors; either may be None).
+        w_geo0 [H,3] / w_color0 [H, 3+G+H]: the nn.Linear weights of layer 0 and of colour layer 0 at the module's width
+        (include/fenerf.h fenerf_siren_input_grads; what autograd leaves in input.grad / ray_directions.grad, siren.py:1509-1530)."""
+        B, P = points.shape[0], points.shape[1]
+        dev = self.device
+        fg, pg, fa, pa = self._film(B, fg, pg, fa, pa)
+        w0, wc0 = _f32(w_geo0, dev), _f32(w_color0, dev)
+        if self.padded:       # zero rows for the padded features (their d theta is zero anyway); the x columns of colour layer 0 are not read
+            d = self.spec["hidden_dim"] - self.logical_H
+            w0, wc0 = torch.nn.functional.pad(w0, (0, 0, 0, d)), torch.nn.functional.pad(wc0, (0, 0, 0, d))
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            fws = self._workspace("film", l.fenerf_film_workspace_bytes(self._h, B))
+            _lib.check(l.fenerf_siren_input_grads(self._h, B, P, _ptr(_f32(points, dev)), _ptr(fg), _ptr(pg), _ptr(fa), _ptr(pa), _ptr(d_t), _ptr(w0),
+                                                  _ptr(wc0), int(wc0.shape[1]), _ptr(d_points), _ptr(d_dirs), C.c_void_p(fws.data_ptr()), _stream()))
+        return d_points, d_dirs
+
     def grid_gradient_ncdhw(self, d_grid_cl):
         """channels-last gradient grid [D,H,W,32] -> the parameter's layout [1,32,D,H,W]"""
         D, Hh, W = d_grid_cl.shape[:3]

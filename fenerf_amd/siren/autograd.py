@@ -128,7 +128,8 @@ def film_layer_weights(module, params):
     return [W for W, _ in roles["geo"]], [W for W, _ in roles["color"]]
 
 
-def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None, tape_format=0, weights=None):
+def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None, tape_format=0, weights=None,
+                     input_grads=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
     `max_points` points: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per image, and every gradient
     is a sum over points, so chunk results simply add.  A chunk is a run of WHOLE images while those fit (the curriculum's early
@@ -137,6 +138,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     features never exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid;
     inside the chain kernel for f16x3 models).
     tape_format / weights: the tape's format (_lib.TAPE_*) and, for the 16-bit tape, film_layer_weights(...).
+    input_grads: None, or (layer 0's weight, colour layer 0's weight, d_points [nB,Pp,3] or None, d_dirs [nB,Pp,3] or None): every chunk
+    also fills its rows of the gradients wrt the sample positions / view directions from its d(theta) dump (NativeModel.siren_input_grads).
     -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
@@ -151,7 +154,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
         chunks = [(b, min(per, nB - b), 0, Pp) for b in range(0, nB, per)]
     else:
         chunks = [(b, 1, s, min(max_points, Pp - s)) for b in range(nB) for s in range(0, Pp, max_points)]
-    if film_only and nat.film_only_native():
+    if film_only and nat.film_only_native() and input_grads is None:      # (the input gradients are read from the dump this route does not write)
         # Inversion on an f16x3 model: the chain writes only its per-tile FiLM sums (fenerf_siren_backward_film) -- no d(theta) dump.
         # A launch is bounded by the kernel's 32-bit tile arithmetic (2^24 points) and by FILM_SUMS_BUDGET_BYTES of FiLM sums (one
         # [L][2][H] block per 128 points, or per 16 points when an image is not a multiple of 128 points: 176 B / 1.4 KB per point at
@@ -206,6 +209,10 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
                 d_t = nat.siren_backward_grid(nb, n, *film_c, out_c, d_out_c, tape_c, pts_c, d_grid, tape_format=tape_format)
             else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
                 d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c, tape_format=tape_format)
+        if input_grads is not None:       # a chunk is whole images or a point range of one image: its rows are contiguous
+            w_g0, w_c0, dp, dd = input_grads
+            nat.siren_input_grads(pts_c, *film_c, d_t, w_g0, w_c0, dp[b:b + nb, s:s + n] if dp is not None else None,
+                                  dd[b:b + nb, s:s + n] if dd is not None else None)
         if overlap:
             ev = torch.cuda.Event()
             ev.record(main)
@@ -371,14 +378,21 @@ class SirenFunction(torch.autograd.Function):
         d_out = d_out.contiguous().float()
         need = ctx.needs_input_grad
         film_only = not any(need[7:])        # inversion: only the FiLM parameters are optimised
+        # gradients wrt the sample positions / view directions (callers of the bare module; the generators build their rays under no_grad)
+        d_points = torch.empty_like(points) if need[1] else None
+        d_dirs = torch.empty_like(dirs) if (need[2] and ctx.has_dirs) else None
+        input_grads = None
+        if d_points is not None or d_dirs is not None:
+            w_geo, w_col = film_layer_weights(module, params)
+            input_grads = (w_geo[0], w_col[0], d_points, d_dirs)
         r, d_grid = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
                                      tape_e if tape_e.numel() else None, film_only, tape_format=ctx.tape_format,
-                                     weights=film_layer_weights(module, params) if ctx.tape_format else None)
+                                     weights=film_layer_weights(module, params) if ctx.tape_format else None, input_grads=input_grads)
         film_grads = (r["d_freq_geo"] if need[3] else None, r["d_phase_geo"] if need[4] else None,
                       r["d_freq_app"] if need[5] else None, r["d_phase_app"] if need[6] else None)
         if film_only:
-            return (None, None, None) + film_grads + (None,) * len(params)
-        return (None, None, None) + film_grads + assemble_param_grads(module, nat, params, r, points, d_grid, need[7:])
+            return (None, d_points, d_dirs) + film_grads + (None,) * len(params)
+        return (None, d_points, d_dirs) + film_grads + assemble_param_grads(module, nat, params, r, points, d_grid, need[7:])
 
 
 class PointwiseSirenFunction(torch.autograd.Function):
@@ -429,10 +443,12 @@ def siren_apply_pointwise(module, points, dirs, fg, pg, fa, pa):
 
 def siren_apply(module, points, dirs, fg, pg, fa, pa):
     """Differentiable SIREN evaluation.  The native path works on whole 32-point tiles per image: other point counts are
-    padded here (with the last point; the pads get no gradient because their outputs are sliced away)."""
-    if points.requires_grad or (dirs is not None and dirs.requires_grad):
-        raise NotImplementedError("fenerf_amd: gradients wrt sample positions / view directions are not provided "
-                                  "(the reference's training and inversion loops do not use them)")
+    padded here (with the last point; the pads get no gradient because their outputs are sliced away).
+    points / dirs that require grad get theirs too (fenerf_siren_input_grads: an extra pass over the fp32 d(theta) dump)."""
+    if (points.requires_grad or (dirs is not None and dirs.requires_grad)) and module.grad_precision in ("amp", "amp16") \
+            and module.precision != "f32":
+        raise NotImplementedError("fenerf_amd: gradients wrt sample positions / view directions read the fp32 d(theta) dump; "
+                                  "grad_precision 'amp' / 'amp16' writes it as bf16 -- use 'f32' or 'tape16'")
     params = module._render_params()
     P = points.shape[1]
     pad = (-P) % 32

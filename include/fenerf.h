@@ -556,6 +556,19 @@ int fenerf_siren_backward_grid(const FenerfModel* m, int B, int64_t P, const flo
                                void* film_ws, void* stream);
 /* channels-last gradient grid [D][H][W][32] -> the parameter's layout [1,32,D,H,W] (spatial_embeddings.grad) */
 int fenerf_grid_gradient_ncdhw(const FenerfModel* m, const float* d_grid_cl, float* d_grid_ncdhw, void* stream);
+/* replaces: what torch autograd leaves in `input.grad` / `ray_directions.grad` of forward_with_frequencies_phase_shifts
+ * (siren.py:1509-1530) for a caller that asked for them: d input = W_0^T dz_0 (:1517-1520) + grid_sample's backward wrt its coordinates
+ * (sample_from_3dgrid, siren.py:314-330, applied to d shared_features = W_c0[:, 3:35]^T dz_c0), times UniformBoxWarp's 2 / 0.24
+ * (siren.py:181-187, :1513); d ray_directions = W_c0[:, 0:3]^T dz_c0 (the cat of :1522).  The generator API never needs it: the
+ * reference builds its rays under torch.no_grad() (generators.py:465, :483); this is for callers of the bare SIREN module.
+ * Call it between fenerf_siren_backward* (which leaves d_t) and fenerf_siren_param_grads, with the same (B, P), points and FiLM
+ * parameters.  d_t must be an fp32 dump (FENERF_E_UNSUPPORTED for the bf16 dump of AMP-class chunks).  w_geo0 [H][3] and w_color0
+ * [H][w_color0_ld] are the nn.Linear weights of layer 0 and of colour layer 0 (columns [dirs 3 | grid features | x]; only the first
+ * 3 + grid channels are read) on the device, at the model's hidden width (zero rows for a padded width).  d_points / d_dirs [B*P][3],
+ * either may be NULL.  film_ws as for fenerf_siren_backward. */
+int fenerf_siren_input_grads(const FenerfModel* m, int B, int64_t P, const float* points, const float* freq_geo, const float* phase_geo,
+                             const float* freq_app, const float* phase_app, const float* d_t, const float* w_geo0,
+                             const float* w_color0, int w_color0_ld, float* d_points, float* d_dirs, void* film_ws, void* stream);
 
 /* replaces: what torch autograd derives for the final fancy_integration of a differentiable render
  * (generators.py:519 / :790; G-step and inversion): gradient wrt rgb_final g_rgb [BR, C-1] -> gradients wrt the SIREN

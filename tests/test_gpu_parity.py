@@ -1569,6 +1569,149 @@ def test_siren_backward_vs_autograd(kind, H, grid, B, P, precision):
     print(f"[parity] SIREN backward {precision} {kind} H={H} B={B} P={P}: worst relative error over {len(sd64) + len(film)} gradient tensors {worst:.2e}")
 
 
+# max-norm relative error of d points / d view directions vs fp64 autograd: measured (profiles/r06_gpu_tests_parity_lines.log) x 1.5
+INPUT_GRAD_BOUND = {"f32": 2.1e-5, "f16x3": 4.2e-5, "tape16": 1.9e-4}
+
+
+@pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
+@pytest.mark.parametrize("kind,H,grid,B,P", [("texture", 32, 5, 2, 75), ("baseline", 64, 0, 1, 64), ("spatial", 32, 0, 2, 33),
+                                             ("texture", 256, 6, 2, 200), ("texture", 100, 5, 2, 75), ("baseline", 192, 0, 3, 160)])
+def test_siren_input_gradients_vs_fp64_autograd(kind, H, grid, B, P, precision):
+    """Gradients wrt the sample positions and view directions of forward_with_frequencies_phase_shifts (siren.py:1509-1530: layer 0,
+    grid_sample's coordinate gradient :314-330, UniformBoxWarp :181-187, the colour layer's cat :1522) -- fenerf_siren_input_grads, an extra
+    pass over the d(theta) dump -- against fp64 autograd of the oracle; asking for them changes no other gradient by a bit; the
+    FiLM-only route (frozen weights) and a chunked backward give the same rows."""
+    from oracle import fenerf_oracle_grad as OG
+    from fenerf_amd.siren import autograd as SA
+    mod, spec, sd = _siren_module(kind, H, grid, precision=precision)
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)     # some points leave the grid box: zero padding
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    film = proc.film_params(spec, B, seed=4)
+    if kind == "spatial":
+        film["freq_app"] = proc.normal("film.freq_app", (B, H), 0.4, 4)
+        film["phase_app"] = proc.normal("film.phase_app", (B, H), 0.4, 4)
+    g_out = rng.normal(size=(B, P, spec["output_dim"])).astype(np.float32)
+    g_out[..., -1] *= 0.02
+
+    def run(points_grad, dirs_grad, film_grad=True):
+        mod.zero_grad(set_to_none=True)
+        film_t = {k: T(v).requires_grad_(film_grad) for k, v in film.items()}
+        p_t, d_t = T(pts).requires_grad_(points_grad), T(dirs).requires_grad_(dirs_grad)
+        if kind == "spatial":
+            out = mod.forward_with_frequencies_phase_shifts(p_t, torch.cat([film_t["freq_geo"], film_t["freq_app"]], -1),
+                                                            torch.cat([film_t["phase_geo"], film_t["phase_app"]], -1), d_t)
+        else:
+            out = mod.forward_with_frequencies_phase_shifts(p_t, film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], d_t)
+        (out * T(g_out)).sum().backward()
+        others = {k: N_(v.grad) for k, v in film_t.items() if v.grad is not None}
+        others.update({k: N_(v.grad) for k, v in mod.named_parameters() if v.grad is not None})
+        return (N_(p_t.grad) if points_grad else None), (N_(d_t.grad) if dirs_grad else None), others
+
+    gp, gd, with_inputs = run(True, True)
+    _, _, without = run(False, False)
+    differing = [k for k in without if not np.array_equal(with_inputs[k], without[k])]
+    # (the grid gradient is a scatter of float atomics: equal to summation order only)
+    assert set(with_inputs) == set(without) and set(differing) <= {"spatial_embeddings"}, differing
+    if differing:
+        assert _rel_err(with_inputs["spatial_embeddings"], without["spatial_embeddings"]) <= 1e-5
+
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sd64 = {k: t64(v) for k, v in sd.items()}
+    p64, d64 = t64(pts).requires_grad_(True), t64(dirs).requires_grad_(True)
+    ref = OG.siren_forward(sd64, spec, p64, d64, t64(film["freq_geo"]), t64(film["phase_geo"]), t64(film["freq_app"]), t64(film["phase_app"]))
+    (ref * t64(g_out)).sum().backward()
+    ep, ed = _rel_err(gp, p64.grad.numpy()), _rel_err(gd, d64.grad.numpy())
+    print(f"[parity] SIREN input gradients {precision} {kind} H={H} B={B} P={P}: d points {ep:.2e} (max |ref| {np.abs(p64.grad.numpy()).max():.2e}), "
+          f"d view directions {ed:.2e} vs fp64 autograd")
+    assert ep <= INPUT_GRAD_BOUND[precision] and ed <= INPUT_GRAD_BOUND[precision], (ep, ed)
+
+    # only the positions: (weights and FiLM parameters frozen: the backward is the FiLM-only one + the dump)
+    for q in mod.parameters():
+        q.requires_grad_(False)
+    gp2, gd2, none = run(True, False, film_grad=False)
+    assert gd2 is None and not none
+    e2 = _rel_err(gp2, p64.grad.numpy())
+    assert e2 <= INPUT_GRAD_BOUND[precision], e2
+    gp3, gd3, _ = run(False, True, film_grad=False)
+    assert gp3 is None and _rel_err(gd3, d64.grad.numpy()) <= INPUT_GRAD_BOUND[precision]
+    for q in mod.parameters():
+        q.requires_grad_(True)
+    # a backward in several chunks fills the same rows
+    old = SA.BACKWARD_CHUNK_POINTS
+    try:
+        SA.BACKWARD_CHUNK_POINTS = 128
+        gp4, gd4, _ = run(True, True)
+    finally:
+        SA.BACKWARD_CHUNK_POINTS = old
+    assert np.array_equal(gp4, gp) and np.array_equal(gd4, gd)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS + ["tape16"])
+@pytest.mark.parametrize("name", ["tiny_texture_input_grad", "tiny_baseline_input_grad", "tiny_spatial_input_grad"])
+def test_siren_input_gradients_vs_reference_autograd(name, precision):
+    """input.grad / ray_directions.grad of the reference module's own forward_with_frequencies_phase_shifts (fixtures made by
+    tools/make_golden.py::run_input_grad_case from the imported reference) against fenerf_siren_input_grads."""
+    g = load_golden(name)
+    spec = spec_from_golden(g)
+    kind, H = spec["kind"], spec["hidden_dim"]
+    mod, spec2, sd = _siren_module(kind, H, spec.get("grid_size", 0), seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]), precision=precision)
+    assert abs(proc.checksum(proc.make_state_dict(spec, seed=int(g["meta_seed"]), sigma_gain=float(g["meta_sigma_gain"]))) - float(g["meta_weights_checksum"])) < 1e-9
+    ref_sd = weights_from_golden(g, spec, with_mapping=False)
+    assert all(np.array_equal(ref_sd[k], sd[k]) for k in sd)
+    film = {k: T(v) for k, v in film_from_golden(g, spec).items()}
+    pts, dirs = T(g["points"]).requires_grad_(True), T(g["dirs"]).requires_grad_(True)
+    if kind == "spatial":
+        out = mod.forward_with_frequencies_phase_shifts(pts, torch.cat([film["freq_geo"], film["freq_app"]], -1),
+                                                        torch.cat([film["phase_geo"], film["phase_app"]], -1), dirs)
+    else:
+        out = mod.forward_with_frequencies_phase_shifts(pts, film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"], dirs)
+    fwd = np.abs(N_(out) - g["out"])
+    (out * T(g["loss_w"])).sum().backward()
+    ep, ed = _rel_err(N_(pts.grad), g["d_points"]), _rel_err(N_(dirs.grad), g["d_dirs"])
+    print(f"[parity] {name} [{precision}] vs the reference's autograd: forward rgb/labels {fwd[..., :-1].max():.2e}, d points {ep:.2e}, d view directions {ed:.2e}")
+    assert fwd[..., :-1].max() <= 2e-5
+    assert ep <= INPUT_GRAD_BOUND[precision] * 2 and ed <= INPUT_GRAD_BOUND[precision] * 2, (ep, ed)      # (x 2: the reference's own fp32 autograd rounding)
+
+
+def test_siren_input_gradients_api_refuses_what_it_cannot_do():
+    """fenerf_siren_input_grads: argument checks, and the bf16 dump of an AMP-class chunk is refused (Python: a NotImplementedError up front)."""
+    import ctypes
+    mod, spec, sd = _siren_module("texture", 32, 4, precision="f16x3")
+    B, P = 1, 64
+    nat = mod.native_differentiable(DEV)
+    film = {k: T(v) for k, v in proc.film_params(spec, B, seed=4).items()}
+    pts = torch.zeros(B, P, 3, device=DEV)
+    l = _lib.lib()
+    ws = torch.empty(int(l.fenerf_film_workspace_bytes(nat._h, B)), dtype=torch.uint8, device=DEV)
+    d_t = torch.zeros(int(l.fenerf_siren_dtheta_floats(nat._h, B * P)), device=DEV)
+    w0, wc0 = mod.network[0].layer.weight.detach().contiguous(), mod.color_layer_sine[0].layer.weight.detach().contiguous()
+    out = torch.empty(B, P, 3, device=DEV)
+    p = native._ptr
+    args = lambda **kw: [kw.get("h", nat._h), B, kw.get("P", P), p(pts), p(film["freq_geo"]), p(film["phase_geo"]), p(film["freq_app"]), p(film["phase_app"]),
+                         kw.get("d_t", p(d_t)), p(w0), p(wc0), kw.get("ld", wc0.shape[1]), kw.get("dp", p(out)), kw.get("dd", None),
+                         ctypes.c_void_p(ws.data_ptr()), None]
+    assert l.fenerf_siren_input_grads(*args()) == 0
+    assert l.fenerf_siren_input_grads(*args(P=33)) == _lib.E_INVALID
+    assert l.fenerf_siren_input_grads(*args(d_t=None)) == _lib.E_INVALID
+    assert l.fenerf_siren_input_grads(*args(dp=None)) == _lib.E_INVALID          # neither output
+    assert l.fenerf_siren_input_grads(*args(ld=10)) == _lib.E_INVALID
+    assert l.fenerf_siren_input_grads(*args(P=0)) == 0
+    plain = mod.native(DEV)                                                       # not differentiable
+    assert l.fenerf_siren_input_grads(*args(h=plain._h)) == _lib.E_UNSUPPORTED
+    mod.grad_precision = "amp"
+    with pytest.raises(NotImplementedError):
+        mod.forward_with_frequencies_phase_shifts(pts.clone().requires_grad_(True), film["freq_geo"], film["freq_app"], film["phase_geo"], film["phase_app"],
+                                                  torch.zeros_like(pts))
+    amp = mod.native_differentiable(DEV)
+    if amp.wgrad_bf16_min_points:
+        big_P = ((amp.wgrad_bf16_min_points + 31) // 32) * 32
+        rc = l.fenerf_siren_input_grads(amp._h, 1, big_P, p(pts), p(film["freq_geo"]), p(film["phase_geo"]), p(film["freq_app"]), p(film["phase_app"]),
+                                        p(d_t), p(w0), p(wc0), wc0.shape[1], p(out), None, ctypes.c_void_p(ws.data_ptr()), None)
+        assert rc == _lib.E_UNSUPPORTED and b"bf16" in l.fenerf_last_error()
+
+
 def test_hidden_width_between_the_instantiated_ones_is_the_padded_network_bit_for_bit():
     """The reference constructs any hidden width (siren.py:1451); the kernels are instantiated for 32 / 64 / 96 / 128 / 192 / 256.  Round 6:
     another width up to 256 runs at the next instantiated one with zero padding (native.padded_hidden_dim): padded features are

@@ -255,6 +255,36 @@ def run_grad_case(refs, name, spec, seed, sigma_gain, B, S, N, kwargs, film_scal
     print(f"{name}: pixels {out['pixels'].shape}, {sum(k.startswith('gparam_') for k in out)} parameter gradients -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_input_grad_case(refs, name, spec, seed, sigma_gain, B, P):
+    """The reference's OWN autograd wrt the radiance field's INPUTS: `input.grad` / `ray_directions.grad` of the SIREN module's
+    forward_with_frequencies_phase_shifts (siren.py:1509-1530 / :1210-1229 / :227-244) for loss = sum(out * w) -- through layer 0, the box
+    warp, grid_sample's coordinate gradient and the colour layer's cat.  (No reference loop asks for them -- the generators build their
+    rays under no_grad, generators.py:465 -- but a caller of the bare module gets them; fenerf_siren_input_grads.)  fp32 on the CPU."""
+    g, sd = build_ref_generator(refs, spec, seed, sigma_gain)
+    film = proc.film_params(spec, B, seed=seed)
+    tf = {k: torch.from_numpy(v) for k, v in film.items()}
+    rng = np.random.default_rng(100 + seed)
+    pts = torch.from_numpy(rng.uniform(-0.125, 0.125, (B, P, 3)).astype(np.float32)).requires_grad_(True)     # some leave the grid box (zeros padding)
+    dirs = rng.normal(size=(B, P, 3)).astype(np.float32)
+    dirs = torch.from_numpy(dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)).requires_grad_(True)
+    if spec["kind"] == "spatial":
+        out_ = g.siren.forward_with_frequencies_phase_shifts(pts, torch.cat([tf["freq_geo"], tf["freq_app"]], -1),
+                                                             torch.cat([tf["phase_geo"], tf["phase_app"]], -1), ray_directions=dirs)
+    else:
+        out_ = g.siren.forward_with_frequencies_phase_shifts(pts, tf["freq_geo"], tf["freq_app"], tf["phase_geo"], tf["phase_app"], ray_directions=dirs)
+    w = rng.normal(size=tuple(out_.shape)).astype(np.float32)
+    w[..., -1] *= 0.02          # sigma is ~sigma_gain x larger than the other outputs
+    (out_ * torch.from_numpy(w)).sum().backward()
+    out = dict(meta_seed=seed, meta_sigma_gain=sigma_gain, meta_B=B, meta_P=P, meta_film_scale=1.0, meta_weights_checksum=proc.checksum(sd),
+               points=np_(pts), dirs=np_(dirs), loss_w=w, out=np_(out_), d_points=np_(pts.grad), d_dirs=np_(dirs.grad))
+    for k, v in spec.items():
+        out["spec_" + k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: out {out['out'].shape}, max |d points| {np.abs(out['d_points']).max():.3g}, max |d dirs| {np.abs(out['d_dirs']).max():.3g} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_grad_autocast_case(refs, name, base, spec, seed, sigma_gain, B, S, N, kwargs, film_scale=1.0):
     """The same generator step as run_grad_case(`base`), run by the reference under torch.autocast(float16) -- the arithmetic its training
     loop uses (torch.cuda.amp.autocast, train_double_latent_semantic.py:402-446; here the CPU autocast of this torch build) -- on the same
@@ -924,6 +954,11 @@ def main(out_dir=None):
                   B=1, S=6, N=6, kwargs=dict(clamp_mode="softplus", nerf_noise=0.3, last_back=True))
     run_grad_case(refs, "tiny_spatial_grad", proc.model_spec("spatial", hidden_dim=32, z_dim=16), seed=8, sigma_gain=60.0,
                   B=2, S=5, N=7, kwargs=dict(clamp_mode="relu", nerf_noise=0.0, lock_view_dependence=True))
+
+    # gradients wrt the SIREN's inputs (round 6): the reference module's own autograd, one fixture per model family
+    run_input_grad_case(refs, "tiny_texture_input_grad", proc.model_spec("texture", hidden_dim=32, grid_size=5, z_dim=16), seed=3, sigma_gain=30.0, B=2, P=75)
+    run_input_grad_case(refs, "tiny_baseline_input_grad", proc.model_spec("baseline", hidden_dim=32, z_dim=16), seed=5, sigma_gain=30.0, B=1, P=64)
+    run_input_grad_case(refs, "tiny_spatial_input_grad", proc.model_spec("spatial", hidden_dim=32, z_dim=16), seed=8, sigma_gain=30.0, B=2, P=33)
 
     baseline = proc.model_spec("baseline", hidden_dim=32, z_dim=16)
     run_film_case(refs, "tiny_baseline_fwd", baseline, seed=5, sigma_gain=300.0, B=2, S=8, N=6, hier=True, kwargs=relu)
