@@ -36,128 +36,153 @@ struct InputGradParams {
 };
 
 constexpr int IG_ROW = 40;     // floats per staged weight row: [w0 xyz, 0 | wc0 dirs xyz, 0 | wc0 grid features 32]
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(float z, float wx, float wy, v2f acc) { return __builtin_elementwise_fma(v2f{z, z}, v2f{wx, wy}, acc); }
 
+// Workgroup = one image's tiles (blockIdx.y = image): the two weight blocks are staged ONCE, every row already multiplied by the image's
+// dz factor (2 pi f' / GEMM result scale), so the inner loop is d theta * row.  A lane owns NP whole points: lanes 0-31 / 32-63 take two
+// different 32-point tiles and fetch BOTH lane halves' 16-byte pieces of a feature group (8 consecutive features of the point), so
+// every lane of the wave multiplies the same weight row (one broadcast LDS read per 4 weights and NP x 64 points), the sums need no
+// cross-lane step, and the loop has no barrier.  Products are v_pk_fma_f32 pairs.
+template <int NP>
 __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P) {
   extern __shared__ float lds[];
   const int H = P.H, L = P.L, G = P.G;
-  float* Wt = lds;                        // [H][IG_ROW]
-  float* sc = Wt + (size_t)H * IG_ROW;    // [2][H]: dz scale of layer 0 | colour layer 0 for the tile's image
-  float* red = sc + 2 * H;                // [4 waves][IG_ROW][32]
-  float* tot = red + 4 * IG_ROW * 32;     // [IG_ROW][32]
+  float* Wt = lds;                        // [H][IG_ROW], scaled
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 31, half = lane >> 5;
+  const int m = lane & 31, t = lane >> 5;
+  const long long b = blockIdx.y;
   const float TWO_PI = 6.28318530717958647692f;
-
   for (int i = tid; i < H * IG_ROW; i += 256) {
     const int n = i / IG_ROW, c = i % IG_ROW;
+    const int l = c < 4 ? 0 : P.n_geo;
     float v = 0.f;
     if (c < 3) v = P.w0[(size_t)n * 3 + c];
     else if (c >= 4 && c < 7) v = P.wc0[(size_t)n * P.wc0_ld + (c - 4)];
     else if (c >= 8 && c - 8 < G) v = P.wc0[(size_t)n * P.wc0_ld + 3 + (c - 8)];
-    Wt[i] = v;
+    Wt[i] = v * (P.fp[((size_t)b * L + l) * H + n] * TWO_PI / (P.inv ? P.inv[(size_t)l * H + n] : 1.f));
   }
+  __syncthreads();
 
-  const long long tl = (long long)(H / 8) * 64;     // float4s per (tile, layer)
-  for (long long tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
-    const long long b = tile * 32 / P.pts_per_image;
-    __syncthreads();      // Wt staged (first trip) / the previous tile's readers of sc, red, tot are done
-    for (int i = tid; i < 2 * H; i += 256) {
-      const int l = i < H ? 0 : P.n_geo, n = i < H ? i : i - H;
-      sc[i] = P.fp[((size_t)b * L + l) * H + n] * TWO_PI / (P.inv ? P.inv[(size_t)l * H + n] : 1.f);
+  const long long tiles_img = P.pts_per_image / 32, tl = (long long)(H / 8) * 64;     // tl: float4s per (tile, layer)
+  const long long units = (tiles_img + 2 * NP - 1) / (2 * NP);
+  const float4* dt4 = reinterpret_cast<const float4*>(P.d_t);
+  for (long long u = (long long)blockIdx.x * 4 + wave; u < units; u += (long long)gridDim.x * 4) {
+    long long gt[NP];      // global tile of the lane's q-th point (clamped to the image's last tile when the unit runs past it)
+    bool valid[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const long long ti = (u * NP + q) * 2 + t;
+      valid[q] = ti < tiles_img;
+      gt[q] = b * tiles_img + (valid[q] ? ti : tiles_img - 1);
     }
-    __syncthreads();
-
-    float a0[3] = {0.f, 0.f, 0.f}, ad[3] = {0.f, 0.f, 0.f}, ae[32];
+    v2f a0[NP][2], ad[NP][2], ae[NP][16];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) ae[c] = 0.f;
-    const float4* d0p = reinterpret_cast<const float4*>(P.d_t) + (tile * L + 0) * tl;
-    const float4* dcp = reinterpret_cast<const float4*>(P.d_t) + (tile * L + P.n_geo) * tl;
-    for (int grp = wave; grp < H / 8; grp += 4) {
-      const float4 d0 = nt_load(d0p + grp * 64 + lane), dc = nt_load(dcp + grp * 64 + lane);
-      const int row = tape_feature(grp, half, 0);
-      const float z0[4] = {d0.x * sc[row + 0], d0.y * sc[row + 1], d0.z * sc[row + 2], d0.w * sc[row + 3]};
-      const float zc[4] = {dc.x * sc[H + row + 0], dc.y * sc[H + row + 1], dc.z * sc[H + row + 2], dc.w * sc[H + row + 3]};
+    for (int q = 0; q < NP; ++q) {
+      a0[q][0] = a0[q][1] = ad[q][0] = ad[q][1] = v2f{0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4* wr = reinterpret_cast<const float4*>(Wt + (size_t)(row + i) * IG_ROW);
+      for (int c = 0; c < 16; ++c) ae[q][c] = v2f{0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int g = 0; g < H / 8; ++g) {
+      float4 d0[NP][2], dc[NP][2];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const float4* p0 = dt4 + (gt[q] * L + 0) * tl + g * 64 + m;
+        const float4* pc = dt4 + (gt[q] * L + P.n_geo) * tl + g * 64 + m;
+        d0[q][0] = nt_load(p0); d0[q][1] = nt_load(p0 + 32);
+        dc[q][0] = nt_load(pc); dc[q][1] = nt_load(pc + 32);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {       // feature 8 g + r = tape_feature(g, r >> 2, r & 3)
+        const float4* wr = reinterpret_cast<const float4*>(Wt + (size_t)(8 * g + r) * IG_ROW);
         const float4 w0 = wr[0], wd = wr[1];
-        a0[0] = fmaf(z0[i], w0.x, a0[0]); a0[1] = fmaf(z0[i], w0.y, a0[1]); a0[2] = fmaf(z0[i], w0.z, a0[2]);
-        ad[0] = fmaf(zc[i], wd.x, ad[0]); ad[1] = fmaf(zc[i], wd.y, ad[1]); ad[2] = fmaf(zc[i], wd.z, ad[2]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const float4 v0 = d0[q][r >> 2], vc = dc[q][r >> 2];
+          const float z0 = (r & 3) == 0 ? v0.x : (r & 3) == 1 ? v0.y : (r & 3) == 2 ? v0.z : v0.w;
+          const float zc = (r & 3) == 0 ? vc.x : (r & 3) == 1 ? vc.y : (r & 3) == 2 ? vc.z : vc.w;
+          a0[q][0] = fma2(z0, w0.x, w0.y, a0[q][0]); a0[q][1] = fma2(z0, w0.z, w0.w, a0[q][1]);
+          ad[q][0] = fma2(zc, wd.x, wd.y, ad[q][0]); ad[q][1] = fma2(zc, wd.z, wd.w, ad[q][1]);
+        }
         if (G) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float4 we = wr[2 + q];
-            ae[4 * q + 0] = fmaf(zc[i], we.x, ae[4 * q + 0]); ae[4 * q + 1] = fmaf(zc[i], we.y, ae[4 * q + 1]);
-            ae[4 * q + 2] = fmaf(zc[i], we.z, ae[4 * q + 2]); ae[4 * q + 3] = fmaf(zc[i], we.w, ae[4 * q + 3]);
+          for (int k = 0; k < 8; ++k) {
+            const float4 we = wr[2 + k];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+              const float4 vc = dc[q][r >> 2];
+              const float zc = (r & 3) == 0 ? vc.x : (r & 3) == 1 ? vc.y : (r & 3) == 2 ? vc.z : vc.w;
+              ae[q][2 * k] = fma2(zc, we.x, we.y, ae[q][2 * k]); ae[q][2 * k + 1] = fma2(zc, we.z, we.w, ae[q][2 * k + 1]);
+            }
           }
         }
       }
     }
-    // the two lane halves hold the two halves of every feature group of the same point: fold, then one partial per wave
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { a0[c] += __shfl_xor(a0[c], 32); ad[c] += __shfl_xor(ad[c], 32); }
+    for (int q = 0; q < NP; ++q) {
+      const long long pt = gt[q] * 32 + m;
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      if (G && P.d_points) {      // grid_sample's backward wrt the coordinates: d ix = sum_corners (+-1) wy wz <d features, grid[corner]>
+        const float qx = P.points[pt * 3 + 0] * P.box_scale, qy = P.points[pt * 3 + 1] * P.box_scale, qz = P.points[pt * 3 + 2] * P.box_scale;
+        const float ix = ((qx + 1.f) / 2.f) * (float)(P.gw - 1);
+        const float iy = ((qy + 1.f) / 2.f) * (float)(P.gh - 1);
+        const float iz = ((qz + 1.f) / 2.f) * (float)(P.gd - 1);
+        const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) ae[c] += __shfl_xor(ae[c], 32);
-    if (half == 0) {
-      float* r = red + (size_t)wave * IG_ROW * 32 + m;
+        for (int c = 0; c < 8; ++c) {
+          const int cz = c >> 2, cy = (c >> 1) & 1, cx = c & 1;
+          const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
+          const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
+          const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
+          const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
+          const bool ok = xi >= 0.f && xi <= (float)(P.gw - 1) && yi >= 0.f && yi <= (float)(P.gh - 1) && zi >= 0.f && zi <= (float)(P.gd - 1);
+          if (ok) {
+            const long long vox = ((long long)(int)zi * P.gh + (int)yi) * P.gw + (int)xi;
+            const float4* gv = reinterpret_cast<const float4*>(P.grid + vox * 32);
+            v2f s2 = v2f{0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { r[c * 32] = a0[c]; r[(4 + c) * 32] = ad[c]; }
-      r[3 * 32] = 0.f; r[7 * 32] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) r[(8 + c) * 32] = ae[c];
-    }
-    __syncthreads();
-    for (int i = tid; i < IG_ROW * 32; i += 256)
-      tot[i] = (red[i] + red[IG_ROW * 32 + i]) + (red[2 * IG_ROW * 32 + i] + red[3 * IG_ROW * 32 + i]);
-    __syncthreads();
-
-    // grid_sample's backward wrt the coordinates: thread = (corner, point); d ix = sum_corners (+-1) wy wz <d features, grid[corner]>
-    float* gr = red;      // [8 corners][3][32], red is free again
-    if (G && P.d_points) {
-      const int corner = tid >> 5, pm = tid & 31;
-      const long long pt = tile * 32 + pm;
-      const float qx = P.points[pt * 3 + 0] * P.box_scale, qy = P.points[pt * 3 + 1] * P.box_scale, qz = P.points[pt * 3 + 2] * P.box_scale;
-      const float ix = ((qx + 1.f) / 2.f) * (float)(P.gw - 1);
-      const float iy = ((qy + 1.f) / 2.f) * (float)(P.gh - 1);
-      const float iz = ((qz + 1.f) / 2.f) * (float)(P.gd - 1);
-      const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
-      const int cz = corner >> 2, cy = (corner >> 1) & 1, cx = corner & 1;
-      const float xi = x0 + cx, yi = y0 + cy, zi = z0 + cz;
-      const float wx = cx ? (ix - x0) : (x0 + 1.f - ix);
-      const float wy = cy ? (iy - y0) : (y0 + 1.f - iy);
-      const float wz = cz ? (iz - z0) : (z0 + 1.f - iz);
-      const bool ok = xi >= 0.f && xi <= (float)(P.gw - 1) && yi >= 0.f && yi <= (float)(P.gh - 1) && zi >= 0.f && zi <= (float)(P.gd - 1);
-      float s = 0.f;
-      if (ok) {
-        const long long vox = ((long long)(int)zi * P.gh + (int)yi) * P.gw + (int)xi;
-        const float4* gv = reinterpret_cast<const float4*>(P.grid + vox * 32);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 v = gv[q];
-          s = fmaf(tot[(8 + 4 * q + 0) * 32 + pm], v.x, s); s = fmaf(tot[(8 + 4 * q + 1) * 32 + pm], v.y, s);
-          s = fmaf(tot[(8 + 4 * q + 2) * 32 + pm], v.z, s); s = fmaf(tot[(8 + 4 * q + 3) * 32 + pm], v.w, s);
+            for (int k = 0; k < 8; ++k) {
+              const float4 v = gv[k];
+              s2 = __builtin_elementwise_fma(ae[q][2 * k], v2f{v.x, v.y}, s2);
+              s2 = __builtin_elementwise_fma(ae[q][2 * k + 1], v2f{v.z, v.w}, s2);
+            }
+            const float s = s2.x + s2.y;
+            gx = fmaf(s, (cx ? 1.f : -1.f) * wy * wz, gx);
+            gy = fmaf(s, wx * (cy ? 1.f : -1.f) * wz, gy);
+            gz = fmaf(s, wx * wy * (cz ? 1.f : -1.f), gz);
+          }
+        }
+        gx *= 0.5f * (float)(P.gw - 1); gy *= 0.5f * (float)(P.gh - 1); gz *= 0.5f * (float)(P.gd - 1);
+      }
+      if (valid[q]) {
+        if (P.d_points) {
+          P.d_points[pt * 3 + 0] = (a0[q][0].x + gx) * P.box_scale;
+          P.d_points[pt * 3 + 1] = (a0[q][0].y + gy) * P.box_scale;
+          P.d_points[pt * 3 + 2] = (a0[q][1].x + gz) * P.box_scale;
+        }
+        if (P.d_dirs) {
+          P.d_dirs[pt * 3 + 0] = ad[q][0].x; P.d_dirs[pt * 3 + 1] = ad[q][0].y; P.d_dirs[pt * 3 + 2] = ad[q][1].x;
         }
       }
-      gr[(corner * 3 + 0) * 32 + pm] = s * ((cx ? 1.f : -1.f) * wy * wz);
-      gr[(corner * 3 + 1) * 32 + pm] = s * (wx * (cy ? 1.f : -1.f) * wz);
-      gr[(corner * 3 + 2) * 32 + pm] = s * (wx * wy * (cz ? 1.f : -1.f));
-    }
-    __syncthreads();
-    if (tid < 96) {
-      const int k = tid >> 5, pm = tid & 31;
-      const long long pt = tile * 32 + pm;
-      if (P.d_points) {
-        float g = 0.f;
-        if (G) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) g += gr[(c * 3 + k) * 32 + pm];
-          g *= 0.5f * (float)((k == 0 ? P.gw : k == 1 ? P.gh : P.gd) - 1);
-        }
-        P.d_points[pt * 3 + k] = (tot[k * 32 + pm] + g) * P.box_scale;
-      }
-      if (P.d_dirs) P.d_dirs[pt * 3 + k] = tot[(4 + k) * 32 + pm];
     }
   }
+}
+
+template <int NP>
+static int launch_ig(const FenerfModel* m, int B, long long P, const InputGradParams& p, void* stream) {
+  auto kfn = siren_input_grad_kernel<NP>;
+  const size_t lds = (size_t)m->H * IG_ROW * sizeof(float);
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
+  // a workgroup's four waves walk units of 2 NP tiles of ONE image; enough workgroups per image to fill the device three deep
+  const long long units = (P / 32 + 2 * NP - 1) / (2 * NP);
+  long long bx = (units + 3) / 4, cap = (3LL * launch_cus(m) + B - 1) / B;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)bx, (unsigned)B), dim3(256), lds, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("input gradient launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+  return FENERF_OK;
 }
 
 int launch_siren_input_grads(const FenerfModel* m, int B, long long P, const float* points, const float* fp, const float* d_t, const float* w_geo0,
@@ -170,14 +195,10 @@ int launch_siren_input_grads(const FenerfModel* m, int B, long long P, const flo
   p.ntiles = (long long)B * P / 32; p.pts_per_image = P;
   p.L = m->L; p.H = m->H; p.n_geo = m->n_geo; p.G = m->grid_ch;
   p.d_points = d_points; p.d_dirs = d_dirs;
-  const size_t lds = ((size_t)m->H * IG_ROW + 2 * (size_t)m->H + 5 * IG_ROW * 32) * sizeof(float);
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(siren_input_grad_kernel), lds)) return rc;
-  long long blocks = 2LL * launch_cus(m);
-  if (blocks > p.ntiles) blocks = p.ntiles;
-  hipLaunchKernelGGL(siren_input_grad_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error(std::string("input gradient launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
-  return FENERF_OK;
+  // two points per lane halve the LDS reads per point (0.31 -> 0.27 ms at 393,216 points, H = 256) but need 128 points per wave step:
+  // only when that still leaves two workgroups per CU (65,536 points: 0.092 vs 0.071 ms the other way round)
+  const long long wgs_np2 = (long long)B * ((P / 32 + 3) / 4 + 3) / 4;
+  return wgs_np2 >= 2LL * launch_cus(m) ? launch_ig<2>(m, B, P, p, stream) : launch_ig<1>(m, B, P, p, stream);
 }
 
 }  // namespace fenerf
