@@ -138,8 +138,9 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     features never exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid;
     inside the chain kernel for f16x3 models).
     tape_format / weights: the tape's format (_lib.TAPE_*) and, for the 16-bit tape, film_layer_weights(...).
-    input_grads: None, or (layer 0's weight, colour layer 0's weight, d_points [nB,Pp,3] or None, d_dirs [nB,Pp,3] or None): every chunk
-    also fills its rows of the gradients wrt the sample positions / view directions from its d(theta) dump (NativeModel.siren_input_grads).
+    input_grads: None, or (layer 0's weight, colour layer 0's weight, d_points [nB,Pp,3] or None, d_dirs [nB,Pp,3] or None[, nothing else
+    wanted]): every chunk also fills its rows of the gradients wrt the sample positions / view directions from its d(theta) dump
+    (NativeModel.siren_input_grads); with the fifth item set (and film_only) the weight-gradient / FiLM-gradient launches are skipped.
     -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
@@ -187,7 +188,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     # The first chain and the last weight-gradient launch have the device to themselves.  Every d(theta) dump is kept alive until the
     # end of the loop and tied to the side stream (record_stream); scratch is per stream (NativeModel._workspace).
     dev = out.device
-    overlap = OVERLAP_WGRAD and len(chunks) > 1
+    inputs_only = bool(input_grads is not None and film_only and len(input_grads) > 4 and input_grads[4])
+    overlap = OVERLAP_WGRAD and len(chunks) > 1 and not inputs_only
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if overlap else main
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -210,7 +212,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
                 d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c, tape_format=tape_format)
         if input_grads is not None:       # a chunk is whole images or a point range of one image: its rows are contiguous
-            w_g0, w_c0, dp, dd = input_grads
+            w_g0, w_c0, dp, dd = input_grads[:4]
             nat.siren_input_grads(pts_c, *film_c, d_t, w_g0, w_c0, dp[b:b + nb, s:s + n] if dp is not None else None,
                                   dd[b:b + nb, s:s + n] if dd is not None else None)
         if overlap:
@@ -219,6 +221,9 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             side.wait_event(ev)
             d_t.record_stream(side)
             keep.append(d_t)
+        if inputs_only:        # nothing but d points / d view directions was asked for: the dump has been read, no weight-gradient launch
+            del d_t
+            continue
         with torch.cuda.stream(side), native.cu_budget(wgrad_cus if (overlap and not last) else 0):
             r = nat.siren_param_grads(pts_c, dirs[b:b + nb, s:s + n] if dirs is not None else None, *film_c, out_c, d_out_c, tape_c,
                                       tape_e[g0:g0 + nb * n] if G else None, d_t, film_only=film_only, tape_format=tape_format, weights=weights)
@@ -236,6 +241,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             if last:
                 for k, rows in film_rows.items():
                     total[k] = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+    if inputs_only:
+        return {k: None for k in FILM_KEYS}, None
     if overlap:
         main.wait_stream(side)
         for t in _flat(total):            # allocated on the side stream, consumed by autograd on `main`
@@ -384,7 +391,7 @@ class SirenFunction(torch.autograd.Function):
         input_grads = None
         if d_points is not None or d_dirs is not None:
             w_geo, w_col = film_layer_weights(module, params)
-            input_grads = (w_geo[0], w_col[0], d_points, d_dirs)
+            input_grads = (w_geo[0], w_col[0], d_points, d_dirs, film_only and not any(need[3:7]))
         r, d_grid = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
                                      tape_e if tape_e.numel() else None, film_only, tape_format=ctx.tape_format,
                                      weights=film_layer_weights(module, params) if ctx.tape_format else None, input_grads=input_grads)
