@@ -989,6 +989,7 @@ extern "C" int fenerf_siren_input_grads(const FenerfModel* m, int B, int64_t P, 
   if (m->grid_ch != 0 && m->grid_ch != 32) return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_input_grads: feature grids of 32 channels only");
   if (m->grid_ch && d_points && !points) return fail(FENERF_E_INVALID, "points is NULL (the grid's coordinate gradient needs the sample positions)");
   if (w_color0_ld < 3 + m->grid_ch) return fail(FENERF_E_INVALID, "w_color0_ld < 3 + grid channels");
+  if (B > 65535) return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_input_grads: at most 65535 images per call (one grid row per image)");
   if (use_bf16_dump(m, (long long)B * P))
     return fail(FENERF_E_UNSUPPORTED, "fenerf_siren_input_grads reads the fp32 d(theta) dump; this chunk's dump is bf16 (wgrad_bf16_min_points)");
   int rc = check_dump(m, d_t, (long long)B * P);
