@@ -535,3 +535,68 @@ def render_latent_video(generator, seed, options, trajectory, latent_type="geo",
         out["depth"].append(depth)
     return {k: torch.cat(v) for k, v in out.items()}
 
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The image dump of the reference's FID evaluation (fid_evaluation.py:96-150), which is how its forward path runs on several GPUs:
+# every rank renders batches of 4 identities with staged_forward and writes the images whose ids are rank, rank + world, ... -- no
+# data-path collective (the FID statistics themselves are third-party code on the dumped files and are not part of this package).
+# ------------------------------------------------------------------------------------------------------------------------------------
+def fid_dump_metadata(input_metadata, img_size=128, batch_size=4):
+    """The option bag both dump loops build from the training step's metadata (fid_evaluation.py:97-106, :127-135): 128 x 128, batches
+    of 4, the *_eval pose spread / distribution when the curriculum has them, psi = 1."""
+    import copy
+    metadata = copy.deepcopy(dict(input_metadata))
+    metadata['img_size'] = img_size
+    metadata['batch_size'] = batch_size
+    metadata['h_stddev'] = metadata.get('h_stddev_eval', metadata['h_stddev'])
+    metadata['v_stddev'] = metadata.get('v_stddev_eval', metadata['v_stddev'])
+    metadata['sample_dist'] = metadata.get('sample_dist_eval', metadata['sample_dist'])
+    metadata['psi'] = 1
+    return metadata
+
+
+def _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw, save):
+    import os
+    from . import imageio_lite
+    module = getattr(generator, "module", generator)        # the reference passes the DistributedDataParallel wrapper
+    os.makedirs(output_dir, exist_ok=True)
+    save = save or (lambda img, path: imageio_lite.save_image(img, path, normalize=True, value_range=(-1, 1)))
+    generator.eval()
+    img_counter = rank
+    written = []
+    with torch.no_grad():
+        while img_counter < num_imgs:
+            generated_imgs = draw(module, metadata)
+            for img in generated_imgs:          # (a batch is written out whole: the last one may run past num_imgs, as in the reference)
+                if img.shape[0] != 3:
+                    img = img[-3:]
+                path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
+                save(img, path)
+                written.append(path)
+                img_counter += world_size
+    return written
+
+
+def output_images(generator, input_metadata, rank, world_size, output_dir, num_imgs=2048, save=None):
+    """fid_evaluation.output_images (:96-123) for the single-latent generators: z ~ randn [4, z_dim] per batch,
+    staged_forward(z, **metadata)[0], image ids rank, rank + world_size, ... as `<id:05>.jpg` normalised from [-1, 1].
+    -> the paths this rank wrote.  `save(img [3,S,S], path)` replaces the writer (tests)."""
+    metadata = fid_dump_metadata(input_metadata)
+
+    def draw(module, md):
+        z = torch.randn((md['batch_size'], module.z_dim), device=module.device)
+        return module.staged_forward(z, **md)[0]
+    return _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw, save)
+
+
+def output_images_double(generator, input_metadata, rank, world_size, output_dir, num_imgs=2048, save=None):
+    """fid_evaluation.output_images_double (:126-150) for the two-latent generators: z_geo then z_app ~ randn [4, dim] per batch,
+    staged_forward(z_geo, z_app, **metadata)[0], the last three channels (rgb) of every image, ids rank, rank + world_size, ..."""
+    metadata = fid_dump_metadata(input_metadata)
+
+    def draw(module, md):
+        z_geo = torch.randn((md['batch_size'], module.z_geo_dim), device=module.device)
+        z_app = torch.randn((md['batch_size'], module.z_app_dim), device=module.device)
+        return module.staged_forward(z_geo, z_app, **md)[0]
+    return _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw, save)

@@ -251,3 +251,131 @@ def test_inversion_targets_options_and_trajectories():
          "w_geo_phase_shift_offsets", "w_app_frequency_offsets", "w_app_phase_shift_offsets"))}
     fg, fa, pg, pa = callers.film_from_inversion(meta)
     assert (float(fg[0, 0]), float(fa[0, 0]), float(pg[0, 0]), float(pa[0, 0])) == (0 + 4, 2 + 6, 1 + 5, 3 + 7)
+
+
+# ---- the FID image dump (fid_evaluation.py:96-150): how the reference runs its forward path on several GPUs ---------------------------
+class _StandInDouble:
+    """a two-latent generator's surface as the dump loops use it (device, z_geo_dim / z_app_dim, eval, staged_forward)"""
+    z_geo_dim, z_app_dim = 5, 7
+
+    def __init__(self):
+        self.device, self.training, self.calls = torch.device("cpu"), True, []
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def staged_forward(self, z_geo, z_app, **md):
+        self.calls.append((z_geo.clone(), z_app.clone(), dict(md)))
+        B, S = z_geo.shape[0], 6
+        base = (z_geo.sum(1) + 2 * z_app.sum(1)).reshape(B, 1, 1, 1)
+        return torch.tanh(base + torch.arange(21 * S * S, dtype=torch.float32).reshape(1, 21, S, S) / (21 * S * S)), torch.zeros(B, S, S)
+
+
+class _StandInSingle(_StandInDouble):
+    z_dim = 4
+
+    def staged_forward(self, z, **md):
+        self.calls.append((z.clone(), dict(md)))
+        B, S = z.shape[0], 6
+        return torch.tanh(z.sum(1).reshape(B, 1, 1, 1) + torch.zeros(B, 3, S, S)), torch.zeros(B, S, S), torch.zeros(B, S, S)
+
+
+class _DDPLike:
+    def __init__(self, module):
+        self.module = module
+
+    def eval(self):
+        self.module.eval()
+        return self
+
+
+_DUMP_MD = dict(img_size=32, batch_size=24, h_stddev=0.3, v_stddev=0.155, h_stddev_eval=0.2, sample_dist='gaussian', sample_dist_eval='uniform',
+                psi=0.7, num_steps=24, fov=12, clamp_mode='relu', nerf_noise=0.0)
+
+
+def _run_dump(fn, gen, rank, world, num_imgs, tmp, seed=100):
+    torch.manual_seed(seed + rank)
+    got = []
+    paths = fn(_DDPLike(gen), _DUMP_MD, rank, world, str(tmp), num_imgs=num_imgs, save=lambda img, path: got.append((os.path.basename(path), img.clone())))
+    assert [os.path.basename(p) for p in paths] == [n for n, _ in got]
+    return got
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_fid_image_dump_shards_by_image_id(tmp_path, world):
+    """callers.output_images_double / output_images: every rank writes the ids rank, rank + world, ... (whole batches of 4, so the last
+    batch may run past num_imgs, as in the reference); the option bag is the reference's (128 x 128, batch 4, *_eval overrides, psi 1);
+    draws are z_geo then z_app per batch; rgb = the last three channels; the caller's metadata is not modified."""
+    num = 10
+    ids = set()
+    for rank in range(world):
+        gen = _StandInDouble()
+        got = _run_dump(callers.output_images_double, gen, rank, world, num, tmp_path)
+        mine = [int(n.split(".")[0]) for n, _ in got]
+        assert mine == list(range(rank, rank + world * len(mine), world)) and all(n.endswith(".jpg") and len(n) == 9 for n, _ in got)
+        assert len(mine) % 4 == 0 and mine[-4] < num <= mine[-1] + world      # the last batch started below num_imgs and ended at or past it
+        ids |= set(mine)
+        assert not gen.training
+        torch.manual_seed(100 + rank)
+        for k, (zg, za, md) in enumerate(gen.calls):
+            assert torch.equal(zg, torch.randn(4, 5)) and torch.equal(za, torch.randn(4, 7))
+            assert md["img_size"] == 128 and md["batch_size"] == 4 and md["psi"] == 1 and md["h_stddev"] == 0.2 and md["v_stddev"] == 0.155
+            assert md["sample_dist"] == "uniform" and md["num_steps"] == 24
+            ref = gen.staged_forward(zg, za)[0]
+            gen.calls.pop()
+            for j in range(4):
+                assert got[4 * k + j][1].shape == (3, 6, 6) and torch.equal(got[4 * k + j][1], ref[j, -3:])
+    assert set(range(num)) <= ids
+    assert _DUMP_MD["img_size"] == 32 and _DUMP_MD["psi"] == 0.7
+    one = _StandInSingle()
+    got = _run_dump(callers.output_images, one, 0, 1, 5, tmp_path)
+    assert [n for n, _ in got] == [f"{i:05d}.jpg" for i in range(8)] and len(one.calls) == 2 and one.calls[0][0].shape == (4, 4)
+    # the default writer: a JPEG through Pillow, normalised from [-1, 1]
+    from PIL import Image
+    paths = callers.output_images(_StandInSingle(), _DUMP_MD, 0, 1, str(tmp_path / "jpg"), num_imgs=1)
+    assert len(paths) == 4 and np.asarray(Image.open(paths[0])).shape == (6, 6, 3)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+@pytest.mark.parametrize("world", [1, 2])
+def test_fid_image_dump_equals_the_references_own_loops(tmp_path, world):
+    """fid_evaluation.output_images / output_images_double themselves (AST-extracted from the reference's file -- importing it needs
+    torchvision and pytorch_fid --, executed with a recording save_image) on the same stand-in generator and seeds: same file names, same
+    tensors, same calls."""
+    import ast
+    import copy
+    src = open("/root/reference/fid_evaluation.py").read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ("output_images", "output_images_double")]
+    assert len(fns) == 2
+    rec = []
+
+    class _Bar:
+        def __init__(self, *a, **k): pass
+        def update(self, n): pass
+        def close(self): pass
+
+    def save_image(img, path, normalize=False, range=None):
+        assert normalize is True and tuple(range) == (-1, 1)
+        rec.append((os.path.basename(path), img.clone()))
+    ns = dict(copy=copy, os=os, torch=torch, tqdm=_Bar, save_image=save_image)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "fid_evaluation.py", "exec"), ns)
+    for name, stand_in in (("output_images_double", _StandInDouble), ("output_images", _StandInSingle)):
+        for rank in range(world):
+            gen_ref, gen_own = stand_in(), stand_in()
+            rec.clear()
+            torch.manual_seed(7 + rank)
+            ns[name](_DDPLike(gen_ref), _DUMP_MD, rank, world, str(tmp_path), num_imgs=9)
+            theirs = list(rec)
+            ours = _run_dump(getattr(callers, name), gen_own, rank, world, 9, tmp_path, seed=7)
+            assert [n for n, _ in ours] == [n for n, _ in theirs] and all(torch.equal(a[1], b[1]) for a, b in zip(ours, theirs))
+            assert len(gen_ref.calls) == len(gen_own.calls)
+            for a, b in zip(gen_ref.calls, gen_own.calls):
+                assert all(torch.equal(x, y) for x, y in zip(a[:-1], b[:-1])) and a[-1] == b[-1]
+
+
+def test_dump_images_front_end_arguments():
+    import dump_images
+    opt = dump_images.build_parser().parse_args(["ckpt/generator.pth", "--curriculum", "CelebA", "--num_imgs", "64", "--output_dir", "o", "--one_device",
+                                                 "--dist_backend", "gloo", "--seed", "3"])
+    assert opt.path == "ckpt/generator.pth" and opt.num_imgs == 64 and opt.one_device and opt.dist_backend == "gloo" and opt.step == 100000 and opt.seed == 3
