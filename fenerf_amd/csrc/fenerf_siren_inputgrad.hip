@@ -43,11 +43,12 @@ __device__ __forceinline__ v2f fma2(float z, float wx, float wy, v2f acc) { retu
 // dz factor (2 pi f' / GEMM result scale), so the inner loop is d theta * row.  A lane owns NP whole points: lanes 0-31 / 32-63 take two
 // different 32-point tiles and fetch BOTH lane halves' 16-byte pieces of a feature group (8 consecutive features of the point), so
 // every lane of the wave multiplies the same weight row (one broadcast LDS read per 4 weights and NP x 64 points), the sums need no
-// cross-lane step, and the loop has no barrier.  Products are v_pk_fma_f32 pairs.
-template <int NP>
+// cross-lane step, and the loop has no barrier.  Products are v_pk_fma_f32 pairs; the dump rows of the next feature group are in flight
+// while the current one is multiplied.
+template <int NP, bool GRID>
 __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P) {
   extern __shared__ float lds[];
-  const int H = P.H, L = P.L, G = P.G;
+  const int H = P.H, L = P.L, G = GRID ? 32 : 0;
   float* Wt = lds;                        // [H][IG_ROW], scaled
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, t = lane >> 5;
@@ -83,15 +84,28 @@ __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P
 #pragma unroll
       for (int c = 0; c < 16; ++c) ae[q][c] = v2f{0.f, 0.f};
     }
+    // the dump rows of feature group g + 1 are in flight while group g is multiplied (two waves per SIMD do not cover an HBM round trip)
+    const float4* p0[NP];
+    const float4* pc[NP];
+    float4 n0[NP][2], nc[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      p0[q] = dt4 + (gt[q] * L + 0) * tl + m;
+      pc[q] = dt4 + (gt[q] * L + P.n_geo) * tl + m;
+      n0[q][0] = nt_load(p0[q]); n0[q][1] = nt_load(p0[q] + 32);
+      nc[q][0] = nt_load(pc[q]); nc[q][1] = nt_load(pc[q] + 32);
+    }
 #pragma unroll 1
     for (int g = 0; g < H / 8; ++g) {
       float4 d0[NP][2], dc[NP][2];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const float4* p0 = dt4 + (gt[q] * L + 0) * tl + g * 64 + m;
-        const float4* pc = dt4 + (gt[q] * L + P.n_geo) * tl + g * 64 + m;
-        d0[q][0] = nt_load(p0); d0[q][1] = nt_load(p0 + 32);
-        dc[q][0] = nt_load(pc); dc[q][1] = nt_load(pc + 32);
+      for (int q = 0; q < NP; ++q) { d0[q][0] = n0[q][0]; d0[q][1] = n0[q][1]; dc[q][0] = nc[q][0]; dc[q][1] = nc[q][1]; }
+      if (g + 1 < H / 8) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          n0[q][0] = nt_load(p0[q] + (g + 1) * 64); n0[q][1] = nt_load(p0[q] + (g + 1) * 64 + 32);
+          nc[q][0] = nt_load(pc[q] + (g + 1) * 64); nc[q][1] = nt_load(pc[q] + (g + 1) * 64 + 32);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {       // feature 8 g + r = tape_feature(g, r >> 2, r & 3)
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P
           a0[q][0] = fma2(z0, w0.x, w0.y, a0[q][0]); a0[q][1] = fma2(z0, w0.z, w0.w, a0[q][1]);
           ad[q][0] = fma2(zc, wd.x, wd.y, ad[q][0]); ad[q][1] = fma2(zc, wd.z, wd.w, ad[q][1]);
         }
-        if (G) {
+        if (GRID) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const float4 we = wr[2 + k];
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P
     for (int q = 0; q < NP; ++q) {
       const long long pt = gt[q] * 32 + m;
       float gx = 0.f, gy = 0.f, gz = 0.f;
-      if (G && P.d_points) {      // grid_sample's backward wrt the coordinates: d ix = sum_corners (+-1) wy wz <d features, grid[corner]>
+      if (GRID && P.d_points) {      // grid_sample's backward wrt the coordinates: d ix = sum_corners (+-1) wy wz <d features, grid[corner]>
         const float qx = P.points[pt * 3 + 0] * P.box_scale, qy = P.points[pt * 3 + 1] * P.box_scale, qz = P.points[pt * 3 + 2] * P.box_scale;
         const float ix = ((qx + 1.f) / 2.f) * (float)(P.gw - 1);
         const float iy = ((qy + 1.f) / 2.f) * (float)(P.gh - 1);
@@ -169,9 +183,9 @@ __global__ __launch_bounds__(256) void siren_input_grad_kernel(InputGradParams P
   }
 }
 
-template <int NP>
+template <int NP, bool GRID>
 static int launch_ig(const FenerfModel* m, int B, long long P, const InputGradParams& p, void* stream) {
-  auto kfn = siren_input_grad_kernel<NP>;
+  auto kfn = siren_input_grad_kernel<NP, GRID>;
   const size_t lds = (size_t)m->H * IG_ROW * sizeof(float);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds)) return rc;
   // a workgroup's four waves walk units of 2 NP tiles of ONE image; enough workgroups per image to fill the device three deep
@@ -195,10 +209,9 @@ int launch_siren_input_grads(const FenerfModel* m, int B, long long P, const flo
   p.ntiles = (long long)B * P / 32; p.pts_per_image = P;
   p.L = m->L; p.H = m->H; p.n_geo = m->n_geo; p.G = m->grid_ch;
   p.d_points = d_points; p.d_dirs = d_dirs;
-  // two points per lane halve the LDS reads per point (0.31 -> 0.27 ms at 393,216 points, H = 256) but need 128 points per wave step:
-  // only when that still leaves two workgroups per CU (65,536 points: 0.092 vs 0.071 ms the other way round)
-  const long long wgs_np2 = (long long)B * ((P / 32 + 3) / 4 + 3) / 4;
-  return wgs_np2 >= 2LL * launch_cus(m) ? launch_ig<2>(m, B, P, p, stream) : launch_ig<1>(m, B, P, p, stream);
+  // NP = 1: two points per lane halve the LDS reads per point, but at 222 registers leave two waves per SIMD where one point per lane
+  // runs three -- measured 0.229 vs 0.213 ms at 393,216 points, 0.062 vs 0.056 ms at 65,536 (profiles/r06_input_grads_timing.txt)
+  return m->grid_ch ? launch_ig<1, true>(m, B, P, p, stream) : launch_ig<1, false>(m, B, P, p, stream);
 }
 
 }  // namespace fenerf
