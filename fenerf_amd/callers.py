@@ -600,3 +600,29 @@ def output_images_double(generator, input_metadata, rank, world_size, output_dir
         z_app = torch.randn((md['batch_size'], module.z_app_dim), device=module.device)
         return module.staged_forward(z_geo, z_app, **md)[0]
     return _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw, save)
+
+
+def eval_metrics_images(generator, curriculum, output_dir, num_images=2048, max_batch_size=94800000, save=None):
+    """The image loop of the reference's eval_metrics.py (:41-52; single-latent generators): render options = the curriculum stage of
+    `generator.step` with img_size 128, psi 1, last_back = eval_last_back, nerf_noise 0; one identity per call, z ~ randn [1, latent_dim],
+    staged_forward(z, max_batch_size=..., **options)[0] written as `<i:05>.jpg` normalised from [-1, 1].  (The script then hands the
+    directory to torch_fidelity -- third-party, not part of this package.)  -> the paths written."""
+    import os
+    from . import curriculums as _cur, imageio_lite
+    options = _cur.extract_metadata(curriculum, generator.step)
+    options['img_size'] = 128
+    options['psi'] = 1
+    options['last_back'] = options.get('eval_last_back', False)
+    options['nerf_noise'] = 0
+    os.makedirs(output_dir, exist_ok=True)
+    save = save or (lambda img, path: imageio_lite.save_image(img, path, normalize=True, value_range=(-1, 1)))
+    generator.eval()
+    written = []
+    for img_counter in range(num_images):
+        z = torch.randn(1, options['latent_dim'], device=generator.device)
+        with torch.no_grad():
+            img = generator.staged_forward(z, max_batch_size=max_batch_size, **options)[0].to(generator.device)
+        path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
+        save(img, path)
+        written.append(path)
+    return written

@@ -379,3 +379,22 @@ def test_dump_images_front_end_arguments():
     opt = dump_images.build_parser().parse_args(["ckpt/generator.pth", "--curriculum", "CelebA", "--num_imgs", "64", "--output_dir", "o", "--one_device",
                                                  "--dist_backend", "gloo", "--seed", "3"])
     assert opt.path == "ckpt/generator.pth" and opt.num_imgs == 64 and opt.one_device and opt.dist_backend == "gloo" and opt.step == 100000 and opt.seed == 3
+
+
+def test_eval_metrics_image_loop_options_and_draws(tmp_path):
+    """callers.eval_metrics_images = the loop of the reference's eval_metrics.py:41-52: the stage of generator.step, 128 x 128, psi 1,
+    last_back = eval_last_back, nerf_noise 0, one randn [1, latent_dim] per image, max_batch_size handed through."""
+    class Gen(_StandInSingle):
+        step = 25000
+    gen = Gen()
+    cur = {0: dict(img_size=32, num_steps=12), 20000: dict(img_size=64, num_steps=24), 'latent_dim': 4, 'eval_last_back': True, 'last_back': False,
+           'fov': 12, 'psi': 0.5, 'nerf_noise': 1.0, 'clamp_mode': 'relu'}
+    got = []
+    torch.manual_seed(3)
+    paths = callers.eval_metrics_images(gen, cur, str(tmp_path / "e"), num_images=3, max_batch_size=777, save=lambda img, path: got.append((os.path.basename(path), img.clone())))
+    assert [os.path.basename(p) for p in paths] == ["00000.jpg", "00001.jpg", "00002.jpg"] and len(gen.calls) == 3 and not gen.training
+    torch.manual_seed(3)
+    for z, md in gen.calls:
+        assert torch.equal(z, torch.randn(1, 4))
+        assert md["img_size"] == 128 and md["num_steps"] == 24 and md["psi"] == 1 and md["last_back"] is True and md["nerf_noise"] == 0 and md["max_batch_size"] == 777
+    assert got[0][1].shape == (1, 3, 6, 6) and cur["psi"] == 0.5 and cur[20000]["img_size"] == 64
