@@ -626,3 +626,46 @@ def eval_metrics_images(generator, curriculum, output_dir, num_images=2048, max_
         save(img, path)
         written.append(path)
     return written
+
+
+def training_snapshots(generator, ema, fixed_z_geo, fixed_z_app, metadata, output_dir, step, device=None):
+    """The sample-image block of the reference's training loop (train_double_latent_semantic.py:464-523), which is how staged_forward is
+    called DURING training: under autocast, 25 fixed identities at 128 x 128 with the pose spread at zero, frontal and tilted
+    (h_mean + 0.5), with the live weights and again with the EMA weights swapped in (store / copy_to / eval ... restore), plus 25 fresh
+    identities at psi = 0.7 under the EMA weights.  Writes `<step>_{seg,img}_{fixed,tilted,fixed_ema,tilted_ema,random}.png`
+    (5 x 5 grids, normalised over the batch like torchvision's save_image(normalize=True)) -> their paths.
+    `generator`: the module or its DistributedDataParallel wrapper; `ema`: a torch_ema.ExponentialMovingAverage (or fenerf_amd.ema's)."""
+    import copy
+    import os
+    from . import imageio_lite
+    module = getattr(generator, "module", generator)
+    device = module.device if device is None else device
+    os.makedirs(output_dir, exist_ok=True)
+    written = []
+
+    def dump(tag, z_geo, z_app, **overrides):
+        with torch.no_grad():
+            with torch.autocast("cuda", enabled=torch.device(device).type == "cuda"):
+                copied_metadata = copy.deepcopy(metadata)
+                copied_metadata['h_stddev'] = copied_metadata['v_stddev'] = 0
+                copied_metadata['img_size'] = 128
+                for k, v in overrides.items():
+                    copied_metadata[k] = copied_metadata[k] + v if k == 'h_mean' else v
+                gen_imgs = module.staged_forward(z_geo.to(device), z_app.to(device), **copied_metadata)[0]
+                gen_labels = mask2color(gen_imgs[:, :-3])
+        for kind, t in (("seg", gen_labels[:25]), ("img", gen_imgs[:25, -3:])):
+            path = os.path.join(output_dir, f"{step}_{kind}_{tag}.png")
+            imageio_lite.save_image(t, path, nrow=5, normalize=True)
+            written.append(path)
+
+    generator.eval()
+    dump("fixed", fixed_z_geo, fixed_z_app)
+    dump("tilted", fixed_z_geo, fixed_z_app, h_mean=0.5)
+    ema.store(generator.parameters())
+    ema.copy_to(generator.parameters())
+    generator.eval()
+    dump("fixed_ema", fixed_z_geo, fixed_z_app)
+    dump("tilted_ema", fixed_z_geo, fixed_z_app, h_mean=0.5)
+    dump("random", torch.randn_like(fixed_z_geo), torch.randn_like(fixed_z_app), psi=0.7)
+    ema.restore(generator.parameters())
+    return written

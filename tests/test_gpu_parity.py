@@ -3985,3 +3985,53 @@ def test_fid_image_dump_two_ranks_on_one_gpu(tmp_path):
     want = ((ref[0, -3:].clamp(-1, 1) + 1) / 2 * 255).permute(1, 2, 0).cpu().numpy()
     print(f"[parity] FID image dump, two ranks on one GPU: 16 JPEGs; rank 0's first file vs staged_forward on the same draws: mean |diff| {np.abs(ims[0] - want).mean():.2f} grey levels")
     assert np.abs(ims[0] - want).mean() < 4.0
+
+
+def test_training_snapshots_under_autocast_with_the_ema_swap(tmp_path):
+    """callers.training_snapshots = the sample-image block of the reference's training loop (train_double_latent_semantic.py:464-523):
+    staged_forward under autocast, live and EMA weights (store / copy_to / eval ... restore through param.data-free copies), ten 5 x 5
+    grids.  The EMA grids are the renders of the EMA weights, the live weights come back bit for bit, and the next render uses them."""
+    import json
+    from PIL import Image
+    from fenerf_amd import callers, curriculums, ema as ema_mod
+    g = load_golden("tiny_multiview")
+    ckpt = _tiny_checkpoint_dir(tmp_path)
+    cur = json.loads(str(g["curriculum_json"]))
+    cur.update(output_dim=22, eval_last_back=False)
+    cur_i = {(int(k[4:]) if k.startswith("int:") else k): v for k, v in cur.items()}
+    md = curriculums.extract_metadata(cur_i, 100000)
+    md["nerf_noise"] = 0.0
+    gen = callers.load_generator(ckpt, DEV, use_ema=False, reset_render_options=False)
+    gen.train()
+    ema = ema_mod.ExponentialMovingAverage(gen.parameters(), decay=0.999)
+    with torch.no_grad():
+        for s_ in ema.shadow_params:             # an average that differs from the live weights
+            s_.mul_(0.9)
+    before = [p.detach().clone() for p in gen.parameters()]
+    torch.manual_seed(0)
+    zg, za = torch.randn(25, gen.z_geo_dim), torch.randn(25, gen.z_app_dim)          # on the CPU, as the training loop keeps them (:113-114)
+    torch.manual_seed(1)
+    paths = callers.training_snapshots(gen, ema, zg, za, md, str(tmp_path / "snap"), step=7000)
+    names = [os.path.basename(p) for p in paths]
+    assert names == [f"7000_{k}_{t}.png" for t in ("fixed", "tilted", "fixed_ema", "tilted_ema", "random") for k in ("seg", "img")]
+    ims = {n: np.asarray(Image.open(p)) for n, p in zip(names, paths)}
+    assert all(im.shape == (5 * 130 + 2, 5 * 130 + 2, 3) for im in ims.values())
+    assert all(torch.equal(a, b) for a, b in zip(before, gen.parameters())) and not gen.training
+    assert not np.array_equal(ims["7000_img_fixed.png"], ims["7000_img_fixed_ema.png"]) and not np.array_equal(ims["7000_img_fixed.png"], ims["7000_img_tilted.png"])
+    # the grids are what staged_forward gives for those weights: live weights now (restored), EMA weights after copy_to
+    def grid_of(**over):
+        opts = dict(md, h_stddev=0, v_stddev=0, img_size=128, **over)
+        with torch.no_grad(), torch.autocast("cuda"):
+            px = gen.staged_forward(zg.to(DEV), za.to(DEV), **opts)[0]
+        from fenerf_amd import imageio_lite
+        return imageio_lite.to_uint8_hwc(imageio_lite.make_grid(px[:25, -3:], nrow=5, normalize=True))
+    torch.manual_seed(1)                         # replay the block's draws: frontal, tilted, (EMA swap) frontal
+    live, tilted = grid_of(), grid_of(h_mean=md["h_mean"] + 0.5)
+    assert np.abs(live.astype(int) - ims["7000_img_fixed.png"].astype(int)).max() <= 1
+    assert np.abs(tilted.astype(int) - ims["7000_img_tilted.png"].astype(int)).max() <= 1
+    ema.copy_to(gen.parameters())
+    gen.eval()
+    avg = grid_of()
+    d = np.abs(avg.astype(int) - ims["7000_img_fixed_ema.png"].astype(int)).max()
+    print(f"[parity] training snapshots: 10 grids of 25 x 128 x 128 under autocast; live grids reproduced, EMA grid within {d} grey level(s)")
+    assert d <= 1
