@@ -10,6 +10,8 @@ Data path on the GPU, all native (include/fenerf.h):
               fenerf_grid_backward        trilinear scatter into the feature-grid gradient
 What is left to torch is the fold of the activation-free label head (tiny products) and handing the buffers to autograd.
 """
+import typing
+
 import torch
 
 from .. import native
@@ -128,6 +130,15 @@ def film_layer_weights(module, params):
     return [W for W, _ in roles["geo"]], [W for W, _ in roles["color"]]
 
 
+class InputGrads(typing.NamedTuple):
+    """what chunked_backward needs to also deliver the gradients wrt the SIREN's inputs (NativeModel.siren_input_grads)"""
+    w_geo0: torch.Tensor                  # layer 0's nn.Linear weight [H, 3]
+    w_color0: torch.Tensor                # colour layer 0's [H, 3 + G + H]
+    d_points: typing.Optional[torch.Tensor]   # [nB, Pp, 3] to fill, or None
+    d_dirs: typing.Optional[torch.Tensor]     # [nB, Pp, 3] to fill, or None
+    only: bool = False                    # nothing else is wanted (with film_only): the weight- / FiLM-gradient launches are skipped
+
+
 def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None, tape_format=0, weights=None,
                      input_grads=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
@@ -138,9 +149,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     features never exists as a tensor: every chunk scatters it into one channels-last gradient grid (fenerf_siren_backward_grid;
     inside the chain kernel for f16x3 models).
     tape_format / weights: the tape's format (_lib.TAPE_*) and, for the 16-bit tape, film_layer_weights(...).
-    input_grads: None, or (layer 0's weight, colour layer 0's weight, d_points [nB,Pp,3] or None, d_dirs [nB,Pp,3] or None[, nothing else
-    wanted]): every chunk also fills its rows of the gradients wrt the sample positions / view directions from its d(theta) dump
-    (NativeModel.siren_input_grads); with the fifth item set (and film_only) the weight-gradient / FiLM-gradient launches are skipped.
+    input_grads: None or an InputGrads: every chunk also fills its rows of the gradients wrt the sample positions / view directions
+    from its d(theta) dump (NativeModel.siren_input_grads); with `only` set (and film_only) the weight- / FiLM-gradient launches are skipped.
     -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
@@ -188,7 +198,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     # The first chain and the last weight-gradient launch have the device to themselves.  Every d(theta) dump is kept alive until the
     # end of the loop and tied to the side stream (record_stream); scratch is per stream (NativeModel._workspace).
     dev = out.device
-    inputs_only = bool(input_grads is not None and film_only and len(input_grads) > 4 and input_grads[4])
+    inputs_only = bool(input_grads is not None and film_only and input_grads.only)
     overlap = OVERLAP_WGRAD and len(chunks) > 1 and not inputs_only
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if overlap else main
@@ -212,8 +222,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
             else:       # no grid, or inversion (only FiLM gradients wanted: nothing to scatter)
                 d_t, _ = nat.siren_backward(nb, n, *film_c, out_c, d_out_c, tape_c, tape_format=tape_format)
         if input_grads is not None:       # a chunk is whole images or a point range of one image: its rows are contiguous
-            w_g0, w_c0, dp, dd = input_grads[:4]
-            nat.siren_input_grads(pts_c, *film_c, d_t, w_g0, w_c0, dp[b:b + nb, s:s + n] if dp is not None else None,
+            dp, dd = input_grads.d_points, input_grads.d_dirs
+            nat.siren_input_grads(pts_c, *film_c, d_t, input_grads.w_geo0, input_grads.w_color0, dp[b:b + nb, s:s + n] if dp is not None else None,
                                   dd[b:b + nb, s:s + n] if dd is not None else None)
         if overlap:
             ev = torch.cuda.Event()
@@ -391,7 +401,7 @@ class SirenFunction(torch.autograd.Function):
         input_grads = None
         if d_points is not None or d_dirs is not None:
             w_geo, w_col = film_layer_weights(module, params)
-            input_grads = (w_geo[0], w_col[0], d_points, d_dirs, film_only and not any(need[3:7]))
+            input_grads = InputGrads(w_geo[0], w_col[0], d_points, d_dirs, only=film_only and not any(need[3:7]))
         r, d_grid = chunked_backward(nat, B, P, (fg, pg, fa, pa), points, dirs if ctx.has_dirs else None, out, d_out, tape,
                                      tape_e if tape_e.numel() else None, film_only, tape_format=ctx.tape_format,
                                      weights=film_layer_weights(module, params) if ctx.tape_format else None, input_grads=input_grads)
