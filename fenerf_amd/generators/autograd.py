@@ -202,6 +202,86 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
+# Exact sparsity of the backward pass (round 6; opt-in per module, `siren.sparse_backward = True`).  A sample whose row of upstream
+# gradients is ALL ZERO contributes exact zeros to every gradient of the step -- and under the reference's relu clamp that is every
+# sample with sigma + noise <= 0: its compositing weight alpha T is 0, so the colour / label channels take 0 * g, and relu' = 0 stops
+# the density gradient (volumetric_rendering.py:36-47; torch autograd multiplies the same zeros through the whole SIREN).  In a density
+# field that is mostly empty space that is most samples: 89 % of the coarse samples of the bench model (tools/exp/empty_fraction.py).
+# So the forward here is the NO-GRAD render kept stage by stage (its 22 outputs per sample are all it saves: 69 MB instead of a 9-GB
+# tape), and the backward runs composite-backward over all samples, keeps the samples with a non-zero gradient row (per image, padded
+# to whole 32-point tiles with samples whose rows are zero anyway), and only THOSE go through forward-save, the chain and the
+# weight-gradient kernels.  Same gradients as the dense node up to the order of the sums; nothing is approximated, nothing is skipped
+# that the reference's arithmetic would not multiply by zero.  With another clamp mode (softplus) every row is non-zero and this is
+# the dense backward plus a re-evaluation.
+# ----------------------------------------------------------------------------------------------------------------------------------
+class SparseHierarchicalRenderFunction(torch.autograd.Function):
+    """HierarchicalRenderFunction's signature and results; see the block comment above."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, *params):
+        nat = module.native_differentiable(origins.device)
+        B, R, N = z_c.shape
+        C = nat.C
+        coarse = nat.siren_forward_rays(origins, dirs, z_c, fg, pg, fa, pa, lock_view=lock_view).reshape(B * R, N, C)
+        zc = z_c.reshape(B * R, N)
+        _, _, w_c, _ = native.composite(coarse, zc, noise_c, copts, want_wsum=False)
+        z_f = native.resample(zc, w_c, u)
+        fine = nat.siren_forward_rays(origins, dirs, z_f.reshape(B, R, N), fg, pg, fa, pa, lock_view=lock_view).reshape(B * R, N, C)
+        rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
+        ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
+        ctx.pack_generation = nat.pack_generation
+        ctx.save_for_backward(origins, dirs, zc, z_f, coarse, fine, noise_f if noise_f is not None else origins.new_empty(0), fg, pg, fa, pa, *params)
+        ctx.mark_non_differentiable(depth)
+        return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_rgb, _g_depth):
+        module, nat, opts = ctx.module, ctx.nat, ctx.opts
+        _siren_autograd.check_same_weights(ctx, nat)
+        need = ctx.needs_input_grad
+        B, R, N = ctx.dims
+        origins, dirs, zc, z_f, coarse, fine, noise_f, fg, pg, fa, pa, *params = ctx.saved_tensors
+        C, P = nat.C, R * N
+        dev = origins.device
+        d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
+                                             noise=noise_f if noise_f.numel() else None)
+        d_all = torch.cat([d_c.reshape(B, P, C), d_f.reshape(B, P, C)], 1)                       # [B, 2P, C]: coarse | fine samples of image b
+        keep = (d_all != 0).any(-1)                                                             # (NaN != 0: a broken row is kept, not hidden)
+        counts = keep.sum(1)
+        Pp = max(32, (int(counts.max()) + 31) // 32 * 32)                                       # the one host sync of this backward
+        # kept samples first, in sample order; the tail of a row is filled with sample 0 and masked out
+        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, torch.full_like(counts, Pp).unsqueeze(1).expand(-1, 2 * P))
+        idx = torch.zeros((B, Pp + 1), dtype=torch.long, device=dev)
+        idx.scatter_(1, slot, torch.arange(2 * P, device=dev).expand(B, -1))
+        idx = idx[:, :Pp]
+        valid = torch.arange(Pp, device=dev).unsqueeze(0) < counts.unsqueeze(1)
+        z_all = torch.cat([zc.reshape(B, P), z_f.reshape(B, P)], 1)
+        ray = torch.div(idx % P, N, rounding_mode="floor")                                      # sample -> its ray
+        o_s, d_s = torch.gather(origins, 1, ray.unsqueeze(-1).expand(-1, -1, 3)), torch.gather(dirs, 1, ray.unsqueeze(-1).expand(-1, -1, 3))
+        pts = (o_s + d_s * torch.gather(z_all, 1, idx).unsqueeze(-1)).contiguous()              # generators.py:504, as the forward's kernels form it
+        rd = None if ctx.lock_view else d_s.contiguous()
+        d_sel = (torch.gather(d_all, 1, idx.unsqueeze(-1).expand(-1, -1, C)) * valid.unsqueeze(-1)).contiguous()
+        del d_all, d_f, d_c
+        film_only = not any(need[14:])
+        fmt = module.tape_format(nat, film_only=film_only)
+        out, tape, tape_e = nat.siren_forward_save(pts, rd, fg, pg, fa, pa, tape_format=fmt)
+        r, d_grid = _siren_autograd.chunked_backward(nat, B, Pp, (fg, pg, fa, pa), pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
+                                                  weights=_siren_autograd.film_layer_weights(module, params) if fmt else None)
+        ctx.kept_points = (int(counts.sum()), 2 * B * P)                                        # for reports (tools/bench_gstep.py, bench.py)
+        SparseHierarchicalRenderFunction.last_kept = ctx.kept_points
+        film_grads = tuple(r[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
+        head = (None,) * 10
+        if film_only:
+            return head + film_grads + (None,) * len(params)
+        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, pts, d_grid, need[14:])
+
+
+SparseHierarchicalRenderFunction.last_kept = None
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
 # The same render as TWO autograd nodes (round 4): for DistributedDataParallel.  With one node every gradient of the step becomes
 # available at the same instant -- the end of the backward -- so DDP's bucketed all-reduce (124 MB, 113 MB of it the 96^3 feature
 # grid; train_double_latent_semantic.py:148-150) can only start when there is nothing left to hide it under.  But the grid gradient is
