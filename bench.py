@@ -79,7 +79,8 @@ def compact_line(out):
     line["n_ranks_seen"] = out.get("n_ranks_seen")
     line["launches_per_step"] = out.get("launches_per_step")
     for name, keys in (("f32", ("value", "ms_per_step")), ("sweep64", ("value", "ms_per_step", "roofline_frac")),
-                       ("gstep", ("ms", "rays_per_s", "peak_GB")), ("gstep_b6", ("ms", "ms_per_image", "peak_GB")),
+                       ("gstep", ("ms", "rays_per_s", "peak_GB")), ("gstep_sparse", ("ms", "peak_GB", "kept_frac")),
+                       ("gstep_b6", ("ms", "ms_per_image", "peak_GB")),
                        ("gstep_ddp", ("ms", "ms_no_ddp", "ms_tuned", "ms_generator_data_parallel", "allreduce_ms_exposed", "allreduce_bytes",
                                       "n_ranks_seen", "dist_backend")),
                        ("gstep_ddp_b6", ("ms", "ms_no_ddp", "ms_generator_data_parallel", "allreduce_ms_exposed"))):
@@ -279,7 +280,7 @@ def cpu_baseline(spec, sd, film, seed, full=True, budget_s=CPU_BASELINE_BUDGET_S
         torch.set_num_threads(prev)
 
 
-def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_precision="f32", per_step_median=False):
+def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_precision="f32", per_step_median=False, sparse=False):
     """BASELINE.json's metric also names the generator step: forward + backward (+ the device-side re-pack an optimizer step
     forces) through DoubleImplicitGenerator3d.forward_with_frequencies on the same workload shape, native differentiable path
     (DESIGN.md 4.5).  Reported beside the headline value; never part of the timed region.
@@ -302,6 +303,7 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
     mod.load_state_dict(tsd, strict=False)
     mod.precision = precision
     mod.grad_precision = grad_precision
+    mod.sparse_backward = bool(sparse)       # opt-in: backward over the samples with a non-zero gradient row only (generators/autograd.py; exact)
     gen = G.DoubleImplicitGenerator3d(functools.partial(S_.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=H), z_dim, z_dim, spec["output_dim"])
     gen.siren = mod
     gen = gen.to(dev)
@@ -354,6 +356,15 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                                           "(point, layer-feature)): gradients within ~1.2e-4 of fp64 autograd instead of ~4e-5 -- a tier between the default "
                                           "and AMP, opt-in (siren.grad_precision = 'tape16')"}[grad_precision],
            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
+    if sparse:
+        from fenerf_amd.generators import autograd as GA
+        kept, total = GA.SparseHierarchicalRenderFunction.last_kept
+        out["what"] += ("; SPARSE backward (opt-in, siren.sparse_backward): the forward is the no-grad render, the backward runs forward-save / chain / "
+                        "weight gradients only over the samples whose upstream gradient row is not all zero -- exact: under the relu clamp a sample "
+                        "with sigma + noise <= 0 has weight 0 and relu' = 0, the reference's autograd multiplies those zeros through the network; "
+                        "data-dependent (this workload's procedural density field)")
+        out["kept_samples"], out["samples"], out["kept_frac"] = kept, total, kept / total
+        return out
     if not breakdown:
         return out
     # ---- HBM roofline of the step: algorithmic bytes per launch group (all sizes per sample point, x points of the step)
@@ -915,6 +926,10 @@ def main(argv=None):
                         out["gstep_" + key] = gstep_leg(spec, sd, dev, B, S, N, args.precision, grad_precision=key)
                     except Exception as e:
                         out["gstep_" + key] = {"error": f"{type(e).__name__}: {e}"}
+            try:   # opt-in exact sparsity of the backward (round 6): beside the dense default, never instead
+                out["gstep_sparse"] = gstep_leg(spec, sd, dev, B, S, N, args.precision, breakdown=False, sparse=True)
+            except Exception as e:
+                out["gstep_sparse"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_gstep_b6 and (B, S, N) == (1, 128, 24):
                 try:   # BASELINE.json configs[2]: the reference's generator micro-batch (batch 24 split 4 -> 6 images of 128x128 x 24+24 per GPU)
                     torch.cuda.empty_cache()
