@@ -250,20 +250,26 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         d_all = torch.cat([d_c.reshape(B, P, C), d_f.reshape(B, P, C)], 1)                       # [B, 2P, C]: coarse | fine samples of image b
         keep = (d_all != 0).any(-1)                                                             # (NaN != 0: a broken row is kept, not hidden)
         counts = keep.sum(1)
-        Pp = max(32, (int(counts.max()) + 31) // 32 * 32)                                       # the one host sync of this backward
-        # kept samples first, in sample order; the tail of a row is filled with sample 0 and masked out
-        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, torch.full_like(counts, Pp).unsqueeze(1).expand(-1, 2 * P))
-        idx = torch.zeros((B, Pp + 1), dtype=torch.long, device=dev)
-        idx.scatter_(1, slot, torch.arange(2 * P, device=dev).expand(B, -1))
-        idx = idx[:, :Pp]
-        valid = torch.arange(Pp, device=dev).unsqueeze(0) < counts.unsqueeze(1)
+        count_host = torch.empty((), dtype=torch.long, pin_memory=True)
+        count_host.copy_(counts.max(), non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        # everything that does not need the kept count is enqueued BEFORE the host waits for it: kept samples first, in sample order (slot =
+        # rank among the image's kept samples; the others land in a dump column)
+        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, 2 * P)
+        idx_full = torch.zeros((B, 2 * P + 1), dtype=torch.long, device=dev)
+        idx_full.scatter_(1, slot, torch.arange(2 * P, device=dev).expand(B, -1))
         z_all = torch.cat([zc.reshape(B, P), z_f.reshape(B, P)], 1)
+        ready.synchronize()                                                                     # the one host sync of this backward
+        Pp = max(32, (int(count_host) + 31) // 32 * 32)
+        idx = idx_full[:, :Pp]                               # beyond an image's count: sample 0 (the scatter never wrote there), masked out below
+        valid = torch.arange(Pp, device=dev).unsqueeze(0) < counts.unsqueeze(1)
         ray = torch.div(idx % P, N, rounding_mode="floor")                                      # sample -> its ray
         o_s, d_s = torch.gather(origins, 1, ray.unsqueeze(-1).expand(-1, -1, 3)), torch.gather(dirs, 1, ray.unsqueeze(-1).expand(-1, -1, 3))
-        pts = (o_s + d_s * torch.gather(z_all, 1, idx).unsqueeze(-1)).contiguous()              # generators.py:504, as the forward's kernels form it
-        rd = None if ctx.lock_view else d_s.contiguous()
-        d_sel = (torch.gather(d_all, 1, idx.unsqueeze(-1).expand(-1, -1, C)) * valid.unsqueeze(-1)).contiguous()
-        del d_all, d_f, d_c
+        pts = o_s + d_s * torch.gather(z_all, 1, idx).unsqueeze(-1)                             # generators.py:504, rounded as the forward's kernels round it (mul, then add)
+        rd = None if ctx.lock_view else d_s
+        d_sel = torch.gather(d_all, 1, idx.unsqueeze(-1).expand(-1, -1, C)) * valid.unsqueeze(-1)
+        del d_all, d_f, d_c, idx_full
         film_only = not any(need[14:])
         fmt = module.tape_format(nat, film_only=film_only)
         out, tape, tape_e = nat.siren_forward_save(pts, rd, fg, pg, fa, pa, tape_format=fmt)

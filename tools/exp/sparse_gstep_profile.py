@@ -39,3 +39,18 @@ print(f"device time per step (sum of kernels): {sum(e.self_device_time_total for
 for e in rows[:28]:
     if e.self_device_time_total > 0:
         print(f"{e.self_device_time_total / 5e3:8.3f} ms  x{e.count // 5:3d}  {e.key[:110]}")
+
+# ---- timeline of ONE step: device intervals in start order with the idle gap before each (where the host-side sync / glue shows)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof1:
+    step()
+    torch.cuda.synchronize()
+ev = sorted([e for e in prof1.events() if e.device_type.name == "CUDA" and e.device_time_total > 0], key=lambda e: e.time_range.start)
+t0, prev_end, gaps = ev[0].time_range.start, ev[0].time_range.start, 0.0
+print(f"timeline of one step ({len(ev)} device intervals); gaps > 15 us:")
+for e in ev:
+    gap = e.time_range.start - prev_end
+    if gap > 15:
+        gaps += gap
+        print(f"  +{(e.time_range.start - t0) / 1e3:7.3f} ms  idle {gap:6.0f} us before {e.name[:80]}")
+    prev_end = max(prev_end, e.time_range.end)
+print(f"span {(prev_end - t0) / 1e3:.3f} ms, idle in gaps > 15 us: {gaps / 1e3:.3f} ms")
