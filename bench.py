@@ -358,7 +358,9 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
            "rays_per_s": B * S * S / (ms * 1e-3), "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
     if sparse:
         from fenerf_amd.generators import autograd as GA
+        GA.SparseHierarchicalRenderFunction.verify()
         kept, total = GA.SparseHierarchicalRenderFunction.last_kept
+        kept = int(kept)
         out["what"] += ("; SPARSE backward (opt-in, siren.sparse_backward): the forward is the no-grad render, the backward runs forward-save / chain / "
                         "weight gradients only over the samples whose upstream gradient row is not all zero -- exact: under the relu clamp a sample "
                         "with sigma + noise <= 0 has weight 0 and relu' = 0, the reference's autograd multiplies those zeros through the network; "

@@ -5,7 +5,7 @@ generators.py:508-519.  Depth is returned detached (the reference's losses never
 constants of the graph, exactly as in the reference where they are produced under torch.no_grad()."""
 import torch
 
-from .. import native
+from .. import _lib, native
 from ..siren import autograd as _siren_autograd
 
 
@@ -212,7 +212,9 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 # to whole 32-point tiles with samples whose rows are zero anyway), and only THOSE go through forward-save, the chain and the
 # weight-gradient kernels.  Same gradients as the dense node up to the order of the sums; nothing is approximated, nothing is skipped
 # that the reference's arithmetic would not multiply by zero.  With another clamp mode (softplus) every row is non-zero and this is
-# the dense backward plus a re-evaluation.
+# the dense backward plus a re-evaluation.  The backward does not wait for the device: the length of its buffers is a bound the FORWARD
+# computes (samples with sigma + max|noise| std > 0, + one per ray with last_back: a row is non-zero only if alpha > 0), fetched
+# asynchronously; which samples are kept is decided on the device from the rows themselves.
 # ----------------------------------------------------------------------------------------------------------------------------------
 class SparseHierarchicalRenderFunction(torch.autograd.Function):
     """HierarchicalRenderFunction's signature and results; see the block comment above."""
@@ -229,6 +231,22 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         z_f = native.resample(zc, w_c, u)
         fine = nat.siren_forward_rays(origins, dirs, z_f.reshape(B, R, N), fg, pg, fa, pa, lock_view=lock_view).reshape(B * R, N, C)
         rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
+        # How many samples of an image CAN carry a non-zero gradient row -- known here, so that the backward never waits for the device:
+        # a row is non-zero only if alpha > 0, i.e. (relu clamp) sigma + noise * std > 0; the noise of a sample is the draw of its SORTED
+        # position, so the bound takes the largest |draw| of the render; `last_back` adds the ray's last sample (its colour row takes the
+        # residual weight whatever its density).  NaN densities count.  The softplus clamp keeps every sample.
+        P = R * N
+        if opts.clamp_mode == _lib.CLAMP["relu"]:
+            sig = torch.cat([coarse[..., -1].reshape(B, P), fine[..., -1].reshape(B, P)], 1)
+            if noise_f is not None and opts.noise_std != 0:
+                sig = sig + noise_f.abs().max() * opts.noise_std
+            cap = (~(sig <= 0)).sum(1).max() + (R if opts.last_back else 0)
+            ctx.cap_host = torch.empty((), dtype=torch.long, pin_memory=True)
+            ctx.cap_host.copy_(cap, non_blocking=True)
+            ctx.cap_ready = torch.cuda.Event()
+            ctx.cap_ready.record()
+        else:
+            ctx.cap_host, ctx.cap_ready = None, None
         ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
         ctx.pack_generation = nat.pack_generation
         ctx.save_for_backward(origins, dirs, zc, z_f, coarse, fine, noise_f if noise_f is not None else origins.new_empty(0), fg, pg, fa, pa, *params)
@@ -250,33 +268,34 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         d_all = torch.cat([d_c.reshape(B, P, C), d_f.reshape(B, P, C)], 1)                       # [B, 2P, C]: coarse | fine samples of image b
         keep = (d_all != 0).any(-1)                                                             # (NaN != 0: a broken row is kept, not hidden)
         counts = keep.sum(1)
-        count_host = torch.empty((), dtype=torch.long, pin_memory=True)
-        count_host.copy_(counts.max(), non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
-        # everything that does not need the kept count is enqueued BEFORE the host waits for it: kept samples first, in sample order (slot =
-        # rank among the image's kept samples; the others land in a dump column)
-        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, 2 * P)
-        idx_full = torch.zeros((B, 2 * P + 1), dtype=torch.long, device=dev)
-        idx_full.scatter_(1, slot, torch.arange(2 * P, device=dev).expand(B, -1))
+        # kept samples first, in sample order (slot = rank among the image's kept samples; the others land in a dump column).  The buffer
+        # length comes from the forward's bound (no wait: that copy finished long ago), so nothing here waits for the device.
+        if ctx.cap_ready is not None:
+            ctx.cap_ready.synchronize()
+            Pp = min(2 * P, int(ctx.cap_host))
+        else:
+            Pp = 2 * P
+        Pp = max(32, (Pp + 31) // 32 * 32)
+        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, Pp)
+        idx = torch.zeros((B, Pp + 1), dtype=torch.long, device=dev)
+        idx.scatter_(1, slot.clamp(max=Pp), torch.arange(2 * P, device=dev).expand(B, -1))
+        idx = idx[:, :Pp]                                    # beyond an image's count: sample 0 (the scatter never wrote there), masked out below
         z_all = torch.cat([zc.reshape(B, P), z_f.reshape(B, P)], 1)
-        ready.synchronize()                                                                     # the one host sync of this backward
-        Pp = max(32, (int(count_host) + 31) // 32 * 32)
-        idx = idx_full[:, :Pp]                               # beyond an image's count: sample 0 (the scatter never wrote there), masked out below
+        # (a count above the bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
+        SparseHierarchicalRenderFunction._check_overflow(counts, Pp, dev)
         valid = torch.arange(Pp, device=dev).unsqueeze(0) < counts.unsqueeze(1)
         ray = torch.div(idx % P, N, rounding_mode="floor")                                      # sample -> its ray
         o_s, d_s = torch.gather(origins, 1, ray.unsqueeze(-1).expand(-1, -1, 3)), torch.gather(dirs, 1, ray.unsqueeze(-1).expand(-1, -1, 3))
         pts = o_s + d_s * torch.gather(z_all, 1, idx).unsqueeze(-1)                             # generators.py:504, rounded as the forward's kernels round it (mul, then add)
         rd = None if ctx.lock_view else d_s
         d_sel = torch.gather(d_all, 1, idx.unsqueeze(-1).expand(-1, -1, C)) * valid.unsqueeze(-1)
-        del d_all, d_f, d_c, idx_full
+        del d_all, d_f, d_c
         film_only = not any(need[14:])
         fmt = module.tape_format(nat, film_only=film_only)
         out, tape, tape_e = nat.siren_forward_save(pts, rd, fg, pg, fa, pa, tape_format=fmt)
         r, d_grid = _siren_autograd.chunked_backward(nat, B, Pp, (fg, pg, fa, pa), pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
                                                   weights=_siren_autograd.film_layer_weights(module, params) if fmt else None)
-        ctx.kept_points = (int(counts.sum()), 2 * B * P)                                        # for reports (tools/bench_gstep.py, bench.py)
-        SparseHierarchicalRenderFunction.last_kept = ctx.kept_points
+        SparseHierarchicalRenderFunction.last_kept = (counts.sum(), 2 * B * P)                  # for reports (a device scalar: read it after the step)
         film_grads = tuple(r[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
         head = (None,) * 10
         if film_only:
@@ -285,6 +304,37 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
 
 
 SparseHierarchicalRenderFunction.last_kept = None
+SparseHierarchicalRenderFunction._pending = None
+
+
+def _check_overflow(counts, Pp, dev):
+    """Deferred assertion of the sparse backward's buffer bound: the flag of THIS call is copied to the host without waiting and read by the
+    next call (or by SparseHierarchicalRenderFunction.verify()); a set flag means samples were dropped -- an error, never a silent result."""
+    cls = SparseHierarchicalRenderFunction
+    cls.verify(wait=False)
+    flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+    flag.copy_(counts.max() > Pp, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    cls._pending = (flag, ev)
+
+
+def _verify(wait=True):
+    cls = SparseHierarchicalRenderFunction
+    if cls._pending is None:
+        return
+    flag, ev = cls._pending
+    if not wait and not ev.query():
+        return
+    ev.synchronize()
+    cls._pending = None
+    if bool(flag):
+        raise RuntimeError("fenerf_amd: sparse backward: more samples carried a non-zero gradient row than the forward's bound allowed for; "
+                           "the gradients of that backward pass are incomplete (please report; siren.sparse_backward = False avoids it)")
+
+
+SparseHierarchicalRenderFunction._check_overflow = staticmethod(_check_overflow)
+SparseHierarchicalRenderFunction.verify = staticmethod(_verify)
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------

@@ -4073,7 +4073,9 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
             (px * w).sum().backward()
             g = {k: N_(v.grad) for k, v in film_t.items()}
             g.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
-            res.append((N_(px), g, GA.SparseHierarchicalRenderFunction.last_kept))
+            kept = GA.SparseHierarchicalRenderFunction.last_kept
+            res.append((N_(px), g, None if kept is None else (int(kept[0]), kept[1])))
+        GA.SparseHierarchicalRenderFunction.verify()      # the deferred check of the buffer bound (raises if a backward dropped samples)
     finally:
         mod.sparse_backward = False
     (px0, g0, k0), (px1, g1, k1) = res

@@ -54,3 +54,25 @@ for e in ev:
         print(f"  +{(e.time_range.start - t0) / 1e3:7.3f} ms  idle {gap:6.0f} us before {e.name[:80]}")
     prev_end = max(prev_end, e.time_range.end)
 print(f"span {(prev_end - t0) / 1e3:.3f} ms, idle in gaps > 15 us: {gaps / 1e3:.3f} ms")
+
+# ---- steady state: five back-to-back steps, device busy time (union of the intervals) against the span
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof5:
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+ev = sorted([e for e in prof5.events() if e.device_type.name == "CUDA" and e.device_time_total > 0], key=lambda e: e.time_range.start)
+busy, cur_s, cur_e = 0.0, ev[0].time_range.start, ev[0].time_range.end
+big = []
+for e in ev[1:]:
+    if e.time_range.start > cur_e:
+        if e.time_range.start - cur_e > 40: big.append((e.time_range.start - cur_e, e.name[:60]))
+        busy += cur_e - cur_s
+        cur_s, cur_e = e.time_range.start, e.time_range.end
+    else:
+        cur_e = max(cur_e, e.time_range.end)
+busy += cur_e - cur_s
+span = cur_e - ev[0].time_range.start
+print(f"five steps back to back: span {span / 5e3:.3f} ms per step, device busy {busy / 5e3:.3f} ms per step, idle {100 * (1 - busy / span):.1f} %")
+from collections import Counter
+c = Counter()
+for g_, n_ in big: c[n_] += g_
+for n_, g_ in c.most_common(8): print(f"   idle {g_ / 5e3:6.3f} ms per step before {n_}")
