@@ -212,7 +212,7 @@ class HierarchicalRenderFunction(torch.autograd.Function):
 # to whole 32-point tiles with samples whose rows are zero anyway), and only THOSE go through forward-save, the chain and the
 # weight-gradient kernels.  Same gradients as the dense node up to the order of the sums; nothing is approximated, nothing is skipped
 # that the reference's arithmetic would not multiply by zero.  With another clamp mode (softplus) every row is non-zero and this is
-# the dense backward plus a re-evaluation.  The backward does not wait for the device: the length of its buffers is a bound the FORWARD
+# the dense backward plus a re-evaluation (`siren.sparse_backward = "auto"` then falls back to the dense node, below).  The backward does not wait for the device: the length of its buffers is a bound the FORWARD
 # computes (samples with sigma + max|noise| std > 0, + one per ray with last_back: a row is non-zero only if alpha > 0), fetched
 # asynchronously; which samples are kept is decided on the device from the rows themselves.
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -276,6 +276,7 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         else:
             Pp = 2 * P
         Pp = max(32, (Pp + 31) // 32 * 32)
+        sparse_auto_observe(module, Pp / (2 * P))
         slot = torch.where(keep, torch.cumsum(keep, 1) - 1, Pp)
         idx = torch.zeros((B, Pp + 1), dtype=torch.long, device=dev)
         idx.scatter_(1, slot.clamp(max=Pp), torch.arange(2 * P, device=dev).expand(B, -1))
@@ -335,6 +336,43 @@ def _verify(wait=True):
 
 SparseHierarchicalRenderFunction._check_overflow = staticmethod(_check_overflow)
 SparseHierarchicalRenderFunction.verify = staticmethod(_verify)
+
+
+# `siren.sparse_backward = "auto"`: the sparse node while it pays, the dense node otherwise.  What the sparse backward costs is set by the
+# length of its buffers -- the forward's bound on the samples with a non-zero row, as a fraction of all samples -- and that number is on
+# the host when the backward starts (no wait).  Model of the two steps at configs[1] (bench.py legs gstep / gstep_sparse):
+# dense = forward-save + chain + weight gradients over everything; sparse = a no-grad render + the same over the fraction f, i.e.
+# sparse / dense ~ 0.35 + 0.93 f: break-even at f ~ 0.7.  While the last observed fraction is above SPARSE_AUTO_MAX_FRACTION the dense node
+# runs and every SPARSE_AUTO_PROBE_EVERY-th step is a sparse one that observes again (a probe at f = 1 costs + 28 % of one step).
+SPARSE_AUTO_MAX_FRACTION = 0.6
+SPARSE_AUTO_PROBE_EVERY = 50
+
+
+def _sparse_auto_state(module):
+    st = module.__dict__.get("_sparse_auto")
+    if st is None:
+        st = module.__dict__["_sparse_auto"] = {"fraction": None, "dense_steps": 0, "last": None}
+    return st
+
+
+def sparse_auto_observe(module, fraction):
+    """called by the sparse backward: the fraction of the samples its buffers were sized for"""
+    _sparse_auto_state(module)["fraction"] = float(fraction)
+
+
+def sparse_auto_choice(module):
+    """True: this step's render is the sparse node.  (Nothing observed yet: sparse -- that step is the first observation.)"""
+    st = _sparse_auto_state(module)
+    f = st["fraction"]
+    if f is None or f <= SPARSE_AUTO_MAX_FRACTION:
+        st["dense_steps"], st["last"] = 0, "sparse"
+        return True
+    st["dense_steps"] += 1
+    if st["dense_steps"] >= SPARSE_AUTO_PROBE_EVERY:
+        st["dense_steps"], st["last"] = 0, "probe"
+        return True
+    st["last"] = "dense"
+    return False
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
 from .autograd import (CompositeFunction, HierarchicalRenderFunction, ImageLayoutFunction, MergeCompositeFunction, SparseHierarchicalRenderFunction,
-                       hierarchical_render_split)
+                       hierarchical_render_split, sparse_auto_choice)
 from . import volumetric_rendering as VR
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
 
@@ -212,7 +212,12 @@ class _Generator3dBase(nn.Module):
                 any(p.requires_grad for p in params if p is not grid):
             # two autograd nodes: the grid gradient reaches DistributedDataParallel before the weight-gradient kernels run (autograd.py)
             return hierarchical_render_split(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u, nc_, nf_, fg, pg, fa, pa)
-        if getattr(self.siren, "sparse_backward", False):
+        sparse = getattr(self.siren, "sparse_backward", False)
+        if sparse == "auto":
+            sparse = sparse_auto_choice(self.siren)
+        elif sparse not in (True, False):
+            raise ValueError(f"siren.sparse_backward must be True, False or 'auto', got {sparse!r}")
+        if sparse:
             # opt-in: the backward runs only over the samples whose upstream gradient row is not all zero (autograd.py: exact)
             return SparseHierarchicalRenderFunction.apply(self.siren, opts, copts, bool(lock_view_dependence), origins, dirs, z_c, u, nc_, nf_, fg, pg,
                                                           fa, pa, *params)

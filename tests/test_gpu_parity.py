@@ -4090,3 +4090,54 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
         assert k1[0] < k1[1]
     # two fp32 evaluations of the same sums in different orders (the tape of a kept sample is re-evaluated from the same inputs)
     assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
+
+
+@pytest.mark.parametrize("clamp", ["relu", "softplus"])
+def test_sparse_backward_auto_picks_the_cheaper_node(clamp, monkeypatch):
+    """siren.sparse_backward = "auto" (generators/autograd.py sparse_auto_choice): the first step is a sparse one (nothing observed yet); it
+    observes the fraction of the samples its buffers were sized for -- on the host, no wait.  Mostly empty space (relu clamp): sparse from
+    then on.  Softplus clamp (every row non-zero, fraction 1): the dense node, with a sparse probe every SPARSE_AUTO_PROBE_EVERY-th step.
+    Whatever node runs, pixels are bit-identical and gradients agree to the order of the sums."""
+    from fenerf_amd.generators import autograd as GA
+    monkeypatch.setattr(GA, "SPARSE_AUTO_PROBE_EVERY", 3)
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision="f16x3")
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    film = proc.film_params(spec, 2, seed=4)
+    kw = dict(img_size=8, fov=12, ray_start=0.88, ray_end=1.12, num_steps=12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2, v_mean=np.pi / 2,
+              hierarchical_sample=True, sample_dist="gaussian", clamp_mode=clamp, nerf_noise=0.0)
+
+    def step():
+        film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+        for p_ in mod.parameters():
+            p_.grad = None
+        torch.manual_seed(11)
+        px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+        px.square().sum().backward()
+        g = {k: N_(v.grad) for k, v in film_t.items()}
+        g.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
+        return N_(px), g
+
+    px0, g0 = step()                                   # the dense node
+    choices = []
+    try:
+        mod.sparse_backward = "auto"
+        for _ in range(8):
+            px, g = step()
+            st = mod.__dict__["_sparse_auto"]
+            choices.append(st["last"])
+            assert np.array_equal(px, px0) and g.keys() == g0.keys()
+            assert max(_rel_err(g[k], g0[k]) for k in g0) <= 2e-6
+        GA.SparseHierarchicalRenderFunction.verify()
+        with pytest.raises(ValueError):
+            mod.sparse_backward = "sometimes"
+            step()
+    finally:
+        mod.sparse_backward = False
+    print(f"[parity] sparse_backward = 'auto' [{clamp}]: buffer fraction {st['fraction']:.3f}, nodes {choices}")
+    if clamp == "relu":
+        assert st["fraction"] < GA.SPARSE_AUTO_MAX_FRACTION and choices == ["sparse"] * 8      # measured: see the printed line
+    else:
+        assert st["fraction"] == 1.0 and choices == ["sparse", "dense", "dense", "probe", "dense", "dense", "probe", "dense"]
