@@ -94,4 +94,123 @@ int launch_film_fold(const FilmFold& J, void* stream) {
   return FENERF_OK;
 }
 
+// ---- selection step of the exact-sparsity backward (fenerf_sparse_select; generators/autograd.py SparseHierarchicalRenderFunction) ----
+// Sample s of image b: s < P the coarse pass's, else the fine pass's sample s - P.  A sample is kept when its row of upstream gradients
+// is not all zero (NaN != 0: kept).  Kept samples go to slots 0 .. count - 1 of their image in sample order.
+// Pass 1: one ballot per wave (mask of kept lanes) + one count per 256-sample block.
+__global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse, const float* d_fine, long long P, int C, unsigned long long* masks,
+                                                           int* block_counts, int* counts, int B) {
+  const int b = blockIdx.y, t = threadIdx.x;
+  const long long s = (long long)blockIdx.x * 256 + t;
+  bool keep = false;
+  if (s < 2 * P) {
+    const float* row = s < P ? d_coarse + ((long long)b * P + s) * C : d_fine + ((long long)b * P + (s - P)) * C;
+    if ((C & 1) == 0) {        // even C (22 here): rows are 8-byte aligned
+      const float2* r2 = reinterpret_cast<const float2*>(row);
+      for (int c = 0; c < C / 2; ++c) { const float2 v = r2[c]; keep |= (v.x != 0.f) | (v.y != 0.f); }
+    } else {
+      for (int c = 0; c < C; ++c) keep |= (row[c] != 0.f);
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  __shared__ int wave_n[4];
+  if ((t & 63) == 0) {
+    masks[((long long)b * gridDim.x + blockIdx.x) * 4 + (t >> 6)] = m;
+    wave_n[t >> 6] = __popcll(m);
+  }
+  __syncthreads();
+  if (t == 0) {
+    block_counts[(long long)b * gridDim.x + blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    if (blockIdx.x == 0 && b == 0) counts[B] = 0;       // the overflow flag pass 2 may raise
+  }
+}
+
+// Pass 2: slot = kept samples of the image before this one; a kept sample writes its point (origins + dirs * z: mul, then add, as every
+// other kernel of the path rounds it), its ray direction and its gradient row to its slot; slots count .. cap - 1 get sample 0's point and
+// direction and a zero row.  counts[b] = kept samples of image b; counts[B] = 1 if some image kept more than cap (those samples are dropped:
+// the caller treats the flag as an error).
+__global__ void __launch_bounds__(256) sparse_gather_kernel(const float* d_coarse, const float* d_fine, const float* z_coarse, const float* z_fine,
+                                                            const float* origins, const float* dirs, int R, int N, int C, long long cap,
+                                                            const unsigned long long* masks, const int* block_counts, float* pts, float* rd,
+                                                            float* d_sel, int* counts, int B) {
+  const int b = blockIdx.y, t = threadIdx.x, nblk = gridDim.x, blk = blockIdx.x;
+  const long long P = (long long)R * N;
+  __shared__ int red[2][4];
+  int before = 0, all = 0;
+  for (int j = t; j < nblk; j += 256) {
+    const int n = block_counts[(long long)b * nblk + j];
+    all += n;
+    if (j < blk) before += n;
+  }
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+  if ((t & 63) == 0) { red[0][t >> 6] = before; red[1][t >> 6] = all; }
+  __syncthreads();
+  before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (blk == 0 && t == 0) {
+    counts[b] = all;
+    if (all > cap) counts[B] = 1;
+  }
+  const int w = t >> 6, lane = t & 63;
+  const unsigned long long* mw = masks + ((long long)b * nblk + blk) * 4;
+  long long slot = before;
+  for (int k = 0; k < w; ++k) slot += __popcll(mw[k]);
+  const unsigned long long m = mw[w];
+  slot += __popcll(m & ((1ull << lane) - 1ull));
+  if (((m >> lane) & 1ull) && slot < cap) {
+    const long long s = (long long)blk * 256 + t;
+    const bool fine = s >= P;
+    const long long q = fine ? s - P : s;
+    const float* row = (fine ? d_fine : d_coarse) + ((long long)b * P + q) * C;
+    const float zz = (fine ? z_fine : z_coarse)[(long long)b * P + q];
+    const long long ray = (long long)b * R + q / N;
+    const long long o = (long long)b * cap + slot;
+    const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    pts[o * 3 + 0] = __fadd_rn(origins[ray * 3 + 0], __fmul_rn(dx, zz));
+    pts[o * 3 + 1] = __fadd_rn(origins[ray * 3 + 1], __fmul_rn(dy, zz));
+    pts[o * 3 + 2] = __fadd_rn(origins[ray * 3 + 2], __fmul_rn(dz, zz));
+    if (rd) { rd[o * 3 + 0] = dx; rd[o * 3 + 1] = dy; rd[o * 3 + 2] = dz; }
+    if ((C & 1) == 0) {
+      const float2* r2 = reinterpret_cast<const float2*>(row);
+      float2* o2 = reinterpret_cast<float2*>(d_sel + o * C);
+      for (int c = 0; c < C / 2; ++c) o2[c] = r2[c];
+    } else {
+      for (int c = 0; c < C; ++c) d_sel[o * C + c] = row[c];
+    }
+  }
+  // the pad slots of the image, shared out over its blocks
+  const long long ray0 = (long long)b * R;
+  for (long long sl = (long long)all + (long long)blk * 256 + t; sl < cap; sl += (long long)nblk * 256) {
+    const long long o = (long long)b * cap + sl;
+    const float zz = z_coarse[(long long)b * P];
+    const float dx = dirs[ray0 * 3 + 0], dy = dirs[ray0 * 3 + 1], dz = dirs[ray0 * 3 + 2];
+    pts[o * 3 + 0] = __fadd_rn(origins[ray0 * 3 + 0], __fmul_rn(dx, zz));
+    pts[o * 3 + 1] = __fadd_rn(origins[ray0 * 3 + 1], __fmul_rn(dy, zz));
+    pts[o * 3 + 2] = __fadd_rn(origins[ray0 * 3 + 2], __fmul_rn(dz, zz));
+    if (rd) { rd[o * 3 + 0] = dx; rd[o * 3 + 1] = dy; rd[o * 3 + 2] = dz; }
+    for (int c = 0; c < C; ++c) d_sel[o * C + c] = 0.f;
+  }
+}
+
+size_t sparse_select_workspace_bytes(int B, long long P) {
+  const long long nblk = (2 * P + 255) / 256;
+  return (size_t)B * nblk * (4 * sizeof(unsigned long long) + sizeof(int));
+}
+
+int launch_sparse_select(int B, int R, int N, int C, long long cap, const float* d_coarse, const float* d_fine, const float* z_coarse,
+                         const float* z_fine, const float* origins, const float* dirs, float* pts, float* rd, float* d_sel, int* counts,
+                         void* workspace, void* stream) {
+  const long long P = (long long)R * N;
+  const long long nblk = (2 * P + 255) / 256;
+  unsigned long long* masks = (unsigned long long*)workspace;
+  int* block_counts = (int*)(masks + (size_t)B * nblk * 4);
+  const dim3 grid((unsigned)nblk, (unsigned)B);
+  hipLaunchKernelGGL(sparse_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, P, C, masks, block_counts, counts, B);
+  hipLaunchKernelGGL(sparse_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, z_coarse, z_fine, origins, dirs, R, N, C, cap,
+                     masks, block_counts, pts, rd, d_sel, counts, B);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("sparse select launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
+  return FENERF_OK;
+}
+
 }  // namespace fenerf

@@ -265,11 +265,7 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         dev = origins.device
         d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
                                              noise=noise_f if noise_f.numel() else None)
-        d_all = torch.cat([d_c.reshape(B, P, C), d_f.reshape(B, P, C)], 1)                       # [B, 2P, C]: coarse | fine samples of image b
-        keep = (d_all != 0).any(-1)                                                             # (NaN != 0: a broken row is kept, not hidden)
-        counts = keep.sum(1)
-        # kept samples first, in sample order (slot = rank among the image's kept samples; the others land in a dump column).  The buffer
-        # length comes from the forward's bound (no wait: that copy finished long ago), so nothing here waits for the device.
+        # the buffer length comes from the forward's bound (that copy finished long ago), so nothing here waits for the device
         if ctx.cap_ready is not None:
             ctx.cap_ready.synchronize()
             Pp = min(2 * P, int(ctx.cap_host))
@@ -277,20 +273,13 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
             Pp = 2 * P
         Pp = max(32, (Pp + 31) // 32 * 32)
         sparse_auto_observe(module, Pp / (2 * P))
-        slot = torch.where(keep, torch.cumsum(keep, 1) - 1, Pp)
-        idx = torch.zeros((B, Pp + 1), dtype=torch.long, device=dev)
-        idx.scatter_(1, slot.clamp(max=Pp), torch.arange(2 * P, device=dev).expand(B, -1))
-        idx = idx[:, :Pp]                                    # beyond an image's count: sample 0 (the scatter never wrote there), masked out below
-        z_all = torch.cat([zc.reshape(B, P), z_f.reshape(B, P)], 1)
+        # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
+        # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: two launches)
+        pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, Pp, want_dirs=not ctx.lock_view)
+        del d_f, d_c
         # (a count above the bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
-        SparseHierarchicalRenderFunction._check_overflow(counts, Pp, dev)
-        valid = torch.arange(Pp, device=dev).unsqueeze(0) < counts.unsqueeze(1)
-        ray = torch.div(idx % P, N, rounding_mode="floor")                                      # sample -> its ray
-        o_s, d_s = torch.gather(origins, 1, ray.unsqueeze(-1).expand(-1, -1, 3)), torch.gather(dirs, 1, ray.unsqueeze(-1).expand(-1, -1, 3))
-        pts = o_s + d_s * torch.gather(z_all, 1, idx).unsqueeze(-1)                             # generators.py:504, rounded as the forward's kernels round it (mul, then add)
-        rd = None if ctx.lock_view else d_s
-        d_sel = torch.gather(d_all, 1, idx.unsqueeze(-1).expand(-1, -1, C)) * valid.unsqueeze(-1)
-        del d_all, d_f, d_c
+        SparseHierarchicalRenderFunction._check_overflow(counts[B])
+        counts = counts[:B]
         film_only = not any(need[14:])
         fmt = module.tape_format(nat, film_only=film_only)
         out, tape, tape_e = nat.siren_forward_save(pts, rd, fg, pg, fa, pa, tape_format=fmt)
@@ -308,13 +297,13 @@ SparseHierarchicalRenderFunction.last_kept = None
 SparseHierarchicalRenderFunction._pending = None
 
 
-def _check_overflow(counts, Pp, dev):
+def _check_overflow(overflowed):
     """Deferred assertion of the sparse backward's buffer bound: the flag of THIS call is copied to the host without waiting and read by the
     next call (or by SparseHierarchicalRenderFunction.verify()); a set flag means samples were dropped -- an error, never a silent result."""
     cls = SparseHierarchicalRenderFunction
     cls.verify(wait=False)
     flag = torch.empty((), dtype=torch.bool, pin_memory=True)
-    flag.copy_(counts.max() > Pp, non_blocking=True)
+    flag.copy_(overflowed != 0, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     cls._pending = (flag, ev)

@@ -1180,6 +1180,28 @@ def merge_composite(fine, coarse, z_fine, z_coarse, noise, opts, want_weights=Tr
     return rgb, depth, w, ws, zs
 
 
+def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_dirs=True):
+    """Selection step of the exact-sparsity backward (fenerf_sparse_select, include/fenerf.h): d_coarse / d_fine [B*R, N, C] (the merged
+    composite's backward), z_coarse / z_fine [B*R, N], origins / dirs [B, R, 3], cap = slots per image (a multiple of 32).
+    -> pts [B, cap, 3], rd [B, cap, 3] or None, d_sel [B, cap, C], counts int32 [B + 1] (kept samples per image, then the overflow flag);
+    two launches, nothing waits."""
+    B, R, _ = origins.shape
+    BR, N, Cc = d_coarse.shape
+    assert BR == B * R and d_fine.shape == d_coarse.shape and cap >= 1
+    dev = d_coarse.device
+    dc, df, zc, zf, o, d = (_f32(t, dev) for t in (d_coarse, d_fine, z_coarse, z_fine, origins, dirs))
+    pts = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((B, cap, 3), dtype=torch.float32, device=dev) if want_dirs else None
+    d_sel = torch.empty((B, cap, Cc), dtype=torch.float32, device=dev)
+    counts = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().fenerf_sparse_select_workspace_bytes(B, R * N)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fenerf_sparse_select(B, R, N, Cc, cap, _ptr(dc), _ptr(df), _ptr(zc), _ptr(zf), _ptr(o), _ptr(d), _ptr(pts), _ptr(rd),
+                                                   _ptr(d_sel), C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, _stream()))
+    return pts, rd, d_sel, counts
+
+
 def composite_backward(g_rgb, rows_a, z_a, opts, rows_b=None, z_b=None, noise=None, out_a=None, out_b=None):
     """Gradient of the final composite wrt its input rows.  Non-merge: rows_a [BR,M,C], z_a [BR,M] -> d_rows_a.
     Merge (rows_b given): fine rows_a / coarse rows_b [BR,N,C], z_a / z_b [BR,N] -> (d_fine, d_coarse).

@@ -579,6 +579,23 @@ int fenerf_composite_backward(int64_t BR, int N, int C, int merge, const float* 
                               const float* z_a, const float* z_b, const float* noise, const FenerfCompositeOpts* opts,
                               const float* g_rgb, float* d_rows_a, float* d_rows_b, void* stream);
 
+/* Bytes of [dev] scratch fenerf_sparse_select needs for B images of P = R * N samples per pass. */
+size_t fenerf_sparse_select_workspace_bytes(int B, int64_t P);
+
+/* replaces: nothing the reference writes down -- its autograd (train_double_latent_semantic.py:402-446, the backward of
+ * generators.py:479-519) multiplies the all-zero gradient rows of empty-space samples through the whole SIREN; this is the selection
+ * step of a backward that does not (exact: a sample whose row of d loss / d SIREN outputs is all zero contributes exact zeros to every
+ * gradient; under the relu clamp of volumetric_rendering.py:36-47 that is every sample with sigma + noise <= 0).
+ * d_coarse / d_fine [B][P][C] are fenerf_composite_backward's outputs (merge = 1: d_rows_b, d_rows_a), P = R * N; z_coarse / z_fine
+ * [B*R][N]; origins / dirs [B][R][3].  Per image, the samples with a non-zero row (NaN counts as non-zero) in sample order (coarse pass
+ * first) fill slots 0 .. counts[b] - 1 of pts / rd [B][cap][3] (origins + dirs * z, generators.py:504; rd may be NULL) and d_sel
+ * [B][cap][C]; the remaining slots repeat the image's first sample with a zero row.  counts [B + 1] (int32, device): kept samples per
+ * image, then a flag that is 1 when some image kept more than cap (the excess is dropped: treat as an error).  Feed pts / rd / d_sel to
+ * fenerf_siren_forward_save + fenerf_siren_backward + fenerf_siren_param_grads with P = cap (a multiple of 32). */
+int fenerf_sparse_select(int B, int R, int N, int C, int64_t cap, const float* d_coarse, const float* d_fine, const float* z_coarse,
+                         const float* z_fine, const float* origins, const float* dirs, float* pts, float* rd, float* d_sel,
+                         int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Bytes of [dev] scratch fenerf_render_forward needs. */
 size_t fenerf_render_workspace_bytes(const FenerfModel* m, int B, int R, int N, int hierarchical);
 
