@@ -3090,7 +3090,7 @@ def test_world_2_on_one_gpu_native_two_stage_backward_through_both_wrappers():
     assert d["world"] == 2 and d["backend"] == "gloo" and d["points_per_image"] == 786432
     assert d["own_vs_mean"] > 1e-2, "the two ranks' own gradients differ (own latents): the mean is not either of them"
     legs = ("gdp_split", "gdp_split_2_micro_batches", "gdp_single_node_backward", "ddp_recommended_split", "ddp_recommended_split_2_micro_batches",
-            "ddp_reference_wrapper")
+            "ddp_reference_wrapper", "gdp_sparse_backward", "gdp_sparse_backward_2_micro_batches", "ddp_reference_wrapper_sparse_backward")
     for k in legs:
         print(f"[dist] world 2 on one GPU (gloo), {k}: worst relative error vs the mean of the bare-module gradients {d[k]['worst_rel_err']:.1e} "
               f"({d[k]['worst']}; {d[k]['tensors']} tensors), identical on both ranks: {d[k]['identical_on_both_ranks']}")
@@ -3155,7 +3155,8 @@ GENERATOR_GRADIENT_BOUNDS = {"tiny_texture_grad": 1.0e-4, "tiny_texture_grad_tra
 @pytest.mark.parametrize("name", ["tiny_texture_grad", "tiny_baseline_grad", "tiny_spatial_grad", "tiny_texture_grad_bigfilm",
                                   "tiny_texture_grad_trained",       # *_trained: at a state the reference's own Adam run produced (round 5)
                                   "h96_texture_grad"])               # hidden width 96 (round 5)
-def test_generator_gradients_vs_reference_autograd(name, precision):
+@pytest.mark.parametrize("sparse", [False, True], ids=["dense", "sparse"])
+def test_generator_gradients_vs_reference_autograd(name, precision, sparse):
     """tests/golden/tiny_*_grad.npz: gradients from the REFERENCE's own autograd through forward_with_frequencies (texture:
     hierarchical 8+8, noise, white_back; baseline: softplus, noise, last_back; single-latent: locked view direction).  The
     native differentiable path on the recorded draws must reproduce the pixels and every gradient (the reference ran fp32 on
@@ -3165,6 +3166,10 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
     kind = spec["kind"]
     gen = (_make_spatial_generator if kind == "spatial" else _make_generator)(g, dict(spec, z_dim=spec.get("z_dim", 16)), precision)
     gen.train()
+    if sparse:                 # round 6: the exact-sparsity backward (generators/autograd.py) against the same reference gradients, same bounds
+        if kind == "spatial":
+            pytest.skip("the per-point-modulated generator has its own autograd node")
+        gen.siren.sparse_backward = True
     film, tf = _film(g, spec)
     if kind == "spatial":      # the golden's film helper draws the colour slice like the generator test above
         film = film_from_golden(g, spec)
@@ -3194,7 +3199,14 @@ def test_generator_gradients_vs_reference_autograd(name, precision):
         if k.startswith("gparam_"):
             worst = max(worst, _rel_err(N_(named[k[7:]].grad), g[k]))
             n += 1
-    print(f"[parity] generator gradients vs the reference's autograd {name}[{precision}]: worst relative error over {n + 4} tensors {worst:.2e}")
+    kept = ""
+    if sparse:
+        from fenerf_amd.generators import autograd as GA
+        GA.SparseHierarchicalRenderFunction.verify()
+        k_ = GA.SparseHierarchicalRenderFunction.last_kept
+        kept = f" (sparse backward: {int(k_[0])} of {k_[1]} samples kept)"
+        assert type(px.grad_fn).__name__ != "HierarchicalRenderFunctionBackward"
+    print(f"[parity] generator gradients vs the reference's autograd {name}[{precision}]{kept}: worst relative error over {n + 4} tensors {worst:.2e}")
     # bound = the reference's own fp32 rounding: the fp64 restatement differs from these fixtures by 1.5e-4 (texture),
     # 4.8e-3 (baseline: softplus + last_back cancellation in final_layer.weight) and 1.8e-4 (single latent) on the CPU
     # Round 6: one bound per fixture = measured (profiles/r05_gpu_tests_parity_lines.log:317-328, both precisions within 15 % of each other) x 1.5

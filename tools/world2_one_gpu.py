@@ -108,6 +108,11 @@ def main():
     check("gdp_split_2_micro_batches", run(gdp, 2), want2)
     fdist.prepare_for_ddp(gen, False)
     check("gdp_single_node_backward", run(gdp, 1), want1)
+    # (a') the exact-sparsity backward (siren.sparse_backward, generators/autograd.py) under the same wrapper: same means
+    gen.siren.sparse_backward = True
+    check("gdp_sparse_backward", run(gdp, 1), want1)
+    check("gdp_sparse_backward_2_micro_batches", run(gdp, 2), want2)
+    gen.siren.sparse_backward = False
     gdp.detach_hooks()
     del gdp
     # (b) DistributedDataParallel with the recommended arguments on the two-stage backward, and the reference's own wrapper arguments
@@ -120,6 +125,11 @@ def main():
     fdist.prepare_for_ddp(gen, False)
     ddp = DDP(gen, device_ids=[0], find_unused_parameters=True)          # train_double_latent_semantic.py:148
     check("ddp_reference_wrapper", run(ddp, 1), want1)
+    gen.siren.sparse_backward = True
+    check("ddp_reference_wrapper_sparse_backward", run(ddp, 1), want1)
+    gen.siren.sparse_backward = False
+    from fenerf_amd.generators import autograd as GA
+    GA.SparseHierarchicalRenderFunction.verify()
     del ddp
     res["peak_GB"] = torch.cuda.max_memory_allocated() / 2**30
     if rank == 0:
