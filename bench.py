@@ -80,7 +80,7 @@ def compact_line(out):
     line["launches_per_step"] = out.get("launches_per_step")
     for name, keys in (("f32", ("value", "ms_per_step")), ("sweep64", ("value", "ms_per_step", "roofline_frac")),
                        ("gstep", ("ms", "rays_per_s", "peak_GB")), ("gstep_sparse", ("ms", "peak_GB", "kept_frac")),
-                       ("gstep_b6", ("ms", "ms_per_image", "peak_GB")),
+                       ("gstep_b6", ("ms", "ms_per_image", "peak_GB")), ("gstep_sparse_b6", ("ms", "ms_per_image", "peak_GB", "kept_frac")),
                        ("gstep_ddp", ("ms", "ms_no_ddp", "ms_tuned", "ms_generator_data_parallel", "allreduce_ms_exposed", "allreduce_bytes",
                                       "n_ranks_seen", "dist_backend")),
                        ("gstep_ddp_b6", ("ms", "ms_no_ddp", "ms_generator_data_parallel", "allreduce_ms_exposed"))):
@@ -940,6 +940,12 @@ def main(argv=None):
                     torch.cuda.empty_cache()
                 except Exception as e:
                     out["gstep_b6"] = {"error": f"{type(e).__name__}: {e}"}
+                try:   # the same micro-batch with the opt-in exact-sparsity backward
+                    out["gstep_sparse_b6"] = gstep_leg(spec, sd, dev, 6, S, N, args.precision, iters=5, breakdown=False, per_step_median=True, sparse=True)
+                    out["gstep_sparse_b6"]["ms_per_image"] = out["gstep_sparse_b6"]["ms"] / 6
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    out["gstep_sparse_b6"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             # N = 1: BASELINE.md's plan (1 warm-up + 3 timed runs x 3 shapes); N > 1: the headline shape once, so that every line of
             # the driver's scaling sweep is self-contained while the other ranks wait at the final barrier for ~20 s, not a minute

@@ -157,7 +157,7 @@ _SIGS = {
     "fenerf_render_backward_stage": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, C.POINTER(FenerfSirenGrads), _vp,
                                           C.POINTER(FenerfSirenGrads), _i64, _vp, _sz, _vp]),
     "fenerf_sparse_select_workspace_bytes": (C.c_size_t, [_i, _i64]),
-    "fenerf_sparse_select": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "fenerf_sparse_select": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "fenerf_composite_backward": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(FenerfCompositeOpts), _vp, _vp, _vp, _vp]),
     "fenerf_render_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "fenerf_render_forward": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 10 + [C.POINTER(FenerfCompositeOpts)] + [_vp] * 4 + [_vp, _sz, _vp]),

@@ -200,8 +200,8 @@ struct FilmFold { float* out[4]; const float* in[4]; int row[4]; int B; };
 int launch_render_points(int B, int R, int N, long long Pp, const float* origins, const float* dirs, const float* z, float* pts, float* rd, void* stream);
 size_t sparse_select_workspace_bytes(int B, long long P);
 int launch_sparse_select(int B, int R, int N, int C, long long cap, const float* d_coarse, const float* d_fine, const float* z_coarse,
-                         const float* z_fine, const float* origins, const float* dirs, float* pts, float* rd, float* d_sel, int* counts,
-                         void* workspace, void* stream);
+                         const float* z_fine, const float* origins, const float* dirs, const long long* images, float* pts, float* rd, float* d_sel,
+                         int* counts, void* workspace, void* stream);
 int launch_pad_rows(const float* src, float* dst, long long nb, long long P, long long Pp, int C, bool to_padded, void* stream);
 int launch_multi_add(const MultiAdd& J, void* stream);
 int launch_film_fold(const FilmFold& J, void* stream);

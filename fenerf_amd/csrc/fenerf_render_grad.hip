@@ -98,13 +98,14 @@ int launch_film_fold(const FilmFold& J, void* stream) {
 // Sample s of image b: s < P the coarse pass's, else the fine pass's sample s - P.  A sample is kept when its row of upstream gradients
 // is not all zero (NaN != 0: kept).  Kept samples go to slots 0 .. count - 1 of their image in sample order.
 // Pass 1: one ballot per wave (mask of kept lanes) + one count per 256-sample block.
-__global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse, const float* d_fine, long long P, int C, unsigned long long* masks,
-                                                           int* block_counts, int* counts, int B) {
+__global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse, const float* d_fine, const long long* images, long long P, int C,
+                                                           unsigned long long* masks, int* block_counts, int* counts, int B) {
   const int b = blockIdx.y, t = threadIdx.x;
+  const long long img = images ? images[b] : b;          // where image b of this call sits in the inputs
   const long long s = (long long)blockIdx.x * 256 + t;
   bool keep = false;
   if (s < 2 * P) {
-    const float* row = s < P ? d_coarse + ((long long)b * P + s) * C : d_fine + ((long long)b * P + (s - P)) * C;
+    const float* row = s < P ? d_coarse + (img * P + s) * C : d_fine + (img * P + (s - P)) * C;
     if ((C & 1) == 0) {        // even C (22 here): rows are 8-byte aligned
       const float2* r2 = reinterpret_cast<const float2*>(row);
       for (int c = 0; c < C / 2; ++c) { const float2 v = r2[c]; keep |= (v.x != 0.f) | (v.y != 0.f); }
@@ -130,10 +131,11 @@ __global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse
 // direction and a zero row.  counts[b] = kept samples of image b; counts[B] = 1 if some image kept more than cap (those samples are dropped:
 // the caller treats the flag as an error).
 __global__ void __launch_bounds__(256) sparse_gather_kernel(const float* d_coarse, const float* d_fine, const float* z_coarse, const float* z_fine,
-                                                            const float* origins, const float* dirs, int R, int N, int C, long long cap,
-                                                            const unsigned long long* masks, const int* block_counts, float* pts, float* rd,
+                                                            const float* origins, const float* dirs, const long long* images, int R, int N, int C,
+                                                            long long cap, const unsigned long long* masks, const int* block_counts, float* pts, float* rd,
                                                             float* d_sel, int* counts, int B) {
   const int b = blockIdx.y, t = threadIdx.x, nblk = gridDim.x, blk = blockIdx.x;
+  const long long img = images ? images[b] : b;
   const long long P = (long long)R * N;
   __shared__ int red[2][4];
   int before = 0, all = 0;
@@ -161,9 +163,9 @@ __global__ void __launch_bounds__(256) sparse_gather_kernel(const float* d_coars
     const long long s = (long long)blk * 256 + t;
     const bool fine = s >= P;
     const long long q = fine ? s - P : s;
-    const float* row = (fine ? d_fine : d_coarse) + ((long long)b * P + q) * C;
-    const float zz = (fine ? z_fine : z_coarse)[(long long)b * P + q];
-    const long long ray = (long long)b * R + q / N;
+    const float* row = (fine ? d_fine : d_coarse) + (img * P + q) * C;
+    const float zz = (fine ? z_fine : z_coarse)[img * P + q];
+    const long long ray = img * R + q / N;
     const long long o = (long long)b * cap + slot;
     const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
     pts[o * 3 + 0] = __fadd_rn(origins[ray * 3 + 0], __fmul_rn(dx, zz));
@@ -179,10 +181,10 @@ __global__ void __launch_bounds__(256) sparse_gather_kernel(const float* d_coars
     }
   }
   // the pad slots of the image, shared out over its blocks
-  const long long ray0 = (long long)b * R;
+  const long long ray0 = img * R;
   for (long long sl = (long long)all + (long long)blk * 256 + t; sl < cap; sl += (long long)nblk * 256) {
     const long long o = (long long)b * cap + sl;
-    const float zz = z_coarse[(long long)b * P];
+    const float zz = z_coarse[img * P];
     const float dx = dirs[ray0 * 3 + 0], dy = dirs[ray0 * 3 + 1], dz = dirs[ray0 * 3 + 2];
     pts[o * 3 + 0] = __fadd_rn(origins[ray0 * 3 + 0], __fmul_rn(dx, zz));
     pts[o * 3 + 1] = __fadd_rn(origins[ray0 * 3 + 1], __fmul_rn(dy, zz));
@@ -198,16 +200,16 @@ size_t sparse_select_workspace_bytes(int B, long long P) {
 }
 
 int launch_sparse_select(int B, int R, int N, int C, long long cap, const float* d_coarse, const float* d_fine, const float* z_coarse,
-                         const float* z_fine, const float* origins, const float* dirs, float* pts, float* rd, float* d_sel, int* counts,
-                         void* workspace, void* stream) {
+                         const float* z_fine, const float* origins, const float* dirs, const long long* images, float* pts, float* rd, float* d_sel,
+                         int* counts, void* workspace, void* stream) {
   const long long P = (long long)R * N;
   const long long nblk = (2 * P + 255) / 256;
   unsigned long long* masks = (unsigned long long*)workspace;
   int* block_counts = (int*)(masks + (size_t)B * nblk * 4);
   const dim3 grid((unsigned)nblk, (unsigned)B);
-  hipLaunchKernelGGL(sparse_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, P, C, masks, block_counts, counts, B);
-  hipLaunchKernelGGL(sparse_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, z_coarse, z_fine, origins, dirs, R, N, C, cap,
-                     masks, block_counts, pts, rd, d_sel, counts, B);
+  hipLaunchKernelGGL(sparse_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, images, P, C, masks, block_counts, counts, B);
+  hipLaunchKernelGGL(sparse_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, z_coarse, z_fine, origins, dirs, images, R, N, C,
+                     cap, masks, block_counts, pts, rd, d_sel, counts, B);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error(std::string("sparse select launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
   return FENERF_OK;

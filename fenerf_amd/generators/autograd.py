@@ -240,8 +240,8 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
             sig = torch.cat([coarse[..., -1].reshape(B, P), fine[..., -1].reshape(B, P)], 1)
             if noise_f is not None and opts.noise_std != 0:
                 sig = sig + noise_f.abs().max() * opts.noise_std
-            cap = (~(sig <= 0)).sum(1).max() + (R if opts.last_back else 0)
-            ctx.cap_host = torch.empty((), dtype=torch.long, pin_memory=True)
+            cap = (~(sig <= 0)).sum(1) + (R if opts.last_back else 0)                          # per image
+            ctx.cap_host = torch.empty((B,), dtype=torch.long, pin_memory=True)
             ctx.cap_host.copy_(cap, non_blocking=True)
             ctx.cap_ready = torch.cuda.Event()
             ctx.cap_ready.record()
@@ -265,34 +265,60 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         dev = origins.device
         d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
                                              noise=noise_f if noise_f.numel() else None)
-        # the buffer length comes from the forward's bound (that copy finished long ago), so nothing here waits for the device
+        # the buffer lengths come from the forward's per-image bounds (that copy finished long ago), so nothing here waits for the device
         if ctx.cap_ready is not None:
             ctx.cap_ready.synchronize()
-            Pp = min(2 * P, int(ctx.cap_host))
+            caps = [min(2 * P, int(c)) for c in ctx.cap_host.tolist()]
         else:
-            Pp = 2 * P
-        Pp = max(32, (Pp + 31) // 32 * 32)
-        sparse_auto_observe(module, Pp / (2 * P))
-        # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
-        # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: two launches)
-        pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, Pp, want_dirs=not ctx.lock_view)
-        del d_f, d_c
-        # (a count above the bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
-        SparseHierarchicalRenderFunction._check_overflow(counts[B])
-        counts = counts[:B]
+            caps = [2 * P] * B
+        caps = [max(32, (c + 31) // 32 * 32) for c in caps]
+        # images that keep similar numbers of samples share a launch group (padded to the group's fullest image); a batch of one dense and
+        # five nearly empty images is not padded to six dense ones
+        groups = plan_sparse_groups(caps, torch.cuda.get_device_properties(dev).multi_processor_count)
+        sparse_auto_observe(module, sum(len(g) * c for g, c in groups) / (2 * P * B))
+        whole = len(groups) == 1
+        perm = None if whole else torch.tensor([b for g, _ in groups for b in g], dtype=torch.long).pin_memory().to(dev, non_blocking=True)
         film_only = not any(need[14:])
         fmt = module.tape_format(nat, film_only=film_only)
-        out, tape, tape_e = nat.siren_forward_save(pts, rd, fg, pg, fa, pa, tape_format=fmt)
-        r, d_grid = _siren_autograd.chunked_backward(nat, B, Pp, (fg, pg, fa, pa), pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
-                                                  weights=_siren_autograd.film_layer_weights(module, params) if fmt else None)
-        SparseHierarchicalRenderFunction.last_kept = (counts.sum(), 2 * B * P)                  # for reports (a device scalar: read it after the step)
-        film_grads = tuple(r[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
+        weights = _siren_autograd.film_layer_weights(module, params) if fmt else None
+        total, d_grid, film_rows, kept, flags, first = None, None, [], [], [], 0
+        for g, cap in groups:
+            ids = None if whole else perm[first:first + len(g)]
+            first += len(g)
+            # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
+            # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: two launches)
+            pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, cap, want_dirs=not ctx.lock_view, images=ids)
+            film_g = (fg, pg, fa, pa) if whole else tuple(t.index_select(0, ids) for t in (fg, pg, fa, pa))
+            out, tape, tape_e = nat.siren_forward_save(pts, rd, *film_g, tape_format=fmt)
+            r, d_grid = _siren_autograd.chunked_backward(nat, len(g), cap, film_g, pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
+                                                      weights=weights, d_grid=d_grid)
+            del out, tape, tape_e, d_sel
+            film_rows.append([r[k] for k in _siren_autograd.FILM_KEYS])
+            if not film_only:
+                if total is None:
+                    total = r
+                else:
+                    _siren_autograd._add_all(_siren_autograd._flat(total, _siren_autograd.FILM_KEYS), _siren_autograd._flat(r, _siren_autograd.FILM_KEYS))
+            kept.append(counts[:len(g)].sum())
+            flags.append(counts[len(g)])
+        del d_f, d_c
+        # (a count above its bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
+        SparseHierarchicalRenderFunction._check_overflow(flags[0] if whole else torch.stack(flags).max())
+        SparseHierarchicalRenderFunction.last_kept = (kept[0] if whole else torch.stack(kept).sum(), 2 * B * P)   # for reports (a device scalar: read it after the step)
+        SparseHierarchicalRenderFunction.last_groups = [(list(g), c) for g, c in groups]
+        if whole:
+            film = film_rows[0]
+        else:       # rows back into image order
+            film = [torch.cat([rows[i] for rows in film_rows], 0).index_select(0, torch.argsort(perm)) for i in range(len(_siren_autograd.FILM_KEYS))]
+        fr = dict(zip(_siren_autograd.FILM_KEYS, film))
+        film_grads = tuple(fr[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
         head = (None,) * 10
         if film_only:
             return head + film_grads + (None,) * len(params)
-        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, r, pts, d_grid, need[14:])
+        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, total, None, d_grid, need[14:])
 
 
+SparseHierarchicalRenderFunction.last_groups = None
 SparseHierarchicalRenderFunction.last_kept = None
 SparseHierarchicalRenderFunction._pending = None
 
@@ -335,6 +361,29 @@ SparseHierarchicalRenderFunction.verify = staticmethod(_verify)
 # runs and every SPARSE_AUTO_PROBE_EVERY-th step is a sparse one that observes again (a probe at f = 1 costs + 28 % of one step).
 SPARSE_AUTO_MAX_FRACTION = 0.6
 SPARSE_AUTO_PROBE_EVERY = 50
+
+
+def plan_sparse_groups(caps, n_cus=256, group_cost=0.6):
+    """caps[b]: slots image b needs (a multiple of 32).  -> [(images, cap)]: a partition of the batch into launch groups, each padded to its
+    fullest image, that minimises  sum over groups of (rounds of 128-point workgroups over the CUs + group_cost)  -- the SIREN kernels are
+    persistent, one workgroup per CU, so a group's time goes with ceil(images * cap / (128 * CUs)); group_cost (in rounds) stands for what a
+    further group adds beside its kernels (five more launches, one more sum over the weight gradients).  Optimal over partitions of the
+    images sorted by cap (dynamic programme, O(B^2)); ties go to fewer groups."""
+    n = len(caps)
+    order = sorted(range(n), key=lambda b: (-caps[b], b))
+    unit = 128 * max(1, n_cus)
+    best, cut = [0.0] + [float("inf")] * n, [0] * (n + 1)
+    for j in range(1, n + 1):
+        for i in range(j):
+            c = best[i] + -(-((j - i) * caps[order[i]]) // unit) + group_cost
+            if c < best[j] - 1e-9:
+                best[j], cut[j] = c, i
+    groups, j = [], n
+    while j > 0:
+        i = cut[j]
+        groups.append((sorted(order[i:j]), caps[order[i]]))
+        j = i
+    return groups[::-1]
 
 
 def _sparse_auto_state(module):

@@ -1180,14 +1180,17 @@ def merge_composite(fine, coarse, z_fine, z_coarse, noise, opts, want_weights=Tr
     return rgb, depth, w, ws, zs
 
 
-def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_dirs=True):
+def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_dirs=True, images=None):
     """Selection step of the exact-sparsity backward (fenerf_sparse_select, include/fenerf.h): d_coarse / d_fine [B*R, N, C] (the merged
     composite's backward), z_coarse / z_fine [B*R, N], origins / dirs [B, R, 3], cap = slots per image (a multiple of 32).
     -> pts [B, cap, 3], rd [B, cap, 3] or None, d_sel [B, cap, C], counts int32 [B + 1] (kept samples per image, then the overflow flag);
-    two launches, nothing waits."""
-    B, R, _ = origins.shape
+    two launches, nothing waits.  images: None, or an int64 device tensor [B'] of image indices -- the call then handles those B' images
+    (outputs [B', ...]) of the inputs' B."""
+    Bin, R, _ = origins.shape
     BR, N, Cc = d_coarse.shape
-    assert BR == B * R and d_fine.shape == d_coarse.shape and cap >= 1
+    assert BR == Bin * R and d_fine.shape == d_coarse.shape and cap >= 1
+    assert images is None or (images.is_cuda and images.dtype == torch.int64 and images.is_contiguous() and images.dim() == 1)
+    B = Bin if images is None else images.numel()
     dev = d_coarse.device
     dc, df, zc, zf, o, d = (_f32(t, dev) for t in (d_coarse, d_fine, z_coarse, z_fine, origins, dirs))
     pts = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
@@ -1197,8 +1200,8 @@ def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_d
     nbytes = _lib.lib().fenerf_sparse_select_workspace_bytes(B, R * N)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().fenerf_sparse_select(B, R, N, Cc, cap, _ptr(dc), _ptr(df), _ptr(zc), _ptr(zf), _ptr(o), _ptr(d), _ptr(pts), _ptr(rd),
-                                                   _ptr(d_sel), C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, _stream()))
+        _lib.check(_lib.lib().fenerf_sparse_select(B, R, N, Cc, cap, _ptr(dc), _ptr(df), _ptr(zc), _ptr(zf), _ptr(o), _ptr(d),
+                                                   C.c_void_p(images.data_ptr()) if images is not None else None, _ptr(pts), _ptr(rd), _ptr(d_sel), C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, _stream()))
     return pts, rd, d_sel, counts
 
 

@@ -140,7 +140,7 @@ class InputGrads(typing.NamedTuple):
 
 
 def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, film_only, max_points=None, tape_format=0, weights=None,
-                     input_grads=None):
+                     input_grads=None, d_grid=None):
     """fenerf_siren_backward + fenerf_siren_param_grads over `nB` images of `Pp` points (a multiple of 32) in chunks of at most
     `max_points` points: tiles, tapes and outputs of an image range are contiguous, FiLM parameters are per image, and every gradient
     is a sum over points, so chunk results simply add.  A chunk is a run of WHOLE images while those fit (the curriculum's early
@@ -151,6 +151,7 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     tape_format / weights: the tape's format (_lib.TAPE_*) and, for the 16-bit tape, film_layer_weights(...).
     input_grads: None or an InputGrads: every chunk also fills its rows of the gradients wrt the sample positions / view directions
     from its d(theta) dump (NativeModel.siren_input_grads); with `only` set (and film_only) the weight- / FiLM-gradient launches are skipped.
+    d_grid: None, or the channels-last gradient grid of an earlier call to add to (returned again).
     -> (grads dict like siren_param_grads with [nB]-leading FiLM gradients, d_grid_cl [D,H,W,32] or None)."""
     max_points = BACKWARD_CHUNK_POINTS if max_points is None else max_points
     max_points = max(128, max_points // 128 * 128)       # whole quads of 32-point tiles except in an image's last chunk
@@ -158,7 +159,8 @@ def chunked_backward(nat, nB, Pp, film, points, dirs, out, d_out, tape, tape_e, 
     G = nat.spec["grid_ch"]
     C = nat.C
     out, d_out = out.reshape(nB, Pp, C), d_out.reshape(nB, Pp, C)
-    d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G and not film_only else None
+    if d_grid is None:       # (given: the gradient grid an earlier call of the same backward pass started, scattered into further)
+        d_grid = torch.zeros(tuple(nat.grid_shape) + (32,), dtype=torch.float32, device=out.device) if G and not film_only else None
     # (first image, images, first point, points) per launch
     if Pp <= max_points:
         per = max(1, max_points // Pp)

@@ -591,10 +591,13 @@ size_t fenerf_sparse_select_workspace_bytes(int B, int64_t P);
  * first) fill slots 0 .. counts[b] - 1 of pts / rd [B][cap][3] (origins + dirs * z, generators.py:504; rd may be NULL) and d_sel
  * [B][cap][C]; the remaining slots repeat the image's first sample with a zero row.  counts [B + 1] (int32, device): kept samples per
  * image, then a flag that is 1 when some image kept more than cap (the excess is dropped: treat as an error).  Feed pts / rd / d_sel to
- * fenerf_siren_forward_save + fenerf_siren_backward + fenerf_siren_param_grads with P = cap (a multiple of 32). */
+ * fenerf_siren_forward_save + fenerf_siren_backward + fenerf_siren_param_grads with P = cap (a multiple of 32).
+ * images (device, may be NULL = 0 .. B - 1): image b of this call is image images[b] of the input arrays -- a batch whose images keep
+ * very different numbers of samples is walked in groups of similar images, each with its own cap, instead of padding every image to
+ * the fullest one. */
 int fenerf_sparse_select(int B, int R, int N, int C, int64_t cap, const float* d_coarse, const float* d_fine, const float* z_coarse,
-                         const float* z_fine, const float* origins, const float* dirs, float* pts, float* rd, float* d_sel,
-                         int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+                         const float* z_fine, const float* origins, const float* dirs, const int64_t* images, float* pts, float* rd,
+                         float* d_sel, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of [dev] scratch fenerf_render_forward needs. */
 size_t fenerf_render_workspace_bytes(const FenerfModel* m, int B, int R, int N, int hierarchical);

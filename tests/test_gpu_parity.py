@@ -4104,6 +4104,62 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
 
 
+@pytest.mark.parametrize("film_only", [False, True], ids=["all_gradients", "film_only"])
+def test_sparse_backward_in_launch_groups_of_similar_images(film_only, monkeypatch):
+    """A batch whose images keep very different numbers of samples is walked in launch groups (generators/autograd.py plan_sparse_groups,
+    fenerf_sparse_select's image list), each padded to its own fullest image.  Here the plan is forced to split (one 128-point workgroup
+    per round, no cost per group): five images with a density bias each (FiLM phase of the last geometry layer shifted), so their kept
+    counts differ; pixels bit-identical to the dense node, gradients equal to the order of the sums, FiLM gradient rows in image order."""
+    from fenerf_amd.generators import autograd as GA
+    plan = GA.plan_sparse_groups
+    monkeypatch.setattr(GA, "plan_sparse_groups", lambda caps, n_cus: plan(caps, 1, 0.0))
+    mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision="f16x3")
+    gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    B = 5
+    film = proc.film_params(spec, B, seed=4)
+    kw = dict(img_size=8, fov=12, ray_start=0.88, ray_end=1.12, num_steps=12, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2, v_mean=np.pi / 2,
+              hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=0.0)
+    if film_only:
+        for p_ in mod.parameters():
+            p_.requires_grad_(False)
+    res = []
+    try:
+        for sparse in (False, True):
+            mod.sparse_backward = sparse
+            film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+            for p_ in mod.parameters():
+                p_.grad = None
+            torch.manual_seed(11)
+            px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+            w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (px * w).sum().backward()
+            g = {k: N_(v.grad) for k, v in film_t.items()}
+            g.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
+            res.append((N_(px), g))
+        GA.SparseHierarchicalRenderFunction.verify()
+        groups = GA.SparseHierarchicalRenderFunction.last_groups
+        kept = GA.SparseHierarchicalRenderFunction.last_kept
+    finally:
+        mod.sparse_backward = False
+        for p_ in mod.parameters():
+            p_.requires_grad_(True)
+    (px0, g0), (px1, g1) = res
+    assert np.array_equal(px0, px1) and g0.keys() == g1.keys() and len(g0) == (4 if film_only else 37)
+    errs = {k: _rel_err(g1[k], g0[k]) for k in g0}
+    worst = max(errs, key=errs.get)
+    print(f"[parity] sparse backward in launch groups [{'FiLM gradients only' if film_only else 'all gradients'}]: {len(groups)} groups {groups}, "
+          f"{int(kept[0])} of {kept[1]} samples kept, pixels bit-identical, worst relative gradient difference over {len(g0)} tensors {errs[worst]:.1e} ({worst})")
+    assert len(groups) >= 2 and sorted(b for g_, _ in groups for b in g_) == list(range(B))
+    assert errs[worst] <= 2e-6, (worst, errs[worst])
+    # per image: the FiLM gradient rows sit at their image's index (a permuted result would be far off row by row)
+    for k in ("freq_geo", "phase_geo", "freq_app", "phase_app"):
+        for b in range(B):
+            assert _rel_err(g1[k][b], g0[k][b]) <= 1e-5, (k, b)
+
+
 @pytest.mark.parametrize("clamp", ["relu", "softplus"])
 def test_sparse_backward_auto_picks_the_cheaper_node(clamp, monkeypatch):
     """siren.sparse_backward = "auto" (generators/autograd.py sparse_auto_choice): the first step is a sparse one (nothing observed yet); it

@@ -732,3 +732,25 @@ def test_bench_cpu_baseline_is_the_torch_oracle_on_all_cores(monkeypatch):
     assert len(quick["runs"]) == 1 and len(quick["runs"][0]["seconds"]) == 1 and len(seen) == 2
     spent = bench.cpu_baseline(spec, sd, film, 7, full=True, budget_s=0.0)
     assert len(spent["runs"][0]["seconds"]) == 1 and all("skipped" in r for r in spent["runs"][1:]) and "numpy_oracle" not in spent
+
+
+def test_sparse_backward_launch_groups():
+    """generators/autograd.py plan_sparse_groups: the exact-sparsity backward pads the images of a launch group to the group's fullest image;
+    the plan is a partition of the batch, every group's cap is its largest member's, and it never costs more (rounds of 128-point workgroups
+    over the CUs + 0.6 per group) than one group for everything or one group per image."""
+    from fenerf_amd.generators.autograd import plan_sparse_groups
+    cost = lambda groups, n_cus=256: sum(-(-(len(g) * c) // (128 * n_cus)) + 0.6 for g, c in groups)
+    assert plan_sparse_groups([133184]) == [([0], 133184)]
+    assert plan_sparse_groups([4096] * 6) == [(list(range(6)), 4096)]                                  # similar images: one group
+    full = plan_sparse_groups([32, 786432, 64, 32, 96, 32])                                           # one dense image among empty ones
+    assert full == [([1], 786432), ([0, 2, 3, 4, 5], 96)]
+    assert plan_sparse_groups([32, 786432, 64], n_cus=1, group_cost=0.0) == [([1], 786432), ([0, 2], 64)]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        B = int(rng.integers(1, 13))
+        caps = [int(c) * 32 for c in rng.integers(1, 24577, B)]
+        n_cus = int(rng.choice([1, 8, 256]))
+        groups = plan_sparse_groups(caps, n_cus)
+        assert sorted(b for g, _ in groups for b in g) == list(range(B))
+        assert all(c == max(caps[b] for b in g) and g == sorted(g) for g, c in groups)
+        assert cost(groups, n_cus) <= min(cost([(list(range(B)), max(caps))], n_cus), cost([([b], caps[b]) for b in range(B)], n_cus)) + 1e-9
