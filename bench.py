@@ -366,6 +366,9 @@ def gstep_leg(spec, sd, dev, B, S, N, precision, iters=8, breakdown=True, grad_p
                         "with sigma + noise <= 0 has weight 0 and relu' = 0, the reference's autograd multiplies those zeros through the network; "
                         "data-dependent (this workload's procedural density field)")
         out["kept_samples"], out["samples"], out["kept_frac"] = kept, total, kept / total
+        groups = GA.SparseHierarchicalRenderFunction.last_groups
+        out["launch_groups"] = [{"images": len(g), "slots_per_image": c} for g, c in groups]       # images padded to their group's fullest
+        out["slots_frac"] = sum(len(g) * c for g, c in groups) / total
         return out
     if not breakdown:
         return out
