@@ -112,6 +112,9 @@ def main():
     gen.siren.sparse_backward = True
     check("gdp_sparse_backward", run(gdp, 1), want1)
     check("gdp_sparse_backward_2_micro_batches", run(gdp, 2), want2)
+    fdist.prepare_for_ddp(gen, True)                   # both switches on: the sparse node goes first
+    check("gdp_split_and_sparse_backward", run(gdp, 1), want1)
+    fdist.prepare_for_ddp(gen, False)
     gen.siren.sparse_backward = False
     gdp.detach_hooks()
     del gdp
