@@ -678,6 +678,9 @@ def main(argv=None):
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="headline shape only, 1 warm-up + 1 timed run")
     ap.add_argument("--no-gstep", action="store_true", help="skip the generator-step (forward + backward) leg")
     ap.add_argument("--no-gstep-b6", action="store_true", help="skip the 6-image generator micro-batch (configs[2]) legs")
+    ap.add_argument("--gstep-sparse-b6", action="store_true",
+                    help="also time the 6-image micro-batch with the opt-in exact-sparsity backward (not in the default command: its 6-image no-grad "
+                         "launches of the headline kernel would mix into that kernel's rocprofv3 average)")
     ap.add_argument("--no-gstep-ddp", action="store_true", help="skip the DistributedDataParallel generator-step legs (run at every N)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-sweep64", action="store_true", help="skip the 64x64, 24+24 scaling-batch leg")
@@ -943,12 +946,14 @@ def main(argv=None):
                     torch.cuda.empty_cache()
                 except Exception as e:
                     out["gstep_b6"] = {"error": f"{type(e).__name__}: {e}"}
-                try:   # the same micro-batch with the opt-in exact-sparsity backward
-                    out["gstep_sparse_b6"] = gstep_leg(spec, sd, dev, 6, S, N, args.precision, iters=5, breakdown=False, per_step_median=True, sparse=True)
-                    out["gstep_sparse_b6"]["ms_per_image"] = out["gstep_sparse_b6"]["ms"] / 6
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    out["gstep_sparse_b6"] = {"error": f"{type(e).__name__}: {e}"}
+                if args.gstep_sparse_b6:
+                    try:   # the same micro-batch with the opt-in exact-sparsity backward (opt-in leg: --gstep-sparse-b6)
+                        out["gstep_sparse_b6"] = gstep_leg(spec, sd, dev, 6, S, N, args.precision, iters=5, breakdown=False, per_step_median=True,
+                                                           sparse=True)
+                        out["gstep_sparse_b6"]["ms_per_image"] = out["gstep_sparse_b6"]["ms"] / 6
+                        torch.cuda.empty_cache()
+                    except Exception as e:
+                        out["gstep_sparse_b6"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             # N = 1: BASELINE.md's plan (1 warm-up + 3 timed runs x 3 shapes); N > 1: the headline shape once, so that every line of
             # the driver's scaling sweep is self-contained while the other ranks wait at the final barrier for ~20 s, not a minute

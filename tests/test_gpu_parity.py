@@ -4115,6 +4115,50 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
 
 
+@pytest.mark.parametrize("B,R,N,C,images", [(1, 49, 11, 22, None), (3, 37, 7, 21, None), (4, 16, 24, 22, [2, 0]), (2, 300, 3, 4, [1]), (1, 1, 1, 5, None)])
+def test_sparse_select_against_torch(B, R, N, C, images):
+    """fenerf_sparse_select (include/fenerf.h) against the torch statements it replaced: per image the samples with a non-zero gradient row
+    (NaN counts) in sample order, coarse pass first; their points origins + dirs * z, directions and rows; pad slots = the image's first
+    sample with a zero row; counts; the overflow flag when cap is too small.  Odd / even C, P not a multiple of 256, an image list."""
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + R)
+    P = R * N
+    rnd = lambda *s: torch.randn(s, device=DEV, generator=g)
+    d_c, d_f = rnd(B * R, N, C), rnd(B * R, N, C)
+    for d in (d_c, d_f):
+        d[torch.rand((B * R, N), device=DEV, generator=g) < 0.7] = 0.0           # 70 % all-zero rows
+    d_c[0, 0, C - 1] = float("nan")                                               # a broken row is kept
+    d_f.view(-1, C)[-1] = 0.0
+    d_f.view(-1, C)[-1, 0] = -0.0                                                  # -0.0 is zero
+    zc, zf, o, dr = rnd(B * R, N), rnd(B * R, N), rnd(B, R, 3), rnd(B, R, 3)
+    ids = list(range(B)) if images is None else images
+    d_all = torch.cat([d_c.reshape(B, P, C), d_f.reshape(B, P, C)], 1)
+    keep = (d_all != 0).any(-1)
+    z_all = torch.cat([zc.reshape(B, P), zf.reshape(B, P)], 1)
+    want_counts = [int(keep[b].sum()) for b in ids]
+    cap = max(32, (max(want_counts) + 31) // 32 * 32)
+    idx = None if images is None else torch.tensor(images, dtype=torch.long, device=DEV)
+    pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, zf, o, dr, cap, images=idx)
+    assert pts.shape == (len(ids), cap, 3) and rd.shape == pts.shape and d_sel.shape == (len(ids), cap, C)
+    assert counts.tolist() == want_counts + [0]
+    for j, b in enumerate(ids):
+        sel = torch.nonzero(keep[b]).flatten()
+        sel = torch.cat([sel, sel.new_zeros(cap - sel.numel())])                  # pad slots: sample 0
+        ray = (sel % P) // N
+        want_pts = o[b, ray] + dr[b, ray] * z_all[b, sel].unsqueeze(-1)
+        want_d = d_all[b, sel]
+        want_d[want_counts[j]:] = 0
+        assert torch.equal(pts[j], want_pts) and torch.equal(rd[j], dr[b, ray])
+        assert torch.equal(torch.nan_to_num(d_sel[j], nan=7.0), torch.nan_to_num(want_d, nan=7.0))
+    pts2, rd2, _, counts2 = native.sparse_select(d_c, d_f, zc, zf, o, dr, cap, want_dirs=False, images=idx)
+    assert rd2 is None and torch.equal(pts2, pts) and torch.equal(counts2, counts)
+    if max(want_counts) > 32:        # a cap below the fullest image's count: flag raised, the first `cap` kept samples delivered
+        small = (max(want_counts) - 1) // 32 * 32
+        pts3, _, d3, counts3 = native.sparse_select(d_c, d_f, zc, zf, o, dr, small, images=idx)
+        assert counts3.tolist() == want_counts + [1]
+        j = int(np.argmax(want_counts))
+        assert torch.equal(pts3[j], pts[j, :small])
+
+
 @pytest.mark.parametrize("film_only", [False, True], ids=["all_gradients", "film_only"])
 def test_sparse_backward_in_launch_groups_of_similar_images(film_only, monkeypatch):
     """A batch whose images keep very different numbers of samples is walked in launch groups (generators/autograd.py plan_sparse_groups,

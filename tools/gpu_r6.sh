@@ -14,6 +14,16 @@ if [ "$which" = "bench" ] || [ "$which" = "all" ]; then
   timeout 900 python bench.py > gpurun_out/r6_bench_default.log 2> gpurun_out/r6_bench_default.err
   echo "bench rc=$? in $(( $(date +%s) - t0 )) s"; tail -1 gpurun_out/r6_bench_default.log | wc -c; tail -1 gpurun_out/r6_bench_default.log
   cp bench_detail.json gpurun_out/r6_bench_detail.json
+  # the opt-in leg that is not part of the default command: the 6-image micro-batch with the exact-sparsity backward
+  timeout 600 python bench.py --gstep-sparse-b6 --no-cpu-baseline --no-f32 --no-sweep64 --no-gstep-ddp > gpurun_out/r6_bench_sparse_b6.log 2>&1
+  python - <<PY
+import json
+d = json.load(open("bench_detail.json"))
+keep = {k: {a: b for a, b in d[k].items() if a != "what"} for k in ("gstep", "gstep_sparse", "gstep_b6", "gstep_sparse_b6") if k in d}
+json.dump(keep, open("gpurun_out/r6_bench_sparse_legs.json", "w"), indent=1)
+print({k: round(v.get("ms", -1), 2) for k, v in keep.items()})
+PY
+  cp gpurun_out/r6_bench_detail.json bench_detail.json
 fi
 if [ "$which" = "full" ]; then
   timeout 3000 python -m pytest tests -q -s -m gpu > gpurun_out/r6_gpu_tests_full.log 2>&1
