@@ -126,33 +126,51 @@ __global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse
   }
 }
 
-// Pass 2: slot = kept samples of the image before this one; a kept sample writes its point (origins + dirs * z: mul, then add, as every
+// Pass 2: one workgroup per image turns its block counts into their exclusive prefix sums in place (a running carry over pieces of 1024
+// blocks: 49,152 samples at 128 x 128 x 24+24 are 3 pieces, 6.3 M at 256 x 256 x 48+48 are 24); counts[b] = the image's total, counts[B] = 1
+// if some image kept more than cap.
+__global__ void __launch_bounds__(1024) sparse_scan_kernel(int* block_counts, int nblk, long long cap, int* counts, int B) {
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int* bc = block_counts + (long long)b * nblk;
+  __shared__ int wave_sum[16];
+  __shared__ int carry_s;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int j = base + t;
+    const int v = j < nblk ? bc[j] : 0;
+    int incl = v;                                           // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_sum[w] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int k = 0; k < w; ++k) before += wave_sum[k];
+    if (j < nblk) bc[j] = before + incl - v;
+    __syncthreads();
+    if (t == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (t == 0) {
+    counts[b] = carry_s;
+    if (carry_s > cap) counts[B] = 1;
+  }
+}
+
+// Pass 3: slot = kept samples of the image before this one; a kept sample writes its point (origins + dirs * z: mul, then add, as every
 // other kernel of the path rounds it), its ray direction and its gradient row to its slot; slots count .. cap - 1 get sample 0's point and
-// direction and a zero row.  counts[b] = kept samples of image b; counts[B] = 1 if some image kept more than cap (those samples are dropped:
-// the caller treats the flag as an error).
+// direction and a zero row.  Kept samples beyond cap are dropped (pass 2 raised the flag: the caller treats it as an error).
 __global__ void __launch_bounds__(256) sparse_gather_kernel(const float* d_coarse, const float* d_fine, const float* z_coarse, const float* z_fine,
                                                             const float* origins, const float* dirs, const long long* images, int R, int N, int C,
                                                             long long cap, const unsigned long long* masks, const int* block_counts, float* pts, float* rd,
-                                                            float* d_sel, int* counts, int B) {
+                                                            float* d_sel, const int* counts) {
   const int b = blockIdx.y, t = threadIdx.x, nblk = gridDim.x, blk = blockIdx.x;
   const long long img = images ? images[b] : b;
   const long long P = (long long)R * N;
-  __shared__ int red[2][4];
-  int before = 0, all = 0;
-  for (int j = t; j < nblk; j += 256) {
-    const int n = block_counts[(long long)b * nblk + j];
-    all += n;
-    if (j < blk) before += n;
-  }
-  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
-  if ((t & 63) == 0) { red[0][t >> 6] = before; red[1][t >> 6] = all; }
-  __syncthreads();
-  before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-  if (blk == 0 && t == 0) {
-    counts[b] = all;
-    if (all > cap) counts[B] = 1;
-  }
+  const int before = block_counts[(long long)b * nblk + blk];      // exclusive prefix (pass 2)
+  const int all = counts[b];
   const int w = t >> 6, lane = t & 63;
   const unsigned long long* mw = masks + ((long long)b * nblk + blk) * 4;
   long long slot = before;
@@ -208,8 +226,9 @@ int launch_sparse_select(int B, int R, int N, int C, long long cap, const float*
   int* block_counts = (int*)(masks + (size_t)B * nblk * 4);
   const dim3 grid((unsigned)nblk, (unsigned)B);
   hipLaunchKernelGGL(sparse_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, images, P, C, masks, block_counts, counts, B);
+  hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, block_counts, (int)nblk, cap, counts, B);
   hipLaunchKernelGGL(sparse_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_coarse, d_fine, z_coarse, z_fine, origins, dirs, images, R, N, C,
-                     cap, masks, block_counts, pts, rd, d_sel, counts, B);
+                     cap, masks, block_counts, pts, rd, d_sel, counts);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error(std::string("sparse select launch: ") + hipGetErrorString(e)); return FENERF_E_HIP; }
   return FENERF_OK;

@@ -286,7 +286,7 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
             ids = None if whole else perm[first:first + len(g)]
             first += len(g)
             # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
-            # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: two launches)
+            # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: three launches)
             pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, cap, want_dirs=not ctx.lock_view, images=ids)
             film_g = (fg, pg, fa, pa) if whole else tuple(t.index_select(0, ids) for t in (fg, pg, fa, pa))
             out, tape, tape_e = nat.siren_forward_save(pts, rd, *film_g, tape_format=fmt)

@@ -1184,7 +1184,7 @@ def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_d
     """Selection step of the exact-sparsity backward (fenerf_sparse_select, include/fenerf.h): d_coarse / d_fine [B*R, N, C] (the merged
     composite's backward), z_coarse / z_fine [B*R, N], origins / dirs [B, R, 3], cap = slots per image (a multiple of 32).
     -> pts [B, cap, 3], rd [B, cap, 3] or None, d_sel [B, cap, C], counts int32 [B + 1] (kept samples per image, then the overflow flag);
-    two launches, nothing waits.  images: None, or an int64 device tensor [B'] of image indices -- the call then handles those B' images
+    three launches, nothing waits.  images: None, or an int64 device tensor [B'] of image indices -- the call then handles those B' images
     (outputs [B', ...]) of the inputs' B."""
     Bin, R, _ = origins.shape
     BR, N, Cc = d_coarse.shape

@@ -4115,7 +4115,8 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
 
 
-@pytest.mark.parametrize("B,R,N,C,images", [(1, 49, 11, 22, None), (3, 37, 7, 21, None), (4, 16, 24, 22, [2, 0]), (2, 300, 3, 4, [1]), (1, 1, 1, 5, None)])
+@pytest.mark.parametrize("B,R,N,C,images", [(1, 49, 11, 22, None), (3, 37, 7, 21, None), (4, 16, 24, 22, [2, 0]), (2, 300, 3, 4, [1]), (1, 1, 1, 5, None),
+                                            (2, 16384, 12, 22, None)])        # 1,536 blocks of 256 samples per image: two pieces of the prefix-sum pass
 def test_sparse_select_against_torch(B, R, N, C, images):
     """fenerf_sparse_select (include/fenerf.h) against the torch statements it replaced: per image the samples with a non-zero gradient row
     (NaN counts) in sample order, coarse pass first; their points origins + dirs * z, directions and rows; pad slots = the image's first
