@@ -4216,6 +4216,75 @@ def test_sparse_backward_in_launch_groups_of_similar_images(film_only, monkeypat
             assert _rel_err(g1[k][b], g0[k][b]) <= 1e-5, (k, b)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_sparse_backward_random_configurations(seed, monkeypatch):
+    """Seeded random configurations of the differentiable render (batch, image size, samples per ray, hidden width, density gain, noise,
+    last_back / white_back, locked view direction, precision tier, FiLM-only or all gradients, forced launch groups): the sparse node against
+    the dense node -- pixels bit-identical, every gradient equal to the order of the sums.  Seeds 8 and 9 push the density bias far below
+    zero: no sample of any image carries density (relu clamp), so nothing (seed 8) or only each ray's last sample (seed 9, last_back) is kept."""
+    from fenerf_amd.generators import autograd as GA
+    rng = np.random.default_rng(1000 + seed)
+    H = int(rng.choice([32, 64, 96]))
+    B, S_, N = int(rng.integers(1, 5)), int(rng.integers(3, 10)), int(rng.integers(4, 25))
+    precision = str(rng.choice(PRECISIONS + ["tape16"]))
+    kind = str(rng.choice(["texture", "baseline"]))
+    mod, spec, sd = _siren_module(kind, H, 5 if kind == "texture" else 0, sigma_gain=float(rng.choice([1.0, 30.0, 400.0])), precision=precision)
+    empty = seed >= 8
+    if empty:
+        with torch.no_grad():
+            mod.final_layer.bias.fill_(-1e5)
+    cls = {"texture": S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, "baseline": S.SIRENBASELINESEMANTICDISENTANGLE}[kind]
+    gen = G.DoubleImplicitGenerator3d(functools.partial(cls, hidden_dim=H), 8, 8, 22)
+    gen.siren = mod
+    gen = gen.to(DEV)
+    gen.device = torch.device(DEV); gen.siren.device = gen.device
+    film = proc.film_params(spec, B, seed=seed)
+    kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2, v_mean=np.pi / 2,
+              hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=float(rng.choice([0.0, 0.0, 0.3, 1.0])),
+              last_back=(seed == 9) or (not empty and bool(rng.integers(0, 2))), white_back=bool(rng.integers(0, 2)),
+              lock_view_dependence=bool(rng.integers(0, 2)))
+    film_only = bool(rng.integers(0, 3) == 0)
+    if bool(rng.integers(0, 2)):       # force the plan to split wherever padding would waste a 128-point unit
+        plan = GA.plan_sparse_groups
+        monkeypatch.setattr(GA, "plan_sparse_groups", lambda caps, n_cus: plan(caps, 1, 0.0))
+    for p_ in mod.parameters():
+        p_.requires_grad_(not film_only)
+    res = []
+    try:
+        for sparse in (False, True):
+            mod.sparse_backward = sparse
+            film_t = {k: T(v).requires_grad_(True) for k, v in film.items()}
+            for p_ in mod.parameters():
+                p_.grad = None
+            torch.manual_seed(11 + seed)
+            px, _ = gen.forward_with_frequencies(film_t["freq_geo"], film_t["freq_app"], film_t["phase_geo"], film_t["phase_app"], **kw)
+            w = torch.randn(px.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            (px * w).sum().backward()
+            g = {k: N_(v.grad) for k, v in film_t.items()}
+            g.update({k: N_(p_.grad) for k, p_ in mod.named_parameters() if p_.grad is not None})
+            res.append((N_(px), g))
+        GA.SparseHierarchicalRenderFunction.verify()
+        kept, groups = GA.SparseHierarchicalRenderFunction.last_kept, GA.SparseHierarchicalRenderFunction.last_groups
+    finally:
+        mod.sparse_backward = False
+        for p_ in mod.parameters():
+            p_.requires_grad_(True)
+    (px0, g0), (px1, g1) = res
+    assert np.array_equal(px0, px1) and g0.keys() == g1.keys() and len(g0) >= 4
+    scale = max(float(np.abs(v).max()) for v in g0.values())
+    errs = {k: float(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-30)) for k in g0 if np.abs(g0[k]).max() > 1e-6 * scale}
+    zero_ok = all(np.abs(g1[k]).max() <= 1e-5 * scale for k in g0 if k not in errs)       # a (numerically) zero gradient stays one
+    worst = max(errs, key=errs.get) if errs else None
+    print(f"[parity] sparse vs dense, random configuration {seed}: {kind} H={H} B={B} {S_}x{S_}x{N}+{N} [{precision}] noise {kw['nerf_noise']} "
+          f"last_back {kw['last_back']} {'FiLM only' if film_only else 'all gradients'}, {int(kept[0])} of {kept[1]} samples kept in {len(groups)} group(s): "
+          f"pixels bit-identical, worst relative gradient difference over {len(errs)} tensors {errs[worst] if worst else 0.0:.1e}")
+    assert zero_ok and (not errs or errs[worst] <= 5e-6), (worst, errs.get(worst))
+    if seed == 8:
+        assert int(kept[0]) == 0
+    if seed == 9:
+        assert int(kept[0]) == B * S_ * S_
+
+
 @pytest.mark.parametrize("clamp", ["relu", "softplus"])
 def test_sparse_backward_auto_picks_the_cheaper_node(clamp, monkeypatch):
     """siren.sparse_backward = "auto" (generators/autograd.py sparse_auto_choice): the first step is a sparse one (nothing observed yet); it
