@@ -11,6 +11,8 @@ reference: mask2color + COLOR_MAP  train_double_latent_semantic.py:35-72
 import numpy as np
 import torch
 
+from . import native
+
 # label id -> RGB (train_double_latent_semantic.py:35-55); configuration data of the dataset's 19 classes
 COLOR_MAP = {
     0: [0, 0, 0], 1: [204, 0, 0], 2: [76, 153, 0], 3: [204, 204, 0], 4: [51, 51, 255], 5: [204, 0, 204], 6: [0, 255, 255],
@@ -135,7 +137,7 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
         fg, pg = avg_fg + psi * (raw_fg - avg_fg), avg_pg + psi * (raw_pg - avg_pg)
         fa, pa = avg_fa + psi * (raw_fa - avg_fa), avg_pa + psi * (raw_pa - avg_pa)
         out = generator.siren.native(samples.device).siren_forward(samples, None, fg, pg, fa, pa)   # None = locked view dir
-    return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()
+    return native.to_host(out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).contiguous()).numpy()
 
 
 def film_from_inversion(meta, device=None):
@@ -158,7 +160,7 @@ def sample_generator_wth_frequencies_phase_shifts(generator, meta, max_batch=Non
     with torch.no_grad():
         out = generator.siren.native(samples.device).siren_forward(samples, None, meta["truncated_frequencies_geo"], meta["truncated_phase_shifts_geo"],
                                                                    meta["truncated_frequencies_app"], meta["truncated_phase_shifts_app"])
-    return out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).cpu().numpy()
+    return native.to_host(out[..., -1].reshape(voxel_resolution, voxel_resolution, voxel_resolution).contiguous()).numpy()
 
 
 # ---- the inversion script's host pieces (inverse_render_double_semantic.py) ------------------------------------------------------------

@@ -375,8 +375,9 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
             pixels, depth, _, pitch, yaw = self._render((fg, pg, fa, pa), img_size, fov, ray_start, ray_end, num_steps, h_stddev,
                                                         v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                         lock_view_dependence, kwargs, use_fill=True, third=None)
-            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
-            pixels = self._finish(pixels, batch_size, img_size).cpu() * 2 - 1
+            depth_map = native.to_host(depth.reshape(batch_size, img_size, img_size).contiguous())
+            # `.cpu() * 2 - 1` of the reference: the same two fp32 operations, on the device (one launch), then one copy through pinned memory
+            pixels = native.to_host(self._finish_scaled(pixels, batch_size, img_size))
         return pixels, depth_map
 
     def staged_forward_with_frequencies(self, truncated_frequencies_geo, truncated_frequencies_app, truncated_phase_shifts_geo,
@@ -392,10 +393,10 @@ class DoubleImplicitGenerator3d(_Generator3dBase):
                 (truncated_frequencies_geo, truncated_phase_shifts_geo, truncated_frequencies_app, truncated_phase_shifts_app),
                 img_size, fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample,
                 sample_dist, lock_view_dependence, kwargs, use_fill=True, third="auto")
-            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            depth_map = native.to_host(depth.reshape(batch_size, img_size, img_size).contiguous())
             weights_sum = third.reshape((batch_size, img_size, img_size, -1))
-            weights_sum = weights_sum.permute(0, 3, 1, 2).contiguous().cpu() * 2 - 1
-            pixels = self._finish(pixels, batch_size, img_size).cpu() * 2 - 1
+            weights_sum = native.to_host(weights_sum.permute(0, 3, 1, 2).contiguous() * 2 - 1)
+            pixels = native.to_host(self._finish_scaled(pixels, batch_size, img_size))
         return pixels, depth_map, weights_sum
 
     def forward_with_frequencies(self, frequencies_geo, frequencies_app, phase_shifts_geo, phase_shifts_app, img_size, fov,
@@ -491,8 +492,8 @@ class ImplicitGenerator3d(_Generator3dBase):
             pixels, depth, third, pitch, yaw = self._render(self._film(f, p), img_size, fov, ray_start, ray_end, num_steps,
                                                             h_stddev, v_stddev, h_mean, v_mean, hierarchical_sample, sample_dist,
                                                             lock_view_dependence, kwargs, use_fill=True, third="auto")
-            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
-            weights_sum = third.reshape((batch_size, img_size, img_size, -1)).permute(0, 3, 1, 2).contiguous().cpu() * 2 - 1
+            depth_map = native.to_host(depth.reshape(batch_size, img_size, img_size).contiguous())
+            weights_sum = native.to_host(third.reshape((batch_size, img_size, img_size, -1)).permute(0, 3, 1, 2).contiguous() * 2 - 1)
             pixels = self._finish_scaled(pixels, batch_size, img_size)   # stays on the device (generators.py:231)
         return pixels, depth_map, weights_sum
 
@@ -507,7 +508,7 @@ class ImplicitGenerator3d(_Generator3dBase):
                                                         fov, ray_start, ray_end, num_steps, h_stddev, v_stddev, h_mean, v_mean,
                                                         hierarchical_sample, sample_dist, lock_view_dependence, kwargs,
                                                         use_fill=True, third=None)
-            depth_map = depth.reshape(batch_size, img_size, img_size).contiguous().cpu()
+            depth_map = native.to_host(depth.reshape(batch_size, img_size, img_size).contiguous())
             pixels = self._finish_scaled(pixels, batch_size, img_size)
         return pixels, depth_map
 

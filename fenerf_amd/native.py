@@ -22,6 +22,20 @@ def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def to_host(t):
+    """t.cpu() through page-locked memory (torch's caching host allocator): the reference's staged_forward ends in `.cpu()` of a 5.8-MB
+    pixel tensor (generators.py:640-646); into pageable memory that copy costs 0.2 ms or 45 ms depending on whether the destination pages
+    were touched before (every other call at 256 x 256: 70 instead of 26 ms per image, tools/exp/staged_calls_profile.py) -- into pinned
+    memory it is 0.2 ms every time.  Returns an ordinary CPU tensor (pinned), complete when the call returns."""
+    if not t.is_cuda:
+        return t.cpu()
+    t = t.detach()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return out
+
+
 
 # Hidden widths the kernels are instantiated for (include/fenerf.h).  Any other width up to the largest is run at the next instantiated one
 # with zero padding (round 6): padded rows / columns of every weight matrix, padded biases and padded FiLM phase shifts are zero, so a padded
