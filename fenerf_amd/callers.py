@@ -19,16 +19,23 @@ COLOR_MAP = {
     7: [255, 204, 204], 8: [102, 51, 0], 9: [255, 0, 0], 10: [102, 204, 0], 11: [255, 255, 0], 12: [0, 0, 153],
     13: [0, 0, 204], 14: [255, 51, 153], 15: [0, 204, 204], 16: [0, 51, 0], 17: [255, 153, 51], 18: [0, 204, 0],
 }
+_COLOR_LUT = np.zeros((max(COLOR_MAP) + 1, 3), dtype=np.float32)
+for _k, _v in COLOR_MAP.items():
+    _COLOR_LUT[_k] = _v
 
 
 def mask2color(masks):
     """[B,19,H,W] logits -> [B,3,H,W] float colours (0..255) on the CPU, like the reference: argmax over the label
     channels (first index wins ties) then the LUT (train_double_latent_semantic.py:66-72)."""
-    idx = torch.argmax(masks, dim=1)
-    lut = torch.zeros((max(COLOR_MAP) + 1, 3), dtype=torch.float)
-    for k, v in COLOR_MAP.items():
-        lut[k] = torch.tensor(v, dtype=torch.float)
-    return lut[idx.cpu()].permute(0, 3, 1, 2).contiguous()
+    # the label channels of an image that is already on the host (staged_forward's result) go through numpy: single-threaded, 4 ms per
+    # 256 x 256 image wherever it runs -- torch's CPU argmax over a non-last dimension takes 9 ms with a sane thread count and 50-70 ms in
+    # a container whose CPU quota is far below its logical CPU count (the GPU boxes of this project: 256 logical CPUs, 16 granted), which
+    # made it the largest item of a 256 x 256 multi-view render (tools/exp/callers_timing.py).  numpy's argmax also returns the first maximum.
+    if masks.is_cuda:
+        idx = torch.argmax(masks, dim=1).cpu().numpy()
+    else:
+        idx = np.argmax(masks.detach().numpy(), axis=1)
+    return torch.from_numpy(np.ascontiguousarray(_COLOR_LUT[idx].transpose(0, 3, 1, 2)))
 
 
 def multiview_kwargs(curriculum, image_size=256, ray_step_multiplier=2, lock_view_dependence=False):
@@ -105,16 +112,21 @@ def render_multiview(generator, curriculum, seed, device, face_angles=(-0.5, -0.
     return torch.cat(images), torch.cat(segmaps)
 
 
-def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0):
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None):
     """Voxel-centre coordinates [1, N^3, 3] exactly as the reference builds them (extract_double_semantic_shapes.py:13-35):
-    note the y / x indices are (i / N) % N and (i / N / N) % N in FLOAT arithmetic (not floor-divided) -- kept as is."""
+    note the y / x indices are (i / N) % N and (i / N / N) % N in FLOAT arithmetic (not floor-divided) -- kept as is.
+    device: build them there (the same statements: int64 -> float conversion, IEEE division (by a tensor divisor), fmod, one multiply and one add per coordinate
+    -- bit for bit the host's values, a GPU test compares) instead of on the host followed by a 200-MB pageable copy at N = 256."""
     voxel_origin = np.array(voxel_origin) - cube_length / 2
     voxel_size = cube_length / (N - 1)
-    overall_index = torch.arange(0, N ** 3, 1, dtype=torch.long)
-    samples = torch.zeros(N ** 3, 3)
+    overall_index = torch.arange(0, N ** 3, 1, dtype=torch.long, device=device)
+    samples = torch.zeros(N ** 3, 3, device=device)
+    # (on a GPU torch divides by a Python scalar as a multiplication by its reciprocal -- not the host's correctly rounded quotient unless N
+    # is a power of two; a tensor divisor takes the IEEE division: tools/exp/div_probe.py)
+    Nf = N if samples.device.type == "cpu" else torch.tensor(float(N), device=samples.device)
     samples[:, 2] = overall_index % N
-    samples[:, 1] = (overall_index.float() / N) % N
-    samples[:, 0] = ((overall_index.float() / N) / N) % N
+    samples[:, 1] = (overall_index.float() / Nf) % Nf
+    samples[:, 0] = ((overall_index.float() / Nf) / Nf) % Nf
     samples[:, 0] = (samples[:, 0] * voxel_size) + voxel_origin[2]
     samples[:, 1] = (samples[:, 1] * voxel_size) + voxel_origin[1]
     samples[:, 2] = (samples[:, 2] * voxel_size) + voxel_origin[0]
@@ -128,8 +140,7 @@ def sample_generator(generator, z_geo, z_app=None, max_batch=None, voxel_resolut
     `max_batch` is accepted for signature compatibility and ignored.  (The reference passes the same z to both mapping
     networks; pass z_app to differ.)"""
     z_app = z_geo if z_app is None else z_app
-    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length)
-    samples = samples.to(z_geo.device)
+    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length, device=z_geo.device)
     avg_fg, avg_pg, avg_fa, avg_pa = generator.generate_avg_frequencies()
     with torch.no_grad():
         raw_fg, raw_pg = generator.siren.geo_mapping_network(z_geo)
@@ -155,8 +166,7 @@ def sample_generator_wth_frequencies_phase_shifts(generator, meta, max_batch=Non
     meta carries 'truncated_frequencies_geo' / '_app' and 'truncated_phase_shifts_geo' / '_app' (the script fills them with mean +
     offset of an inversion checkpoint, :127-133 -- film_from_inversion above); view direction locked to (0, 0, -1); `max_batch` and `psi`
     are accepted and ignored (the reference ignores psi here too)."""
-    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length)
-    samples = samples.to(generator.device)
+    samples, _, _ = create_samples(voxel_resolution, voxel_origin, cube_length, device=generator.device)
     with torch.no_grad():
         out = generator.siren.native(samples.device).siren_forward(samples, None, meta["truncated_frequencies_geo"], meta["truncated_phase_shifts_geo"],
                                                                    meta["truncated_frequencies_app"], meta["truncated_phase_shifts_app"])

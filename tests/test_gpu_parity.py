@@ -4115,6 +4115,17 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
 
 
+@pytest.mark.parametrize("N", [7, 32, 129])
+def test_create_samples_on_the_device_equals_the_host(N):
+    """callers.create_samples(device=...) -- the voxel centres of extract_double_semantic_shapes.py:13-35 built on the device instead of on
+    the host + a 200-MB copy: int64 -> float, IEEE division, fmod, one multiply and one add, bit for bit the host's values."""
+    from fenerf_amd import callers
+    host, vo, vs = callers.create_samples(N, (0.01, -0.02, 0.03), 0.3)
+    devs, vo2, vs2 = callers.create_samples(N, (0.01, -0.02, 0.03), 0.3, device=torch.device(DEV))
+    assert devs.is_cuda and np.array_equal(vo, vo2) and vs == vs2
+    assert torch.equal(devs.cpu(), host)
+
+
 @pytest.mark.parametrize("B,R,N,C,images", [(1, 49, 11, 22, None), (3, 37, 7, 21, None), (4, 16, 24, 22, [2, 0]), (2, 300, 3, 4, [1]), (1, 1, 1, 5, None),
                                             (2, 16384, 12, 22, None)])        # 1,536 blocks of 256 samples per image: two pieces of the prefix-sum pass
 def test_sparse_select_against_torch(B, R, N, C, images):
