@@ -1131,8 +1131,8 @@ extern "C" int fenerf_sparse_select(int B, int R, int N, int C, int64_t cap, con
                                     float* d_sel, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
   if (B < 1 || B > 65535 || R < 1 || N < 1 || C < 1 || cap < 1) return fail(FENERF_E_INVALID, "need 1 <= B <= 65535, R, N, C, cap >= 1");
   if ((int64_t)R * N > (int64_t)1 << 36) return fail(FENERF_E_INVALID, "too many samples per image");
-  if (!d_coarse || !d_fine || !z_coarse || !z_fine || !origins || !dirs || !pts || !d_sel || !counts || !workspace)
-    return fail(FENERF_E_INVALID, "NULL pointer");
+  if (!d_coarse || !z_coarse || !origins || !dirs || !pts || !d_sel || !counts || !workspace || (!d_fine) != (!z_fine))
+    return fail(FENERF_E_INVALID, "NULL pointer (d_fine and z_fine may be NULL together: one pass)");
   if (workspace_bytes < sparse_select_workspace_bytes(B, (int64_t)R * N)) return fail(FENERF_E_INVALID, "workspace too small (fenerf_sparse_select_workspace_bytes)");
   { PhaseScope ph(PH_OTHER, stream); return launch_sparse_select(B, R, N, C, cap, d_coarse, d_fine, z_coarse, z_fine, origins, dirs, (const long long*)images, pts, rd, d_sel, counts, workspace, stream); }
 }

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) sparse_count_kernel(const float* d_coarse
   const long long img = images ? images[b] : b;          // where image b of this call sits in the inputs
   const long long s = (long long)blockIdx.x * 256 + t;
   bool keep = false;
-  if (s < 2 * P) {
+  if (s < (d_fine ? 2 * P : P)) {      // d_fine == nullptr: one pass (a render without importance resampling)
     const float* row = s < P ? d_coarse + (img * P + s) * C : d_fine + (img * P + (s - P)) * C;
     if ((C & 1) == 0) {        // even C (22 here): rows are 8-byte aligned
       const float2* r2 = reinterpret_cast<const float2*>(row);
@@ -221,7 +221,7 @@ int launch_sparse_select(int B, int R, int N, int C, long long cap, const float*
                          const float* z_fine, const float* origins, const float* dirs, const long long* images, float* pts, float* rd, float* d_sel,
                          int* counts, void* workspace, void* stream) {
   const long long P = (long long)R * N;
-  const long long nblk = (2 * P + 255) / 256;
+  const long long nblk = ((d_fine ? 2 * P : P) + 255) / 256;
   unsigned long long* masks = (unsigned long long*)workspace;
   int* block_counts = (int*)(masks + (size_t)B * nblk * 4);
   const dim3 grid((unsigned)nblk, (unsigned)B);

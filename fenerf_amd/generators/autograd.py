@@ -231,22 +231,8 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         z_f = native.resample(zc, w_c, u)
         fine = nat.siren_forward_rays(origins, dirs, z_f.reshape(B, R, N), fg, pg, fa, pa, lock_view=lock_view).reshape(B * R, N, C)
         rgb, depth, _, _, _ = native.merge_composite(fine, coarse, z_f, zc, noise_f, opts, want_weights=False, want_wsum=False, want_z=False)
-        # How many samples of an image CAN carry a non-zero gradient row -- known here, so that the backward never waits for the device:
-        # a row is non-zero only if alpha > 0, i.e. (relu clamp) sigma + noise * std > 0; the noise of a sample is the draw of its SORTED
-        # position, so the bound takes the largest |draw| of the render; `last_back` adds the ray's last sample (its colour row takes the
-        # residual weight whatever its density).  NaN densities count.  The softplus clamp keeps every sample.
         P = R * N
-        if opts.clamp_mode == _lib.CLAMP["relu"]:
-            sig = torch.cat([coarse[..., -1].reshape(B, P), fine[..., -1].reshape(B, P)], 1)
-            if noise_f is not None and opts.noise_std != 0:
-                sig = sig + noise_f.abs().max() * opts.noise_std
-            cap = (~(sig <= 0)).sum(1) + (R if opts.last_back else 0)                          # per image
-            ctx.cap_host = torch.empty((B,), dtype=torch.long, pin_memory=True)
-            ctx.cap_host.copy_(cap, non_blocking=True)
-            ctx.cap_ready = torch.cuda.Event()
-            ctx.cap_ready.record()
-        else:
-            ctx.cap_host, ctx.cap_ready = None, None
+        _record_bound(ctx, opts, torch.cat([coarse[..., -1].reshape(B, P), fine[..., -1].reshape(B, P)], 1), noise_f, B, R)
         ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
         ctx.pack_generation = nat.pack_generation
         ctx.save_for_backward(origins, dirs, zc, z_f, coarse, fine, noise_f if noise_f is not None else origins.new_empty(0), fg, pg, fa, pa, *params)
@@ -265,57 +251,116 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         dev = origins.device
         d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
                                              noise=noise_f if noise_f.numel() else None)
-        # the buffer lengths come from the forward's per-image bounds (that copy finished long ago), so nothing here waits for the device
-        if ctx.cap_ready is not None:
-            ctx.cap_ready.synchronize()
-            caps = [min(2 * P, int(c)) for c in ctx.cap_host.tolist()]
-        else:
-            caps = [2 * P] * B
-        caps = [max(32, (c + 31) // 32 * 32) for c in caps]
-        # images that keep similar numbers of samples share a launch group (padded to the group's fullest image); a batch of one dense and
-        # five nearly empty images is not padded to six dense ones
-        groups = plan_sparse_groups(caps, torch.cuda.get_device_properties(dev).multi_processor_count)
-        sparse_auto_observe(module, sum(len(g) * c for g, c in groups) / (2 * P * B))
-        whole = len(groups) == 1
-        perm = None if whole else torch.tensor([b for g, _ in groups for b in g], dtype=torch.long).pin_memory().to(dev, non_blocking=True)
-        film_only = not any(need[14:])
-        fmt = module.tape_format(nat, film_only=film_only)
-        weights = _siren_autograd.film_layer_weights(module, params) if fmt else None
-        total, d_grid, film_rows, kept, flags, first = None, None, [], [], [], 0
-        for g, cap in groups:
-            ids = None if whole else perm[first:first + len(g)]
-            first += len(g)
-            # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
-            # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: three launches)
-            pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, cap, want_dirs=not ctx.lock_view, images=ids)
-            film_g = (fg, pg, fa, pa) if whole else tuple(t.index_select(0, ids) for t in (fg, pg, fa, pa))
-            out, tape, tape_e = nat.siren_forward_save(pts, rd, *film_g, tape_format=fmt)
-            r, d_grid = _siren_autograd.chunked_backward(nat, len(g), cap, film_g, pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
-                                                      weights=weights, d_grid=d_grid)
-            del out, tape, tape_e, d_sel
-            film_rows.append([r[k] for k in _siren_autograd.FILM_KEYS])
-            if not film_only:
-                if total is None:
-                    total = r
-                else:
-                    _siren_autograd._add_all(_siren_autograd._flat(total, _siren_autograd.FILM_KEYS), _siren_autograd._flat(r, _siren_autograd.FILM_KEYS))
-            kept.append(counts[:len(g)].sum())
-            flags.append(counts[len(g)])
-        del d_f, d_c
-        # (a count above its bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
-        SparseHierarchicalRenderFunction._check_overflow(flags[0] if whole else torch.stack(flags).max())
-        SparseHierarchicalRenderFunction.last_kept = (kept[0] if whole else torch.stack(kept).sum(), 2 * B * P)   # for reports (a device scalar: read it after the step)
-        SparseHierarchicalRenderFunction.last_groups = [(list(g), c) for g, c in groups]
-        if whole:
-            film = film_rows[0]
-        else:       # rows back into image order
-            film = [torch.cat([rows[i] for rows in film_rows], 0).index_select(0, torch.argsort(perm)) for i in range(len(_siren_autograd.FILM_KEYS))]
-        fr = dict(zip(_siren_autograd.FILM_KEYS, film))
-        film_grads = tuple(fr[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
-        head = (None,) * 10
-        if film_only:
-            return head + film_grads + (None,) * len(params)
-        return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, total, None, d_grid, need[14:])
+        return _sparse_siren_backward(ctx, module, nat, need, B, R, N, 2, d_c, d_f, zc, z_f, origins, dirs, (fg, pg, fa, pa), params)
+
+
+def _record_bound(ctx, opts, sig, noise, B, R):
+    """How many samples of an image CAN carry a non-zero gradient row -- computed in the forward so that the backward never waits for the
+    device: a row is non-zero only if alpha > 0, i.e. (relu clamp) sigma + noise * std > 0; the noise of a sample is the draw of its SORTED
+    position, so the bound takes the largest |draw| of the render; `last_back` adds the ray's last sample (its colour row takes the residual
+    weight whatever its density).  NaN densities count.  The softplus clamp keeps every sample.  sig [B, samples of the image]."""
+    if opts.clamp_mode == _lib.CLAMP["relu"]:
+        if noise is not None and opts.noise_std != 0:
+            sig = sig + noise.abs().max() * opts.noise_std
+        cap = (~(sig <= 0)).sum(1) + (R if opts.last_back else 0)                          # per image
+        ctx.cap_host = torch.empty((B,), dtype=torch.long, pin_memory=True)
+        ctx.cap_host.copy_(cap, non_blocking=True)
+        ctx.cap_ready = torch.cuda.Event()
+        ctx.cap_ready.record()
+    else:
+        ctx.cap_host, ctx.cap_ready = None, None
+
+
+def _sparse_siren_backward(ctx, module, nat, need, B, R, N, passes, d_c, d_f, zc, z_f, origins, dirs, film, params):
+    """The SIREN part of a sparse backward: d_c (/ d_f) [B*R, N, C] = gradients wrt the outputs of the pass(es) -> the autograd node's
+    return tuple (10 Nones, four FiLM gradients, parameter gradients).  passes = 2: coarse | fine; 1: d_f = z_f = None."""
+    fg, pg, fa, pa = film
+    S = passes * R * N                                                          # samples per image
+    dev = origins.device
+    # the buffer lengths come from the forward's per-image bounds (that copy finished long ago), so nothing here waits for the device
+    if ctx.cap_ready is not None:
+        ctx.cap_ready.synchronize()
+        caps = [min(S, int(c)) for c in ctx.cap_host.tolist()]
+    else:
+        caps = [S] * B
+    caps = [max(32, (c + 31) // 32 * 32) for c in caps]
+    # images that keep similar numbers of samples share a launch group (padded to the group's fullest image); a batch of one dense and
+    # five nearly empty images is not padded to six dense ones
+    groups = plan_sparse_groups(caps, torch.cuda.get_device_properties(dev).multi_processor_count)
+    sparse_auto_observe(module, sum(len(g) * c for g, c in groups) / (S * B))
+    whole = len(groups) == 1
+    perm = None if whole else torch.tensor([b for g, _ in groups for b in g], dtype=torch.long).pin_memory().to(dev, non_blocking=True)
+    film_only = not any(need[14:])
+    fmt = module.tape_format(nat, film_only=film_only)
+    weights = _siren_autograd.film_layer_weights(module, params) if fmt else None
+    total, d_grid, film_rows, kept, flags, first = None, None, [], [], [], 0
+    for g, cap in groups:
+        ids = None if whole else perm[first:first + len(g)]
+        first += len(g)
+        # kept samples (a row with a non-zero -- NaN != 0: a broken row is kept, not hidden) first, in sample order, coarse pass first; the
+        # slots beyond an image's count repeat its first sample with a zero row (native.sparse_select: three launches)
+        pts, rd, d_sel, counts = native.sparse_select(d_c, d_f, zc, z_f, origins, dirs, cap, want_dirs=not ctx.lock_view, images=ids)
+        film_g = (fg, pg, fa, pa) if whole else tuple(t.index_select(0, ids) for t in (fg, pg, fa, pa))
+        out, tape, tape_e = nat.siren_forward_save(pts, rd, *film_g, tape_format=fmt)
+        r, d_grid = _siren_autograd.chunked_backward(nat, len(g), cap, film_g, pts, rd, out, d_sel, tape, tape_e, film_only, tape_format=fmt,
+                                                  weights=weights, d_grid=d_grid)
+        del out, tape, tape_e, d_sel
+        film_rows.append([r[k] for k in _siren_autograd.FILM_KEYS])
+        if not film_only:
+            if total is None:
+                total = r
+            else:
+                _siren_autograd._add_all(_siren_autograd._flat(total, _siren_autograd.FILM_KEYS), _siren_autograd._flat(r, _siren_autograd.FILM_KEYS))
+        kept.append(counts[:len(g)].sum())
+        flags.append(counts[len(g)])
+    # (a count above its bound would mean the bound's argument is wrong: checked without waiting, reported by the next backward)
+    cls = SparseHierarchicalRenderFunction
+    cls._check_overflow(flags[0] if whole else torch.stack(flags).max())
+    cls.last_kept = (kept[0] if whole else torch.stack(kept).sum(), S * B)            # for reports (a device scalar: read it after the step)
+    cls.last_groups = [(list(g), c) for g, c in groups]
+    if whole:
+        film_g = film_rows[0]
+    else:       # rows back into image order
+        film_g = [torch.cat([rows[i] for rows in film_rows], 0).index_select(0, torch.argsort(perm)) for i in range(len(_siren_autograd.FILM_KEYS))]
+    fr = dict(zip(_siren_autograd.FILM_KEYS, film_g))
+    film_grads = tuple(fr[k] if need[10 + i] else None for i, k in enumerate(("d_freq_geo", "d_phase_geo", "d_freq_app", "d_phase_app")))
+    head = (None,) * 10
+    if film_only:
+        return head + film_grads + (None,) * len(params)
+    return head + film_grads + _siren_autograd.assemble_param_grads(module, nat, params, total, None, d_grid, need[14:])
+
+
+class SparseSinglePassRenderFunction(torch.autograd.Function):
+    """The render WITHOUT importance resampling (hierarchical_sample False: generators.py:479-483 + :519 on the coarse samples -- the
+    reference's inversion renders, inverse_render_double_semantic.py:225-247) as one node with the exact-sparsity backward of the block
+    comment above: SparseHierarchicalRenderFunction's signature (u and noise_c unused) and results."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, module, opts, copts, lock_view, origins, dirs, z_c, u, noise_c, noise_f, fg, pg, fa, pa, *params):
+        nat = module.native_differentiable(origins.device)
+        B, R, N = z_c.shape
+        C = nat.C
+        rows = nat.siren_forward_rays(origins, dirs, z_c, fg, pg, fa, pa, lock_view=lock_view).reshape(B * R, N, C)
+        zc = z_c.reshape(B * R, N)
+        rgb, depth, _, _ = native.composite(rows, zc, noise_f, opts, want_weights=False, want_wsum=False)
+        _record_bound(ctx, opts, rows[..., -1].reshape(B, R * N), noise_f, B, R)
+        ctx.module, ctx.nat, ctx.opts, ctx.dims, ctx.lock_view = module, nat, opts, (B, R, N), lock_view
+        ctx.pack_generation = nat.pack_generation
+        ctx.save_for_backward(origins, dirs, zc, rows, noise_f if noise_f is not None else origins.new_empty(0), fg, pg, fa, pa, *params)
+        ctx.mark_non_differentiable(depth)
+        return rgb.reshape(B, R, C - 1), depth.reshape(B, R)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_rgb, _g_depth):
+        module, nat, opts = ctx.module, ctx.nat, ctx.opts
+        _siren_autograd.check_same_weights(ctx, nat)
+        B, R, N = ctx.dims
+        origins, dirs, zc, rows, noise_f, fg, pg, fa, pa, *params = ctx.saved_tensors
+        C = nat.C
+        d = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), rows, zc, opts, noise=noise_f if noise_f.numel() else None)
+        return _sparse_siren_backward(ctx, module, nat, ctx.needs_input_grad, B, R, N, 1, d, None, zc, None, origins, dirs, (fg, pg, fa, pa), params)
 
 
 SparseHierarchicalRenderFunction.last_groups = None

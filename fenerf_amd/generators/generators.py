@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import _lib, native
 from ..siren import autograd as _siren_autograd
 from .autograd import (CompositeFunction, HierarchicalRenderFunction, ImageLayoutFunction, MergeCompositeFunction, SparseHierarchicalRenderFunction,
-                       hierarchical_render_split, sparse_auto_choice)
+                       SparseSinglePassRenderFunction, hierarchical_render_split, sparse_auto_choice)
 from . import volumetric_rendering as VR
 from .volumetric_rendering import _DEFAULT_DRAWS, sample_rays
 
@@ -197,7 +197,16 @@ class _Generator3dBase(nn.Module):
             rd = None if lock_view_dependence else dirs.unsqueeze(2).expand(-1, -1, N, -1).reshape(B, R * N, 3)
             return _siren_autograd.siren_apply(self.siren, pts.reshape(B, R * N, 3), rd, fg, pg, fa, pa)
 
+        sparse = getattr(self.siren, "sparse_backward", False)
+        if sparse == "auto":
+            sparse = sparse_auto_choice(self.siren)
+        elif sparse not in (True, False):
+            raise ValueError(f"siren.sparse_backward must be True, False or 'auto', got {sparse!r}")
         if not hierarchical_sample:
+            if sparse:      # opt-in exact-sparsity backward (autograd.py), the render without importance resampling: the reference's inversion renders
+                return SparseSinglePassRenderFunction.apply(self.siren, opts, None, bool(lock_view_dependence), origins, dirs, z_c, None, None,
+                                                            noise_f.reshape(B * R, M) if use_noise else None, fg, pg, fa, pa,
+                                                            *self.siren._render_params())
             coarse = field(z_c)
             rgb, depth = CompositeFunction.apply(coarse.reshape(B * R, N, C), z_c.reshape(B * R, N),
                                                  noise_f.reshape(B * R, M) if use_noise else None, opts)
@@ -208,11 +217,6 @@ class _Generator3dBase(nn.Module):
         nc_, nf_ = (noise_c.reshape(B * R, N) if use_noise else None), (noise_f.reshape(B * R, M) if use_noise else None)
         params = self.siren._render_params()
         grid = self.siren._roles(params)["grid"]
-        sparse = getattr(self.siren, "sparse_backward", False)
-        if sparse == "auto":
-            sparse = sparse_auto_choice(self.siren)
-        elif sparse not in (True, False):
-            raise ValueError(f"siren.sparse_backward must be True, False or 'auto', got {sparse!r}")
         if sparse:
             # opt-in: the backward runs only over the samples whose upstream gradient row is not all zero (autograd.py: exact).  It goes before
             # the two-node form below: what that form hides behind the weight-gradient kernels (the grid's all-reduce, ~1.5 ms) is less than

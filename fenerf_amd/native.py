@@ -1199,14 +1199,14 @@ def sparse_select(d_coarse, d_fine, z_coarse, z_fine, origins, dirs, cap, want_d
     composite's backward), z_coarse / z_fine [B*R, N], origins / dirs [B, R, 3], cap = slots per image (a multiple of 32).
     -> pts [B, cap, 3], rd [B, cap, 3] or None, d_sel [B, cap, C], counts int32 [B + 1] (kept samples per image, then the overflow flag);
     three launches, nothing waits.  images: None, or an int64 device tensor [B'] of image indices -- the call then handles those B' images
-    (outputs [B', ...]) of the inputs' B."""
+    (outputs [B', ...]) of the inputs' B.  d_fine = z_fine = None: one pass (no importance resampling)."""
     Bin, R, _ = origins.shape
     BR, N, Cc = d_coarse.shape
-    assert BR == Bin * R and d_fine.shape == d_coarse.shape and cap >= 1
+    assert BR == Bin * R and cap >= 1 and (d_fine is None) == (z_fine is None) and (d_fine is None or d_fine.shape == d_coarse.shape)
     assert images is None or (images.is_cuda and images.dtype == torch.int64 and images.is_contiguous() and images.dim() == 1)
     B = Bin if images is None else images.numel()
     dev = d_coarse.device
-    dc, df, zc, zf, o, d = (_f32(t, dev) for t in (d_coarse, d_fine, z_coarse, z_fine, origins, dirs))
+    dc, df, zc, zf, o, d = (_f32(t, dev) if t is not None else None for t in (d_coarse, d_fine, z_coarse, z_fine, origins, dirs))
     pts = torch.empty((B, cap, 3), dtype=torch.float32, device=dev)
     rd = torch.empty((B, cap, 3), dtype=torch.float32, device=dev) if want_dirs else None
     d_sel = torch.empty((B, cap, Cc), dtype=torch.float32, device=dev)

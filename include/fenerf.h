@@ -592,6 +592,8 @@ size_t fenerf_sparse_select_workspace_bytes(int B, int64_t P);
  * [B][cap][C]; the remaining slots repeat the image's first sample with a zero row.  counts [B + 1] (int32, device): kept samples per
  * image, then a flag that is 1 when some image kept more than cap (the excess is dropped: treat as an error).  Feed pts / rd / d_sel to
  * fenerf_siren_forward_save + fenerf_siren_backward + fenerf_siren_param_grads with P = cap (a multiple of 32).
+ * d_fine = z_fine = NULL: a render without importance resampling (generators.py:479-519 with hierarchical_sample False, the
+ * reference's inversion renders): one pass, P samples per image.
  * images (device, may be NULL = 0 .. B - 1): image b of this call is image images[b] of the input arrays -- a batch whose images keep
  * very different numbers of samples is walked in groups of similar images, each with its own cap, instead of padding every image to
  * the fullest one. */

@@ -4064,7 +4064,11 @@ def test_training_snapshots_under_autocast_with_the_ema_swap(tmp_path):
 @pytest.mark.parametrize("case", [dict(kind="texture", H=32, grid=5, B=2, S=7, N=11, kw=dict(clamp_mode="relu", nerf_noise=0.2, last_back=False)),
                                   dict(kind="texture", H=64, grid=6, B=1, S=9, N=12, kw=dict(clamp_mode="relu", nerf_noise=0.0, last_back=True, white_back=True)),
                                   dict(kind="baseline", H=32, grid=0, B=3, S=6, N=8, kw=dict(clamp_mode="softplus", nerf_noise=0.0, lock_view_dependence=True)),
-                                  dict(kind="texture", H=256, grid=8, B=1, S=16, N=24, kw=dict(clamp_mode="relu", nerf_noise=0.0))])
+                                  dict(kind="texture", H=256, grid=8, B=1, S=16, N=24, kw=dict(clamp_mode="relu", nerf_noise=0.0)),
+                                  # without importance resampling (the reference's inversion renders): SparseSinglePassRenderFunction
+                                  dict(kind="texture", H=64, grid=6, B=2, S=9, N=12, kw=dict(clamp_mode="relu", nerf_noise=0.3, hierarchical_sample=False)),
+                                  dict(kind="texture", H=256, grid=8, B=1, S=16, N=24, kw=dict(clamp_mode="relu", nerf_noise=0.0, last_back=True,
+                                                                                               hierarchical_sample=False, lock_view_dependence=True))])
 def test_sparse_backward_equals_the_dense_backward(case, precision):
     """siren.sparse_backward (generators/autograd.py SparseHierarchicalRenderFunction): the backward runs only over the samples whose row
     of upstream gradients is not all zero -- under the relu clamp every sample with sigma + noise <= 0 has an all-zero row (weight 0,
@@ -4081,7 +4085,8 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     B, S_, N = case["B"], case["S"], case["N"]
     film = proc.film_params(spec, B, seed=4)
     kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2,
-              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian", **case["kw"])
+              v_mean=np.pi / 2, hierarchical_sample=True, sample_dist="gaussian")
+    kw.update(case["kw"])
     res = []
     try:
         for sparse in (False, True):
@@ -4105,14 +4110,15 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
     assert k0 is None and k1 is not None and np.array_equal(px0, px1) and g0.keys() == g1.keys() and len(g0) > 25
     errs = {k: _rel_err(g1[k], g0[k]) for k in g0}
     worst = max(errs, key=errs.get)
-    print(f"[parity] sparse backward vs dense [{precision}] {kind} H={H} {case['kw']['clamp_mode']}: {k1[0]} of {k1[1]} samples kept ({100 * k1[0] / k1[1]:.1f} %), "
+    print(f"[parity] sparse backward vs dense [{precision}] {kind} H={H} {case['kw']['clamp_mode']}{'' if kw['hierarchical_sample'] else ' one pass'}: {k1[0]} of {k1[1]} samples kept ({100 * k1[0] / k1[1]:.1f} %), "
           f"pixels bit-identical, worst relative gradient difference over {len(g0)} tensors {errs[worst]:.1e} ({worst})")
     if case["kw"]["clamp_mode"] == "softplus":
         assert k1[0] == k1[1]
     else:
         assert k1[0] < k1[1]
     # two fp32 evaluations of the same sums in different orders (the tape of a kept sample is re-evaluated from the same inputs)
-    assert errs[worst] <= 2e-6, (worst, errs[worst])      # measured 2.0e-7 .. 5.1e-7
+    # measured 2.0e-7 .. 5.1e-7; 2.4e-6 on final_layer.bias (the sum of d sigma over all samples, heavy cancellation) of the one-pass H = 256 case
+    assert errs[worst] <= 5e-6, (worst, errs[worst])
 
 
 @pytest.mark.parametrize("N", [7, 32, 129])
@@ -4251,7 +4257,7 @@ def test_sparse_backward_random_configurations(seed, monkeypatch):
     gen.device = torch.device(DEV); gen.siren.device = gen.device
     film = proc.film_params(spec, B, seed=seed)
     kw = dict(img_size=S_, fov=12, ray_start=0.88, ray_end=1.12, num_steps=N, h_stddev=0.3, v_stddev=0.155, h_mean=np.pi / 2, v_mean=np.pi / 2,
-              hierarchical_sample=True, sample_dist="gaussian", clamp_mode="relu", nerf_noise=float(rng.choice([0.0, 0.0, 0.3, 1.0])),
+              hierarchical_sample=bool(rng.integers(0, 3) > 0), sample_dist="gaussian", clamp_mode="relu", nerf_noise=float(rng.choice([0.0, 0.0, 0.3, 1.0])),
               last_back=(seed == 9) or (not empty and bool(rng.integers(0, 2))), white_back=bool(rng.integers(0, 2)),
               lock_view_dependence=bool(rng.integers(0, 2)))
     film_only = bool(rng.integers(0, 3) == 0)
@@ -4287,13 +4293,14 @@ def test_sparse_backward_random_configurations(seed, monkeypatch):
     zero_ok = all(np.abs(g1[k]).max() <= 1e-5 * scale for k in g0 if k not in errs)       # a (numerically) zero gradient stays one
     worst = max(errs, key=errs.get) if errs else None
     print(f"[parity] sparse vs dense, random configuration {seed}: {kind} H={H} B={B} {S_}x{S_}x{N}+{N} [{precision}] noise {kw['nerf_noise']} "
-          f"last_back {kw['last_back']} {'FiLM only' if film_only else 'all gradients'}, {int(kept[0])} of {kept[1]} samples kept in {len(groups)} group(s): "
+          f"last_back {kw['last_back']} {'two passes' if kw['hierarchical_sample'] else 'one pass'} {'FiLM only' if film_only else 'all gradients'}, {int(kept[0])} of {kept[1]} samples kept in {len(groups)} group(s): "
           f"pixels bit-identical, worst relative gradient difference over {len(errs)} tensors {errs[worst] if worst else 0.0:.1e}")
     assert zero_ok and (not errs or errs[worst] <= 5e-6), (worst, errs.get(worst))
     if seed == 8:
         assert int(kept[0]) == 0
     if seed == 9:
         assert int(kept[0]) == B * S_ * S_
+    assert kept[1] == B * S_ * S_ * N * (2 if kw["hierarchical_sample"] else 1)
 
 
 @pytest.mark.parametrize("clamp", ["relu", "softplus"])
