@@ -1322,12 +1322,13 @@ def test_inversion_and_shape_front_ends_as_commands(tmp_path):
     r2 = subprocess.run(cmd + ["--checkpoint_path", os.path.join(out, "freq_phase_offset_t.pth")], capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0 and "loss" not in r2.stdout, (r2.stdout[-500:], r2.stderr[-2000:])
     # the same optimisation with the exact-sparsity backward picked per iteration (round 6): same draws, same losses to rounding
-    r3 = subprocess.run(cmd + ["--sparse_backward", "auto"], capture_output=True, text=True, timeout=900)
+    out3 = str(tmp_path / "inv_sparse")          # (its own directory: the checkpoint of the first run is read again below)
+    r3 = subprocess.run([out3 if a == out else a for a in cmd] + ["--sparse_backward", "auto"], capture_output=True, text=True, timeout=900)
     assert r3.returncode == 0, (r3.stdout[-500:], r3.stderr[-2000:])
     line3 = [l for l in r3.stdout.splitlines() if "loss" in l][0]
     print("[parity] tools/inverse_render.py --sparse_backward auto:", line3.strip())
     import re
-    nums, nums3 = ([float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", l)] for l in (line, line3))
+    nums, nums3 = ([float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", l.split(" -> /")[0])] for l in (line, line3))
     assert len(nums) == len(nums3) and len(nums) >= 1 and all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(nums, nums3)), (line, line3)
     # shapes: the inverted identity, then two seeded ones
     shapes = str(tmp_path / "shapes")
