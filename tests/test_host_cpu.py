@@ -754,3 +754,43 @@ def test_sparse_backward_launch_groups():
         assert sorted(b for g, _ in groups for b in g) == list(range(B))
         assert all(c == max(caps[b] for b in g) and g == sorted(g) for g, c in groups)
         assert cost(groups, n_cus) <= min(cost([(list(range(B)), max(caps))], n_cus), cost([([b], caps[b]) for b in range(B)], n_cus)) + 1e-9
+
+
+def test_image_writer_numpy_path_equals_the_torch_statements():
+    """imageio_lite.make_grid / to_uint8_hwc run in numpy float32 (single-threaded: robust against CPU-quota containers, tools/exp/
+    dump_timing.py); bit for bit what the torch statements they replaced computed (torchvision 0.9's make_grid / save_image arithmetic)."""
+    import math
+    from fenerf_amd import imageio_lite as io
+
+    def old_grid(tensor, nrow=8, padding=2, normalize=False, value_range=None, pad_value=0.0):
+        t = torch.as_tensor(tensor).detach().float().cpu()
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        if t.shape[1] == 1:
+            t = t.repeat(1, 3, 1, 1)
+        if normalize:
+            t = t.clone()
+            low, high = (float(value_range[0]), float(value_range[1])) if value_range is not None else (float(t.min()), float(t.max()))
+            t = (t.clamp(low, high) - low) / max(high - low, 1e-5)
+        B, C, H, W = t.shape
+        if B == 1:
+            return t[0]
+        xmaps = min(nrow, B)
+        ymaps = int(math.ceil(B / xmaps))
+        hh, ww = H + padding, W + padding
+        grid = torch.full((C, hh * ymaps + padding, ww * xmaps + padding), float(pad_value))
+        for k in range(B):
+            y, x = divmod(k, xmaps)
+            grid[:, y * hh + padding: y * hh + padding + H, x * ww + padding: x * ww + padding + W] = t[k]
+        return grid
+
+    old_u8 = lambda g: g.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    g = torch.Generator().manual_seed(0)
+    for shape, kw in (((3, 33, 29), dict(normalize=True, value_range=(-1, 1))), ((5, 3, 16, 16), dict(normalize=True)),
+                      ((7, 1, 9, 11), dict(nrow=3, padding=1, pad_value=0.3)), ((25, 3, 8, 8), dict(nrow=5, normalize=True, value_range=(-1, 1))),
+                      ((12, 12), dict()), ((2, 3, 5, 5), dict(normalize=True, value_range=(0.25, 0.25)))):
+        t = torch.randn(shape, generator=g) * 1.3
+        a, b = old_grid(t, **kw), io.make_grid(t, **kw)
+        assert torch.equal(a, b) and np.array_equal(old_u8(a), io.to_uint8_hwc(b)), (shape, kw)
