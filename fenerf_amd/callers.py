@@ -362,13 +362,17 @@ def inverse_render(generator, gt_image, gt_seg, options, n_iterations=700, init_
         optimizer.step()
         optimizer.zero_grad()
         scheduler.step()
-        losses.append(float(loss.detach()))
+        # the loss stays on the device unless a callback wants it now: reading it every iteration makes the host wait for the step it has
+        # just enqueued, and the next iteration's launches then start from an idle device
+        losses.append(loss.detach() if on_step is None else float(loss.detach()))
         if record_offsets:
             history.append(tuple(o.detach().cpu().clone() for o in (o_gf, o_gp, o_af, o_ap)))
         if on_step is not None:      # (i, loss, the reference's checkpoint dict at this iteration: what its in-loop preview renders use, :419-452)
             on_step(i, losses[-1], dict(w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
                                         w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
                                         w_app_frequency_offsets=o_af.detach(), w_app_phase_shift_offsets=o_ap.detach()))
+    if losses and on_step is None:
+        losses = torch.stack(losses).cpu().tolist()
     extra = dict(offset_history=history) if record_offsets else {}
     return dict(**extra, w_geo_frequencies=w_gf, w_geo_phase_shifts=w_gp, w_app_frequencies=w_af, w_app_phase_shifts=w_ap,
                 w_geo_frequency_offsets=o_gf.detach(), w_geo_phase_shift_offsets=o_gp.detach(),
