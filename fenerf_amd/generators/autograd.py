@@ -406,6 +406,10 @@ SparseHierarchicalRenderFunction.verify = staticmethod(_verify)
 # runs and every SPARSE_AUTO_PROBE_EVERY-th step is a sparse one that observes again (a probe at f = 1 costs + 28 % of one step).
 SPARSE_AUTO_MAX_FRACTION = 0.6
 SPARSE_AUTO_PROBE_EVERY = 50
+# ... and only for renders of at least this many samples: the sparse step has about twice the dense step's fixed cost (more launches, the
+# wait for the forward's bound), which short kernels do not pay back -- 4 x 32 x 32 x 12+12 (98,304 samples, 13 % kept): 2.37 against 2.17 ms;
+# 6 x 64 x 64 x 12+12 (589,824, 21 % kept): 6.51 against 9.55 ms (tools/exp/gstep_small_shapes.py)
+SPARSE_AUTO_MIN_SAMPLES = 262144
 
 
 def plan_sparse_groups(caps, n_cus=256, group_cost=0.6):
@@ -443,9 +447,13 @@ def sparse_auto_observe(module, fraction):
     _sparse_auto_state(module)["fraction"] = float(fraction)
 
 
-def sparse_auto_choice(module):
-    """True: this step's render is the sparse node.  (Nothing observed yet: sparse -- that step is the first observation.)"""
+def sparse_auto_choice(module, samples=None):
+    """True: this step's render is the sparse node.  (Nothing observed yet: sparse -- that step is the first observation.)
+    samples: samples of the render (all images, all passes); below SPARSE_AUTO_MIN_SAMPLES the dense node."""
     st = _sparse_auto_state(module)
+    if samples is not None and samples < SPARSE_AUTO_MIN_SAMPLES:
+        st["last"] = "dense"
+        return False
     f = st["fraction"]
     if f is None or f <= SPARSE_AUTO_MAX_FRACTION:
         st["dense_steps"], st["last"] = 0, "sparse"

@@ -199,7 +199,7 @@ class _Generator3dBase(nn.Module):
 
         sparse = getattr(self.siren, "sparse_backward", False)
         if sparse == "auto":
-            sparse = sparse_auto_choice(self.siren)
+            sparse = sparse_auto_choice(self.siren, B * R * N * (2 if hierarchical_sample else 1))
         elif sparse not in (True, False):
             raise ValueError(f"siren.sparse_backward must be True, False or 'auto', got {sparse!r}")
         if not hierarchical_sample:

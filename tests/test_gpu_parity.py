@@ -4312,6 +4312,7 @@ def test_sparse_backward_auto_picks_the_cheaper_node(clamp, monkeypatch):
     Whatever node runs, pixels are bit-identical and gradients agree to the order of the sums."""
     from fenerf_amd.generators import autograd as GA
     monkeypatch.setattr(GA, "SPARSE_AUTO_PROBE_EVERY", 3)
+    monkeypatch.setattr(GA, "SPARSE_AUTO_MIN_SAMPLES", 0)          # (this render is tiny: 3,072 samples)
     mod, spec, sd = _siren_module("texture", 32, 5, sigma_gain=150.0, precision="f16x3")
     gen = G.DoubleImplicitGenerator3d(functools.partial(S.TextureEmbeddingPiGAN128SEMANTICDISENTANGLE, hidden_dim=32), 8, 8, 22)
     gen.siren = mod
@@ -4346,6 +4347,11 @@ def test_sparse_backward_auto_picks_the_cheaper_node(clamp, monkeypatch):
         with pytest.raises(ValueError):
             mod.sparse_backward = "sometimes"
             step()
+        # below SPARSE_AUTO_MIN_SAMPLES the dense node whatever was observed (the sparse step's fixed cost is not paid back by short kernels)
+        monkeypatch.setattr(GA, "SPARSE_AUTO_MIN_SAMPLES", 10 ** 9)
+        mod.sparse_backward = "auto"
+        px, g = step()
+        assert mod.__dict__["_sparse_auto"]["last"] == "dense" and np.array_equal(px, px0)
     finally:
         mod.sparse_backward = False
     print(f"[parity] sparse_backward = 'auto' [{clamp}]: buffer fraction {st['fraction']:.3f}, nodes {choices}")
