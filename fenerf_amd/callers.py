@@ -572,6 +572,30 @@ def fid_dump_metadata(input_metadata, img_size=128, batch_size=4):
     return metadata
 
 
+class _OrderedWriter:
+    """save(img, path) calls on ONE worker thread, in submission order: the JPEG encoding of a batch runs while the device renders the next
+    one (the reference writes between renders, fid_evaluation.py:115-121; same files, same order).  An exception of `save` is raised by
+    the next submit() or by close()."""
+
+    def __init__(self, save):
+        from concurrent.futures import ThreadPoolExecutor
+        self.save, self.pool, self.pending = save, ThreadPoolExecutor(max_workers=1), []
+
+    def _reap(self, wait):
+        while self.pending and (wait or self.pending[0].done()):
+            self.pending.pop(0).result()
+
+    def submit(self, img, path):
+        self._reap(False)
+        self.pending.append(self.pool.submit(self.save, img, path))
+
+    def close(self):
+        try:
+            self._reap(True)
+        finally:
+            self.pool.shutdown(wait=True)
+
+
 def _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw, save):
     import os
     from . import imageio_lite
@@ -581,16 +605,20 @@ def _dump_loop(generator, metadata, rank, world_size, output_dir, num_imgs, draw
     generator.eval()
     img_counter = rank
     written = []
-    with torch.no_grad():
-        while img_counter < num_imgs:
-            generated_imgs = draw(module, metadata)
-            for img in generated_imgs:          # (a batch is written out whole: the last one may run past num_imgs, as in the reference)
-                if img.shape[0] != 3:
-                    img = img[-3:]
-                path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
-                save(img, path)
-                written.append(path)
-                img_counter += world_size
+    writer = _OrderedWriter(save)
+    try:
+        with torch.no_grad():
+            while img_counter < num_imgs:
+                generated_imgs = draw(module, metadata)
+                for img in generated_imgs:          # (a batch is written out whole: the last one may run past num_imgs, as in the reference)
+                    if img.shape[0] != 3:
+                        img = img[-3:]
+                    path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
+                    writer.submit(img, path)
+                    written.append(path)
+                    img_counter += world_size
+    finally:
+        writer.close()
     return written
 
 
@@ -634,13 +662,17 @@ def eval_metrics_images(generator, curriculum, output_dir, num_images=2048, max_
     save = save or (lambda img, path: imageio_lite.save_image(img, path, normalize=True, value_range=(-1, 1)))
     generator.eval()
     written = []
-    for img_counter in range(num_images):
-        z = torch.randn(1, options['latent_dim'], device=generator.device)
-        with torch.no_grad():
-            img = generator.staged_forward(z, max_batch_size=max_batch_size, **options)[0].to(generator.device)
-        path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
-        save(img, path)
-        written.append(path)
+    writer = _OrderedWriter(save)
+    try:
+        for img_counter in range(num_images):
+            z = torch.randn(1, options['latent_dim'], device=generator.device)
+            with torch.no_grad():
+                img = generator.staged_forward(z, max_batch_size=max_batch_size, **options)[0].to(generator.device)
+            path = os.path.join(output_dir, f'{img_counter:0>5}.jpg')
+            writer.submit(img, path)
+            written.append(path)
+    finally:
+        writer.close()
     return written
 
 

@@ -26,6 +26,17 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 ev = [e for e in prof.events() if e.device_type.name == "CUDA" and e.device_time_total > 0]
 devms = sum(e.device_time_total for e in ev) / 1e3
 cpu = sorted([e for e in prof.events() if e.device_type.name == "CPU"], key=lambda e: -e.self_cpu_time_total)[:6]
+tot = {}
+for e in prof.events():
+    if e.device_type.name == "CPU":
+        a = tot.setdefault(e.name[:40], [0.0, 0]); a[0] += e.cpu_time_total / 1e3; a[1] += 1
+print("CPU time by op (total, calls) over 16 images:", sorted(((k, round(v[0], 1), v[1]) for k, v in tot.items()), key=lambda t: -t[1])[:14])
+ev_sorted = sorted(ev, key=lambda e: e.time_range.start)
+gaps = []
+for a, b in zip(ev_sorted, ev_sorted[1:]):
+    g = b.time_range.start - a.time_range.end
+    if g > 300: gaps.append((round(g / 1e3, 2), b.name[:50]))
+print("device idle gaps > 0.3 ms:", gaps[:16])
 print(f"output_images_double, {n} images of 128 x 128 x 24+24 in batches of 4: {ms / n:.2f} ms per image end to end; device {devms / 16:.2f} ms per image; "
       f"top self-CPU of 16 images: {[(e.name[:30], round(e.self_cpu_time_total / 1e3, 1)) for e in cpu]}")
 t0 = time.perf_counter()
