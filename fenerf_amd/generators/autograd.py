@@ -247,9 +247,7 @@ class SparseHierarchicalRenderFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         B, R, N = ctx.dims
         origins, dirs, zc, z_f, coarse, fine, noise_f, fg, pg, fa, pa, *params = ctx.saved_tensors
-        C, P = nat.C, R * N
-        dev = origins.device
-        d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
+        d_f, d_c = native.composite_backward(g_rgb.contiguous().float().reshape(B * R, nat.C - 1), fine, z_f, opts, rows_b=coarse, z_b=zc,
                                              noise=noise_f if noise_f.numel() else None)
         return _sparse_siren_backward(ctx, module, nat, need, B, R, N, 2, d_c, d_f, zc, z_f, origins, dirs, (fg, pg, fa, pa), params)
 
