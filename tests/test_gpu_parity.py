@@ -4119,7 +4119,7 @@ def test_sparse_backward_equals_the_dense_backward(case, precision):
         assert k1[0] < k1[1]
     # two fp32 evaluations of the same sums in different orders (the tape of a kept sample is re-evaluated from the same inputs)
     # measured 2.0e-7 .. 5.1e-7; 2.4e-6 on final_layer.bias (the sum of d sigma over all samples, heavy cancellation) of the one-pass H = 256 case
-    assert errs[worst] <= 5e-6, (worst, errs[worst])
+    assert errs[worst] <= 1e-5, (worst, errs[worst])
 
 
 @pytest.mark.parametrize("N", [7, 32, 129])
@@ -4296,7 +4296,7 @@ def test_sparse_backward_random_configurations(seed, monkeypatch):
     print(f"[parity] sparse vs dense, random configuration {seed}: {kind} H={H} B={B} {S_}x{S_}x{N}+{N} [{precision}] noise {kw['nerf_noise']} "
           f"last_back {kw['last_back']} {'two passes' if kw['hierarchical_sample'] else 'one pass'} {'FiLM only' if film_only else 'all gradients'}, {int(kept[0])} of {kept[1]} samples kept in {len(groups)} group(s): "
           f"pixels bit-identical, worst relative gradient difference over {len(errs)} tensors {errs[worst] if worst else 0.0:.1e}")
-    assert zero_ok and (not errs or errs[worst] <= 5e-6), (worst, errs.get(worst))
+    assert zero_ok and (not errs or errs[worst] <= 1e-5), (worst, errs.get(worst))        # measured <= 1.4e-6
     if seed == 8:
         assert int(kept[0]) == 0
     if seed == 9:
