@@ -24,15 +24,19 @@ for _k, _v in COLOR_MAP.items():
     _COLOR_LUT[_k] = _v
 
 
-def mask2color(masks):
+def mask2color(masks, device=None):
     """[B,19,H,W] logits -> [B,3,H,W] float colours (0..255) on the CPU, like the reference: argmax over the label
     channels (first index wins ties) then the LUT (train_double_latent_semantic.py:66-72)."""
     # the label channels of an image that is already on the host (staged_forward's result) go through numpy: single-threaded, 4 ms per
     # 256 x 256 image wherever it runs -- torch's CPU argmax over a non-last dimension takes 9 ms with a sane thread count and 50-70 ms in
     # a container whose CPU quota is far below its logical CPU count (the GPU boxes of this project: 256 logical CPUs, 16 granted), which
     # made it the largest item of a 256 x 256 multi-view render (tools/exp/callers_timing.py).  numpy's argmax also returns the first maximum.
+    # `device`: a GPU the caller has at hand -- the host image's label channels take the argmax there (0.5 ms round trip through pinned memory
+    # instead of 4 ms; the device's argmax also returns the first maximum, NaNs included: tools/exp/argmax_ties_probe.py)
+    if not masks.is_cuda and device is not None and torch.device(device).type == "cuda":
+        masks = masks.to(device, non_blocking=True)
     if masks.is_cuda:
-        idx = torch.argmax(masks, dim=1).cpu().numpy()
+        idx = native.to_host(torch.argmax(masks, dim=1).to(torch.uint8)).numpy()
     else:
         idx = np.argmax(masks.detach().numpy(), axis=1)
     return torch.from_numpy(np.ascontiguousarray(_COLOR_LUT[idx].transpose(0, 3, 1, 2)))
@@ -108,7 +112,7 @@ def render_multiview(generator, curriculum, seed, device, face_angles=(-0.5, -0.
         with torch.no_grad():
             img, _ = generator.staged_forward(z_geo, z_app, **kw)
         images.append(img[:, -3:])
-        segmaps.append(mask2color(img[:, :-3]) / 255.0)
+        segmaps.append(mask2color(img[:, :-3], device) / 255.0)
     return torch.cat(images), torch.cat(segmaps)
 
 
@@ -300,7 +304,7 @@ def render_inversion_recon(generator, meta, render_options, trajectory, max_batc
         for _, pitch, yaw, _ in trajectory:
             kw.update(h_mean=float(yaw), v_mean=float(pitch))
             frame, _, _ = generator.staged_forward_with_frequencies(*film, max_batch_size=max_batch_size, lock_view_dependence=lock_view_dependence, **kw)
-            image, sem = to_u8(frame[:, -3:].cpu()), to_u8(mask2color(frame[:, :-3]).cpu())
+            image, sem = to_u8(frame[:, -3:].cpu()), to_u8(mask2color(frame[:, :-3], generator.device))
             blend = image * 0.5 + sem * 0.5
             frames.append(np.concatenate([image, sem, blend], axis=1).astype("uint8"))
     return frames
@@ -493,7 +497,7 @@ def render_double_latent_video(generator, seed, options, trajectory, latent_type
         kw.update(h_mean=float(yaw), v_mean=float(pitch), fov=float(fov), h_stddev=0, v_stddev=0)
         frame, depth, weight_sum = generator.staged_forward_with_frequencies(*film, **kw)
         out["images"].append(frame[:, -3:])
-        out["labels"].append(mask2color(frame[:, :-3]))
+        out["labels"].append(mask2color(frame[:, :-3], device))
         out["acc"].append(weight_sum[:, -3:])
         out["depth"].append(depth)
     return {k: torch.cat(v) for k, v in out.items()}
@@ -700,7 +704,7 @@ def training_snapshots(generator, ema, fixed_z_geo, fixed_z_app, metadata, outpu
                 for k, v in overrides.items():
                     copied_metadata[k] = copied_metadata[k] + v if k == 'h_mean' else v
                 gen_imgs = module.staged_forward(z_geo.to(device), z_app.to(device), **copied_metadata)[0]
-                gen_labels = mask2color(gen_imgs[:, :-3])
+                gen_labels = mask2color(gen_imgs[:, :-3], device)
         for kind, t in (("seg", gen_labels[:25]), ("img", gen_imgs[:25, -3:])):
             path = os.path.join(output_dir, f"{step}_{kind}_{tag}.png")
             imageio_lite.save_image(t, path, nrow=5, normalize=True)
