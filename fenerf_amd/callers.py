@@ -24,7 +24,7 @@ for _k, _v in COLOR_MAP.items():
     _COLOR_LUT[_k] = _v
 
 
-def mask2color(masks, device=None):
+def mask2color(masks, device=None, scale=None):
     """[B,19,H,W] logits -> [B,3,H,W] float colours (0..255) on the CPU, like the reference: argmax over the label
     channels (first index wins ties) then the LUT (train_double_latent_semantic.py:66-72)."""
     # the label channels of an image that is already on the host (staged_forward's result) go through numpy: single-threaded, 4 ms per
@@ -39,7 +39,10 @@ def mask2color(masks, device=None):
         idx = native.to_host(torch.argmax(masks, dim=1).to(torch.uint8)).numpy()
     else:
         idx = np.argmax(masks.detach().numpy(), axis=1)
-    return torch.from_numpy(np.ascontiguousarray(_COLOR_LUT[idx].transpose(0, 3, 1, 2)))
+    out = np.ascontiguousarray(_COLOR_LUT[idx].transpose(0, 3, 1, 2))
+    if scale is not None:          # `mask2color(...) / 255.` of the reference's scripts, as one fp32 division per element here (numpy) instead of
+        out = out / np.float32(scale)    # a torch CPU operation per view (5-15 ms each where the CPU quota is far below the CPU count)
+    return torch.from_numpy(out)
 
 
 def multiview_kwargs(curriculum, image_size=256, ray_step_multiplier=2, lock_view_dependence=False):
@@ -112,7 +115,7 @@ def render_multiview(generator, curriculum, seed, device, face_angles=(-0.5, -0.
         with torch.no_grad():
             img, _ = generator.staged_forward(z_geo, z_app, **kw)
         images.append(img[:, -3:])
-        segmaps.append(mask2color(img[:, :-3], device) / 255.0)
+        segmaps.append(mask2color(img[:, :-3], device, scale=255.0))
     return torch.cat(images), torch.cat(segmaps)
 
 

@@ -16,7 +16,8 @@ gen.eval()
 
 
 def timed(name, fn, reps=3):
-    fn(); torch.cuda.synchronize()
+    for _ in range(3): fn()          # (the first ~10 images of a process run 1.5 x slow: tools/exp/staged_segments.py)
+    torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
