@@ -194,32 +194,7 @@ def _oracle_torch_run(spec, tsd, film, S, N, hier, seed, max_batch_size):
     return time.perf_counter() - t0
 
 
-def effective_host_cores():
-    """The host cores this process may actually use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU quota
-    (v2 cpu.max / v1 cpu.cfs_quota_us).  The GPU boxes of this pool show 256 logical CPUs with a quota of 16 (`cpu.max 1600000 100000`):
-    256 OpenMP threads on 16 cores' worth of time ran the torch-CPU oracle 16 x SLOWER than 16 threads (tools/exp/cpu_threads_probe.py,
-    round 6: 118 vs 1,765 rays/s at 64x64x24+24)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    quota = None
-    try:
-        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = float(q) / float(period)
-    except (OSError, ValueError):
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / period
-        except (OSError, ValueError):
-            pass
-    if quota:
-        n = min(n, max(1, int(quota + 0.5)))
-    return n
+from fenerf_amd.host import effective_host_cores          # noqa: E402  (cgroup quota / affinity aware; shared with the command-line front ends)
 
 
 CPU_BASELINE_BUDGET_S = 40.0        # bound on the whole leg (the contract: ~10-30 s of CPU work, the default bench run within minutes)

@@ -794,3 +794,20 @@ def test_image_writer_numpy_path_equals_the_torch_statements():
         t = torch.randn(shape, generator=g) * 1.3
         a, b = old_grid(t, **kw), io.make_grid(t, **kw)
         assert torch.equal(a, b) and np.array_equal(old_u8(a), io.to_uint8_hwc(b)), (shape, kw)
+
+
+def test_respect_cpu_quota_caps_torch_threads(monkeypatch):
+    """fenerf_amd/host.py: the cores a process may use = min(logical CPUs, affinity, cgroup quota); respect_cpu_quota() lowers torch's intra-op
+    thread count to it (never raises it) -- what the command-line front ends call first, since a pool sized by the logical CPU count makes
+    every small CPU tensor operation cost milliseconds in a quota-limited container."""
+    from fenerf_amd import host
+    n = host.effective_host_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(host, "effective_host_cores", lambda: 1)
+        assert host.respect_cpu_quota() == 1 and torch.get_num_threads() == 1
+        monkeypatch.setattr(host, "effective_host_cores", lambda: 10 ** 6)
+        assert host.respect_cpu_quota() == 1                      # never raised
+    finally:
+        torch.set_num_threads(before)

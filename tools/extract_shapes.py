@@ -33,6 +33,8 @@ def build_parser():
 
 
 def main(argv=None):
+    from fenerf_amd import host
+    host.respect_cpu_quota()          # torch's CPU thread pool no larger than the cores this process is granted (fenerf_amd/host.py)
     opt = build_parser().parse_args(argv)
     import torch
     from fenerf_amd import callers, imageio_lite

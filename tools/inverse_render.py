@@ -144,6 +144,8 @@ def run_render_recon_video(opt, generator, checkpoint_path):
 
 
 def main(argv=None):
+    from fenerf_amd import host
+    host.respect_cpu_quota()          # torch's CPU thread pool no larger than the cores this process is granted (fenerf_amd/host.py)
     opt = build_parser().parse_args(argv)
     import torch
     from fenerf_amd import callers

@@ -72,6 +72,8 @@ def run_single_latent(opt, generator, options, device):
 
 
 def main(argv=None):
+    from fenerf_amd import host
+    host.respect_cpu_quota()          # torch's CPU thread pool no larger than the cores this process is granted (fenerf_amd/host.py)
     opt = build_parser().parse_args(argv)
     import numpy as np
     import torch
